@@ -1,0 +1,218 @@
+"""Headline benchmark: pre-training volumes/sec of the ViT-B/16^3 (contrastive) MAE step on MI355X.
+
+    python bench.py --gpus 1 --steps 30 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one full optimisation step of BASELINE config 2 (ViT-B/16^3 autoenc as the reference
+scripts train it, i.e. ``contr_mae_vit_base_patch16``; synthetic BraTS-shape 96^3 x 4ch volumes,
+batch 4 per GPU, mask 0.75): forward (both views) + loss chain + backward + global grad norm +
+AdamW, with the gradient all-reduce over RCCL at N > 1.  Inputs are resident in HBM before the timed
+region.  Rank 0 prints ONE JSON line (contract in the task statement) carrying ``roofline`` (the
+GEMM kernel family, timed with HIP events on the launch stream in instrumented steps right after
+the timed region) and, at N = 1, ``cpu_baseline`` (the oracle's CPU step on the same workload).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+VOL, CH, PATCH = 96, 4, 16
+PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
+ALGO_GFLOP_PER_VOL = {'contr': 136.3, 'mae': 90.8}   # BASELINE.md §4 (fwd+bwd, reference formulation)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--batch', type=int, default=4, help='volumes per GPU per step (BASELINE config 2: 4)')
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--model', default='contr', choices=['contr', 'mae'])
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-steps', type=int, default=2)
+    ap.add_argument('--profile-steps', type=int, default=3, help='instrumented steps for the roofline block')
+    return ap.parse_args()
+
+
+def synthetic_batches(batch, rank, n_batches=4):
+    """view2 ~ N(0,1), view1 = z-score(view2 + 0.1 N(0,1)); CPU generator 1234+rank."""
+    out = []
+    for i in range(n_batches):
+        g = torch.Generator(device='cpu').manual_seed(1234 + rank + 1000 * i)
+        v2 = torch.randn(batch, CH, VOL, VOL, VOL, generator=g)
+        v1 = v2 + 0.1 * torch.randn(batch, CH, VOL, VOL, VOL, generator=g)
+        dims = (2, 3, 4)
+        v1 = (v1 - v1.mean(dim=dims, keepdim=True)) / v1.std(dim=dims, keepdim=True)
+        out.append((v1.contiguous(), v2.contiguous()))
+    return out
+
+
+def cpu_baseline(args, batches, sd_cpu, noises):
+    """The oracle (CPU restatement of the reference, validated against it in tests) timed on this
+    host: full training steps of the same workload.  Also returns the first-step losses."""
+    from oracle import mae_ref as R
+    from oracle import train_ref as T
+    cfg = R.vit_base_cfg(volume_size=(VOL,) * 3, patch_size=PATCH, in_chans=CH, contrastive=args.model == 'contr')
+    cores = torch.get_num_threads()
+    tr = T.RefTrainer(cfg, sd_cpu, lr=1e-4, weight_decay=0.05)
+    first = None
+    times = []
+    for i in range(args.cpu_steps + 1):
+        v1, v2 = batches[i % len(batches)]
+        n1, n2 = noises[i % len(noises)]
+        t0 = time.perf_counter()
+        terms, _, _ = tr.step(v1, v2, n1, n2, lr=1e-4, mask_ratio=0.75, edge_map_weight=0.01, contr_weight=0.001)
+        dt = time.perf_counter() - t0
+        if i == 0:
+            first = terms
+        else:
+            times.append(dt)
+    sec = sum(times) / len(times)
+    return {'value': args.batch / sec, 'unit': 'volumes/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{args.cpu_steps} timed full steps (fwd+loss+bwd+AdamW) of the same workload, batch {args.batch}, '
+                      f'fp32, torch {torch.__version__} CPU, after 1 warm-up step; {sec:.2f} s/step'}, first
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (the HIP path has no CPU fallback)')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    from vit_ae_plus_plus_amd.model import vit_autoenc as VA
+    from vit_ae_plus_plus_amd.optim import FusedAdamW
+    from oracle import mae_ref as R   # weights by state-dict from the oracle's seed-0 init
+
+    contr = args.model == 'contr'
+    cfg = R.vit_base_cfg(volume_size=(VOL,) * 3, patch_size=PATCH, in_chans=CH, contrastive=contr)
+    sd_cpu = R.init_state_dict(cfg, seed=0)
+    margs = argparse.Namespace(use_imagenet=False, perceptual_weight=0)
+    ctor = VA.contr_mae_vit_base_patch16 if contr else VA.mae_vit_base_patch16
+    model = ctor(volume_size=VOL, in_chans=CH, patch_size=PATCH, args=margs, precision=args.precision)
+    model.load_state_dict(sd_cpu)
+    model = model.to(dev).train()
+    eng = model._ensure_engine(dev)
+    opt = FusedAdamW(model, lr=1e-4, weight_decay=0.05, betas=(0.9, 0.95))
+    _ = opt.engine
+    model.enable_data_parallel(dev)
+    eng.set_loss_weights(0.01, 0.001 if contr else 0.0, 1, world)
+
+    cpu_batches = synthetic_batches(args.batch, rank)
+    batches = [(a.to(dev), b.to(dev)) for a, b in cpu_batches]
+    L = cfg.num_patches
+    noises = [R.masking_noise(args.batch, L, seed=4321 + rank + i) for i in range(len(batches))]
+    runner = model._step_runner(args.batch, 0.75, True, False, not args.no_graph)
+
+    def step(i):
+        v1, v2 = batches[i % len(batches)]
+        runner.load(v1, v2 if contr else None)
+        eng.optimizer_hparams(lr=1e-4)
+        runner.run()
+
+    # first step with the CPU-generated noise of step 0 for the parity report
+    model.set_masking_noise(*(noises[0] if contr else noises[0][:1]))
+    step(0)
+    torch.cuda.synchronize()
+    first_gpu = eng.losses.cpu().tolist()
+    for i in range(1, max(args.warmup, 1)):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax)
+    last = eng.losses.cpu().tolist()
+    ms = elapsed / args.steps * 1e3
+    value = world * args.batch * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel family (GEMM): eager instrumented steps, HIP events on the
+    # launch stream around every GEMM launch (split-K reduce included in its launch)
+    roof = None
+    if rank == 0:
+        eager = model._step_runner(args.batch, 0.75, True, False, False)
+        eng.gemm_timer = []
+        for i in range(args.profile_steps):
+            v1, v2 = batches[i % len(batches)]
+            eager.load(v1, v2 if contr else None)
+            eng.optimizer_hparams(lr=1e-4)
+            if world > 1:   # keep collectives matched: other ranks idle here, so time phases locally only
+                for k in range(3):
+                    eager._phase(k)
+            else:
+                eager.run()
+        torch.cuda.synchronize()
+        recs = eng.gemm_timer
+        eng.gemm_timer = None
+        tot_ms = sum(a.elapsed_time(b) for a, b, _ in recs)
+        tot_fl = sum(f for _, _, f in recs)
+        n_launch = len(recs) / args.profile_steps
+        ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        peak = PEAK_TFLOPS[args.precision]
+        roof = {'bound': 'mfma', 'kernel': 'gemm_kernel<prec,a_kc,b_kc> (+splitk_reduce)', 'achieved': round(ach, 2),
+                'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': None,
+                'launches_per_step': n_launch, 'gflop_per_step': round(tot_fl / args.profile_steps / 1e9, 2),
+                'gemm_ms_per_step': round(tot_ms / args.profile_steps, 3),
+                'step_frac_of_peak': round(world * args.batch * ALGO_GFLOP_PER_VOL[args.model] * 1e9 / (ms * 1e-3) / 1e12 / (peak * world), 4)}
+    if world > 1:
+        dist.barrier()
+
+    cpu, parity = None, None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu, first_cpu = cpu_baseline(args, cpu_batches, sd_cpu, noises)
+        ref_total, ref_recon = first_cpu['loss'], first_cpu['reconstruction_loss']
+        got_total, got_recon = first_gpu[0] + (first_gpu[4] if contr else 0.0), first_gpu[2]
+        parity = {'recon_loss_gpu': got_recon, 'recon_loss_cpu_oracle': ref_recon,
+                  'recon_rel_err': abs(got_recon - ref_recon) / abs(ref_recon),
+                  'total_rel_err': abs(got_total - ref_total) / abs(ref_total), 'precision': args.precision}
+
+    if rank == 0:
+        out = {'metric': 'pretrain volumes/sec (96^3x4ch, mask 0.75) at 1/2/4/8 MI355X + recon-loss parity',
+               'value': round(value, 2), 'unit': 'volumes/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+               'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+               'dtype': args.precision, 'data': 'synthetic',
+               'config': {'workload': f'ViT-B/16^3 {"contrastive " if contr else ""}MAE full optimisation step '
+                                      f'(fwd+loss+bwd+grad-norm+AdamW), synthetic BraTS-shape 96^3x4ch, batch '
+                                      f'{args.batch}/GPU, mask 0.75 (BASELINE config 2{" / 3" if world > 1 else ""})',
+                          'global_batch': world * args.batch, 'parallelism': f'dp{world}',
+                          'hip_graph': not args.no_graph, 'final_losses': [round(x, 6) for x in last[:6]]},
+               'roofline': roof, 'cpu_baseline': cpu}
+        if parity:
+            out['parity'] = parity
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

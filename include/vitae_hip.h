@@ -1,0 +1,173 @@
+/* libvitae_hip.so — C ABI of the MI355X (gfx950) ViT-AE++ pre-training hot path.
+ *
+ * The reference (chinmay5/vit_ae_plus_plus) is pure Python/PyTorch and has no FFI of its own
+ * (SURVEY §2.2, §8b): its hot path lowers to stock ATen ops.  This header therefore defines the
+ * boundary a maintainer would bind instead of those ops — one launcher per fused op, each citing the
+ * reference lines (relative to the reference repo root) whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - every tensor argument is a raw DEVICE pointer to contiguous fp32 (unless stated), sizes are
+ *     plain ints/longs; no torch types cross this boundary;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *   - nothing allocates, frees or synchronises: every call only enqueues kernels (graph-capture
+ *     safe); scratch space is passed in by the caller;
+ *   - return value: 0 = enqueued; VITAE_ERR_INVALID_ARG (-1), VITAE_ERR_UNSUPPORTED_SHAPE (-2),
+ *     VITAE_ERR_LAUNCH (-3).  Nothing throws across the boundary;
+ *   - gradients of parameters ACCUMULATE into their destination (+=) where noted, so the caller
+ *     zeroes the gradient arena once per optimisation step (reference: optimizer.zero_grad(),
+ *     utils/train_one_epoch.py:35,73-74).
+ */
+#ifndef VITAE_HIP_H
+#define VITAE_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VITAE_ABI_VERSION 1
+
+/* matrix-core arithmetic of the dense contractions */
+#define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
+#define VITAE_PREC_BF16 1 /* v_mfma_f32_32x32x16_bf16: bf16 operands, fp32 accumulate */
+
+/* GEMM epilogues */
+#define VITAE_EPI_NONE 0
+#define VITAE_EPI_GELU 1      /* aux <- pre-activation, out <- exact-erf GELU (nn.GELU, model/vit.py:85-92) */
+#define VITAE_EPI_DGELU 2     /* out <- acc * GELU'(aux) */
+#define VITAE_EPI_RELU_MASK 3 /* out <- aux > 0 ? acc : 0 */
+
+/* device-resident hyper-parameter block `hp` (float[VITAE_HP_COUNT]) */
+#define VITAE_HP_LR 0
+#define VITAE_HP_BETA1 1
+#define VITAE_HP_BETA2 2
+#define VITAE_HP_EPS 3
+#define VITAE_HP_BC1 4       /* 1 - beta1^t */
+#define VITAE_HP_BC2 5       /* 1 - beta2^t */
+#define VITAE_HP_GRAD_MUL 6  /* multiplier applied to grads inside AdamW (1/loss_scale; 1 here) */
+#define VITAE_HP_G_RECON 7   /* d total / d recon_loss  */
+#define VITAE_HP_G_EDGE 8    /* d total / d raw_edge_mse (= edge_map_weight * upstream) */
+#define VITAE_HP_G_CONTR 9   /* d total / d (mean-cosine term), includes contr_weight */
+#define VITAE_HP_EDGE_W 10   /* edge_map_weight (model/vit_autoenc.py:225) */
+#define VITAE_HP_CONTR_W 11  /* args.contr_weight (utils/train_one_epoch.py:114) */
+#define VITAE_HP_COUNT 16
+
+/* device-resident scalar accumulators `acc` (double[VITAE_ACC_COUNT]); caller zeroes them per step */
+#define VITAE_ACC_RECON 0
+#define VITAE_ACC_EDGE 1
+#define VITAE_ACC_COS 2
+#define VITAE_ACC_GRADSQ 3
+#define VITAE_ACC_COUNT 8
+
+#define VITAE_MAX_TAPS 33
+
+int vitae_abi_version(void);
+const char* vitae_build_arch(void);
+int vitae_memset_zero(void* ptr, long bytes, void* stream);
+
+/* ---- dense contractions -------------------------------------------------------------------------
+ * Generic C[M,N] (+)= epi(sum_k A(m,k) B(n,k) + bias[n]) (+ residual).  *_kcontig = 1: element
+ * (row,k) at ptr[row*ld + k]; 0: at ptr[k*ld + row].  split_k > 1 needs
+ * vitae_gemm_workspace_floats() floats of scratch. */
+int vitae_gemm(int prec, int a_kcontig, int b_kcontig, const float* A, long lda, const float* B, long ldb,
+               float* C, long ldc, int M, int N, int K, const float* bias, const float* residual, long ldr,
+               int epi, float* aux, long ldaux, int accumulate, int split_k, float* splitk_ws, void* stream);
+long vitae_gemm_workspace_floats(int M, int N, int K, int split_k);
+int vitae_gemm_pick_split_k(int M, int N, int K);
+
+/* nn.Linear forward  y = x W^T + b  (model/vit.py:85-96 fc1/fc2, :107-114 qkv, :109,122 proj;
+ * model/vit_autoenc.py:41 decoder_embed, :53 decoder_pred, :263-268 predictor; and the Conv3d patch
+ * embedding of model/vit.py:65,72 as a GEMM over gathered patches).  x[M,K], w[N,K], y[M,N]. */
+int vitae_linear_fwd(int prec, const float* x, const float* w, const float* bias, float* y, int M, int N, int K,
+                     int epi, float* aux, const float* residual, int split_k, float* ws, void* stream);
+/* dx[M,K] (+)= epi(dy[M,N] W[N,K]) */
+int vitae_linear_bwd_input(int prec, const float* dy, const float* w, float* dx, int M, int N, int K, int epi,
+                           float* aux, int accumulate, int split_k, float* ws, void* stream);
+/* dW[N,K] (+)= dy[M,N]^T x[M,K] */
+int vitae_linear_bwd_weight(int prec, const float* dy, const float* x, float* dw, int M, int N, int K,
+                            int accumulate, int split_k, float* ws, void* stream);
+/* out[n] += sum_m dy[m*ld + n]  (bias gradients) */
+int vitae_colsum_accum(const float* dy, long ld, float* out, int M, int N, void* stream);
+
+/* ---- LayerNorm (partial(nn.LayerNorm, eps=1e-6): model/vit_autoenc.py:292,300,308; used at
+ * model/vit.py:132,135,142-143, model/vit_autoenc.py:36,51,175,195) ------------------------------ */
+int vitae_layernorm_fwd(const float* x, const float* w, const float* b, float* y, float* mean, float* rstd,
+                        int M, int D, float eps, void* stream);
+/* dw, db accumulate (+=); dx overwritten, or += when dx_accumulate */
+int vitae_layernorm_bwd(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
+                        float* dx, float* dw, float* db, int M, int D, int dx_accumulate, void* stream);
+
+/* ---- attention core  softmax(q k^T / sqrt(hd)) v  (model/vit.py:117-121) -------------------------
+ * qkv [B,N,3,H,hd] (output of the qkv Linear, model/vit.py:114), o [B,N,H*hd], lse/delta [B,H,N]. */
+int vitae_sdpa_fwd(const float* qkv, float* o, float* lse, int B, int N, int H, int head_dim, void* stream);
+int vitae_sdpa_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv,
+                   float* delta_ws, int B, int N, int H, int head_dim, void* stream);
+
+/* ---- masking and sequence assembly ---------------------------------------------------------------
+ * random_masking (model/vit_autoenc.py:141-153) from a caller-supplied noise[B,L] (the torch.rand of
+ * :139): ids_shuffle/ids_restore int32 [B,L], mask fp32 [B,L] (0 keep, 1 remove); ids_restore_i64
+ * optional (the int64 tensor the reference returns). */
+int vitae_random_masking(const float* noise, int* ids_shuffle, int* ids_restore, float* mask,
+                         long long* ids_restore_i64, int B, int L, int len_keep, void* stream);
+/* rows of the patch-embedding GEMM for the kept patches only: out[B*keep, C*p^3] in Conv3d weight
+ * order (model/vit.py:65,72-74 + model/vit_autoenc.py:147-148) */
+int vitae_gather_patches(const float* vol, const int* ids_shuffle, float* out, int B, int C, int Lz, int Hy, int Wx,
+                         int p, int keep, void* stream);
+/* x[B,keep+1,D]: + pos_embed, cls token (model/vit_autoenc.py:162-170) */
+int vitae_encoder_assemble_fwd(const float* tok, const float* cls_token, const float* pos_embed,
+                               const int* ids_shuffle, float* x, int B, int L, int keep, int D, void* stream);
+int vitae_encoder_assemble_bwd(const float* dx, float* dtok, float* dcls_accum, int B, int keep, int D, void* stream);
+/* xd[B,L+1,Dd]: mask-token fill + unshuffle + decoder_pos_embed (model/vit_autoenc.py:184-190) */
+int vitae_decoder_assemble_fwd(const float* e, const float* mask_token, const float* dpos, const int* ids_restore,
+                               float* xd, int B, int L, int keep, int Dd, void* stream);
+int vitae_decoder_assemble_bwd(const float* dxd, const int* ids_shuffle, float* de, float* dmask_token_accum, int B,
+                               int L, int keep, int Dd, void* stream);
+
+/* ---- loss chain ----------------------------------------------------------------------------------
+ * pred element (b,l,e) lives at pred[b*pred_bstride + l*P + e] (P = p^3*C), so the decoder output
+ * with its cls row is read in place (model/vit_autoenc.py:198-201). */
+int vitae_recon_loss_fwd(const float* pred, long pred_bstride, const float* imgs, const float* mask, double* acc,
+                         int B, int C, int Lz, int Hy, int Wx, int p, void* stream);   /* :205-227 */
+int vitae_recon_loss_bwd(const float* pred, long pred_bstride, const float* imgs, const float* mask, const float* hp,
+                         float* dpred, float mask_sum, int B, int C, int Lz, int Hy, int Wx, int p, void* stream);
+int vitae_unpatchify(const float* pred, long pred_bstride, float* vol, int B, int C, int Lz, int Hy, int Wx, int p,
+                     void* stream);                                                     /* :115-128 */
+/* separable 3-pass blur == dense k(x)k(x)k conv3d of model/model_utils/gaussian_filter.py:16-26;
+ * taps_host is a HOST array (copied into the launch), ntaps odd */
+int vitae_gauss_blur_fwd(const float* vol, float* tmp, float* out, const float* taps_host, int ntaps, int BC, int Lz,
+                         int Hy, int Wx, void* stream);
+/* edge[B,Lz,Hy,Wx] = sum_c |sobel(vol[:,c])| (model/model_utils/sobel_filter.py:37-45); with edge_ref
+ * also acc[VITAE_ACC_EDGE] += sum (edge-edge_ref)^2 (model/vit_autoenc.py:224) */
+int vitae_sobel_edge_fwd(const float* vol, float* edge, const float* edge_ref, double* acc, int B, int C, int Lz,
+                         int Hy, int Wx, void* stream);
+/* dpred += d(edge mse)/d pred ; dG_ws = B*C*3*Lz*Hy*Wx floats of scratch */
+int vitae_sobel_edge_bwd(const float* pred_vol, const float* edge_pred, const float* edge_tgt, const float* hp,
+                         float* dG_ws, float* dpred, long pred_bstride, int B, int C, int Lz, int Hy, int Wx, int p,
+                         void* stream);
+/* out4 = [loss, raw_edge_mse, recon, percep=0] (model/vit_autoenc.py:231-232) */
+int vitae_loss_finalize(const double* acc, const float* hp, float* out4, float mask_sum, long edge_count, void* stream);
+
+/* ---- contrastive head ----------------------------------------------------------------------------
+ * BatchNorm1d (training) + ReLU of the predictor (model/vit_autoenc.py:263-268); running stats updated
+ * in place (momentum 0.1, unbiased variance). */
+int vitae_bn1d_relu_fwd(const float* x, const float* w, const float* b, float* y, float* save_mean, float* save_rstd,
+                        float* running_mean, float* running_var, long long* num_batches_tracked, int R, int D,
+                        float eps, float momentum, void* stream);
+int vitae_bn1d_relu_bwd(const float* dy, const float* x, const float* y, const float* w, const float* save_mean,
+                        const float* save_rstd, float* dx, float* dw_accum, float* db_accum, int R, int D, void* stream);
+/* contr = contr_w * (-(mean cos(p1,z2) + mean cos(p2,z1))/2)  (utils/train_one_epoch.py:113-114) */
+int vitae_cosine_loss_fwd(const float* p1, const float* z2, const float* p2, const float* z1, double* acc,
+                          const float* hp, float* out1, int R, int D, void* stream);
+int vitae_cosine_loss_bwd(const float* p1, const float* z2, const float* p2, const float* z1, const float* hp,
+                          float* dp1, float* dp2, int R, int D, void* stream);
+
+/* ---- optimiser -----------------------------------------------------------------------------------
+ * utils/misc.py:265-266,280-292 (global grad L2 norm) and torch.optim.AdamW
+ * (k_fold_training_scripts/k_fold_cross_valid_combined_brats.py:168-169). */
+int vitae_grad_sqnorm(const float* grads, long n, double* acc, float* norm_out, void* stream);
+int vitae_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, const float* hp,
+                     const float* grad_norm, float weight_decay, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITAE_HIP_H */

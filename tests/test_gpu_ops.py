@@ -1,0 +1,372 @@
+"""GPU parity, kernel by kernel: each C-ABI launcher of libvitae_hip.so against the plain fp32
+PyTorch (CPU) statement of the same op / the oracle function that restates the reference.
+Tolerances: fp32-MFMA path ~1e-5 relative (accumulation order), bf16-MFMA path ~1e-2 of the output
+scale (operands rounded to 8 mantissa bits)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import mae_ref as R   # the checker
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from vit_ae_plus_plus_amd._abi import lib as L
+    L.load()
+    return L
+
+
+@pytest.fixture(scope='module')
+def C():
+    from vit_ae_plus_plus_amd._abi import CONSTS
+    return CONSTS
+
+
+def dev(t):
+    return t.detach().clone().contiguous().cuda()
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def rel_err(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def gen(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# --------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize('prec,tol', [(0, 2e-5), (1, 2e-2)])
+@pytest.mark.parametrize('M,N,K', [(440, 2304, 768), (37, 48, 128), (868, 512, 2048), (64, 64, 32), (130, 72, 4096)])
+def test_linear_fwd_bwd(lib, C, prec, tol, M, N, K):
+    x, w, b = gen(M, K, seed=1), gen(N, K, seed=2, scale=K ** -0.5), gen(N, seed=3)
+    res = gen(M, N, seed=4)
+    xd, wd, bd, rd = dev(x), dev(w), dev(b), dev(res)
+    ws = torch.empty(1 << 22, device='cuda')
+    # forward + bias + residual, with and without split-K
+    for split in (1, lib.vitae_gemm_pick_split_k(M, N, K), 3):
+        if split * M * N > ws.numel():
+            continue
+        y = torch.empty(M, N, device='cuda')
+        lib.vitae_linear_fwd(prec, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), M, N, K, 0, None,
+                             rd.data_ptr(), split, ws.data_ptr(), st())
+        assert rel_err(y, F.linear(x, w, b) + res) < tol, f'split {split}'
+    # GELU epilogue (aux = pre-activation)
+    y, aux = torch.empty(M, N, device='cuda'), torch.empty(M, N, device='cuda')
+    lib.vitae_linear_fwd(prec, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), M, N, K, C['VITAE_EPI_GELU'],
+                         aux.data_ptr(), None, 1, None, st())
+    pre = F.linear(x, w, b)
+    assert rel_err(aux, pre) < tol and rel_err(y, F.gelu(pre)) < tol
+    # dgrad with the GELU-derivative epilogue: dx = (dy @ W) * gelu'(h)
+    dy = gen(M, N, seed=5)
+    h = gen(M, K, seed=6)
+    dyd, hd = dev(dy), dev(h)
+    dx = torch.empty(M, K, device='cuda')
+    split = lib.vitae_gemm_pick_split_k(M, K, N)
+    lib.vitae_linear_bwd_input(prec, dyd.data_ptr(), wd.data_ptr(), dx.data_ptr(), M, N, K, C['VITAE_EPI_DGELU'],
+                               hd.data_ptr(), 0, split, ws.data_ptr(), st())
+    hh = h.clone().requires_grad_(True)
+    F.gelu(hh).backward(dy @ w)
+    assert rel_err(dx, hh.grad) < tol
+    # dgrad accumulate
+    base = gen(M, K, seed=7)
+    dx2 = dev(base)
+    lib.vitae_linear_bwd_input(prec, dyd.data_ptr(), wd.data_ptr(), dx2.data_ptr(), M, N, K, 0, None, 1, 1, None, st())
+    assert rel_err(dx2, base + dy @ w) < tol
+    # wgrad (+ accumulate) and bias grad
+    dw = torch.empty(N, K, device='cuda')
+    split = lib.vitae_gemm_pick_split_k(N, K, M)
+    lib.vitae_linear_bwd_weight(prec, dyd.data_ptr(), xd.data_ptr(), dw.data_ptr(), M, N, K, 0, split, ws.data_ptr(), st())
+    assert rel_err(dw, dy.t() @ x) < tol
+    lib.vitae_linear_bwd_weight(prec, dyd.data_ptr(), xd.data_ptr(), dw.data_ptr(), M, N, K, 1, 1, None, st())
+    assert rel_err(dw, 2 * (dy.t() @ x)) < tol
+    db = torch.zeros(N, device='cuda')
+    lib.vitae_colsum_accum(dyd.data_ptr(), N, db.data_ptr(), M, N, st())
+    assert rel_err(db, dy.sum(0)) < 2e-5
+
+
+def test_gemm_asymmetric_layout(lib):
+    """A = I against an asymmetric B catches transposed C writes (cdna guide §3)."""
+    M = N = K = 64
+    a = torch.eye(64)
+    b = torch.arange(64 * 64, dtype=torch.float32).reshape(64, 64) / 100.0
+    y = torch.empty(M, N, device='cuda')
+    for prec in (0, 1):
+        lib.vitae_linear_fwd(prec, dev(a).data_ptr(), dev(b).data_ptr(), None, y.data_ptr(), M, N, K, 0, None, None, 1,
+                             None, st())
+        assert rel_err(y, b.t()) < (1e-6 if prec == 0 else 5e-3)
+
+
+def test_gemm_rejects_bad_shapes(lib):
+    from vit_ae_plus_plus_amd._abi import VitaeError
+    x = torch.zeros(8, 6, device='cuda')
+    with pytest.raises(VitaeError):
+        lib.vitae_linear_fwd(0, x.data_ptr(), x.data_ptr(), None, x.data_ptr(), 8, 8, 6, 0, None, None, 1, None, st())
+
+
+# --------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize('M,D', [(440, 768), (868, 512), (33, 48), (7, 1024)])
+def test_layernorm(lib, M, D):
+    x, w, b, dy = gen(M, D, seed=1, scale=2.0) + 0.3, gen(D, seed=2) + 1.0, gen(D, seed=3), gen(M, D, seed=4)
+    xd, wd, bd, dyd = dev(x), dev(w), dev(b), dev(dy)
+    y, mean, rstd = torch.empty(M, D, device='cuda'), torch.empty(M, device='cuda'), torch.empty(M, device='cuda')
+    lib.vitae_layernorm_fwd(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                            M, D, 1e-6, st())
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (D,), wr, br, 1e-6)
+    ref.backward(dy)
+    assert rel_err(y, ref) < 1e-5
+    base = gen(M, D, seed=5)
+    for accum in (0, 1):
+        dx = dev(base)
+        dw, db = torch.zeros(D, device='cuda'), torch.zeros(D, device='cuda')
+        lib.vitae_layernorm_bwd(dyd.data_ptr(), xd.data_ptr(), wd.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                dx.data_ptr(), dw.data_ptr(), db.data_ptr(), M, D, accum, st())
+        assert rel_err(dx, xr.grad + (base if accum else 0)) < 2e-5
+        assert rel_err(dw, wr.grad) < 2e-5 and rel_err(db, br.grad) < 2e-5
+
+
+# --------------------------------------------------------------------------- attention
+@pytest.mark.parametrize('B,N,H,hd', [(8, 55, 12, 64), (4, 217, 16, 32), (2, 17, 3, 16), (1, 130, 2, 64), (2, 70, 2, 128)])
+def test_sdpa(lib, B, N, H, hd):
+    D = H * hd
+    qkv, do = gen(B, N, 3 * D, seed=1), gen(B, N, D, seed=2)
+    qr = qkv.clone().requires_grad_(True)
+    q, k, v = qr.reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    att = ((q @ k.transpose(-2, -1)) * hd ** -0.5).softmax(-1)
+    ref = (att @ v).transpose(1, 2).reshape(B, N, D)
+    ref.backward(do)
+    qd, dod = dev(qkv), dev(do)
+    o, lse = torch.empty(B, N, D, device='cuda'), torch.empty(B * H * N, device='cuda')
+    lib.vitae_sdpa_fwd(qd.data_ptr(), o.data_ptr(), lse.data_ptr(), B, N, H, hd, st())
+    assert rel_err(o, ref) < 1e-5
+    dqkv, delta = torch.zeros(B, N, 3 * D, device='cuda'), torch.empty(B * H * N, device='cuda')
+    lib.vitae_sdpa_bwd(qd.data_ptr(), o.data_ptr(), dod.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), delta.data_ptr(),
+                       B, N, H, hd, st())
+    assert rel_err(dqkv, qr.grad) < 2e-5
+
+
+def test_sdpa_large_logits(lib):
+    """Online-softmax rescale path: one key dominates from a late tile."""
+    B, N, H, hd = 1, 100, 1, 32
+    qkv = gen(B, N, 3 * hd, seed=3)
+    qkv[0, 5, :hd] *= 30
+    qkv[0, 77, hd:2 * hd] = qkv[0, 5, :hd] / 10
+    q, k, v = qkv.reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    ref = (((q @ k.transpose(-2, -1)) * hd ** -0.5).softmax(-1) @ v).transpose(1, 2).reshape(B, N, hd)
+    o, lse = torch.empty(B, N, hd, device='cuda'), torch.empty(N, device='cuda')
+    lib.vitae_sdpa_fwd(dev(qkv).data_ptr(), o.data_ptr(), lse.data_ptr(), B, N, H, hd, st())
+    assert rel_err(o, ref) < 1e-5
+
+
+# --------------------------------------------------------------------------- masking / assembly
+@pytest.mark.parametrize('B,L,keep', [(8, 216, 54), (2, 64, 16), (2, 1728, 432), (3, 288, 72)])
+def test_random_masking(lib, B, L, keep):
+    noise = torch.rand(B, L, generator=torch.Generator().manual_seed(L))
+    noise[0, 3] = noise[0, 9]   # a tie: stable order keeps index 3 first
+    ids_keep, ids_restore, mask = R.masking_from_noise(noise, keep)
+    sh = torch.empty(B, L, dtype=torch.int32, device='cuda')
+    rs = torch.empty(B, L, dtype=torch.int32, device='cuda')
+    rs64 = torch.empty(B, L, dtype=torch.int64, device='cuda')
+    mk = torch.empty(B, L, device='cuda')
+    lib.vitae_random_masking(dev(noise).data_ptr(), sh.data_ptr(), rs.data_ptr(), mk.data_ptr(), rs64.data_ptr(), B, L, keep,
+                             st())
+    assert torch.equal(rs64.cpu(), torch.argsort(torch.argsort(noise, dim=1, stable=True), dim=1))
+    assert torch.equal(rs.cpu().long(), rs64.cpu())
+    assert torch.equal(sh.cpu().long(), torch.argsort(noise, dim=1, stable=True))
+    rank = torch.argsort(torch.argsort(noise, dim=1, stable=True), dim=1)
+    assert torch.equal(mk.cpu(), (rank >= keep).float()) and float(mk.sum()) == B * (L - keep)
+    if not (noise[0, 3] == noise[0, 9] and (rank[0, 3] < keep) != (rank[0, 9] < keep)):
+        assert torch.equal(mk.cpu(), mask)   # the oracle's (reference's) mask
+
+
+@pytest.mark.parametrize('C_,vol,p', [(4, (32, 32, 32), 16), (2, (16, 16, 16), 4), (1, (32, 16, 8), 8)])
+def test_gather_patches_and_assemble(lib, C_, vol, p):
+    B, D, Dd = 2, 48, 32
+    cfg = R.RefConfig(volume_size=vol, patch_size=p, in_chans=C_, embed_dim=D, depth=1, num_heads=3,
+                      decoder_embed_dim=Dd, decoder_depth=1, decoder_num_heads=2)
+    L, P = cfg.num_patches, cfg.patch_dim
+    keep = max(1, L // 4)
+    x = gen(B, C_, *vol, seed=1)
+    noise = torch.rand(B, L, generator=torch.Generator().manual_seed(2))
+    ids_keep, ids_restore, mask = R.masking_from_noise(noise, keep)
+    ids_shuffle = torch.argsort(noise, dim=1)
+    sh = ids_shuffle.int().cuda()
+    rows = torch.empty(B * keep, P, device='cuda')
+    lib.vitae_gather_patches(dev(x).data_ptr(), sh.data_ptr(), rows.data_ptr(), B, C_, *vol, p, keep, st())
+    # conv-order rows: unfold the volume the way Conv3d's weight is flattened
+    g = cfg.grid
+    pat = x.reshape(B, C_, g[0], p, g[1], p, g[2], p).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(B, L, P)
+    ref = torch.gather(pat, 1, ids_keep.unsqueeze(-1).expand(-1, -1, P)).reshape(B * keep, P)
+    assert torch.equal(rows.cpu(), ref)
+    # encoder assembly fwd/bwd
+    tok, cls, pos = gen(B * keep, D, seed=3), gen(D, seed=4), gen(L + 1, D, seed=5)
+    xs = torch.empty(B, keep + 1, D, device='cuda')
+    lib.vitae_encoder_assemble_fwd(dev(tok).data_ptr(), dev(cls).data_ptr(), dev(pos).data_ptr(), sh.data_ptr(),
+                                   xs.data_ptr(), B, L, keep, D, st())
+    ref = torch.cat([(cls + pos[0]).expand(B, 1, D),
+                     tok.reshape(B, keep, D) + pos[1:][ids_keep]], 1)
+    assert torch.allclose(xs.cpu(), ref, atol=1e-6)
+    dxs = gen(B, keep + 1, D, seed=6)
+    dtok, dcls = torch.empty(B * keep, D, device='cuda'), torch.zeros(D, device='cuda')
+    lib.vitae_encoder_assemble_bwd(dev(dxs).data_ptr(), dtok.data_ptr(), dcls.data_ptr(), B, keep, D, st())
+    assert torch.equal(dtok.cpu(), dxs[:, 1:].reshape(B * keep, D))
+    assert torch.allclose(dcls.cpu(), dxs[:, 0].sum(0), atol=1e-5)
+    # decoder assembly fwd/bwd against the oracle's cat/gather formulation (vit_autoenc.py:184-190)
+    e, mt, dpos = gen(B, keep + 1, Dd, seed=7), gen(Dd, seed=8), gen(L + 1, Dd, seed=9)
+    er, mtr = e.clone().requires_grad_(True), mt.clone().requires_grad_(True)
+    x_ = torch.cat([er[:, 1:], mtr.reshape(1, 1, Dd).repeat(B, L - keep, 1)], 1)
+    x_ = torch.gather(x_, 1, ids_restore.unsqueeze(-1).repeat(1, 1, Dd))
+    ref = torch.cat([er[:, :1], x_], 1) + dpos
+    dxd = gen(B, L + 1, Dd, seed=10)
+    ref.backward(dxd)
+    xd = torch.empty(B, L + 1, Dd, device='cuda')
+    rs = ids_restore.int().cuda()
+    lib.vitae_decoder_assemble_fwd(dev(e).data_ptr(), dev(mt).data_ptr(), dev(dpos).data_ptr(), rs.data_ptr(), xd.data_ptr(),
+                                   B, L, keep, Dd, st())
+    assert torch.allclose(xd.cpu(), ref.detach(), atol=1e-6)
+    de, dmt = torch.empty(B, keep + 1, Dd, device='cuda'), torch.zeros(Dd, device='cuda')
+    lib.vitae_decoder_assemble_bwd(dev(dxd).data_ptr(), sh.data_ptr(), de.data_ptr(), dmt.data_ptr(), B, L, keep, Dd, st())
+    assert torch.allclose(de.cpu(), er.grad, atol=1e-6)
+    assert rel_err(dmt, mtr.grad) < 1e-5
+
+
+# --------------------------------------------------------------------------- loss chain
+@pytest.mark.parametrize('C_,vol,p', [(4, (32, 32, 32), 16), (2, (16, 16, 16), 4), (1, (24, 16, 8), 8)])
+def test_loss_chain(lib, C, C_, vol, p):
+    from vit_ae_plus_plus_amd.engine import gaussian_taps_host
+    B = 2
+    cfg = R.RefConfig(volume_size=vol, patch_size=p, in_chans=C_, embed_dim=48, depth=1, num_heads=3,
+                      decoder_embed_dim=32, decoder_depth=1, decoder_num_heads=2)
+    L, P = cfg.num_patches, cfg.patch_dim
+    V = vol[0] * vol[1] * vol[2]
+    imgs = gen(B, C_, *vol, seed=1)
+    predfull = gen(B, L + 1, P, seed=2, scale=0.5)
+    mask = (torch.rand(B, L, generator=torch.Generator().manual_seed(3)) < 0.75).float()
+    mask[:, 0] = 1
+    edge_w, g_up = 0.37, 0.5
+    pr = predfull.clone().requires_grad_(True)
+    trace = {}
+    losses = R.loss_terms(imgs, pr[:, 1:, :], mask, cfg, edge_w, trace=trace)
+    (losses[0] * g_up).backward()
+    hp = torch.zeros(C['VITAE_HP_COUNT'], device='cuda')
+    hp[C['VITAE_HP_G_RECON']], hp[C['VITAE_HP_G_EDGE']], hp[C['VITAE_HP_EDGE_W']] = g_up, edge_w * g_up, edge_w
+    acc = torch.zeros(C['VITAE_ACC_COUNT'], dtype=torch.float64, device='cuda')
+    pd, im, mk = dev(predfull), dev(imgs), dev(mask)
+    pp, pbs = pd.data_ptr() + P * 4, (L + 1) * P
+    lib.vitae_recon_loss_fwd(pp, pbs, im.data_ptr(), mk.data_ptr(), acc.data_ptr(), B, C_, *vol, p, st())
+    pv = torch.empty(B, C_, *vol, device='cuda')
+    lib.vitae_unpatchify(pp, pbs, pv.data_ptr(), B, C_, *vol, p, st())
+    assert torch.equal(pv.cpu(), R.unpatchify(predfull[:, 1:, :], p, cfg.grid))
+    taps = gaussian_taps_host(2.0)
+    tmp, bl = torch.empty_like(im), torch.empty_like(im)
+    lib.vitae_gauss_blur_fwd(im.data_ptr(), tmp.data_ptr(), bl.data_ptr(), taps.ctypes.data, len(taps), B * C_, *vol, st())
+    assert rel_err(bl, trace['blurred']) < 1e-5
+    et, ep = torch.empty(B, *vol, device='cuda'), torch.empty(B, *vol, device='cuda')
+    lib.vitae_sobel_edge_fwd(bl.data_ptr(), et.data_ptr(), None, None, B, C_, *vol, st())
+    lib.vitae_sobel_edge_fwd(pv.data_ptr(), ep.data_ptr(), et.data_ptr(), acc.data_ptr(), B, C_, *vol, st())
+    assert rel_err(et, trace['edge_target']) < 1e-5 and rel_err(ep, trace['edge_pred']) < 1e-5
+    out = torch.zeros(4, device='cuda')
+    msum = float(mask.sum())
+    lib.vitae_loss_finalize(acc.data_ptr(), hp.data_ptr(), out.data_ptr(), msum, B * V, st())
+    ref = torch.stack([l.detach() for l in losses])
+    assert torch.allclose(out.cpu(), ref, rtol=2e-5, atol=1e-6), (out.cpu(), ref)
+    dpred = torch.zeros(B, L + 1, P, device='cuda')
+    dG = torch.empty(B * C_ * 3 * V, device='cuda')
+    lib.vitae_recon_loss_bwd(pp, pbs, im.data_ptr(), mk.data_ptr(), hp.data_ptr(), dpred.data_ptr() + P * 4, msum, B, C_, *vol,
+                             p, st())
+    lib.vitae_sobel_edge_bwd(pv.data_ptr(), ep.data_ptr(), et.data_ptr(), hp.data_ptr(), dG.data_ptr(), dpred.data_ptr() + P * 4,
+                             pbs, B, C_, *vol, p, st())
+    assert float(dpred[:, 0].abs().max()) == 0.0
+    assert rel_err(dpred, pr.grad) < 3e-5
+
+
+def test_sobel_kat_and_nan_semantics(lib):
+    """centre components (-32, 96, 288), |g| = 305.26056; zero input -> NaN gradient."""
+    x = torch.arange(27, dtype=torch.float32).reshape(1, 1, 3, 3, 3)
+    e = torch.empty(1, 3, 3, 3, device='cuda')
+    lib.vitae_sobel_edge_fwd(dev(x).data_ptr(), e.data_ptr(), None, None, 1, 1, 3, 3, 3, st())
+    assert abs(float(e[0, 1, 1, 1]) - 305.26056) < 1e-3
+    assert rel_err(e, R.sobel_magnitude(x)) < 1e-6
+
+
+# --------------------------------------------------------------------------- predictor pieces
+def test_bn1d_relu(lib):
+    Rr, D = 220, 768
+    x, w, b, dy = gen(Rr, D, seed=1) * 2 + 0.5, gen(D, seed=2) + 1, gen(D, seed=3) * 0.1, gen(Rr, D, seed=4)
+    bn = torch.nn.BatchNorm1d(D)
+    with torch.no_grad():
+        bn.weight.copy_(w); bn.bias.copy_(b)
+    xr = x.clone().requires_grad_(True)
+    ref = F.relu(bn(xr))
+    ref.backward(dy)
+    y, sm, sr = torch.empty(Rr, D, device='cuda'), torch.empty(D, device='cuda'), torch.empty(D, device='cuda')
+    rm, rv = torch.zeros(D, device='cuda'), torch.ones(D, device='cuda')
+    nbt = torch.zeros((), dtype=torch.int64, device='cuda')
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    lib.vitae_bn1d_relu_fwd(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), sm.data_ptr(), sr.data_ptr(),
+                            rm.data_ptr(), rv.data_ptr(), nbt.data_ptr(), Rr, D, 1e-5, 0.1, st())
+    assert rel_err(y, ref) < 1e-5 and int(nbt) == 1
+    assert rel_err(rm, bn.running_mean) < 1e-5 and rel_err(rv, bn.running_var) < 1e-5
+    dx, dw, db = torch.empty(Rr, D, device='cuda'), torch.zeros(D, device='cuda'), torch.zeros(D, device='cuda')
+    lib.vitae_bn1d_relu_bwd(dev(dy).data_ptr(), xd.data_ptr(), y.data_ptr(), wd.data_ptr(), sm.data_ptr(), sr.data_ptr(),
+                            dx.data_ptr(), dw.data_ptr(), db.data_ptr(), Rr, D, st())
+    assert rel_err(dx, xr.grad) < 2e-5 and rel_err(dw, bn.weight.grad) < 2e-5 and rel_err(db, bn.bias.grad) < 2e-5
+
+
+def test_cosine_loss(lib, C):
+    Rr, D, w, g_up = 220, 768, 0.001, 0.5
+    p1, p2, z1, z2 = (gen(Rr, D, seed=s) for s in (1, 2, 3, 4))
+    a, b = p1.clone().requires_grad_(True), p2.clone().requires_grad_(True)
+    ref = R.contrastive_loss(a, b, z1, z2, w)
+    (ref * g_up).backward()
+    hp = torch.zeros(C['VITAE_HP_COUNT'], device='cuda')
+    hp[C['VITAE_HP_CONTR_W']], hp[C['VITAE_HP_G_CONTR']] = w, w * g_up
+    acc = torch.zeros(C['VITAE_ACC_COUNT'], dtype=torch.float64, device='cuda')
+    out = torch.zeros(1, device='cuda')
+    d = [dev(t) for t in (p1, z2, p2, z1)]
+    lib.vitae_cosine_loss_fwd(*(t.data_ptr() for t in d), acc.data_ptr(), hp.data_ptr(), out.data_ptr(), Rr, D, st())
+    assert abs(float(out) - float(ref)) < 1e-9 + 1e-5 * abs(float(ref))
+    dp1, dp2 = torch.empty(Rr, D, device='cuda'), torch.empty(Rr, D, device='cuda')
+    lib.vitae_cosine_loss_bwd(*(t.data_ptr() for t in d), hp.data_ptr(), dp1.data_ptr(), dp2.data_ptr(), Rr, D, st())
+    assert rel_err(dp1, a.grad) < 1e-5 and rel_err(dp2, b.grad) < 1e-5
+
+
+# --------------------------------------------------------------------------- optimiser
+def test_adamw_and_gradnorm(lib, C):
+    n = 100003
+    p0, g1, g2 = gen(n, seed=1), gen(n, seed=2) * 0.01, gen(n, seed=3) * 0.01
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([ref], lr=3e-4, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05)
+    npad = (n + 3) // 4 * 4
+    p, m, v = torch.zeros(npad, device='cuda'), torch.zeros(npad, device='cuda'), torch.zeros(npad, device='cuda')
+    p[:n] = p0.cuda()
+    hp = torch.zeros(C['VITAE_HP_COUNT'], device='cuda')
+    acc = torch.zeros(C['VITAE_ACC_COUNT'], dtype=torch.float64, device='cuda')
+    gn = torch.zeros(1, device='cuda')
+    for t, g in enumerate((g1, g2), 1):
+        ref.grad = g.clone()
+        opt.step()
+        gd = torch.zeros(npad, device='cuda'); gd[:n] = g.cuda()
+        hp[C['VITAE_HP_LR']], hp[C['VITAE_HP_BETA1']], hp[C['VITAE_HP_BETA2']], hp[C['VITAE_HP_EPS']] = 3e-4, 0.9, 0.95, 1e-8
+        hp[C['VITAE_HP_BC1']], hp[C['VITAE_HP_BC2']], hp[C['VITAE_HP_GRAD_MUL']] = 1 - 0.9 ** t, 1 - 0.95 ** t, 1.0
+        acc.zero_()
+        lib.vitae_grad_sqnorm(gd.data_ptr(), n, acc.data_ptr(), gn.data_ptr(), st())
+        assert abs(float(gn) - float(g.norm())) < 1e-5 * float(g.norm())
+        lib.vitae_adamw_step(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, hp.data_ptr(), gn.data_ptr(), 0.05, st())
+        assert rel_err(p[:n], ref) < 2e-6
+    # non-finite gradient norm -> step skipped (GradScaler.step semantics)
+    before = p.clone()
+    gn.fill_(float('inf'))
+    lib.vitae_adamw_step(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, hp.data_ptr(), gn.data_ptr(), 0.05, st())
+    assert torch.equal(p, before)

@@ -1,0 +1,162 @@
+"""CPU: host-side logic of the drop-in surface (no kernels): schedule, meters, scaler state,
+factories / state-dict keys, arena layout rules, drop-in aliases, loud failure on CPU tensors."""
+import argparse
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mae_ref as R
+from vit_ae_plus_plus_amd._abi import VitaeError
+from vit_ae_plus_plus_amd.model import model_factory, vit_autoenc
+from vit_ae_plus_plus_amd.model.model_utils.vit_helpers import get_3d_sincos_pos_embed
+from vit_ae_plus_plus_amd.utils import lr_sched, misc
+
+
+def test_lr_schedule_matches_oracle_restatement():
+    from oracle.train_ref import lr_at
+    args = argparse.Namespace(lr=1e-3, min_lr=1e-5, warmup_epochs=40, epochs=50)
+
+    class Opt:
+        param_groups = [{'lr': 0.0}, {'lr': 0.0, 'lr_scale': 0.5}]
+    for e in (0.0, 0.5, 3.25, 39.99, 40.0, 44.4, 50.0):
+        lr = lr_sched.adjust_learning_rate(Opt, e, args)
+        assert lr == pytest.approx(lr_at(e, 1e-3, 1e-5, 40, 50), rel=1e-15, abs=1e-20)
+        assert Opt.param_groups[0]['lr'] == lr and Opt.param_groups[1]['lr'] == lr * 0.5
+
+
+def test_smoothed_value_and_logger(capsys):
+    m = misc.SmoothedValue(window_size=3)
+    for v in (1.0, 5.0, 3.0, 4.0):
+        m.update(v)
+    assert m.count == 4 and m.total == 13.0 and m.global_avg == 3.25
+    assert m.median == float(torch.tensor([5.0, 3.0, 4.0]).median()) and m.max == 5.0 and m.value == 4.0
+    assert abs(m.avg - 4.0) < 1e-6
+    m2 = misc.SmoothedValue(window_size=4)
+    for v in (1.0, 2.0, 3.0, 4.0):
+        m2.update(v)
+    assert m2.median == float(torch.tensor([1.0, 2.0, 3.0, 4.0]).median()) == 2.0   # lower middle
+    lg = misc.MetricLogger(delimiter="  ")
+    lg.add_meter('lr', misc.SmoothedValue(window_size=1, fmt='{value:.6f}'))
+    seen = [x for x in lg.log_every(range(5), 2, 'Epoch: [0]')]
+    assert seen == list(range(5))
+    lg.update(loss=torch.tensor(2.0), lr=0.1, skipped=None)
+    assert lg.loss.global_avg == 2.0 and 'skipped' not in lg.meters
+    out = capsys.readouterr().out
+    assert 'Epoch: [0]' in out and 'Total time' in out
+    with pytest.raises(AttributeError):
+        lg.nope
+
+
+def test_scaler_state_dict_format():
+    s = misc.NativeScalerWithGradNormCount()
+    sd = s.state_dict()
+    assert set(sd) == {'scale', 'growth_factor', 'backoff_factor', 'growth_interval', '_growth_tracker'}
+    s.load_state_dict({'scale': 65536.0, 'growth_factor': 2.0, 'backoff_factor': 0.5, 'growth_interval': 2000,
+                       '_growth_tracker': 7})
+    assert s.state_dict()['scale'] == 1.0 and s.state_dict()['_growth_tracker'] == 7
+    assert misc.all_reduce_mean(3.5) == 3.5 and misc.get_world_size() == 1 and misc.is_main_process()
+
+
+def test_get_grad_norm_matches_reference_formula():
+    ps = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7)), torch.nn.Parameter(torch.randn(2))]
+    ps[0].grad, ps[1].grad = torch.randn(5, 3), torch.randn(7)
+    want = torch.norm(torch.stack([torch.norm(p.grad, 2.0) for p in ps[:2]]), 2.0)
+    assert torch.allclose(misc.get_grad_norm_(ps), want)
+    assert float(misc.get_grad_norm_([ps[2]])) == 0.0
+
+
+def _args(**kw):
+    d = dict(model='contr_mae_vit_base_patch16', volume_size=96, in_channels=4, patch_size=16, use_imagenet=False,
+             perceptual_weight=0)
+    d.update(kw)
+    return argparse.Namespace(**d)
+
+
+@pytest.mark.parametrize('name,contr', [('contr_mae_vit_tiny_patch16', True), ('mae_vit_tiny_patch16', False)])
+def test_factory_state_dict_keys_match_reference_layout(name, contr):
+    model = model_factory.get_models('autoenc', _args(model=name, volume_size=64, in_channels=1))
+    cfg = R.RefConfig(volume_size=(64,) * 3, patch_size=16, in_chans=1, embed_dim=128, depth=2, num_heads=4,
+                      decoder_embed_dim=64, decoder_depth=1, decoder_num_heads=4, contrastive=contr)
+    spec = R.state_dict_spec(cfg)   # pinned against the reference's own state dict in test_oracle_golden
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(spec.keys())
+    for k, shp in spec.items():
+        assert tuple(sd[k].shape) == shp, k
+    frozen = {k for k, p in model.named_parameters() if not p.requires_grad}
+    assert frozen == {'pos_embed', 'decoder_pos_embed', 'sobel_filter3D.sobel_filter.weight',
+                      'sobel_filter3D.sobel_filter.bias'}
+    np.testing.assert_array_equal(sd['pos_embed'][0].numpy(),
+                                  get_3d_sincos_pos_embed(128, 4, True).astype(np.float32))
+    np.testing.assert_array_equal(sd['sobel_filter3D.sobel_filter.weight'].numpy(), R.sobel_kernels().numpy())
+    # init statistics (vit_autoenc.py:65-98): LN (1,0), linear biases 0, xavier bound
+    assert float(sd['blocks.0.norm1.weight'].min()) == 1.0 and float(sd['blocks.1.mlp.fc2.bias'].abs().max()) == 0.0
+    w = sd['blocks.0.attn.qkv.weight']
+    assert float(w.abs().max()) <= math.sqrt(6.0 / (128 + 384)) + 1e-6
+    w = sd['patch_embed.proj.weight']
+    assert float(w.abs().max()) <= math.sqrt(6.0 / (128 + 4096)) + 1e-6
+    # reference-format state dicts (incl. the real reference's perceptual_loss.* tensors) load
+    ref_sd = R.init_state_dict(cfg, seed=1)
+    ref_sd['perceptual_loss.slice1.0.weight'] = torch.zeros(3)
+    model.load_state_dict(ref_sd)
+    assert torch.equal(model.state_dict()['decoder_pred.weight'], ref_sd['decoder_pred.weight'])
+
+
+def test_vitb_parameter_count_matches_survey():
+    model = vit_autoenc.contr_mae_vit_base_patch16(volume_size=96, in_chans=4, patch_size=16, args=_args())
+    n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    n_all = sum(p.numel() for p in model.parameters())   # trainable + frozen (tables, sobel)
+    assert n_train == 132_841_728 and n_all == 133_119_572
+    assert model.patch_embed.num_patches == 216 and model.patch_embed.patch_size == (16, 16, 16)
+    assert model.patch_embed.grid_size == (6, 6, 6) and model.embed_dim == 768 and len(model.blocks) == 12
+
+
+def test_patchify_roundtrip_and_kat():
+    model = vit_autoenc.mae_vit_tiny_patch16(volume_size=(8, 4, 12), in_chans=3, patch_size=4, args=_args())
+    v = torch.randn(2, 3, 8, 4, 12)
+    assert torch.equal(model.unpatchify(model.patchify(v)), v)
+    assert torch.equal(model.patchify(v), R.patchify(v, 4))
+
+
+def test_cpu_forward_fails_loudly_instead_of_falling_back():
+    model = model_factory.get_models('autoenc', _args(model='contr_mae_vit_tiny_patch16', volume_size=64, in_channels=1))
+    x = torch.zeros(1, 1, 64, 64, 64)
+    with pytest.raises(VitaeError, match='no CPU fallback'):
+        model(view1=x, view2=x)
+    from vit_ae_plus_plus_amd.utils.train_one_epoch import compute_contrastive_loss
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        compute_contrastive_loss(_args(contr_weight=1.0), None, torch.zeros(2, 4), torch.zeros(2, 4), torch.zeros(2, 4),
+                                 torch.zeros(2, 4))
+
+
+def test_unsupported_options_are_rejected():
+    with pytest.raises(VitaeError):
+        vit_autoenc.mae_vit_tiny_patch16(volume_size=64, in_chans=1, patch_size=16, args=_args(perceptual_weight=1))
+    with pytest.raises(VitaeError):
+        vit_autoenc.mae_vit_tiny_patch16(volume_size=64, in_chans=1, patch_size=16, args=_args(), norm_pix_loss=True)
+    with pytest.raises(NotImplementedError):
+        model_factory.get_models('nope', _args())
+
+
+def test_dropin_aliases():
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import vit_ae_plus_plus_amd.dropin as d; d.install();"
+            "from model.model_factory import get_models; from model.vit_autoenc import ContrastiveMAEViT;"
+            "from utils import misc, lr_sched; from utils.train_one_epoch import train_one_stage_epoch, train_one_epoch, "
+            "compute_contrastive_loss; from model.model_utils.vit_helpers import get_3d_sincos_pos_embed, interpolate_pos_embed;"
+            "from model.vit import PatchEmbed3D, Mlp3D, Attention, Block; print('ok')")
+    r = subprocess.run([sys.executable, '-c', code], cwd=root, capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stderr
+
+
+def test_fused_adamw_param_groups_follow_timm_rule():
+    from vit_ae_plus_plus_amd.optim import FusedAdamW
+    model = vit_autoenc.contr_mae_vit_tiny_patch16(volume_size=64, in_chans=1, patch_size=16, args=_args())
+    opt = FusedAdamW(model, lr=1e-3, weight_decay=0.05)
+    names = {id(p): n for n, p in model.named_parameters()}
+    ref = R.param_groups(dict(model.named_parameters()), 0.05)
+    assert [names[id(p)] for p in opt.param_groups[0]['params']] == ref[0]['names']
+    assert [names[id(p)] for p in opt.param_groups[1]['params']] == ref[1]['names']
+    assert 'cls_token' in ref[1]['names'] and 'norm.weight' in ref[0]['names']

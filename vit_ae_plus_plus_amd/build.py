@@ -1,0 +1,68 @@
+"""Builds ``libvitae_hip.so`` (the C-ABI HIP library, gfx950 only) in-tree with hipcc.
+
+    python -m vit_ae_plus_plus_amd.build [--force]
+
+No torch headers are involved: the library is plain HIP behind ``include/vitae_hip.h``.  Objects are
+cached per source under ``csrc/_obj`` keyed on mtime so incremental rebuilds take seconds.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, 'csrc')
+OBJ = os.path.join(CSRC, '_obj')
+LIB = os.path.join(PKG, 'libvitae_hip.so')
+SOURCES = ['gemm.hip', 'norm.hip', 'attention.hip', 'tokens.hip', 'loss.hip', 'optim.hip']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast',
+         '-I', os.path.join(ROOT, 'include'), '-I', CSRC]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError('hipcc not found')
+
+
+def _newer(a: str, deps) -> bool:
+    if not os.path.exists(a):
+        return False
+    t = os.path.getmtime(a)
+    return all(os.path.getmtime(d) <= t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    headers = [os.path.join(CSRC, 'common.hpp'), os.path.join(ROOT, 'include', 'vitae_hip.h')]
+    hipcc = _hipcc()
+    objs, jobs = [], []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(OBJ, s.replace('.hip', '.o'))
+        objs.append(obj)
+        if force or not _newer(obj, [src] + headers):
+            jobs.append([hipcc, *FLAGS, '-c', src, '-o', obj])
+
+    def run(cmd):
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f'hipcc failed:\n{r.stdout}\n{r.stderr}')
+        return r
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+            list(ex.map(run, jobs))
+    if jobs or not _newer(LIB, objs):
+        run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB, *objs])
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv))

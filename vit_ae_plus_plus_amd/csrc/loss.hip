@@ -1,0 +1,375 @@
+// Loss chain of the ViT-AE++ objective (reference ops K14-K21 and K24):
+//   masked-voxel reconstruction MSE   model/vit_autoenc.py:226-227 (target = patchify(imgs), :100-113)
+//   unpatchify(pred)                  model/vit_autoenc.py:115-128, 221
+//   Gaussian blur of the target       model/model_utils/gaussian_filter.py:16-26 (11 taps, zero pad)
+//   3D Sobel magnitude, channel sum   model/model_utils/sobel_filter.py:37-45
+//   edge-map MSE                      model/vit_autoenc.py:224-225
+//   SimSiam cosine loss               utils/train_one_epoch.py:113-114
+// All HBM-bound streaming / stencil work in fp32.  `pred` is addressed through (row stride P, batch
+// stride) so the decoder output with its cls row ([B, L+1, P]) is consumed in place.  Scalar sums go
+// to a double accumulator block `acc` (VITAE_ACC_*), finalised by tiny kernels; upstream gradient
+// multipliers are read from the device-resident `hp` block (VITAE_HP_*) so captured graphs can be
+// replayed while edge_map_weight / accum scaling change.
+#include "common.hpp"
+#include "vitae_hip.h"
+
+namespace {
+
+struct VolGeom {
+    int C, Lz, Hy, Wx, p, g1, g2, L;
+    long P, pred_bstride;   // pred element (b, l, e) at pred[b*pred_bstride + l*P + e]
+};
+
+__device__ __forceinline__ long vol_index(const VolGeom& g, int b, int l, int e) {
+    // patchify order inside a patch: e = ((r*p + s)*p + q)*C + c   (vit_autoenc.py:111)
+    const int c = e % g.C;
+    int rem = e / g.C;
+    const int q = rem % g.p; rem /= g.p;
+    const int s = rem % g.p;
+    const int r = rem / g.p;
+    const int gl = l / (g.g1 * g.g2), gh = (l / g.g2) % g.g1, gw = l % g.g2;
+    return (((long)(b * g.C + c) * g.Lz + gl * g.p + r) * g.Hy + gh * g.p + s) * g.Wx + gw * g.p + q;
+}
+
+// ---------------------------------------------------------------- masked reconstruction loss
+__global__ __launch_bounds__(256) void recon_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ imgs,
+                                                        const float* __restrict__ mask, double* __restrict__ acc,
+                                                        VolGeom g) {
+    __shared__ float red[4];
+    const int l = blockIdx.x, b = blockIdx.y;
+    if (mask[(long)b * g.L + l] == 0.f) return;
+    const float* prow = pred + (long)b * g.pred_bstride + (long)l * g.P;
+    float s = 0.f;
+    for (int e = threadIdx.x; e < g.P; e += 256) {
+        const float d = prow[e] - imgs[vol_index(g, b, l, e)];
+        s += d * d;
+    }
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) atomicAdd(acc + VITAE_ACC_RECON, (double)(s / (float)g.P));
+}
+
+// dpred = 2 (pred - target) * mask / (P * mask.sum()) * g_recon
+__global__ __launch_bounds__(256) void recon_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ imgs,
+                                                        const float* __restrict__ mask, const float* __restrict__ hp,
+                                                        float* __restrict__ dpred, float inv_p_masksum, VolGeom g) {
+    const int l = blockIdx.x, b = blockIdx.y;
+    const long off = (long)b * g.pred_bstride + (long)l * g.P;
+    float* drow = dpred + off;
+    if (mask[(long)b * g.L + l] == 0.f) {
+        for (int e = threadIdx.x; e < g.P; e += 256) drow[e] = 0.f;
+        return;
+    }
+    const float coef = 2.f * hp[VITAE_HP_G_RECON] * inv_p_masksum;
+    const float* prow = pred + off;
+    for (int e = threadIdx.x; e < g.P; e += 256) drow[e] = coef * (prow[e] - imgs[vol_index(g, b, l, e)]);
+}
+
+// ---------------------------------------------------------------- unpatchify(pred) -> volume
+__global__ __launch_bounds__(256) void unpatchify_kernel(const float* __restrict__ pred, float* __restrict__ vol, VolGeom g) {
+    const int l = blockIdx.x, b = blockIdx.y;
+    const float* prow = pred + (long)b * g.pred_bstride + (long)l * g.P;
+    for (int e = threadIdx.x; e < g.P; e += 256) vol[vol_index(g, b, l, e)] = prow[e];
+}
+
+// ---------------------------------------------------------------- separable Gaussian blur (one axis)
+struct Taps { float k[VITAE_MAX_TAPS]; int n; };
+
+__global__ __launch_bounds__(256) void blur_axis_kernel(const float* __restrict__ in, float* __restrict__ out, long total,
+                                                        int len, long inner, Taps t) {
+    const int rad = t.n / 2;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int pos = (int)((idx / inner) % len);
+        float s = 0.f;
+        for (int i = 0; i < t.n; ++i) {
+            const int pp = pos + i - rad;
+            if (pp >= 0 && pp < len) s += t.k[i] * in[idx + (long)(i - rad) * inner];
+        }
+        out[idx] = s;
+    }
+}
+
+// ---------------------------------------------------------------- 3D Sobel
+// Cross-correlation with the three kernels of sobel_filter.py:12-31 (zero padding 1):
+//   g0 = s(z) s(y) d(x),  g1 = s(z) e(y) s(x),  g2 = e(z) s(y) s(x),  s=[1,2,1], d=[1,0,-1], e=[-1,0,1]
+__device__ __forceinline__ void sobel_at(const float* __restrict__ v, int z, int y, int x, int Lz, int Hy, int Wx,
+                                         float& g0, float& g1, float& g2) {
+    g0 = g1 = g2 = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int zz = z + a - 1;
+        if (zz < 0 || zz >= Lz) continue;
+        const float sa = a == 1 ? 2.f : 1.f, ea = (float)(a - 1);
+#pragma unroll
+        for (int bb = 0; bb < 3; ++bb) {
+            const int yy = y + bb - 1;
+            if (yy < 0 || yy >= Hy) continue;
+            const float sb = bb == 1 ? 2.f : 1.f, eb = (float)(bb - 1);
+            const float* row = v + ((long)zz * Hy + yy) * Wx;
+            const float xm = x > 0 ? row[x - 1] : 0.f;
+            const float x0 = row[x];
+            const float xp = x + 1 < Wx ? row[x + 1] : 0.f;
+            const float sx = xm + 2.f * x0 + xp;   // s along x
+            const float dx = xm - xp;              // d = [1, 0, -1] along x
+            g0 += sa * sb * dx;
+            g1 += sa * eb * sx;
+            g2 += ea * sb * sx;
+        }
+    }
+}
+
+// E[b, z, y, x] = sum_c |grad|;  optionally accumulates sum (E - E_ref)^2 into acc[VITAE_ACC_EDGE].
+__global__ __launch_bounds__(256) void sobel_mag_kernel(const float* __restrict__ vol, float* __restrict__ E,
+                                                        const float* __restrict__ E_ref, double* __restrict__ acc,
+                                                        int B, int C, int Lz, int Hy, int Wx) {
+    __shared__ float red[4];
+    const long V = (long)Lz * Hy * Wx, total = (long)B * V;
+    float sq = 0.f;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int b = (int)(idx / V);
+        const long r = idx % V;
+        const int x = (int)(r % Wx), y = (int)((r / Wx) % Hy), z = (int)(r / ((long)Wx * Hy));
+        float e = 0.f;
+        for (int c = 0; c < C; ++c) {
+            float g0, g1, g2;
+            sobel_at(vol + ((long)b * C + c) * V, z, y, x, Lz, Hy, Wx, g0, g1, g2);
+            e += sqrtf(g0 * g0 + g1 * g1 + g2 * g2);
+        }
+        E[idx] = e;
+        if (E_ref) { const float d = e - E_ref[idx]; sq += d * d; }
+    }
+    if (E_ref) {
+        sq = block_sum_256(sq, red);
+        if (threadIdx.x == 0) atomicAdd(acc + VITAE_ACC_EDGE, (double)sq);
+    }
+}
+
+// dG[b, c, a, voxel] = dE * g_a / |g|,  dE = 2 (E_pred - E_tgt) * g_edge / (B*V).
+// |g| == 0 gives 0/0 = NaN exactly like sqrt's backward in the reference.
+__global__ __launch_bounds__(256) void sobel_bwd_components_kernel(const float* __restrict__ vol, const float* __restrict__ Ep,
+                                                                   const float* __restrict__ Et, const float* __restrict__ hp,
+                                                                   float* __restrict__ dG, float inv_count, int B, int C,
+                                                                   int Lz, int Hy, int Wx) {
+    const long V = (long)Lz * Hy * Wx, total = (long)B * V;
+    const float coef = 2.f * hp[VITAE_HP_G_EDGE] * inv_count;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int b = (int)(idx / V);
+        const long r = idx % V;
+        const int x = (int)(r % Wx), y = (int)((r / Wx) % Hy), z = (int)(r / ((long)Wx * Hy));
+        const float dE = coef * (Ep[idx] - Et[idx]);
+        for (int c = 0; c < C; ++c) {
+            float g0, g1, g2;
+            sobel_at(vol + ((long)b * C + c) * V, z, y, x, Lz, Hy, Wx, g0, g1, g2);
+            const float m = sqrtf(g0 * g0 + g1 * g1 + g2 * g2);
+            const float f = dE / m;
+            float* o = dG + (((long)b * C + c) * 3) * V + r;
+            o[0] = f * g0; o[V] = f * g1; o[2 * V] = f * g2;
+        }
+    }
+}
+
+// dvol[u] = sum_a sum_o w_a[o] * dG_a[u - o + 1]  (transpose of the correlation), scattered straight
+// into dpred (patchify order) with +=.
+__global__ __launch_bounds__(256) void sobel_bwd_scatter_kernel(const float* __restrict__ dG, float* __restrict__ dpred,
+                                                                int B, VolGeom g) {
+    const int Lz = g.Lz, Hy = g.Hy, Wx = g.Wx, C = g.C, p = g.p;
+    const long V = (long)Lz * Hy * Wx, total = (long)B * V;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int b = (int)(idx / V);
+        const long r = idx % V;
+        const int x = (int)(r % Wx), y = (int)((r / Wx) % Hy), z = (int)(r / ((long)Wx * Hy));
+        const int l = ((z / p) * g.g1 + y / p) * g.g2 + x / p;
+        const int e0 = (((z % p) * p + y % p) * p + x % p) * C;
+        float* drow = dpred + (long)b * g.pred_bstride + (long)l * g.P + e0;
+        for (int c = 0; c < C; ++c) {
+            const float* d0 = dG + (((long)b * C + c) * 3) * V;
+            float acc = 0.f;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const int zz = z - a + 1;
+                if (zz < 0 || zz >= Lz) continue;
+                const float sa = a == 1 ? 2.f : 1.f, ea = (float)(a - 1);
+#pragma unroll
+                for (int bb = 0; bb < 3; ++bb) {
+                    const int yy = y - bb + 1;
+                    if (yy < 0 || yy >= Hy) continue;
+                    const float sb = bb == 1 ? 2.f : 1.f, eb = (float)(bb - 1);
+                    const long ro = ((long)zz * Hy + yy) * Wx;
+                    // o = 0,1,2 along x reads dG at x+1, x, x-1 with weights (d: 1,0,-1 ; s: 1,2,1)
+                    const bool hp_ = x + 1 < Wx, hm = x > 0;
+                    const float a0p = hp_ ? d0[ro + x + 1] : 0.f, a0m = hm ? d0[ro + x - 1] : 0.f;
+                    const float a1p = hp_ ? d0[V + ro + x + 1] : 0.f, a10 = d0[V + ro + x], a1m = hm ? d0[V + ro + x - 1] : 0.f;
+                    const float a2p = hp_ ? d0[2 * V + ro + x + 1] : 0.f, a20 = d0[2 * V + ro + x], a2m = hm ? d0[2 * V + ro + x - 1] : 0.f;
+                    acc += sa * sb * (a0p - a0m);
+                    acc += sa * eb * (a1p + 2.f * a10 + a1m);
+                    acc += ea * sb * (a2p + 2.f * a20 + a2m);
+                }
+            }
+            drow[c] += acc;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- scalar finalisation
+// out = [loss, raw_edge_mse, recon, percep(=0)]   (vit_autoenc.py:231-232)
+__global__ void loss_finalize_kernel(const double* __restrict__ acc, const float* __restrict__ hp, float* __restrict__ out,
+                                     float inv_masksum, float inv_edge_count) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float recon = (float)(acc[VITAE_ACC_RECON]) * inv_masksum;
+    const float edge = (float)(acc[VITAE_ACC_EDGE] * (double)inv_edge_count);
+    out[0] = hp[VITAE_HP_EDGE_W] * edge + recon + 0.f;
+    out[1] = edge;
+    out[2] = recon;
+    out[3] = 0.f;
+}
+
+// ---------------------------------------------------------------- SimSiam cosine loss
+// One wave per row: cos(p, z) = <p/max(|p|,eps), z/max(|z|,eps)>  (nn.CosineSimilarity, eps 1e-8)
+__global__ __launch_bounds__(256) void cosine_fwd_kernel(const float* __restrict__ p1, const float* __restrict__ z2,
+                                                         const float* __restrict__ p2, const float* __restrict__ z1,
+                                                         double* __restrict__ acc, int R, int D, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= R) return;
+#pragma unroll
+    for (int pair = 0; pair < 2; ++pair) {
+        const float* p = (pair == 0 ? p1 : p2) + (long)row * D;
+        const float* z = (pair == 0 ? z2 : z1) + (long)row * D;
+        float dot = 0.f, pp = 0.f, zz = 0.f;
+        for (int d = lane; d < D; d += 64) { const float a = p[d], b = z[d]; dot += a * b; pp += a * a; zz += b * b; }
+        dot = wave_sum(dot); pp = wave_sum(pp); zz = wave_sum(zz);
+        const float c = dot / (fmaxf(sqrtf(pp), eps) * fmaxf(sqrtf(zz), eps));
+        if (lane == 0) atomicAdd(acc + VITAE_ACC_COS, (double)c);
+    }
+}
+
+// contr = contr_w * (-(mean cos(p1,z2) + mean cos(p2,z1)) / 2)
+__global__ void cosine_finalize_kernel(const double* __restrict__ acc, const float* __restrict__ hp, float* __restrict__ out, float inv_rows) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    out[0] = hp[VITAE_HP_CONTR_W] * (float)(-0.5 * acc[VITAE_ACC_COS] * (double)inv_rows);
+}
+
+// dp = g_contr * (-0.5 / R) * ( z/(|p||z|) - cos * p/|p|^2 )
+__global__ __launch_bounds__(256) void cosine_bwd_kernel(const float* __restrict__ p1, const float* __restrict__ z2,
+                                                         const float* __restrict__ p2, const float* __restrict__ z1,
+                                                         const float* __restrict__ hp, float* __restrict__ dp1,
+                                                         float* __restrict__ dp2, int R, int D, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= R) return;
+    const float coef = hp[VITAE_HP_G_CONTR] * (-0.5f / (float)R);
+#pragma unroll
+    for (int pair = 0; pair < 2; ++pair) {
+        const float* p = (pair == 0 ? p1 : p2) + (long)row * D;
+        const float* z = (pair == 0 ? z2 : z1) + (long)row * D;
+        float* dp = (pair == 0 ? dp1 : dp2) + (long)row * D;
+        float dot = 0.f, pp = 0.f, zz = 0.f;
+        for (int d = lane; d < D; d += 64) { const float a = p[d], b = z[d]; dot += a * b; pp += a * a; zz += b * b; }
+        dot = wave_sum(dot); pp = wave_sum(pp); zz = wave_sum(zz);
+        const float np = fmaxf(sqrtf(pp), eps), nz = fmaxf(sqrtf(zz), eps);
+        const float c = dot / (np * nz);
+        const float k1 = coef / (np * nz), k2 = coef * c / (np * np);
+        for (int d = lane; d < D; d += 64) dp[d] = k1 * z[d] - k2 * p[d];
+    }
+}
+
+inline VolGeom make_geom(int C, int Lz, int Hy, int Wx, int p, long pred_bstride) {
+    VolGeom g;
+    g.C = C; g.Lz = Lz; g.Hy = Hy; g.Wx = Wx; g.p = p;
+    g.g1 = Hy / p; g.g2 = Wx / p; g.L = (Lz / p) * g.g1 * g.g2;
+    g.P = (long)p * p * p * C; g.pred_bstride = pred_bstride;
+    return g;
+}
+
+inline int stream_blocks(long total) {
+    long b = (total + 255) / 256;
+    return (int)(b > 4096 ? 4096 : b);
+}
+
+}  // namespace
+
+extern "C" int vitae_recon_loss_fwd(const float* pred, long pred_bstride, const float* imgs, const float* mask,
+                                    double* acc, int B, int C, int Lz, int Hy, int Wx, int p, void* stream) {
+    if (!pred || !imgs || !mask || !acc || B <= 0 || p <= 0 || Lz % p || Hy % p || Wx % p) return VITAE_ERR_INVALID_ARG;
+    VolGeom g = make_geom(C, Lz, Hy, Wx, p, pred_bstride);
+    hipLaunchKernelGGL(recon_fwd_kernel, dim3(g.L, B), dim3(256), 0, (hipStream_t)stream, pred, imgs, mask, acc, g);
+    return vitae_launch_status();
+}
+
+extern "C" int vitae_recon_loss_bwd(const float* pred, long pred_bstride, const float* imgs, const float* mask,
+                                    const float* hp, float* dpred, float mask_sum, int B, int C, int Lz, int Hy,
+                                    int Wx, int p, void* stream) {
+    if (!pred || !imgs || !mask || !hp || !dpred || B <= 0 || p <= 0 || mask_sum <= 0.f) return VITAE_ERR_INVALID_ARG;
+    VolGeom g = make_geom(C, Lz, Hy, Wx, p, pred_bstride);
+    const float inv = 1.0f / ((float)g.P * mask_sum);
+    hipLaunchKernelGGL(recon_bwd_kernel, dim3(g.L, B), dim3(256), 0, (hipStream_t)stream, pred, imgs, mask, hp, dpred,
+                       inv, g);
+    return vitae_launch_status();
+}
+
+extern "C" int vitae_unpatchify(const float* pred, long pred_bstride, float* vol, int B, int C, int Lz, int Hy, int Wx,
+                                int p, void* stream) {
+    if (!pred || !vol || B <= 0 || p <= 0 || Lz % p || Hy % p || Wx % p) return VITAE_ERR_INVALID_ARG;
+    VolGeom g = make_geom(C, Lz, Hy, Wx, p, pred_bstride);
+    hipLaunchKernelGGL(unpatchify_kernel, dim3(g.L, B), dim3(256), 0, (hipStream_t)stream, pred, vol, g);
+    return vitae_launch_status();
+}
+
+extern "C" int vitae_gauss_blur_fwd(const float* vol, float* tmp, float* out, const float* taps_host, int ntaps,
+                                    int BC, int Lz, int Hy, int Wx, void* stream) {
+    if (!vol || !tmp || !out || !taps_host || ntaps <= 0 || ntaps > VITAE_MAX_TAPS || !(ntaps & 1)) return VITAE_ERR_INVALID_ARG;
+    Taps t; t.n = ntaps;
+    for (int i = 0; i < ntaps; ++i) t.k[i] = taps_host[i];
+    const long total = (long)BC * Lz * Hy * Wx;
+    const int blocks = stream_blocks(total);
+    hipStream_t st = (hipStream_t)stream;
+    // x, then y, then z (exact-arithmetic equal to the dense k (x) k (x) k kernel of the reference)
+    hipLaunchKernelGGL(blur_axis_kernel, dim3(blocks), dim3(256), 0, st, vol, out, total, Wx, 1L, t);
+    hipLaunchKernelGGL(blur_axis_kernel, dim3(blocks), dim3(256), 0, st, out, tmp, total, Hy, (long)Wx, t);
+    hipLaunchKernelGGL(blur_axis_kernel, dim3(blocks), dim3(256), 0, st, tmp, out, total, Lz, (long)Wx * Hy, t);
+    return vitae_launch_status();
+}
+
+extern "C" int vitae_sobel_edge_fwd(const float* vol, float* edge, const float* edge_ref, double* acc, int B, int C,
+                                    int Lz, int Hy, int Wx, void* stream) {
+    if (!vol || !edge || B <= 0 || C <= 0 || (edge_ref && !acc)) return VITAE_ERR_INVALID_ARG;
+    const long total = (long)B * Lz * Hy * Wx;
+    hipLaunchKernelGGL(sobel_mag_kernel, dim3(stream_blocks(total)), dim3(256), 0, (hipStream_t)stream, vol, edge,
+                       edge_ref, acc, B, C, Lz, Hy, Wx);
+    return vitae_launch_status();
+}
+
+extern "C" int vitae_sobel_edge_bwd(const float* pred_vol, const float* edge_pred, const float* edge_tgt,
+                                    const float* hp, float* dG_ws, float* dpred, long pred_bstride, int B, int C,
+                                    int Lz, int Hy, int Wx, int p, void* stream) {
+    if (!pred_vol || !edge_pred || !edge_tgt || !hp || !dG_ws || !dpred || B <= 0) return VITAE_ERR_INVALID_ARG;
+    const long total = (long)B * Lz * Hy * Wx;
+    VolGeom g = make_geom(C, Lz, Hy, Wx, p, pred_bstride);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(sobel_bwd_components_kernel, dim3(stream_blocks(total)), dim3(256), 0, st, pred_vol, edge_pred,
+                       edge_tgt, hp, dG_ws, 1.0f / (float)total, B, C, Lz, Hy, Wx);
+    hipLaunchKernelGGL(sobel_bwd_scatter_kernel, dim3(stream_blocks(total)), dim3(256), 0, st, dG_ws, dpred, B, g);
+    return vitae_launch_status();
+}
+
+extern "C" int vitae_loss_finalize(const double* acc, const float* hp, float* out4, float mask_sum, long edge_count,
+                                   void* stream) {
+    if (!acc || !hp || !out4 || mask_sum <= 0.f || edge_count <= 0) return VITAE_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, acc, hp, out4, 1.0f / mask_sum,
+                       1.0f / (float)edge_count);
+    return vitae_launch_status();
+}
+
+extern "C" int vitae_cosine_loss_fwd(const float* p1, const float* z2, const float* p2, const float* z1, double* acc,
+                                     const float* hp, float* out1, int R, int D, void* stream) {
+    if (!p1 || !z2 || !p2 || !z1 || !acc || !hp || !out1 || R <= 0 || D <= 0) return VITAE_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(cosine_fwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, st, p1, z2, p2, z1, acc, R, D, 1e-8f);
+    hipLaunchKernelGGL(cosine_finalize_kernel, dim3(1), dim3(64), 0, st, acc, hp, out1, 1.0f / (float)R);
+    return vitae_launch_status();
+}
+
+extern "C" int vitae_cosine_loss_bwd(const float* p1, const float* z2, const float* p2, const float* z1,
+                                     const float* hp, float* dp1, float* dp2, int R, int D, void* stream) {
+    if (!p1 || !z2 || !p2 || !z1 || !hp || !dp1 || !dp2 || R <= 0 || D <= 0) return VITAE_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(cosine_bwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, p1, z2, p2, z1, hp, dp1,
+                       dp2, R, D, 1e-8f);
+    return vitae_launch_status();
+}

@@ -1,0 +1,249 @@
+// Row / column normalisation kernels: LayerNorm (reference op K5: partial(nn.LayerNorm, eps=1e-6),
+// model/vit_autoenc.py:292,300,308 used at model/vit.py:132,135,142-143 and vit_autoenc.py:36,51)
+// and the predictor's BatchNorm1d + ReLU (op K23, vit_autoenc.py:263-268).  HBM-bound:
+// LayerNorm keeps the row in registers (one wave per row, 16-byte loads when D % 256 == 0),
+// statistics by wave shuffles; parameter gradients are wave-partial sums + one atomicAdd per
+// column per block into the (pre-zeroed) gradient arena.
+#include "common.hpp"
+#include "vitae_hip.h"
+
+namespace {
+
+constexpr int LN_MAX_PER_LANE = 16;   // D <= 1024
+
+// ------------------------------------------------------------------ LayerNorm forward
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ b, float* __restrict__ y,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                            int M, int D, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int lane = threadIdx.x & 63;
+    const float* xr = x + (long)row * D;
+    float v[LN_MAX_PER_LANE];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < D ? xr[c] : 0.f;
+        s += v[i];
+    }
+    const float mean = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+        const int c = lane + 64 * i;
+        const float d = c < D ? v[i] - mean : 0.f;
+        q += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(q) / D + eps);
+    float* yr = y + (long)row * D;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+        const int c = lane + 64 * i;
+        if (c < D) yr[c] = (v[i] - mean) * rstd * w[c] + b[c];
+    }
+    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+}
+
+// ------------------------------------------------------------------ LayerNorm backward
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w;  dw += dy * xhat;  db += dy.
+// Each wave walks rows row0, row0 + nwaves, ...; per-lane column partials are combined over the
+// block's 4 waves in LDS and added atomically.  `dx_accumulate` adds into dx (residual joins).
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ w, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, float* __restrict__ dx,
+                                                            float* __restrict__ dw, float* __restrict__ db,
+                                                            int M, int D, int dx_accumulate) {
+    __shared__ float red[2][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nwaves = gridDim.x * 4;
+    float pw[LN_MAX_PER_LANE], pb[LN_MAX_PER_LANE], wv[LN_MAX_PER_LANE];
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+        pw[i] = 0.f; pb[i] = 0.f;
+        const int c = lane + 64 * i;
+        wv[i] = c < D ? w[c] : 0.f;
+    }
+    for (int row = blockIdx.x * 4 + wave; row < M; row += nwaves) {
+        const float mu = mean[row], rs = rstd[row];
+        const float* xr = x + (long)row * D;
+        const float* dyr = dy + (long)row * D;
+        float xh[LN_MAX_PER_LANE], g[LN_MAX_PER_LANE];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+            const int c = lane + 64 * i;
+            float d = 0.f, xv = 0.f;
+            if (c < D) { d = dyr[c]; xv = (xr[c] - mu) * rs; }
+            xh[i] = xv; g[i] = d * wv[i];
+            pw[i] += d * xv; pb[i] += d;
+            s1 += g[i]; s2 += g[i] * xv;
+        }
+        s1 = wave_sum(s1) / D; s2 = wave_sum(s2) / D;
+        float* dxr = dx + (long)row * D;
+#pragma unroll
+        for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+            const int c = lane + 64 * i;
+            if (c < D) {
+                float r = rs * (g[i] - s1 - xh[i] * s2);
+                if (dx_accumulate) r += dxr[c];
+                dxr[c] = r;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+        if (64 * i >= D) break;
+        __syncthreads();
+        red[0][wave][lane] = pw[i]; red[1][wave][lane] = pb[i];
+        __syncthreads();
+        if (wave == 0) {
+            const int c = lane + 64 * i;
+            if (c < D) {
+                atomicAdd(dw + c, red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane]);
+                atomicAdd(db + c, red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ column sum (bias gradients)
+// out[n] += sum_m dy[m, n].  Threads own columns (coalesced rows), blocks own row slabs.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dy, long ld, float* __restrict__ out,
+                                                     int M, int N, int rows_per_block) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float s = 0.f;
+    for (int m = r0; m < r1; ++m) s += dy[(long)m * ld + n];
+    atomicAdd(out + n, s);
+}
+
+// ------------------------------------------------------------------ BatchNorm1d (+ReLU), training mode
+// Block = 32 feature columns x 8 row groups (256 threads): rows are strided over the 8 groups,
+// column partials are combined through LDS.  R rows (R = B * Ne = 220 at config 2).  Two passes
+// (mean, then centred variance) like ATen's CPU batch_norm.  Saves mean / rstd, updates the running
+// stats with momentum and the unbiased variance (nn.BatchNorm1d semantics).
+__device__ __forceinline__ float bn_col_reduce(float v, float (*red)[32], int col, int grp) {
+    __syncthreads();
+    red[grp][col] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) s += red[g][col];
+    return s;
+}
+
+__global__ __launch_bounds__(256) void bn1d_relu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ b, float* __restrict__ y,
+                                                            float* __restrict__ save_mean, float* __restrict__ save_rstd,
+                                                            float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                            long long* __restrict__ num_batches_tracked,
+                                                            int R, int D, float eps, float momentum) {
+    __shared__ float red[8][32];
+    if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
+    const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + col;
+    const bool ok = c < D;
+    float s = 0.f;
+    if (ok) for (int r = grp; r < R; r += 8) s += x[(long)r * D + c];
+    const float mean = bn_col_reduce(s, red, col, grp) / R;
+    float q = 0.f;
+    if (ok) for (int r = grp; r < R; r += 8) { const float d = x[(long)r * D + c] - mean; q += d * d; }
+    q = bn_col_reduce(q, red, col, grp);
+    if (!ok) return;
+    const float rstd = rsqrtf(q / R + eps);
+    const float g = w[c], be = b[c];
+    for (int r = grp; r < R; r += 8) {
+        const float v = (x[(long)r * D + c] - mean) * rstd * g + be;
+        y[(long)r * D + c] = v > 0.f ? v : 0.f;
+    }
+    if (grp == 0) {
+        save_mean[c] = mean; save_rstd[c] = rstd;
+        if (run_mean) {
+            run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
+            run_var[c] = (1.f - momentum) * run_var[c] + momentum * (q / (R > 1 ? R - 1 : 1));
+        }
+    }
+}
+
+// dy arrives for the ReLU output y; ReLU mask = (y > 0).  dx = w*rstd*(g - mean(g) - xhat*mean(g*xhat)).
+__global__ __launch_bounds__(256) void bn1d_relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ y, const float* __restrict__ w,
+                                                            const float* __restrict__ save_mean,
+                                                            const float* __restrict__ save_rstd, float* __restrict__ dx,
+                                                            float* __restrict__ dw, float* __restrict__ db, int R, int D) {
+    __shared__ float red[8][32];
+    const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + col;
+    const bool ok = c < D;
+    const float mean = ok ? save_mean[c] : 0.f, rstd = ok ? save_rstd[c] : 0.f, g = ok ? w[c] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    if (ok) for (int r = grp; r < R; r += 8) {
+        const long i = (long)r * D + c;
+        const float d = y[i] > 0.f ? dy[i] : 0.f;
+        s1 += d; s2 += d * (x[i] - mean) * rstd;
+    }
+    s1 = bn_col_reduce(s1, red, col, grp);
+    s2 = bn_col_reduce(s2, red, col, grp);
+    if (!ok) return;
+    if (grp == 0) { atomicAdd(dw + c, s2); atomicAdd(db + c, s1); }
+    const float m1 = s1 / R, m2 = s2 / R;
+    for (int r = grp; r < R; r += 8) {
+        const long i = (long)r * D + c;
+        const float d = y[i] > 0.f ? dy[i] : 0.f;
+        dx[i] = g * rstd * (d - m1 - (x[i] - mean) * rstd * m2);
+    }
+}
+
+}  // namespace
+
+extern "C" int vitae_layernorm_fwd(const float* x, const float* w, const float* b, float* y, float* mean,
+                                   float* rstd, int M, int D, float eps, void* stream) {
+    if (!x || !w || !b || !y || !mean || !rstd || M <= 0 || D <= 0) return VITAE_ERR_INVALID_ARG;
+    if (D > 64 * LN_MAX_PER_LANE) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, w, b, y, mean,
+                       rstd, M, D, eps);
+    return vitae_launch_status();
+}
+
+extern "C" int vitae_layernorm_bwd(const float* dy, const float* x, const float* w, const float* mean,
+                                   const float* rstd, float* dx, float* dw, float* db, int M, int D,
+                                   int dx_accumulate, void* stream) {
+    if (!dy || !x || !w || !mean || !rstd || !dx || !dw || !db || M <= 0 || D <= 0) return VITAE_ERR_INVALID_ARG;
+    if (D > 64 * LN_MAX_PER_LANE) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    int blocks = cdiv(M, 4);
+    if (blocks > 128) blocks = 128;   // bounds the number of atomics per column
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, w, mean, rstd,
+                       dx, dw, db, M, D, dx_accumulate);
+    return vitae_launch_status();
+}
+
+extern "C" int vitae_colsum_accum(const float* dy, long ld, float* out, int M, int N, void* stream) {
+    if (!dy || !out || M <= 0 || N <= 0) return VITAE_ERR_INVALID_ARG;
+    const int rpb = 32;
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 256), cdiv(M, rpb)), dim3(256), 0, (hipStream_t)stream, dy, ld, out,
+                       M, N, rpb);
+    return vitae_launch_status();
+}
+
+extern "C" int vitae_bn1d_relu_fwd(const float* x, const float* w, const float* b, float* y, float* save_mean,
+                                   float* save_rstd, float* running_mean, float* running_var,
+                                   long long* num_batches_tracked, int R, int D, float eps, float momentum,
+                                   void* stream) {
+    if (!x || !w || !b || !y || !save_mean || !save_rstd || R <= 0 || D <= 0) return VITAE_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(bn1d_relu_fwd_kernel, dim3(cdiv(D, 32)), dim3(256), 0, (hipStream_t)stream, x, w, b, y,
+                       save_mean, save_rstd, running_mean, running_var, num_batches_tracked, R, D, eps, momentum);
+    return vitae_launch_status();
+}
+
+extern "C" int vitae_bn1d_relu_bwd(const float* dy, const float* x, const float* y, const float* w,
+                                   const float* save_mean, const float* save_rstd, float* dx, float* dw,
+                                   float* db, int R, int D, void* stream) {
+    if (!dy || !x || !y || !w || !save_mean || !save_rstd || !dx || !dw || !db || R <= 0 || D <= 0)
+        return VITAE_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(bn1d_relu_bwd_kernel, dim3(cdiv(D, 32)), dim3(256), 0, (hipStream_t)stream, dy, x, y, w,
+                       save_mean, save_rstd, dx, dw, db, R, D);
+    return vitae_launch_status();
+}

@@ -1,0 +1,204 @@
+// Token bookkeeping around the transformer stacks (HBM / index bound):
+//   * random masking from a given noise tensor  (reference op K3, model/vit_autoenc.py:141-153)
+//   * patch gather = im2col restricted to the KEPT patches (op K1 input side, model/vit.py:72-74;
+//     the reference embeds all L patches and then discards 75 % of them at vit_autoenc.py:147 —
+//     rows of a GEMM are independent, so embedding only the kept ones is the same numbers)
+//   * encoder sequence assembly: +pos_embed, cls token (ops K2, K4; vit_autoenc.py:162-170)
+//   * decoder sequence assembly: mask-token fill, un-shuffle, +decoder_pos_embed (op K11/K12;
+//     vit_autoenc.py:184-190) and both backward scatters.
+#include "common.hpp"
+#include "vitae_hip.h"
+
+namespace {
+
+// ---------------------------------------------------------------- masking
+// One block per sample.  rank[i] = #{j : noise[j] < noise[i] or (== and j < i)} is the stable
+// ascending argsort position, so ids_restore[i] = rank[i] (= argsort(argsort(noise))),
+// ids_shuffle[rank[i]] = i and mask[i] = rank[i] >= len_keep (0 = keep, 1 = remove).
+__global__ __launch_bounds__(256) void random_masking_kernel(const float* __restrict__ noise, int* __restrict__ ids_shuffle,
+                                                             int* __restrict__ ids_restore, float* __restrict__ mask,
+                                                             long long* __restrict__ ids_restore64, int L, int len_keep) {
+    extern __shared__ float nz[];
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < L; i += 256) nz[i] = noise[(long)b * L + i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < L; i += 256) {
+        const float v = nz[i];
+        int rank = 0;
+        for (int j = 0; j < L; ++j) {
+            const float u = nz[j];
+            rank += (u < v) || (u == v && j < i);
+        }
+        ids_restore[(long)b * L + i] = rank;
+        if (ids_restore64) ids_restore64[(long)b * L + i] = rank;
+        ids_shuffle[(long)b * L + rank] = i;
+        mask[(long)b * L + i] = rank >= len_keep ? 1.f : 0.f;
+    }
+}
+
+// ---------------------------------------------------------------- kept-patch gather (im2col rows)
+// out[(b*keep + j), c*p^3 + r*p^2 + s*p + q] = vol[b, c, gl*p + r, gh*p + s, gw*p + q]
+// for patch l = ids_shuffle[b, j] = (gl, gh, gw): the Conv3d weight's (C, p, p, p) flattening.
+__global__ __launch_bounds__(256) void gather_patches_kernel(const float* __restrict__ vol, const int* __restrict__ ids_shuffle,
+                                                             float* __restrict__ out, int C, int Lz, int Hy, int Wx, int p,
+                                                             int g1, int g2, int L, int keep) {
+    const int j = blockIdx.x, b = blockIdx.y;
+    const int l = ids_shuffle[(long)b * L + j];
+    const int gl = l / (g1 * g2), gh = (l / g2) % g1, gw = l % g2;
+    const int p4 = p / 4;
+    const int P4 = C * p * p * p4;
+    const long vstride = (long)Lz * Hy * Wx;
+    const float* vb = vol + (long)b * C * vstride;
+    float* orow = out + ((long)b * keep + j) * ((long)C * p * p * p);
+    for (int i = threadIdx.x; i < P4; i += 256) {
+        const int q4 = i % p4, s = (i / p4) % p, r = (i / (p4 * p)) % p, c = i / (p4 * p * p);
+        const float* src = vb + c * vstride + ((long)(gl * p + r) * Hy + (gh * p + s)) * Wx + gw * p + q4 * 4;
+        *reinterpret_cast<f32x4*>(orow + (long)i * 4) = *reinterpret_cast<const f32x4*>(src);
+    }
+}
+
+// ---------------------------------------------------------------- encoder sequence assembly
+// x[b, 0]     = cls_token + pos_embed[0]
+// x[b, 1 + j] = tok[b*keep + j] + pos_embed[1 + ids_shuffle[b, j]]       (tok already has the conv bias)
+__global__ __launch_bounds__(256) void encoder_assemble_fwd_kernel(const float* __restrict__ tok, const float* __restrict__ cls,
+                                                                   const float* __restrict__ pos, const int* __restrict__ ids_shuffle,
+                                                                   float* __restrict__ x, int L, int keep, int D) {
+    const int t = blockIdx.x, b = blockIdx.y;   // t in [0, keep]
+    float* xr = x + ((long)b * (keep + 1) + t) * D;
+    if (t == 0) {
+        for (int d = threadIdx.x; d < D; d += 256) xr[d] = cls[d] + pos[d];
+    } else {
+        const int l = ids_shuffle[(long)b * L + t - 1];
+        const float* tr = tok + ((long)b * keep + t - 1) * D;
+        const float* pr = pos + (long)(1 + l) * D;
+        for (int d = threadIdx.x; d < D; d += 256) xr[d] = tr[d] + pr[d];
+    }
+}
+
+// dtok[b*keep + j] = dx[b, 1 + j];  dcls += sum_b dx[b, 0]
+__global__ __launch_bounds__(256) void encoder_assemble_bwd_kernel(const float* __restrict__ dx, float* __restrict__ dtok,
+                                                                   float* __restrict__ dcls, int B, int keep, int D) {
+    const int t = blockIdx.x, b = blockIdx.y;
+    const float* dr = dx + ((long)b * (keep + 1) + t) * D;
+    if (t == 0) {
+        if (b != 0) return;   // block (0,0) sums the cls rows of every sample
+        for (int d = threadIdx.x; d < D; d += 256) {
+            float s = 0.f;
+            for (int bb = 0; bb < B; ++bb) s += dx[((long)bb * (keep + 1)) * D + d];
+            atomicAdd(dcls + d, s);
+        }
+    } else {
+        float* o = dtok + ((long)b * keep + t - 1) * D;
+        for (int d = threadIdx.x; d < D; d += 256) o[d] = dr[d];
+    }
+}
+
+// ---------------------------------------------------------------- decoder sequence assembly
+// e = decoder_embed(latent) [B, keep+1, Dd].
+// xd[b, 0]     = e[b, 0] + dpos[0]
+// xd[b, 1 + l] = (r = ids_restore[b, l]) < keep ? e[b, 1 + r] : mask_token) + dpos[1 + l]
+__global__ __launch_bounds__(256) void decoder_assemble_fwd_kernel(const float* __restrict__ e, const float* __restrict__ mask_token,
+                                                                   const float* __restrict__ dpos, const int* __restrict__ ids_restore,
+                                                                   float* __restrict__ xd, int L, int keep, int Dd) {
+    const int t = blockIdx.x, b = blockIdx.y;   // t in [0, L]
+    float* xr = xd + ((long)b * (L + 1) + t) * Dd;
+    const float* pr = dpos + (long)t * Dd;
+    const float* src;
+    if (t == 0) src = e + ((long)b * (keep + 1)) * Dd;
+    else {
+        const int r = ids_restore[(long)b * L + t - 1];
+        src = r < keep ? e + ((long)b * (keep + 1) + 1 + r) * Dd : mask_token;
+    }
+    for (int d = threadIdx.x; d < Dd; d += 256) xr[d] = src[d] + pr[d];
+}
+
+// de[b, 0] = dxd[b, 0];  de[b, 1 + r] = dxd[b, 1 + ids_shuffle[b, r]]  (r < keep)
+__global__ __launch_bounds__(256) void decoder_assemble_bwd_kernel(const float* __restrict__ dxd, const int* __restrict__ ids_shuffle,
+                                                                   float* __restrict__ de, int L, int keep, int Dd) {
+    const int t = blockIdx.x, b = blockIdx.y;   // t in [0, keep]
+    const int srow = t == 0 ? 0 : 1 + ids_shuffle[(long)b * L + t - 1];
+    const float* s = dxd + ((long)b * (L + 1) + srow) * Dd;
+    float* o = de + ((long)b * (keep + 1) + t) * Dd;
+    for (int d = threadIdx.x; d < Dd; d += 256) o[d] = s[d];
+}
+
+// dmask_token[d] += sum over masked positions of dxd.  Threads own columns; blockIdx.y slices the
+// (b, masked-rank) list so the sum is spread over enough blocks.
+__global__ __launch_bounds__(256) void mask_token_grad_kernel(const float* __restrict__ dxd, const int* __restrict__ ids_shuffle,
+                                                              float* __restrict__ dmask, int B, int L, int keep, int Dd,
+                                                              int per_block) {
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    if (d >= Dd) return;
+    const int nm = L - keep;
+    const int i0 = blockIdx.y * per_block, i1 = min(B * nm, i0 + per_block);
+    float s = 0.f;
+    for (int i = i0; i < i1; ++i) {
+        const int b = i / nm, r = keep + i % nm;
+        const int l = ids_shuffle[(long)b * L + r];
+        s += dxd[((long)b * (L + 1) + 1 + l) * Dd + d];
+    }
+    atomicAdd(dmask + d, s);
+}
+
+}  // namespace
+
+extern "C" int vitae_random_masking(const float* noise, int* ids_shuffle, int* ids_restore, float* mask,
+                                    long long* ids_restore_i64, int B, int L, int len_keep, void* stream) {
+    if (!noise || !ids_shuffle || !ids_restore || !mask || B <= 0 || L <= 0 || len_keep < 0 || len_keep > L)
+        return VITAE_ERR_INVALID_ARG;
+    if ((size_t)L * 4 > 60000) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    hipLaunchKernelGGL(random_masking_kernel, dim3(B), dim3(256), (size_t)L * 4, (hipStream_t)stream, noise,
+                       ids_shuffle, ids_restore, mask, ids_restore_i64, L, len_keep);
+    return vitae_launch_status();
+}
+
+extern "C" int vitae_gather_patches(const float* vol, const int* ids_shuffle, float* out, int B, int C, int Lz,
+                                    int Hy, int Wx, int p, int keep, void* stream) {
+    if (!vol || !ids_shuffle || !out || B <= 0 || C <= 0 || p <= 0 || keep <= 0) return VITAE_ERR_INVALID_ARG;
+    if ((p & 3) || Lz % p || Hy % p || Wx % p || ((uintptr_t)vol & 15)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    const int g0 = Lz / p, g1 = Hy / p, g2 = Wx / p;
+    hipLaunchKernelGGL(gather_patches_kernel, dim3(keep, B), dim3(256), 0, (hipStream_t)stream, vol, ids_shuffle, out,
+                       C, Lz, Hy, Wx, p, g1, g2, g0 * g1 * g2, keep);
+    return vitae_launch_status();
+}
+
+extern "C" int vitae_encoder_assemble_fwd(const float* tok, const float* cls_token, const float* pos_embed,
+                                          const int* ids_shuffle, float* x, int B, int L, int keep, int D,
+                                          void* stream) {
+    if (!tok || !cls_token || !pos_embed || !ids_shuffle || !x || B <= 0) return VITAE_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(encoder_assemble_fwd_kernel, dim3(keep + 1, B), dim3(256), 0, (hipStream_t)stream, tok,
+                       cls_token, pos_embed, ids_shuffle, x, L, keep, D);
+    return vitae_launch_status();
+}
+
+extern "C" int vitae_encoder_assemble_bwd(const float* dx, float* dtok, float* dcls, int B, int keep, int D,
+                                          void* stream) {
+    if (!dx || !dtok || !dcls || B <= 0) return VITAE_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(encoder_assemble_bwd_kernel, dim3(keep + 1, B), dim3(256), 0, (hipStream_t)stream, dx, dtok,
+                       dcls, B, keep, D);
+    return vitae_launch_status();
+}
+
+extern "C" int vitae_decoder_assemble_fwd(const float* e, const float* mask_token, const float* dpos,
+                                          const int* ids_restore, float* xd, int B, int L, int keep, int Dd,
+                                          void* stream) {
+    if (!e || !mask_token || !dpos || !ids_restore || !xd || B <= 0) return VITAE_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(decoder_assemble_fwd_kernel, dim3(L + 1, B), dim3(256), 0, (hipStream_t)stream, e, mask_token,
+                       dpos, ids_restore, xd, L, keep, Dd);
+    return vitae_launch_status();
+}
+
+extern "C" int vitae_decoder_assemble_bwd(const float* dxd, const int* ids_shuffle, float* de, float* dmask_token,
+                                          int B, int L, int keep, int Dd, void* stream) {
+    if (!dxd || !ids_shuffle || !de || !dmask_token || B <= 0) return VITAE_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(decoder_assemble_bwd_kernel, dim3(keep + 1, B), dim3(256), 0, st, dxd, ids_shuffle, de, L, keep,
+                       Dd);
+    const int total = B * (L - keep);
+    if (total > 0) {
+        const int per_block = 32;
+        hipLaunchKernelGGL(mask_token_grad_kernel, dim3(cdiv(Dd, 256), cdiv(total, per_block)), dim3(256), 0, st, dxd,
+                           ids_shuffle, dmask_token, B, L, keep, Dd, per_block);
+    }
+    return vitae_launch_status();
+}

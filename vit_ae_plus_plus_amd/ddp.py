@@ -1,0 +1,90 @@
+"""Data-parallel gradient exchange: one process per GPU, bucketed all-reduce over RCCL / xGMI.
+
+The reference's pre-training scripts never wrap the model in DDP (only scalar metric
+all-reduces exist on that path, utils/misc.py:332-340), so this is new functionality with the
+standard DDP contract: after the exchange every rank holds the MEAN of the per-rank gradients.
+
+Design for MI355X: the gradient arena of ``HipMAEEngine`` is laid out in forward order, and the
+hand-ordered backward finishes it in three contiguous ranges (decoder+predictor, upper encoder half,
+lower encoder half + patch embedding).  Each range is one bucket (tens to hundreds of MB — large
+messages, since xGMI rings are per-link bound): its all-reduce is issued asynchronously the moment
+the backward phase that completes it has been enqueued, so RCCL runs on its own stream underneath
+the remaining backward kernels; the small token/vector segment goes last.  The 1/world_size of the
+mean is folded into the loss-gradient multipliers up front (``HipMAEEngine.set_loss_weights``), so
+a SUM all-reduce yields the mean with no extra pass over the 0.5 GB arena.
+The reducer only needs a flat tensor and ranges, so it is exercised on CPU with gloo in tests.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def is_distributed() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+class GradBucketReducer:
+    """Asynchronous SUM all-reduce of contiguous ranges of one flat gradient tensor."""
+
+    def __init__(self, flat: torch.Tensor, ranges: Sequence[Tuple[int, int]], group=None,
+                 max_bucket_elems: Optional[int] = None):
+        assert flat.dim() == 1
+        self.flat, self.group = flat, group
+        self.ranges: List[List[Tuple[int, int]]] = []
+        for s, e in ranges:
+            assert 0 <= s <= e <= flat.numel()
+            parts = []
+            if max_bucket_elems and e - s > max_bucket_elems:
+                k = s
+                while k < e:
+                    parts.append((k, min(e, k + max_bucket_elems)))
+                    k += max_bucket_elems
+            else:
+                parts.append((s, e))
+            self.ranges.append(parts)
+        self.pending = []
+
+    @property
+    def world_size(self) -> int:
+        return dist.get_world_size(self.group) if is_distributed() else 1
+
+    def launch(self, bucket: int):
+        """Issue the all-reduce of bucket ``bucket`` (non-blocking; ordered after work already enqueued
+        on the current stream)."""
+        if self.world_size == 1:
+            return
+        for s, e in self.ranges[bucket]:
+            if e > s:
+                self.pending.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group,
+                                                    async_op=True))
+
+    def wait(self):
+        """Make the current stream (or the host, for CPU backends) wait for every launched bucket."""
+        for w in self.pending:
+            w.wait()
+        self.pending.clear()
+
+
+def engine_bucket_ranges(engine) -> List[Tuple[int, int]]:
+    """[decoder+predictor matrices, upper-half encoder matrices, lower half + patch embedding,
+    tokens+vectors] as element ranges of ``engine.grads`` — the completion order of
+    ``HipMAEEngine.backward``'s phases."""
+    lay = engine.layout
+    cfg = engine.cfg
+    mid = cfg.depth // 2
+    dec0 = lay['decoder_embed.weight'][0]
+    hi0 = lay[f'blocks.{mid}.attn.qkv.weight'][0] if cfg.depth > 1 else lay['blocks.0.attn.qkv.weight'][0]
+    return [(dec0, engine.tok_off), (hi0, dec0), (0, hi0), (engine.tok_off, engine.n_total)]
+
+
+def broadcast_parameters(engine, src: int = 0, group=None):
+    """Start from identical replicas (what DistributedDataParallel does at construction)."""
+    if not is_distributed():
+        return
+    dist.broadcast(engine.params, src=src, group=group)
+    for k, t in engine.buffers.items():
+        if k.startswith('predictor.1.'):
+            dist.broadcast(t, src=src, group=group)

@@ -1,0 +1,579 @@
+"""Host-side sequencing of the HIP hot path: one flat parameter arena, one activation workspace,
+and hand-ordered forward / backward / optimiser launch lists on a single HIP stream.
+
+This replaces what autograd + ATen do for the reference (``ContrastiveMAEViT.forward``,
+model/vit_autoenc.py:270-285, driven by ``train_one_stage_epoch``, utils/train_one_epoch.py:21-110):
+every arithmetic step is a kernel of ``libvitae_hip.so`` called through the C ABI
+(``include/vitae_hip.h``); torch only owns the device memory and the stream.  Nothing here allocates
+after ``_alloc`` or synchronises, so a whole optimisation step can be captured in a HIP graph
+(``capture_train_step``) and replayed; lr / loss weights reach the kernels through the device-resident
+``hp`` block.
+
+Design points that differ from the reference on purpose (same numbers, less work):
+  * the two encoder passes of the contrastive model (vit_autoenc.py:272,277) run as ONE pass over the
+    2B concatenated samples (rows of every op are per-sample independent; BatchNorm of the predictor
+    is still applied per view, :280-284);
+  * the patch embedding is computed for the kept 25 % of the patches only (masking is decided first);
+  * weight gradients of matrices are written with beta=0 on the first micro-step, so only the small
+    vector/token segment of the gradient arena needs zeroing.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from ._abi import CONSTS, VitaeError, lib
+
+_C = CONSTS
+EPI_NONE, EPI_GELU, EPI_DGELU, EPI_RELU = (_C['VITAE_EPI_NONE'], _C['VITAE_EPI_GELU'], _C['VITAE_EPI_DGELU'],
+                                           _C['VITAE_EPI_RELU_MASK'])
+HP = {k[len('VITAE_HP_'):]: v for k, v in _C.items() if k.startswith('VITAE_HP_')}
+PREC = {'fp32': _C['VITAE_PREC_F32'], 'bf16': _C['VITAE_PREC_BF16']}
+
+
+def _triple(v):
+    if isinstance(v, (tuple, list)):
+        assert len(v) == 3
+        return tuple(int(i) for i in v)
+    return (int(v),) * 3
+
+
+@dataclass
+class MAEConfig:
+    """Constructor arguments of the reference model classes (model/vit_autoenc.py:18-21,242-245)."""
+    volume_size: Tuple[int, int, int] = (96, 96, 96)
+    patch_size: int = 16
+    in_chans: int = 4
+    embed_dim: int = 768
+    depth: int = 12
+    num_heads: int = 12
+    decoder_embed_dim: int = 512
+    decoder_depth: int = 8
+    decoder_num_heads: int = 16
+    mlp_ratio: float = 4.0
+    contrastive: bool = False
+    ln_eps: float = 1e-6
+
+    def __post_init__(self):
+        self.volume_size = _triple(self.volume_size)
+        self.patch_size = int(self.patch_size if not isinstance(self.patch_size, (tuple, list)) else self.patch_size[0])
+
+    @property
+    def grid(self):
+        p = self.patch_size
+        return tuple(v // p for v in self.volume_size)
+
+    @property
+    def num_patches(self):
+        g = self.grid
+        return g[0] * g[1] * g[2]
+
+    @property
+    def patch_dim(self):
+        return self.patch_size ** 3 * self.in_chans
+
+    def len_keep(self, mask_ratio):
+        return int(self.num_patches * (1 - mask_ratio))
+
+
+def gaussian_taps_host(sigma: float = 2.0) -> np.ndarray:
+    """1-D taps of model/model_utils/gaussian_filter.py:5-13 (ks = int(5*sigma) made odd, samples at
+    linspace(-ks//2, ks//2+1, ks)), normalised in float64 so that k (x) k (x) k equals the reference's
+    renormalised dense kernel (gaussian_filter.py:22-23) to fp32 round-off."""
+    ks = int(sigma * 5)
+    if ks % 2 == 0:
+        ks += 1
+    ts = np.linspace(float(-ks // 2), float(ks // 2 + 1), ks, dtype=np.float64)
+    g = np.exp(-(ts / sigma) ** 2 / 2)
+    return (g / g.sum()).astype(np.float32)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+class HipMAEEngine:
+    """Owns arenas + workspace for one model instance on one GPU and sequences the kernels."""
+
+    def __init__(self, cfg: MAEConfig, params: "OrderedDict[str, torch.Tensor]",
+                 buffers: Dict[str, torch.Tensor], device: torch.device, precision: str = 'fp32'):
+        if device.type != 'cuda':
+            raise VitaeError('HipMAEEngine needs a ROCm device: the hot path is HIP-only (no CPU fallback)')
+        lib.load()
+        self.cfg, self.device = cfg, device
+        self.prec = PREC[precision]
+        self.precision = precision
+        D, Dd = cfg.embed_dim, cfg.decoder_embed_dim
+        if D % cfg.num_heads or Dd % cfg.decoder_num_heads:
+            raise VitaeError('embed dims must be divisible by the head counts')
+        self.hd, self.hdd = D // cfg.num_heads, Dd // cfg.decoder_num_heads
+        self.Hm, self.Hmd = int(D * cfg.mlp_ratio), int(Dd * cfg.mlp_ratio)
+        if cfg.patch_size % 4:
+            raise VitaeError('patch_size must be a multiple of 4 (16-byte gathers)')
+        self._build_arena(params)
+        self.buffers = buffers   # pos_embed, decoder_pos_embed, BN running stats (device tensors)
+        f32 = dict(dtype=torch.float32, device=device)
+        # ring of pinned staging buffers: the host may run a few steps ahead of the stream, so the
+        # buffer an in-flight async copy reads from must not be rewritten by the next step
+        self.hp_vals = [0.0] * _C['VITAE_HP_COUNT']
+        self.hp_ring = [torch.zeros(_C['VITAE_HP_COUNT'], dtype=torch.float32).pin_memory() for _ in range(16)]
+        self.hp_slot = 0
+        self.hp = torch.zeros(_C['VITAE_HP_COUNT'], **f32)
+        self.acc = torch.zeros(_C['VITAE_ACC_COUNT'], dtype=torch.float64, device=device)
+        self.losses = torch.zeros(8, **f32)   # [loss, raw_edge, recon, percep, contr, grad_norm, -, -]
+        self.taps = gaussian_taps_host(2.0)
+        self._taps_c = self.taps.ctypes.data
+        self.ws = torch.empty(1 << 24, **f32)   # split-K scratch (64 MiB)
+        self.B = None
+        self.buf: Dict[str, torch.Tensor] = {}
+        self.opt_state = None
+        self.opt_step = 0
+        self._accum = False
+        self._split_cache: Dict[Tuple[int, int, int], int] = {}
+        self.stream = 0
+        self.gemm_timer = None   # bench.py: list collecting (start_event, end_event, flops) per GEMM launch
+        self.set_hparams(lr=0.0, beta1=0.9, beta2=0.95, eps=1e-8, bc1=1.0, bc2=1.0, grad_mul=1.0, g_recon=1.0,
+                         g_edge=0.0, g_contr=0.0, edge_w=0.0, contr_w=0.0)
+
+    # ------------------------------------------------------------------ arenas
+    def _build_arena(self, params: "OrderedDict[str, torch.Tensor]"):
+        """Flat fp32 arena: [matrices | cls/mask tokens | vectors]; every tensor 16-byte aligned.
+        AdamW decays the first two segments (timm add_weight_decay: no decay iff ndim == 1 or
+        name.endswith('.bias')); the last two are the atomically-accumulated gradients that are
+        zeroed every step."""
+        mats, toks, vecs = [], [], []
+        for n, p in params.items():
+            if p.ndim <= 1 or n.endswith('.bias'):
+                vecs.append(n)
+            elif n in ('cls_token', 'mask_token'):
+                toks.append(n)
+            else:
+                mats.append(n)
+        self.layout: "OrderedDict[str, Tuple[int, Tuple[int, ...]]]" = OrderedDict()
+        off = 0
+        for n in mats + toks + vecs:
+            if n == (toks[0] if toks else None):
+                self.tok_off = off
+            if n == (vecs[0] if vecs else None):
+                self.vec_off = off
+            shp = tuple(params[n].shape)
+            self.layout[n] = (off, shp)
+            off += (int(np.prod(shp)) + 3) // 4 * 4
+        if not toks:
+            self.tok_off = self.vec_off
+        self.n_total = off
+        dev = self.device
+        self.params = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.p: Dict[str, torch.Tensor] = {}
+        self.g: Dict[str, torch.Tensor] = {}
+        for n, (o, shp) in self.layout.items():
+            k = int(np.prod(shp))
+            self.p[n] = self.params[o:o + k].view(shp)
+            self.g[n] = self.grads[o:o + k].view(shp)
+            self.p[n].copy_(params[n].detach().to(device=dev, dtype=torch.float32))
+
+    # ------------------------------------------------------------------ hyper-parameters
+    def set_hparams(self, **kw):
+        for k, v in kw.items():
+            self.hp_vals[HP[k.upper()]] = float(v)
+        host = self.hp_ring[self.hp_slot % len(self.hp_ring)]
+        self.hp_slot += 1
+        host.copy_(torch.tensor(self.hp_vals, dtype=torch.float32))
+        self.hp.copy_(host, non_blocking=True)
+
+    # ------------------------------------------------------------------ workspace
+    def _alloc(self, B: int, mask_ratio: float):
+        cfg = self.cfg
+        keep = cfg.len_keep(mask_ratio)
+        if keep <= 0 or keep >= cfg.num_patches:
+            raise VitaeError(f'mask_ratio {mask_ratio} leaves {keep} of {cfg.num_patches} patches')
+        if self.B == B and self.keep == keep:
+            return
+        self.B, self.keep = B, keep
+        self.Be = 2 * B if cfg.contrastive else B
+        L, P, D, Dd = cfg.num_patches, cfg.patch_dim, cfg.embed_dim, cfg.decoder_embed_dim
+        Ne, Nd, Be = keep + 1, L + 1, self.Be
+        Me, Md = Be * Ne, B * Nd
+        self.Ne, self.Nd, self.Me, self.Md = Ne, Nd, Me, Md
+        dev = self.device
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        b = self.buf = {}
+        V = cfg.volume_size[0] * cfg.volume_size[1] * cfg.volume_size[2]
+        b['noise'] = f(Be, L)
+        b['ids_shuffle'] = torch.empty(Be, L, dtype=torch.int32, device=dev)
+        b['ids_restore'] = torch.empty(Be, L, dtype=torch.int32, device=dev)
+        b['ids_restore64'] = torch.empty(Be, L, dtype=torch.int64, device=dev)
+        b['mask'] = f(Be, L)
+        b['patches'] = f(Be * keep, P)
+        b['tok'] = f(Be * keep, D)
+        b['dtok'] = f(Be * keep, D)
+
+        def stack(pre, depth, M, d, h):
+            b[pre + 'x'] = [f(M, d) for _ in range(depth + 1)]
+            for i in range(depth):
+                q = f'{pre}{i}.'
+                b[q + 'y1'], b[q + 'mean1'], b[q + 'rstd1'] = f(M, d), f(M), f(M)
+                b[q + 'qkv'], b[q + 'o'] = f(M, 3 * d), f(M, d)
+                b[q + 'xmid'], b[q + 'y2'], b[q + 'mean2'], b[q + 'rstd2'] = f(M, d), f(M, d), f(M), f(M)
+                b[q + 'hpre'], b[q + 'act'] = f(M, h), f(M, h)
+            b[pre + 'dx'], b[pre + 'dy'], b[pre + 'do'] = f(M, d), f(M, d), f(M, d)
+            b[pre + 'dh'], b[pre + 'dqkv'] = f(M, h), f(M, 3 * d)
+
+        stack('enc', cfg.depth, Me, D, self.Hm)
+        stack('dec', cfg.decoder_depth, Md, Dd, self.Hmd)
+        for i in range(cfg.depth):
+            b[f'enc{i}.lse'] = f(Be * cfg.num_heads * Ne)
+        for i in range(cfg.decoder_depth):
+            b[f'dec{i}.lse'] = f(B * cfg.decoder_num_heads * Nd)
+        b['delta'] = f(max(Be * cfg.num_heads * Ne, B * cfg.decoder_num_heads * Nd))
+        b['latent'], b['lat_mean'], b['lat_rstd'], b['dlatent'] = f(Me, D), f(Me), f(Me), f(Me, D)
+        b['e'], b['de'] = f(B * Ne, Dd), f(B * Ne, Dd)
+        b['dn'], b['dn_mean'], b['dn_rstd'], b['ddn'] = f(Md, Dd), f(Md), f(Md), f(Md, Dd)
+        b['predfull'] = f(B, Nd, P)
+        b['dpredfull'] = torch.zeros(B, Nd, P, dtype=torch.float32, device=dev)   # cls rows stay zero
+        b['pred_vol'] = f(B, cfg.in_chans, *cfg.volume_size)
+        b['blur_tmp'], b['blurred'] = f(B * cfg.in_chans * V), f(B * cfg.in_chans * V)
+        b['edge_t'], b['edge_p'] = f(B * V), f(B * V)
+        b['dG'] = f(B * cfg.in_chans * 3 * V)
+        if cfg.contrastive:
+            R = B * Ne
+            self.R = R
+            b['ph'], b['pr'], b['pout'] = f(2 * R, D), f(2 * R, D), f(2 * R, D)
+            b['bn_mean'], b['bn_rstd'] = f(2, D), f(2, D)
+            b['dp'], b['dpr'], b['dph'] = f(2 * R, D), f(2 * R, D), f(2 * R, D)
+        self.mask_sum = float(B * (L - keep))
+        self.edge_count = B * V
+
+    # ------------------------------------------------------------------ thin launch helpers
+    def _split(self, M, N, K):
+        key = (M, N, K)
+        s = self._split_cache.get(key)
+        if s is None:
+            s = lib.vitae_gemm_pick_split_k(M, N, K)
+            while s > 1 and s * M * N > self.ws.numel():
+                s -= 1
+            self._split_cache[key] = s
+        return s
+
+    def _timed(self, flops):
+        if self.gemm_timer is None:
+            return None
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.gemm_timer.append((a, b, flops))
+        a.record()
+        return b
+
+    def _lin_fwd(self, x, w, bias, y, M, N, K, epi=EPI_NONE, aux=None, res=None):
+        s = 1 if epi == EPI_GELU else self._split(M, N, K)
+        t = self._timed(2.0 * M * N * K)
+        lib.vitae_linear_fwd(self.prec, _ptr(x), _ptr(w), _ptr(bias), _ptr(y), M, N, K, epi, _ptr(aux), _ptr(res), s,
+                             self.ws.data_ptr(), self.stream)
+        if t is not None:
+            t.record()
+
+    def _lin_bwd_x(self, dy, w, dx, M, N, K, epi=EPI_NONE, aux=None, accumulate=0):
+        s = self._split(M, K, N)
+        t = self._timed(2.0 * M * N * K)
+        lib.vitae_linear_bwd_input(self.prec, _ptr(dy), _ptr(w), _ptr(dx), M, N, K, epi, _ptr(aux), accumulate, s,
+                                   self.ws.data_ptr(), self.stream)
+        if t is not None:
+            t.record()
+
+    def _lin_bwd_w(self, dy, x, dw, db, M, N, K):
+        s = self._split(N, K, M)
+        t = self._timed(2.0 * M * N * K)
+        lib.vitae_linear_bwd_weight(self.prec, _ptr(dy), _ptr(x), _ptr(dw), M, N, K, int(self._accum), s,
+                                    self.ws.data_ptr(), self.stream)
+        if t is not None:
+            t.record()
+        if db is not None:
+            lib.vitae_colsum_accum(_ptr(dy), N, _ptr(db), M, N, self.stream)
+
+    def _ln_fwd(self, x, pre, y, mean, rstd, M, D):
+        lib.vitae_layernorm_fwd(_ptr(x), _ptr(self.p[pre + 'weight']), _ptr(self.p[pre + 'bias']), _ptr(y), _ptr(mean),
+                                _ptr(rstd), M, D, self.cfg.ln_eps, self.stream)
+
+    def _ln_bwd(self, dy, x, pre, mean, rstd, dx, M, D, dx_accumulate):
+        lib.vitae_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(self.p[pre + 'weight']), _ptr(mean), _ptr(rstd), _ptr(dx),
+                                _ptr(self.g[pre + 'weight']), _ptr(self.g[pre + 'bias']), M, D, dx_accumulate,
+                                self.stream)
+
+    # ------------------------------------------------------------------ transformer block
+    def _block_fwd(self, pre, q, x_in, x_out, Bs, N, d, heads, hd, hid):
+        """model/vit.py:139-144.  pre = state-dict prefix, q = workspace prefix."""
+        b, p, M = self.buf, self.p, Bs * N
+        self._ln_fwd(x_in, pre + 'norm1.', b[q + 'y1'], b[q + 'mean1'], b[q + 'rstd1'], M, d)
+        self._lin_fwd(b[q + 'y1'], p[pre + 'attn.qkv.weight'], p[pre + 'attn.qkv.bias'], b[q + 'qkv'], M, 3 * d, d)
+        lib.vitae_sdpa_fwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(b[q + 'lse']), Bs, N, heads, hd, self.stream)
+        self._lin_fwd(b[q + 'o'], p[pre + 'attn.proj.weight'], p[pre + 'attn.proj.bias'], b[q + 'xmid'], M, d, d,
+                      res=x_in)
+        self._ln_fwd(b[q + 'xmid'], pre + 'norm2.', b[q + 'y2'], b[q + 'mean2'], b[q + 'rstd2'], M, d)
+        self._lin_fwd(b[q + 'y2'], p[pre + 'mlp.fc1.weight'], p[pre + 'mlp.fc1.bias'], b[q + 'act'], M, hid, d,
+                      epi=EPI_GELU, aux=b[q + 'hpre'])
+        self._lin_fwd(b[q + 'act'], p[pre + 'mlp.fc2.weight'], p[pre + 'mlp.fc2.bias'], x_out, M, d, hid,
+                      res=b[q + 'xmid'])
+
+    def _block_bwd(self, pre, q, s, x_in, Bs, N, d, heads, hd, hid):
+        """Backward of one block; the running gradient lives in buf[s+'dx'] and is updated in place."""
+        b, p, g, M = self.buf, self.p, self.g, Bs * N
+        dx, dh, dy, do, dqkv = b[s + 'dx'], b[s + 'dh'], b[s + 'dy'], b[s + 'do'], b[s + 'dqkv']
+        # mlp.fc2
+        self._lin_bwd_w(dx, b[q + 'act'], g[pre + 'mlp.fc2.weight'], g[pre + 'mlp.fc2.bias'], M, d, hid)
+        self._lin_bwd_x(dx, p[pre + 'mlp.fc2.weight'], dh, M, d, hid, epi=EPI_DGELU, aux=b[q + 'hpre'])
+        # mlp.fc1
+        self._lin_bwd_w(dh, b[q + 'y2'], g[pre + 'mlp.fc1.weight'], g[pre + 'mlp.fc1.bias'], M, hid, d)
+        self._lin_bwd_x(dh, p[pre + 'mlp.fc1.weight'], dy, M, hid, d)
+        self._ln_bwd(dy, b[q + 'xmid'], pre + 'norm2.', b[q + 'mean2'], b[q + 'rstd2'], dx, M, d, 1)
+        # attn.proj
+        self._lin_bwd_w(dx, b[q + 'o'], g[pre + 'attn.proj.weight'], g[pre + 'attn.proj.bias'], M, d, d)
+        self._lin_bwd_x(dx, p[pre + 'attn.proj.weight'], do, M, d, d)
+        lib.vitae_sdpa_bwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(do), _ptr(b[q + 'lse']), _ptr(dqkv),
+                           _ptr(b['delta']), Bs, N, heads, hd, self.stream)
+        # attn.qkv
+        self._lin_bwd_w(dqkv, b[q + 'y1'], g[pre + 'attn.qkv.weight'], g[pre + 'attn.qkv.bias'], M, 3 * d, d)
+        self._lin_bwd_x(dqkv, p[pre + 'attn.qkv.weight'], dy, M, 3 * d, d)
+        self._ln_bwd(dy, x_in, pre + 'norm1.', b[q + 'mean1'], b[q + 'rstd1'], dx, M, d, 1)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, view1: torch.Tensor, view2: Optional[torch.Tensor], noise: torch.Tensor, mask_ratio: float,
+                training: bool = True):
+        """Everything up to the four loss scalars and (contrastive) p1/p2.  ``noise`` is [Be, L]
+        (view-1 rows first), the torch.rand of vit_autoenc.py:139."""
+        cfg = self.cfg
+        B = view1.shape[0]
+        self._alloc(B, mask_ratio)
+        self.stream = torch.cuda.current_stream(self.device).cuda_stream
+        st, b, p = self.stream, self.buf, self.p
+        Be, keep, L, D, Dd, P = self.Be, self.keep, cfg.num_patches, cfg.embed_dim, cfg.decoder_embed_dim, cfg.patch_dim
+        Ne, Nd, Me, Md = self.Ne, self.Nd, self.Me, self.Md
+        C, (Lz, Hy, Wx), ps = cfg.in_chans, cfg.volume_size, cfg.patch_size
+        for v in (view1, view2):
+            if v is not None and (v.dtype != torch.float32 or not v.is_contiguous() or v.device != self.device
+                                  or tuple(v.shape) != (B, C, Lz, Hy, Wx)):
+                raise VitaeError(f'volumes must be contiguous fp32 [B,{C},{Lz},{Hy},{Wx}] on {self.device}')
+        if cfg.contrastive and view2 is None:
+            raise VitaeError('contrastive model needs view2')
+        if tuple(noise.shape) != (Be, L) or noise.dtype != torch.float32 or not noise.is_contiguous():
+            raise VitaeError(f'noise must be contiguous fp32 [{Be},{L}]')
+        self.view1 = view1
+        lib.vitae_memset_zero(self.acc.data_ptr(), self.acc.numel() * 8, st)
+        # --- masking, kept-patch gather, patch embedding, sequence assembly
+        lib.vitae_random_masking(_ptr(noise), _ptr(b['ids_shuffle']), _ptr(b['ids_restore']), _ptr(b['mask']),
+                                 _ptr(b['ids_restore64']), Be, L, keep, st)
+        lib.vitae_gather_patches(_ptr(view1), _ptr(b['ids_shuffle']), _ptr(b['patches']), B, C, Lz, Hy, Wx, ps, keep, st)
+        if cfg.contrastive:
+            lib.vitae_gather_patches(_ptr(view2), b['ids_shuffle'].data_ptr() + B * L * 4,
+                                     b['patches'].data_ptr() + B * keep * P * 4, B, C, Lz, Hy, Wx, ps, keep, st)
+        self._lin_fwd(b['patches'], p['patch_embed.proj.weight'], p['patch_embed.proj.bias'], b['tok'], Be * keep, D, P)
+        ex = b['encx']
+        lib.vitae_encoder_assemble_fwd(_ptr(b['tok']), _ptr(p['cls_token']), _ptr(self.buffers['pos_embed']),
+                                       _ptr(b['ids_shuffle']), _ptr(ex[0]), Be, L, keep, D, st)
+        for i in range(cfg.depth):
+            self._block_fwd(f'blocks.{i}.', f'enc{i}.', ex[i], ex[i + 1], Be, Ne, D, cfg.num_heads, self.hd, self.Hm)
+        self._ln_fwd(ex[cfg.depth], 'norm.', b['latent'], b['lat_mean'], b['lat_rstd'], Me, D)
+        # --- decoder (view 1 only)
+        self._lin_fwd(b['latent'], p['decoder_embed.weight'], p['decoder_embed.bias'], b['e'], B * Ne, Dd, D)
+        dx_ = b['decx']
+        lib.vitae_decoder_assemble_fwd(_ptr(b['e']), _ptr(p['mask_token']), _ptr(self.buffers['decoder_pos_embed']),
+                                       _ptr(b['ids_restore']), _ptr(dx_[0]), B, L, keep, Dd, st)
+        for i in range(cfg.decoder_depth):
+            self._block_fwd(f'decoder_blocks.{i}.', f'dec{i}.', dx_[i], dx_[i + 1], B, Nd, Dd, cfg.decoder_num_heads,
+                            self.hdd, self.Hmd)
+        self._ln_fwd(dx_[cfg.decoder_depth], 'decoder_norm.', b['dn'], b['dn_mean'], b['dn_rstd'], Md, Dd)
+        self._lin_fwd(b['dn'], p['decoder_pred.weight'], p['decoder_pred.bias'], b['predfull'], Md, P, Dd)
+        # --- loss chain on pred = predfull[:, 1:, :]
+        pred_ptr, pbs = b['predfull'].data_ptr() + P * 4, Nd * P
+        lib.vitae_recon_loss_fwd(pred_ptr, pbs, _ptr(view1), _ptr(b['mask']), _ptr(self.acc), B, C, Lz, Hy, Wx, ps, st)
+        lib.vitae_unpatchify(pred_ptr, pbs, _ptr(b['pred_vol']), B, C, Lz, Hy, Wx, ps, st)
+        lib.vitae_gauss_blur_fwd(_ptr(view1), _ptr(b['blur_tmp']), _ptr(b['blurred']), self._taps_c, len(self.taps),
+                                 B * C, Lz, Hy, Wx, st)
+        lib.vitae_sobel_edge_fwd(_ptr(b['blurred']), _ptr(b['edge_t']), None, None, B, C, Lz, Hy, Wx, st)
+        lib.vitae_sobel_edge_fwd(_ptr(b['pred_vol']), _ptr(b['edge_p']), _ptr(b['edge_t']), _ptr(self.acc), B, C, Lz, Hy,
+                                 Wx, st)
+        lib.vitae_loss_finalize(_ptr(self.acc), _ptr(self.hp), _ptr(self.losses), self.mask_sum, self.edge_count, st)
+        # --- predictor on both views (vit_autoenc.py:280-284)
+        if cfg.contrastive:
+            R = self.R
+            self._lin_fwd(b['latent'], p['predictor.0.weight'], None, b['ph'], 2 * R, D, D)
+            for v in range(2):
+                o = v * R * D * 4
+                lib.vitae_bn1d_relu_fwd(b['ph'].data_ptr() + o, _ptr(p['predictor.1.weight']), _ptr(p['predictor.1.bias']),
+                                        b['pr'].data_ptr() + o, b['bn_mean'].data_ptr() + v * D * 4,
+                                        b['bn_rstd'].data_ptr() + v * D * 4,
+                                        _ptr(self.buffers['predictor.1.running_mean']) if training else None,
+                                        _ptr(self.buffers['predictor.1.running_var']) if training else None,
+                                        _ptr(self.buffers['predictor.1.num_batches_tracked']) if training else None,
+                                        R, D, 1e-5, 0.1, st)
+            self._lin_fwd(b['pr'], p['predictor.3.weight'], p['predictor.3.bias'], b['pout'], 2 * R, D, D)
+
+    def contrastive_loss_fwd(self):
+        """utils/train_one_epoch.py:113-114 on (p1, z2), (p2, z1); result -> losses[4]."""
+        b, R, D = self.buf, self.R, self.cfg.embed_dim
+        o = R * D * 4
+        p1, p2, z1, z2 = b['pout'].data_ptr(), b['pout'].data_ptr() + o, b['latent'].data_ptr(), b['latent'].data_ptr() + o
+        lib.vitae_cosine_loss_fwd(p1, z2, p2, z1, _ptr(self.acc), _ptr(self.hp), self.losses.data_ptr() + 16, R, D,
+                                  self.stream)
+
+    def contrastive_loss_bwd(self):
+        b, R, D = self.buf, self.R, self.cfg.embed_dim
+        o = R * D * 4
+        p1, p2, z1, z2 = b['pout'].data_ptr(), b['pout'].data_ptr() + o, b['latent'].data_ptr(), b['latent'].data_ptr() + o
+        lib.vitae_cosine_loss_bwd(p1, z2, p2, z1, _ptr(self.hp), b['dp'].data_ptr(), b['dp'].data_ptr() + o, R, D,
+                                  self.stream)
+
+    # ------------------------------------------------------------------ backward
+    def begin_grad_window(self, accumulate: bool):
+        """accumulate=False: first micro-step after zero_grad (matrix grads written with beta=0)."""
+        self._accum = bool(accumulate)
+        if not accumulate:
+            n = self.n_total - self.tok_off
+            lib.vitae_memset_zero(self.grads.data_ptr() + self.tok_off * 4, n * 4,
+                                  torch.cuda.current_stream(self.device).cuda_stream)
+
+    def backward(self, have_dp: bool):
+        """Reverse sweep.  hp[G_RECON], hp[G_EDGE] hold d total/d recon, d total/d raw_edge; when
+        ``have_dp`` buf['dp'] holds d total / d [p1; p2].  Three phases; after phase k the gradient
+        range ``ddp.engine_bucket_ranges(self)[k]`` is final (bucket k may be all-reduced)."""
+        mid = self.cfg.depth // 2
+        self.backward_dec(have_dp)
+        self.backward_enc(self.cfg.depth - 1, mid)
+        self.backward_enc(mid - 1, 0)
+        self.backward_tail()
+
+    def backward_dec(self, have_dp: bool):
+        """loss chain, decoder, predictor, final encoder norm."""
+        cfg = self.cfg
+        self.stream = torch.cuda.current_stream(self.device).cuda_stream
+        st, b, p, g = self.stream, self.buf, self.p, self.g
+        B, Be, keep, L, D, Dd, P = self.B, self.Be, self.keep, cfg.num_patches, cfg.embed_dim, cfg.decoder_embed_dim, cfg.patch_dim
+        Ne, Nd, Me, Md = self.Ne, self.Nd, self.Me, self.Md
+        C, (Lz, Hy, Wx), ps = cfg.in_chans, cfg.volume_size, cfg.patch_size
+        view1 = self.view1
+        pred_ptr, dpred_ptr, pbs = b['predfull'].data_ptr() + P * 4, b['dpredfull'].data_ptr() + P * 4, Nd * P
+        lib.vitae_recon_loss_bwd(pred_ptr, pbs, _ptr(view1), _ptr(b['mask']), _ptr(self.hp), dpred_ptr, self.mask_sum, B, C,
+                                 Lz, Hy, Wx, ps, st)
+        lib.vitae_sobel_edge_bwd(_ptr(b['pred_vol']), _ptr(b['edge_p']), _ptr(b['edge_t']), _ptr(self.hp), _ptr(b['dG']),
+                                 dpred_ptr, pbs, B, C, Lz, Hy, Wx, ps, st)
+        # decoder_pred, decoder_norm
+        self._lin_bwd_w(b['dpredfull'], b['dn'], g['decoder_pred.weight'], g['decoder_pred.bias'], Md, P, Dd)
+        self._lin_bwd_x(b['dpredfull'], p['decoder_pred.weight'], b['ddn'], Md, P, Dd)
+        dx_ = b['decx']
+        self._ln_bwd(b['ddn'], dx_[cfg.decoder_depth], 'decoder_norm.', b['dn_mean'], b['dn_rstd'], b['decdx'], Md, Dd, 0)
+        for i in reversed(range(cfg.decoder_depth)):
+            self._block_bwd(f'decoder_blocks.{i}.', f'dec{i}.', 'dec', dx_[i], B, Nd, Dd, cfg.decoder_num_heads, self.hdd,
+                            self.Hmd)
+        lib.vitae_decoder_assemble_bwd(_ptr(b['decdx']), _ptr(b['ids_shuffle']), _ptr(b['de']), _ptr(g['mask_token']), B, L,
+                                       keep, Dd, st)
+        self._lin_bwd_w(b['de'], b['latent'], g['decoder_embed.weight'], g['decoder_embed.bias'], B * Ne, Dd, D)
+        # predictor (both views) -> dlatent ; then decoder_embed adds into the view-1 rows
+        if cfg.contrastive and have_dp:
+            R = self.R
+            self._lin_bwd_w(b['dp'], b['pr'], g['predictor.3.weight'], g['predictor.3.bias'], 2 * R, D, D)
+            self._lin_bwd_x(b['dp'], p['predictor.3.weight'], b['dpr'], 2 * R, D, D)
+            for v in range(2):
+                o = v * R * D * 4
+                lib.vitae_bn1d_relu_bwd(b['dpr'].data_ptr() + o, b['ph'].data_ptr() + o, b['pr'].data_ptr() + o,
+                                        _ptr(p['predictor.1.weight']), b['bn_mean'].data_ptr() + v * D * 4,
+                                        b['bn_rstd'].data_ptr() + v * D * 4, b['dph'].data_ptr() + o,
+                                        _ptr(g['predictor.1.weight']), _ptr(g['predictor.1.bias']), R, D, st)
+            self._lin_bwd_w(b['dph'], b['latent'], g['predictor.0.weight'], None, 2 * R, D, D)
+            self._lin_bwd_x(b['dph'], p['predictor.0.weight'], b['dlatent'], 2 * R, D, D)
+            self._lin_bwd_x(b['de'], p['decoder_embed.weight'], b['dlatent'], B * Ne, Dd, D, accumulate=1)
+        else:
+            if cfg.contrastive:   # predictor unused this step: its matrices get exact zeros
+                for n in ('predictor.0.weight', 'predictor.3.weight'):
+                    if not self._accum:
+                        lib.vitae_memset_zero(g[n].data_ptr(), g[n].numel() * 4, st)
+            if Be != B:
+                lib.vitae_memset_zero(b['dlatent'].data_ptr(), b['dlatent'].numel() * 4, st)
+            self._lin_bwd_x(b['de'], p['decoder_embed.weight'], b['dlatent'], B * Ne, Dd, D)
+        self._ln_bwd(b['dlatent'], b['encx'][cfg.depth], 'norm.', b['lat_mean'], b['lat_rstd'], b['encdx'], Me, D, 0)
+
+    def backward_enc(self, hi: int, lo: int):
+        """encoder blocks hi, hi-1, ..., lo."""
+        cfg = self.cfg
+        self.stream = torch.cuda.current_stream(self.device).cuda_stream
+        ex = self.buf['encx']
+        for i in range(hi, lo - 1, -1):
+            self._block_bwd(f'blocks.{i}.', f'enc{i}.', 'enc', ex[i], self.Be, self.Ne, cfg.embed_dim, cfg.num_heads,
+                            self.hd, self.Hm)
+
+    def backward_tail(self):
+        """sequence assembly and patch-embedding weight gradient (the input is data: no dgrad)."""
+        cfg = self.cfg
+        self.stream = torch.cuda.current_stream(self.device).cuda_stream
+        b, g = self.buf, self.g
+        lib.vitae_encoder_assemble_bwd(_ptr(b['encdx']), _ptr(b['dtok']), _ptr(g['cls_token']), self.Be, self.keep,
+                                       cfg.embed_dim, self.stream)
+        self._lin_bwd_w(b['dtok'], b['patches'], g['patch_embed.proj.weight'], g['patch_embed.proj.bias'],
+                        self.Be * self.keep, cfg.embed_dim, cfg.patch_dim)
+
+    # ------------------------------------------------------------------ optimiser
+    def init_optimizer(self, weight_decay: float = 0.05, betas=(0.9, 0.95), eps: float = 1e-8):
+        self.opt_state = {'exp_avg': torch.zeros_like(self.params), 'exp_avg_sq': torch.zeros_like(self.params)}
+        self.weight_decay, self.betas, self.eps = weight_decay, betas, eps
+        self.opt_step = 0
+
+    def optimizer_hparams(self, lr: float):
+        """Host side of one AdamW step: advances the step count, refreshes lr / bias corrections."""
+        self.opt_step += 1
+        b1, b2 = self.betas
+        self.set_hparams(lr=lr, beta1=b1, beta2=b2, eps=self.eps, bc1=1 - b1 ** self.opt_step,
+                         bc2=1 - b2 ** self.opt_step)
+
+    def grad_norm_and_step(self):
+        """utils/misc.py:265-267: global grad L2 norm -> losses[5]; AdamW over the arena
+        (decayed: matrices + tokens; not decayed: vectors)."""
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        gn = self.losses.data_ptr() + 20
+        lib.vitae_grad_sqnorm(self.grads.data_ptr(), self.n_total, _ptr(self.acc), gn, st)
+        s = self.opt_state
+        lib.vitae_adamw_step(self.params.data_ptr(), self.grads.data_ptr(), s['exp_avg'].data_ptr(),
+                             s['exp_avg_sq'].data_ptr(), self.vec_off, _ptr(self.hp), gn, self.weight_decay, st)
+        o = self.vec_off * 4
+        lib.vitae_adamw_step(self.params.data_ptr() + o, self.grads.data_ptr() + o, s['exp_avg'].data_ptr() + o,
+                             s['exp_avg_sq'].data_ptr() + o, self.n_total - self.vec_off, _ptr(self.hp), gn, 0.0, st)
+
+    # ------------------------------------------------------------------ fused training step
+    N_PHASES = 4
+
+    def train_phase(self, k: int, view1, view2, noise, mask_ratio: float, update: bool = True,
+                    accumulate: bool = False):
+        """Phase k of one optimisation step (only kernel launches, no host sync):
+        0 = forward + losses + backward through decoder/predictor; 1 = upper encoder half backward;
+        2 = lower half + patch embedding; 3 = grad-norm + AdamW.  Gradient bucket k (ddp) is final
+        after phase k.  Loss multipliers and lr must already be in ``hp``."""
+        cfg = self.cfg
+        mid = cfg.depth // 2
+        if k == 0:
+            self.forward(view1, view2, noise, mask_ratio, training=True)
+            if cfg.contrastive:
+                self.contrastive_loss_fwd()
+            self.begin_grad_window(accumulate)
+            if cfg.contrastive:
+                self.contrastive_loss_bwd()
+            self.backward_dec(have_dp=cfg.contrastive)
+        elif k == 1:
+            self.backward_enc(cfg.depth - 1, mid)
+        elif k == 2:
+            self.backward_enc(mid - 1, 0)
+            self.backward_tail()
+        elif k == 3 and update:
+            self.grad_norm_and_step()
+
+    def train_step_launch(self, view1, view2, noise, mask_ratio: float, update: bool = True, accumulate: bool = False):
+        for k in range(self.N_PHASES):
+            self.train_phase(k, view1, view2, noise, mask_ratio, update, accumulate)
+
+    def set_loss_weights(self, edge_map_weight: float, contr_weight: float, accum_iter: int = 1, world_size: int = 1):
+        """Loss weights + upstream gradient multipliers; 1/(accum_iter*world_size) makes a SUM
+        all-reduce of the per-rank gradients their mean."""
+        s = 1.0 / (accum_iter * world_size)
+        self.set_hparams(edge_w=edge_map_weight, contr_w=contr_weight, g_recon=s, g_edge=edge_map_weight * s,
+                         g_contr=contr_weight * s)

@@ -1,0 +1,434 @@
+"""3-D ViT masked autoencoder (+ SimSiam-style contrastive head) with the reference's Python surface
+(reference: model/vit_autoenc.py:14-315) on top of the HIP engine.
+
+Same class names, constructor keywords, sub-module / state-dict names and return tuples as the
+reference, so ``utils.train_one_epoch.train_one_stage_epoch`` and the BraTS/EGD scripts drive it
+unchanged.  ``forward`` is ONE autograd node: its forward runs ``HipMAEEngine.forward`` (kernels of
+libvitae_hip.so), its backward runs ``HipMAEEngine.backward`` and publishes the gradients as
+``param.grad`` views of the engine's flat gradient arena.  There is no CPU path: a CPU tensor raises.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from functools import partial
+from typing import Optional
+
+import torch
+from torch import nn
+
+from .._abi import VitaeError
+from ..engine import HP, HipMAEEngine, MAEConfig
+from .model_utils.perceptual_loss import vgg_perceptual_loss
+from .model_utils.sobel_filter import SobelFilter3d
+from .model_utils.vit_helpers import get_3d_sincos_pos_embed
+from .vit import Block, PatchEmbed3D
+
+
+class _MAEStep(torch.autograd.Function):
+    """(anchor, model, view1, view2, noise, mask_ratio, edge_w) ->
+    (losses[5], pred, mask, p1, p2).  Gradients flow to the parameters as a side effect
+    (param.grad = view of the engine's gradient arena); the anchor only keeps the node alive."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, view1, view2, noise, mask_ratio, edge_w):
+        eng: HipMAEEngine = model._engine
+        eng.set_hparams(edge_w=edge_w)
+        eng.forward(view1, view2, noise, mask_ratio, training=model.training)
+        ctx.model, ctx.edge_w = model, float(edge_w)
+        ctx.set_materialize_grads(False)
+        b, cfg, B = eng.buf, eng.cfg, view1.shape[0]
+        losses = eng.losses[:4].clone()
+        pred = b['predfull'][:, 1:, :]
+        mask = b['mask'][:B]
+        if cfg.contrastive:
+            R = eng.R
+            p1, p2 = b['pout'][:R], b['pout'][R:]
+        else:
+            p1 = p2 = None
+        ctx.mark_non_differentiable(mask)
+        return losses, pred, mask, p1, p2
+
+    @staticmethod
+    def backward(ctx, g_losses, g_pred, g_mask, g_p1, g_p2):
+        model = ctx.model
+        eng: HipMAEEngine = model._engine
+        if g_pred is not None:
+            raise VitaeError('gradients through `pred` other than via the returned losses are not supported')
+        hp = eng.hp
+        if g_losses is None:
+            hp[HP['G_RECON']] = 0.0
+            hp[HP['G_EDGE']] = 0.0
+        else:   # total = w_e*edge + recon (+0): d/d recon = g0 + g2 ; d/d raw_edge = w_e*g0 + g1
+            hp[HP['G_RECON']] = g_losses[0] + g_losses[2]
+            hp[HP['G_EDGE']] = ctx.edge_w * g_losses[0] + g_losses[1]
+        have_dp = eng.cfg.contrastive and (g_p1 is not None or g_p2 is not None)
+        if have_dp:
+            R = eng.R
+            dp = eng.buf['dp']
+            for half, g in ((dp[:R], g_p1), (dp[R:], g_p2)):
+                if g is None:
+                    half.zero_()
+                else:
+                    half.copy_(g)
+        fresh = all(p.grad is None for p in model._trainable)
+        eng.begin_grad_window(accumulate=not fresh)
+        eng.backward(have_dp)
+        if fresh:
+            for n, p in model._trainable_named:
+                p.grad = eng.g[n]
+        return None, None, None, None, None, None, None
+
+
+class _StepRunner:
+    """One (batch size, mask ratio, update?, accumulate?) variant of the fused optimisation step:
+    static input buffers + either eager launches or a captured HIP graph of the whole step."""
+
+    def __init__(self, model, B, mask_ratio, update, accumulate, use_graph):
+        self.model, self.eng = model, model._engine
+        self.B, self.mask_ratio, self.update, self.accumulate = B, mask_ratio, update, accumulate
+        eng, cfg, dev = self.eng, model._cfg, model._engine.device
+        st = model._static.get(B)
+        if st is None:
+            st = model._static[B] = {
+                'v1': torch.empty(B, cfg.in_chans, *cfg.volume_size, dtype=torch.float32, device=dev),
+                'v2': torch.empty(B, cfg.in_chans, *cfg.volume_size, dtype=torch.float32, device=dev)
+                if cfg.contrastive else None,
+                'noise': torch.empty((2 * B if cfg.contrastive else B), cfg.num_patches, dtype=torch.float32,
+                                     device=dev)}
+        self.v1, self.v2, self.noise = st['v1'], st['v2'], st['noise']
+        self.graphs = None
+        self.use_graph = use_graph
+
+    def load(self, view1, view2):
+        """Stage one batch (host or device tensors) and fresh masking noise into the static buffers."""
+        self.v1.copy_(view1, non_blocking=True)
+        if self.v2 is not None:
+            self.v2.copy_(view2, non_blocking=True)
+        m = self.model
+        if m._noise_queue:
+            self.noise.copy_(m._draw_noise(2 if m._contrastive else 1, self.B, self.noise.device))
+        else:
+            self.noise.uniform_()   # torch.rand of vit_autoenc.py:139
+
+    def _phase(self, k):
+        self.eng.train_phase(k, self.v1, self.v2, self.noise, self.mask_ratio, update=self.update,
+                             accumulate=self.accumulate)
+
+    def _capture(self, groups):
+        """Warm up once (loads code objects, sizes the workspace; state restored afterwards), then
+        capture each group of phases as one HIP graph."""
+        eng = self.eng
+        keep = [eng.params, eng.grads] + ([eng.opt_state['exp_avg'], eng.opt_state['exp_avg_sq']] if eng.opt_state else [])
+        keep += [t for k, t in eng.buffers.items() if k.startswith('predictor.1.')]
+        snap = [t.clone() for t in keep]
+        step = eng.opt_step
+        cur = torch.cuda.current_stream(eng.device)
+        side = torch.cuda.Stream(device=eng.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for k in range(eng.N_PHASES):
+                self._phase(k)
+        cur.wait_stream(side)
+        for t, s in zip(keep, snap):
+            t.copy_(s)
+        eng.opt_step = step
+        torch.cuda.synchronize(eng.device)
+        self.graphs = []
+        for grp in groups:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                for k in grp:
+                    self._phase(k)
+            self.graphs.append(g)
+
+    def run(self):
+        """Enqueue one optimisation step.  Single process: one graph (or one eager launch list).
+        Data parallel: phases 0..2 each followed by the asynchronous all-reduce of the gradient bucket
+        they complete, then wait + grad-norm/AdamW (no exchange on gradient-accumulation micro-steps)."""
+        eng, red = self.eng, self.model._reducer
+        exchange = red is not None and red.world_size > 1 and self.update
+        groups = [[0], [1], [2], [3]] if exchange else [list(range(eng.N_PHASES))]
+        if self.use_graph and self.graphs is None:
+            self._capture(groups)
+        for i, grp in enumerate(groups):
+            if self.use_graph:
+                self.graphs[i].replay()
+            else:
+                for k in grp:
+                    self._phase(k)
+            if exchange and i < 3:
+                red.launch(i)
+                if i == 2:
+                    red.launch(3)
+                    red.wait()
+
+
+class MaskedAutoencoderViT(nn.Module):
+    """Masked Autoencoder with a 3-D VisionTransformer backbone (reference vit_autoenc.py:14-238)."""
+
+    _contrastive = False
+
+    def __init__(self, volume_size=224, patch_size=16, in_chans=3,
+                 embed_dim=1024, depth=24, num_heads=16,
+                 decoder_embed_dim=512, decoder_depth=8, decoder_num_heads=16,
+                 mlp_ratio=4., norm_layer=nn.LayerNorm, norm_pix_loss=False, args=None, precision=None):
+        super().__init__()
+        if norm_pix_loss:
+            raise VitaeError('norm_pix_loss=True is not on the HIP path (never enabled by model_factory.get_models)')
+        self.patch_embed = PatchEmbed3D(volume_size, patch_size, in_chans, embed_dim)
+        num_patches = self.patch_embed.num_patches
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, embed_dim), requires_grad=False)
+        self.embed_dim = embed_dim
+        self.blocks = nn.ModuleList([Block(embed_dim, num_heads, mlp_ratio, qkv_bias=True, norm_layer=norm_layer)
+                                     for _ in range(depth)])
+        self.norm = norm_layer(embed_dim)
+        self.decoder_embed = nn.Linear(embed_dim, decoder_embed_dim, bias=True)
+        self.mask_token = nn.Parameter(torch.zeros(1, 1, decoder_embed_dim))
+        self.decoder_pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, decoder_embed_dim), requires_grad=False)
+        self.decoder_blocks = nn.ModuleList([Block(decoder_embed_dim, decoder_num_heads, mlp_ratio, qkv_bias=True,
+                                                   norm_layer=norm_layer) for _ in range(decoder_depth)])
+        self.decoder_norm = norm_layer(decoder_embed_dim)
+        p = self.patch_embed.patch_size[0]
+        self.decoder_pred = nn.Linear(decoder_embed_dim, p ** 3 * in_chans, bias=True)
+        self.sobel_filter3D = SobelFilter3d()
+        self.perceptual_loss = vgg_perceptual_loss(use_imagenet=getattr(args, 'use_imagenet', False))
+        self.args = args
+        self.perceptual_weight = 1 if args is None else args.perceptual_weight
+        if self.perceptual_weight:
+            raise VitaeError('perceptual_weight != 0 needs torchvision VGG16 + ckp-399.pth (out of scope, SURVEY D9); '
+                             'the reference configuration uses 0')
+        print(f"Using perceptual weight of {self.perceptual_weight}")
+        self.norm_pix_loss = norm_pix_loss
+        eps = getattr(self.norm, 'eps', 1e-6)
+        self._cfg = MAEConfig(volume_size=self.patch_embed.volume_size, patch_size=p, in_chans=in_chans,
+                              embed_dim=embed_dim, depth=depth, num_heads=num_heads,
+                              decoder_embed_dim=decoder_embed_dim, decoder_depth=decoder_depth,
+                              decoder_num_heads=decoder_num_heads, mlp_ratio=mlp_ratio,
+                              contrastive=self._contrastive, ln_eps=eps)
+        self._precision = precision or getattr(args, 'precision', None) or 'fp32'
+        self._engine: Optional[HipMAEEngine] = None
+        self._noise_queue = []
+        self._static, self._runners = {}, {}
+        self._reducer = None
+        self.initialize_weights()
+
+    # ------------------------------------------------------------------ init (vit_autoenc.py:65-98)
+    def initialize_weights(self):
+        grid = self.patch_embed.grid_size
+        with torch.no_grad():
+            for name, dim in (('pos_embed', self.pos_embed.shape[-1]), ('decoder_pos_embed', self.decoder_pos_embed.shape[-1])):
+                table = get_3d_sincos_pos_embed(dim, grid, cls_token=True)
+                getattr(self, name).copy_(torch.from_numpy(table).float().unsqueeze(0))
+            w = self.patch_embed.proj.weight
+            nn.init.xavier_uniform_(w.view(w.shape[0], -1))      # like nn.Linear, not like a conv
+            nn.init.normal_(self.cls_token, std=.02)
+            nn.init.normal_(self.mask_token, std=.02)
+        self.apply(self._init_weights)
+
+    def _init_weights(self, m):
+        if isinstance(m, nn.Linear):
+            nn.init.xavier_uniform_(m.weight)
+            if m.bias is not None:
+                nn.init.zeros_(m.bias)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.ones_(m.weight)
+            nn.init.zeros_(m.bias)
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        eng = self.__dict__.get('_engine')
+        if eng is not None and any(p.data_ptr() != eng.p[n].data_ptr() or p.device != eng.device
+                                   for n, p in self._trainable_named):
+            self._engine = None   # parameters moved / were re-typed: re-adopt them into a fresh arena lazily
+        return out
+
+    def _ensure_engine(self, device: torch.device) -> HipMAEEngine:
+        if device.type != 'cuda':
+            raise VitaeError(f'input is on {device}: vit_ae_plus_plus_amd computes on MI355X only — there is '
+                             f'no CPU fallback (the CPU restatement lives in oracle/ for tests)')
+        if self._engine is not None and self._engine.device == device:
+            return self._engine
+        named = OrderedDict((n, p) for n, p in self.named_parameters() if p.requires_grad)
+        bufs = {'pos_embed': self.pos_embed.data.to(device).reshape(-1, self.pos_embed.shape[-1]).contiguous(),
+                'decoder_pos_embed': self.decoder_pos_embed.data.to(device).reshape(
+                    -1, self.decoder_pos_embed.shape[-1]).contiguous()}
+        if self._contrastive:
+            bn = self.predictor[1]
+            for k in ('running_mean', 'running_var', 'num_batches_tracked'):
+                t = getattr(bn, k)
+                if t.device != device:
+                    setattr(bn, k, t.to(device))
+                bufs['predictor.1.' + k] = getattr(bn, k)
+        eng = HipMAEEngine(self._cfg, named, bufs, device, precision=self._precision)
+        for n, p in named.items():          # parameters become views of the flat arena
+            p.data = eng.p[n]
+            p.grad = None
+        self._trainable_named = list(named.items())
+        self._trainable = [p for _, p in self._trainable_named]
+        self._engine = eng
+        return eng
+
+    def _step_runner(self, B, mask_ratio, update, accumulate, use_graph) -> _StepRunner:
+        key = (int(B), float(mask_ratio), bool(update), bool(accumulate), bool(use_graph), id(self._engine))
+        r = self._runners.get(key)
+        if r is None:
+            r = self._runners[key] = _StepRunner(self, int(B), float(mask_ratio), bool(update), bool(accumulate),
+                                                 bool(use_graph))
+        return r
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        # tolerate the real reference's extra VGG tensors (perceptual_loss.*), SURVEY §8b
+        sd = {k: v for k, v in state_dict.items() if not k.startswith('perceptual_loss.')}
+        out = super().load_state_dict(sd, strict=strict, **kw)
+        eng = self._engine
+        if eng is not None:   # frozen tables are engine-side copies
+            eng.buffers['pos_embed'].copy_(self.pos_embed.data.reshape(eng.buffers['pos_embed'].shape))
+            eng.buffers['decoder_pos_embed'].copy_(
+                self.decoder_pos_embed.data.reshape(eng.buffers['decoder_pos_embed'].shape))
+        return out
+
+    def enable_data_parallel(self, device=None, group=None):
+        """One process per GPU: broadcast rank 0's replica and all-reduce gradient buckets over RCCL
+        (overlapped with backward) inside the fused step.  No-op for a single process."""
+        from .. import ddp
+        if not ddp.is_distributed():
+            self._reducer = None
+            return None
+        eng = self._ensure_engine(torch.device(device) if device is not None else next(self.parameters()).device)
+        ddp.broadcast_parameters(eng, 0, group)
+        self._reducer = ddp.GradBucketReducer(eng.grads, ddp.engine_bucket_ranges(eng), group=group)
+        self._runners.clear()
+        return self._reducer
+
+    @property
+    def engine(self) -> Optional[HipMAEEngine]:
+        return self._engine
+
+    def set_precision(self, precision: str):
+        """'fp32' (exact-fp32 MFMA, the reference's precision) or 'bf16' (bf16 MFMA, fp32 accumulate)."""
+        self._precision = precision
+        self._engine = None
+
+    def set_masking_noise(self, *noises):
+        """Queue [B, L] noise tensors consumed (in order) instead of drawing torch.rand
+        (vit_autoenc.py:139) — the parity hook of SURVEY §7.2 'RNG'."""
+        self._noise_queue = [n for n in noises]
+
+    def _draw_noise(self, n_views, B, device):
+        L = self.patch_embed.num_patches
+        parts = []
+        for _ in range(n_views):
+            if self._noise_queue:
+                z = self._noise_queue.pop(0).to(device=device, dtype=torch.float32)
+                assert tuple(z.shape) == (B, L)
+            else:
+                z = torch.rand(B, L, device=device)
+            parts.append(z)
+        return parts[0].contiguous() if n_views == 1 else torch.cat(parts, 0)
+
+    def _prep(self, v):
+        if v.dtype != torch.float32 or not v.is_contiguous():
+            v = v.contiguous().float()
+        return v
+
+    # ------------------------------------------------------------------ pure index permutations
+    def patchify(self, volume):
+        """[N, C, L, H, W] -> [N, l*h*w, p^3*C]  (vit_autoenc.py:100-113; order (r, p, q, c))."""
+        p = self.patch_embed.patch_size[0]
+        N, C = volume.shape[:2]
+        l, h, w = (s // p for s in volume.shape[2:])
+        assert all(s % p == 0 for s in volume.shape[2:])
+        x = volume.reshape(N, C, l, p, h, p, w, p).permute(0, 2, 4, 6, 3, 5, 7, 1)
+        return x.reshape(N, l * h * w, p ** 3 * C)
+
+    def unpatchify(self, x):
+        """[N, l*h*w, p^3*C] -> [N, C, L, H, W]  (vit_autoenc.py:115-128)."""
+        p = self.patch_embed.patch_size[0]
+        l, h, w = self.patch_embed.grid_size
+        assert l * h * w == x.shape[1]
+        N = x.shape[0]
+        x = x.reshape(N, l, h, w, p, p, p, -1).permute(0, 7, 1, 4, 2, 5, 3, 6)
+        return x.reshape(N, -1, l * p, h * p, w * p)
+
+    # ------------------------------------------------------------------ forward
+    def _step(self, view1, view2, mask_ratio, edge_map_weight):
+        view1 = self._prep(view1)
+        view2 = self._prep(view2) if view2 is not None else None
+        eng = self._ensure_engine(view1.device)
+        noise = self._draw_noise(2 if self._contrastive else 1, view1.shape[0], view1.device)
+        return _MAEStep.apply(self.cls_token, self, view1, view2, noise, float(mask_ratio), float(edge_map_weight))
+
+    def forward(self, sample, mask_ratio=0.75, edge_map_weight=0):
+        """-> ([loss, raw_edge_mse, recon, percep], pred [N, L, p^3 C], mask [N, L])  (vit_autoenc.py:234-238)"""
+        losses, pred, mask, _, _ = self._step(sample, None, mask_ratio, edge_map_weight)
+        return [losses[0], losses[1], losses[2], losses[3]], pred, mask
+
+
+class ContrastiveMAEViT(MaskedAutoencoderViT):
+    """MAE + SimSiam predictor on the two views' latents (reference vit_autoenc.py:241-285)."""
+
+    _contrastive = True
+
+    def __init__(self, volume_size=224, patch_size=16, in_chans=3,
+                 embed_dim=1024, depth=24, num_heads=16,
+                 decoder_embed_dim=512, decoder_depth=8, decoder_num_heads=16,
+                 mlp_ratio=4., norm_layer=nn.LayerNorm, norm_pix_loss=False, args=None, use_proj=False,
+                 precision=None):
+        if use_proj:
+            raise VitaeError('use_proj=True (projection_head) is never used by the reference pre-training path')
+        super().__init__(volume_size=volume_size, patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim,
+                         depth=depth, num_heads=num_heads, decoder_embed_dim=decoder_embed_dim,
+                         decoder_depth=decoder_depth, decoder_num_heads=decoder_num_heads, mlp_ratio=mlp_ratio,
+                         norm_layer=norm_layer, norm_pix_loss=norm_pix_loss, args=args, precision=precision)
+        self.use_proj = use_proj
+        # built after the base init, exactly like the reference (default nn.Linear / BatchNorm1d init)
+        self.predictor = nn.Sequential(nn.Linear(embed_dim, embed_dim, bias=False), nn.BatchNorm1d(embed_dim),
+                                       nn.ReLU(inplace=True), nn.Linear(embed_dim, embed_dim))
+
+    def forward(self, view1, view2, mask_ratio=0.75, edge_map_weight=0):
+        """-> (loss_list, pred, mask, p1, p2, z1.detach(), z2.detach())  (vit_autoenc.py:270-285)"""
+        losses, pred, mask, p1, p2 = self._step(view1, view2, mask_ratio, edge_map_weight)
+        eng = self._engine
+        R = eng.R
+        z = eng.buf['latent']
+        return [losses[0], losses[1], losses[2], losses[3]], pred, mask, p1, p2, z[:R].detach(), z[R:].detach()
+
+
+def mae_vit_large_patch16_dec512d8b(**kwargs):
+    return MaskedAutoencoderViT(embed_dim=1024, depth=24, num_heads=16, decoder_embed_dim=512, decoder_depth=8,
+                                decoder_num_heads=16, mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+
+
+def mae_vit_base_patch16_dec512d8b(**kwargs):
+    return MaskedAutoencoderViT(embed_dim=768, depth=12, num_heads=12, decoder_embed_dim=512, decoder_depth=8,
+                                decoder_num_heads=16, mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+
+
+def contr_mae_vit_base_patch16_dec512d8b(**kwargs):
+    return ContrastiveMAEViT(embed_dim=768, depth=12, num_heads=12, decoder_embed_dim=512, decoder_depth=8,
+                             decoder_num_heads=16, mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+
+
+def contr_mae_vit_large_patch16_dec512d8b(**kwargs):
+    return ContrastiveMAEViT(embed_dim=1024, depth=24, num_heads=16, decoder_embed_dim=512, decoder_depth=8,
+                             decoder_num_heads=16, mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+
+
+def contr_mae_vit_tiny_patch16(**kwargs):
+    """BASELINE config 1 (tiny plumbing model: D=128, depth 2, 4 heads; decoder 64 / 1 / 4)."""
+    return ContrastiveMAEViT(embed_dim=128, depth=2, num_heads=4, decoder_embed_dim=64, decoder_depth=1,
+                             decoder_num_heads=4, mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+
+
+def mae_vit_tiny_patch16(**kwargs):
+    return MaskedAutoencoderViT(embed_dim=128, depth=2, num_heads=4, decoder_embed_dim=64, decoder_depth=1,
+                                decoder_num_heads=4, mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+
+
+# recommended archs (same aliases as the reference, vit_autoenc.py:313-315)
+mae_vit_base_patch16 = mae_vit_base_patch16_dec512d8b
+mae_vit_large_patch16 = mae_vit_large_patch16_dec512d8b
+contr_mae_vit_base_patch16 = contr_mae_vit_base_patch16_dec512d8b
+contr_mae_vit_large_patch16 = contr_mae_vit_large_patch16_dec512d8b
