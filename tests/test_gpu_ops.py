@@ -27,8 +27,22 @@ def C():
     return CONSTS
 
 
+_KEEP = []
+
+
 def dev(t):
-    return t.detach().clone().contiguous().cuda()
+    """Device copy that stays alive until the end of the test (launches are asynchronous: a temporary
+    passed as ``dev(x).data_ptr()`` must not be recycled by the caching allocator before the kernel ran)."""
+    d = t.detach().clone().contiguous().cuda()
+    _KEEP.append(d)
+    return d
+
+
+@pytest.fixture(autouse=True)
+def _release_device_copies():
+    yield
+    torch.cuda.synchronize()
+    _KEEP.clear()
 
 
 def st():
@@ -101,8 +115,9 @@ def test_gemm_asymmetric_layout(lib):
     a = torch.eye(64)
     b = torch.arange(64 * 64, dtype=torch.float32).reshape(64, 64) / 100.0
     y = torch.empty(M, N, device='cuda')
+    ad, bd = dev(a), dev(b)
     for prec in (0, 1):
-        lib.vitae_linear_fwd(prec, dev(a).data_ptr(), dev(b).data_ptr(), None, y.data_ptr(), M, N, K, 0, None, None, 1,
+        lib.vitae_linear_fwd(prec, ad.data_ptr(), bd.data_ptr(), None, y.data_ptr(), M, N, K, 0, None, None, 1,
                              None, st())
         assert rel_err(y, b.t()) < (1e-6 if prec == 0 else 5e-3)
 
@@ -165,7 +180,8 @@ def test_sdpa_large_logits(lib):
     q, k, v = qkv.reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
     ref = (((q @ k.transpose(-2, -1)) * hd ** -0.5).softmax(-1) @ v).transpose(1, 2).reshape(B, N, hd)
     o, lse = torch.empty(B, N, hd, device='cuda'), torch.empty(N, device='cuda')
-    lib.vitae_sdpa_fwd(dev(qkv).data_ptr(), o.data_ptr(), lse.data_ptr(), B, N, H, hd, st())
+    qd = dev(qkv)
+    lib.vitae_sdpa_fwd(qd.data_ptr(), o.data_ptr(), lse.data_ptr(), B, N, H, hd, st())
     assert rel_err(o, ref) < 1e-5
 
 

@@ -10,6 +10,12 @@ import os
 import re
 from typing import Dict, List, Tuple
 
+# torch must come first: it ships its own libamdhip64.so and libvitae_hip.so has to bind to THAT HIP
+# runtime instance (same SONAME -> the loader reuses the one already mapped).  Loading our library first
+# would map /opt/rocm's copy and leave the process with a runtime that does not know torch's streams and
+# allocations (seen as VITAE_ERR_LAUNCH from the first hipMemsetAsync).
+import torch  # noqa: F401  (import order matters)
+
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 HEADER = os.path.join(ROOT, 'include', 'vitae_hip.h')

@@ -248,6 +248,8 @@ class MaskedAutoencoderViT(nn.Module):
         if device.type != 'cuda':
             raise VitaeError(f'input is on {device}: vit_ae_plus_plus_amd computes on MI355X only — there is '
                              f'no CPU fallback (the CPU restatement lives in oracle/ for tests)')
+        if device.index is None:
+            device = torch.device('cuda', torch.cuda.current_device())
         if self._engine is not None and self._engine.device == device:
             return self._engine
         named = OrderedDict((n, p) for n, p in self.named_parameters() if p.requires_grad)
