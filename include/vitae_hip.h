@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITAE_ABI_VERSION 1
+#define VITAE_ABI_VERSION 3
 
 /* matrix-core arithmetic of the dense contractions */
 #define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
@@ -74,6 +74,15 @@ int vitae_gemm(int prec, int a_kcontig, int b_kcontig, const float* A, long lda,
 long vitae_gemm_workspace_floats(int M, int N, int K, int split_k);
 int vitae_gemm_pick_split_k(int M, int N, int K);
 
+/* Throughput-mode variant (bf16 MFMA, fp32 accumulate): A fp32, B fp32 or a bf16 shadow (b_is_bf16);
+ * pipelined 64 x {64,128} x 64 tiles, transpose reads for row-contiguous operands, XCD-aware order. */
+int vitae_gemm_bf16(int a_kcontig, int b_kcontig, const float* A, long lda, const void* B, long ldb, int b_is_bf16,
+                    float* C, long ldc, int M, int N, int K, const float* bias, const float* residual, long ldr,
+                    int epi, float* aux, long ldaux, int accumulate, int split_k, float* splitk_ws, void* stream);
+int vitae_gemm_bf16_pick_split_k(int M, int N, int K);
+/* dst_bf16[i] = bf16(src[i]) (round to nearest even) */
+int vitae_cast_bf16(const float* src, void* dst_bf16, long n, void* stream);
+
 /* nn.Linear forward  y = x W^T + b  (model/vit.py:85-96 fc1/fc2, :107-114 qkv, :109,122 proj;
  * model/vit_autoenc.py:41 decoder_embed, :53 decoder_pred, :263-268 predictor; and the Conv3d patch
  * embedding of model/vit.py:65,72 as a GEMM over gathered patches).  x[M,K], w[N,K], y[M,N]. */
@@ -101,6 +110,12 @@ int vitae_layernorm_bwd(const float* dy, const float* x, const float* w, const f
 int vitae_sdpa_fwd(const float* qkv, float* o, float* lse, int B, int N, int H, int head_dim, void* stream);
 int vitae_sdpa_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv,
                    float* delta_ws, int B, int N, int H, int head_dim, void* stream);
+
+/* bf16-MFMA implementation of the same two entry points (head_dim 32 or 64; operands rounded to bf16,
+ * fp32 softmax / accumulation); VITAE_ERR_UNSUPPORTED_SHAPE for other head dims. */
+int vitae_sdpa_mfma_fwd(const float* qkv, float* o, float* lse, int B, int N, int H, int head_dim, void* stream);
+int vitae_sdpa_mfma_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv,
+                        float* delta_ws, int B, int N, int H, int head_dim, void* stream);
 
 /* ---- masking and sequence assembly ---------------------------------------------------------------
  * random_masking (model/vit_autoenc.py:141-153) from a caller-supplied noise[B,L] (the torch.rand of
@@ -164,8 +179,9 @@ int vitae_cosine_loss_bwd(const float* p1, const float* z2, const float* p2, con
  * utils/misc.py:265-266,280-292 (global grad L2 norm) and torch.optim.AdamW
  * (k_fold_training_scripts/k_fold_cross_valid_combined_brats.py:168-169). */
 int vitae_grad_sqnorm(const float* grads, long n, double* acc, float* norm_out, void* stream);
-int vitae_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, const float* hp,
-                     const float* grad_norm, float weight_decay, void* stream);
+/* shadow_bf16 (optional): bf16 copy of the updated parameters, written in the same pass */
+int vitae_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, long n,
+                     const float* hp, const float* grad_norm, float weight_decay, void* stream);
 
 #ifdef __cplusplus
 }

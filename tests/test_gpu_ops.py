@@ -109,6 +109,61 @@ def test_linear_fwd_bwd(lib, C, prec, tol, M, N, K):
     assert rel_err(db, dy.sum(0)) < 2e-5
 
 
+@pytest.mark.parametrize('b16', [0, 1])
+@pytest.mark.parametrize('M,N,K', [(440, 2304, 768), (37, 48, 128), (868, 512, 2048), (64, 64, 64), (130, 72, 4096),
+                                   (432, 768, 16384), (868, 16384, 512)])
+def test_gemm_bf16_pipeline(lib, C, b16, M, N, K):
+    """vitae_gemm_bf16 in its three operand forms (fwd KC/KC, dgrad KC/row, wgrad row/row), fp32 or bf16 B."""
+    tol = 2e-2
+    x, w, b, res = gen(M, K, seed=1), gen(N, K, seed=2, scale=K ** -0.5), gen(N, seed=3), gen(M, N, seed=4)
+    xd, wd, bd, rd = dev(x), dev(w), dev(b), dev(res)
+    w16 = wd.to(torch.bfloat16); _KEEP.append(w16)
+    wp = w16 if b16 else wd
+    ws = torch.empty(1 << 24, device='cuda')
+    for split in (1, lib.vitae_gemm_bf16_pick_split_k(M, N, K)):
+        y = torch.full((M, N), float('nan'), device='cuda')
+        lib.vitae_gemm_bf16(1, 1, xd.data_ptr(), K, wp.data_ptr(), K, b16, y.data_ptr(), N, M, N, K, bd.data_ptr(), rd.data_ptr(),
+                            N, 0, None, 0, 0, split, ws.data_ptr(), st())
+        assert rel_err(y, F.linear(x, w, b) + res) < tol, f'fwd split {split}'
+    y, aux = torch.empty(M, N, device='cuda'), torch.empty(M, N, device='cuda')
+    lib.vitae_gemm_bf16(1, 1, xd.data_ptr(), K, wp.data_ptr(), K, b16, y.data_ptr(), N, M, N, K, bd.data_ptr(), None, 0,
+                        C['VITAE_EPI_GELU'], aux.data_ptr(), N, 0, 1, None, st())
+    pre = F.linear(x, w, b)
+    assert rel_err(aux, pre) < tol and rel_err(y, F.gelu(pre)) < tol
+    dy = gen(M, N, seed=5)
+    dyd = dev(dy)
+    dx = torch.full((M, K), float('nan'), device='cuda')
+    split = lib.vitae_gemm_bf16_pick_split_k(M, K, N)
+    lib.vitae_gemm_bf16(1, 0, dyd.data_ptr(), N, wp.data_ptr(), K, b16, dx.data_ptr(), K, M, K, N, None, None, 0, 0, None, 0, 0,
+                        split, ws.data_ptr(), st())
+    assert rel_err(dx, dy @ w) < tol, 'dgrad'
+    if not b16:
+        dw = torch.full((N, K), float('nan'), device='cuda')
+        split = lib.vitae_gemm_bf16_pick_split_k(N, K, M)
+        lib.vitae_gemm_bf16(0, 0, dyd.data_ptr(), N, xd.data_ptr(), K, 0, dw.data_ptr(), K, N, K, M, None, None, 0, 0, None, 0, 0,
+                            split, ws.data_ptr(), st())
+        assert rel_err(dw, dy.t() @ x) < tol, 'wgrad'
+        lib.vitae_gemm_bf16(0, 0, dyd.data_ptr(), N, xd.data_ptr(), K, 0, dw.data_ptr(), K, N, K, M, None, None, 0, 0, None, 0, 1,
+                            1, None, st())
+        assert rel_err(dw, 2 * (dy.t() @ x)) < tol, 'wgrad accumulate'
+
+
+def test_gemm_bf16_asymmetric(lib):
+    a = torch.eye(64)
+    b = torch.arange(64 * 64, dtype=torch.float32).reshape(64, 64) / 128.0
+    ad, bd = dev(a), dev(b)
+    y = torch.empty(64, 64, device='cuda')
+    lib.vitae_gemm_bf16(1, 1, ad.data_ptr(), 64, bd.data_ptr(), 64, 0, y.data_ptr(), 64, 64, 64, 64, None, None, 0, 0, None, 0, 0, 1,
+                        None, st())
+    assert rel_err(y, b.t()) < 5e-3
+    lib.vitae_gemm_bf16(1, 0, ad.data_ptr(), 64, bd.data_ptr(), 64, 0, y.data_ptr(), 64, 64, 64, 64, None, None, 0, 0, None, 0, 0, 1,
+                        None, st())
+    assert rel_err(y, b) < 5e-3          # B read as (k, n): y = I @ b
+    lib.vitae_gemm_bf16(0, 0, bd.data_ptr(), 64, ad.data_ptr(), 64, 0, y.data_ptr(), 64, 64, 64, 64, None, None, 0, 0, None, 0, 0, 1,
+                        None, st())
+    assert rel_err(y, b.t()) < 5e-3      # A read as (m, k) = b[k, m]: y = b^T @ I
+
+
 def test_gemm_asymmetric_layout(lib):
     """A = I against an asymmetric B catches transposed C writes (cdna guide §3)."""
     M = N = K = 64
@@ -169,6 +224,30 @@ def test_sdpa(lib, B, N, H, hd):
     lib.vitae_sdpa_bwd(qd.data_ptr(), o.data_ptr(), dod.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), delta.data_ptr(),
                        B, N, H, hd, st())
     assert rel_err(dqkv, qr.grad) < 2e-5
+
+
+@pytest.mark.parametrize('B,N,H,hd', [(8, 55, 12, 64), (4, 217, 16, 32), (2, 17, 3, 32), (1, 130, 2, 64), (1, 300, 1, 32)])
+def test_sdpa_mfma_bf16(lib, B, N, H, hd):
+    D = H * hd
+    qkv, do = gen(B, N, 3 * D, seed=1), gen(B, N, D, seed=2)
+    qr = qkv.clone().requires_grad_(True)
+    q, k, v = qr.reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    att = ((q @ k.transpose(-2, -1)) * hd ** -0.5).softmax(-1)
+    ref = (att @ v).transpose(1, 2).reshape(B, N, D)
+    ref.backward(do)
+    ref_lse = torch.logsumexp((q @ k.transpose(-2, -1)) * hd ** -0.5, -1).detach()   # [B,H,N]
+    qd, dod = dev(qkv), dev(do)
+    o, lse = torch.full((B, N, D), float('nan'), device='cuda'), torch.empty(B * H * N, device='cuda')
+    lib.vitae_sdpa_mfma_fwd(qd.data_ptr(), o.data_ptr(), lse.data_ptr(), B, N, H, hd, st())
+    assert rel_err(o, ref) < 2e-2
+    assert float((lse.cpu().reshape(B, H, N) - ref_lse).abs().max()) < 3e-2
+    dqkv, delta = torch.full((B, N, 3 * D), float('nan'), device='cuda'), torch.empty(B * H * N, device='cuda')
+    lib.vitae_sdpa_mfma_bwd(qd.data_ptr(), o.data_ptr(), dod.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), delta.data_ptr(),
+                            B, N, H, hd, st())
+    g = qr.grad.reshape(B, N, 3, D)
+    got = dqkv.cpu().reshape(B, N, 3, D)
+    for i, name in enumerate('qkv'):
+        assert rel_err(got[:, :, i], g[:, :, i]) < 3e-2, name
 
 
 def test_sdpa_large_logits(lib):
@@ -366,6 +445,7 @@ def test_adamw_and_gradnorm(lib, C):
     opt = torch.optim.AdamW([ref], lr=3e-4, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05)
     npad = (n + 3) // 4 * 4
     p, m, v = torch.zeros(npad, device='cuda'), torch.zeros(npad, device='cuda'), torch.zeros(npad, device='cuda')
+    sh = torch.zeros(npad, dtype=torch.bfloat16, device='cuda')
     p[:n] = p0.cuda()
     hp = torch.zeros(C['VITAE_HP_COUNT'], device='cuda')
     acc = torch.zeros(C['VITAE_ACC_COUNT'], dtype=torch.float64, device='cuda')
@@ -379,10 +459,11 @@ def test_adamw_and_gradnorm(lib, C):
         acc.zero_()
         lib.vitae_grad_sqnorm(gd.data_ptr(), n, acc.data_ptr(), gn.data_ptr(), st())
         assert abs(float(gn) - float(g.norm())) < 1e-5 * float(g.norm())
-        lib.vitae_adamw_step(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, hp.data_ptr(), gn.data_ptr(), 0.05, st())
+        lib.vitae_adamw_step(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), sh.data_ptr(), n, hp.data_ptr(), gn.data_ptr(), 0.05, st())
         assert rel_err(p[:n], ref) < 2e-6
+        assert torch.equal(sh[:n], p[:n].to(torch.bfloat16))
     # non-finite gradient norm -> step skipped (GradScaler.step semantics)
     before = p.clone()
     gn.fill_(float('inf'))
-    lib.vitae_adamw_step(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, hp.data_ptr(), gn.data_ptr(), 0.05, st())
+    lib.vitae_adamw_step(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), None, n, hp.data_ptr(), gn.data_ptr(), 0.05, st())
     assert torch.equal(p, before)

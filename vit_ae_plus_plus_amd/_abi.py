@@ -89,7 +89,7 @@ class _Lib:
     def __getattr__(self, name):
         dll = self.load()
         fn = getattr(dll, name)
-        if PROTOS[name][0] != 'int' or name in ('vitae_abi_version', 'vitae_gemm_pick_split_k'):
+        if PROTOS[name][0] != 'int' or name == 'vitae_abi_version' or name.endswith('pick_split_k'):
             return fn
 
         def checked(*args):

@@ -1,0 +1,376 @@
+// bf16-MFMA flash attention (forward, dQ, dK/dV) for head_dim 32 / 64 — the throughput-mode
+// implementation of reference op K7 (model/vit.py:117-121).  fp32 tensors in HBM (same layouts as
+// attention.hip), operands rounded to bf16 while being staged, fp32 accumulation and softmax.
+//
+// Everything is arranged so that NO cross-lane data movement is needed between the two matrix
+// products of a tile (v_mfma_f32_32x32x16_bf16; C layout: lane holds column j = lane & 31 and the 16
+// rows crow(r, hi) = (r & 3) + 8 (r >> 2) + 4 hi):
+//   forward / dQ : S^T[key, q] = K Q^T  -> the lane's column is ONE query, so the softmax statistics
+//                  (running max / sum, lse, delta) are per-lane scalars, and the 16 registers
+//                  (bf16-packed) are directly the B operand of  O^T[d, q] += V^T[d, key] P^T[key, q];
+//   dK/dV        : S[q, key] = Q K^T    -> the lane's column is ONE key; P and dS registers are the
+//                  B operands of dV^T[d, key] += dO^T[d, q] P[q, key], dK^T[d, key] += Q^T[d, q] dS[q, key].
+// The reduction-slot -> row mapping of those second products is whatever the C layout dictates
+// (slot (s, hi, e) <-> row crow(8 s + e, hi)); the A operands (V^T, K^T, dO^T, Q^T) are gathered to
+// match with ds_read_b64_tr_b16 (hardware transpose read: within a 16-lane group lane i receives
+// element i of the four rows addressed by lanes 4 j .. 4 j + 3) from row-major bf16 LDS tiles.
+// LDS rows are padded to HD + 8 elements: conflict-free for both the b128 fragment reads and the
+// transpose reads.  Rows beyond N are zero-filled so stale LDS bits can never reach an MFMA.
+#include "common.hpp"
+#include "vitae_hip.h"
+
+namespace {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+constexpr float LOG2E = 1.44269504088896340736f;
+constexpr float LN2 = 0.69314718055994530942f;
+constexpr int CH = 128;   // rows (keys or queries) staged per LDS chunk
+
+__device__ __forceinline__ int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+__device__ __forceinline__ bf16x8 cvt8(const f32x4 a, const f32x4 b, float mul) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[e] = (__bf16)(a[e] * mul); o[4 + e] = (__bf16)(b[e] * mul); }
+    return o;
+}
+
+// 8 consecutive floats of one row -> bf16x8 (zeros when !valid)
+__device__ __forceinline__ bf16x8 load_frag(const float* __restrict__ p, bool valid, float mul) {
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+    if (valid) { a = *reinterpret_cast<const f32x4*>(p); b = *reinterpret_cast<const f32x4*>(p + 4); }
+    return cvt8(a, b, mul);
+}
+
+// rows [r0, r0 + CH) of a [*, HD] fp32 matrix (row stride ld) -> bf16 LDS tile [CH][HD + 8]
+template <int HD>
+__device__ __forceinline__ void stage_bf16(__bf16* dst, const float* __restrict__ src, long ld, int r0, int N, float mul) {
+    constexpr int LD = HD + 8, V = HD / 4;
+    for (int idx = threadIdx.x; idx < CH * V; idx += 256) {
+        const int row = idx / V, c4 = idx % V;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r0 + row < N) v = *reinterpret_cast<const f32x4*>(src + (long)(r0 + row) * ld + c4 * 4);
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (__bf16)(v[e] * mul);
+        *reinterpret_cast<bf16x4*>(dst + row * LD + c4 * 4) = o;
+    }
+}
+
+// A operand (32 x 16 slice of T^T) for reduction slots (s2, hi, e) <-> rows rowbase + crow(8 s2 + e, hi),
+// output rows i <-> columns colbase + (lane & 31) of the row-major LDS tile T (row stride LD).
+template <int LD>
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16* T, int rowbase, int s2, int colbase, int lane) {
+    const int gg = lane >> 4, li = lane & 15;
+    const int row = rowbase + 16 * s2 + 4 * (gg >> 1) + (li >> 2);
+    const int col = colbase + 16 * (gg & 1) + 4 * (li & 3);
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(T + row * LD + col));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(T + (row + 8) * LD + col));
+    union { s16x4 s[2]; bf16x8 b; } u;
+    u.s[0] = lo; u.s[1] = hi;
+    return u.b;
+}
+
+__device__ __forceinline__ void pack16(const f32x16& p, bf16x8 (&f)[2]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { f[0][e] = (__bf16)p[e]; f[1][e] = (__bf16)p[8 + e]; }
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+
+// ------------------------------------------------------------------------------- forward
+template <int HD>
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ o,
+                                                            float* __restrict__ lse, int N, int H, float scale) {
+    constexpr int LD = HD + 8, NKK = HD / 16, NT = HD / 32;
+    __shared__ __attribute__((aligned(16))) __bf16 Ks[CH * LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Vs[CH * LD];
+    const int b = blockIdx.z, h = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int D = H * HD;
+    const long ld = 3L * D;
+    const float* base = qkv + (long)b * N * ld + h * HD;
+    const int q0 = (blockIdx.x * 4 + wave) * 32, qrow = q0 + l31;
+    const bool qvalid = qrow < N, wave_live = q0 < N;
+    bf16x8 qf[NKK];
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) qf[kk] = load_frag(base + (long)qrow * ld + 16 * kk + 8 * hi, qvalid, scale * LOG2E);
+    f32x16 oacc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) oacc[nt] = zero16();
+    float m = -1e30f, lsum = 0.f;
+    for (int c0 = 0; c0 < N; c0 += CH) {
+        __syncthreads();
+        stage_bf16<HD>(Ks, base + D, ld, c0, N, 1.f);
+        stage_bf16<HD>(Vs, base + 2 * D, ld, c0, N, 1.f);
+        __syncthreads();
+        if (!wave_live) continue;
+        const int kend = min(CH, N - c0);
+        for (int kt = 0; kt * 32 < kend; ++kt) {
+            f32x16 s = zero16();
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(&Ks[(kt * 32 + l31) * LD + 16 * kk + 8 * hi]);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[kk], s, 0, 0, 0);
+            }
+            if (c0 + kt * 32 + 32 > N) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) if (c0 + kt * 32 + crow(r, hi) >= N) s[r] = -1e30f;
+            }
+            float tmax = s[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float mn = fmaxf(m, tmax);
+            const float corr = __builtin_amdgcn_exp2f(m - mn);
+            m = mn;
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - mn); psum += s[r]; }
+            lsum = lsum * corr + psum;
+            bf16x8 pf[2];
+            pack16(s, pf);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[nt][r] *= corr;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8 a = tr_frag<LD>(Vs, kt * 32, s2, 32 * nt, lane);
+                    oacc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pf[s2], oacc[nt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (!wave_live) return;
+    const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+    if (qvalid) {
+        const float inv = 1.f / ltot;
+        float* orow = o + ((long)b * N + qrow) * D + h * HD;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = {oacc[nt][4 * g] * inv, oacc[nt][4 * g + 1] * inv, oacc[nt][4 * g + 2] * inv, oacc[nt][4 * g + 3] * inv};
+                *reinterpret_cast<f32x4*>(orow + 32 * nt + 8 * g + 4 * hi) = v;
+            }
+        if (hi == 0) lse[((long)b * H + h) * N + qrow] = (m + __builtin_amdgcn_logf(ltot)) * LN2;
+    }
+}
+
+// ------------------------------------------------------------------------------- backward: dQ (+ delta)
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
+                                                               const float* __restrict__ d_o, const float* __restrict__ lse,
+                                                               float* __restrict__ dqkv, float* __restrict__ delta,
+                                                               int N, int H, float scale) {
+    constexpr int LD = HD + 8, NKK = HD / 16, NT = HD / 32;
+    __shared__ __attribute__((aligned(16))) __bf16 Ks[CH * LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Vs[CH * LD];
+    const int b = blockIdx.z, h = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int D = H * HD;
+    const long ld = 3L * D;
+    const float* base = qkv + (long)b * N * ld + h * HD;
+    const int q0 = (blockIdx.x * 4 + wave) * 32, qrow = q0 + l31;
+    const bool qvalid = qrow < N, wave_live = q0 < N;
+    bf16x8 qf[NKK], gf[NKK];
+    float dl = 0.f;
+    const float* grow = d_o + ((long)b * N + qrow) * D + h * HD;
+    const float* orow = o + ((long)b * N + qrow) * D + h * HD;
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+        const int c = 16 * kk + 8 * hi;
+        qf[kk] = load_frag(base + (long)qrow * ld + c, qvalid, scale * LOG2E);
+        f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, o0 = g0, o1 = g0;
+        if (qvalid) {
+            g0 = *reinterpret_cast<const f32x4*>(grow + c); g1 = *reinterpret_cast<const f32x4*>(grow + c + 4);
+            o0 = *reinterpret_cast<const f32x4*>(orow + c); o1 = *reinterpret_cast<const f32x4*>(orow + c + 4);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dl += g0[e] * o0[e] + g1[e] * o1[e];
+        gf[kk] = cvt8(g0, g1, 1.f);
+    }
+    dl += __shfl_xor(dl, 32, 64);
+    const float Lq = qvalid ? lse[((long)b * H + h) * N + qrow] * LOG2E : 0.f;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = zero16();
+    for (int c0 = 0; c0 < N; c0 += CH) {
+        __syncthreads();
+        stage_bf16<HD>(Ks, base + D, ld, c0, N, 1.f);
+        stage_bf16<HD>(Vs, base + 2 * D, ld, c0, N, 1.f);
+        __syncthreads();
+        if (!wave_live) continue;
+        const int kend = min(CH, N - c0);
+        for (int kt = 0; kt * 32 < kend; ++kt) {
+            f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                const bf16x8 ak = *reinterpret_cast<const bf16x8*>(&Ks[(kt * 32 + l31) * LD + 16 * kk + 8 * hi]);
+                const bf16x8 av = *reinterpret_cast<const bf16x8*>(&Vs[(kt * 32 + l31) * LD + 16 * kk + 8 * hi]);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ak, qf[kk], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, gf[kk], dp, 0, 0, 0);
+            }
+            const bool tail = c0 + kt * 32 + 32 > N;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float p = __builtin_amdgcn_exp2f(s[r] - Lq);
+                if (tail && c0 + kt * 32 + crow(r, hi) >= N) p = 0.f;
+                s[r] = p * (dp[r] - dl);
+            }
+            bf16x8 dsf[2];
+            pack16(s, dsf);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8 a = tr_frag<LD>(Ks, kt * 32, s2, 32 * nt, lane);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, dsf[s2], acc[nt], 0, 0, 0);
+                }
+        }
+    }
+    if (!wave_live || !qvalid) return;
+    float* out = dqkv + ((long)b * N + qrow) * ld + h * HD;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v = {acc[nt][4 * g] * scale, acc[nt][4 * g + 1] * scale, acc[nt][4 * g + 2] * scale, acc[nt][4 * g + 3] * scale};
+            *reinterpret_cast<f32x4*>(out + 32 * nt + 8 * g + 4 * hi) = v;
+        }
+    if (hi == 0) delta[((long)b * H + h) * N + qrow] = dl;
+}
+
+// ------------------------------------------------------------------------------- backward: dK, dV
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ d_o,
+                                                                const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                float* __restrict__ dqkv, int N, int H, float scale) {
+    constexpr int LD = HD + 8, NKK = HD / 16, NT = HD / 32;
+    __shared__ __attribute__((aligned(16))) __bf16 Qs[CH * LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Gs[CH * LD];
+    __shared__ __attribute__((aligned(16))) float Ls[CH];
+    __shared__ __attribute__((aligned(16))) float Ds[CH];
+    const int b = blockIdx.z, h = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int D = H * HD;
+    const long ld = 3L * D;
+    const float* base = qkv + (long)b * N * ld + h * HD;
+    const int k0 = (blockIdx.x * 4 + wave) * 32, krow = k0 + l31;
+    const bool kvalid = krow < N, wave_live = k0 < N;
+    bf16x8 kf[NKK], vf[NKK];
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+        kf[kk] = load_frag(base + (long)krow * ld + D + 16 * kk + 8 * hi, kvalid, 1.f);
+        vf[kk] = load_frag(base + (long)krow * ld + 2 * D + 16 * kk + 8 * hi, kvalid, 1.f);
+    }
+    f32x16 dk[NT], dv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { dk[nt] = zero16(); dv[nt] = zero16(); }
+    const float* gbase = d_o + (long)b * N * D + h * HD;
+    const float* lrow = lse + ((long)b * H + h) * N;
+    const float* drow = delta + ((long)b * H + h) * N;
+    for (int c0 = 0; c0 < N; c0 += CH) {
+        __syncthreads();
+        stage_bf16<HD>(Qs, base, ld, c0, N, scale * LOG2E);
+        stage_bf16<HD>(Gs, gbase, D, c0, N, 1.f);
+        if (threadIdx.x < CH) {
+            const int q = c0 + threadIdx.x;
+            Ls[threadIdx.x] = q < N ? lrow[q] * LOG2E : 1e30f;   // invalid query -> P = exp2(-huge) = 0
+            Ds[threadIdx.x] = q < N ? drow[q] : 0.f;
+        }
+        __syncthreads();
+        if (!wave_live) continue;
+        const int qend = min(CH, N - c0);
+        for (int qt = 0; qt * 32 < qend; ++qt) {
+            f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                const bf16x8 aq = *reinterpret_cast<const bf16x8*>(&Qs[(qt * 32 + l31) * LD + 16 * kk + 8 * hi]);
+                const bf16x8 ag = *reinterpret_cast<const bf16x8*>(&Gs[(qt * 32 + l31) * LD + 16 * kk + 8 * hi]);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, kf[kk], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ag, vf[kk], dp, 0, 0, 0);
+            }
+            f32x16 p;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 L4 = *reinterpret_cast<const f32x4*>(&Ls[qt * 32 + 8 * g + 4 * hi]);
+                const f32x4 D4 = *reinterpret_cast<const f32x4*>(&Ds[qt * 32 + 8 * g + 4 * hi]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pe = __builtin_amdgcn_exp2f(s[4 * g + e] - L4[e]);
+                    p[4 * g + e] = pe;
+                    s[4 * g + e] = pe * (dp[4 * g + e] - D4[e]);
+                }
+            }
+            bf16x8 pf[2], dsf[2];
+            pack16(p, pf);
+            pack16(s, dsf);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8 ag = tr_frag<LD>(Gs, qt * 32, s2, 32 * nt, lane);
+                    dv[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ag, pf[s2], dv[nt], 0, 0, 0);
+                    const bf16x8 aq = tr_frag<LD>(Qs, qt * 32, s2, 32 * nt, lane);
+                    dk[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, dsf[s2], dk[nt], 0, 0, 0);
+                }
+        }
+    }
+    if (!wave_live || !kvalid) return;
+    float* out = dqkv + ((long)b * N + krow) * ld + h * HD;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d = 32 * nt + 8 * g + 4 * hi;
+            f32x4 vk = {dk[nt][4 * g] * LN2, dk[nt][4 * g + 1] * LN2, dk[nt][4 * g + 2] * LN2, dk[nt][4 * g + 3] * LN2};
+            f32x4 vv = {dv[nt][4 * g], dv[nt][4 * g + 1], dv[nt][4 * g + 2], dv[nt][4 * g + 3]};
+            *reinterpret_cast<f32x4*>(out + D + d) = vk;       // Qs carried scale*log2e: dK = sum dS * scale * Q
+            *reinterpret_cast<f32x4*>(out + 2 * D + d) = vv;
+        }
+}
+
+}  // namespace
+
+// Returns VITAE_ERR_UNSUPPORTED_SHAPE for head dims without an MFMA instantiation (caller falls back
+// to the fp32 VALU kernels of attention.hip — same results to bf16 round-off).
+extern "C" int vitae_sdpa_mfma_fwd(const float* qkv, float* o, float* lse, int B, int N, int H, int head_dim, void* stream) {
+    if (!qkv || !o || !lse || B <= 0 || N <= 0 || H <= 0) return VITAE_ERR_INVALID_ARG;
+    if ((((long)H * head_dim) & 3) || ((uintptr_t)qkv & 15) || ((uintptr_t)o & 15)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    const float scale = 1.0f / sqrtf((float)head_dim);
+    dim3 grid(cdiv(N, 128), H, B);
+    hipStream_t st = (hipStream_t)stream;
+    if (head_dim == 32) hipLaunchKernelGGL((attn_fwd_mfma_kernel<32>), grid, dim3(256), 0, st, qkv, o, lse, N, H, scale);
+    else if (head_dim == 64) hipLaunchKernelGGL((attn_fwd_mfma_kernel<64>), grid, dim3(256), 0, st, qkv, o, lse, N, H, scale);
+    else return VITAE_ERR_UNSUPPORTED_SHAPE;
+    return vitae_launch_status();
+}
+
+extern "C" int vitae_sdpa_mfma_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv,
+                                   float* delta_ws, int B, int N, int H, int head_dim, void* stream) {
+    if (!qkv || !o || !d_o || !lse || !dqkv || !delta_ws || B <= 0 || N <= 0 || H <= 0) return VITAE_ERR_INVALID_ARG;
+    if ((((long)H * head_dim) & 3) || ((uintptr_t)qkv & 15) || ((uintptr_t)o & 15) || ((uintptr_t)d_o & 15) ||
+        ((uintptr_t)dqkv & 15))
+        return VITAE_ERR_UNSUPPORTED_SHAPE;
+    const float scale = 1.0f / sqrtf((float)head_dim);
+    dim3 grid(cdiv(N, 128), H, B);
+    hipStream_t st = (hipStream_t)stream;
+    if (head_dim == 32) {
+        hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<32>), grid, dim3(256), 0, st, qkv, o, d_o, lse, dqkv, delta_ws, N, H, scale);
+        hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<32>), grid, dim3(256), 0, st, qkv, d_o, lse, delta_ws, dqkv, N, H, scale);
+    } else if (head_dim == 64) {
+        hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<64>), grid, dim3(256), 0, st, qkv, o, d_o, lse, dqkv, delta_ws, N, H, scale);
+        hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<64>), grid, dim3(256), 0, st, qkv, d_o, lse, delta_ws, dqkv, N, H, scale);
+    } else {
+        return VITAE_ERR_UNSUPPORTED_SHAPE;
+    }
+    return vitae_launch_status();
+}

@@ -10,6 +10,8 @@
 
 namespace {
 
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
 __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const float* __restrict__ g, long n, double* __restrict__ acc) {
     __shared__ float red[4];
     float s = 0.f;
@@ -31,8 +33,9 @@ __global__ void grad_norm_finalize_kernel(const double* __restrict__ acc, float*
 // torch.optim.AdamW (single-tensor form): p *= 1 - lr*wd; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
 // p -= (lr / bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                    float* __restrict__ v, long n, const float* __restrict__ hp,
-                                                    const float* __restrict__ gnorm, float weight_decay) {
+                                                    float* __restrict__ v, __bf16* __restrict__ shadow, long n,
+                                                    const float* __restrict__ hp, const float* __restrict__ gnorm,
+                                                    float weight_decay) {
     if (gnorm) { const float gn = gnorm[0]; if (!(gn == gn) || fabsf(gn) == INFINITY) return; }
     const float lr = hp[VITAE_HP_LR], b1 = hp[VITAE_HP_BETA1], b2 = hp[VITAE_HP_BETA2], eps = hp[VITAE_HP_EPS];
     const float bc1 = hp[VITAE_HP_BC1], sq_bc2 = sqrtf(hp[VITAE_HP_BC2]);
@@ -54,6 +57,12 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
             pp[e] -= step * (mm[e] / (sqrtf(vv[e]) / sq_bc2 + eps));
         }
         p4[i] = pp; m4[i] = mm; v4[i] = vv;
+        if (shadow) {
+            bf16x4 sh;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sh[e] = (__bf16)pp[e];
+            reinterpret_cast<bf16x4*>(shadow)[i] = sh;
+        }
     }
     if (blockIdx.x == 0) {
         for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) {
@@ -63,6 +72,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
             const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
             pp -= step * (mm / (sqrtf(vv) / sq_bc2 + eps));
             p[i] = pp; m[i] = mm; v[i] = vv;
+            if (shadow) shadow[i] = (__bf16)pp;
         }
     }
 }
@@ -80,22 +90,42 @@ extern "C" int vitae_grad_sqnorm(const float* grads, long n, double* acc, float*
     return vitae_launch_status();
 }
 
-extern "C" int vitae_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n,
-                                const float* hp, const float* grad_norm, float weight_decay, void* stream) {
+extern "C" int vitae_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                                void* shadow_bf16, long n, const float* hp, const float* grad_norm,
+                                float weight_decay, void* stream) {
     if (!params || !grads || !exp_avg || !exp_avg_sq || !hp || n <= 0) return VITAE_ERR_INVALID_ARG;
     if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return VITAE_ERR_INVALID_ARG;
+    if ((uintptr_t)shadow_bf16 & 7) return VITAE_ERR_INVALID_ARG;
     long blocks = (n / 4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(adamw_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
-                       exp_avg_sq, n, hp, grad_norm, weight_decay);
+                       exp_avg_sq, reinterpret_cast<__bf16*>(shadow_bf16), n, hp, grad_norm, weight_decay);
     return vitae_launch_status();
 }
 
+namespace {
+// Own fill kernel instead of hipMemsetAsync: as a captured graph memset node the latter left a few words
+// of a 787 KB region unwritten on ROCm 7.2 (seen as garbage in the cls_token gradient under graph replay).
+__global__ __launch_bounds__(256) void zero_kernel(unsigned int* __restrict__ p, long nwords) {
+    const long n4 = nwords / 4;
+    u32x4_t* p4 = reinterpret_cast<u32x4_t*>(p);
+    const u32x4_t z = {0u, 0u, 0u, 0u};
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) p4[i] = z;
+    if (blockIdx.x == 0) for (long i = n4 * 4 + threadIdx.x; i < nwords; i += 256) p[i] = 0u;
+}
+}  // namespace
+
 extern "C" int vitae_memset_zero(void* ptr, long bytes, void* stream) {
-    if (!ptr || bytes < 0) return VITAE_ERR_INVALID_ARG;
+    if (!ptr || bytes < 0 || (bytes & 3) || ((uintptr_t)ptr & 15)) return VITAE_ERR_INVALID_ARG;
     if (bytes == 0) return VITAE_OK;
-    return hipMemsetAsync(ptr, 0, (size_t)bytes, (hipStream_t)stream) == hipSuccess ? VITAE_OK : VITAE_ERR_LAUNCH;
+    const long nwords = bytes / 4;
+    long blocks = (nwords / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(zero_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<unsigned int*>(ptr), nwords);
+    return vitae_launch_status();
 }
 
 extern "C" int vitae_abi_version(void) { return VITAE_ABI_VERSION; }

@@ -177,6 +177,21 @@ class HipMAEEngine:
             self.p[n] = self.params[o:o + k].view(shp)
             self.g[n] = self.grads[o:o + k].view(shp)
             self.p[n].copy_(params[n].detach().to(device=dev, dtype=torch.float32))
+        # bf16 weight shadow for the throughput-mode GEMMs (kept current by the fused AdamW kernel;
+        # any other in-place change of the fp32 arena bumps its torch version counter -> re-cast)
+        self.params16, self.p16, self._shadow_version = None, {}, None
+        if self.prec == PREC['bf16']:
+            self.params16 = torch.zeros(off, dtype=torch.bfloat16, device=dev)
+            for n, (o, shp) in self.layout.items():
+                self.p16[n] = self.params16[o:o + int(np.prod(shp))].view(shp)
+
+    def refresh_shadow(self, force: bool = False):
+        if self.params16 is None:
+            return
+        if force or self._shadow_version != self.params._version:
+            lib.vitae_cast_bf16(self.params.data_ptr(), self.params16.data_ptr(), self.n_total,
+                                torch.cuda.current_stream(self.device).cuda_stream)
+            self._shadow_version = self.params._version
 
     # ------------------------------------------------------------------ hyper-parameters
     def set_hparams(self, **kw):
@@ -255,11 +270,18 @@ class HipMAEEngine:
         key = (M, N, K)
         s = self._split_cache.get(key)
         if s is None:
-            s = lib.vitae_gemm_pick_split_k(M, N, K)
+            s = (lib.vitae_gemm_bf16_pick_split_k if self.prec == PREC['bf16'] else lib.vitae_gemm_pick_split_k)(M, N, K)
             while s > 1 and s * M * N > self.ws.numel():
                 s -= 1
             self._split_cache[key] = s
         return s
+
+    def _w16(self, w):
+        """Device pointer of the bf16 shadow of arena weight ``w`` (0 when ``w`` is not an arena tensor)."""
+        off = w.data_ptr() - self.params.data_ptr()
+        if self.params16 is None or off < 0 or off >= self.n_total * 4:
+            return 0
+        return self.params16.data_ptr() + off // 2
 
     def _timed(self, flops):
         if self.gemm_timer is None:
@@ -272,24 +294,38 @@ class HipMAEEngine:
     def _lin_fwd(self, x, w, bias, y, M, N, K, epi=EPI_NONE, aux=None, res=None):
         s = 1 if epi == EPI_GELU else self._split(M, N, K)
         t = self._timed(2.0 * M * N * K)
-        lib.vitae_linear_fwd(self.prec, _ptr(x), _ptr(w), _ptr(bias), _ptr(y), M, N, K, epi, _ptr(aux), _ptr(res), s,
-                             self.ws.data_ptr(), self.stream)
+        if self.prec == PREC['bf16']:
+            w16 = self._w16(w)
+            lib.vitae_gemm_bf16(1, 1, _ptr(x), K, w16 if w16 else _ptr(w), K, 1 if w16 else 0, _ptr(y), N, M, N, K,
+                                _ptr(bias), _ptr(res), N, epi, _ptr(aux), N, 0, s, self.ws.data_ptr(), self.stream)
+        else:
+            lib.vitae_linear_fwd(self.prec, _ptr(x), _ptr(w), _ptr(bias), _ptr(y), M, N, K, epi, _ptr(aux), _ptr(res), s,
+                                 self.ws.data_ptr(), self.stream)
         if t is not None:
             t.record()
 
     def _lin_bwd_x(self, dy, w, dx, M, N, K, epi=EPI_NONE, aux=None, accumulate=0):
         s = self._split(M, K, N)
         t = self._timed(2.0 * M * N * K)
-        lib.vitae_linear_bwd_input(self.prec, _ptr(dy), _ptr(w), _ptr(dx), M, N, K, epi, _ptr(aux), accumulate, s,
-                                   self.ws.data_ptr(), self.stream)
+        if self.prec == PREC['bf16']:
+            w16 = self._w16(w)
+            lib.vitae_gemm_bf16(1, 0, _ptr(dy), N, w16 if w16 else _ptr(w), K, 1 if w16 else 0, _ptr(dx), K, M, K, N,
+                                None, None, 0, epi, _ptr(aux), K, accumulate, s, self.ws.data_ptr(), self.stream)
+        else:
+            lib.vitae_linear_bwd_input(self.prec, _ptr(dy), _ptr(w), _ptr(dx), M, N, K, epi, _ptr(aux), accumulate, s,
+                                       self.ws.data_ptr(), self.stream)
         if t is not None:
             t.record()
 
     def _lin_bwd_w(self, dy, x, dw, db, M, N, K):
         s = self._split(N, K, M)
         t = self._timed(2.0 * M * N * K)
-        lib.vitae_linear_bwd_weight(self.prec, _ptr(dy), _ptr(x), _ptr(dw), M, N, K, int(self._accum), s,
-                                    self.ws.data_ptr(), self.stream)
+        if self.prec == PREC['bf16']:
+            lib.vitae_gemm_bf16(0, 0, _ptr(dy), N, _ptr(x), K, 0, _ptr(dw), K, N, K, M, None, None, 0, EPI_NONE, None, 0,
+                                int(self._accum), s, self.ws.data_ptr(), self.stream)
+        else:
+            lib.vitae_linear_bwd_weight(self.prec, _ptr(dy), _ptr(x), _ptr(dw), M, N, K, int(self._accum), s,
+                                        self.ws.data_ptr(), self.stream)
         if t is not None:
             t.record()
         if db is not None:
@@ -310,7 +346,8 @@ class HipMAEEngine:
         b, p, M = self.buf, self.p, Bs * N
         self._ln_fwd(x_in, pre + 'norm1.', b[q + 'y1'], b[q + 'mean1'], b[q + 'rstd1'], M, d)
         self._lin_fwd(b[q + 'y1'], p[pre + 'attn.qkv.weight'], p[pre + 'attn.qkv.bias'], b[q + 'qkv'], M, 3 * d, d)
-        lib.vitae_sdpa_fwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(b[q + 'lse']), Bs, N, heads, hd, self.stream)
+        sdpa_fwd = lib.vitae_sdpa_mfma_fwd if (self.prec == PREC['bf16'] and hd in (32, 64)) else lib.vitae_sdpa_fwd
+        sdpa_fwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(b[q + 'lse']), Bs, N, heads, hd, self.stream)
         self._lin_fwd(b[q + 'o'], p[pre + 'attn.proj.weight'], p[pre + 'attn.proj.bias'], b[q + 'xmid'], M, d, d,
                       res=x_in)
         self._ln_fwd(b[q + 'xmid'], pre + 'norm2.', b[q + 'y2'], b[q + 'mean2'], b[q + 'rstd2'], M, d)
@@ -333,8 +370,9 @@ class HipMAEEngine:
         # attn.proj
         self._lin_bwd_w(dx, b[q + 'o'], g[pre + 'attn.proj.weight'], g[pre + 'attn.proj.bias'], M, d, d)
         self._lin_bwd_x(dx, p[pre + 'attn.proj.weight'], do, M, d, d)
-        lib.vitae_sdpa_bwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(do), _ptr(b[q + 'lse']), _ptr(dqkv),
-                           _ptr(b['delta']), Bs, N, heads, hd, self.stream)
+        sdpa_bwd = lib.vitae_sdpa_mfma_bwd if (self.prec == PREC['bf16'] and hd in (32, 64)) else lib.vitae_sdpa_bwd
+        sdpa_bwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(do), _ptr(b[q + 'lse']), _ptr(dqkv),
+                 _ptr(b['delta']), Bs, N, heads, hd, self.stream)
         # attn.qkv
         self._lin_bwd_w(dqkv, b[q + 'y1'], g[pre + 'attn.qkv.weight'], g[pre + 'attn.qkv.bias'], M, 3 * d, d)
         self._lin_bwd_x(dqkv, p[pre + 'attn.qkv.weight'], dy, M, 3 * d, d)
@@ -362,6 +400,7 @@ class HipMAEEngine:
         if tuple(noise.shape) != (Be, L) or noise.dtype != torch.float32 or not noise.is_contiguous():
             raise VitaeError(f'noise must be contiguous fp32 [{Be},{L}]')
         self.view1 = view1
+        self.refresh_shadow()
         lib.vitae_memset_zero(self.acc.data_ptr(), self.acc.numel() * 8, st)
         # --- masking, kept-patch gather, patch embedding, sequence assembly
         lib.vitae_random_masking(_ptr(noise), _ptr(b['ids_shuffle']), _ptr(b['ids_restore']), _ptr(b['mask']),
@@ -534,11 +573,14 @@ class HipMAEEngine:
         gn = self.losses.data_ptr() + 20
         lib.vitae_grad_sqnorm(self.grads.data_ptr(), self.n_total, _ptr(self.acc), gn, st)
         s = self.opt_state
+        sh = self.params16.data_ptr() if self.params16 is not None else 0
         lib.vitae_adamw_step(self.params.data_ptr(), self.grads.data_ptr(), s['exp_avg'].data_ptr(),
-                             s['exp_avg_sq'].data_ptr(), self.vec_off, _ptr(self.hp), gn, self.weight_decay, st)
+                             s['exp_avg_sq'].data_ptr(), sh if sh else None, self.vec_off, _ptr(self.hp), gn,
+                             self.weight_decay, st)
         o = self.vec_off * 4
         lib.vitae_adamw_step(self.params.data_ptr() + o, self.grads.data_ptr() + o, s['exp_avg'].data_ptr() + o,
-                             s['exp_avg_sq'].data_ptr() + o, self.n_total - self.vec_off, _ptr(self.hp), gn, 0.0, st)
+                             s['exp_avg_sq'].data_ptr() + o, (sh + o // 2) if sh else None, self.n_total - self.vec_off,
+                             _ptr(self.hp), gn, 0.0, st)
 
     # ------------------------------------------------------------------ fused training step
     N_PHASES = 4

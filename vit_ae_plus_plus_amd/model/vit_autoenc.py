@@ -132,6 +132,7 @@ class _StepRunner:
         for t, s in zip(keep, snap):
             t.copy_(s)
         eng.opt_step = step
+        eng.refresh_shadow(force=True)     # restoring bumped the arena's version: re-cast now, not inside the graph
         torch.cuda.synchronize(eng.device)
         self.graphs = []
         for grp in groups:

@@ -243,7 +243,7 @@ def engine_grad_norm(engine) -> torch.Tensor:
     """L2 norm of the whole gradient arena by ``vitae_grad_sqnorm`` -> 0-dim device tensor."""
     from .._abi import lib
     st = torch.cuda.current_stream(engine.device).cuda_stream
-    lib.vitae_memset_zero(engine.acc.data_ptr() + 8 * 3, 8, st)
+    lib.vitae_memset_zero(engine.acc.data_ptr(), engine.acc.numel() * 8, st)   # scalars were already read out
     lib.vitae_grad_sqnorm(engine.grads.data_ptr(), engine.n_total, engine.acc.data_ptr(),
                           engine.losses.data_ptr() + 20, st)
     return engine.losses[5]
