@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITAE_ABI_VERSION 3
+#define VITAE_ABI_VERSION 6
 
 /* matrix-core arithmetic of the dense contractions */
 #define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
@@ -75,11 +75,26 @@ long vitae_gemm_workspace_floats(int M, int N, int K, int split_k);
 int vitae_gemm_pick_split_k(int M, int N, int K);
 
 /* Throughput-mode variant (bf16 MFMA, fp32 accumulate): A fp32, B fp32 or a bf16 shadow (b_is_bf16);
- * pipelined 64 x {64,128} x 64 tiles, transpose reads for row-contiguous operands, XCD-aware order. */
+ * 64 x {64,128} tiles with deep k-phases, transpose reads for row-contiguous operands, XCD-aware order.
+ * a_colsum_accum (optional, A k-contiguous): a_colsum_accum[k] += sum_m A(m,k) — the bias gradient of a
+ * Linear computed while its dgrad streams dy. */
 int vitae_gemm_bf16(int a_kcontig, int b_kcontig, const float* A, long lda, const void* B, long ldb, int b_is_bf16,
                     float* C, long ldc, int M, int N, int K, const float* bias, const float* residual, long ldr,
-                    int epi, float* aux, long ldaux, int accumulate, int split_k, float* splitk_ws, void* stream);
+                    int epi, float* aux, long ldaux, int accumulate, int split_k, float* splitk_ws,
+                    float* a_colsum_accum, void* stream);
 int vitae_gemm_bf16_pick_split_k(int M, int N, int K);
+/* Backward of one nn.Linear in a single launch (dgrad + wgrad + bias grad), bf16 MFMA:
+ * dx[M,K] (+)= epi(dy[M,N] W[N,K]) (W from its bf16 shadow), dW[N,K] (+)= dy^T x, db[N] += colsum(dy). */
+int vitae_linear_bwd_pair_bf16(const float* dy, const void* w_bf16, const float* x, float* dx, float* dw,
+                               float* db_accum, int M, int N, int K, int epi, float* aux, int dx_accumulate,
+                               int dw_accumulate, void* stream);
+/* bf16 x bf16 variant with a 4-stage LDS-DMA (global_load_lds) pipeline; A16/B16 bf16, K % 64 == 0;
+ * C (fp32) and/or C16 (bf16 copy of the result) may be given. */
+int vitae_gemm_glds(int a_kcontig, int b_kcontig, const void* A16, long lda, const void* B16, long ldb, float* C,
+                    long ldc, void* C16, long ldc16, int M, int N, int K, const float* bias, const float* residual,
+                    long ldr, int epi, float* aux, long ldaux, int accumulate, int split_k, float* splitk_ws,
+                    void* stream);
+int vitae_gemm_glds_pick_split_k(int M, int N, int K);
 /* dst_bf16[i] = bf16(src[i]) (round to nearest even) */
 int vitae_cast_bf16(const float* src, void* dst_bf16, long n, void* stream);
 

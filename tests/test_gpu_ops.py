@@ -123,29 +123,48 @@ def test_gemm_bf16_pipeline(lib, C, b16, M, N, K):
     for split in (1, lib.vitae_gemm_bf16_pick_split_k(M, N, K)):
         y = torch.full((M, N), float('nan'), device='cuda')
         lib.vitae_gemm_bf16(1, 1, xd.data_ptr(), K, wp.data_ptr(), K, b16, y.data_ptr(), N, M, N, K, bd.data_ptr(), rd.data_ptr(),
-                            N, 0, None, 0, 0, split, ws.data_ptr(), st())
+                            N, 0, None, 0, 0, split, ws.data_ptr(), None, st())
         assert rel_err(y, F.linear(x, w, b) + res) < tol, f'fwd split {split}'
     y, aux = torch.empty(M, N, device='cuda'), torch.empty(M, N, device='cuda')
     lib.vitae_gemm_bf16(1, 1, xd.data_ptr(), K, wp.data_ptr(), K, b16, y.data_ptr(), N, M, N, K, bd.data_ptr(), None, 0,
-                        C['VITAE_EPI_GELU'], aux.data_ptr(), N, 0, 1, None, st())
+                        C['VITAE_EPI_GELU'], aux.data_ptr(), N, 0, 1, None, None, st())
     pre = F.linear(x, w, b)
     assert rel_err(aux, pre) < tol and rel_err(y, F.gelu(pre)) < tol
     dy = gen(M, N, seed=5)
     dyd = dev(dy)
     dx = torch.full((M, K), float('nan'), device='cuda')
     split = lib.vitae_gemm_bf16_pick_split_k(M, K, N)
+    db = torch.zeros(N, device='cuda')
     lib.vitae_gemm_bf16(1, 0, dyd.data_ptr(), N, wp.data_ptr(), K, b16, dx.data_ptr(), K, M, K, N, None, None, 0, 0, None, 0, 0,
-                        split, ws.data_ptr(), st())
+                        split, ws.data_ptr(), db.data_ptr(), st())
     assert rel_err(dx, dy @ w) < tol, 'dgrad'
+    assert rel_err(db, dy.sum(0)) < 2e-5, 'bias gradient riding on the dgrad'
     if not b16:
         dw = torch.full((N, K), float('nan'), device='cuda')
         split = lib.vitae_gemm_bf16_pick_split_k(N, K, M)
         lib.vitae_gemm_bf16(0, 0, dyd.data_ptr(), N, xd.data_ptr(), K, 0, dw.data_ptr(), K, N, K, M, None, None, 0, 0, None, 0, 0,
-                            split, ws.data_ptr(), st())
+                            split, ws.data_ptr(), None, st())
         assert rel_err(dw, dy.t() @ x) < tol, 'wgrad'
         lib.vitae_gemm_bf16(0, 0, dyd.data_ptr(), N, xd.data_ptr(), K, 0, dw.data_ptr(), K, N, K, M, None, None, 0, 0, None, 0, 1,
-                            1, None, st())
+                            1, None, None, st())
         assert rel_err(dw, 2 * (dy.t() @ x)) < tol, 'wgrad accumulate'
+
+
+@pytest.mark.parametrize('M,N,K', [(440, 2304, 768), (868, 512, 2048), (440, 768, 3072), (37, 48, 128), (868, 16384, 512)])
+def test_linear_bwd_pair_bf16(lib, C, M, N, K):
+    """dgrad + wgrad + bias grad of one Linear in a single launch."""
+    x, w, dy, h = gen(M, K, seed=1), gen(N, K, seed=2, scale=K ** -0.5), gen(M, N, seed=5), gen(M, K, seed=6)
+    xd, wd, dyd, hd_ = dev(x), dev(w), dev(dy), dev(h)
+    w16 = wd.to(torch.bfloat16); _KEEP.append(w16)
+    dx, dw, db = torch.full((M, K), float('nan'), device='cuda'), torch.full((N, K), float('nan'), device='cuda'), torch.zeros(N, device='cuda')
+    lib.vitae_linear_bwd_pair_bf16(dyd.data_ptr(), w16.data_ptr(), xd.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), M, N, K,
+                                   C['VITAE_EPI_DGELU'], hd_.data_ptr(), 0, 0, st())
+    hh = h.clone().requires_grad_(True)
+    F.gelu(hh).backward(dy @ w)
+    assert rel_err(dx, hh.grad) < 2e-2 and rel_err(dw, dy.t() @ x) < 2e-2 and rel_err(db, dy.sum(0)) < 2e-5
+    lib.vitae_linear_bwd_pair_bf16(dyd.data_ptr(), w16.data_ptr(), xd.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), M, N, K,
+                                   0, None, 1, 1, st())
+    assert rel_err(dx, hh.grad + dy @ w) < 2e-2 and rel_err(dw, 2 * (dy.t() @ x)) < 2e-2
 
 
 def test_gemm_bf16_asymmetric(lib):
@@ -154,13 +173,13 @@ def test_gemm_bf16_asymmetric(lib):
     ad, bd = dev(a), dev(b)
     y = torch.empty(64, 64, device='cuda')
     lib.vitae_gemm_bf16(1, 1, ad.data_ptr(), 64, bd.data_ptr(), 64, 0, y.data_ptr(), 64, 64, 64, 64, None, None, 0, 0, None, 0, 0, 1,
-                        None, st())
+                        None, None, st())
     assert rel_err(y, b.t()) < 5e-3
     lib.vitae_gemm_bf16(1, 0, ad.data_ptr(), 64, bd.data_ptr(), 64, 0, y.data_ptr(), 64, 64, 64, 64, None, None, 0, 0, None, 0, 0, 1,
-                        None, st())
+                        None, None, st())
     assert rel_err(y, b) < 5e-3          # B read as (k, n): y = I @ b
     lib.vitae_gemm_bf16(0, 0, bd.data_ptr(), 64, ad.data_ptr(), 64, 0, y.data_ptr(), 64, 64, 64, 64, None, None, 0, 0, None, 0, 0, 1,
-                        None, st())
+                        None, None, st())
     assert rel_err(y, b.t()) < 5e-3      # A read as (m, k) = b[k, m]: y = b^T @ I
 
 

@@ -1,0 +1,93 @@
+"""Micro-benchmark of vitae_gemm_bf16 on the GEMM shapes of BASELINE config 2 (B=4, contrastive)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from vit_ae_plus_plus_amd._abi import lib
+
+def graph_time(go, iters):
+    """GPU time per launch with the launches replayed from a HIP graph (eager python launches are host bound)."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        for _ in range(iters): go_on_current(go)
+    g.replay(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); g.replay(); g.replay(); e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (2 * iters) * 1e3
+
+
+def go_on_current(go):
+    go()
+
+
+def run(name, form, M, N, K, b16, iters=50):
+    """form: 'fwd' (A[M,K] kc, B[N,K] kc), 'dgrad' (A[M,K] kc, B stored [K,N] row-contig), 'wgrad' (A stored [K,M], B stored [K,N])."""
+    dev = 'cuda'
+    akc, bkc = {'fwd': (1, 1), 'dgrad': (1, 0), 'wgrad': (0, 0)}[form]
+    A = torch.randn((M, K) if akc else (K, M), device=dev)
+    Bt = torch.randn((N, K) if bkc else (K, N), device=dev)
+    Bp = Bt.to(torch.bfloat16) if b16 else Bt
+    C = torch.empty(M, N, device=dev)
+    ws = torch.empty(1 << 24, device=dev)
+    lda = K if akc else M
+    ldb = K if bkc else N
+    split = lib.vitae_gemm_bf16_pick_split_k(M, N, K)
+    def go():
+        lib.vitae_gemm_bf16(akc, bkc, A.data_ptr(), lda, Bp.data_ptr(), ldb, b16, C.data_ptr(), N, M, N, K, None, None, 0, 0, None, 0, 0,
+                            split, ws.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+    for _ in range(5): go()
+    torch.cuda.synchronize()
+    us = graph_time(go, iters)
+    print(f'{name:28s} {form:5s} M={M:5d} N={N:5d} K={K:5d} b16={b16} split={split:2d}  {us:8.1f} us  {2.0*M*N*K/us/1e6:7.1f} TF/s')
+    return us
+
+def run_glds(name, form, M, N, K, iters=50, check=True):
+    dev = 'cuda'
+    akc, bkc = {'fwd': (1, 1), 'dgrad': (1, 0), 'wgrad': (0, 0)}[form]
+    Kp = (K + 63) // 64 * 64
+    A = torch.zeros((M, Kp) if akc else (Kp, M), device=dev)
+    Bt = torch.zeros((N, Kp) if bkc else (Kp, N), device=dev)
+    if akc: A[:, :K] = torch.randn(M, K, device=dev)
+    else: A[:K] = torch.randn(K, M, device=dev)
+    if bkc: Bt[:, :K] = torch.randn(N, K, device=dev)
+    else: Bt[:K] = torch.randn(K, N, device=dev)
+    A16, B16 = A.to(torch.bfloat16), Bt.to(torch.bfloat16)
+    C = torch.full((M, N), float('nan'), device=dev)
+    ws = torch.empty(1 << 24, device=dev)
+    lda = Kp if akc else M
+    ldb = Kp if bkc else N
+    split = lib.vitae_gemm_glds_pick_split_k(M, N, Kp)
+    def go():
+        lib.vitae_gemm_glds(akc, bkc, A16.data_ptr(), lda, B16.data_ptr(), ldb, C.data_ptr(), N, None, 0, M, N, Kp, None, None, 0, 0,
+                            None, 0, 0, split, ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    for _ in range(5): go()
+    torch.cuda.synchronize()
+    err = ''
+    if check:
+        Af = A16.float() if akc else A16.float().t()
+        Bf = B16.float() if bkc else B16.float().t()
+        ref = Af @ Bf.t()
+        e = float((C - ref).abs().max() / (ref.abs().max() + 1e-20))
+        err = f' relerr {e:.1e}' + (' !!!' if not (e < 2e-3) else '')
+    us = graph_time(go, iters)
+    print(f'GLDS {name:24s} {form:5s} M={M:5d} N={N:5d} K={K:5d} split={split:2d}  {us:8.1f} us  {2.0*M*N*K/us/1e6:7.1f} TF/s{err}')
+    return us
+
+
+if __name__ == '__main__':
+    glds = len(sys.argv) > 1 and sys.argv[1] == 'glds'
+    tot = 0.0
+    E, D_ = 440, 868
+    shapes = []
+    for (nm, M, d, h, cnt) in (('enc', 440, 768, 3072, 12), ('dec', 868, 512, 2048, 8)):
+        for (n2, N, K) in (('qkv', 3 * d, d), ('proj', d, d), ('fc1', h, d), ('fc2', d, h)):
+            shapes.append((f'{nm}.{n2}', 'fwd', M, N, K, 1, cnt))
+            shapes.append((f'{nm}.{n2}', 'dgrad', M, K, N, 1, cnt))
+            shapes.append((f'{nm}.{n2}', 'wgrad', N, K, M, 0, cnt))
+    shapes += [('patch_embed', 'fwd', 432, 768, 16384, 1, 1), ('patch_embed', 'wgrad', 768, 16384, 432, 0, 1),
+               ('pred', 'fwd', 868, 16384, 512, 1, 1), ('pred', 'dgrad', 868, 512, 16384, 1, 1), ('pred', 'wgrad', 16384, 512, 868, 0, 1),
+               ('dec_embed', 'fwd', 220, 512, 768, 1, 1), ('predictor', 'fwd', 440, 768, 768, 1, 2)]
+    for nm, form, M, N, K, b16, cnt in shapes:
+        tot += cnt * (run_glds(nm, form, M, N, K) if glds else run(nm, form, M, N, K, b16))
+    print(f'weighted total {tot/1e3:.3f} ms per step')

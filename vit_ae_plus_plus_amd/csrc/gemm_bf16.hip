@@ -6,14 +6,15 @@
 // Operand storage flags as in gemm.hip (*_KC: element (row,k) at ptr[row*ld + k], else ptr[k*ld + row]).
 //
 // MI355X-specific structure
-//  * tiles 64 x BN (BN = 128 or 64), BK = 64, 4 waves (2 x 2), wave tile 32 x BN/2: M is only
-//    ~440-870 rows on this path, so small M tiles keep >100 workgroups in flight;
+//  * tiles 64 x 64 (BK 256) or 64 x 128 (BK 128), 4 waves (2 x 2), wave tile 32 x BN/2: M is only
+//    ~440-870 rows on this path, so small M tiles keep >=256 workgroups in flight;
 //  * LDS images keep the GLOBAL orientation of each operand (no transposing stores): k-contiguous
 //    tiles are read with ds_read_b128, row-contiguous tiles (dgrad's W, both wgrad operands) with the
 //    hardware transpose read ds_read_b64_tr_b16 — no transposed copies of weights or activations exist;
 //    row strides are padded (+8 / +16 elements) so both read kinds are bank-conflict free;
-//  * the K loop is latency bound at these sizes, so global loads run TWO k-tiles ahead of the MFMAs
-//    (two register sets + double-buffered LDS, one barrier per k-tile);
+//  * the K loop is latency bound at these sizes (a CU fetches ~bytes-in-flight / ~1.2 us), so a k-tile is
+//    a deep "phase": up to ~100 KB of 16-byte loads per workgroup in flight while the previous phase's
+//    MFMAs run from LDS (single register set + single LDS buffer, two barriers per phase);
 //  * workgroup ids are remapped so that all M-tiles of one weight panel run on the same XCD (its L2
 //    then serves the panel to the 7-14 workgroups that share it);
 //  * split-K partials go to a workspace and are reduced deterministically (shared with gemm.hip).
@@ -24,7 +25,7 @@ namespace {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-constexpr int BM = 64, BK = 64;
+constexpr int BM = 64;
 
 struct GemmArgs {
     const float* A; long lda;
@@ -37,6 +38,7 @@ struct GemmArgs {
     float* aux; long ldaux;
     int epi, accumulate;
     float* ws;
+    float* colsum;   // optional: colsum[k] += sum_m A(m,k)  (bias gradient riding on the dgrad's A tiles)
     int tiles_m, tiles_n, n_per_xcd;
 };
 
@@ -63,14 +65,19 @@ __host__ __device__ constexpr int ld_pad(int n) { return n == 128 ? n + 16 : n +
 
 // ---------------------------------------------------------------- operand staging
 // One operand tile = ROWS rows x BK k.  Per thread NPIECE 16-byte global pieces.
-template <int ROWS, bool KC, bool BF16> struct Stage {
+template <int ROWS, int BK, bool KC, bool BF16> struct Stage {
     static constexpr int EPP = BF16 ? 8 : 4;                       // elements per 16-byte piece
     static constexpr int NPIECE = ROWS * BK / EPP / 256;
-    static constexpr int LD = KC ? ld_pad(BK) : ld_pad(ROWS);      // LDS row stride in bf16 elements
+    static constexpr int LD = KC ? BK + 8 : ld_pad(ROWS);          // LDS row stride in bf16 elements (conflict-free)
     static constexpr int BYTES = (KC ? ROWS : BK) * LD * 2;
     u32x4 r[NPIECE];
+    unsigned ok;   // bit j: piece j is inside the operand (others are zero-filled at store time)
 
+    // Loads are UNCONDITIONAL (indices clamped into the operand) and the zero-fill of out-of-range
+    // pieces happens in store(): a per-piece `if (inside) load` makes hipcc branch around every load and
+    // drain vmcnt(0) each k-tile, which serialises the whole prefetch pipeline (measured: 17 us floor).
     __device__ __forceinline__ void load(const void* __restrict__ P, long ld, int rows, int r0, int k0, int kend) {
+        ok = 0u;
 #pragma unroll
         for (int j = 0; j < NPIECE; ++j) {
             const int p = threadIdx.x + 256 * j;
@@ -78,13 +85,30 @@ template <int ROWS, bool KC, bool BF16> struct Stage {
             if (KC) { row = p / (BK / EPP); k = (p % (BK / EPP)) * EPP; }
             else { k = p / (ROWS / EPP); row = (p % (ROWS / EPP)) * EPP; }
             const int gr = r0 + row, gk = k0 + k;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (gr < rows && gk < kend) {
-                const long off = KC ? ((long)gr * ld + gk) : ((long)gk * ld + gr);
-                v = BF16 ? *reinterpret_cast<const u32x4*>(reinterpret_cast<const __bf16*>(P) + off)
-                         : *reinterpret_cast<const u32x4*>(reinterpret_cast<const float*>(P) + off);
-            }
-            r[j] = v;
+            ok |= (gr < rows && gk < kend) ? (1u << j) : 0u;
+            // clamp to the last in-range piece (kend and rows are multiples of the piece width)
+            const int cr = min(gr, rows - (KC ? 1 : EPP)), ck = min(gk, kend - (KC ? EPP : 1));
+            const long off = KC ? ((long)cr * ld + ck) : ((long)ck * ld + cr);
+            r[j] = BF16 ? *reinterpret_cast<const u32x4*>(reinterpret_cast<const __bf16*>(P) + off)
+                        : *reinterpret_cast<const u32x4*>(reinterpret_cast<const float*>(P) + off);
+        }
+    }
+
+    // colsum[k0 + k] += sum over this tile's rows of the fp32 operand (k-contiguous fp32 tiles only).
+    // Every piece of a thread has the same k (piece stride 256 is a multiple of the pieces per row).
+    __device__ __forceinline__ void colsum_accumulate(float* __restrict__ out, int k0, int kend) const {
+        static_assert(!BF16, "column sums ride on fp32 tiles");
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NPIECE; ++j) {
+            union { u32x4 u; f32x4 f; } in;
+            in.u = r[j];
+            if ((ok >> j) & 1u) s += in.f;
+        }
+        const int k = k0 + (threadIdx.x % (BK / EPP)) * EPP;
+        if (k < kend) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(out + k + e, s[e]);
         }
     }
 
@@ -96,11 +120,14 @@ template <int ROWS, bool KC, bool BF16> struct Stage {
             if (KC) { row = p / (BK / EPP); k = (p % (BK / EPP)) * EPP; }
             else { k = p / (ROWS / EPP); row = (p % (ROWS / EPP)) * EPP; }
             __bf16* dst = KC ? (lds + row * LD + k) : (lds + k * LD + row);
+            const bool inside = (ok >> j) & 1u;
+            u32x4 v = r[j];
+            if (!inside) v = u32x4{0u, 0u, 0u, 0u};
             if (BF16) {
-                *reinterpret_cast<u32x4*>(dst) = r[j];
+                *reinterpret_cast<u32x4*>(dst) = v;
             } else {
                 union { u32x4 u; f32x4 f; } in;
-                in.u = r[j];
+                in.u = v;
                 bf16x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (__bf16)in.f[e];
@@ -127,19 +154,23 @@ __device__ __forceinline__ bf16x8 frag(const __bf16* T, int row0, int kk, int la
     }
 }
 
-template <int BN, bool A_KC, bool B_KC, bool B_BF16>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs p) {
-    using SA = Stage<BM, A_KC, false>;
-    using SB = Stage<BN, B_KC, B_BF16>;
+template <int BN, int BK, bool A_KC, bool B_KC, bool B_BF16> struct TileCfg {
+    using SA = Stage<BM, BK, A_KC, false>;
+    using SB = Stage<BN, BK, B_KC, B_BF16>;
+    static constexpr int SMEM = SA::BYTES + SB::BYTES;
+};
+
+template <int BN, int BK, bool A_KC, bool B_KC, bool B_BF16>
+__device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, const int zid, unsigned char* smem) {
+    using SA = Stage<BM, BK, A_KC, false>;
+    using SB = Stage<BN, BK, B_KC, B_BF16>;
     constexpr int FN = BN / 64;                         // 32-col fragments per wave (wave tile 32 x BN/2)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (SA::BYTES + SB::BYTES)];
     // XCD-aware tile order: hardware places workgroup b on XCD b % 8; give each XCD whole weight panels.
-    const int bid = blockIdx.x;
     const int xcd = bid & 7, local = bid >> 3;
     const int tn = xcd + 8 * (local / p.tiles_m), tm = local % p.tiles_m;
     if (tn >= p.tiles_n) return;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int kbeg = blockIdx.z * p.k_per_split;
+    const int kbeg = zid * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
     const int nk = (kend - kbeg + BK - 1) / BK;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -152,13 +183,29 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[f][i] = 0.f;
 
-    SA a0, a1;
-    SB b0, b1;
-    auto As = [&](int s) { return reinterpret_cast<__bf16*>(smem + s * (SA::BYTES + SB::BYTES)); };
-    auto Bs = [&](int s) { return reinterpret_cast<__bf16*>(smem + s * (SA::BYTES + SB::BYTES) + SA::BYTES); };
-    auto compute = [&](int s) {
-        const __bf16* at = As(s);
-        const __bf16* bt = Bs(s);
+    // One k-tile of BK = 128 / 256 is a whole "phase": all of its 16-byte loads (up to ~100 KB per
+    // workgroup) are in flight together while the previous phase's MFMAs run from LDS.  Per-CU fetch
+    // rate here is set by bytes in flight (latency bound), so few large phases beat many small tiles,
+    // and one register set + one LDS buffer is the structure hipcc keeps intact (it collapses a
+    // two-register-set software pipeline into a single in-flight tile).
+    SA ra;
+    SB rb;
+    __bf16* at = reinterpret_cast<__bf16*>(smem);
+    __bf16* bt = reinterpret_cast<__bf16*>(smem + SA::BYTES);
+    if (nk > 0) {
+        ra.load(p.A, p.lda, p.M, m0, kbeg, kend);
+        rb.load(p.B, p.ldb, p.N, n0, kbeg, kend);
+    }
+    const bool do_colsum = A_KC && p.colsum != nullptr && tn == 0;
+    for (int t = 0; t < nk; ++t) {
+        if constexpr (A_KC) { if (do_colsum) ra.colsum_accumulate(p.colsum, kbeg + t * BK, kend); }
+        ra.store(at);
+        rb.store(bt);
+        __syncthreads();
+        if (t + 1 < nk) {
+            ra.load(p.A, p.lda, p.M, m0, kbeg + (t + 1) * BK, kend);
+            rb.load(p.B, p.ldb, p.N, n0, kbeg + (t + 1) * BK, kend);
+        }
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
             const bf16x8 fa = frag<A_KC, SA::LD>(at, wm * 32, kk, lane);
@@ -168,35 +215,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs p) {
                 acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[f], 0, 0, 0);
             }
         }
-    };
-
-    if (nk > 0) {
-        a0.load(p.A, p.lda, p.M, m0, kbeg, kend);
-        b0.load(p.B, p.ldb, p.N, n0, kbeg, kend);
-    }
-    if (nk > 1) {
-        a1.load(p.A, p.lda, p.M, m0, kbeg + BK, kend);
-        b1.load(p.B, p.ldb, p.N, n0, kbeg + BK, kend);
-    }
-    if (nk > 0) { a0.store(As(0)); b0.store(Bs(0)); }
-    __syncthreads();
-    // steady state, unrolled by two so both register sets are statically indexed:
-    //   tile t   lives in LDS stage t & 1, tile t+1 in registers (set (t+1) & 1), tile t+2 being issued.
-    for (int t = 0; t < nk; t += 2) {
-        if (t + 2 < nk) {
-            a0.load(p.A, p.lda, p.M, m0, kbeg + (t + 2) * BK, kend);
-            b0.load(p.B, p.ldb, p.N, n0, kbeg + (t + 2) * BK, kend);
-        }
-        compute(0);
-        if (t + 1 < nk) { a1.store(As(1)); b1.store(Bs(1)); }
-        __syncthreads();
-        if (t + 1 >= nk) break;
-        if (t + 3 < nk) {
-            a1.load(p.A, p.lda, p.M, m0, kbeg + (t + 3) * BK, kend);
-            b1.load(p.B, p.ldb, p.N, n0, kbeg + (t + 3) * BK, kend);
-        }
-        compute(1);
-        if (t + 2 < nk) { a0.store(As(0)); b0.store(Bs(0)); }
         __syncthreads();
     }
 
@@ -208,10 +226,27 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs p) {
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm * 32 + crow(r, hi);
             if (m >= p.M) continue;
-            if (p.splits > 1) p.ws[((long)blockIdx.z * p.M + m) * p.N + n] = acc[f][r];
+            if (p.splits > 1) p.ws[((long)zid * p.M + m) * p.N + n] = acc[f][r];
             else epilogue_store(p, acc[f][r], m, n);
         }
     }
+}
+
+template <int BN, int BK, bool A_KC, bool B_KC, bool B_BF16>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[TileCfg<BN, BK, A_KC, B_KC, B_BF16>::SMEM];
+    gemm_body<BN, BK, A_KC, B_KC, B_BF16>(p, blockIdx.x, blockIdx.z, smem);
+}
+
+// One launch, two independent GEMMs that consume the same dy: the dgrad (dy @ W, bf16 weight shadow read
+// row-contiguous) and the wgrad (dy^T @ x).  Each alone leaves most CUs idle or latency-stalled at these
+// sizes; together they double the resident workgroups per CU and share one launch boundary.
+template <int BN1, int BK1, int BN2, int BK2>
+__global__ __launch_bounds__(256) void gemm_bf16_pair_kernel(const GemmArgs p1, const GemmArgs p2, const int nb1) {
+    constexpr int S1 = TileCfg<BN1, BK1, true, false, true>::SMEM, S2 = TileCfg<BN2, BK2, false, false, false>::SMEM;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[S1 > S2 ? S1 : S2];
+    if ((int)blockIdx.x < nb1) gemm_body<BN1, BK1, true, false, true>(p1, blockIdx.x, 0, smem);
+    else gemm_body<BN2, BK2, false, false, false>(p2, blockIdx.x - nb1, 0, smem);
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const GemmArgs p) {
@@ -223,23 +258,31 @@ __global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const GemmArgs 
     }
 }
 
-template <int BN, bool B_BF16>
+template <int BN, int BK, bool B_BF16>
 void launch(const GemmArgs& p, bool a_kc, bool b_kc, dim3 grid, hipStream_t st) {
     dim3 block(256);
-    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<BN, true, true, B_BF16>), grid, block, 0, st, p);
-    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<BN, true, false, B_BF16>), grid, block, 0, st, p);
-    else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<BN, false, true, B_BF16>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<BN, false, false, B_BF16>), grid, block, 0, st, p);
+    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<BN, BK, true, true, B_BF16>), grid, block, 0, st, p);
+    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<BN, BK, true, false, B_BF16>), grid, block, 0, st, p);
+    else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<BN, BK, false, true, B_BF16>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<BN, BK, false, false, B_BF16>), grid, block, 0, st, p);
 }
 
 }  // namespace
 
+// Two tile configurations: 64 x 64 with 256-deep phases (default: most workgroups, most bytes in flight
+// per CU) and 64 x 128 with 128-deep phases once that still yields several waves of workgroups.
+static inline int pick_bn(int M, int N) {
+    if (N < 128) return 64;
+    return (long)cdiv(M, BM) * cdiv(N, 128) >= 512 ? 128 : 64;
+}
+static inline int bk_of(int bn) { return bn == 128 ? 128 : 256; }
+
 extern "C" int vitae_gemm_bf16_pick_split_k(int M, int N, int K) {
-    const int bn = N >= 512 ? 128 : 64;
+    const int bn = pick_bn(M, N);
     const long tiles = (long)cdiv(M, BM) * cdiv(N, bn);
     if (tiles >= 128 || K < 1024) return 1;
     long s = (256 + tiles - 1) / tiles;
-    const long max_by_k = K / 512;   // keep >= 8 k-tiles per split
+    const long max_by_k = K / 512;   // keep >= 2 phases per split
     if (s > max_by_k) s = max_by_k;
     if (s > 32) s = 32;
     return s < 1 ? 1 : (int)s;
@@ -248,8 +291,9 @@ extern "C" int vitae_gemm_bf16_pick_split_k(int M, int N, int K) {
 extern "C" int vitae_gemm_bf16(int a_kcontig, int b_kcontig, const float* A, long lda, const void* B, long ldb,
                                int b_is_bf16, float* C, long ldc, int M, int N, int K, const float* bias,
                                const float* residual, long ldr, int epi, float* aux, long ldaux, int accumulate,
-                               int split_k, float* splitk_ws, void* stream) {
+                               int split_k, float* splitk_ws, float* a_colsum_accum, void* stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return VITAE_ERR_INVALID_ARG;
+    if (a_colsum_accum && !a_kcontig) return VITAE_ERR_INVALID_ARG;
     if (epi != VITAE_EPI_NONE && !aux) return VITAE_ERR_INVALID_ARG;
     const int b_epp = b_is_bf16 ? 8 : 4;
     const int a_vec = a_kcontig ? K : M, b_vec = b_kcontig ? K : N;
@@ -260,26 +304,63 @@ extern "C" int vitae_gemm_bf16(int a_kcontig, int b_kcontig, const float* A, lon
     GemmArgs p;
     p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc;
     p.M = M; p.N = N; p.K = K;
-    int kps = cdiv(cdiv(K, split_k), BK) * BK;
+    const int bn = pick_bn(M, N);
+    const int bk = bk_of(bn);
+    int kps = cdiv(cdiv(K, split_k), bk) * bk;
     split_k = cdiv(K, kps);
     if (split_k > 1 && !splitk_ws) return VITAE_ERR_INVALID_ARG;
     p.k_per_split = kps; p.splits = split_k;
     p.bias = bias; p.residual = residual; p.ldr = ldr; p.aux = aux; p.ldaux = ldaux;
-    p.epi = epi; p.accumulate = accumulate; p.ws = splitk_ws;
-    const int bn = N >= 512 ? 128 : 64;
+    p.epi = epi; p.accumulate = accumulate; p.ws = splitk_ws; p.colsum = a_colsum_accum;
     p.tiles_m = cdiv(M, BM); p.tiles_n = cdiv(N, bn);
     p.n_per_xcd = cdiv(p.tiles_n, 8);
     dim3 grid(8 * p.n_per_xcd * p.tiles_m, 1, split_k);
     hipStream_t st = (hipStream_t)stream;
     const bool akc = a_kcontig != 0, bkc = b_kcontig != 0;
-    if (bn == 128) { if (b_is_bf16) launch<128, true>(p, akc, bkc, grid, st); else launch<128, false>(p, akc, bkc, grid, st); }
-    else { if (b_is_bf16) launch<64, true>(p, akc, bkc, grid, st); else launch<64, false>(p, akc, bkc, grid, st); }
+    if (bn == 128) { if (b_is_bf16) launch<128, 128, true>(p, akc, bkc, grid, st); else launch<128, 128, false>(p, akc, bkc, grid, st); }
+    else { if (b_is_bf16) launch<64, 256, true>(p, akc, bkc, grid, st); else launch<64, 256, false>(p, akc, bkc, grid, st); }
     if (split_k > 1) {
         const long total = (long)M * N;
         int blocks = (int)((total + 255) / 256);
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(splitk_reduce_bf16_kernel, dim3(blocks), dim3(256), 0, st, p);
     }
+    return vitae_launch_status();
+}
+
+// Backward of one Linear in ONE launch (bf16 MFMA): dx[M,K] (+)= epi(dy[M,N] @ W[N,K]) with W read from its
+// bf16 shadow, dW[N,K] (+)= dy^T @ x, db[N] += colsum(dy).  No split-K (the two GEMMs fill the chip together).
+extern "C" int vitae_linear_bwd_pair_bf16(const float* dy, const void* w_bf16, const float* x, float* dx, float* dw,
+                                          float* db_accum, int M, int N, int K, int epi, float* aux,
+                                          int dx_accumulate, int dw_accumulate, void* stream) {
+    if (!dy || !w_bf16 || !x || !dx || !dw || M <= 0 || N <= 0 || K <= 0) return VITAE_ERR_INVALID_ARG;
+    if (epi != VITAE_EPI_NONE && !aux) return VITAE_ERR_INVALID_ARG;
+    if ((N & 7) || (K & 7)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    if (((uintptr_t)dy & 15) || ((uintptr_t)w_bf16 & 15) || ((uintptr_t)x & 15)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    GemmArgs p1, p2;
+    // dgrad: rows M, cols K (in-features), reduction N
+    p1.A = dy; p1.lda = N; p1.B = w_bf16; p1.ldb = K; p1.C = dx; p1.ldc = K;
+    p1.M = M; p1.N = K; p1.K = N;
+    const int bn1 = pick_bn(M, K), bk1 = bk_of(bn1);
+    p1.k_per_split = cdiv(N, bk1) * bk1; p1.splits = 1;
+    p1.bias = nullptr; p1.residual = nullptr; p1.ldr = 0; p1.aux = aux; p1.ldaux = K; p1.epi = epi;
+    p1.accumulate = dx_accumulate; p1.ws = nullptr; p1.colsum = db_accum;
+    p1.tiles_m = cdiv(M, BM); p1.tiles_n = cdiv(K, bn1); p1.n_per_xcd = cdiv(p1.tiles_n, 8);
+    // wgrad: rows N (out-features), cols K, reduction M (tokens)
+    p2.A = dy; p2.lda = N; p2.B = x; p2.ldb = K; p2.C = dw; p2.ldc = K;
+    p2.M = N; p2.N = K; p2.K = M;
+    const int bn2 = pick_bn(N, K), bk2 = bk_of(bn2);
+    p2.k_per_split = cdiv(M, bk2) * bk2; p2.splits = 1;
+    p2.bias = nullptr; p2.residual = nullptr; p2.ldr = 0; p2.aux = nullptr; p2.ldaux = 0; p2.epi = VITAE_EPI_NONE;
+    p2.accumulate = dw_accumulate; p2.ws = nullptr; p2.colsum = nullptr;
+    p2.tiles_m = cdiv(N, BM); p2.tiles_n = cdiv(K, bn2); p2.n_per_xcd = cdiv(p2.tiles_n, 8);
+    const int nb1 = 8 * p1.n_per_xcd * p1.tiles_m, nb2 = 8 * p2.n_per_xcd * p2.tiles_m;
+    dim3 grid(nb1 + nb2), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (bn1 == 64 && bn2 == 64) hipLaunchKernelGGL((gemm_bf16_pair_kernel<64, 256, 64, 256>), grid, block, 0, st, p1, p2, nb1);
+    else if (bn1 == 64) hipLaunchKernelGGL((gemm_bf16_pair_kernel<64, 256, 128, 128>), grid, block, 0, st, p1, p2, nb1);
+    else if (bn2 == 64) hipLaunchKernelGGL((gemm_bf16_pair_kernel<128, 128, 64, 256>), grid, block, 0, st, p1, p2, nb1);
+    else hipLaunchKernelGGL((gemm_bf16_pair_kernel<128, 128, 128, 128>), grid, block, 0, st, p1, p2, nb1);
     return vitae_launch_status();
 }
 

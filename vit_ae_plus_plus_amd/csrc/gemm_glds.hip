@@ -1,0 +1,252 @@
+// bf16 x bf16 GEMM with a 4-stage LDS-DMA pipeline (global_load_lds, 16 B per lane) — the throughput
+// kernel of the path once activations are kept in bf16:
+//   C[M,N] (+)= epi( sum_k A(m,k) * B(n,k) + bias[n] ) (+ residual)      (fp32 accumulate / fp32 C,
+//   optional bf16 copy C16 for the next GEMM's operand)
+// Operand storage flags as in gemm.hip (*_KC: element (row,k) at ptr[row*ld + k], else ptr[k*ld + row]).
+//
+// Why this shape on MI355X: at M ~ 440-870 a workgroup's K loop is latency bound (a CU fetches
+// ~bytes-in-flight per ~1 us), and hipcc collapses register-staged multi-tile prefetch into one tile in
+// flight.  LDS-DMA needs no registers: three 64-deep k-tiles (3 x 16-24 KB per workgroup) stay in
+// flight behind the tile being multiplied, retired with COUNTED s_waitcnt vmcnt(N) + a raw s_barrier
+// (a __syncthreads() would drain the DMA queue; cdna_hip_programming.md §5 "Pipelining across barriers").
+// The DMA writes LDS lane-linearly (wave-uniform base + lane*16), so bank conflicts are avoided by
+// permuting the SOURCE addresses: 16-byte chunk c of tile row r is stored at chunk slot c ^ (r & 7),
+// and the fragment reads (ds_read_b128 for k-contiguous tiles, ds_read_b64_tr_b16 for row-contiguous
+// ones) apply the same XOR.  K (and the k-range of each split) must be a multiple of 64 — the engine
+// pads token counts of its bf16 activation buffers to 64 with zero rows for the wgrad reductions.
+#include "common.hpp"
+#include "vitae_hip.h"
+
+namespace {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+constexpr int BM = 64, BK = 64, NS = 4;
+
+struct GArgs {
+    const __bf16* A; long lda;
+    const __bf16* B; long ldb;
+    float* C; long ldc;
+    __bf16* C16; long ldc16;
+    int M, N, K;
+    int k_per_split, splits;
+    const float* bias;
+    const float* residual; long ldr;
+    float* aux; long ldaux;
+    int epi, accumulate;
+    float* ws;
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ void epilogue_store(const GArgs& p, float v, int m, int n) {
+    if (p.bias) v += p.bias[n];
+    if (p.epi == VITAE_EPI_GELU) {
+        p.aux[(long)m * p.ldaux + n] = v;
+        v = gelu_erf(v);
+    } else if (p.epi == VITAE_EPI_DGELU) {
+        v *= gelu_erf_grad(p.aux[(long)m * p.ldaux + n]);
+    } else if (p.epi == VITAE_EPI_RELU_MASK) {
+        v = p.aux[(long)m * p.ldaux + n] > 0.f ? v : 0.f;
+    }
+    if (p.residual) v += p.residual[(long)m * p.ldr + n];
+    if (p.C) {
+        float* c = p.C + (long)m * p.ldc + n;
+        if (p.accumulate) v += *c;
+        *c = v;
+    }
+    if (p.C16) p.C16[(long)m * p.ldc16 + n] = (__bf16)v;
+}
+
+__device__ __forceinline__ int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// Issue the LDS-DMA of one operand tile (ROWS rows x 64 k, bf16) into `lds` (byte address, tile base).
+// KC tile image: [row][8 chunks]; !KC image: [k][ROWS/8 chunks]; chunk slot = chunk ^ (line & 7).
+template <int ROWS, bool KC>
+__device__ __forceinline__ void dma_tile(const __bf16* __restrict__ P, long ld, int rows, int r0, int k0,
+                                         unsigned char* lds, int wave, int lane) {
+    constexpr int LINES = KC ? ROWS : BK;                 // LDS lines (each LINE_CH chunks of 16 B)
+    constexpr int LINE_CH = KC ? BK / 8 : ROWS / 8;       // 8 (128 B) or 16 (256 B)
+    constexpr int LPI = 64 / LINE_CH;                     // lines per wave-instruction (1 KB)
+    constexpr int NI = LINES / LPI / 4;                   // instructions per wave
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int inst = wave * NI + j;
+        const int line = inst * LPI + lane / LINE_CH;
+        const int slot = lane % LINE_CH;
+        const int chunk = slot ^ (line & 7);
+        long off;
+        if (KC) {
+            const int gr = min(r0 + line, rows - 1);      // rows past the operand: any valid row (never stored)
+            off = (long)gr * ld + k0 + chunk * 8;
+        } else {
+            const int gr = min(r0 + chunk * 8, rows - 8);
+            off = (long)(k0 + line) * ld + gr;
+        }
+        __builtin_amdgcn_global_load_lds(P + off, (__attribute__((address_space(3))) void*)(lds + inst * 1024), 16, 0, 0);
+    }
+}
+
+// MFMA operand fragment (32 rows x 16 k): rows row0 + (lane & 31), k-slots kk*16 + 8*hi + e
+template <int ROWS, bool KC>
+__device__ __forceinline__ bf16x8 frag(const unsigned char* T, int row0, int kk, int lane) {
+    if (KC) {
+        const int r = row0 + (lane & 31), c = 2 * kk + (lane >> 5);
+        return *reinterpret_cast<const bf16x8*>(T + r * 128 + ((c ^ (r & 7)) << 4));
+    } else {
+        constexpr int LB = ROWS * 2;
+        const int gg = lane >> 4, li = lane & 15;
+        const int k = kk * 16 + 8 * (gg >> 1) + (li >> 2);
+        const int col = row0 + 16 * (gg & 1) + 4 * (li & 3);
+        const int c = col >> 3, w = (col & 7) * 2;
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        union { s16x4 s[2]; bf16x8 b; } u;
+        u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(T + k * LB + ((c ^ (k & 7)) << 4) + w));
+        u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(T + (k + 4) * LB + ((c ^ ((k + 4) & 7)) << 4) + w));
+        return u.b;
+    }
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BN, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_glds_kernel(const GArgs p) {
+    constexpr int FN = BN / 64;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+    constexpr int G = (BM + BN) / 32;                      // DMA instructions per wave per stage
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGE];   // the ONLY LDS object
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, local = bid >> 3;
+    const int tn = xcd + 8 * (local / p.tiles_m), tm = local % p.tiles_m;
+    if (tn >= p.tiles_n) return;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = blockIdx.z * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+    const int nk = (kend - kbeg) / BK;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    f32x16 acc[FN];
+#pragma unroll
+    for (int f = 0; f < FN; ++f)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[f][i] = 0.f;
+
+    auto issue = [&](int t) {
+        unsigned char* st = smem + (t % NS) * STAGE;
+        dma_tile<BM, A_KC>(p.A, p.lda, p.M, m0, kbeg + t * BK, st, wave, lane);
+        dma_tile<BN, B_KC>(p.B, p.ldb, p.N, n0, kbeg + t * BK, st + A_BYTES, wave, lane);
+    };
+    const int pre = min(nk, NS - 1);
+    for (int t = 0; t < pre; ++t) issue(t);
+
+    for (int t = 0; t < nk; ++t) {
+        // tile t must have landed: allow the (up to two) younger stages to stay in flight
+        const int younger = min(nk - 1 - t, NS - 2);
+        if (younger >= 2) wait_vmcnt<2 * G>();
+        else if (younger == 1) wait_vmcnt<G>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();          // everyone's DMA pieces of tile t landed; tile t-1 fully consumed
+        if (t + NS - 1 < nk) issue(t + NS - 1);   // refills the stage tile t-1 used
+        const unsigned char* at = smem + (t % NS) * STAGE;
+        const unsigned char* bt = at + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            const bf16x8 fa = frag<BM, A_KC>(at, wm * 32, kk, lane);
+#pragma unroll
+            for (int f = 0; f < FN; ++f) {
+                const bf16x8 fb = frag<BN, B_KC>(bt, wn * (BN / 2) + f * 32, kk, lane);
+                acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[f], 0, 0, 0);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int f = 0; f < FN; ++f) {
+        const int n = n0 + wn * (BN / 2) + f * 32 + l31;
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 32 + crow(r, hi);
+            if (m >= p.M) continue;
+            if (p.splits > 1) p.ws[((long)blockIdx.z * p.M + m) * p.N + n] = acc[f][r];
+            else epilogue_store(p, acc[f][r], m, n);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_glds_kernel(const GArgs p) {
+    const long total = (long)p.M * p.N;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        float v = 0.f;
+        for (int s = 0; s < p.splits; ++s) v += p.ws[(long)s * total + i];
+        epilogue_store(p, v, (int)(i / p.N), (int)(i % p.N));
+    }
+}
+
+template <int BN>
+void launch(const GArgs& p, bool a_kc, bool b_kc, dim3 grid, hipStream_t st) {
+    dim3 block(256);
+    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_glds_kernel<BN, true, true>), grid, block, 0, st, p);
+    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_glds_kernel<BN, true, false>), grid, block, 0, st, p);
+    else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_glds_kernel<BN, false, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((gemm_glds_kernel<BN, false, false>), grid, block, 0, st, p);
+}
+
+inline int pick_bn(int M, int N) {
+    if (N < 128) return 64;
+    return (long)cdiv(M, BM) * cdiv(N, 128) >= 400 ? 128 : 64;
+}
+
+}  // namespace
+
+extern "C" int vitae_gemm_glds_pick_split_k(int M, int N, int K) {
+    const int bn = pick_bn(M, N);
+    const long tiles = (long)cdiv(M, BM) * cdiv(N, bn);
+    if (tiles >= 192 || K < 1024) return 1;
+    long s = (384 + tiles - 1) / tiles;
+    const long max_by_k = K / 512;   // >= 8 k-tiles per split
+    if (s > max_by_k) s = max_by_k;
+    if (s > 32) s = 32;
+    return s < 1 ? 1 : (int)s;
+}
+
+extern "C" int vitae_gemm_glds(int a_kcontig, int b_kcontig, const void* A16, long lda, const void* B16, long ldb,
+                               float* C, long ldc, void* C16, long ldc16, int M, int N, int K, const float* bias,
+                               const float* residual, long ldr, int epi, float* aux, long ldaux, int accumulate,
+                               int split_k, float* splitk_ws, void* stream) {
+    if (!A16 || !B16 || (!C && !C16) || M <= 0 || N <= 0 || K <= 0) return VITAE_ERR_INVALID_ARG;
+    if (epi != VITAE_EPI_NONE && !aux) return VITAE_ERR_INVALID_ARG;
+    if (K % BK) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    const int a_vec = a_kcontig ? K : M, b_vec = b_kcontig ? K : N;
+    if ((a_vec & 7) || (lda & 7) || (b_vec & 7) || (ldb & 7)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    if (((uintptr_t)A16 & 15) || ((uintptr_t)B16 & 15)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    if (split_k < 1) split_k = 1;
+    if (epi == VITAE_EPI_GELU) split_k = 1;
+    GArgs p;
+    p.A = reinterpret_cast<const __bf16*>(A16); p.lda = lda;
+    p.B = reinterpret_cast<const __bf16*>(B16); p.ldb = ldb;
+    p.C = C; p.ldc = ldc; p.C16 = reinterpret_cast<__bf16*>(C16); p.ldc16 = ldc16;
+    p.M = M; p.N = N; p.K = K;
+    int kps = cdiv(cdiv(K, split_k), BK) * BK;
+    split_k = cdiv(K, kps);
+    if (split_k > 1 && !splitk_ws) return VITAE_ERR_INVALID_ARG;
+    p.k_per_split = kps; p.splits = split_k;
+    p.bias = bias; p.residual = residual; p.ldr = ldr; p.aux = aux; p.ldaux = ldaux;
+    p.epi = epi; p.accumulate = accumulate; p.ws = splitk_ws;
+    const int bn = pick_bn(M, N);
+    p.tiles_m = cdiv(M, BM); p.tiles_n = cdiv(N, bn);
+    dim3 grid(8 * cdiv(p.tiles_n, 8) * p.tiles_m, 1, split_k);
+    hipStream_t st = (hipStream_t)stream;
+    if (bn == 128) launch<128>(p, a_kcontig != 0, b_kcontig != 0, grid, st);
+    else launch<64>(p, a_kcontig != 0, b_kcontig != 0, grid, st);
+    if (split_k > 1) {
+        const long total = (long)M * N;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_glds_kernel, dim3(blocks), dim3(256), 0, st, p);
+    }
+    return vitae_launch_status();
+}

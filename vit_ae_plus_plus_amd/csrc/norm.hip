@@ -214,7 +214,7 @@ extern "C" int vitae_layernorm_bwd(const float* dy, const float* x, const float*
     if (!dy || !x || !w || !mean || !rstd || !dx || !dw || !db || M <= 0 || D <= 0) return VITAE_ERR_INVALID_ARG;
     if (D > 64 * LN_MAX_PER_LANE) return VITAE_ERR_UNSUPPORTED_SHAPE;
     int blocks = cdiv(M, 4);
-    if (blocks > 128) blocks = 128;   // bounds the number of atomics per column
+    if (blocks > 256) blocks = 256;   // one row per wave up to 1024 rows (row work dominates; capping at 48 blocks doubled the time)
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, w, mean, rstd,
                        dx, dw, db, M, D, dx_accumulate);
     return vitae_launch_status();

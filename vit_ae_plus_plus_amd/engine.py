@@ -136,6 +136,11 @@ class HipMAEEngine:
         self._accum = False
         self._split_cache: Dict[Tuple[int, int, int], int] = {}
         self.stream = 0
+        self.side = torch.cuda.Stream(device=device)   # target-side loss branch runs beside the transformer
+        self.wside = torch.cuda.Stream(device=device)  # weight-gradient GEMMs run beside the dgrad chain
+        self.overlap_wgrad = True
+        self._wg_events: Dict[str, torch.cuda.Event] = {}
+        self._wg_pending = set()
         self.gemm_timer = None   # bench.py: list collecting (start_event, end_event, flops) per GEMM launch
         self.set_hparams(lr=0.0, beta1=0.9, beta2=0.95, eps=1e-8, bc1=1.0, bc2=1.0, grad_mul=1.0, g_recon=1.0,
                          g_edge=0.0, g_contr=0.0, edge_w=0.0, contr_w=0.0)
@@ -297,39 +302,83 @@ class HipMAEEngine:
         if self.prec == PREC['bf16']:
             w16 = self._w16(w)
             lib.vitae_gemm_bf16(1, 1, _ptr(x), K, w16 if w16 else _ptr(w), K, 1 if w16 else 0, _ptr(y), N, M, N, K,
-                                _ptr(bias), _ptr(res), N, epi, _ptr(aux), N, 0, s, self.ws.data_ptr(), self.stream)
+                                _ptr(bias), _ptr(res), N, epi, _ptr(aux), N, 0, s, self.ws.data_ptr(), None, self.stream)
         else:
             lib.vitae_linear_fwd(self.prec, _ptr(x), _ptr(w), _ptr(bias), _ptr(y), M, N, K, epi, _ptr(aux), _ptr(res), s,
                                  self.ws.data_ptr(), self.stream)
         if t is not None:
             t.record()
 
-    def _lin_bwd_x(self, dy, w, dx, M, N, K, epi=EPI_NONE, aux=None, accumulate=0):
+    def _lin_bwd_x(self, dy, w, dx, M, N, K, epi=EPI_NONE, aux=None, accumulate=0, db=None):
+        """dx = epi(dy @ W); with ``db`` the bias gradient colsum(dy) rides on the same launch (bf16 mode)
+        or is a separate column-sum kernel (fp32 mode)."""
         s = self._split(M, K, N)
         t = self._timed(2.0 * M * N * K)
         if self.prec == PREC['bf16']:
             w16 = self._w16(w)
             lib.vitae_gemm_bf16(1, 0, _ptr(dy), N, w16 if w16 else _ptr(w), K, 1 if w16 else 0, _ptr(dx), K, M, K, N,
-                                None, None, 0, epi, _ptr(aux), K, accumulate, s, self.ws.data_ptr(), self.stream)
+                                None, None, 0, epi, _ptr(aux), K, accumulate, s, self.ws.data_ptr(), _ptr(db), self.stream)
         else:
             lib.vitae_linear_bwd_input(self.prec, _ptr(dy), _ptr(w), _ptr(dx), M, N, K, epi, _ptr(aux), accumulate, s,
                                        self.ws.data_ptr(), self.stream)
+            if db is not None:
+                lib.vitae_colsum_accum(_ptr(dy), N, _ptr(db), M, N, self.stream)
         if t is not None:
             t.record()
 
-    def _lin_bwd_w(self, dy, x, dw, db, M, N, K):
+    def _lin_bwd_w(self, dy, x, dw, db, M, N, K, tag=None):
+        """dW (+)= dy^T x.  With ``tag`` (and overlap enabled) the GEMM is enqueued on the wgrad side stream:
+        it only needs dy / x, which are final when this is called, and nobody reads dW before the end of the
+        backward phase.  ``tag`` names the dy buffer so that ``_wg_fence(tag)`` can be placed in front of the
+        kernel that next overwrites it."""
         s = self._split(N, K, M)
+        side = tag is not None and self.overlap_wgrad and s == 1 and self.gemm_timer is None
+        if side:
+            main = torch.cuda.current_stream(self.device)
+            self.wside.wait_stream(main)
+            stream = self.wside.cuda_stream
+        else:
+            stream = self.stream
         t = self._timed(2.0 * M * N * K)
         if self.prec == PREC['bf16']:
             lib.vitae_gemm_bf16(0, 0, _ptr(dy), N, _ptr(x), K, 0, _ptr(dw), K, N, K, M, None, None, 0, EPI_NONE, None, 0,
-                                int(self._accum), s, self.ws.data_ptr(), self.stream)
+                                int(self._accum), s, self.ws.data_ptr(), None, stream)
         else:
             lib.vitae_linear_bwd_weight(self.prec, _ptr(dy), _ptr(x), _ptr(dw), M, N, K, int(self._accum), s,
-                                        self.ws.data_ptr(), self.stream)
+                                        self.ws.data_ptr(), stream)
         if t is not None:
             t.record()
         if db is not None:
-            lib.vitae_colsum_accum(_ptr(dy), N, _ptr(db), M, N, self.stream)
+            lib.vitae_colsum_accum(_ptr(dy), N, _ptr(db), M, N, stream)
+        if side:
+            ev = self._wg_events.get(tag)
+            if ev is None:
+                ev = self._wg_events[tag] = torch.cuda.Event()
+            ev.record(self.wside)
+            self._wg_pending.add(tag)
+
+    def _lin_bwd(self, dy, w, x, dx, dw, db, M, N, K, epi=EPI_NONE, aux=None, dx_accumulate=0, tag=None):
+        """Full backward of y = x W^T + b given dy: dx (+)= epi(dy W), dW (+)= dy^T x, db += colsum(dy).
+        bf16 mode: ONE paired launch (dgrad + wgrad blocks side by side); fp32 mode: separate launches."""
+        w16 = self._w16(w) if self.prec == PREC['bf16'] else 0
+        if w16 and self.gemm_timer is None:
+            lib.vitae_linear_bwd_pair_bf16(_ptr(dy), w16, _ptr(x), _ptr(dx), _ptr(dw), _ptr(db), M, N, K, epi, _ptr(aux),
+                                           dx_accumulate, int(self._accum), self.stream)
+            return
+        self._lin_bwd_w(dy, x, dw, None, M, N, K, tag=tag)
+        self._lin_bwd_x(dy, w, dx, M, N, K, epi=epi, aux=aux, accumulate=dx_accumulate, db=db)
+
+    def _wg_fence(self, tag):
+        """Make the current stream wait for the side-stream wgrad that still reads buffer ``tag``."""
+        if tag in self._wg_pending:
+            torch.cuda.current_stream(self.device).wait_event(self._wg_events[tag])
+            self._wg_pending.discard(tag)
+
+    def _wg_join(self):
+        """All side-stream wgrads issued so far are complete for the current stream (end of a phase)."""
+        if self._wg_pending:
+            torch.cuda.current_stream(self.device).wait_stream(self.wside)
+            self._wg_pending.clear()
 
     def _ln_fwd(self, x, pre, y, mean, rstd, M, D):
         lib.vitae_layernorm_fwd(_ptr(x), _ptr(self.p[pre + 'weight']), _ptr(self.p[pre + 'bias']), _ptr(y), _ptr(mean),
@@ -360,22 +409,25 @@ class HipMAEEngine:
         """Backward of one block; the running gradient lives in buf[s+'dx'] and is updated in place."""
         b, p, g, M = self.buf, self.p, self.g, Bs * N
         dx, dh, dy, do, dqkv = b[s + 'dx'], b[s + 'dh'], b[s + 'dy'], b[s + 'do'], b[s + 'dqkv']
-        # mlp.fc2
-        self._lin_bwd_w(dx, b[q + 'act'], g[pre + 'mlp.fc2.weight'], g[pre + 'mlp.fc2.bias'], M, d, hid)
-        self._lin_bwd_x(dx, p[pre + 'mlp.fc2.weight'], dh, M, d, hid, epi=EPI_DGELU, aux=b[q + 'hpre'])
-        # mlp.fc1
-        self._lin_bwd_w(dh, b[q + 'y2'], g[pre + 'mlp.fc1.weight'], g[pre + 'mlp.fc1.bias'], M, hid, d)
-        self._lin_bwd_x(dh, p[pre + 'mlp.fc1.weight'], dy, M, hid, d)
+        # mlp.fc2 / fc1
+        self._wg_fence(s + 'dh')                       # previous block's fc1 wgrad may still read dh
+        self._lin_bwd(dx, p[pre + 'mlp.fc2.weight'], b[q + 'act'], dh, g[pre + 'mlp.fc2.weight'], g[pre + 'mlp.fc2.bias'],
+                      M, d, hid, epi=EPI_DGELU, aux=b[q + 'hpre'], tag=s + 'dx')
+        self._lin_bwd(dh, p[pre + 'mlp.fc1.weight'], b[q + 'y2'], dy, g[pre + 'mlp.fc1.weight'], g[pre + 'mlp.fc1.bias'],
+                      M, hid, d, tag=s + 'dh')
+        self._wg_fence(s + 'dx')                       # fc2 wgrad reads dx; LN backward updates it in place
         self._ln_bwd(dy, b[q + 'xmid'], pre + 'norm2.', b[q + 'mean2'], b[q + 'rstd2'], dx, M, d, 1)
         # attn.proj
-        self._lin_bwd_w(dx, b[q + 'o'], g[pre + 'attn.proj.weight'], g[pre + 'attn.proj.bias'], M, d, d)
-        self._lin_bwd_x(dx, p[pre + 'attn.proj.weight'], do, M, d, d)
+        self._lin_bwd(dx, p[pre + 'attn.proj.weight'], b[q + 'o'], do, g[pre + 'attn.proj.weight'], g[pre + 'attn.proj.bias'],
+                      M, d, d, tag=s + 'dx')
+        self._wg_fence(s + 'dqkv')                     # previous block's qkv wgrad may still read dqkv
         sdpa_bwd = lib.vitae_sdpa_mfma_bwd if (self.prec == PREC['bf16'] and hd in (32, 64)) else lib.vitae_sdpa_bwd
         sdpa_bwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(do), _ptr(b[q + 'lse']), _ptr(dqkv),
                  _ptr(b['delta']), Bs, N, heads, hd, self.stream)
         # attn.qkv
-        self._lin_bwd_w(dqkv, b[q + 'y1'], g[pre + 'attn.qkv.weight'], g[pre + 'attn.qkv.bias'], M, 3 * d, d)
-        self._lin_bwd_x(dqkv, p[pre + 'attn.qkv.weight'], dy, M, 3 * d, d)
+        self._lin_bwd(dqkv, p[pre + 'attn.qkv.weight'], b[q + 'y1'], dy, g[pre + 'attn.qkv.weight'], g[pre + 'attn.qkv.bias'],
+                      M, 3 * d, d, tag=s + 'dqkv')
+        self._wg_fence(s + 'dx')                       # proj wgrad reads dx
         self._ln_bwd(dy, x_in, pre + 'norm1.', b[q + 'mean1'], b[q + 'rstd1'], dx, M, d, 1)
 
     # ------------------------------------------------------------------ forward
@@ -402,6 +454,15 @@ class HipMAEEngine:
         self.view1 = view1
         self.refresh_shadow()
         lib.vitae_memset_zero(self.acc.data_ptr(), self.acc.numel() * 8, st)
+        # --- target branch of the edge loss (blur + Sobel of the input, vit_autoenc.py:221-223) depends on the
+        # data only: it runs on a side stream underneath the encoder/decoder and is joined before the edge MSE
+        main = torch.cuda.current_stream(self.device)
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            ss = self.side.cuda_stream
+            lib.vitae_gauss_blur_fwd(_ptr(view1), _ptr(b['blur_tmp']), _ptr(b['blurred']), self._taps_c, len(self.taps),
+                                     B * C, Lz, Hy, Wx, ss)
+            lib.vitae_sobel_edge_fwd(_ptr(b['blurred']), _ptr(b['edge_t']), None, None, B, C, Lz, Hy, Wx, ss)
         # --- masking, kept-patch gather, patch embedding, sequence assembly
         lib.vitae_random_masking(_ptr(noise), _ptr(b['ids_shuffle']), _ptr(b['ids_restore']), _ptr(b['mask']),
                                  _ptr(b['ids_restore64']), Be, L, keep, st)
@@ -430,9 +491,7 @@ class HipMAEEngine:
         pred_ptr, pbs = b['predfull'].data_ptr() + P * 4, Nd * P
         lib.vitae_recon_loss_fwd(pred_ptr, pbs, _ptr(view1), _ptr(b['mask']), _ptr(self.acc), B, C, Lz, Hy, Wx, ps, st)
         lib.vitae_unpatchify(pred_ptr, pbs, _ptr(b['pred_vol']), B, C, Lz, Hy, Wx, ps, st)
-        lib.vitae_gauss_blur_fwd(_ptr(view1), _ptr(b['blur_tmp']), _ptr(b['blurred']), self._taps_c, len(self.taps),
-                                 B * C, Lz, Hy, Wx, st)
-        lib.vitae_sobel_edge_fwd(_ptr(b['blurred']), _ptr(b['edge_t']), None, None, B, C, Lz, Hy, Wx, st)
+        torch.cuda.current_stream(self.device).wait_stream(self.side)   # edge map of the blurred target is ready
         lib.vitae_sobel_edge_fwd(_ptr(b['pred_vol']), _ptr(b['edge_p']), _ptr(b['edge_t']), _ptr(self.acc), B, C, Lz, Hy,
                                  Wx, st)
         lib.vitae_loss_finalize(_ptr(self.acc), _ptr(self.hp), _ptr(self.losses), self.mask_sum, self.edge_count, st)
@@ -500,8 +559,8 @@ class HipMAEEngine:
         lib.vitae_sobel_edge_bwd(_ptr(b['pred_vol']), _ptr(b['edge_p']), _ptr(b['edge_t']), _ptr(self.hp), _ptr(b['dG']),
                                  dpred_ptr, pbs, B, C, Lz, Hy, Wx, ps, st)
         # decoder_pred, decoder_norm
-        self._lin_bwd_w(b['dpredfull'], b['dn'], g['decoder_pred.weight'], g['decoder_pred.bias'], Md, P, Dd)
-        self._lin_bwd_x(b['dpredfull'], p['decoder_pred.weight'], b['ddn'], Md, P, Dd)
+        self._lin_bwd(b['dpredfull'], p['decoder_pred.weight'], b['dn'], b['ddn'], g['decoder_pred.weight'],
+                      g['decoder_pred.bias'], Md, P, Dd)
         dx_ = b['decx']
         self._ln_bwd(b['ddn'], dx_[cfg.decoder_depth], 'decoder_norm.', b['dn_mean'], b['dn_rstd'], b['decdx'], Md, Dd, 0)
         for i in reversed(range(cfg.decoder_depth)):
@@ -509,12 +568,12 @@ class HipMAEEngine:
                             self.Hmd)
         lib.vitae_decoder_assemble_bwd(_ptr(b['decdx']), _ptr(b['ids_shuffle']), _ptr(b['de']), _ptr(g['mask_token']), B, L,
                                        keep, Dd, st)
-        self._lin_bwd_w(b['de'], b['latent'], g['decoder_embed.weight'], g['decoder_embed.bias'], B * Ne, Dd, D)
+        self._lin_bwd_w(b['de'], b['latent'], g['decoder_embed.weight'], None, B * Ne, Dd, D)
         # predictor (both views) -> dlatent ; then decoder_embed adds into the view-1 rows
         if cfg.contrastive and have_dp:
             R = self.R
-            self._lin_bwd_w(b['dp'], b['pr'], g['predictor.3.weight'], g['predictor.3.bias'], 2 * R, D, D)
-            self._lin_bwd_x(b['dp'], p['predictor.3.weight'], b['dpr'], 2 * R, D, D)
+            self._lin_bwd_w(b['dp'], b['pr'], g['predictor.3.weight'], None, 2 * R, D, D)
+            self._lin_bwd_x(b['dp'], p['predictor.3.weight'], b['dpr'], 2 * R, D, D, db=g['predictor.3.bias'])
             for v in range(2):
                 o = v * R * D * 4
                 lib.vitae_bn1d_relu_bwd(b['dpr'].data_ptr() + o, b['ph'].data_ptr() + o, b['pr'].data_ptr() + o,
@@ -523,7 +582,8 @@ class HipMAEEngine:
                                         _ptr(g['predictor.1.weight']), _ptr(g['predictor.1.bias']), R, D, st)
             self._lin_bwd_w(b['dph'], b['latent'], g['predictor.0.weight'], None, 2 * R, D, D)
             self._lin_bwd_x(b['dph'], p['predictor.0.weight'], b['dlatent'], 2 * R, D, D)
-            self._lin_bwd_x(b['de'], p['decoder_embed.weight'], b['dlatent'], B * Ne, Dd, D, accumulate=1)
+            self._lin_bwd_x(b['de'], p['decoder_embed.weight'], b['dlatent'], B * Ne, Dd, D, accumulate=1,
+                            db=g['decoder_embed.bias'])
         else:
             if cfg.contrastive:   # predictor unused this step: its matrices get exact zeros
                 for n in ('predictor.0.weight', 'predictor.3.weight'):
@@ -531,8 +591,9 @@ class HipMAEEngine:
                         lib.vitae_memset_zero(g[n].data_ptr(), g[n].numel() * 4, st)
             if Be != B:
                 lib.vitae_memset_zero(b['dlatent'].data_ptr(), b['dlatent'].numel() * 4, st)
-            self._lin_bwd_x(b['de'], p['decoder_embed.weight'], b['dlatent'], B * Ne, Dd, D)
+            self._lin_bwd_x(b['de'], p['decoder_embed.weight'], b['dlatent'], B * Ne, Dd, D, db=g['decoder_embed.bias'])
         self._ln_bwd(b['dlatent'], b['encx'][cfg.depth], 'norm.', b['lat_mean'], b['lat_rstd'], b['encdx'], Me, D, 0)
+        self._wg_join()
 
     def backward_enc(self, hi: int, lo: int):
         """encoder blocks hi, hi-1, ..., lo."""
@@ -542,6 +603,7 @@ class HipMAEEngine:
         for i in range(hi, lo - 1, -1):
             self._block_bwd(f'blocks.{i}.', f'enc{i}.', 'enc', ex[i], self.Be, self.Ne, cfg.embed_dim, cfg.num_heads,
                             self.hd, self.Hm)
+        self._wg_join()
 
     def backward_tail(self):
         """sequence assembly and patch-embedding weight gradient (the input is data: no dgrad)."""
