@@ -18,6 +18,7 @@
 //  * workgroup ids are remapped so that all M-tiles of one weight panel run on the same XCD (its L2
 //    then serves the panel to the 7-14 workgroups that share it);
 //  * split-K partials go to a workspace and are reduced deterministically (shared with gemm.hip).
+#include <cstdlib>
 #include "common.hpp"
 #include "vitae_hip.h"
 
@@ -25,7 +26,6 @@ namespace {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-constexpr int BM = 64;
 
 struct GemmArgs {
     const float* A; long lda;
@@ -65,9 +65,9 @@ __host__ __device__ constexpr int ld_pad(int n) { return n == 128 ? n + 16 : n +
 
 // ---------------------------------------------------------------- operand staging
 // One operand tile = ROWS rows x BK k.  Per thread NPIECE 16-byte global pieces.
-template <int ROWS, int BK, bool KC, bool BF16> struct Stage {
+template <int ROWS, int BK, int NT, bool KC, bool BF16> struct Stage {
     static constexpr int EPP = BF16 ? 8 : 4;                       // elements per 16-byte piece
-    static constexpr int NPIECE = ROWS * BK / EPP / 256;
+    static constexpr int NPIECE = ROWS * BK / EPP / NT;
     static constexpr int LD = KC ? BK + 8 : ld_pad(ROWS);          // LDS row stride in bf16 elements (conflict-free)
     static constexpr int BYTES = (KC ? ROWS : BK) * LD * 2;
     u32x4 r[NPIECE];
@@ -80,7 +80,7 @@ template <int ROWS, int BK, bool KC, bool BF16> struct Stage {
         ok = 0u;
 #pragma unroll
         for (int j = 0; j < NPIECE; ++j) {
-            const int p = threadIdx.x + 256 * j;
+            const int p = threadIdx.x + NT * j;
             int row, k;
             if (KC) { row = p / (BK / EPP); k = (p % (BK / EPP)) * EPP; }
             else { k = p / (ROWS / EPP); row = (p % (ROWS / EPP)) * EPP; }
@@ -115,7 +115,7 @@ template <int ROWS, int BK, bool KC, bool BF16> struct Stage {
     __device__ __forceinline__ void store(__bf16* lds) const {
 #pragma unroll
         for (int j = 0; j < NPIECE; ++j) {
-            const int p = threadIdx.x + 256 * j;
+            const int p = threadIdx.x + NT * j;
             int row, k;
             if (KC) { row = p / (BK / EPP); k = (p % (BK / EPP)) * EPP; }
             else { k = p / (ROWS / EPP); row = (p % (ROWS / EPP)) * EPP; }
@@ -154,17 +154,23 @@ __device__ __forceinline__ bf16x8 frag(const __bf16* T, int row0, int kk, int la
     }
 }
 
-template <int BN, int BK, bool A_KC, bool B_KC, bool B_BF16> struct TileCfg {
-    using SA = Stage<BM, BK, A_KC, false>;
-    using SB = Stage<BN, BK, B_KC, B_BF16>;
+// Tile configurations (BM x BN x BK, threads): 64x64x256/256 (default), 64x128x128/256 (large GEMMs),
+// 32x64x256/128 (small GEMMs: twice the workgroups, 2-3 resident per CU so one's MFMA loop overlaps
+// another's load wait).  Waves form a (BM/32) x (rest) grid; wave tile 32 x (32*FN).
+template <int BM, int BN, int BK, int NT, bool A_KC, bool B_KC, bool B_BF16> struct TileCfg {
+    using SA = Stage<BM, BK, NT, A_KC, false>;
+    using SB = Stage<BN, BK, NT, B_KC, B_BF16>;
     static constexpr int SMEM = SA::BYTES + SB::BYTES;
+    static constexpr int KS = NT > 256 ? NT / 256 : 1;            // wave groups splitting each phase's k range
+    static constexpr int WM = BM / 32, WN = (NT / 64 / KS) / WM, FN = BN / WN / 32;
 };
 
-template <int BN, int BK, bool A_KC, bool B_KC, bool B_BF16>
+template <int BM, int BN, int BK, int NT, bool A_KC, bool B_KC, bool B_BF16>
 __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, const int zid, unsigned char* smem) {
-    using SA = Stage<BM, BK, A_KC, false>;
-    using SB = Stage<BN, BK, B_KC, B_BF16>;
-    constexpr int FN = BN / 64;                         // 32-col fragments per wave (wave tile 32 x BN/2)
+    using CFG = TileCfg<BM, BN, BK, NT, A_KC, B_KC, B_BF16>;
+    using SA = typename CFG::SA;
+    using SB = typename CFG::SB;
+    constexpr int FN = CFG::FN, WN = CFG::WN, KS = CFG::KS;
     // XCD-aware tile order: hardware places workgroup b on XCD b % 8; give each XCD whole weight panels.
     const int xcd = bid & 7, local = bid >> 3;
     const int tn = xcd + 8 * (local / p.tiles_m), tm = local % p.tiles_m;
@@ -174,7 +180,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, cons
     const int kend = min(p.K, kbeg + p.k_per_split);
     const int nk = (kend - kbeg + BK - 1) / BK;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int kh = wave / (NT / 64 / KS), wq = wave % (NT / 64 / KS);   // k-group, position in the wave grid
+    const int wm = wq / WN, wn = wq % WN;
     const int l31 = lane & 31, hi = lane >> 5;
 
     f32x16 acc[FN];
@@ -207,20 +214,39 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, cons
             rb.load(p.B, p.ldb, p.N, n0, kbeg + (t + 1) * BK, kend);
         }
 #pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
+        for (int kq = 0; kq < BK / 16 / KS; ++kq) {
+            const int kk = kh * (BK / 16 / KS) + kq;
             const bf16x8 fa = frag<A_KC, SA::LD>(at, wm * 32, kk, lane);
 #pragma unroll
             for (int f = 0; f < FN; ++f) {
-                const bf16x8 fb = frag<B_KC, SB::LD>(bt, wn * (BN / 2) + f * 32, kk, lane);
+                const bf16x8 fb = frag<B_KC, SB::LD>(bt, wn * (32 * FN) + f * 32, kk, lane);
                 acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[f], 0, 0, 0);
             }
         }
         __syncthreads();
     }
 
+    if constexpr (KS > 1) {
+        // the k-groups' partial tiles meet in LDS (tile buffers are free after the last barrier)
+        float* red = reinterpret_cast<float*>(smem);
+        if (kh > 0) {
+#pragma unroll
+            for (int f = 0; f < FN; ++f)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(((kh - 1) * (NT / 64 / KS) + wq) * FN + f) * 1024 + r * 64 + lane] = acc[f][r];
+        }
+        __syncthreads();
+        if (kh > 0) return;
+#pragma unroll
+        for (int g = 1; g < KS; ++g)
+#pragma unroll
+            for (int f = 0; f < FN; ++f)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[f][r] += red[(((g - 1) * (NT / 64 / KS) + wq) * FN + f) * 1024 + r * 64 + lane];
+    }
 #pragma unroll
     for (int f = 0; f < FN; ++f) {
-        const int n = n0 + wn * (BN / 2) + f * 32 + l31;
+        const int n = n0 + wn * (32 * FN) + f * 32 + l31;
         if (n >= p.N) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -232,21 +258,22 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, cons
     }
 }
 
-template <int BN, int BK, bool A_KC, bool B_KC, bool B_BF16>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[TileCfg<BN, BK, A_KC, B_KC, B_BF16>::SMEM];
-    gemm_body<BN, BK, A_KC, B_KC, B_BF16>(p, blockIdx.x, blockIdx.z, smem);
+template <int BM, int BN, int BK, int NT, bool A_KC, bool B_KC, bool B_BF16>
+__global__ __launch_bounds__(NT) void gemm_bf16_kernel(const GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[TileCfg<BM, BN, BK, NT, A_KC, B_KC, B_BF16>::SMEM];
+    gemm_body<BM, BN, BK, NT, A_KC, B_KC, B_BF16>(p, blockIdx.x, blockIdx.z, smem);
 }
 
 // One launch, two independent GEMMs that consume the same dy: the dgrad (dy @ W, bf16 weight shadow read
 // row-contiguous) and the wgrad (dy^T @ x).  Each alone leaves most CUs idle or latency-stalled at these
 // sizes; together they double the resident workgroups per CU and share one launch boundary.
-template <int BN1, int BK1, int BN2, int BK2>
-__global__ __launch_bounds__(256) void gemm_bf16_pair_kernel(const GemmArgs p1, const GemmArgs p2, const int nb1) {
-    constexpr int S1 = TileCfg<BN1, BK1, true, false, true>::SMEM, S2 = TileCfg<BN2, BK2, false, false, false>::SMEM;
+template <int NT, int BM1, int BN1, int BK1, int BM2, int BN2, int BK2>
+__global__ __launch_bounds__(NT) void gemm_bf16_pair_kernel(const GemmArgs p1, const GemmArgs p2, const int nb1) {
+    constexpr int S1 = TileCfg<BM1, BN1, BK1, NT, true, false, true>::SMEM;
+    constexpr int S2 = TileCfg<BM2, BN2, BK2, NT, false, false, false>::SMEM;
     __shared__ __attribute__((aligned(16))) unsigned char smem[S1 > S2 ? S1 : S2];
-    if ((int)blockIdx.x < nb1) gemm_body<BN1, BK1, true, false, true>(p1, blockIdx.x, 0, smem);
-    else gemm_body<BN2, BK2, false, false, false>(p2, blockIdx.x - nb1, 0, smem);
+    if ((int)blockIdx.x < nb1) gemm_body<BM1, BN1, BK1, NT, true, false, true>(p1, blockIdx.x, 0, smem);
+    else gemm_body<BM2, BN2, BK2, NT, false, false, false>(p2, blockIdx.x - nb1, 0, smem);
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const GemmArgs p) {
@@ -258,30 +285,41 @@ __global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const GemmArgs 
     }
 }
 
-template <int BN, int BK, bool B_BF16>
+template <int BM, int BN, int BK, int NT, bool B_BF16>
 void launch(const GemmArgs& p, bool a_kc, bool b_kc, dim3 grid, hipStream_t st) {
-    dim3 block(256);
-    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<BN, BK, true, true, B_BF16>), grid, block, 0, st, p);
-    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<BN, BK, true, false, B_BF16>), grid, block, 0, st, p);
-    else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<BN, BK, false, true, B_BF16>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<BN, BK, false, false, B_BF16>), grid, block, 0, st, p);
+    dim3 block(NT);
+    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, BK, NT, true, true, B_BF16>), grid, block, 0, st, p);
+    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, BK, NT, true, false, B_BF16>), grid, block, 0, st, p);
+    else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, BK, NT, false, true, B_BF16>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, BK, NT, false, false, B_BF16>), grid, block, 0, st, p);
 }
 
 }  // namespace
 
-// Two tile configurations: 64 x 64 with 256-deep phases (default: most workgroups, most bytes in flight
-// per CU) and 64 x 128 with 128-deep phases once that still yields several waves of workgroups.
-static inline int pick_bn(int M, int N) {
-    if (N < 128) return 64;
-    return (long)cdiv(M, BM) * cdiv(N, 128) >= 512 ? 128 : 64;
+// Tile configuration: cfg 0 = 32x64x256 (128 threads), 1 = 64x64x256, 2 = 64x128x128,
+// 3 = 64x64x256 with 512 threads (two wave groups split each phase's k range: 2 waves per SIMD hide the
+// LDS / MFMA latency of the fragment loop; partial tiles meet in LDS once).
+static inline int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
 }
-static inline int bk_of(int bn) { return bn == 128 ? 128 : 256; }
+static inline int pick_cfg(int M, int N) {
+    static const int big = env_int("VITAE_BN128_MIN_TILES", 512), small = env_int("VITAE_BM32_MAX_TILES", 0);
+    static const int w8 = env_int("VITAE_GEMM_8WAVES", 1);
+    if (N >= 128 && (long)cdiv(M, 64) * cdiv(N, 128) >= big) return 2;
+    if ((long)cdiv(M, 64) * cdiv(N, 64) < small) return 0;
+    return w8 ? 3 : 1;
+}
+static inline int cfg_bm(int c) { return c == 0 ? 32 : 64; }
+static inline int cfg_nt(int c) { return c == 0 ? 128 : (c == 3 ? 512 : 256); }
+static inline int cfg_bn(int c) { return c == 2 ? 128 : 64; }
+static inline int cfg_bk(int c) { return c == 2 ? 128 : 256; }
 
 extern "C" int vitae_gemm_bf16_pick_split_k(int M, int N, int K) {
-    const int bn = pick_bn(M, N);
-    const long tiles = (long)cdiv(M, BM) * cdiv(N, bn);
-    if (tiles >= 128 || K < 1024) return 1;
-    long s = (256 + tiles - 1) / tiles;
+    const int c = pick_cfg(M, N);
+    const long tiles = (long)cdiv(M, cfg_bm(c)) * cdiv(N, cfg_bn(c));
+    if (tiles >= 256 || K < 1024) return 1;
+    long s = (512 + tiles - 1) / tiles;
     const long max_by_k = K / 512;   // keep >= 2 phases per split
     if (s > max_by_k) s = max_by_k;
     if (s > 32) s = 32;
@@ -304,21 +342,23 @@ extern "C" int vitae_gemm_bf16(int a_kcontig, int b_kcontig, const float* A, lon
     GemmArgs p;
     p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc;
     p.M = M; p.N = N; p.K = K;
-    const int bn = pick_bn(M, N);
-    const int bk = bk_of(bn);
+    const int c = pick_cfg(M, N);
+    const int bm = cfg_bm(c), bn = cfg_bn(c), bk = cfg_bk(c);
     int kps = cdiv(cdiv(K, split_k), bk) * bk;
     split_k = cdiv(K, kps);
     if (split_k > 1 && !splitk_ws) return VITAE_ERR_INVALID_ARG;
     p.k_per_split = kps; p.splits = split_k;
     p.bias = bias; p.residual = residual; p.ldr = ldr; p.aux = aux; p.ldaux = ldaux;
     p.epi = epi; p.accumulate = accumulate; p.ws = splitk_ws; p.colsum = a_colsum_accum;
-    p.tiles_m = cdiv(M, BM); p.tiles_n = cdiv(N, bn);
+    p.tiles_m = cdiv(M, bm); p.tiles_n = cdiv(N, bn);
     p.n_per_xcd = cdiv(p.tiles_n, 8);
     dim3 grid(8 * p.n_per_xcd * p.tiles_m, 1, split_k);
     hipStream_t st = (hipStream_t)stream;
     const bool akc = a_kcontig != 0, bkc = b_kcontig != 0;
-    if (bn == 128) { if (b_is_bf16) launch<128, 128, true>(p, akc, bkc, grid, st); else launch<128, 128, false>(p, akc, bkc, grid, st); }
-    else { if (b_is_bf16) launch<64, 256, true>(p, akc, bkc, grid, st); else launch<64, 256, false>(p, akc, bkc, grid, st); }
+    if (c == 2) { if (b_is_bf16) launch<64, 128, 128, 256, true>(p, akc, bkc, grid, st); else launch<64, 128, 128, 256, false>(p, akc, bkc, grid, st); }
+    else if (c == 3) { if (b_is_bf16) launch<64, 64, 256, 512, true>(p, akc, bkc, grid, st); else launch<64, 64, 256, 512, false>(p, akc, bkc, grid, st); }
+    else if (c == 1) { if (b_is_bf16) launch<64, 64, 256, 256, true>(p, akc, bkc, grid, st); else launch<64, 64, 256, 256, false>(p, akc, bkc, grid, st); }
+    else { if (b_is_bf16) launch<32, 64, 256, 128, true>(p, akc, bkc, grid, st); else launch<32, 64, 256, 128, false>(p, akc, bkc, grid, st); }
     if (split_k > 1) {
         const long total = (long)M * N;
         int blocks = (int)((total + 255) / 256);
@@ -341,26 +381,33 @@ extern "C" int vitae_linear_bwd_pair_bf16(const float* dy, const void* w_bf16, c
     // dgrad: rows M, cols K (in-features), reduction N
     p1.A = dy; p1.lda = N; p1.B = w_bf16; p1.ldb = K; p1.C = dx; p1.ldc = K;
     p1.M = M; p1.N = K; p1.K = N;
-    const int bn1 = pick_bn(M, K), bk1 = bk_of(bn1);
+    int c1 = pick_cfg(M, K), c2 = pick_cfg(N, K);
+    if (cfg_nt(c1) != cfg_nt(c2)) {   // one block size per launch: fall back to the 256-thread shapes
+        if (c1 == 0 || c1 == 3) c1 = 1;
+        if (c2 == 0 || c2 == 3) c2 = 1;
+    }
+    const int bm1 = cfg_bm(c1), bn1 = cfg_bn(c1), bk1 = cfg_bk(c1);
     p1.k_per_split = cdiv(N, bk1) * bk1; p1.splits = 1;
     p1.bias = nullptr; p1.residual = nullptr; p1.ldr = 0; p1.aux = aux; p1.ldaux = K; p1.epi = epi;
     p1.accumulate = dx_accumulate; p1.ws = nullptr; p1.colsum = db_accum;
-    p1.tiles_m = cdiv(M, BM); p1.tiles_n = cdiv(K, bn1); p1.n_per_xcd = cdiv(p1.tiles_n, 8);
+    p1.tiles_m = cdiv(M, bm1); p1.tiles_n = cdiv(K, bn1); p1.n_per_xcd = cdiv(p1.tiles_n, 8);
     // wgrad: rows N (out-features), cols K, reduction M (tokens)
     p2.A = dy; p2.lda = N; p2.B = x; p2.ldb = K; p2.C = dw; p2.ldc = K;
     p2.M = N; p2.N = K; p2.K = M;
-    const int bn2 = pick_bn(N, K), bk2 = bk_of(bn2);
+    const int bm2 = cfg_bm(c2), bn2 = cfg_bn(c2), bk2 = cfg_bk(c2);
     p2.k_per_split = cdiv(M, bk2) * bk2; p2.splits = 1;
     p2.bias = nullptr; p2.residual = nullptr; p2.ldr = 0; p2.aux = nullptr; p2.ldaux = 0; p2.epi = VITAE_EPI_NONE;
     p2.accumulate = dw_accumulate; p2.ws = nullptr; p2.colsum = nullptr;
-    p2.tiles_m = cdiv(N, BM); p2.tiles_n = cdiv(K, bn2); p2.n_per_xcd = cdiv(p2.tiles_n, 8);
+    p2.tiles_m = cdiv(N, bm2); p2.tiles_n = cdiv(K, bn2); p2.n_per_xcd = cdiv(p2.tiles_n, 8);
     const int nb1 = 8 * p1.n_per_xcd * p1.tiles_m, nb2 = 8 * p2.n_per_xcd * p2.tiles_m;
-    dim3 grid(nb1 + nb2), block(256);
+    dim3 grid(nb1 + nb2);
     hipStream_t st = (hipStream_t)stream;
-    if (bn1 == 64 && bn2 == 64) hipLaunchKernelGGL((gemm_bf16_pair_kernel<64, 256, 64, 256>), grid, block, 0, st, p1, p2, nb1);
-    else if (bn1 == 64) hipLaunchKernelGGL((gemm_bf16_pair_kernel<64, 256, 128, 128>), grid, block, 0, st, p1, p2, nb1);
-    else if (bn2 == 64) hipLaunchKernelGGL((gemm_bf16_pair_kernel<128, 128, 64, 256>), grid, block, 0, st, p1, p2, nb1);
-    else hipLaunchKernelGGL((gemm_bf16_pair_kernel<128, 128, 128, 128>), grid, block, 0, st, p1, p2, nb1);
+    if (c1 == 0) hipLaunchKernelGGL((gemm_bf16_pair_kernel<128, 32, 64, 256, 32, 64, 256>), grid, dim3(128), 0, st, p1, p2, nb1);
+    else if (c1 == 3) hipLaunchKernelGGL((gemm_bf16_pair_kernel<512, 64, 64, 256, 64, 64, 256>), grid, dim3(512), 0, st, p1, p2, nb1);
+    else if (c1 == 1 && c2 == 1) hipLaunchKernelGGL((gemm_bf16_pair_kernel<256, 64, 64, 256, 64, 64, 256>), grid, dim3(256), 0, st, p1, p2, nb1);
+    else if (c1 == 1) hipLaunchKernelGGL((gemm_bf16_pair_kernel<256, 64, 64, 256, 64, 128, 128>), grid, dim3(256), 0, st, p1, p2, nb1);
+    else if (c2 == 1) hipLaunchKernelGGL((gemm_bf16_pair_kernel<256, 64, 128, 128, 64, 64, 256>), grid, dim3(256), 0, st, p1, p2, nb1);
+    else hipLaunchKernelGGL((gemm_bf16_pair_kernel<256, 64, 128, 128, 64, 128, 128>), grid, dim3(256), 0, st, p1, p2, nb1);
     return vitae_launch_status();
 }
 
