@@ -305,7 +305,7 @@ static inline int env_int(const char* name, int dflt) {
 }
 static inline int pick_cfg(int M, int N) {
     static const int big = env_int("VITAE_BN128_MIN_TILES", 512), small = env_int("VITAE_BM32_MAX_TILES", 0);
-    static const int w8 = env_int("VITAE_GEMM_8WAVES", 1);
+    static const int w8 = env_int("VITAE_GEMM_8WAVES", 0);   // faster on L2-warm operands, slower in the real (cold-weight) step
     if (N >= 128 && (long)cdiv(M, 64) * cdiv(N, 128) >= big) return 2;
     if ((long)cdiv(M, 64) * cdiv(N, 64) < small) return 0;
     return w8 ? 3 : 1;
