@@ -156,32 +156,44 @@ def main():
     ms = elapsed / args.steps * 1e3
     value = world * args.batch * args.steps / elapsed
 
-    # ---- roofline of the dominant kernel family (GEMM): eager instrumented steps, HIP events on the
-    # launch stream around every GEMM launch (split-K reduce included in its launch)
+    # ---- roofline of the dominant kernel family (the MFMA GEMM kernels of csrc/gemm_bf16.hip / gemm.hip):
+    # instrumented eager steps right after the timed region, HIP events (torch.cuda.Event on the launch
+    # stream = torch's current stream) around every GEMM launch.  A spin kernel is queued first so the host
+    # enqueues the whole step while the GPU is still busy: event deltas then contain no host-launch gaps.
     roof = None
     if rank == 0:
         eager = model._step_runner(args.batch, 0.75, True, False, False)
-        eng.gemm_timer = []
+        recs = []
         for i in range(args.profile_steps):
             v1, v2 = batches[i % len(batches)]
             eager.load(v1, v2 if contr else None)
             eng.optimizer_hparams(lr=1e-4)
+            torch.cuda._sleep(200_000_000)
+            eng.gemm_timer = []
             if world > 1:   # keep collectives matched: other ranks idle here, so time phases locally only
                 for k in range(3):
                     eager._phase(k)
             else:
                 eager.run()
-        torch.cuda.synchronize()
-        recs = eng.gemm_timer
-        eng.gemm_timer = None
+            torch.cuda.synchronize()
+            recs += eng.gemm_timer
+            eng.gemm_timer = None
         tot_ms = sum(a.elapsed_time(b) for a, b, _ in recs)
         tot_fl = sum(f for _, _, f in recs)
         n_launch = len(recs) / args.profile_steps
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.precision]
-        roof = {'bound': 'mfma', 'kernel': 'gemm_kernel<prec,a_kc,b_kc> (+splitk_reduce)', 'achieved': round(ach, 2),
-                'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': None,
+        kname = ('gemm_bf16_kernel / gemm_bf16_pair_kernel (csrc/gemm_bf16.hip)' if args.precision == 'bf16'
+                 else 'gemm_kernel<0,..> (csrc/gemm.hip)')
+        traffic = None   # PMC counters cannot be read from inside the process: last committed rocprofv3 --pmc result
+        tfile = os.path.join(ROOT, 'profiles', 'round1_gemm_traffic.json')
+        if args.precision == 'bf16' and os.path.exists(tfile):
+            traffic = json.load(open(tfile)).get('avg_bytes_per_gemm_launch')
+        roof = {'bound': 'mfma', 'kernel': kname, 'achieved': round(ach, 2),
+                'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': traffic,
+                'traffic_unit': 'bytes per GEMM launch (fabric side, profiles/round1_gemm_traffic.json)',
                 'launches_per_step': n_launch, 'gflop_per_step': round(tot_fl / args.profile_steps / 1e9, 2),
+                'avg_launch_us': round(tot_ms * 1e3 / len(recs), 2),
                 'gemm_ms_per_step': round(tot_ms / args.profile_steps, 3),
                 'step_frac_of_peak': round(world * args.batch * ALGO_GFLOP_PER_VOL[args.model] * 1e9 / (ms * 1e-3) / 1e12 / (peak * world), 4)}
     if world > 1:

@@ -60,7 +60,11 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, float v, int m
 
 __device__ __forceinline__ int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
-// LDS row stride (elements) for a tile whose contiguous dimension has `n` elements
+// LDS row stride (bf16 elements) of a row-contiguous tile [k][n].  ds_read_b64_tr_b16 is serviced in two
+// 32-lane groups touching 4 consecutive k-rows x 64 B; fully conflict-free needs a stride of 16 or 48
+// dwords mod 64 (n + 32 elements), which was MEASURED SLOWER end to end: the larger tiles (98 KB) drop the
+// paired dgrad+wgrad launch from 2 to 1 workgroup per CU.  n + 8 / n + 16 keeps 2-way conflicts
+// (SQ_LDS_BANK_CONFLICT = 28 % of SQ_LDS_IDX_ACTIVE in profiles/) but two resident workgroups.
 __host__ __device__ constexpr int ld_pad(int n) { return n == 128 ? n + 16 : n + 8; }
 
 // ---------------------------------------------------------------- operand staging

@@ -361,9 +361,12 @@ class HipMAEEngine:
         """Full backward of y = x W^T + b given dy: dx (+)= epi(dy W), dW (+)= dy^T x, db += colsum(dy).
         bf16 mode: ONE paired launch (dgrad + wgrad blocks side by side); fp32 mode: separate launches."""
         w16 = self._w16(w) if self.prec == PREC['bf16'] else 0
-        if w16 and self.gemm_timer is None:
+        if w16:
+            t = self._timed(4.0 * M * N * K)   # dgrad + wgrad
             lib.vitae_linear_bwd_pair_bf16(_ptr(dy), w16, _ptr(x), _ptr(dx), _ptr(dw), _ptr(db), M, N, K, epi, _ptr(aux),
                                            dx_accumulate, int(self._accum), self.stream)
+            if t is not None:
+                t.record()
             return
         self._lin_bwd_w(dy, x, dw, None, M, N, K, tag=tag)
         self._lin_bwd_x(dy, w, dx, M, N, K, epi=epi, aux=aux, accumulate=dx_accumulate, db=db)

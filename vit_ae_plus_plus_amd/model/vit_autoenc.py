@@ -137,7 +137,7 @@ class _StepRunner:
         self.graphs = []
         for grp in groups:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side):
+            with torch.cuda.graph(g, stream=side, capture_error_mode='thread_local'):
                 for k in grp:
                     self._phase(k)
             self.graphs.append(g)
