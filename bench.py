@@ -91,12 +91,18 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if rank != 0:   # only rank 0 talks on stdout (the contract is ONE JSON line)
+        sys.stdout = open(os.devnull, 'w')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (the HIP path has no CPU fallback)')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
+    force_ddp = os.environ.get('VITAE_FORCE_DDP') == '1' and world == 1   # single-GPU check of the N>1 machinery
+    if world > 1 or force_ddp:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=dev)
 
     from vit_ae_plus_plus_amd.model import vit_autoenc as VA
@@ -114,7 +120,7 @@ def main():
     eng = model._ensure_engine(dev)
     opt = FusedAdamW(model, lr=1e-4, weight_decay=0.05, betas=(0.9, 0.95))
     _ = opt.engine
-    model.enable_data_parallel(dev)
+    model.enable_data_parallel(dev, force=force_ddp)
     eng.set_loss_weights(0.01, 0.001 if contr else 0.0, 1, world)
 
     cpu_batches = synthetic_batches(args.batch, rank)
@@ -221,9 +227,16 @@ def main():
                'roofline': roof, 'cpu_baseline': cpu}
         if parity:
             out['parity'] = parity
-        print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_ddp:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner through C stdio: drain that first so the JSON line is the LAST line
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':

@@ -30,9 +30,10 @@ class GradBucketReducer:
     """Asynchronous SUM all-reduce of contiguous ranges of one flat gradient tensor."""
 
     def __init__(self, flat: torch.Tensor, ranges: Sequence[Tuple[int, int]], group=None,
-                 max_bucket_elems: Optional[int] = None):
+                 max_bucket_elems: Optional[int] = None, force: bool = False):
         assert flat.dim() == 1
         self.flat, self.group = flat, group
+        self.force = force   # exercise the exchange machinery even at world size 1 (single-GPU validation)
         self.ranges: List[List[Tuple[int, int]]] = []
         for s, e in ranges:
             assert 0 <= s <= e <= flat.numel()
@@ -51,10 +52,14 @@ class GradBucketReducer:
     def world_size(self) -> int:
         return dist.get_world_size(self.group) if is_distributed() else 1
 
+    @property
+    def active(self) -> bool:
+        return self.world_size > 1 or (self.force and dist.is_available() and dist.is_initialized())
+
     def launch(self, bucket: int):
         """Issue the all-reduce of bucket ``bucket`` (non-blocking; ordered after work already enqueued
         on the current stream)."""
-        if self.world_size == 1:
+        if not self.active:
             return
         for s, e in self.ranges[bucket]:
             if e > s:

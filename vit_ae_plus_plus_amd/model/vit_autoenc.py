@@ -147,7 +147,7 @@ class _StepRunner:
         Data parallel: phases 0..2 each followed by the asynchronous all-reduce of the gradient bucket
         they complete, then wait + grad-norm/AdamW (no exchange on gradient-accumulation micro-steps)."""
         eng, red = self.eng, self.model._reducer
-        exchange = red is not None and red.world_size > 1 and self.update
+        exchange = red is not None and red.active and self.update
         groups = [[0], [1], [2], [3]] if exchange else [list(range(eng.N_PHASES))]
         if self.use_graph and self.graphs is None:
             self._capture(groups)
@@ -292,16 +292,16 @@ class MaskedAutoencoderViT(nn.Module):
                 self.decoder_pos_embed.data.reshape(eng.buffers['decoder_pos_embed'].shape))
         return out
 
-    def enable_data_parallel(self, device=None, group=None):
+    def enable_data_parallel(self, device=None, group=None, force=False):
         """One process per GPU: broadcast rank 0's replica and all-reduce gradient buckets over RCCL
         (overlapped with backward) inside the fused step.  No-op for a single process."""
         from .. import ddp
-        if not ddp.is_distributed():
+        if not ddp.is_distributed() and not (force and torch.distributed.is_initialized()):
             self._reducer = None
             return None
         eng = self._ensure_engine(torch.device(device) if device is not None else next(self.parameters()).device)
         ddp.broadcast_parameters(eng, 0, group)
-        self._reducer = ddp.GradBucketReducer(eng.grads, ddp.engine_bucket_ranges(eng), group=group)
+        self._reducer = ddp.GradBucketReducer(eng.grads, ddp.engine_bucket_ranges(eng), group=group, force=force)
         self._runners.clear()
         return self._reducer
 
