@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITAE_ABI_VERSION 6
+#define VITAE_ABI_VERSION 8
 
 /* matrix-core arithmetic of the dense contractions */
 #define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
@@ -89,12 +89,18 @@ int vitae_linear_bwd_pair_bf16(const float* dy, const void* w_bf16, const float*
                                float* db_accum, int M, int N, int K, int epi, float* aux, int dx_accumulate,
                                int dw_accumulate, void* stream);
 /* bf16 x bf16 variant with a 4-stage LDS-DMA (global_load_lds) pipeline; A16/B16 bf16, K % 64 == 0;
- * C (fp32) and/or C16 (bf16 copy of the result) may be given. */
+ * C (fp32) and/or C16 (bf16 copy of the result) may be given; out_colsum_accum[n] += sum_m result(m,n). */
 int vitae_gemm_glds(int a_kcontig, int b_kcontig, const void* A16, long lda, const void* B16, long ldb, float* C,
                     long ldc, void* C16, long ldc16, int M, int N, int K, const float* bias, const float* residual,
                     long ldr, int epi, float* aux, long ldaux, int accumulate, int split_k, float* splitk_ws,
-                    void* stream);
+                    float* out_colsum_accum, void* stream);
 int vitae_gemm_glds_pick_split_k(int M, int N, int K);
+/* Backward of one nn.Linear on bf16 operands in one launch: dx / dx16 [M,K] = epi(dy16 W16), optional
+ * dx_colsum_accum[k] += sum_m dx(m,k); dW[N,K] (+)= dy16^T x16 reduced over Mpad (>= M, multiple of 64) token
+ * rows — rows M..Mpad-1 of dy16 and x16 must be zero. */
+int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, const void* x16, float* dx, void* dx16, float* dw,
+                               int M, int Mpad, int N, int K, int epi, float* aux, float* dx_colsum_accum,
+                               int dw_accumulate, void* stream);
 /* dst_bf16[i] = bf16(src[i]) (round to nearest even) */
 int vitae_cast_bf16(const float* src, void* dst_bf16, long n, void* stream);
 
@@ -114,11 +120,14 @@ int vitae_colsum_accum(const float* dy, long ld, float* out, int M, int N, void*
 
 /* ---- LayerNorm (partial(nn.LayerNorm, eps=1e-6): model/vit_autoenc.py:292,300,308; used at
  * model/vit.py:132,135,142-143, model/vit_autoenc.py:36,51,175,195) ------------------------------ */
-int vitae_layernorm_fwd(const float* x, const float* w, const float* b, float* y, float* mean, float* rstd,
-                        int M, int D, float eps, void* stream);
-/* dw, db accumulate (+=); dx overwritten, or += when dx_accumulate */
+/* y (fp32) and/or y_bf16 (bf16 copy for the next GEMM's operand) */
+int vitae_layernorm_fwd(const float* x, const float* w, const float* b, float* y, void* y_bf16, float* mean,
+                        float* rstd, int M, int D, float eps, void* stream);
+/* dw, db accumulate (+=); dx overwritten, or += when dx_accumulate; optional dx_bf16 = bf16(final dx) and
+ * dx_colsum_accum[c] += sum_m final dx(m,c) (the bias gradient of the Linear whose output gradient dx is) */
 int vitae_layernorm_bwd(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
-                        float* dx, float* dw, float* db, int M, int D, int dx_accumulate, void* stream);
+                        float* dx, float* dw, float* db, void* dx_bf16, float* dx_colsum_accum, int M, int D,
+                        int dx_accumulate, void* stream);
 
 /* ---- attention core  softmax(q k^T / sqrt(hd)) v  (model/vit.py:117-121) -------------------------
  * qkv [B,N,3,H,hd] (output of the qkv Linear, model/vit.py:114), o [B,N,H*hd], lse/delta [B,H,N]. */
@@ -128,9 +137,10 @@ int vitae_sdpa_bwd(const float* qkv, const float* o, const float* d_o, const flo
 
 /* bf16-MFMA implementation of the same two entry points (head_dim 32 or 64; operands rounded to bf16,
  * fp32 softmax / accumulation); VITAE_ERR_UNSUPPORTED_SHAPE for other head dims. */
-int vitae_sdpa_mfma_fwd(const float* qkv, float* o, float* lse, int B, int N, int H, int head_dim, void* stream);
+int vitae_sdpa_mfma_fwd(const float* qkv, float* o, void* o_bf16, float* lse, int B, int N, int H, int head_dim,
+                        void* stream);
 int vitae_sdpa_mfma_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv,
-                        float* delta_ws, int B, int N, int H, int head_dim, void* stream);
+                        void* dqkv_bf16, float* delta_ws, int B, int N, int H, int head_dim, void* stream);
 
 /* ---- masking and sequence assembly ---------------------------------------------------------------
  * random_masking (model/vit_autoenc.py:141-153) from a caller-supplied noise[B,L] (the torch.rand of
@@ -140,12 +150,13 @@ int vitae_random_masking(const float* noise, int* ids_shuffle, int* ids_restore,
                          long long* ids_restore_i64, int B, int L, int len_keep, void* stream);
 /* rows of the patch-embedding GEMM for the kept patches only: out[B*keep, C*p^3] in Conv3d weight
  * order (model/vit.py:65,72-74 + model/vit_autoenc.py:147-148) */
-int vitae_gather_patches(const float* vol, const int* ids_shuffle, float* out, int B, int C, int Lz, int Hy, int Wx,
-                         int p, int keep, void* stream);
+int vitae_gather_patches(const float* vol, const int* ids_shuffle, float* out, void* out_bf16, int B, int C, int Lz,
+                         int Hy, int Wx, int p, int keep, void* stream);
 /* x[B,keep+1,D]: + pos_embed, cls token (model/vit_autoenc.py:162-170) */
 int vitae_encoder_assemble_fwd(const float* tok, const float* cls_token, const float* pos_embed,
                                const int* ids_shuffle, float* x, int B, int L, int keep, int D, void* stream);
-int vitae_encoder_assemble_bwd(const float* dx, float* dtok, float* dcls_accum, int B, int keep, int D, void* stream);
+int vitae_encoder_assemble_bwd(const float* dx, float* dtok, void* dtok_bf16, float* dcls_accum, int B, int keep, int D,
+                               void* stream);
 /* xd[B,L+1,Dd]: mask-token fill + unshuffle + decoder_pos_embed (model/vit_autoenc.py:184-190) */
 int vitae_decoder_assemble_fwd(const float* e, const float* mask_token, const float* dpos, const int* ids_restore,
                                float* xd, int B, int L, int keep, int Dd, void* stream);
@@ -171,8 +182,8 @@ int vitae_sobel_edge_fwd(const float* vol, float* edge, const float* edge_ref, d
                          int Hy, int Wx, void* stream);
 /* dpred += d(edge mse)/d pred ; dG_ws = B*C*3*Lz*Hy*Wx floats of scratch */
 int vitae_sobel_edge_bwd(const float* pred_vol, const float* edge_pred, const float* edge_tgt, const float* hp,
-                         float* dG_ws, float* dpred, long pred_bstride, int B, int C, int Lz, int Hy, int Wx, int p,
-                         void* stream);
+                         float* dG_ws, float* dpred, void* dpred_bf16, long pred_bstride, int B, int C, int Lz, int Hy,
+                         int Wx, int p, void* stream);
 /* out4 = [loss, raw_edge_mse, recon, percep=0] (model/vit_autoenc.py:231-232) */
 int vitae_loss_finalize(const double* acc, const float* hp, float* out4, float mask_sum, long edge_count, void* stream);
 

@@ -167,6 +167,48 @@ def test_linear_bwd_pair_bf16(lib, C, M, N, K):
     assert rel_err(dx, hh.grad + dy @ w) < 2e-2 and rel_err(dw, 2 * (dy.t() @ x)) < 2e-2
 
 
+@pytest.mark.parametrize('M,N,K', [(440, 2304, 768), (868, 512, 2048), (440, 768, 3072), (868, 16384, 512), (100, 64, 64)])
+def test_linear_bwd_pair_glds(lib, C, M, N, K):
+    """bf16-operand backward of one Linear (LDS-DMA kernels): dx, bf16 dx, colsum(dx), dW."""
+    Mp = (M + 63) // 64 * 64
+    x, w, dy, h = gen(M, K, seed=1), gen(N, K, seed=2, scale=K ** -0.5), gen(M, N, seed=5), gen(M, K, seed=6)
+    x16 = torch.zeros(Mp, K, dtype=torch.bfloat16, device='cuda'); x16[:M] = x.cuda().to(torch.bfloat16)
+    dy16 = torch.zeros(Mp, N, dtype=torch.bfloat16, device='cuda'); dy16[:M] = dy.cuda().to(torch.bfloat16)
+    w16 = w.cuda().to(torch.bfloat16)
+    hd_ = dev(h)
+    dx, dx16 = torch.full((M, K), float('nan'), device='cuda'), torch.zeros(M, K, dtype=torch.bfloat16, device='cuda')
+    dw, cs = torch.full((N, K), float('nan'), device='cuda'), torch.zeros(K, device='cuda')
+    lib.vitae_linear_bwd_pair_glds(dy16.data_ptr(), w16.data_ptr(), x16.data_ptr(), dx.data_ptr(), dx16.data_ptr(), dw.data_ptr(),
+                                   M, Mp, N, K, C['VITAE_EPI_DGELU'], hd_.data_ptr(), cs.data_ptr(), 0, st())
+    dyr, wr, xr = dy16[:M].float().cpu(), w16.float().cpu(), x16[:M].float().cpu()
+    hh = h.clone().requires_grad_(True)
+    F.gelu(hh).backward(dyr @ wr)
+    assert rel_err(dx, hh.grad) < 2e-3 and rel_err(dw, dyr.t() @ xr) < 2e-3
+    assert torch.equal(dx16, dx.to(torch.bfloat16)) and rel_err(cs, dx.sum(0)) < 1e-4
+    lib.vitae_linear_bwd_pair_glds(dy16.data_ptr(), w16.data_ptr(), x16.data_ptr(), dx.data_ptr(), None, dw.data_ptr(),
+                                   M, Mp, N, K, 0, None, None, 1, st())
+    assert rel_err(dx, dyr @ wr) < 2e-3 and rel_err(dw, 2 * (dyr.t() @ xr)) < 2e-3
+
+
+@pytest.mark.parametrize('M,N,K', [(440, 2304, 768), (432, 768, 16384), (868, 16384, 512), (100, 72, 128)])
+def test_gemm_glds_forward_forms(lib, C, M, N, K):
+    x, w, b, res = gen(M, K, seed=1), gen(N, K, seed=2, scale=K ** -0.5), gen(N, seed=3), gen(M, N, seed=4)
+    x16, w16 = x.cuda().to(torch.bfloat16), w.cuda().to(torch.bfloat16)
+    bd, rd = dev(b), dev(res)
+    ws = torch.empty(1 << 24, device='cuda')
+    ref = F.linear(x16.float().cpu(), w16.float().cpu(), b)
+    for split in (1, lib.vitae_gemm_glds_pick_split_k(M, N, K)):
+        y, y16, cs = torch.full((M, N), float('nan'), device='cuda'), torch.zeros(M, N, dtype=torch.bfloat16, device='cuda'), torch.zeros(N, device='cuda')
+        lib.vitae_gemm_glds(1, 1, x16.data_ptr(), K, w16.data_ptr(), K, y.data_ptr(), N, y16.data_ptr(), N, M, N, K, bd.data_ptr(),
+                            rd.data_ptr(), N, 0, None, 0, 0, split, ws.data_ptr(), cs.data_ptr(), st())
+        assert rel_err(y, ref + res) < 2e-3, f'split {split}'
+        assert torch.equal(y16, y.to(torch.bfloat16)) and rel_err(cs, y.sum(0)) < 1e-4
+    y16, aux = torch.zeros(M, N, dtype=torch.bfloat16, device='cuda'), torch.empty(M, N, device='cuda')
+    lib.vitae_gemm_glds(1, 1, x16.data_ptr(), K, w16.data_ptr(), K, None, 0, y16.data_ptr(), N, M, N, K, bd.data_ptr(), None, 0,
+                        C['VITAE_EPI_GELU'], aux.data_ptr(), N, 0, 1, None, None, st())
+    assert rel_err(aux, ref) < 2e-3 and rel_err(y16.float(), F.gelu(ref)) < 1e-2
+
+
 def test_gemm_bf16_asymmetric(lib):
     a = torch.eye(64)
     b = torch.arange(64 * 64, dtype=torch.float32).reshape(64, 64) / 128.0
@@ -209,19 +251,24 @@ def test_layernorm(lib, M, D):
     x, w, b, dy = gen(M, D, seed=1, scale=2.0) + 0.3, gen(D, seed=2) + 1.0, gen(D, seed=3), gen(M, D, seed=4)
     xd, wd, bd, dyd = dev(x), dev(w), dev(b), dev(dy)
     y, mean, rstd = torch.empty(M, D, device='cuda'), torch.empty(M, device='cuda'), torch.empty(M, device='cuda')
-    lib.vitae_layernorm_fwd(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+    y16 = torch.empty(M, D, dtype=torch.bfloat16, device='cuda')
+    lib.vitae_layernorm_fwd(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), y16.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                             M, D, 1e-6, st())
     xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
     ref = F.layer_norm(xr, (D,), wr, br, 1e-6)
     ref.backward(dy)
     assert rel_err(y, ref) < 1e-5
+    assert torch.equal(y16, y.to(torch.bfloat16))
     base = gen(M, D, seed=5)
     for accum in (0, 1):
         dx = dev(base)
         dw, db = torch.zeros(D, device='cuda'), torch.zeros(D, device='cuda')
+        dx16 = torch.empty(M, D, dtype=torch.bfloat16, device='cuda')
+        cs = torch.zeros(D, device='cuda')
         lib.vitae_layernorm_bwd(dyd.data_ptr(), xd.data_ptr(), wd.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                dx.data_ptr(), dw.data_ptr(), db.data_ptr(), M, D, accum, st())
+                                dx.data_ptr(), dw.data_ptr(), db.data_ptr(), dx16.data_ptr(), cs.data_ptr(), M, D, accum, st())
         assert rel_err(dx, xr.grad + (base if accum else 0)) < 2e-5
+        assert torch.equal(dx16, dx.to(torch.bfloat16)) and rel_err(cs, dx.sum(0)) < 2e-5
         assert rel_err(dw, wr.grad) < 2e-5 and rel_err(db, br.grad) < 2e-5
 
 
@@ -257,12 +304,16 @@ def test_sdpa_mfma_bf16(lib, B, N, H, hd):
     ref_lse = torch.logsumexp((q @ k.transpose(-2, -1)) * hd ** -0.5, -1).detach()   # [B,H,N]
     qd, dod = dev(qkv), dev(do)
     o, lse = torch.full((B, N, D), float('nan'), device='cuda'), torch.empty(B * H * N, device='cuda')
-    lib.vitae_sdpa_mfma_fwd(qd.data_ptr(), o.data_ptr(), lse.data_ptr(), B, N, H, hd, st())
+    o16 = torch.empty(B, N, D, dtype=torch.bfloat16, device='cuda')
+    lib.vitae_sdpa_mfma_fwd(qd.data_ptr(), o.data_ptr(), o16.data_ptr(), lse.data_ptr(), B, N, H, hd, st())
+    assert torch.equal(o16, o.to(torch.bfloat16))
     assert rel_err(o, ref) < 2e-2
     assert float((lse.cpu().reshape(B, H, N) - ref_lse).abs().max()) < 3e-2
     dqkv, delta = torch.full((B, N, 3 * D), float('nan'), device='cuda'), torch.empty(B * H * N, device='cuda')
-    lib.vitae_sdpa_mfma_bwd(qd.data_ptr(), o.data_ptr(), dod.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), delta.data_ptr(),
-                            B, N, H, hd, st())
+    g16 = torch.empty(B, N, 3 * D, dtype=torch.bfloat16, device='cuda')
+    lib.vitae_sdpa_mfma_bwd(qd.data_ptr(), o.data_ptr(), dod.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), g16.data_ptr(),
+                            delta.data_ptr(), B, N, H, hd, st())
+    assert torch.equal(g16, dqkv.to(torch.bfloat16))
     g = qr.grad.reshape(B, N, 3, D)
     got = dqkv.cpu().reshape(B, N, 3, D)
     for i, name in enumerate('qkv'):
@@ -317,7 +368,9 @@ def test_gather_patches_and_assemble(lib, C_, vol, p):
     ids_shuffle = torch.argsort(noise, dim=1)
     sh = ids_shuffle.int().cuda()
     rows = torch.empty(B * keep, P, device='cuda')
-    lib.vitae_gather_patches(dev(x).data_ptr(), sh.data_ptr(), rows.data_ptr(), B, C_, *vol, p, keep, st())
+    rows16 = torch.empty(B * keep, P, dtype=torch.bfloat16, device='cuda')
+    lib.vitae_gather_patches(dev(x).data_ptr(), sh.data_ptr(), rows.data_ptr(), rows16.data_ptr(), B, C_, *vol, p, keep, st())
+    assert torch.equal(rows16, rows.to(torch.bfloat16))
     # conv-order rows: unfold the volume the way Conv3d's weight is flattened
     g = cfg.grid
     pat = x.reshape(B, C_, g[0], p, g[1], p, g[2], p).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(B, L, P)
@@ -333,7 +386,7 @@ def test_gather_patches_and_assemble(lib, C_, vol, p):
     assert torch.allclose(xs.cpu(), ref, atol=1e-6)
     dxs = gen(B, keep + 1, D, seed=6)
     dtok, dcls = torch.empty(B * keep, D, device='cuda'), torch.zeros(D, device='cuda')
-    lib.vitae_encoder_assemble_bwd(dev(dxs).data_ptr(), dtok.data_ptr(), dcls.data_ptr(), B, keep, D, st())
+    lib.vitae_encoder_assemble_bwd(dev(dxs).data_ptr(), dtok.data_ptr(), None, dcls.data_ptr(), B, keep, D, st())
     assert torch.equal(dtok.cpu(), dxs[:, 1:].reshape(B * keep, D))
     assert torch.allclose(dcls.cpu(), dxs[:, 0].sum(0), atol=1e-5)
     # decoder assembly fwd/bwd against the oracle's cat/gather formulation (vit_autoenc.py:184-190)
@@ -399,10 +452,12 @@ def test_loss_chain(lib, C, C_, vol, p):
     dG = torch.empty(B * C_ * 3 * V, device='cuda')
     lib.vitae_recon_loss_bwd(pp, pbs, im.data_ptr(), mk.data_ptr(), hp.data_ptr(), dpred.data_ptr() + P * 4, msum, B, C_, *vol,
                              p, st())
+    dpred16 = torch.zeros(B, L + 1, P, dtype=torch.bfloat16, device='cuda')
     lib.vitae_sobel_edge_bwd(pv.data_ptr(), ep.data_ptr(), et.data_ptr(), hp.data_ptr(), dG.data_ptr(), dpred.data_ptr() + P * 4,
-                             pbs, B, C_, *vol, p, st())
+                             dpred16.data_ptr() + P * 2, pbs, B, C_, *vol, p, st())
     assert float(dpred[:, 0].abs().max()) == 0.0
     assert rel_err(dpred, pr.grad) < 3e-5
+    assert torch.equal(dpred16, dpred.to(torch.bfloat16))
 
 
 def test_sobel_kat_and_nan_semantics(lib):

@@ -21,6 +21,13 @@ def go_on_current(go):
     go()
 
 
+COLD = '--cold' in sys.argv
+
+
+def ncopies(nbytes):
+    return max(1, min(64, int(400e6 // max(nbytes, 1)))) if COLD else 1
+
+
 def run(name, form, M, N, K, b16, iters=50):
     """form: 'fwd' (A[M,K] kc, B[N,K] kc), 'dgrad' (A[M,K] kc, B stored [K,N] row-contig), 'wgrad' (A stored [K,M], B stored [K,N])."""
     dev = 'cuda'
@@ -28,12 +35,16 @@ def run(name, form, M, N, K, b16, iters=50):
     A = torch.randn((M, K) if akc else (K, M), device=dev)
     Bt = torch.randn((N, K) if bkc else (K, N), device=dev)
     Bp = Bt.to(torch.bfloat16) if b16 else Bt
+    Bs = [Bp] + [Bp.clone() for _ in range(ncopies(Bp.numel() * Bp.element_size()) - 1)]
+    cnt = [0]
     C = torch.empty(M, N, device=dev)
     ws = torch.empty(1 << 24, device=dev)
     lda = K if akc else M
     ldb = K if bkc else N
     split = lib.vitae_gemm_bf16_pick_split_k(M, N, K)
     def go():
+        cnt[0] += 1
+        Bp = Bs[cnt[0] % len(Bs)]
         lib.vitae_gemm_bf16(akc, bkc, A.data_ptr(), lda, Bp.data_ptr(), ldb, b16, C.data_ptr(), N, M, N, K, None, None, 0, 0, None, 0, 0,
                             split, ws.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
     for _ in range(5): go()
@@ -52,15 +63,20 @@ def run_glds(name, form, M, N, K, iters=50, check=True):
     else: A[:K] = torch.randn(K, M, device=dev)
     if bkc: Bt[:, :K] = torch.randn(N, K, device=dev)
     else: Bt[:K] = torch.randn(K, N, device=dev)
-    A16, B16 = A.to(torch.bfloat16), Bt.to(torch.bfloat16)
+    A16, B16_0 = A.to(torch.bfloat16), Bt.to(torch.bfloat16)
+    B16 = B16_0
+    Bs = [B16_0] + [B16_0.clone() for _ in range(ncopies(B16_0.numel() * 2) - 1)]
+    cnt = [0]
     C = torch.full((M, N), float('nan'), device=dev)
     ws = torch.empty(1 << 24, device=dev)
     lda = Kp if akc else M
     ldb = Kp if bkc else N
     split = lib.vitae_gemm_glds_pick_split_k(M, N, Kp)
     def go():
+        cnt[0] += 1
+        B16 = Bs[cnt[0] % len(Bs)]
         lib.vitae_gemm_glds(akc, bkc, A16.data_ptr(), lda, B16.data_ptr(), ldb, C.data_ptr(), N, None, 0, M, N, Kp, None, None, 0, 0,
-                            None, 0, 0, split, ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                            None, 0, 0, split, ws.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
     for _ in range(5): go()
     torch.cuda.synchronize()
     err = ''
@@ -76,7 +92,7 @@ def run_glds(name, form, M, N, K, iters=50, check=True):
 
 
 if __name__ == '__main__':
-    glds = len(sys.argv) > 1 and sys.argv[1] == 'glds'
+    glds = 'glds' in sys.argv
     tot = 0.0
     E, D_ = 440, 868
     shapes = []

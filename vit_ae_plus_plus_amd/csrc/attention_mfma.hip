@@ -87,6 +87,7 @@ __device__ __forceinline__ f32x16 zero16() {
 // ------------------------------------------------------------------------------- forward
 template <int HD>
 __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ o,
+                                                            __bf16* __restrict__ o16,
                                                             float* __restrict__ lse, int N, int H, float scale) {
     constexpr int LD = HD + 8, NKK = HD / 16, NT = HD / 32;
     __shared__ __attribute__((aligned(16))) __bf16 Ks[CH * LD];
@@ -159,6 +160,12 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float* __restr
             for (int g = 0; g < 4; ++g) {
                 f32x4 v = {oacc[nt][4 * g] * inv, oacc[nt][4 * g + 1] * inv, oacc[nt][4 * g + 2] * inv, oacc[nt][4 * g + 3] * inv};
                 *reinterpret_cast<f32x4*>(orow + 32 * nt + 8 * g + 4 * hi) = v;
+                if (o16) {
+                    bf16x4 v16;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v16[e] = (__bf16)v[e];
+                    *reinterpret_cast<bf16x4*>(o16 + ((long)b * N + qrow) * D + h * HD + 32 * nt + 8 * g + 4 * hi) = v16;
+                }
             }
         if (hi == 0) lse[((long)b * H + h) * N + qrow] = (m + __builtin_amdgcn_logf(ltot)) * LN2;
     }
@@ -168,8 +175,8 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float* __restr
 template <int HD>
 __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
                                                                const float* __restrict__ d_o, const float* __restrict__ lse,
-                                                               float* __restrict__ dqkv, float* __restrict__ delta,
-                                                               int N, int H, float scale) {
+                                                               float* __restrict__ dqkv, __bf16* __restrict__ dqkv16,
+                                                               float* __restrict__ delta, int N, int H, float scale) {
     constexpr int LD = HD + 8, NKK = HD / 16, NT = HD / 32;
     __shared__ __attribute__((aligned(16))) __bf16 Ks[CH * LD];
     __shared__ __attribute__((aligned(16))) __bf16 Vs[CH * LD];
@@ -244,6 +251,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const float* __re
         for (int g = 0; g < 4; ++g) {
             f32x4 v = {acc[nt][4 * g] * scale, acc[nt][4 * g + 1] * scale, acc[nt][4 * g + 2] * scale, acc[nt][4 * g + 3] * scale};
             *reinterpret_cast<f32x4*>(out + 32 * nt + 8 * g + 4 * hi) = v;
+            if (dqkv16) {
+                bf16x4 v16;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v16[e] = (__bf16)v[e];
+                *reinterpret_cast<bf16x4*>(dqkv16 + ((long)b * N + qrow) * ld + h * HD + 32 * nt + 8 * g + 4 * hi) = v16;
+            }
         }
     if (hi == 0) delta[((long)b * H + h) * N + qrow] = dl;
 }
@@ -252,7 +265,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const float* __re
 template <int HD>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ d_o,
                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                float* __restrict__ dqkv, int N, int H, float scale) {
+                                                                float* __restrict__ dqkv, __bf16* __restrict__ dqkv16,
+                                                                int N, int H, float scale) {
     constexpr int LD = HD + 8, NKK = HD / 16, NT = HD / 32;
     __shared__ __attribute__((aligned(16))) __bf16 Qs[CH * LD];
     __shared__ __attribute__((aligned(16))) __bf16 Gs[CH * LD];
@@ -335,6 +349,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const float* __r
             f32x4 vv = {dv[nt][4 * g], dv[nt][4 * g + 1], dv[nt][4 * g + 2], dv[nt][4 * g + 3]};
             *reinterpret_cast<f32x4*>(out + D + d) = vk;       // Qs carried scale*log2e: dK = sum dS * scale * Q
             *reinterpret_cast<f32x4*>(out + 2 * D + d) = vv;
+            if (dqkv16) {
+                bf16x4 k16, v16;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { k16[e] = (__bf16)vk[e]; v16[e] = (__bf16)vv[e]; }
+                __bf16* o16 = dqkv16 + ((long)b * N + krow) * ld + h * HD;
+                *reinterpret_cast<bf16x4*>(o16 + D + d) = k16;
+                *reinterpret_cast<bf16x4*>(o16 + 2 * D + d) = v16;
+            }
         }
 }
 
@@ -342,20 +364,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const float* __r
 
 // Returns VITAE_ERR_UNSUPPORTED_SHAPE for head dims without an MFMA instantiation (caller falls back
 // to the fp32 VALU kernels of attention.hip — same results to bf16 round-off).
-extern "C" int vitae_sdpa_mfma_fwd(const float* qkv, float* o, float* lse, int B, int N, int H, int head_dim, void* stream) {
+extern "C" int vitae_sdpa_mfma_fwd(const float* qkv, float* o, void* o_bf16, float* lse, int B, int N, int H, int head_dim,
+                                   void* stream) {
     if (!qkv || !o || !lse || B <= 0 || N <= 0 || H <= 0) return VITAE_ERR_INVALID_ARG;
     if ((((long)H * head_dim) & 3) || ((uintptr_t)qkv & 15) || ((uintptr_t)o & 15)) return VITAE_ERR_UNSUPPORTED_SHAPE;
     const float scale = 1.0f / sqrtf((float)head_dim);
     dim3 grid(cdiv(N, 128), H, B);
     hipStream_t st = (hipStream_t)stream;
-    if (head_dim == 32) hipLaunchKernelGGL((attn_fwd_mfma_kernel<32>), grid, dim3(256), 0, st, qkv, o, lse, N, H, scale);
-    else if (head_dim == 64) hipLaunchKernelGGL((attn_fwd_mfma_kernel<64>), grid, dim3(256), 0, st, qkv, o, lse, N, H, scale);
+    __bf16* o16 = reinterpret_cast<__bf16*>(o_bf16);
+    if (head_dim == 32) hipLaunchKernelGGL((attn_fwd_mfma_kernel<32>), grid, dim3(256), 0, st, qkv, o, o16, lse, N, H, scale);
+    else if (head_dim == 64) hipLaunchKernelGGL((attn_fwd_mfma_kernel<64>), grid, dim3(256), 0, st, qkv, o, o16, lse, N, H, scale);
     else return VITAE_ERR_UNSUPPORTED_SHAPE;
     return vitae_launch_status();
 }
 
 extern "C" int vitae_sdpa_mfma_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv,
-                                   float* delta_ws, int B, int N, int H, int head_dim, void* stream) {
+                                   void* dqkv_bf16, float* delta_ws, int B, int N, int H, int head_dim, void* stream) {
     if (!qkv || !o || !d_o || !lse || !dqkv || !delta_ws || B <= 0 || N <= 0 || H <= 0) return VITAE_ERR_INVALID_ARG;
     if ((((long)H * head_dim) & 3) || ((uintptr_t)qkv & 15) || ((uintptr_t)o & 15) || ((uintptr_t)d_o & 15) ||
         ((uintptr_t)dqkv & 15))
@@ -363,12 +387,13 @@ extern "C" int vitae_sdpa_mfma_bwd(const float* qkv, const float* o, const float
     const float scale = 1.0f / sqrtf((float)head_dim);
     dim3 grid(cdiv(N, 128), H, B);
     hipStream_t st = (hipStream_t)stream;
+    __bf16* g16 = reinterpret_cast<__bf16*>(dqkv_bf16);
     if (head_dim == 32) {
-        hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<32>), grid, dim3(256), 0, st, qkv, o, d_o, lse, dqkv, delta_ws, N, H, scale);
-        hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<32>), grid, dim3(256), 0, st, qkv, d_o, lse, delta_ws, dqkv, N, H, scale);
+        hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<32>), grid, dim3(256), 0, st, qkv, o, d_o, lse, dqkv, g16, delta_ws, N, H, scale);
+        hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<32>), grid, dim3(256), 0, st, qkv, d_o, lse, delta_ws, dqkv, g16, N, H, scale);
     } else if (head_dim == 64) {
-        hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<64>), grid, dim3(256), 0, st, qkv, o, d_o, lse, dqkv, delta_ws, N, H, scale);
-        hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<64>), grid, dim3(256), 0, st, qkv, d_o, lse, delta_ws, dqkv, N, H, scale);
+        hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<64>), grid, dim3(256), 0, st, qkv, o, d_o, lse, dqkv, g16, delta_ws, N, H, scale);
+        hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<64>), grid, dim3(256), 0, st, qkv, d_o, lse, delta_ws, dqkv, g16, N, H, scale);
     } else {
         return VITAE_ERR_UNSUPPORTED_SHAPE;
     }

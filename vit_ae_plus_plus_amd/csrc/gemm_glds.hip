@@ -34,10 +34,11 @@ struct GArgs {
     float* aux; long ldaux;
     int epi, accumulate;
     float* ws;
+    float* out_colsum;   // optional: out_colsum[n] += sum_m (epilogue result)(m, n)  (bias gradient of the NEXT Linear)
     int tiles_m, tiles_n;
 };
 
-__device__ __forceinline__ void epilogue_store(const GArgs& p, float v, int m, int n) {
+__device__ __forceinline__ float epilogue_store(const GArgs& p, float v, int m, int n) {
     if (p.bias) v += p.bias[n];
     if (p.epi == VITAE_EPI_GELU) {
         p.aux[(long)m * p.ldaux + n] = v;
@@ -54,6 +55,7 @@ __device__ __forceinline__ void epilogue_store(const GArgs& p, float v, int m, i
         *c = v;
     }
     if (p.C16) p.C16[(long)m * p.ldc16 + n] = (__bf16)v;
+    return v;
 }
 
 __device__ __forceinline__ int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
@@ -109,18 +111,20 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+template <int BN> struct GCfg {
+    static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES, SMEM = NS * STAGE;
+};
+
 template <int BN, bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256) void gemm_glds_kernel(const GArgs p) {
+__device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, const int zid, unsigned char* smem) {
     constexpr int FN = BN / 64;
-    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_BYTES = GCfg<BN>::A_BYTES, STAGE = GCfg<BN>::STAGE;
     constexpr int G = (BM + BN) / 32;                      // DMA instructions per wave per stage
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGE];   // the ONLY LDS object
-    const int bid = blockIdx.x;
     const int xcd = bid & 7, local = bid >> 3;
     const int tn = xcd + 8 * (local / p.tiles_m), tm = local % p.tiles_m;
     if (tn >= p.tiles_n) return;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int kbeg = blockIdx.z * p.k_per_split;
+    const int kbeg = zid * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
     const int nk = (kend - kbeg) / BK;
     const int lane = threadIdx.x & 63;
@@ -128,11 +132,15 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GArgs p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, hi = lane >> 5;
 
-    f32x16 acc[FN];
+    // two accumulators per output fragment (even / odd 16-deep k-slices): consecutive MFMAs never depend
+    // on each other, so the matrix pipe is not serialised on the 32x32 accumulate latency
+    f32x16 acc[2][FN];
 #pragma unroll
-    for (int f = 0; f < FN; ++f)
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[f][i] = 0.f;
+        for (int f = 0; f < FN; ++f)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[h][f][i] = 0.f;
 
     auto issue = [&](int t) {
         unsigned char* st = smem + (t % NS) * STAGE;
@@ -152,29 +160,54 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GArgs p) {
         if (t + NS - 1 < nk) issue(t + NS - 1);   // refills the stage tile t-1 used
         const unsigned char* at = smem + (t % NS) * STAGE;
         const unsigned char* bt = at + A_BYTES;
+        bf16x8 fa[BK / 16], fb[BK / 16][FN];
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
-            const bf16x8 fa = frag<BM, A_KC>(at, wm * 32, kk, lane);
+            fa[kk] = frag<BM, A_KC>(at, wm * 32, kk, lane);
 #pragma unroll
-            for (int f = 0; f < FN; ++f) {
-                const bf16x8 fb = frag<BN, B_KC>(bt, wn * (BN / 2) + f * 32, kk, lane);
-                acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[f], 0, 0, 0);
-            }
+            for (int f = 0; f < FN; ++f) fb[kk][f] = frag<BN, B_KC>(bt, wn * (BN / 2) + f * 32, kk, lane);
         }
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk)
+#pragma unroll
+            for (int f = 0; f < FN; ++f)
+                acc[kk & 1][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk], fb[kk][f], acc[kk & 1][f], 0, 0, 0);
     }
 
 #pragma unroll
     for (int f = 0; f < FN; ++f) {
         const int n = n0 + wn * (BN / 2) + f * 32 + l31;
-        if (n >= p.N) continue;
+        float csum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm * 32 + crow(r, hi);
-            if (m >= p.M) continue;
-            if (p.splits > 1) p.ws[((long)blockIdx.z * p.M + m) * p.N + n] = acc[f][r];
-            else epilogue_store(p, acc[f][r], m, n);
+            const float a = acc[0][f][r] + acc[1][f][r];
+            if (n < p.N && m < p.M) {
+                if (p.splits > 1) p.ws[((long)zid * p.M + m) * p.N + n] = a;
+                else csum += epilogue_store(p, a, m, n);
+            }
+        }
+        if (p.out_colsum && p.splits == 1) {
+            csum += __shfl_xor(csum, 32, 64);
+            if (hi == 0 && n < p.N) atomicAdd(p.out_colsum + n, csum);
         }
     }
+}
+
+template <int BN, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_glds_kernel(const GArgs p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[GCfg<BN>::SMEM];   // the ONLY LDS object
+    gemm_glds_body<BN, A_KC, B_KC>(p, blockIdx.x, blockIdx.z, smem);
+}
+
+// dgrad (dy @ W: A k-contiguous, B = bf16 weights read row-contiguous) and wgrad (dy^T @ x: both operands
+// row-contiguous) of one Linear in one launch — they share dy, and together they double the resident
+// workgroups per CU.
+template <int BN1, int BN2>
+__global__ __launch_bounds__(256) void gemm_glds_pair_kernel(const GArgs p1, const GArgs p2, const int nb1) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[GCfg<(BN1 > BN2 ? BN1 : BN2)>::SMEM];
+    if ((int)blockIdx.x < nb1) gemm_glds_body<BN1, true, false>(p1, blockIdx.x, 0, smem);
+    else gemm_glds_body<BN2, false, false>(p2, blockIdx.x - nb1, 0, smem);
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_glds_kernel(const GArgs p) {
@@ -182,7 +215,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_glds_kernel(const GArgs p) 
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         float v = 0.f;
         for (int s = 0; s < p.splits; ++s) v += p.ws[(long)s * total + i];
-        epilogue_store(p, v, (int)(i / p.N), (int)(i % p.N));
+        const float r = epilogue_store(p, v, (int)(i / p.N), (int)(i % p.N));
+        if (p.out_colsum) atomicAdd(p.out_colsum + (i % p.N), r);
     }
 }
 
@@ -216,7 +250,7 @@ extern "C" int vitae_gemm_glds_pick_split_k(int M, int N, int K) {
 extern "C" int vitae_gemm_glds(int a_kcontig, int b_kcontig, const void* A16, long lda, const void* B16, long ldb,
                                float* C, long ldc, void* C16, long ldc16, int M, int N, int K, const float* bias,
                                const float* residual, long ldr, int epi, float* aux, long ldaux, int accumulate,
-                               int split_k, float* splitk_ws, void* stream) {
+                               int split_k, float* splitk_ws, float* out_colsum_accum, void* stream) {
     if (!A16 || !B16 || (!C && !C16) || M <= 0 || N <= 0 || K <= 0) return VITAE_ERR_INVALID_ARG;
     if (epi != VITAE_EPI_NONE && !aux) return VITAE_ERR_INVALID_ARG;
     if (K % BK) return VITAE_ERR_UNSUPPORTED_SHAPE;
@@ -235,7 +269,7 @@ extern "C" int vitae_gemm_glds(int a_kcontig, int b_kcontig, const void* A16, lo
     if (split_k > 1 && !splitk_ws) return VITAE_ERR_INVALID_ARG;
     p.k_per_split = kps; p.splits = split_k;
     p.bias = bias; p.residual = residual; p.ldr = ldr; p.aux = aux; p.ldaux = ldaux;
-    p.epi = epi; p.accumulate = accumulate; p.ws = splitk_ws;
+    p.epi = epi; p.accumulate = accumulate; p.ws = splitk_ws; p.out_colsum = out_colsum_accum;
     const int bn = pick_bn(M, N);
     p.tiles_m = cdiv(M, BM); p.tiles_n = cdiv(N, bn);
     dim3 grid(8 * cdiv(p.tiles_n, 8) * p.tiles_m, 1, split_k);
@@ -248,5 +282,42 @@ extern "C" int vitae_gemm_glds(int a_kcontig, int b_kcontig, const void* A16, lo
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(splitk_reduce_glds_kernel, dim3(blocks), dim3(256), 0, st, p);
     }
+    return vitae_launch_status();
+}
+
+// Backward of one Linear on bf16 operands in ONE launch: dx[M,K] = epi(dy16[M,N] @ W16[N,K]) (fp32 dx and/or
+// bf16 dx16; optional colsum of the result = bias gradient of the layer in front), dW[N,K] (+)= dy16^T @ x16.
+// Mpad = token count rounded up to 64: rows M..Mpad-1 of dy16 and x16 must be zero (wgrad reduces over them).
+extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, const void* x16, float* dx, void* dx16,
+                                          float* dw, int M, int Mpad, int N, int K, int epi, float* aux,
+                                          float* dx_colsum_accum, int dw_accumulate, void* stream) {
+    if (!dy16 || !w16 || !x16 || (!dx && !dx16) || !dw || M <= 0 || N <= 0 || K <= 0) return VITAE_ERR_INVALID_ARG;
+    if (epi != VITAE_EPI_NONE && !aux) return VITAE_ERR_INVALID_ARG;
+    if ((N % BK) || (Mpad % BK) || (K & 7) || Mpad < M) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    if (((uintptr_t)dy16 & 15) || ((uintptr_t)w16 & 15) || ((uintptr_t)x16 & 15)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    GArgs p1, p2;
+    p1.A = reinterpret_cast<const __bf16*>(dy16); p1.lda = N;
+    p1.B = reinterpret_cast<const __bf16*>(w16); p1.ldb = K;
+    p1.C = dx; p1.ldc = K; p1.C16 = reinterpret_cast<__bf16*>(dx16); p1.ldc16 = K;
+    p1.M = M; p1.N = K; p1.K = N; p1.k_per_split = N; p1.splits = 1;
+    p1.bias = nullptr; p1.residual = nullptr; p1.ldr = 0; p1.aux = aux; p1.ldaux = K; p1.epi = epi; p1.accumulate = 0;
+    p1.ws = nullptr; p1.out_colsum = dx_colsum_accum;
+    const int bn1 = pick_bn(M, K);
+    p1.tiles_m = cdiv(M, BM); p1.tiles_n = cdiv(K, bn1);
+    p2.A = reinterpret_cast<const __bf16*>(dy16); p2.lda = N;
+    p2.B = reinterpret_cast<const __bf16*>(x16); p2.ldb = K;
+    p2.C = dw; p2.ldc = K; p2.C16 = nullptr; p2.ldc16 = 0;
+    p2.M = N; p2.N = K; p2.K = Mpad; p2.k_per_split = Mpad; p2.splits = 1;
+    p2.bias = nullptr; p2.residual = nullptr; p2.ldr = 0; p2.aux = nullptr; p2.ldaux = 0; p2.epi = VITAE_EPI_NONE;
+    p2.accumulate = dw_accumulate; p2.ws = nullptr; p2.out_colsum = nullptr;
+    const int bn2 = pick_bn(N, K);
+    p2.tiles_m = cdiv(N, BM); p2.tiles_n = cdiv(K, bn2);
+    const int nb1 = 8 * cdiv(p1.tiles_n, 8) * p1.tiles_m, nb2 = 8 * cdiv(p2.tiles_n, 8) * p2.tiles_m;
+    dim3 grid(nb1 + nb2), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (bn1 == 64 && bn2 == 64) hipLaunchKernelGGL((gemm_glds_pair_kernel<64, 64>), grid, block, 0, st, p1, p2, nb1);
+    else if (bn1 == 64) hipLaunchKernelGGL((gemm_glds_pair_kernel<64, 128>), grid, block, 0, st, p1, p2, nb1);
+    else if (bn2 == 64) hipLaunchKernelGGL((gemm_glds_pair_kernel<128, 64>), grid, block, 0, st, p1, p2, nb1);
+    else hipLaunchKernelGGL((gemm_glds_pair_kernel<128, 128>), grid, block, 0, st, p1, p2, nb1);
     return vitae_launch_status();
 }

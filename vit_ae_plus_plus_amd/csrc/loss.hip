@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void sobel_bwd_components_kernel(const float* 
 // dvol[u] = sum_a sum_o w_a[o] * dG_a[u - o + 1]  (transpose of the correlation), scattered straight
 // into dpred (patchify order) with +=.
 __global__ __launch_bounds__(256) void sobel_bwd_scatter_kernel(const float* __restrict__ dG, float* __restrict__ dpred,
-                                                                int B, VolGeom g) {
+                                                                __bf16* __restrict__ dpred16, int B, VolGeom g) {
     const int Lz = g.Lz, Hy = g.Hy, Wx = g.Wx, C = g.C, p = g.p;
     const long V = (long)Lz * Hy * Wx, total = (long)B * V;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
@@ -179,7 +179,8 @@ __global__ __launch_bounds__(256) void sobel_bwd_scatter_kernel(const float* __r
         const int x = (int)(r % Wx), y = (int)((r / Wx) % Hy), z = (int)(r / ((long)Wx * Hy));
         const int l = ((z / p) * g.g1 + y / p) * g.g2 + x / p;
         const int e0 = (((z % p) * p + y % p) * p + x % p) * C;
-        float* drow = dpred + (long)b * g.pred_bstride + (long)l * g.P + e0;
+        const long doff = (long)b * g.pred_bstride + (long)l * g.P + e0;
+        float* drow = dpred + doff;
         for (int c = 0; c < C; ++c) {
             const float* d0 = dG + (((long)b * C + c) * 3) * V;
             float acc = 0.f;
@@ -204,7 +205,9 @@ __global__ __launch_bounds__(256) void sobel_bwd_scatter_kernel(const float* __r
                     acc += ea * sb * (a2p + 2.f * a20 + a2m);
                 }
             }
-            drow[c] += acc;
+            const float fin = drow[c] + acc;
+            drow[c] = fin;
+            if (dpred16) dpred16[doff + c] = (__bf16)fin;
         }
     }
 }
@@ -337,7 +340,7 @@ extern "C" int vitae_sobel_edge_fwd(const float* vol, float* edge, const float* 
 }
 
 extern "C" int vitae_sobel_edge_bwd(const float* pred_vol, const float* edge_pred, const float* edge_tgt,
-                                    const float* hp, float* dG_ws, float* dpred, long pred_bstride, int B, int C,
+                                    const float* hp, float* dG_ws, float* dpred, void* dpred_bf16, long pred_bstride, int B, int C,
                                     int Lz, int Hy, int Wx, int p, void* stream) {
     if (!pred_vol || !edge_pred || !edge_tgt || !hp || !dG_ws || !dpred || B <= 0) return VITAE_ERR_INVALID_ARG;
     const long total = (long)B * Lz * Hy * Wx;
@@ -345,7 +348,8 @@ extern "C" int vitae_sobel_edge_bwd(const float* pred_vol, const float* edge_pre
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(sobel_bwd_components_kernel, dim3(stream_blocks(total)), dim3(256), 0, st, pred_vol, edge_pred,
                        edge_tgt, hp, dG_ws, 1.0f / (float)total, B, C, Lz, Hy, Wx);
-    hipLaunchKernelGGL(sobel_bwd_scatter_kernel, dim3(stream_blocks(total)), dim3(256), 0, st, dG_ws, dpred, B, g);
+    hipLaunchKernelGGL(sobel_bwd_scatter_kernel, dim3(stream_blocks(total)), dim3(256), 0, st, dG_ws, dpred,
+                       reinterpret_cast<__bf16*>(dpred_bf16), B, g);
     return vitae_launch_status();
 }
 

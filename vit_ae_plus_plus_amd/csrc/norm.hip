@@ -14,6 +14,7 @@ constexpr int LN_MAX_PER_LANE = 16;   // D <= 1024
 // ------------------------------------------------------------------ LayerNorm forward
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ b, float* __restrict__ y,
+                                                            __bf16* __restrict__ y16,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                             int M, int D, float eps) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -37,11 +38,14 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
         q += d * d;
     }
     const float rstd = rsqrtf(wave_sum(q) / D + eps);
-    float* yr = y + (long)row * D;
 #pragma unroll
     for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
         const int c = lane + 64 * i;
-        if (c < D) yr[c] = (v[i] - mean) * rstd * w[c] + b[c];
+        if (c < D) {
+            const float o = (v[i] - mean) * rstd * w[c] + b[c];
+            if (y) y[(long)row * D + c] = o;
+            if (y16) y16[(long)row * D + c] = (__bf16)o;
+        }
     }
     if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
 }
@@ -54,14 +58,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ w, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, float* __restrict__ dx,
                                                             float* __restrict__ dw, float* __restrict__ db,
+                                                            __bf16* __restrict__ dx16, float* __restrict__ dx_colsum,
                                                             int M, int D, int dx_accumulate) {
-    __shared__ float red[2][4][64];
+    __shared__ float red[3][4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nwaves = gridDim.x * 4;
-    float pw[LN_MAX_PER_LANE], pb[LN_MAX_PER_LANE], wv[LN_MAX_PER_LANE];
+    float pw[LN_MAX_PER_LANE], pb[LN_MAX_PER_LANE], wv[LN_MAX_PER_LANE], pc[LN_MAX_PER_LANE];
 #pragma unroll
     for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
-        pw[i] = 0.f; pb[i] = 0.f;
+        pw[i] = 0.f; pb[i] = 0.f; pc[i] = 0.f;
         const int c = lane + 64 * i;
         wv[i] = c < D ? w[c] : 0.f;
     }
@@ -89,6 +94,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                 float r = rs * (g[i] - s1 - xh[i] * s2);
                 if (dx_accumulate) r += dxr[c];
                 dxr[c] = r;
+                if (dx16) dx16[(long)row * D + c] = (__bf16)r;
+                pc[i] += r;
             }
         }
     }
@@ -96,13 +103,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
         if (64 * i >= D) break;
         __syncthreads();
-        red[0][wave][lane] = pw[i]; red[1][wave][lane] = pb[i];
+        red[0][wave][lane] = pw[i]; red[1][wave][lane] = pb[i]; red[2][wave][lane] = pc[i];
         __syncthreads();
         if (wave == 0) {
             const int c = lane + 64 * i;
             if (c < D) {
                 atomicAdd(dw + c, red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane]);
                 atomicAdd(db + c, red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]);
+                if (dx_colsum) atomicAdd(dx_colsum + c, red[2][0][lane] + red[2][1][lane] + red[2][2][lane] + red[2][3][lane]);
             }
         }
     }
@@ -199,24 +207,24 @@ __global__ __launch_bounds__(256) void bn1d_relu_bwd_kernel(const float* __restr
 
 }  // namespace
 
-extern "C" int vitae_layernorm_fwd(const float* x, const float* w, const float* b, float* y, float* mean,
+extern "C" int vitae_layernorm_fwd(const float* x, const float* w, const float* b, float* y, void* y_bf16, float* mean,
                                    float* rstd, int M, int D, float eps, void* stream) {
-    if (!x || !w || !b || !y || !mean || !rstd || M <= 0 || D <= 0) return VITAE_ERR_INVALID_ARG;
+    if (!x || !w || !b || (!y && !y_bf16) || !mean || !rstd || M <= 0 || D <= 0) return VITAE_ERR_INVALID_ARG;
     if (D > 64 * LN_MAX_PER_LANE) return VITAE_ERR_UNSUPPORTED_SHAPE;
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, w, b, y, mean,
-                       rstd, M, D, eps);
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, w, b, y,
+                       reinterpret_cast<__bf16*>(y_bf16), mean, rstd, M, D, eps);
     return vitae_launch_status();
 }
 
 extern "C" int vitae_layernorm_bwd(const float* dy, const float* x, const float* w, const float* mean,
-                                   const float* rstd, float* dx, float* dw, float* db, int M, int D,
-                                   int dx_accumulate, void* stream) {
+                                   const float* rstd, float* dx, float* dw, float* db, void* dx_bf16,
+                                   float* dx_colsum_accum, int M, int D, int dx_accumulate, void* stream) {
     if (!dy || !x || !w || !mean || !rstd || !dx || !dw || !db || M <= 0 || D <= 0) return VITAE_ERR_INVALID_ARG;
     if (D > 64 * LN_MAX_PER_LANE) return VITAE_ERR_UNSUPPORTED_SHAPE;
     int blocks = cdiv(M, 4);
     if (blocks > 256) blocks = 256;   // one row per wave up to 1024 rows (row work dominates; capping at 48 blocks doubled the time)
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, w, mean, rstd,
-                       dx, dw, db, M, D, dx_accumulate);
+                       dx, dw, db, reinterpret_cast<__bf16*>(dx_bf16), dx_colsum_accum, M, D, dx_accumulate);
     return vitae_launch_status();
 }
 

@@ -40,7 +40,8 @@ __global__ __launch_bounds__(256) void random_masking_kernel(const float* __rest
 // out[(b*keep + j), c*p^3 + r*p^2 + s*p + q] = vol[b, c, gl*p + r, gh*p + s, gw*p + q]
 // for patch l = ids_shuffle[b, j] = (gl, gh, gw): the Conv3d weight's (C, p, p, p) flattening.
 __global__ __launch_bounds__(256) void gather_patches_kernel(const float* __restrict__ vol, const int* __restrict__ ids_shuffle,
-                                                             float* __restrict__ out, int C, int Lz, int Hy, int Wx, int p,
+                                                             float* __restrict__ out, __bf16* __restrict__ out16,
+                                                             int C, int Lz, int Hy, int Wx, int p,
                                                              int g1, int g2, int L, int keep) {
     const int j = blockIdx.x, b = blockIdx.y;
     const int l = ids_shuffle[(long)b * L + j];
@@ -49,11 +50,18 @@ __global__ __launch_bounds__(256) void gather_patches_kernel(const float* __rest
     const int P4 = C * p * p * p4;
     const long vstride = (long)Lz * Hy * Wx;
     const float* vb = vol + (long)b * C * vstride;
-    float* orow = out + ((long)b * keep + j) * ((long)C * p * p * p);
+    const long rowoff = ((long)b * keep + j) * ((long)C * p * p * p);
     for (int i = threadIdx.x; i < P4; i += 256) {
         const int q4 = i % p4, s = (i / p4) % p, r = (i / (p4 * p)) % p, c = i / (p4 * p * p);
         const float* src = vb + c * vstride + ((long)(gl * p + r) * Hy + (gh * p + s)) * Wx + gw * p + q4 * 4;
-        *reinterpret_cast<f32x4*>(orow + (long)i * 4) = *reinterpret_cast<const f32x4*>(src);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+        if (out) *reinterpret_cast<f32x4*>(out + rowoff + (long)i * 4) = v;
+        if (out16) {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+            *reinterpret_cast<bf16x4*>(out16 + rowoff + (long)i * 4) = o;
+        }
     }
 }
 
@@ -77,6 +85,7 @@ __global__ __launch_bounds__(256) void encoder_assemble_fwd_kernel(const float* 
 
 // dtok[b*keep + j] = dx[b, 1 + j];  dcls += sum_b dx[b, 0]
 __global__ __launch_bounds__(256) void encoder_assemble_bwd_kernel(const float* __restrict__ dx, float* __restrict__ dtok,
+                                                                   __bf16* __restrict__ dtok16,
                                                                    float* __restrict__ dcls, int B, int keep, int D) {
     const int t = blockIdx.x, b = blockIdx.y;
     const float* dr = dx + ((long)b * (keep + 1) + t) * D;
@@ -88,8 +97,12 @@ __global__ __launch_bounds__(256) void encoder_assemble_bwd_kernel(const float* 
             atomicAdd(dcls + d, s);
         }
     } else {
-        float* o = dtok + ((long)b * keep + t - 1) * D;
-        for (int d = threadIdx.x; d < D; d += 256) o[d] = dr[d];
+        const long oo = ((long)b * keep + t - 1) * D;
+        for (int d = threadIdx.x; d < D; d += 256) {
+            const float v = dr[d];
+            if (dtok) dtok[oo + d] = v;
+            if (dtok16) dtok16[oo + d] = (__bf16)v;
+        }
     }
 }
 
@@ -152,13 +165,13 @@ extern "C" int vitae_random_masking(const float* noise, int* ids_shuffle, int* i
     return vitae_launch_status();
 }
 
-extern "C" int vitae_gather_patches(const float* vol, const int* ids_shuffle, float* out, int B, int C, int Lz,
-                                    int Hy, int Wx, int p, int keep, void* stream) {
-    if (!vol || !ids_shuffle || !out || B <= 0 || C <= 0 || p <= 0 || keep <= 0) return VITAE_ERR_INVALID_ARG;
+extern "C" int vitae_gather_patches(const float* vol, const int* ids_shuffle, float* out, void* out_bf16, int B, int C,
+                                    int Lz, int Hy, int Wx, int p, int keep, void* stream) {
+    if (!vol || !ids_shuffle || (!out && !out_bf16) || B <= 0 || C <= 0 || p <= 0 || keep <= 0) return VITAE_ERR_INVALID_ARG;
     if ((p & 3) || Lz % p || Hy % p || Wx % p || ((uintptr_t)vol & 15)) return VITAE_ERR_UNSUPPORTED_SHAPE;
     const int g0 = Lz / p, g1 = Hy / p, g2 = Wx / p;
     hipLaunchKernelGGL(gather_patches_kernel, dim3(keep, B), dim3(256), 0, (hipStream_t)stream, vol, ids_shuffle, out,
-                       C, Lz, Hy, Wx, p, g1, g2, g0 * g1 * g2, keep);
+                       reinterpret_cast<__bf16*>(out_bf16), C, Lz, Hy, Wx, p, g1, g2, g0 * g1 * g2, keep);
     return vitae_launch_status();
 }
 
@@ -171,11 +184,11 @@ extern "C" int vitae_encoder_assemble_fwd(const float* tok, const float* cls_tok
     return vitae_launch_status();
 }
 
-extern "C" int vitae_encoder_assemble_bwd(const float* dx, float* dtok, float* dcls, int B, int keep, int D,
-                                          void* stream) {
-    if (!dx || !dtok || !dcls || B <= 0) return VITAE_ERR_INVALID_ARG;
+extern "C" int vitae_encoder_assemble_bwd(const float* dx, float* dtok, void* dtok_bf16, float* dcls, int B, int keep,
+                                          int D, void* stream) {
+    if (!dx || (!dtok && !dtok_bf16) || !dcls || B <= 0) return VITAE_ERR_INVALID_ARG;
     hipLaunchKernelGGL(encoder_assemble_bwd_kernel, dim3(keep + 1, B), dim3(256), 0, (hipStream_t)stream, dx, dtok,
-                       dcls, B, keep, D);
+                       reinterpret_cast<__bf16*>(dtok_bf16), dcls, B, keep, D);
     return vitae_launch_status();
 }
 

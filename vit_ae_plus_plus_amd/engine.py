@@ -116,6 +116,11 @@ class HipMAEEngine:
         if cfg.patch_size % 4:
             raise VitaeError('patch_size must be a multiple of 4 (16-byte gathers)')
         self._build_arena(params)
+        # bf16 activations + LDS-DMA GEMMs for the transformer blocks, decoder_pred and the patch embedding:
+        # needs every contraction length to be a multiple of 64 and an MFMA attention head size
+        dims = (D, Dd, self.Hm, self.Hmd, cfg.patch_dim)
+        self.act16 = (self.prec == PREC['bf16'] and all(v % 64 == 0 for v in dims)
+                      and self.hd in (32, 64) and self.hdd in (32, 64))
         self.buffers = buffers   # pos_embed, decoder_pos_embed, BN running stats (device tensors)
         f32 = dict(dtype=torch.float32, device=device)
         # ring of pinned staging buffers: the host may run a few steps ahead of the stream, so the
@@ -247,6 +252,19 @@ class HipMAEEngine:
 
         stack('enc', cfg.depth, Me, D, self.Hm)
         stack('dec', cfg.decoder_depth, Md, Dd, self.Hmd)
+        if self.act16:
+            # bf16 GEMM operands, token rows padded to 64 with zeros (wgrad reduces over the padded count)
+            z16 = lambda *s: torch.zeros(*s, dtype=torch.bfloat16, device=dev)
+            pad = lambda m: (m + 63) // 64 * 64
+            self.Mpe, self.Mpd, self.Mpt = pad(Me), pad(Md), pad(Be * keep)
+            for pre, depth, Mp, d, h in (('enc', cfg.depth, self.Mpe, D, self.Hm), ('dec', cfg.decoder_depth, self.Mpd, Dd, self.Hmd)):
+                for i in range(depth):
+                    q = f'{pre}{i}.'
+                    b[q + 'y1_16'], b[q + 'o_16'], b[q + 'y2_16'], b[q + 'act_16'] = z16(Mp, d), z16(Mp, d), z16(Mp, d), z16(Mp, h)
+                b[pre + 'dx_16'], b[pre + 'dh_16'], b[pre + 'dqkv_16'] = z16(Mp, d), z16(Mp, h), z16(Mp, 3 * d)
+            b['dn_16'] = z16(self.Mpd, Dd)
+            b['dpred_16'] = z16(self.Mpd, P)
+            b['patches_16'], b['dtok_16'] = z16(self.Mpt, P), z16(self.Mpt, D)
         for i in range(cfg.depth):
             b[f'enc{i}.lse'] = f(Be * cfg.num_heads * Ne)
         for i in range(cfg.decoder_depth):
@@ -383,23 +401,84 @@ class HipMAEEngine:
             torch.cuda.current_stream(self.device).wait_stream(self.wside)
             self._wg_pending.clear()
 
-    def _ln_fwd(self, x, pre, y, mean, rstd, M, D):
-        lib.vitae_layernorm_fwd(_ptr(x), _ptr(self.p[pre + 'weight']), _ptr(self.p[pre + 'bias']), _ptr(y), _ptr(mean),
-                                _ptr(rstd), M, D, self.cfg.ln_eps, self.stream)
+    def _ln_fwd(self, x, pre, y, mean, rstd, M, D, y16=None):
+        lib.vitae_layernorm_fwd(_ptr(x), _ptr(self.p[pre + 'weight']), _ptr(self.p[pre + 'bias']), _ptr(y), _ptr(y16),
+                                _ptr(mean), _ptr(rstd), M, D, self.cfg.ln_eps, self.stream)
 
-    def _ln_bwd(self, dy, x, pre, mean, rstd, dx, M, D, dx_accumulate):
+    def _ln_bwd(self, dy, x, pre, mean, rstd, dx, M, D, dx_accumulate, dx16=None, dx_colsum=None):
         lib.vitae_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(self.p[pre + 'weight']), _ptr(mean), _ptr(rstd), _ptr(dx),
-                                _ptr(self.g[pre + 'weight']), _ptr(self.g[pre + 'bias']), M, D, dx_accumulate,
-                                self.stream)
+                                _ptr(self.g[pre + 'weight']), _ptr(self.g[pre + 'bias']), _ptr(dx16), _ptr(dx_colsum),
+                                M, D, dx_accumulate, self.stream)
+
+    # ------------------------------------------------------------------ bf16-activation GEMM helpers (LDS-DMA kernel)
+    def _g16_fwd(self, x16, w, bias, M, N, K, y=None, y16=None, epi=EPI_NONE, aux=None, res=None):
+        """y / y16 = epi(x16 @ W16^T + b) (+ res) on the LDS-DMA GEMM (bf16 operands in HBM)."""
+        key = ('g', M, N, K)
+        s = self._split_cache.get(key)
+        if s is None:
+            s = 1 if epi == EPI_GELU else lib.vitae_gemm_glds_pick_split_k(M, N, K)
+            while s > 1 and s * M * N > self.ws.numel():
+                s -= 1
+            self._split_cache[key] = s
+        t = self._timed(2.0 * M * N * K)
+        lib.vitae_gemm_glds(1, 1, _ptr(x16), K, self._w16(w), K, _ptr(y), N, _ptr(y16), N, M, N, K, _ptr(bias), _ptr(res), N,
+                            epi, _ptr(aux), N, 0, s, self.ws.data_ptr(), None, self.stream)
+        if t is not None:
+            t.record()
+
+    def _g16_bwd(self, dy16, w, x16, dw, M, Mpad, N, K, dx=None, dx16=None, epi=EPI_NONE, aux=None, dx_colsum=None):
+        """dx / dx16 = epi(dy16 @ W16), dW (+)= dy16^T @ x16 in one paired launch."""
+        t = self._timed(4.0 * M * N * K)
+        lib.vitae_linear_bwd_pair_glds(_ptr(dy16), self._w16(w), _ptr(x16), _ptr(dx), _ptr(dx16), _ptr(dw), M, Mpad, N, K,
+                                       epi, _ptr(aux), _ptr(dx_colsum), int(self._accum), self.stream)
+        if t is not None:
+            t.record()
 
     # ------------------------------------------------------------------ transformer block
+    def _block_fwd16(self, pre, q, x_in, x_out, Bs, N, d, heads, hd, hid):
+        """model/vit.py:139-144 with bf16 GEMM operands written by their producers."""
+        b, p, M = self.buf, self.p, Bs * N
+        self._ln_fwd(x_in, pre + 'norm1.', None, b[q + 'mean1'], b[q + 'rstd1'], M, d, y16=b[q + 'y1_16'])
+        self._g16_fwd(b[q + 'y1_16'], p[pre + 'attn.qkv.weight'], p[pre + 'attn.qkv.bias'], M, 3 * d, d, y=b[q + 'qkv'])
+        lib.vitae_sdpa_mfma_fwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(b[q + 'o_16']), _ptr(b[q + 'lse']), Bs, N, heads, hd,
+                                self.stream)
+        self._g16_fwd(b[q + 'o_16'], p[pre + 'attn.proj.weight'], p[pre + 'attn.proj.bias'], M, d, d, y=b[q + 'xmid'], res=x_in)
+        self._ln_fwd(b[q + 'xmid'], pre + 'norm2.', None, b[q + 'mean2'], b[q + 'rstd2'], M, d, y16=b[q + 'y2_16'])
+        self._g16_fwd(b[q + 'y2_16'], p[pre + 'mlp.fc1.weight'], p[pre + 'mlp.fc1.bias'], M, hid, d, y16=b[q + 'act_16'],
+                      epi=EPI_GELU, aux=b[q + 'hpre'])
+        self._g16_fwd(b[q + 'act_16'], p[pre + 'mlp.fc2.weight'], p[pre + 'mlp.fc2.bias'], M, d, hid, y=x_out, res=b[q + 'xmid'])
+
+    def _block_bwd16(self, pre, q, s, x_in, Bs, N, d, heads, hd, hid, Mp, prev_fc2_bias):
+        """Backward of one block on bf16 operands.  On entry buf[s+'dx'] (fp32) and buf[s+'dx_16'] hold the
+        output gradient and the fc2 bias gradient has already been produced by whoever wrote dx.
+        ``prev_fc2_bias``: gradient slot of the fc2 bias of the block this one feeds INTO dx for (block i-1)."""
+        b, p, g, M = self.buf, self.p, self.g, Bs * N
+        dx, dx16, dh16, dy, do, dqkv, dqkv16 = (b[s + 'dx'], b[s + 'dx_16'], b[s + 'dh_16'], b[s + 'dy'], b[s + 'do'],
+                                                  b[s + 'dqkv'], b[s + 'dqkv_16'])
+        self._g16_bwd(dx16, p[pre + 'mlp.fc2.weight'], b[q + 'act_16'], g[pre + 'mlp.fc2.weight'], M, Mp, d, hid,
+                      dx16=dh16, epi=EPI_DGELU, aux=b[q + 'hpre'], dx_colsum=g[pre + 'mlp.fc1.bias'])
+        self._g16_bwd(dh16, p[pre + 'mlp.fc1.weight'], b[q + 'y2_16'], g[pre + 'mlp.fc1.weight'], M, Mp, hid, d, dx=dy)
+        self._ln_bwd(dy, b[q + 'xmid'], pre + 'norm2.', b[q + 'mean2'], b[q + 'rstd2'], dx, M, d, 1, dx16=dx16,
+                     dx_colsum=g[pre + 'attn.proj.bias'])
+        self._g16_bwd(dx16, p[pre + 'attn.proj.weight'], b[q + 'o_16'], g[pre + 'attn.proj.weight'], M, Mp, d, d, dx=do)
+        lib.vitae_sdpa_mfma_bwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(do), _ptr(b[q + 'lse']), _ptr(dqkv), _ptr(dqkv16),
+                                _ptr(b['delta']), Bs, N, heads, hd, self.stream)
+        lib.vitae_colsum_accum(_ptr(dqkv), 3 * d, _ptr(g[pre + 'attn.qkv.bias']), M, 3 * d, self.stream)
+        self._g16_bwd(dqkv16, p[pre + 'attn.qkv.weight'], b[q + 'y1_16'], g[pre + 'attn.qkv.weight'], M, Mp, 3 * d, d, dx=dy)
+        self._ln_bwd(dy, x_in, pre + 'norm1.', b[q + 'mean1'], b[q + 'rstd1'], dx, M, d, 1, dx16=dx16,
+                     dx_colsum=prev_fc2_bias)
+
     def _block_fwd(self, pre, q, x_in, x_out, Bs, N, d, heads, hd, hid):
         """model/vit.py:139-144.  pre = state-dict prefix, q = workspace prefix."""
+        if self.act16:
+            return self._block_fwd16(pre, q, x_in, x_out, Bs, N, d, heads, hd, hid)
         b, p, M = self.buf, self.p, Bs * N
         self._ln_fwd(x_in, pre + 'norm1.', b[q + 'y1'], b[q + 'mean1'], b[q + 'rstd1'], M, d)
         self._lin_fwd(b[q + 'y1'], p[pre + 'attn.qkv.weight'], p[pre + 'attn.qkv.bias'], b[q + 'qkv'], M, 3 * d, d)
-        sdpa_fwd = lib.vitae_sdpa_mfma_fwd if (self.prec == PREC['bf16'] and hd in (32, 64)) else lib.vitae_sdpa_fwd
-        sdpa_fwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(b[q + 'lse']), Bs, N, heads, hd, self.stream)
+        if self.prec == PREC['bf16'] and hd in (32, 64):
+            lib.vitae_sdpa_mfma_fwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), None, _ptr(b[q + 'lse']), Bs, N, heads, hd, self.stream)
+        else:
+            lib.vitae_sdpa_fwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(b[q + 'lse']), Bs, N, heads, hd, self.stream)
         self._lin_fwd(b[q + 'o'], p[pre + 'attn.proj.weight'], p[pre + 'attn.proj.bias'], b[q + 'xmid'], M, d, d,
                       res=x_in)
         self._ln_fwd(b[q + 'xmid'], pre + 'norm2.', b[q + 'y2'], b[q + 'mean2'], b[q + 'rstd2'], M, d)
@@ -424,9 +503,12 @@ class HipMAEEngine:
         self._lin_bwd(dx, p[pre + 'attn.proj.weight'], b[q + 'o'], do, g[pre + 'attn.proj.weight'], g[pre + 'attn.proj.bias'],
                       M, d, d, tag=s + 'dx')
         self._wg_fence(s + 'dqkv')                     # previous block's qkv wgrad may still read dqkv
-        sdpa_bwd = lib.vitae_sdpa_mfma_bwd if (self.prec == PREC['bf16'] and hd in (32, 64)) else lib.vitae_sdpa_bwd
-        sdpa_bwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(do), _ptr(b[q + 'lse']), _ptr(dqkv),
-                 _ptr(b['delta']), Bs, N, heads, hd, self.stream)
+        if self.prec == PREC['bf16'] and hd in (32, 64):
+            lib.vitae_sdpa_mfma_bwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(do), _ptr(b[q + 'lse']), _ptr(dqkv), None,
+                                    _ptr(b['delta']), Bs, N, heads, hd, self.stream)
+        else:
+            lib.vitae_sdpa_bwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(do), _ptr(b[q + 'lse']), _ptr(dqkv),
+                               _ptr(b['delta']), Bs, N, heads, hd, self.stream)
         # attn.qkv
         self._lin_bwd(dqkv, p[pre + 'attn.qkv.weight'], b[q + 'y1'], dy, g[pre + 'attn.qkv.weight'], g[pre + 'attn.qkv.bias'],
                       M, 3 * d, d, tag=s + 'dqkv')
@@ -469,11 +551,18 @@ class HipMAEEngine:
         # --- masking, kept-patch gather, patch embedding, sequence assembly
         lib.vitae_random_masking(_ptr(noise), _ptr(b['ids_shuffle']), _ptr(b['ids_restore']), _ptr(b['mask']),
                                  _ptr(b['ids_restore64']), Be, L, keep, st)
-        lib.vitae_gather_patches(_ptr(view1), _ptr(b['ids_shuffle']), _ptr(b['patches']), B, C, Lz, Hy, Wx, ps, keep, st)
+        a16 = self.act16
+        pat, pat16 = (None, b['patches_16']) if a16 else (b['patches'], None)
+        lib.vitae_gather_patches(_ptr(view1), _ptr(b['ids_shuffle']), _ptr(pat), _ptr(pat16), B, C, Lz, Hy, Wx, ps, keep, st)
         if cfg.contrastive:
+            o = B * keep * P
             lib.vitae_gather_patches(_ptr(view2), b['ids_shuffle'].data_ptr() + B * L * 4,
-                                     b['patches'].data_ptr() + B * keep * P * 4, B, C, Lz, Hy, Wx, ps, keep, st)
-        self._lin_fwd(b['patches'], p['patch_embed.proj.weight'], p['patch_embed.proj.bias'], b['tok'], Be * keep, D, P)
+                                     None if a16 else pat.data_ptr() + o * 4, pat16.data_ptr() + o * 2 if a16 else None,
+                                     B, C, Lz, Hy, Wx, ps, keep, st)
+        if a16:
+            self._g16_fwd(pat16, p['patch_embed.proj.weight'], p['patch_embed.proj.bias'], Be * keep, D, P, y=b['tok'])
+        else:
+            self._lin_fwd(b['patches'], p['patch_embed.proj.weight'], p['patch_embed.proj.bias'], b['tok'], Be * keep, D, P)
         ex = b['encx']
         lib.vitae_encoder_assemble_fwd(_ptr(b['tok']), _ptr(p['cls_token']), _ptr(self.buffers['pos_embed']),
                                        _ptr(b['ids_shuffle']), _ptr(ex[0]), Be, L, keep, D, st)
@@ -488,8 +577,12 @@ class HipMAEEngine:
         for i in range(cfg.decoder_depth):
             self._block_fwd(f'decoder_blocks.{i}.', f'dec{i}.', dx_[i], dx_[i + 1], B, Nd, Dd, cfg.decoder_num_heads,
                             self.hdd, self.Hmd)
-        self._ln_fwd(dx_[cfg.decoder_depth], 'decoder_norm.', b['dn'], b['dn_mean'], b['dn_rstd'], Md, Dd)
-        self._lin_fwd(b['dn'], p['decoder_pred.weight'], p['decoder_pred.bias'], b['predfull'], Md, P, Dd)
+        if a16:
+            self._ln_fwd(dx_[cfg.decoder_depth], 'decoder_norm.', None, b['dn_mean'], b['dn_rstd'], Md, Dd, y16=b['dn_16'])
+            self._g16_fwd(b['dn_16'], p['decoder_pred.weight'], p['decoder_pred.bias'], Md, P, Dd, y=b['predfull'])
+        else:
+            self._ln_fwd(dx_[cfg.decoder_depth], 'decoder_norm.', b['dn'], b['dn_mean'], b['dn_rstd'], Md, Dd)
+            self._lin_fwd(b['dn'], p['decoder_pred.weight'], p['decoder_pred.bias'], b['predfull'], Md, P, Dd)
         # --- loss chain on pred = predfull[:, 1:, :]
         pred_ptr, pbs = b['predfull'].data_ptr() + P * 4, Nd * P
         lib.vitae_recon_loss_fwd(pred_ptr, pbs, _ptr(view1), _ptr(b['mask']), _ptr(self.acc), B, C, Lz, Hy, Wx, ps, st)
@@ -559,16 +652,28 @@ class HipMAEEngine:
         pred_ptr, dpred_ptr, pbs = b['predfull'].data_ptr() + P * 4, b['dpredfull'].data_ptr() + P * 4, Nd * P
         lib.vitae_recon_loss_bwd(pred_ptr, pbs, _ptr(view1), _ptr(b['mask']), _ptr(self.hp), dpred_ptr, self.mask_sum, B, C,
                                  Lz, Hy, Wx, ps, st)
+        a16 = self.act16
         lib.vitae_sobel_edge_bwd(_ptr(b['pred_vol']), _ptr(b['edge_p']), _ptr(b['edge_t']), _ptr(self.hp), _ptr(b['dG']),
-                                 dpred_ptr, pbs, B, C, Lz, Hy, Wx, ps, st)
-        # decoder_pred, decoder_norm
-        self._lin_bwd(b['dpredfull'], p['decoder_pred.weight'], b['dn'], b['ddn'], g['decoder_pred.weight'],
-                      g['decoder_pred.bias'], Md, P, Dd)
+                                 dpred_ptr, (b['dpred_16'].data_ptr() + P * 2) if a16 else None, pbs, B, C, Lz, Hy, Wx, ps, st)
         dx_ = b['decx']
-        self._ln_bwd(b['ddn'], dx_[cfg.decoder_depth], 'decoder_norm.', b['dn_mean'], b['dn_rstd'], b['decdx'], Md, Dd, 0)
-        for i in reversed(range(cfg.decoder_depth)):
-            self._block_bwd(f'decoder_blocks.{i}.', f'dec{i}.', 'dec', dx_[i], B, Nd, Dd, cfg.decoder_num_heads, self.hdd,
-                            self.Hmd)
+        nd = cfg.decoder_depth
+        if a16:
+            # decoder_pred (bias grad from the fp32 dpred), decoder_norm -> dx, dx_16, fc2 bias grad of the last block
+            lib.vitae_colsum_accum(_ptr(b['dpredfull']), P, _ptr(g['decoder_pred.bias']), Md, P, st)
+            self._g16_bwd(b['dpred_16'], p['decoder_pred.weight'], b['dn_16'], g['decoder_pred.weight'], Md, self.Mpd, P, Dd,
+                          dx=b['ddn'])
+            self._ln_bwd(b['ddn'], dx_[nd], 'decoder_norm.', b['dn_mean'], b['dn_rstd'], b['decdx'], Md, Dd, 0,
+                         dx16=b['decdx_16'], dx_colsum=g[f'decoder_blocks.{nd - 1}.mlp.fc2.bias'])
+            for i in reversed(range(nd)):
+                self._block_bwd16(f'decoder_blocks.{i}.', f'dec{i}.', 'dec', dx_[i], B, Nd, Dd, cfg.decoder_num_heads, self.hdd,
+                                  self.Hmd, self.Mpd, g[f'decoder_blocks.{i - 1}.mlp.fc2.bias'] if i > 0 else None)
+        else:
+            self._lin_bwd(b['dpredfull'], p['decoder_pred.weight'], b['dn'], b['ddn'], g['decoder_pred.weight'],
+                          g['decoder_pred.bias'], Md, P, Dd)
+            self._ln_bwd(b['ddn'], dx_[nd], 'decoder_norm.', b['dn_mean'], b['dn_rstd'], b['decdx'], Md, Dd, 0)
+            for i in reversed(range(nd)):
+                self._block_bwd(f'decoder_blocks.{i}.', f'dec{i}.', 'dec', dx_[i], B, Nd, Dd, cfg.decoder_num_heads, self.hdd,
+                                self.Hmd)
         lib.vitae_decoder_assemble_bwd(_ptr(b['decdx']), _ptr(b['ids_shuffle']), _ptr(b['de']), _ptr(g['mask_token']), B, L,
                                        keep, Dd, st)
         self._lin_bwd_w(b['de'], b['latent'], g['decoder_embed.weight'], None, B * Ne, Dd, D)
@@ -595,7 +700,11 @@ class HipMAEEngine:
             if Be != B:
                 lib.vitae_memset_zero(b['dlatent'].data_ptr(), b['dlatent'].numel() * 4, st)
             self._lin_bwd_x(b['de'], p['decoder_embed.weight'], b['dlatent'], B * Ne, Dd, D, db=g['decoder_embed.bias'])
-        self._ln_bwd(b['dlatent'], b['encx'][cfg.depth], 'norm.', b['lat_mean'], b['lat_rstd'], b['encdx'], Me, D, 0)
+        if a16:
+            self._ln_bwd(b['dlatent'], b['encx'][cfg.depth], 'norm.', b['lat_mean'], b['lat_rstd'], b['encdx'], Me, D, 0,
+                         dx16=b['encdx_16'], dx_colsum=g[f'blocks.{cfg.depth - 1}.mlp.fc2.bias'])
+        else:
+            self._ln_bwd(b['dlatent'], b['encx'][cfg.depth], 'norm.', b['lat_mean'], b['lat_rstd'], b['encdx'], Me, D, 0)
         self._wg_join()
 
     def backward_enc(self, hi: int, lo: int):
@@ -604,8 +713,12 @@ class HipMAEEngine:
         self.stream = torch.cuda.current_stream(self.device).cuda_stream
         ex = self.buf['encx']
         for i in range(hi, lo - 1, -1):
-            self._block_bwd(f'blocks.{i}.', f'enc{i}.', 'enc', ex[i], self.Be, self.Ne, cfg.embed_dim, cfg.num_heads,
-                            self.hd, self.Hm)
+            if self.act16:
+                self._block_bwd16(f'blocks.{i}.', f'enc{i}.', 'enc', ex[i], self.Be, self.Ne, cfg.embed_dim, cfg.num_heads,
+                                  self.hd, self.Hm, self.Mpe, self.g[f'blocks.{i - 1}.mlp.fc2.bias'] if i > 0 else None)
+            else:
+                self._block_bwd(f'blocks.{i}.', f'enc{i}.', 'enc', ex[i], self.Be, self.Ne, cfg.embed_dim, cfg.num_heads,
+                                self.hd, self.Hm)
         self._wg_join()
 
     def backward_tail(self):
@@ -613,10 +726,20 @@ class HipMAEEngine:
         cfg = self.cfg
         self.stream = torch.cuda.current_stream(self.device).cuda_stream
         b, g = self.buf, self.g
-        lib.vitae_encoder_assemble_bwd(_ptr(b['encdx']), _ptr(b['dtok']), _ptr(g['cls_token']), self.Be, self.keep,
-                                       cfg.embed_dim, self.stream)
-        self._lin_bwd_w(b['dtok'], b['patches'], g['patch_embed.proj.weight'], g['patch_embed.proj.bias'],
-                        self.Be * self.keep, cfg.embed_dim, cfg.patch_dim)
+        T, D, P = self.Be * self.keep, cfg.embed_dim, cfg.patch_dim
+        lib.vitae_encoder_assemble_bwd(_ptr(b['encdx']), _ptr(b['dtok']), _ptr(b['dtok_16']) if self.act16 else None,
+                                       _ptr(g['cls_token']), self.Be, self.keep, D, self.stream)
+        if self.act16:
+            # dW[D, P] = dtok16^T @ patches16 (both row-contiguous bf16, reduced over the padded token count)
+            t = self._timed(2.0 * T * D * P)
+            lib.vitae_gemm_glds(0, 0, _ptr(b['dtok_16']), D, _ptr(b['patches_16']), P, _ptr(g['patch_embed.proj.weight']), P,
+                                None, 0, D, P, self.Mpt, None, None, 0, EPI_NONE, None, 0, int(self._accum), 1, None, None,
+                                self.stream)
+            if t is not None:
+                t.record()
+            lib.vitae_colsum_accum(_ptr(b['dtok']), D, _ptr(g['patch_embed.proj.bias']), T, D, self.stream)
+        else:
+            self._lin_bwd_w(b['dtok'], b['patches'], g['patch_embed.proj.weight'], g['patch_embed.proj.bias'], T, D, P)
 
     # ------------------------------------------------------------------ optimiser
     def init_optimizer(self, weight_decay: float = 0.05, betas=(0.9, 0.95), eps: float = 1e-8):

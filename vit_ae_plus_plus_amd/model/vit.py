@@ -58,7 +58,7 @@ def hip_layernorm(x, weight, bias, eps):
     y = torch.empty_like(x2)
     mean = torch.empty(M, dtype=torch.float32, device=x.device)
     rstd = torch.empty_like(mean)
-    lib.vitae_layernorm_fwd(x2.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), mean.data_ptr(),
+    lib.vitae_layernorm_fwd(x2.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), None, mean.data_ptr(),
                             rstd.data_ptr(), M, D, eps, _stream(x))
     return y.reshape(x.shape)
 
@@ -88,7 +88,7 @@ class PatchEmbed3D(nn.Module):
         ids = torch.arange(n, dtype=torch.int32, device=x.device).repeat(B, 1).contiguous()
         xc = x.contiguous().float()
         rows = torch.empty(B * n, C * p ** 3, dtype=torch.float32, device=x.device)
-        lib.vitae_gather_patches(xc.data_ptr(), ids.data_ptr(), rows.data_ptr(), B, C, L, H, W, p, n, _stream(x))
+        lib.vitae_gather_patches(xc.data_ptr(), ids.data_ptr(), rows.data_ptr(), None, B, C, L, H, W, p, n, _stream(x))
         w = self.proj.weight.reshape(self.proj.weight.shape[0], -1)
         y = hip_linear(rows, w, self.proj.bias).reshape(B, n, -1)
         if not self.flatten:
