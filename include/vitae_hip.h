@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITAE_ABI_VERSION 8
+#define VITAE_ABI_VERSION 9
 
 /* matrix-core arithmetic of the dense contractions */
 #define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
@@ -184,6 +184,13 @@ int vitae_sobel_edge_fwd(const float* vol, float* edge, const float* edge_ref, d
 int vitae_sobel_edge_bwd(const float* pred_vol, const float* edge_pred, const float* edge_tgt, const float* hp,
                          float* dG_ws, float* dpred, void* dpred_bf16, long pred_bstride, int B, int C, int Lz, int Hy,
                          int Wx, int p, void* stream);
+/* whole loss backward in one pass (model/vit_autoenc.py:224-232 differentiated):
+ * dpred = mask*2*g_recon*(pred-target)/(P*mask.sum()) + d(edge mse)/d pred, fp32 and optionally bf16.
+ * C in {1,4}: one LDS-tiled kernel; other C: recon_bwd + the two Sobel backward kernels (needs dG_ws). */
+int vitae_loss_bwd_fused(const float* pred, const float* pred_vol, const float* imgs, const float* mask,
+                         const float* edge_pred, const float* edge_tgt, const float* hp, float* dG_ws, float* dpred,
+                         void* dpred_bf16, long pred_bstride, float mask_sum, int B, int C, int Lz, int Hy, int Wx, int p,
+                         void* stream);
 /* out4 = [loss, raw_edge_mse, recon, percep=0] (model/vit_autoenc.py:231-232) */
 int vitae_loss_finalize(const double* acc, const float* hp, float* out4, float mask_sum, long edge_count, void* stream);
 

@@ -409,7 +409,8 @@ def test_gather_patches_and_assemble(lib, C_, vol, p):
 
 
 # --------------------------------------------------------------------------- loss chain
-@pytest.mark.parametrize('C_,vol,p', [(4, (32, 32, 32), 16), (2, (16, 16, 16), 4), (1, (24, 16, 8), 8)])
+@pytest.mark.parametrize('C_,vol,p', [(4, (32, 32, 32), 16), (2, (16, 16, 16), 4), (1, (24, 16, 8), 8), (4, (48, 24, 40), 8),
+                                      (1, (16, 48, 80), 16)])
 def test_loss_chain(lib, C, C_, vol, p):
     from vit_ae_plus_plus_amd.engine import gaussian_taps_host
     B = 2
@@ -458,6 +459,14 @@ def test_loss_chain(lib, C, C_, vol, p):
     assert float(dpred[:, 0].abs().max()) == 0.0
     assert rel_err(dpred, pr.grad) < 3e-5
     assert torch.equal(dpred16, dpred.to(torch.bfloat16))
+    # the one-pass backward (recon + edge) the training step uses
+    dfu = torch.zeros(B, L + 1, P, device='cuda')
+    dfu16 = torch.zeros(B, L + 1, P, dtype=torch.bfloat16, device='cuda')
+    lib.vitae_loss_bwd_fused(pp, pv.data_ptr(), im.data_ptr(), mk.data_ptr(), ep.data_ptr(), et.data_ptr(), hp.data_ptr(),
+                             dG.data_ptr(), dfu.data_ptr() + P * 4, dfu16.data_ptr() + P * 2, pbs, msum, B, C_, *vol, p, st())
+    assert float(dfu[:, 0].abs().max()) == 0.0
+    assert rel_err(dfu, pr.grad) < 3e-5
+    assert torch.equal(dfu16, dfu.to(torch.bfloat16))
 
 
 def test_sobel_kat_and_nan_semantics(lib):
@@ -467,6 +476,23 @@ def test_sobel_kat_and_nan_semantics(lib):
     lib.vitae_sobel_edge_fwd(dev(x).data_ptr(), e.data_ptr(), None, None, 1, 1, 3, 3, 3, st())
     assert abs(float(e[0, 1, 1, 1]) - 305.26056) < 1e-3
     assert rel_err(e, R.sobel_magnitude(x)) < 1e-6
+    # constant volume: interior gradient magnitude is exactly 0 -> d sqrt = 0/0 = NaN, as in the reference
+    vol, p = (16, 16, 16), 8
+    P, L = p ** 3, 8
+    hp = torch.zeros(16, device='cuda'); hp[6:9] = 1.0
+    pv = torch.ones(1, 1, *vol, device='cuda')
+    ep, et = torch.empty(1, *vol, device='cuda'), torch.zeros(1, *vol, device='cuda')
+    lib.vitae_sobel_edge_fwd(pv.data_ptr(), ep.data_ptr(), None, None, 1, 1, *vol, st())
+    pred = torch.ones(1, L, P, device='cuda')
+    mk = torch.ones(1, L, device='cuda')
+    d = torch.zeros(1, L, P, device='cuda')
+    lib.vitae_loss_bwd_fused(pred.data_ptr(), pv.data_ptr(), pv.data_ptr(), mk.data_ptr(), ep.data_ptr(), et.data_ptr(),
+                             hp.data_ptr(), None, d.data_ptr(), None, L * P, 8.0, 1, 1, *vol, p, st())
+    xr = torch.ones(1, 1, *vol, requires_grad=True)
+    (R.sobel_magnitude(xr) ** 2).mean().backward()
+    ref = xr.grad[0, 0]
+    got = R.unpatchify(d.cpu(), p, (2, 2, 2))[0, 0]
+    assert torch.equal(torch.isnan(got), torch.isnan(ref)) and bool(torch.isnan(ref).any())
 
 
 # --------------------------------------------------------------------------- predictor pieces

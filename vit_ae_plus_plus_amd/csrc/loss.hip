@@ -212,6 +212,285 @@ __global__ __launch_bounds__(256) void sobel_bwd_scatter_kernel(const float* __r
     }
 }
 
+// ---------------------------------------------------------------- LDS-tiled variants (the ones the step uses)
+// Blur, x and y axes in one pass: a block owns a band of TY rows of one (b,c,z) plane, stages the band plus
+// RAD halo rows (zero padded in x and y) in LDS, blurs along x into a second LDS buffer, then along y.
+// Summation order per axis equals blur_axis_kernel's (out-of-range taps add an exact 0).
+template <int RAD>
+__global__ __launch_bounds__(256) void blur_xy_kernel(const float* __restrict__ in, float* __restrict__ out, int Hy, int Wx,
+                                                      int TY, Taps t) {
+    extern __shared__ float sm[];
+    const int rows = TY + 2 * RAD, stride = Wx + 2 * RAD;
+    float* a = sm;                    // [rows][stride]
+    float* m = sm + rows * stride;    // [rows][Wx]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int y0 = blockIdx.x * TY;
+    const float* src = in + (long)blockIdx.y * Hy * Wx;
+    float* dst = out + (long)blockIdx.y * Hy * Wx;
+    for (int r = wave; r < rows; r += 4) {
+        const int yy = y0 - RAD + r;
+        const bool rin = yy >= 0 && yy < Hy;
+        for (int xs = lane; xs < stride; xs += 64) {
+            const int xx = xs - RAD;
+            a[r * stride + xs] = (rin && xx >= 0 && xx < Wx) ? src[(long)yy * Wx + xx] : 0.f;
+        }
+    }
+    __syncthreads();
+    for (int r = wave; r < rows; r += 4)
+        for (int x = lane; x < Wx; x += 64) {
+            const float* row = a + r * stride + x;
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2 * RAD + 1; ++i) acc += t.k[i] * row[i];
+            m[r * Wx + x] = acc;
+        }
+    __syncthreads();
+    for (int r = wave; r < TY; r += 4) {
+        const int yy = y0 + r;
+        if (yy >= Hy) break;
+        for (int x = lane; x < Wx; x += 64) {
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2 * RAD + 1; ++i) acc += t.k[i] * m[(r + i) * Wx + x];
+            dst[(long)yy * Wx + x] = acc;
+        }
+    }
+}
+
+// Blur along z: one thread per (y,x) column and z chunk; the ZC + 2 RAD inputs are fetched up front (all loads
+// in flight together) and each output is a static-index dot product in registers.
+template <int RAD, int ZC>
+__global__ __launch_bounds__(256) void blur_z_kernel(const float* __restrict__ in, float* __restrict__ out, int Lz, long plane,
+                                                     Taps t) {
+    const long pos = (long)blockIdx.x * 256 + threadIdx.x;
+    if (pos >= plane) return;
+    const int z0 = blockIdx.y * ZC;
+    const float* src = in + (long)blockIdx.z * Lz * plane + pos;
+    float* dst = out + (long)blockIdx.z * Lz * plane + pos;
+    float v[ZC + 2 * RAD];
+#pragma unroll
+    for (int i = 0; i < ZC + 2 * RAD; ++i) {
+        const int zz = z0 - RAD + i;
+        v[i] = (zz >= 0 && zz < Lz) ? src[(long)zz * plane] : 0.f;
+    }
+#pragma unroll
+    for (int o = 0; o < ZC; ++o) {
+        if (z0 + o >= Lz) break;
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2 * RAD + 1; ++i) acc += t.k[i] * v[o + i];
+        dst[(long)(z0 + o) * plane] = acc;
+    }
+}
+
+// Sobel stencils, separable form.  In-plane partials of one z plane at (y, x):
+//   A = s(y) d(x),  Bp = e(y) s(x),  Cp = s(y) s(x);   g0 = s(z) A, g1 = s(z) Bp, g2 = e(z) Cp.
+// `row` points at the LDS element (y-1, x-1) of the plane, `rs` is the LDS row stride.
+__device__ __forceinline__ void sobel_plane(const float* row, int rs, float& A, float& Bp, float& Cp) {
+    const float a0 = row[0], a1 = row[1], a2 = row[2];
+    const float b0 = row[rs], b1 = row[rs + 1], b2 = row[rs + 2];
+    const float c0 = row[2 * rs], c1 = row[2 * rs + 1], c2 = row[2 * rs + 2];
+    const float sa = a0 + 2.f * a1 + a2, sb = b0 + 2.f * b1 + b2, sc = c0 + 2.f * c1 + c2;
+    const float da = a0 - a2, db = b0 - b2, dc = c0 - c2;
+    A = da + 2.f * db + dc;
+    Bp = sc - sa;
+    Cp = sa + 2.f * sb + sc;
+}
+
+constexpr int TZ = 8, TY_ = 8, TX = 32;                       // output tile of the Sobel kernels (z, y, x)
+
+// E = sum_c |grad vol_c| on a TZ x TY x TX tile: the tile plus a 1-voxel halo of one channel sits in LDS, each
+// thread owns one (y, x) column and marches along z with a 3-plane register ring of the in-plane partials.
+__global__ __launch_bounds__(256) void sobel_mag_tiled_kernel(const float* __restrict__ vol, float* __restrict__ E,
+                                                              const float* __restrict__ E_ref, double* __restrict__ acc,
+                                                              int C, int Lz, int Hy, int Wx, int xtiles) {
+    constexpr int RZ = TZ + 2, RY = TY_ + 2, RX = TX + 2;
+    __shared__ float sv[RZ * RY * RX];
+    __shared__ float red[4];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int x0 = (blockIdx.x % xtiles) * TX, y0 = (blockIdx.x / xtiles) * TY_, z0 = blockIdx.y * TZ, b = blockIdx.z;
+    const long V = (long)Lz * Hy * Wx;
+    float e[TZ];
+#pragma unroll
+    for (int i = 0; i < TZ; ++i) e[i] = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float* src = vol + ((long)b * C + c) * V;
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < RZ * RY * RX; idx += 256) {
+            const int xx = idx % RX, r = idx / RX, yy = r % RY, zz = r / RY;
+            const int gx = x0 - 1 + xx, gy = y0 - 1 + yy, gz = z0 - 1 + zz;
+            const bool in = gx >= 0 && gx < Wx && gy >= 0 && gy < Hy && gz >= 0 && gz < Lz;
+            sv[idx] = in ? src[((long)gz * Hy + gy) * Wx + gx] : 0.f;
+        }
+        __syncthreads();
+        float A0, B0, C0, A1, B1, C1, A2, B2, C2;
+        sobel_plane(sv + (0 * RY + ty) * RX + tx, RX, A0, B0, C0);
+        sobel_plane(sv + (1 * RY + ty) * RX + tx, RX, A1, B1, C1);
+#pragma unroll
+        for (int zz = 2; zz < RZ; ++zz) {
+            sobel_plane(sv + (zz * RY + ty) * RX + tx, RX, A2, B2, C2);
+            const float g0 = A0 + 2.f * A1 + A2, g1 = B0 + 2.f * B1 + B2, g2 = C2 - C0;
+            e[zz - 2] += sqrtf(g0 * g0 + g1 * g1 + g2 * g2);
+            A0 = A1; B0 = B1; C0 = C1; A1 = A2; B1 = B2; C1 = C2;
+        }
+    }
+    float sq = 0.f;
+    const int x = x0 + tx, y = y0 + ty;
+    if (x < Wx && y < Hy) {
+#pragma unroll
+        for (int i = 0; i < TZ; ++i) {
+            const int z = z0 + i;
+            if (z >= Lz) break;
+            const long o = (long)b * V + ((long)z * Hy + y) * Wx + x;
+            E[o] = e[i];
+            if (E_ref) { const float d = e[i] - E_ref[o]; sq += d * d; }
+        }
+    }
+    if (E_ref) {
+        sq = block_sum_256(sq, red);
+        if (threadIdx.x == 0) atomicAdd(acc + VITAE_ACC_EDGE, (double)sq);
+    }
+}
+
+// Whole loss backward in one pass over the volume:
+//   dpred = mask * 2 g_recon (pred - img) / (P mask.sum())  +  d(edge mse)/d pred          (fp32 and optional bf16)
+// Per tile and channel: pred_vol tile + 2-voxel halo -> LDS; Sobel components on tile + 1 halo, scaled by
+// dE / |g| (dE = 2 g_edge (E_pred - E_tgt) / (B V), exact 0 outside the volume; |g| == 0 gives NaN like the
+// reference's sqrt backward) -> three LDS arrays; transposed (flipped) separable stencils over those -> dvol.
+// All C channels of a voxel are adjacent in patchify order, so they are collected in registers and stored as
+// one vector per voxel.
+template <int CH>
+__global__ __launch_bounds__(256) void loss_bwd_fused_kernel(const float* __restrict__ pvol, const float* __restrict__ imgs,
+                                                             const float* __restrict__ mask, const float* __restrict__ Ep,
+                                                             const float* __restrict__ Et, const float* __restrict__ hp,
+                                                             float* __restrict__ dpred, __bf16* __restrict__ dpred16,
+                                                             float inv_count, float inv_p_masksum, int xtiles, VolGeom g) {
+    constexpr int VZ = TZ + 4, VY = TY_ + 4, VX = TX + 4;      // pred_vol region (halo 2)
+    constexpr int GZ = TZ + 2, GY = TY_ + 2, GX = TX + 2;      // dG region (halo 1)
+    constexpr int NCOL = GY * GX, NPASS = (NCOL + 255) / 256;
+    __shared__ float sv[VZ * VY * VX];
+    __shared__ float sg[3][GZ * GY * GX];
+    const int Lz = g.Lz, Hy = g.Hy, Wx = g.Wx;
+    const long V = (long)Lz * Hy * Wx;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int x0 = (blockIdx.x % xtiles) * TX, y0 = (blockIdx.x / xtiles) * TY_, z0 = blockIdx.y * TZ, b = blockIdx.z;
+    const float ce = 2.f * hp[VITAE_HP_G_EDGE] * inv_count, cr = 2.f * hp[VITAE_HP_G_RECON] * inv_p_masksum;
+
+    // dE at this thread's dG columns (same for every channel); NaN marks "outside the volume"
+    float de[NPASS][GZ];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const int col = threadIdx.x + ps * 256;
+        const int cx = col % GX, cy = col / GX;
+        const int gx = x0 - 1 + cx, gy = y0 - 1 + cy;
+        const bool cin = col < NCOL && gx >= 0 && gx < Wx && gy >= 0 && gy < Hy;
+#pragma unroll
+        for (int k = 0; k < GZ; ++k) {
+            const int gz = z0 - 1 + k;
+            float v = __builtin_nanf("");
+            if (cin && gz >= 0 && gz < Lz) {
+                const long o = (long)b * V + ((long)gz * Hy + gy) * Wx + gx;
+                v = ce * (Ep[o] - Et[o]);
+            }
+            de[ps][k] = v;
+        }
+    }
+    float o[CH][TZ];
+    const int x = x0 + tx, y = y0 + ty;
+    const bool live = x < Wx && y < Hy;
+    for (int c = 0; c < CH; ++c) {
+        const float* src = pvol + ((long)b * g.C + c) * V;
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < VZ * VY * VX; idx += 256) {
+            const int xx = idx % VX, r = idx / VX, yy = r % VY, zz = r / VY;
+            const int gx = x0 - 2 + xx, gy = y0 - 2 + yy, gz = z0 - 2 + zz;
+            const bool in = gx >= 0 && gx < Wx && gy >= 0 && gy < Hy && gz >= 0 && gz < Lz;
+            sv[idx] = in ? src[((long)gz * Hy + gy) * Wx + gx] : 0.f;
+        }
+        __syncthreads();
+        // ---- dG on the halo-1 region, one (y, x) column per thread (and a second one for the first threads)
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int col = threadIdx.x + ps * 256;
+            if (col < NCOL) {
+                const int cx = col % GX, cy = col / GX;
+                const float* base = sv + cy * VX + cx;        // region (vz, cy .. cy+2, cx .. cx+2)
+                float A0, B0, C0, A1, B1, C1, A2, B2, C2;
+                sobel_plane(base, VX, A0, B0, C0);
+                sobel_plane(base + VY * VX, VX, A1, B1, C1);
+#pragma unroll
+                for (int vz = 2; vz < VZ; ++vz) {
+                    sobel_plane(base + vz * VY * VX, VX, A2, B2, C2);
+                    const float g0 = A0 + 2.f * A1 + A2, g1 = B0 + 2.f * B1 + B2, g2 = C2 - C0;
+                    const float d = de[ps][vz - 2];
+                    const bool in = d == d;
+                    const float f = d / sqrtf(g0 * g0 + g1 * g1 + g2 * g2);
+                    const int gi = ((vz - 2) * GY + cy) * GX + cx;
+                    sg[0][gi] = in ? f * g0 : 0.f;
+                    sg[1][gi] = in ? f * g1 : 0.f;
+                    sg[2][gi] = in ? f * g2 : 0.f;
+                    A0 = A1; B0 = B1; C0 = C1; A1 = A2; B1 = B2; C1 = C2;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- transposed stencils: dvol = s(z)[ s(y)e(x) G0 + d(y)s(x) G1 ] + d(z) s(y)s(x) G2
+        float Q0, P0, Q1, P1, Q2, P2;
+        auto plane = [&](int gz, float& Q, float& P) {
+            const float* r0 = &sg[0][(gz * GY + ty) * GX + tx];
+            const float* r1 = &sg[1][(gz * GY + ty) * GX + tx];
+            const float* r2 = &sg[2][(gz * GY + ty) * GX + tx];
+            const float q0 = (r0[2] - r0[0]) + 2.f * (r0[GX + 2] - r0[GX]) + (r0[2 * GX + 2] - r0[2 * GX]);
+            const float s1a = r1[0] + 2.f * r1[1] + r1[2], s1c = r1[2 * GX] + 2.f * r1[2 * GX + 1] + r1[2 * GX + 2];
+            const float s2a = r2[0] + 2.f * r2[1] + r2[2], s2b = r2[GX] + 2.f * r2[GX + 1] + r2[GX + 2],
+                        s2c = r2[2 * GX] + 2.f * r2[2 * GX + 1] + r2[2 * GX + 2];
+            Q = q0 + (s1a - s1c);
+            P = s2a + 2.f * s2b + s2c;
+        };
+        plane(0, Q0, P0);
+        plane(1, Q1, P1);
+#pragma unroll
+        for (int gz = 2; gz < GZ; ++gz) {
+            plane(gz, Q2, P2);
+            const int tz = gz - 2, z = z0 + tz;
+            float val = (Q0 + 2.f * Q1 + Q2) + (P0 - P2);
+            if (live && z < Lz) {
+                const int l = ((z / g.p) * g.g1 + y / g.p) * g.g2 + x / g.p;
+                if (mask[(long)b * g.L + l] != 0.f) {
+                    const float pv = sv[((tz + 2) * VY + ty + 2) * VX + tx + 2];
+                    val = cr * (pv - imgs[((long)b * g.C + c) * V + ((long)z * Hy + y) * Wx + x]) + val;
+                }
+            }
+            o[c][tz] = val;
+            Q0 = Q1; P0 = P1; Q1 = Q2; P1 = P2;
+        }
+    }
+    if (!live) return;
+#pragma unroll
+    for (int tz = 0; tz < TZ; ++tz) {
+        const int z = z0 + tz;
+        if (z >= Lz) break;
+        const int p = g.p;
+        const int l = ((z / p) * g.g1 + y / p) * g.g2 + x / p;
+        const int e0 = (((z % p) * p + y % p) * p + x % p) * CH;
+        const long doff = (long)b * g.pred_bstride + (long)l * g.P + e0;
+        if constexpr (CH == 4) {
+            *reinterpret_cast<float4*>(dpred + doff) = make_float4(o[0][tz], o[1][tz], o[2][tz], o[3][tz]);
+            if (dpred16) {
+                typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+                bf4 h = {(__bf16)o[0][tz], (__bf16)o[1][tz], (__bf16)o[2][tz], (__bf16)o[3][tz]};
+                *reinterpret_cast<bf4*>(dpred16 + doff) = h;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                dpred[doff + c] = o[c][tz];
+                if (dpred16) dpred16[doff + c] = (__bf16)o[c][tz];
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- scalar finalisation
 // out = [loss, raw_edge_mse, recon, percep(=0)]   (vit_autoenc.py:231-232)
 __global__ void loss_finalize_kernel(const double* __restrict__ acc, const float* __restrict__ hp, float* __restrict__ out,
@@ -324,6 +603,16 @@ extern "C" int vitae_gauss_blur_fwd(const float* vol, float* tmp, float* out, co
     const int blocks = stream_blocks(total);
     hipStream_t st = (hipStream_t)stream;
     // x, then y, then z (exact-arithmetic equal to the dense k (x) k (x) k kernel of the reference)
+    if (ntaps == 11 && Wx <= 384 && (long)Lz * BC <= 65535) {
+        constexpr int RAD = 5, ROWS = 32, ZC = 32;
+        const int TY = ROWS - 2 * RAD;
+        const size_t lds = (size_t)ROWS * (2 * Wx + 2 * RAD) * sizeof(float);
+        hipLaunchKernelGGL(blur_xy_kernel<RAD>, dim3(cdiv(Hy, TY), Lz * BC), dim3(256), lds, st, vol, tmp, Hy, Wx, TY, t);
+        const long plane = (long)Hy * Wx;
+        hipLaunchKernelGGL((blur_z_kernel<RAD, ZC>), dim3(cdiv(plane, 256), cdiv(Lz, ZC), BC), dim3(256), 0, st, tmp, out, Lz,
+                           plane, t);
+        return vitae_launch_status();
+    }
     hipLaunchKernelGGL(blur_axis_kernel, dim3(blocks), dim3(256), 0, st, vol, out, total, Wx, 1L, t);
     hipLaunchKernelGGL(blur_axis_kernel, dim3(blocks), dim3(256), 0, st, out, tmp, total, Hy, (long)Wx, t);
     hipLaunchKernelGGL(blur_axis_kernel, dim3(blocks), dim3(256), 0, st, tmp, out, total, Lz, (long)Wx * Hy, t);
@@ -333,6 +622,12 @@ extern "C" int vitae_gauss_blur_fwd(const float* vol, float* tmp, float* out, co
 extern "C" int vitae_sobel_edge_fwd(const float* vol, float* edge, const float* edge_ref, double* acc, int B, int C,
                                     int Lz, int Hy, int Wx, void* stream) {
     if (!vol || !edge || B <= 0 || C <= 0 || (edge_ref && !acc)) return VITAE_ERR_INVALID_ARG;
+    const int xt = cdiv(Wx, TX), yt = cdiv(Hy, TY_), zt = cdiv(Lz, TZ);
+    if (zt <= 65535 && B <= 65535) {
+        hipLaunchKernelGGL(sobel_mag_tiled_kernel, dim3(xt * yt, zt, B), dim3(256), 0, (hipStream_t)stream, vol, edge,
+                           edge_ref, acc, C, Lz, Hy, Wx, xt);
+        return vitae_launch_status();
+    }
     const long total = (long)B * Lz * Hy * Wx;
     hipLaunchKernelGGL(sobel_mag_kernel, dim3(stream_blocks(total)), dim3(256), 0, (hipStream_t)stream, vol, edge,
                        edge_ref, acc, B, C, Lz, Hy, Wx);
@@ -350,6 +645,38 @@ extern "C" int vitae_sobel_edge_bwd(const float* pred_vol, const float* edge_pre
                        edge_tgt, hp, dG_ws, 1.0f / (float)total, B, C, Lz, Hy, Wx);
     hipLaunchKernelGGL(sobel_bwd_scatter_kernel, dim3(stream_blocks(total)), dim3(256), 0, st, dG_ws, dpred,
                        reinterpret_cast<__bf16*>(dpred_bf16), B, g);
+    return vitae_launch_status();
+}
+
+extern "C" int vitae_loss_bwd_fused(const float* pred, const float* pred_vol, const float* imgs, const float* mask, const float* edge_pred,
+                                    const float* edge_tgt, const float* hp, float* dG_ws, float* dpred, void* dpred_bf16,
+                                    long pred_bstride, float mask_sum, int B, int C, int Lz, int Hy, int Wx, int p,
+                                    void* stream) {
+    if (!pred || !pred_vol || !imgs || !mask || !edge_pred || !edge_tgt || !hp || !dpred || B <= 0 || p <= 0 || mask_sum <= 0.f ||
+        Lz % p || Hy % p || Wx % p)
+        return VITAE_ERR_INVALID_ARG;
+    VolGeom g = make_geom(C, Lz, Hy, Wx, p, pred_bstride);
+    const long total = (long)B * Lz * Hy * Wx;
+    const float inv_count = 1.0f / (float)total, inv_pm = 1.0f / ((float)g.P * mask_sum);
+    const int xt = cdiv(Wx, TX), yt = cdiv(Hy, TY_), zt = cdiv(Lz, TZ);
+    hipStream_t st = (hipStream_t)stream;
+    __bf16* d16 = reinterpret_cast<__bf16*>(dpred_bf16);
+    const bool vec_ok = ((uintptr_t)dpred % 16 == 0) && ((uintptr_t)dpred_bf16 % 8 == 0) && pred_bstride % 4 == 0;
+    if (zt <= 65535 && B <= 65535 && (C == 1 || (C == 4 && vec_ok))) {
+        if (C == 1)
+            hipLaunchKernelGGL(loss_bwd_fused_kernel<1>, dim3(xt * yt, zt, B), dim3(256), 0, st, pred_vol, imgs, mask, edge_pred,
+                               edge_tgt, hp, dpred, d16, inv_count, inv_pm, xt, g);
+        else
+            hipLaunchKernelGGL(loss_bwd_fused_kernel<4>, dim3(xt * yt, zt, B), dim3(256), 0, st, pred_vol, imgs, mask, edge_pred,
+                               edge_tgt, hp, dpred, d16, inv_count, inv_pm, xt, g);
+        return vitae_launch_status();
+    }
+    // other channel counts: the three-kernel path (needs the dG scratch)
+    if (!dG_ws) return VITAE_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(recon_bwd_kernel, dim3(g.L, B), dim3(256), 0, st, pred, imgs, mask, hp, dpred, inv_pm, g);
+    hipLaunchKernelGGL(sobel_bwd_components_kernel, dim3(stream_blocks(total)), dim3(256), 0, st, pred_vol, edge_pred,
+                       edge_tgt, hp, dG_ws, inv_count, B, C, Lz, Hy, Wx);
+    hipLaunchKernelGGL(sobel_bwd_scatter_kernel, dim3(stream_blocks(total)), dim3(256), 0, st, dG_ws, dpred, d16, B, g);
     return vitae_launch_status();
 }
 

@@ -278,7 +278,8 @@ class HipMAEEngine:
         b['pred_vol'] = f(B, cfg.in_chans, *cfg.volume_size)
         b['blur_tmp'], b['blurred'] = f(B * cfg.in_chans * V), f(B * cfg.in_chans * V)
         b['edge_t'], b['edge_p'] = f(B * V), f(B * V)
-        b['dG'] = f(B * cfg.in_chans * 3 * V)
+        if cfg.in_chans not in (1, 4):   # the one-pass loss backward covers C = 1 and 4; others need the dG scratch
+            b['dG'] = f(B * cfg.in_chans * 3 * V)
         if cfg.contrastive:
             R = B * Ne
             self.R = R
@@ -650,11 +651,10 @@ class HipMAEEngine:
         C, (Lz, Hy, Wx), ps = cfg.in_chans, cfg.volume_size, cfg.patch_size
         view1 = self.view1
         pred_ptr, dpred_ptr, pbs = b['predfull'].data_ptr() + P * 4, b['dpredfull'].data_ptr() + P * 4, Nd * P
-        lib.vitae_recon_loss_bwd(pred_ptr, pbs, _ptr(view1), _ptr(b['mask']), _ptr(self.hp), dpred_ptr, self.mask_sum, B, C,
-                                 Lz, Hy, Wx, ps, st)
         a16 = self.act16
-        lib.vitae_sobel_edge_bwd(_ptr(b['pred_vol']), _ptr(b['edge_p']), _ptr(b['edge_t']), _ptr(self.hp), _ptr(b['dG']),
-                                 dpred_ptr, (b['dpred_16'].data_ptr() + P * 2) if a16 else None, pbs, B, C, Lz, Hy, Wx, ps, st)
+        lib.vitae_loss_bwd_fused(pred_ptr, _ptr(b['pred_vol']), _ptr(view1), _ptr(b['mask']), _ptr(b['edge_p']), _ptr(b['edge_t']),
+                                 _ptr(self.hp), _ptr(b.get('dG')), dpred_ptr, (b['dpred_16'].data_ptr() + P * 2) if a16 else None,
+                                 pbs, self.mask_sum, B, C, Lz, Hy, Wx, ps, st)
         dx_ = b['decx']
         nd = cfg.decoder_depth
         if a16:
