@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITAE_ABI_VERSION 9
+#define VITAE_ABI_VERSION 10
 
 /* matrix-core arithmetic of the dense contractions */
 #define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
@@ -88,8 +88,13 @@ int vitae_gemm_bf16_pick_split_k(int M, int N, int K);
 int vitae_linear_bwd_pair_bf16(const float* dy, const void* w_bf16, const float* x, float* dx, float* dw,
                                float* db_accum, int M, int N, int K, int epi, float* aux, int dx_accumulate,
                                int dw_accumulate, void* stream);
-/* bf16 x bf16 variant with a 4-stage LDS-DMA (global_load_lds) pipeline; A16/B16 bf16, K % 64 == 0;
- * C (fp32) and/or C16 (bf16 copy of the result) may be given; out_colsum_accum[n] += sum_m result(m,n). */
+/* bf16 x bf16 variant with a 3-stage LDS-DMA (global_load_lds) pipeline; A16/B16 bf16, K % 64 == 0;
+ * C (fp32) and/or C16 (bf16 copy of the result) may be given; out_colsum_accum[n] += sum_m result(m,n).
+ * split_k > 1 reduces inside the launch (last workgroup of a tile sums the partials in split order and runs the
+ * epilogue): splitk_ws must hold vitae_gemm_glds_ws_floats(M, N, split_k) floats whose first VITAE_GLDS_TICKETS
+ * words are ZERO before the first use (the kernel leaves them zero again). */
+#define VITAE_GLDS_TICKETS 4096
+long vitae_gemm_glds_ws_floats(int M, int N, int split_k);
 int vitae_gemm_glds(int a_kcontig, int b_kcontig, const void* A16, long lda, const void* B16, long ldb, float* C,
                     long ldc, void* C16, long ldc16, int M, int N, int K, const float* bias, const float* residual,
                     long ldr, int epi, float* aux, long ldaux, int accumulate, int split_k, float* splitk_ws,
@@ -100,7 +105,9 @@ int vitae_gemm_glds_pick_split_k(int M, int N, int K);
  * rows — rows M..Mpad-1 of dy16 and x16 must be zero. */
 int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, const void* x16, float* dx, void* dx16, float* dw,
                                int M, int Mpad, int N, int K, int epi, float* aux, float* dx_colsum_accum,
-                               int dw_accumulate, void* stream);
+                               int dw_accumulate, int split_k, float* splitk_ws, void* stream);
+/* split of the dgrad reduction for the call above (1 = none); workspace as for vitae_gemm_glds with (M, K) */
+int vitae_linear_bwd_pair_pick_split_k(int M, int Mpad, int N, int K);
 /* dst_bf16[i] = bf16(src[i]) (round to nearest even) */
 int vitae_cast_bf16(const float* src, void* dst_bf16, long n, void* stream);
 

@@ -68,7 +68,7 @@ def run_glds(name, form, M, N, K, iters=50, check=True):
     Bs = [B16_0] + [B16_0.clone() for _ in range(ncopies(B16_0.numel() * 2) - 1)]
     cnt = [0]
     C = torch.full((M, N), float('nan'), device=dev)
-    ws = torch.empty(1 << 24, device=dev)
+    ws = torch.zeros(1 << 24, device=dev)
     lda = Kp if akc else M
     ldb = Kp if bkc else N
     split = lib.vitae_gemm_glds_pick_split_k(M, N, Kp)
@@ -91,7 +91,41 @@ def run_glds(name, form, M, N, K, iters=50, check=True):
     return us
 
 
+def run_pair(name, M, N, K, iters=50):
+    """Backward of Linear(K -> N) on M tokens: dx[M,K] = dy16 @ W16, dW[N,K] = dy16^T @ x16 in one launch."""
+    dev = 'cuda'
+    Mp = (M + 63) // 64 * 64
+    dy16 = torch.zeros(Mp, N, dtype=torch.bfloat16, device=dev); dy16[:M] = torch.randn(M, N, device=dev)
+    x16 = torch.zeros(Mp, K, dtype=torch.bfloat16, device=dev); x16[:M] = torch.randn(M, K, device=dev)
+    w0 = (torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16)
+    Ws = [w0] + [w0.clone() for _ in range(ncopies(w0.numel() * 2) - 1)]
+    dx, dw = torch.empty(M, K, device=dev), torch.empty(N, K, device=dev)
+    cnt = [0]
+    split = lib.vitae_linear_bwd_pair_pick_split_k(M, Mp, N, K)
+    ws = torch.zeros(1 << 23, device=dev)
+    def go():
+        cnt[0] += 1
+        w = Ws[cnt[0] % len(Ws)]
+        lib.vitae_linear_bwd_pair_glds(dy16.data_ptr(), w.data_ptr(), x16.data_ptr(), dx.data_ptr(), None, dw.data_ptr(), M, Mp, N, K,
+                                       0, None, None, 0, split, ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    for _ in range(5): go()
+    torch.cuda.synchronize()
+    e1 = float((dx - dy16[:M].float() @ w0.float()).abs().max() / (dx.abs().max() + 1e-20))
+    e2 = float((dw - dy16.float().t() @ x16.float()).abs().max() / (dw.abs().max() + 1e-20))
+    us = graph_time(go, iters)
+    print(f'PAIR {name:24s} M={M:5d} N={N:5d} K={K:5d} split={split}  {us:8.1f} us  {4.0*M*N*K/us/1e6:7.1f} TF/s  err {e1:.1e} {e2:.1e}' + (' !!!' if max(e1, e2) > 2e-3 else ''))
+    return us
+
+
 if __name__ == '__main__':
+    if 'pair' in sys.argv:
+        tot = 0.0
+        for (nm, M, d, h, cnt) in (('enc', 440, 768, 3072, 12), ('dec', 868, 512, 2048, 8)):
+            for (n2, N, K) in (('qkv', 3 * d, d), ('proj', d, d), ('fc1', h, d), ('fc2', d, h)):
+                tot += cnt * run_pair(f'{nm}.{n2}', M, N, K)
+        tot += run_pair('pred', 868, 16384, 512)
+        print(f'weighted total {tot/1e3:.3f} ms per step')
+        sys.exit(0)
     glds = 'glds' in sys.argv
     tot = 0.0
     E, D_ = 440, 868

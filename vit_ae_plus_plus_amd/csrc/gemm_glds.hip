@@ -1,4 +1,4 @@
-// bf16 x bf16 GEMM with a 4-stage LDS-DMA pipeline (global_load_lds, 16 B per lane) — the throughput
+// bf16 x bf16 GEMM with a 3-stage LDS-DMA pipeline (global_load_lds, 16 B per lane) — the throughput
 // kernel of the path once activations are kept in bf16:
 //   C[M,N] (+)= epi( sum_k A(m,k) * B(n,k) + bias[n] ) (+ residual)      (fp32 accumulate / fp32 C,
 //   optional bf16 copy C16 for the next GEMM's operand)
@@ -6,21 +6,27 @@
 //
 // Why this shape on MI355X: at M ~ 440-870 a workgroup's K loop is latency bound (a CU fetches
 // ~bytes-in-flight per ~1 us), and hipcc collapses register-staged multi-tile prefetch into one tile in
-// flight.  LDS-DMA needs no registers: three 64-deep k-tiles (3 x 16-24 KB per workgroup) stay in
-// flight behind the tile being multiplied, retired with COUNTED s_waitcnt vmcnt(N) + a raw s_barrier
+// flight.  LDS-DMA needs no registers: two 64-deep k-tiles (2 x 16-24 KB per workgroup) stay in
+// flight behind the tile being multiplied (a third in-flight stage bought nothing, while 48 KB instead of
+// 64 KB of LDS lets three workgroups share a CU: pred fwd 73 -> 50 us), retired with COUNTED s_waitcnt
+// vmcnt(N) + a raw s_barrier
 // (a __syncthreads() would drain the DMA queue; cdna_hip_programming.md §5 "Pipelining across barriers").
 // The DMA writes LDS lane-linearly (wave-uniform base + lane*16), so bank conflicts are avoided by
 // permuting the SOURCE addresses: 16-byte chunk c of tile row r is stored at chunk slot c ^ (r & 7),
 // and the fragment reads (ds_read_b128 for k-contiguous tiles, ds_read_b64_tr_b16 for row-contiguous
 // ones) apply the same XOR.  K (and the k-range of each split) must be a multiple of 64 — the engine
 // pads token counts of its bf16 activation buffers to 64 with zero rows for the wgrad reductions.
+#include <cstdlib>
 #include "common.hpp"
 #include "vitae_hip.h"
 
 namespace {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
-constexpr int BM = 64, BK = 64, NS = 4;
+#ifndef VITAE_GLDS_NS
+#define VITAE_GLDS_NS 3
+#endif
+constexpr int BM = 64, BK = 64, NS = VITAE_GLDS_NS;
 
 struct GArgs {
     const __bf16* A; long lda;
@@ -33,7 +39,7 @@ struct GArgs {
     const float* residual; long ldr;
     float* aux; long ldaux;
     int epi, accumulate;
-    float* ws;
+    float* ws;           // split-K: [VITAE_GLDS_TICKETS ints of tile tickets (zero between launches)][partial tiles]
     float* out_colsum;   // optional: out_colsum[n] += sum_m (epilogue result)(m, n)  (bias gradient of the NEXT Linear)
     int tiles_m, tiles_n;
 };
@@ -174,6 +180,48 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
                 acc[kk & 1][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk], fb[kk][f], acc[kk & 1][f], 0, 0, 0);
     }
 
+    float a[FN][16];
+#pragma unroll
+    for (int f = 0; f < FN; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[f][r] = acc[0][f][r] + acc[1][f][r];
+
+    if (p.splits > 1) {
+        // Split-K fix-up without a second launch: every split parks its partial tile (fragment order, coalesced),
+        // takes a ticket, and the LAST one to arrive sums all partials in split order (bitwise reproducible whatever
+        // the arrival order) and runs the epilogue.  Fences: release before the ticket, acquire after it.
+        // Partials and tickets move with agent-scope relaxed atomics (sc1: written through to / read from the
+        // memory side, coherent across the 8 XCD L2s); a full release/acquire fence pair instead would write back
+        // and invalidate the whole L2 per workgroup (measured 3x slower than no split at all).
+        const int tile = tm * p.tiles_n + tn;
+        float* part = p.ws + VITAE_GLDS_TICKETS + ((long)tile * p.splits) * (BM * BN);
+        int* ticket = reinterpret_cast<int*>(p.ws) + tile;
+#pragma unroll
+        for (int f = 0; f < FN; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                __hip_atomic_store(&part[(long)zid * (BM * BN) + (f * 16 + r) * 256 + threadIdx.x], a[f][r], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this thread's partials are out
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(smem);
+        if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*flag != p.splits - 1) return;
+#pragma unroll
+        for (int f = 0; f < FN; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[f][r] = 0.f;
+        for (int sp = 0; sp < p.splits; ++sp)
+#pragma unroll
+            for (int f = 0; f < FN; ++f)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    a[f][r] += __hip_atomic_load(&part[(long)sp * (BM * BN) + (f * 16 + r) * 256 + threadIdx.x], __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+
 #pragma unroll
     for (int f = 0; f < FN; ++f) {
         const int n = n0 + wn * (BN / 2) + f * 32 + l31;
@@ -181,13 +229,9 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm * 32 + crow(r, hi);
-            const float a = acc[0][f][r] + acc[1][f][r];
-            if (n < p.N && m < p.M) {
-                if (p.splits > 1) p.ws[((long)zid * p.M + m) * p.N + n] = a;
-                else csum += epilogue_store(p, a, m, n);
-            }
+            if (n < p.N && m < p.M) csum += epilogue_store(p, a[f][r], m, n);
         }
-        if (p.out_colsum && p.splits == 1) {
+        if (p.out_colsum) {
             csum += __shfl_xor(csum, 32, 64);
             if (hi == 0 && n < p.N) atomicAdd(p.out_colsum + n, csum);
         }
@@ -206,18 +250,9 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GArgs p) {
 template <int BN1, int BN2>
 __global__ __launch_bounds__(256) void gemm_glds_pair_kernel(const GArgs p1, const GArgs p2, const int nb1) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[GCfg<(BN1 > BN2 ? BN1 : BN2)>::SMEM];
-    if ((int)blockIdx.x < nb1) gemm_glds_body<BN1, true, false>(p1, blockIdx.x, 0, smem);
-    else gemm_glds_body<BN2, false, false>(p2, blockIdx.x - nb1, 0, smem);
-}
-
-__global__ __launch_bounds__(256) void splitk_reduce_glds_kernel(const GArgs p) {
-    const long total = (long)p.M * p.N;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        float v = 0.f;
-        for (int s = 0; s < p.splits; ++s) v += p.ws[(long)s * total + i];
-        const float r = epilogue_store(p, v, (int)(i / p.N), (int)(i % p.N));
-        if (p.out_colsum) atomicAdd(p.out_colsum + (i % p.N), r);
-    }
+    // nb1 = workgroups of one dgrad split; the dgrad's long reduction (N of the Linear) is cut into p1.splits
+    if ((int)blockIdx.x < nb1 * p1.splits) gemm_glds_body<BN1, true, false>(p1, blockIdx.x % nb1, blockIdx.x / nb1, smem);
+    else gemm_glds_body<BN2, false, false>(p2, blockIdx.x - nb1 * p1.splits, 0, smem);
 }
 
 template <int BN>
@@ -247,6 +282,12 @@ extern "C" int vitae_gemm_glds_pick_split_k(int M, int N, int K) {
     return s < 1 ? 1 : (int)s;
 }
 
+extern "C" long vitae_gemm_glds_ws_floats(int M, int N, int split_k) {
+    if (split_k <= 1) return 0;
+    const int bn = pick_bn(M, N);
+    return VITAE_GLDS_TICKETS + (long)cdiv(M, BM) * cdiv(N, bn) * split_k * BM * bn;
+}
+
 extern "C" int vitae_gemm_glds(int a_kcontig, int b_kcontig, const void* A16, long lda, const void* B16, long ldb,
                                float* C, long ldc, void* C16, long ldc16, int M, int N, int K, const float* bias,
                                const float* residual, long ldr, int epi, float* aux, long ldaux, int accumulate,
@@ -272,25 +313,34 @@ extern "C" int vitae_gemm_glds(int a_kcontig, int b_kcontig, const void* A16, lo
     p.epi = epi; p.accumulate = accumulate; p.ws = splitk_ws; p.out_colsum = out_colsum_accum;
     const int bn = pick_bn(M, N);
     p.tiles_m = cdiv(M, BM); p.tiles_n = cdiv(N, bn);
+    if (split_k > 1 && (long)p.tiles_m * p.tiles_n > VITAE_GLDS_TICKETS) return VITAE_ERR_UNSUPPORTED_SHAPE;
     dim3 grid(8 * cdiv(p.tiles_n, 8) * p.tiles_m, 1, split_k);
     hipStream_t st = (hipStream_t)stream;
     if (bn == 128) launch<128>(p, a_kcontig != 0, b_kcontig != 0, grid, st);
     else launch<64>(p, a_kcontig != 0, b_kcontig != 0, grid, st);
-    if (split_k > 1) {
-        const long total = (long)M * N;
-        int blocks = (int)((total + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(splitk_reduce_glds_kernel, dim3(blocks), dim3(256), 0, st, p);
-    }
     return vitae_launch_status();
 }
 
 // Backward of one Linear on bf16 operands in ONE launch: dx[M,K] = epi(dy16[M,N] @ W16[N,K]) (fp32 dx and/or
 // bf16 dx16; optional colsum of the result = bias gradient of the layer in front), dW[N,K] (+)= dy16^T @ x16.
 // Mpad = token count rounded up to 64: rows M..Mpad-1 of dy16 and x16 must be zero (wgrad reduces over them).
+extern "C" int vitae_linear_bwd_pair_pick_split_k(int M, int Mpad, int N, int K) {
+    // cut the dgrad reduction (N / 64 k-tiles on only ceil(M/64) * K/64 workgroups) down to about the length of the
+    // wgrad's (Mpad / 64 k-tiles), which otherwise finishes long before it
+    static const int target = getenv("VITAE_PAIR_SPLIT_TARGET") ? atoi(getenv("VITAE_PAIR_SPLIT_TARGET")) : 10;
+    if (target <= 0) return 1;
+    const int ks1 = N / BK, ks2 = Mpad / BK;
+    int s = (ks1 + (ks2 > target ? ks2 : target) / 2) / (ks2 > target ? ks2 : target);
+    if (s > 8) s = 8;
+    while (s > 1 && ks1 / s < 4) --s;
+    if ((long)cdiv(M, BM) * cdiv(K, pick_bn(M, K)) > VITAE_GLDS_TICKETS) s = 1;
+    return s < 1 ? 1 : s;
+}
+
 extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, const void* x16, float* dx, void* dx16,
                                           float* dw, int M, int Mpad, int N, int K, int epi, float* aux,
-                                          float* dx_colsum_accum, int dw_accumulate, void* stream) {
+                                          float* dx_colsum_accum, int dw_accumulate, int split_k, float* splitk_ws,
+                                          void* stream) {
     if (!dy16 || !w16 || !x16 || (!dx && !dx16) || !dw || M <= 0 || N <= 0 || K <= 0) return VITAE_ERR_INVALID_ARG;
     if (epi != VITAE_EPI_NONE && !aux) return VITAE_ERR_INVALID_ARG;
     if ((N % BK) || (Mpad % BK) || (K & 7) || Mpad < M) return VITAE_ERR_UNSUPPORTED_SHAPE;
@@ -299,9 +349,12 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
     p1.A = reinterpret_cast<const __bf16*>(dy16); p1.lda = N;
     p1.B = reinterpret_cast<const __bf16*>(w16); p1.ldb = K;
     p1.C = dx; p1.ldc = K; p1.C16 = reinterpret_cast<__bf16*>(dx16); p1.ldc16 = K;
-    p1.M = M; p1.N = K; p1.K = N; p1.k_per_split = N; p1.splits = 1;
+    if (split_k < 1 || !splitk_ws) split_k = 1;
+    const int kps = cdiv(cdiv(N, split_k), BK) * BK;
+    split_k = cdiv(N, kps);
+    p1.M = M; p1.N = K; p1.K = N; p1.k_per_split = kps; p1.splits = split_k;
     p1.bias = nullptr; p1.residual = nullptr; p1.ldr = 0; p1.aux = aux; p1.ldaux = K; p1.epi = epi; p1.accumulate = 0;
-    p1.ws = nullptr; p1.out_colsum = dx_colsum_accum;
+    p1.ws = splitk_ws; p1.out_colsum = dx_colsum_accum;
     const int bn1 = pick_bn(M, K);
     p1.tiles_m = cdiv(M, BM); p1.tiles_n = cdiv(K, bn1);
     p2.A = reinterpret_cast<const __bf16*>(dy16); p2.lda = N;
@@ -313,7 +366,7 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
     const int bn2 = pick_bn(N, K);
     p2.tiles_m = cdiv(N, BM); p2.tiles_n = cdiv(K, bn2);
     const int nb1 = 8 * cdiv(p1.tiles_n, 8) * p1.tiles_m, nb2 = 8 * cdiv(p2.tiles_n, 8) * p2.tiles_m;
-    dim3 grid(nb1 + nb2), block(256);
+    dim3 grid(nb1 * split_k + nb2), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (bn1 == 64 && bn2 == 64) hipLaunchKernelGGL((gemm_glds_pair_kernel<64, 64>), grid, block, 0, st, p1, p2, nb1);
     else if (bn1 == 64) hipLaunchKernelGGL((gemm_glds_pair_kernel<64, 128>), grid, block, 0, st, p1, p2, nb1);

@@ -220,9 +220,11 @@ template <int RAD>
 __global__ __launch_bounds__(256) void blur_xy_kernel(const float* __restrict__ in, float* __restrict__ out, int Hy, int Wx,
                                                       int TY, Taps t) {
     extern __shared__ float sm[];
-    const int rows = TY + 2 * RAD, stride = Wx + 2 * RAD;
-    float* a = sm;                    // [rows][stride]
-    float* m = sm + rows * stride;    // [rows][Wx]
+    constexpr int NT = 2 * RAD + 1, XB = 4;   // XB outputs per thread along x share their NT + XB - 1 inputs
+    const int rows = TY + 2 * RAD;
+    const int Wp = (Wx + XB - 1) / XB * XB, stride = Wp + 2 * RAD + 2;   // +2: de-phase consecutive rows' banks
+    float* a = sm;                    // [rows][stride]  input, zero padded
+    float* m = sm + rows * stride;    // [rows][Wp]      blurred along x
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int y0 = blockIdx.x * TY;
     const float* src = in + (long)blockIdx.y * Hy * Wx;
@@ -236,23 +238,39 @@ __global__ __launch_bounds__(256) void blur_xy_kernel(const float* __restrict__ 
         }
     }
     __syncthreads();
-    for (int r = wave; r < rows; r += 4)
-        for (int x = lane; x < Wx; x += 64) {
-            const float* row = a + r * stride + x;
+    const int groups = Wp / XB;
+    for (int w = threadIdx.x; w < rows * groups; w += 256) {
+        const int r = w / groups, x = (w - r * groups) * XB;
+        const float* row = a + r * stride + x;
+        float v[NT + XB - 1];
+#pragma unroll
+        for (int i = 0; i < NT + XB - 1; ++i) v[i] = row[i];
+#pragma unroll
+        for (int o = 0; o < XB; ++o) {
             float acc = 0.f;
 #pragma unroll
-            for (int i = 0; i < 2 * RAD + 1; ++i) acc += t.k[i] * row[i];
-            m[r * Wx + x] = acc;
+            for (int i = 0; i < NT; ++i) acc += t.k[i] * v[o + i];
+            m[r * Wp + x + o] = acc;
         }
+    }
     __syncthreads();
-    for (int r = wave; r < TY; r += 4) {
-        const int yy = y0 + r;
-        if (yy >= Hy) break;
-        for (int x = lane; x < Wx; x += 64) {
-            float acc = 0.f;
+    // y: one thread per (column, half band); inputs fetched once into registers
+    constexpr int YB = 11;
+    const int segs = (TY + YB - 1) / YB;
+    for (int w = threadIdx.x; w < Wx * segs; w += 256) {
+        const int sgm = w / Wx, x = w - sgm * Wx, r0 = sgm * YB;
+        float v[YB + NT - 1];
 #pragma unroll
-            for (int i = 0; i < 2 * RAD + 1; ++i) acc += t.k[i] * m[(r + i) * Wx + x];
-            dst[(long)yy * Wx + x] = acc;
+        for (int i = 0; i < YB + NT - 1; ++i) v[i] = (r0 + i < rows) ? m[(r0 + i) * Wp + x] : 0.f;
+#pragma unroll
+        for (int o = 0; o < YB; ++o) {
+            const int yy = y0 + r0 + o;
+            if (r0 + o < TY && yy < Hy) {
+                float acc = 0.f;
+#pragma unroll
+                for (int i = 0; i < NT; ++i) acc += t.k[i] * v[o + i];
+                dst[(long)yy * Wx + x] = acc;
+            }
         }
     }
 }
@@ -313,16 +331,29 @@ __global__ __launch_bounds__(256) void sobel_mag_tiled_kernel(const float* __res
     float e[TZ];
 #pragma unroll
     for (int i = 0; i < TZ; ++i) e[i] = 0.f;
-    for (int c = 0; c < C; ++c) {
+    constexpr int NLD = (RZ * RY * RX + 255) / 256;
+    float pre[NLD];
+    auto fetch = [&](int c) {
         const float* src = vol + ((long)b * C + c) * V;
-        __syncthreads();
-        for (int idx = threadIdx.x; idx < RZ * RY * RX; idx += 256) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int idx = threadIdx.x + k * 256;
             const int xx = idx % RX, r = idx / RX, yy = r % RY, zz = r / RY;
             const int gx = x0 - 1 + xx, gy = y0 - 1 + yy, gz = z0 - 1 + zz;
-            const bool in = gx >= 0 && gx < Wx && gy >= 0 && gy < Hy && gz >= 0 && gz < Lz;
-            sv[idx] = in ? src[((long)gz * Hy + gy) * Wx + gx] : 0.f;
+            const bool in = idx < RZ * RY * RX && gx >= 0 && gx < Wx && gy >= 0 && gy < Hy && gz >= 0 && gz < Lz;
+            pre[k] = in ? src[((long)gz * Hy + gy) * Wx + gx] : 0.f;
+        }
+    };
+    fetch(0);
+    for (int c = 0; c < C; ++c) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int idx = threadIdx.x + k * 256;
+            if (idx < RZ * RY * RX) sv[idx] = pre[k];
         }
         __syncthreads();
+        if (c + 1 < C) fetch(c + 1);     // next channel's loads fly underneath this channel's stencil
         float A0, B0, C0, A1, B1, C1, A2, B2, C2;
         sobel_plane(sv + (0 * RY + ty) * RX + tx, RX, A0, B0, C0);
         sobel_plane(sv + (1 * RY + ty) * RX + tx, RX, A1, B1, C1);
@@ -337,13 +368,20 @@ __global__ __launch_bounds__(256) void sobel_mag_tiled_kernel(const float* __res
     float sq = 0.f;
     const int x = x0 + tx, y = y0 + ty;
     if (x < Wx && y < Hy) {
+        float er[TZ];
+#pragma unroll
+        for (int i = 0; i < TZ; ++i) {
+            const long o = (long)b * V + ((long)min(z0 + i, Lz - 1) * Hy + y) * Wx + x;
+            er[i] = E_ref ? E_ref[o] : 0.f;
+        }
 #pragma unroll
         for (int i = 0; i < TZ; ++i) {
             const int z = z0 + i;
-            if (z >= Lz) break;
-            const long o = (long)b * V + ((long)z * Hy + y) * Wx + x;
-            E[o] = e[i];
-            if (E_ref) { const float d = e[i] - E_ref[o]; sq += d * d; }
+            if (z < Lz) {
+                E[(long)b * V + ((long)z * Hy + y) * Wx + x] = e[i];
+                const float d = e[i] - er[i];
+                sq += d * d;
+            }
         }
     }
     if (E_ref) {
@@ -398,16 +436,41 @@ __global__ __launch_bounds__(256) void loss_bwd_fused_kernel(const float* __rest
     float o[CH][TZ];
     const int x = x0 + tx, y = y0 + ty;
     const bool live = x < Wx && y < Hy;
-    for (int c = 0; c < CH; ++c) {
+    const int xc = min(x, Wx - 1), yc = min(y, Hy - 1);
+    // reconstruction-term inputs of this thread's TZ voxels: mask flags now, image values per channel (below)
+    float mk[TZ], im[TZ];
+#pragma unroll
+    for (int tz = 0; tz < TZ; ++tz) {
+        const int z = min(z0 + tz, Lz - 1);
+        const int l = ((z / g.p) * g.g1 + yc / g.p) * g.g2 + xc / g.p;
+        mk[tz] = mask[(long)b * g.L + l];
+    }
+    constexpr int NLD = (VZ * VY * VX + 255) / 256;
+    float pre[NLD];
+    auto fetch = [&](int c) {
         const float* src = pvol + ((long)b * g.C + c) * V;
-        __syncthreads();
-        for (int idx = threadIdx.x; idx < VZ * VY * VX; idx += 256) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int idx = threadIdx.x + k * 256;
             const int xx = idx % VX, r = idx / VX, yy = r % VY, zz = r / VY;
             const int gx = x0 - 2 + xx, gy = y0 - 2 + yy, gz = z0 - 2 + zz;
-            const bool in = gx >= 0 && gx < Wx && gy >= 0 && gy < Hy && gz >= 0 && gz < Lz;
-            sv[idx] = in ? src[((long)gz * Hy + gy) * Wx + gx] : 0.f;
+            const bool in = idx < VZ * VY * VX && gx >= 0 && gx < Wx && gy >= 0 && gy < Hy && gz >= 0 && gz < Lz;
+            pre[k] = in ? src[((long)gz * Hy + gy) * Wx + gx] : 0.f;
+        }
+    };
+    fetch(0);
+    for (int c = 0; c < CH; ++c) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int idx = threadIdx.x + k * 256;
+            if (idx < VZ * VY * VX) sv[idx] = pre[k];
         }
         __syncthreads();
+        if (c + 1 < CH) fetch(c + 1);    // next channel's tile flies underneath this channel's stencils
+#pragma unroll
+        for (int tz = 0; tz < TZ; ++tz)
+            im[tz] = imgs[((long)b * g.C + c) * V + ((long)min(z0 + tz, Lz - 1) * Hy + yc) * Wx + xc];
         // ---- dG on the halo-1 region, one (y, x) column per thread (and a second one for the first threads)
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
@@ -452,15 +515,9 @@ __global__ __launch_bounds__(256) void loss_bwd_fused_kernel(const float* __rest
 #pragma unroll
         for (int gz = 2; gz < GZ; ++gz) {
             plane(gz, Q2, P2);
-            const int tz = gz - 2, z = z0 + tz;
+            const int tz = gz - 2;
             float val = (Q0 + 2.f * Q1 + Q2) + (P0 - P2);
-            if (live && z < Lz) {
-                const int l = ((z / g.p) * g.g1 + y / g.p) * g.g2 + x / g.p;
-                if (mask[(long)b * g.L + l] != 0.f) {
-                    const float pv = sv[((tz + 2) * VY + ty + 2) * VX + tx + 2];
-                    val = cr * (pv - imgs[((long)b * g.C + c) * V + ((long)z * Hy + y) * Wx + x]) + val;
-                }
-            }
+            if (mk[tz] != 0.f) val = cr * (sv[((tz + 2) * VY + ty + 2) * VX + tx + 2] - im[tz]) + val;
             o[c][tz] = val;
             Q0 = Q1; P0 = P1; Q1 = Q2; P1 = P2;
         }
@@ -606,7 +663,8 @@ extern "C" int vitae_gauss_blur_fwd(const float* vol, float* tmp, float* out, co
     if (ntaps == 11 && Wx <= 384 && (long)Lz * BC <= 65535) {
         constexpr int RAD = 5, ROWS = 32, ZC = 32;
         const int TY = ROWS - 2 * RAD;
-        const size_t lds = (size_t)ROWS * (2 * Wx + 2 * RAD) * sizeof(float);
+        const int Wp = (Wx + 3) / 4 * 4;
+        const size_t lds = (size_t)ROWS * (2 * Wp + 2 * RAD + 2) * sizeof(float);
         hipLaunchKernelGGL(blur_xy_kernel<RAD>, dim3(cdiv(Hy, TY), Lz * BC), dim3(256), lds, st, vol, tmp, Hy, Wx, TY, t);
         const long plane = (long)Hy * Wx;
         hipLaunchKernelGGL((blur_z_kernel<RAD, ZC>), dim3(cdiv(plane, 256), cdiv(Lz, ZC), BC), dim3(256), 0, st, tmp, out, Lz,

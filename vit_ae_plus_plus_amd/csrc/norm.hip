@@ -116,6 +116,78 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
 }
 
+// D <= 768 (every model of the reference): each wave owns RPW consecutive rows whose loads are all issued up front;
+// column partials accumulate in registers over the wave's rows and meet the other waves' in LDS in a single round
+// (7.6 us vs 10.8 us for the generic kernel at [440, 768], 8.8 vs 13.2 at [868, 512]).
+template <int RPW>
+__global__ __launch_bounds__(256) void layernorm_bwd_rows_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                 const float* __restrict__ w, const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd, float* __restrict__ dx,
+                                                                 float* __restrict__ dw, float* __restrict__ db,
+                                                                 __bf16* __restrict__ dx16, float* __restrict__ dx_colsum,
+                                                                 int M, int D, int dx_accumulate) {
+    extern __shared__ float red[];   // [3][4][D]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row0 = (blockIdx.x * 4 + wave) * RPW;
+    constexpr int NL = 12;           // D <= 768 in this variant
+    float dv[RPW][NL], xv[RPW][NL], ov[RPW][NL], mu[RPW], rs[RPW], wv[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) { const int c = lane + 64 * i; wv[i] = c < D ? w[c] : 0.f; }
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int row = min(row0 + r, M - 1);
+        mu[r] = mean[row]; rs[r] = rstd[row];
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int c = lane + 64 * i;
+            const bool ok = c < D;
+            dv[r][i] = ok ? dy[(long)row * D + c] : 0.f;
+            xv[r][i] = ok ? x[(long)row * D + c] : 0.f;
+            ov[r][i] = (ok && dx_accumulate) ? dx[(long)row * D + c] : 0.f;
+        }
+    }
+    float pw[NL], pb[NL], pc[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) { pw[i] = 0.f; pb[i] = 0.f; pc[i] = 0.f; }
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int row = row0 + r;
+        if (row >= M) break;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int c = lane + 64 * i;
+            const float xh = c < D ? (xv[r][i] - mu[r]) * rs[r] : 0.f;
+            const float g = dv[r][i] * wv[i];
+            pw[i] += dv[r][i] * xh; pb[i] += dv[r][i];
+            s1 += g; s2 += g * xh;
+            xv[r][i] = xh; dv[r][i] = g;
+        }
+        s1 = wave_sum(s1) / D; s2 = wave_sum(s2) / D;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int c = lane + 64 * i;
+            if (c < D) {
+                const float o = rs[r] * (dv[r][i] - s1 - xv[r][i] * s2) + ov[r][i];
+                dx[(long)row * D + c] = o;
+                if (dx16) dx16[(long)row * D + c] = (__bf16)o;
+                pc[i] += o;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const int c = lane + 64 * i;
+        if (c < D) { red[(0 * 4 + wave) * D + c] = pw[i]; red[(1 * 4 + wave) * D + c] = pb[i]; red[(2 * 4 + wave) * D + c] = pc[i]; }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+        atomicAdd(dw + c, red[0 * D + c] + red[1 * D + c] + red[2 * D + c] + red[3 * D + c]);
+        atomicAdd(db + c, red[4 * D + c] + red[5 * D + c] + red[6 * D + c] + red[7 * D + c]);
+        if (dx_colsum) atomicAdd(dx_colsum + c, red[8 * D + c] + red[9 * D + c] + red[10 * D + c] + red[11 * D + c]);
+    }
+}
+
 // ------------------------------------------------------------------ column sum (bias gradients)
 // out[n] += sum_m dy[m, n].  Threads own columns (coalesced rows), blocks own row slabs.
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dy, long ld, float* __restrict__ out,
@@ -221,6 +293,12 @@ extern "C" int vitae_layernorm_bwd(const float* dy, const float* x, const float*
                                    float* dx_colsum_accum, int M, int D, int dx_accumulate, void* stream) {
     if (!dy || !x || !w || !mean || !rstd || !dx || !dw || !db || M <= 0 || D <= 0) return VITAE_ERR_INVALID_ARG;
     if (D > 64 * LN_MAX_PER_LANE) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    if (D <= 768) {
+        hipLaunchKernelGGL(layernorm_bwd_rows_kernel<2>, dim3(cdiv(M, 8)), dim3(256), (size_t)12 * D * sizeof(float),
+                           (hipStream_t)stream, dy, x, w, mean, rstd, dx, dw, db, reinterpret_cast<__bf16*>(dx_bf16),
+                           dx_colsum_accum, M, D, dx_accumulate);
+        return vitae_launch_status();
+    }
     int blocks = cdiv(M, 4);
     if (blocks > 256) blocks = 256;   // one row per wave up to 1024 rows (row work dominates; capping at 48 blocks doubled the time)
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, w, mean, rstd,

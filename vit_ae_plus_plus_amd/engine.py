@@ -134,6 +134,7 @@ class HipMAEEngine:
         self.taps = gaussian_taps_host(2.0)
         self._taps_c = self.taps.ctypes.data
         self.ws = torch.empty(1 << 24, **f32)   # split-K scratch (64 MiB)
+        self.ws16 = torch.zeros(1 << 23, **f32)  # LDS-DMA GEMMs: tile tickets (kept zero by the kernels) + partial tiles
         self.B = None
         self.buf: Dict[str, torch.Tensor] = {}
         self.opt_state = None
@@ -418,20 +419,27 @@ class HipMAEEngine:
         s = self._split_cache.get(key)
         if s is None:
             s = 1 if epi == EPI_GELU else lib.vitae_gemm_glds_pick_split_k(M, N, K)
-            while s > 1 and s * M * N > self.ws.numel():
+            while s > 1 and lib.vitae_gemm_glds_ws_floats(M, N, s) > self.ws16.numel():
                 s -= 1
             self._split_cache[key] = s
         t = self._timed(2.0 * M * N * K)
         lib.vitae_gemm_glds(1, 1, _ptr(x16), K, self._w16(w), K, _ptr(y), N, _ptr(y16), N, M, N, K, _ptr(bias), _ptr(res), N,
-                            epi, _ptr(aux), N, 0, s, self.ws.data_ptr(), None, self.stream)
+                            epi, _ptr(aux), N, 0, s, self.ws16.data_ptr(), None, self.stream)
         if t is not None:
             t.record()
 
     def _g16_bwd(self, dy16, w, x16, dw, M, Mpad, N, K, dx=None, dx16=None, epi=EPI_NONE, aux=None, dx_colsum=None):
         """dx / dx16 = epi(dy16 @ W16), dW (+)= dy16^T @ x16 in one paired launch."""
+        key = ('p', M, N, K)
+        s = self._split_cache.get(key)
+        if s is None:
+            s = lib.vitae_linear_bwd_pair_pick_split_k(M, Mpad, N, K)
+            while s > 1 and lib.vitae_gemm_glds_ws_floats(M, K, s) > self.ws16.numel():
+                s -= 1
+            self._split_cache[key] = s
         t = self._timed(4.0 * M * N * K)
         lib.vitae_linear_bwd_pair_glds(_ptr(dy16), self._w16(w), _ptr(x16), _ptr(dx), _ptr(dx16), _ptr(dw), M, Mpad, N, K,
-                                       epi, _ptr(aux), _ptr(dx_colsum), int(self._accum), self.stream)
+                                       epi, _ptr(aux), _ptr(dx_colsum), int(self._accum), s, self.ws16.data_ptr(), self.stream)
         if t is not None:
             t.record()
 
