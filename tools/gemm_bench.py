@@ -72,10 +72,17 @@ def run_glds(name, form, M, N, K, iters=50, check=True):
     lda = Kp if akc else M
     ldb = Kp if bkc else N
     split = lib.vitae_gemm_glds_pick_split_k(M, N, Kp)
+    RES = 'resid' in sys.argv
+    bias = torch.randn(N, device=dev)
+    As = [A16] + [A16.clone() for _ in range(len(Bs) - 1)] if RES else [A16]
+    Rs = [torch.randn(M, N, device=dev) for _ in range(len(Bs))] if RES else [None]
+    Cs = [torch.empty(M, N, device=dev) for _ in range(len(Bs))] if RES else [C]
     def go():
         cnt[0] += 1
         B16 = Bs[cnt[0] % len(Bs)]
-        lib.vitae_gemm_glds(akc, bkc, A16.data_ptr(), lda, B16.data_ptr(), ldb, C.data_ptr(), N, None, 0, M, N, Kp, None, None, 0, 0,
+        i = cnt[0] % len(As)
+        lib.vitae_gemm_glds(akc, bkc, As[i].data_ptr(), lda, B16.data_ptr(), ldb, Cs[i % len(Cs)].data_ptr(), N, None, 0, M, N, Kp,
+                            bias.data_ptr() if RES else None, Rs[i % len(Rs)].data_ptr() if RES else None, N, 0,
                             None, 0, 0, split, ws.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
     for _ in range(5): go()
     torch.cuda.synchronize()

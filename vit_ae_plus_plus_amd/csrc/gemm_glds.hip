@@ -44,27 +44,57 @@ struct GArgs {
     int tiles_m, tiles_n;
 };
 
-__device__ __forceinline__ float epilogue_store(const GArgs& p, float v, int m, int n) {
-    if (p.bias) v += p.bias[n];
-    if (p.epi == VITAE_EPI_GELU) {
-        p.aux[(long)m * p.ldaux + n] = v;
-        v = gelu_erf(v);
-    } else if (p.epi == VITAE_EPI_DGELU) {
-        v *= gelu_erf_grad(p.aux[(long)m * p.ldaux + n]);
-    } else if (p.epi == VITAE_EPI_RELU_MASK) {
-        v = p.aux[(long)m * p.ldaux + n] > 0.f ? v : 0.f;
-    }
-    if (p.residual) v += p.residual[(long)m * p.ldr + n];
-    if (p.C) {
-        float* c = p.C + (long)m * p.ldc + n;
-        if (p.accumulate) v += *c;
-        *c = v;
-    }
-    if (p.C16) p.C16[(long)m * p.ldc16 + n] = (__bf16)v;
-    return v;
-}
-
 __device__ __forceinline__ int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// Epilogue of one 32x32 accumulator fragment: column n, rows mbase + crow(r, hi).  All the reads the epilogue
+// needs (aux / residual / old C) are issued first, from clamped addresses, so their latencies overlap — one
+// dependent load -> store per element made the residual GEMMs 2x slower than the bare product.
+// Returns the column sum of the stored values.
+__device__ __forceinline__ float epilogue_frag(const GArgs& p, float (&v)[16], int mbase, int n, int hi) {
+    const int nc = min(n, p.N - 1);
+    int mrow[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mrow[r] = min(mbase + crow(r, hi), p.M - 1);
+    float ax[16], rs[16], co[16];
+    const bool need_aux = p.epi == VITAE_EPI_DGELU || p.epi == VITAE_EPI_RELU_MASK;
+    if (need_aux) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ax[r] = p.aux[(long)mrow[r] * p.ldaux + nc];
+    }
+    if (p.residual) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rs[r] = p.residual[(long)mrow[r] * p.ldr + nc];
+    }
+    if (p.C && p.accumulate) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) co[r] = p.C[(long)mrow[r] * p.ldc + nc];
+    }
+    const float bias = p.bias ? p.bias[nc] : 0.f;
+    float csum = 0.f;
+    const bool ncol = n < p.N;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = mbase + crow(r, hi);
+        if (!(ncol && m < p.M)) continue;
+        float x = v[r] + bias;
+        if (p.epi == VITAE_EPI_GELU) {
+            p.aux[(long)m * p.ldaux + n] = x;
+            x = gelu_erf(x);
+        } else if (p.epi == VITAE_EPI_DGELU) {
+            x *= gelu_erf_grad(ax[r]);
+        } else if (p.epi == VITAE_EPI_RELU_MASK) {
+            x = ax[r] > 0.f ? x : 0.f;
+        }
+        if (p.residual) x += rs[r];
+        if (p.C) {
+            if (p.accumulate) x += co[r];
+            p.C[(long)m * p.ldc + n] = x;
+        }
+        if (p.C16) p.C16[(long)m * p.ldc16 + n] = (__bf16)x;
+        csum += x;
+    }
+    return csum;
+}
 
 // Issue the LDS-DMA of one operand tile (ROWS rows x 64 k, bf16) into `lds` (byte address, tile base).
 // KC tile image: [row][8 chunks]; !KC image: [k][ROWS/8 chunks]; chunk slot = chunk ^ (line & 7).
@@ -225,12 +255,7 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
 #pragma unroll
     for (int f = 0; f < FN; ++f) {
         const int n = n0 + wn * (BN / 2) + f * 32 + l31;
-        float csum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * 32 + crow(r, hi);
-            if (n < p.N && m < p.M) csum += epilogue_store(p, a[f][r], m, n);
-        }
+        float csum = epilogue_frag(p, a[f], m0 + wm * 32, n, hi);
         if (p.out_colsum) {
             csum += __shfl_xor(csum, 32, 64);
             if (hi == 0 && n < p.N) atomicAdd(p.out_colsum + n, csum);
@@ -272,11 +297,13 @@ inline int pick_bn(int M, int N) {
 }  // namespace
 
 extern "C" int vitae_gemm_glds_pick_split_k(int M, int N, int K) {
+    static const int min_kt = getenv("VITAE_GLDS_SPLIT_MIN_KT") ? atoi(getenv("VITAE_GLDS_SPLIT_MIN_KT")) : 8;
+    static const int target = getenv("VITAE_GLDS_SPLIT_BLOCKS") ? atoi(getenv("VITAE_GLDS_SPLIT_BLOCKS")) : 384;
     const int bn = pick_bn(M, N);
     const long tiles = (long)cdiv(M, BM) * cdiv(N, bn);
-    if (tiles >= 192 || K < 1024) return 1;
-    long s = (384 + tiles - 1) / tiles;
-    const long max_by_k = K / 512;   // >= 8 k-tiles per split
+    if (tiles >= target / 2 || tiles > VITAE_GLDS_TICKETS) return 1;
+    long s = (target + tiles - 1) / tiles;
+    const long max_by_k = K / (BK * min_kt);   // >= min_kt k-tiles per split
     if (s > max_by_k) s = max_by_k;
     if (s > 32) s = 32;
     return s < 1 ? 1 : (int)s;
