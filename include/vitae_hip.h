@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITAE_ABI_VERSION 10
+#define VITAE_ABI_VERSION 11
 
 /* matrix-core arithmetic of the dense contractions */
 #define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
@@ -147,7 +147,8 @@ int vitae_sdpa_bwd(const float* qkv, const float* o, const float* d_o, const flo
 int vitae_sdpa_mfma_fwd(const float* qkv, float* o, void* o_bf16, float* lse, int B, int N, int H, int head_dim,
                         void* stream);
 int vitae_sdpa_mfma_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv,
-                        void* dqkv_bf16, float* delta_ws, int B, int N, int H, int head_dim, void* stream);
+                        void* dqkv_bf16, float* dqkv_colsum_accum /* [3*H*hd] += column sums of dqkv, or NULL */,
+                        float* delta_ws, int B, int N, int H, int head_dim, void* stream);
 
 /* ---- masking and sequence assembly ---------------------------------------------------------------
  * random_masking (model/vit_autoenc.py:141-153) from a caller-supplied noise[B,L] (the torch.rand of

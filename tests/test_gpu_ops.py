@@ -319,9 +319,11 @@ def test_sdpa_mfma_bf16(lib, B, N, H, hd):
     assert float((lse.cpu().reshape(B, H, N) - ref_lse).abs().max()) < 3e-2
     dqkv, delta = torch.full((B, N, 3 * D), float('nan'), device='cuda'), torch.empty(B * H * N, device='cuda')
     g16 = torch.empty(B, N, 3 * D, dtype=torch.bfloat16, device='cuda')
+    cs = torch.zeros(3 * D, device='cuda')
     lib.vitae_sdpa_mfma_bwd(qd.data_ptr(), o.data_ptr(), dod.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), g16.data_ptr(),
-                            delta.data_ptr(), B, N, H, hd, st())
+                            cs.data_ptr(), delta.data_ptr(), B, N, H, hd, st())
     assert torch.equal(g16, dqkv.to(torch.bfloat16))
+    assert rel_err(cs, dqkv.reshape(-1, 3 * D).sum(0)) < 1e-5
     g = qr.grad.reshape(B, N, 3, D)
     got = dqkv.cpu().reshape(B, N, 3, D)
     for i, name in enumerate('qkv'):

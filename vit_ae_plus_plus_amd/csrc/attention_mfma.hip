@@ -84,6 +84,35 @@ __device__ __forceinline__ f32x16 zero16() {
     return z;
 }
 
+// Column sums of a lane-per-row fragment set (the qkv bias gradient, fused into the kernels that produce dqkv):
+// v[i] of the 32 lanes sharing `hi` are added by a butterfly over lane bits 0..4, the four waves' totals meet in
+// LDS (`red`, 4 * 16 * NT * 2 floats), and one thread per column issues a single atomicAdd.
+// Every wave of the block must call this (it contains a barrier).
+template <int NV>
+__device__ __forceinline__ void colsum_to(float (&v)[NV], bool valid, float* __restrict__ out, float* red, int hi, int l31,
+                                          int wave) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float x = valid ? v[i] : 0.f;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+        v[i] = x;
+    }
+    __syncthreads();
+    if (l31 == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int nt = i / 16, r = i % 16;
+            red[wave * (2 * NV) + 32 * nt + 8 * (r >> 2) + 4 * hi + (r & 3)] = v[i];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * NV) {
+        const int c = threadIdx.x;
+        atomicAdd(out + c, red[c] + red[2 * NV + c] + red[4 * NV + c] + red[6 * NV + c]);
+    }
+}
+
 // ------------------------------------------------------------------------------- forward
 template <int HD>
 __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ o,
@@ -176,7 +205,8 @@ template <int HD>
 __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
                                                                const float* __restrict__ d_o, const float* __restrict__ lse,
                                                                float* __restrict__ dqkv, __bf16* __restrict__ dqkv16,
-                                                               float* __restrict__ delta, int N, int H, float scale) {
+                                                               float* __restrict__ dbias, float* __restrict__ delta, int N,
+                                                               int H, float scale) {
     constexpr int LD = HD + 8, NKK = HD / 16, NT = HD / 32;
     __shared__ __attribute__((aligned(16))) __bf16 Ks[CH * LD];
     __shared__ __attribute__((aligned(16))) __bf16 Vs[CH * LD];
@@ -243,6 +273,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const float* __re
                 }
         }
     }
+    if (dbias) {
+        float cs[16 * NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cs[16 * nt + r] = acc[nt][r] * scale;
+        colsum_to<16 * NT>(cs, wave_live && qvalid, dbias + h * HD, reinterpret_cast<float*>(Ks), hi, l31, wave);
+    }
     if (!wave_live || !qvalid) return;
     float* out = dqkv + ((long)b * N + qrow) * ld + h * HD;
 #pragma unroll
@@ -266,7 +304,7 @@ template <int HD>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ d_o,
                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
                                                                 float* __restrict__ dqkv, __bf16* __restrict__ dqkv16,
-                                                                int N, int H, float scale) {
+                                                                float* __restrict__ dbias, int N, int H, float scale) {
     constexpr int LD = HD + 8, NKK = HD / 16, NT = HD / 32;
     __shared__ __attribute__((aligned(16))) __bf16 Qs[CH * LD];
     __shared__ __attribute__((aligned(16))) __bf16 Gs[CH * LD];
@@ -338,6 +376,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const float* __r
                 }
         }
     }
+    if (dbias) {
+        float ck[16 * NT], cv[16 * NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { ck[16 * nt + r] = dk[nt][r] * LN2; cv[16 * nt + r] = dv[nt][r]; }
+        colsum_to<16 * NT>(ck, wave_live && kvalid, dbias + D + h * HD, reinterpret_cast<float*>(Qs), hi, l31, wave);
+        colsum_to<16 * NT>(cv, wave_live && kvalid, dbias + 2 * D + h * HD, reinterpret_cast<float*>(Gs), hi, l31, wave);
+    }
     if (!wave_live || !kvalid) return;
     float* out = dqkv + ((long)b * N + krow) * ld + h * HD;
 #pragma unroll
@@ -379,7 +426,8 @@ extern "C" int vitae_sdpa_mfma_fwd(const float* qkv, float* o, void* o_bf16, flo
 }
 
 extern "C" int vitae_sdpa_mfma_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv,
-                                   void* dqkv_bf16, float* delta_ws, int B, int N, int H, int head_dim, void* stream) {
+                                   void* dqkv_bf16, float* dqkv_colsum_accum, float* delta_ws, int B, int N, int H,
+                                   int head_dim, void* stream) {
     if (!qkv || !o || !d_o || !lse || !dqkv || !delta_ws || B <= 0 || N <= 0 || H <= 0) return VITAE_ERR_INVALID_ARG;
     if ((((long)H * head_dim) & 3) || ((uintptr_t)qkv & 15) || ((uintptr_t)o & 15) || ((uintptr_t)d_o & 15) ||
         ((uintptr_t)dqkv & 15))
@@ -389,11 +437,11 @@ extern "C" int vitae_sdpa_mfma_bwd(const float* qkv, const float* o, const float
     hipStream_t st = (hipStream_t)stream;
     __bf16* g16 = reinterpret_cast<__bf16*>(dqkv_bf16);
     if (head_dim == 32) {
-        hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<32>), grid, dim3(256), 0, st, qkv, o, d_o, lse, dqkv, g16, delta_ws, N, H, scale);
-        hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<32>), grid, dim3(256), 0, st, qkv, d_o, lse, delta_ws, dqkv, g16, N, H, scale);
+        hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<32>), grid, dim3(256), 0, st, qkv, o, d_o, lse, dqkv, g16, dqkv_colsum_accum, delta_ws, N, H, scale);
+        hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<32>), grid, dim3(256), 0, st, qkv, d_o, lse, delta_ws, dqkv, g16, dqkv_colsum_accum, N, H, scale);
     } else if (head_dim == 64) {
-        hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<64>), grid, dim3(256), 0, st, qkv, o, d_o, lse, dqkv, g16, delta_ws, N, H, scale);
-        hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<64>), grid, dim3(256), 0, st, qkv, d_o, lse, delta_ws, dqkv, g16, N, H, scale);
+        hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<64>), grid, dim3(256), 0, st, qkv, o, d_o, lse, dqkv, g16, dqkv_colsum_accum, delta_ws, N, H, scale);
+        hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<64>), grid, dim3(256), 0, st, qkv, d_o, lse, delta_ws, dqkv, g16, dqkv_colsum_accum, N, H, scale);
     } else {
         return VITAE_ERR_UNSUPPORTED_SHAPE;
     }

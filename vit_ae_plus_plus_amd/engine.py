@@ -471,8 +471,7 @@ class HipMAEEngine:
                      dx_colsum=g[pre + 'attn.proj.bias'])
         self._g16_bwd(dx16, p[pre + 'attn.proj.weight'], b[q + 'o_16'], g[pre + 'attn.proj.weight'], M, Mp, d, d, dx=do)
         lib.vitae_sdpa_mfma_bwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(do), _ptr(b[q + 'lse']), _ptr(dqkv), _ptr(dqkv16),
-                                _ptr(b['delta']), Bs, N, heads, hd, self.stream)
-        lib.vitae_colsum_accum(_ptr(dqkv), 3 * d, _ptr(g[pre + 'attn.qkv.bias']), M, 3 * d, self.stream)
+                                _ptr(g[pre + 'attn.qkv.bias']), _ptr(b['delta']), Bs, N, heads, hd, self.stream)
         self._g16_bwd(dqkv16, p[pre + 'attn.qkv.weight'], b[q + 'y1_16'], g[pre + 'attn.qkv.weight'], M, Mp, 3 * d, d, dx=dy)
         self._ln_bwd(dy, x_in, pre + 'norm1.', b[q + 'mean1'], b[q + 'rstd1'], dx, M, d, 1, dx16=dx16,
                      dx_colsum=prev_fc2_bias)
@@ -513,7 +512,7 @@ class HipMAEEngine:
                       M, d, d, tag=s + 'dx')
         self._wg_fence(s + 'dqkv')                     # previous block's qkv wgrad may still read dqkv
         if self.prec == PREC['bf16'] and hd in (32, 64):
-            lib.vitae_sdpa_mfma_bwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(do), _ptr(b[q + 'lse']), _ptr(dqkv), None,
+            lib.vitae_sdpa_mfma_bwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(do), _ptr(b[q + 'lse']), _ptr(dqkv), None, None,
                                     _ptr(b['delta']), Bs, N, heads, hd, self.stream)
         else:
             lib.vitae_sdpa_bwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(do), _ptr(b[q + 'lse']), _ptr(dqkv),
