@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITAE_ABI_VERSION 11
+#define VITAE_ABI_VERSION 12
 
 /* matrix-core arithmetic of the dense contractions */
 #define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
@@ -165,6 +165,9 @@ int vitae_encoder_assemble_fwd(const float* tok, const float* cls_token, const f
                                const int* ids_shuffle, float* x, int B, int L, int keep, int D, void* stream);
 int vitae_encoder_assemble_bwd(const float* dx, float* dtok, void* dtok_bf16, float* dcls_accum, int B, int keep, int D,
                                void* stream);
+/* out[B,D] = mean_{n >= first} x[B,N,D]: global average pool over the patch tokens of the encoder-only model
+ * (model/vit.py:277-278, first = 1 skips the cls token) */
+int vitae_mean_pool_tokens(const float* x, float* out, int B, int N, int D, int first, void* stream);
 /* xd[B,L+1,Dd]: mask-token fill + unshuffle + decoder_pos_embed (model/vit_autoenc.py:184-190) */
 int vitae_decoder_assemble_fwd(const float* e, const float* mask_token, const float* dpos, const int* ids_restore,
                                float* xd, int B, int L, int keep, int Dd, void* stream);

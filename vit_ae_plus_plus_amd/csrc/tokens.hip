@@ -153,6 +153,23 @@ __global__ __launch_bounds__(256) void mask_token_grad_kernel(const float* __res
     atomicAdd(dmask + d, s);
 }
 
+// out[b, d] = mean over tokens n = first .. N-1 of x[b, n, d]  (global pool without the cls token,
+// reference model/vit.py:277-278).  One thread per (b, d); rows are read coalesced, summed in token order.
+__global__ __launch_bounds__(256) void mean_pool_tokens_kernel(const float* __restrict__ x, float* __restrict__ out, int N,
+                                                               int D, int first) {
+    const int d = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (d >= D) return;
+    const float* xb = x + ((long)b * N + first) * D + d;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const int cnt = N - first;
+    int n = 0;
+    for (; n + 4 <= cnt; n += 4) {
+        s0 += xb[(long)n * D]; s1 += xb[(long)(n + 1) * D]; s2 += xb[(long)(n + 2) * D]; s3 += xb[(long)(n + 3) * D];
+    }
+    for (; n < cnt; ++n) s0 += xb[(long)n * D];
+    out[(long)b * D + d] = ((s0 + s1) + (s2 + s3)) / (float)cnt;
+}
+
 }  // namespace
 
 extern "C" int vitae_random_masking(const float* noise, int* ids_shuffle, int* ids_restore, float* mask,
@@ -213,5 +230,11 @@ extern "C" int vitae_decoder_assemble_bwd(const float* dxd, const int* ids_shuff
         hipLaunchKernelGGL(mask_token_grad_kernel, dim3(cdiv(Dd, 256), cdiv(total, per_block)), dim3(256), 0, st, dxd,
                            ids_shuffle, dmask_token, B, L, keep, Dd, per_block);
     }
+    return vitae_launch_status();
+}
+
+extern "C" int vitae_mean_pool_tokens(const float* x, float* out, int B, int N, int D, int first, void* stream) {
+    if (!x || !out || B <= 0 || D <= 0 || first < 0 || first >= N) return VITAE_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(mean_pool_tokens_kernel, dim3(cdiv(D, 256), B), dim3(256), 0, (hipStream_t)stream, x, out, N, D, first);
     return vitae_launch_status();
 }

@@ -9,6 +9,7 @@ libvitae_hip.so.  Their stand-alone ``forward`` methods run the same HIP kernels
 """
 from __future__ import annotations
 
+import math
 from functools import partial
 
 import torch
@@ -159,15 +160,121 @@ class Block(nn.Module):
         return self.mlp(hip_layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps), residual=x)
 
 
-class VisionTransformer3D(nn.Module):
-    """Down-stream encoder-only ViT (reference model/vit.py:147-298).  Listed under SURVEY §8(f)
-    'next rows' (feature extraction); not part of the round-1 training hot path."""
+def _init_vit_weights(module: nn.Module, name: str = '', head_bias: float = 0.):
+    """The reference's default ('') init scheme (model/vit.py:14-46): Linear weights trunc-normal(std .02) with zero
+    bias, the classifier head zero, LayerNorm (1, 0); convolutions keep PyTorch's default."""
+    if isinstance(module, nn.Linear):
+        if name.startswith('head'):
+            nn.init.zeros_(module.weight)
+            nn.init.constant_(module.bias, head_bias)
+        else:
+            nn.init.trunc_normal_(module.weight, std=.02)
+            if module.bias is not None:
+                nn.init.zeros_(module.bias)
+    elif isinstance(module, (nn.LayerNorm, nn.GroupNorm, nn.BatchNorm2d)):
+        nn.init.zeros_(module.bias)
+        nn.init.ones_(module.weight)
 
-    def __init__(self, *a, **k):
+
+class VisionTransformer3D(nn.Module):
+    """Encoder-only 3-D ViT that consumes the pre-trained weights (reference model/vit.py:147-298): same constructor,
+    state-dict keys and ``forward_features`` / ``forward`` results; the arithmetic runs on the HIP kernels through
+    ``HipEncoder`` (inference: feature extraction, utils/feature_extraction.py).  Not covered: the DeiT distillation
+    token/head, ``representation_size`` pre-logits, non-zero dropout / stochastic depth, and back-propagation
+    (fine-tuning) — the constructor or the call says so instead of computing something else.
+
+    ``precision``: 'fp32' (exact-fp32 MFMA, matches the CPU reference to ~1e-6) or 'bf16' (bf16 MFMA operands with
+    fp32 accumulation — the counterpart of the ``torch.cuda.amp.autocast()`` the reference wraps around
+    forward_features, utils/feature_extraction.py:35-36)."""
+
+    def __init__(self, volume_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12,
+                 num_heads=12, mlp_ratio=4., qkv_bias=True, representation_size=None, distilled=False,
+                 drop_rate=0., attn_drop_rate=0., drop_path_rate=0., embed_layer=PatchEmbed3D, norm_layer=None,
+                 act_layer=None, weight_init='', global_pool=False, precision=None):
         super().__init__()
-        raise NotImplementedError('VisionTransformer3D (feature extraction / fine-tuning) is a §8(f) "next" row; '
-                                  'the MI355X path currently covers MAE pre-training')
+        if distilled or representation_size:
+            raise NotImplementedError('distilled / representation_size variants are not built for MI355X')
+        if act_layer not in (None, nn.GELU):
+            raise NotImplementedError('only the exact-GELU MLP of the reference is built')
+        if weight_init not in ('', 'nlhb'):
+            raise NotImplementedError("only the default ('') and 'nlhb' weight_init schemes are supported")
+        self.num_classes = num_classes
+        self.num_features = self.embed_dim = embed_dim
+        self.num_tokens = 1
+        self.num_heads = num_heads
+        # dropout / stochastic depth are identities in eval mode; kept so the reference's hyper-parameters are accepted
+        self.drop_rate, self.attn_drop_rate, self.drop_path_rate = drop_rate, attn_drop_rate, drop_path_rate
+        norm_layer = norm_layer or partial(nn.LayerNorm, eps=1e-6)
+        self.patch_embed = embed_layer(volume_size=volume_size, patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim)
+        num_patches = self.patch_embed.num_patches
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.dist_token = None
+        self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + self.num_tokens, embed_dim))
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        self.blocks = nn.Sequential(*[
+            Block(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, drop=drop_rate,
+                  attn_drop=attn_drop_rate, norm_layer=norm_layer) for _ in range(depth)])
+        self.norm = norm_layer(embed_dim)
+        self.ln_eps = self.norm.eps
+        self.pre_logits = nn.Identity()
+        self.head = nn.Linear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()
+        self.head_dist = None
+        self.global_pool = global_pool
+        if self.global_pool:
+            self.fc_norm = norm_layer(embed_dim)
+            del self.norm  # as the reference: fc_norm replaces norm (model/vit.py:218-221)
+        self._precision = precision or 'fp32'
+        self._encoder = None
+        self.init_weights(weight_init)
+
+    def init_weights(self, mode=''):
+        head_bias = -math.log(self.num_classes) if 'nlhb' in mode else 0.
+        nn.init.trunc_normal_(self.pos_embed, std=.02)
+        nn.init.trunc_normal_(self.cls_token, std=.02)
+        for name, mod in self.named_modules():
+            _init_vit_weights(mod, name, head_bias)
+
+    def _init_weights(self, m):
+        _init_vit_weights(m)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {'pos_embed', 'cls_token', 'dist_token'}
+
+    def get_classifier(self):
+        return self.head
+
+    def reset_classifier(self, num_classes, global_pool=''):
+        self.num_classes = num_classes
+        self.head = nn.Linear(self.embed_dim, num_classes) if num_classes > 0 else nn.Identity()
+
+    def set_precision(self, precision: str):
+        self._precision = precision
+        self._encoder = None
+
+    def forward_features(self, x):
+        """[B, C, Lz, Hy, Wx] -> [B, embed_dim] (reference model/vit.py:265-284)."""
+        if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
+            raise VitaeError('VisionTransformer3D on MI355X is inference-only (feature extraction); call it under '
+                             'torch.no_grad() / model.eval() — fine-tuning is not built yet')
+        if (self.training and (self.drop_rate or self.attn_drop_rate or self.drop_path_rate)):
+            raise VitaeError('dropout / stochastic depth are not implemented; use model.eval()')
+        if self._encoder is None:
+            from ..encoder import HipEncoder
+            self._encoder = HipEncoder(self, self._precision)
+        return self._encoder.forward_features(x)
+
+    def forward(self, x):
+        f = self.forward_features(x)
+        if isinstance(self.head, nn.Identity):
+            return f
+        return hip_linear(f, self.head.weight, self.head.bias)
 
 
 class VisionTransformer3DContrastive(VisionTransformer3D):
-    pass
+    """Reference model/vit.py:300-340 (SimSiam fine-tuning variant): a training-only model, not part of the
+    feature-extraction row; constructing it says so."""
+
+    def __init__(self, *a, **k):
+        raise NotImplementedError('VisionTransformer3DContrastive is a training-only down-stream model; the MI355X path '
+                                  'covers MAE pre-training and encoder-only feature extraction')
