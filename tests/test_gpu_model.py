@@ -224,3 +224,73 @@ def test_three_steps_track_oracle_training():
         upd_ref = (ref_sd[k] - sd[k]).double()
         err = float((v.cpu().double() - ref_sd[k].double()).norm() / (upd_ref.norm() + 1e-12))
         assert err < (0.6 if k.endswith('qkv.bias') else 0.05), (k, err)
+
+
+def _ref_adamw(params, lr, wd):
+    groups = R.param_groups(params, wd)
+    return torch.optim.AdamW([{'params': [params[n] for n in g['names']], 'weight_decay': g['weight_decay']}
+                              for g in groups], lr=lr, betas=(0.9, 0.95))
+
+
+def test_checkpoint_wire_format_both_ways(tmp_path):
+    """SURVEY §8(f) row 2 (utils/misc.py:295-329): a checkpoint written the way the reference writes it
+    ({'model','optimizer','epoch','scaler','args'}, torch.optim.AdamW state layout) resumes on the HIP path, and a
+    checkpoint written by the HIP path resumes in a plain torch.optim.AdamW — the next step agrees either way."""
+    from vit_ae_plus_plus_amd.utils import misc
+    from vit_ae_plus_plus_amd.utils.train_one_epoch import train_one_stage_epoch
+    cfg = R.RefConfig(contrastive=True, **MICRO)
+    sd0 = R.init_state_dict(cfg, seed=3)
+    lr, wd, B = 1e-3, 0.05, 2
+
+    def batch(i):
+        v1, v2 = R.synthetic_views((B, cfg.in_chans, *cfg.volume_size), seed=300 + i)
+        return v1, v2, R.masking_noise(B, cfg.num_patches, seed=400 + i)
+
+    def hip_epoch(model, opt, i):
+        v1, v2, noises = batch(i)
+        model.set_masking_noise(*noises)
+        args = argparse.Namespace(accum_iter=1, mask_ratio=0.75, contr_weight=0.001, lr=lr, min_lr=0.0, warmup_epochs=0,
+                                  epochs=50, hip_graph=False, no_fused_step=False)
+        return train_one_stage_epoch(model, [(v1, v2, torch.zeros(B))], opt, torch.device('cuda'), 0,
+                                     misc.NativeScalerWithGradNormCount(), log_writer=None, args=args, edge_map_weight=0.01)
+
+    # ---- reference-format checkpoint (CPU torch.optim.AdamW after one step) -> HIP path
+    tr = T.RefTrainer(cfg, sd0, lr=lr, weight_decay=wd)
+    v1, v2, (n1, n2) = batch(0)
+    tr.step(v1, v2, n1, n2, lr=lr, edge_map_weight=0.01, contr_weight=0.001)
+    ref_ck = tmp_path / 'checkpoint-0.pth'
+    torch.save({'model': tr.state_dict(), 'optimizer': tr.optimizer.state_dict(), 'epoch': 0,
+                'scaler': torch.cuda.amp.GradScaler(enabled=False).state_dict(), 'args': argparse.Namespace(lr=lr)}, ref_ck)
+    model = build(cfg, sd0)
+    named = dict(model.named_parameters())
+    opt = _ref_adamw(named, lr, wd)
+    misc.load_model(argparse.Namespace(resume=str(ref_ck)), model, opt, misc.NativeScalerWithGradNormCount())
+    stats = hip_epoch(model, opt, 1)
+    v1, v2, (n1, n2) = batch(1)
+    terms, _, _ = tr.step(v1, v2, n1, n2, lr=lr, edge_map_weight=0.01, contr_weight=0.001)
+    close(stats['loss'], terms['loss'], 2e-4, 1e-7)
+    ref_sd = tr.state_dict()
+    for k in ('decoder_pred.weight', 'blocks.0.mlp.fc1.weight', 'patch_embed.proj.weight', 'predictor.3.weight'):
+        upd = (ref_sd[k] - sd0[k]).double().norm()
+        assert float((model.state_dict()[k].cpu().double() - ref_sd[k].double()).norm() / upd) < 0.05, k
+
+    # ---- HIP-path checkpoint -> file -> fresh HIP model AND plain torch AdamW on the oracle
+    out = tmp_path / 'out'
+    out.mkdir()
+    misc.save_model(argparse.Namespace(output_dir=str(out)), 1, model, model, opt, misc.NativeScalerWithGradNormCount())
+    ck = torch.load(out / 'checkpoint-1.pth', map_location='cpu', weights_only=False)
+    assert set(ck) == {'model', 'optimizer', 'epoch', 'scaler', 'args'}
+    assert set(ck['optimizer']) == {'state', 'param_groups'} and set(ck['optimizer']['state'][0]) == {'step', 'exp_avg', 'exp_avg_sq'}
+    model2 = build(cfg, sd0)
+    opt2 = _ref_adamw(dict(model2.named_parameters()), lr, wd)
+    misc.load_model(argparse.Namespace(resume=str(out / 'checkpoint-1.pth')), model2, opt2, misc.NativeScalerWithGradNormCount())
+    s_a, s_b = hip_epoch(model, opt, 2), hip_epoch(model2, opt2, 2)
+    close(s_a['loss'], s_b['loss'], 1e-6, 1e-9)
+    tr2 = T.RefTrainer(cfg, ck['model'], lr=lr, weight_decay=wd)
+    tr2.optimizer.load_state_dict(ck['optimizer'])
+    v1, v2, (n1, n2) = batch(2)
+    terms2, _, _ = tr2.step(v1, v2, n1, n2, lr=lr, edge_map_weight=0.01, contr_weight=0.001)
+    close(s_a['loss'], terms2['loss'], 2e-4, 1e-7)
+    k = 'decoder_pred.weight'
+    upd = (tr2.state_dict()[k] - ck['model'][k]).double().norm()
+    assert float((model.state_dict()[k].cpu().double() - tr2.state_dict()[k].double()).norm() / upd) < 0.05
