@@ -162,7 +162,7 @@ def main():
     ms = elapsed / args.steps * 1e3
     value = world * args.batch * args.steps / elapsed
 
-    # ---- roofline of the dominant kernel family (the MFMA GEMM kernels of csrc/gemm_bf16.hip / gemm.hip):
+    # ---- roofline of the dominant kernel (the MFMA GEMM kernels of csrc/gemm_glds.hip / gemm_bf16.hip / gemm.hip):
     # instrumented eager steps right after the timed region, HIP events (torch.cuda.Event on the launch
     # stream = torch's current stream) around every GEMM launch.  A spin kernel is queued first so the host
     # enqueues the whole step while the GPU is still busy: event deltas then contain no host-launch gaps.
@@ -184,23 +184,36 @@ def main():
             torch.cuda.synchronize()
             recs += eng.gemm_timer
             eng.gemm_timer = None
-        tot_ms = sum(a.elapsed_time(b) for a, b, _ in recs)
-        tot_fl = sum(f for _, _, f in recs)
-        n_launch = len(recs) / args.profile_steps
-        ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        fam = {}
+        for a, b, f, tag in recs:
+            d = fam.setdefault(tag, [0.0, 0.0, 0])
+            d[0] += a.elapsed_time(b); d[1] += f; d[2] += 1
+        tot_ms = sum(d[0] for d in fam.values())
+        tot_fl = sum(d[1] for d in fam.values())
+        dom = max(fam, key=lambda k: fam[k][0])          # the kernel the step spends most GEMM time in
+        d_ms, d_fl, d_n = fam[dom]
+        ach = d_fl / (d_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.precision]
-        kname = ('gemm_bf16_kernel / gemm_bf16_pair_kernel (csrc/gemm_bf16.hip)' if args.precision == 'bf16'
-                 else 'gemm_kernel<0,..> (csrc/gemm.hip)')
-        traffic = None   # PMC counters cannot be read from inside the process: last committed rocprofv3 --pmc result
+        kname = {'glds_pair': 'gemm_glds_pair_kernel<64,64> (csrc/gemm_glds.hip: dgrad + wgrad of one Linear per launch)',
+                 'glds': 'gemm_glds_kernel<64,..> (csrc/gemm_glds.hip)',
+                 'other': ('gemm_bf16_kernel / gemm_bf16_pair_kernel (csrc/gemm_bf16.hip)' if args.precision == 'bf16'
+                           else 'gemm_kernel<0,..> (csrc/gemm.hip)')}[dom]
+        traffic, tnote = None, None   # PMC counters cannot be read in-process: last committed rocprofv3 --pmc result
         tfile = os.path.join(ROOT, 'profiles', 'round1_gemm_traffic.json')
-        if args.precision == 'bf16' and os.path.exists(tfile):
-            traffic = json.load(open(tfile)).get('avg_bytes_per_gemm_launch')
+        if args.precision == 'bf16' and args.batch == 4 and os.path.exists(tfile):
+            tj = json.load(open(tfile))
+            traffic = tj.get('bytes_per_launch', {}).get(dom)
+            tnote = 'HBM-side bytes per launch of that kernel (2*FETCH_SIZE + WRITE_SIZE, profiles/round1_gemm_traffic.json)'
         roof = {'bound': 'mfma', 'kernel': kname, 'achieved': round(ach, 2),
                 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': traffic,
-                'traffic_unit': 'bytes per GEMM launch (fabric side, profiles/round1_gemm_traffic.json)',
-                'launches_per_step': n_launch, 'gflop_per_step': round(tot_fl / args.profile_steps / 1e9, 2),
-                'avg_launch_us': round(tot_ms * 1e3 / len(recs), 2),
-                'gemm_ms_per_step': round(tot_ms / args.profile_steps, 3),
+                'traffic_unit': tnote,
+                'launches_per_step': d_n / args.profile_steps, 'gflop_per_launch': round(d_fl / d_n / 1e9, 3),
+                'avg_launch_us': round(d_ms * 1e3 / d_n, 2),
+                'gemm_family': {'launches_per_step': len(recs) / args.profile_steps,
+                                'gflop_per_step': round(tot_fl / args.profile_steps / 1e9, 2),
+                                'ms_per_step': round(tot_ms / args.profile_steps, 3),
+                                'tflops': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
+                                'by_kernel_ms_per_step': {k: round(v[0] / args.profile_steps, 3) for k, v in fam.items()}},
                 'step_frac_of_peak': round(world * args.batch * ALGO_GFLOP_PER_VOL[args.model] * 1e9 / (ms * 1e-3) / 1e12 / (peak * world), 4)}
     if world > 1:
         dist.barrier()

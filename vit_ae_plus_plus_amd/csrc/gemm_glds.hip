@@ -46,52 +46,61 @@ struct GArgs {
 
 __device__ __forceinline__ int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
-// Epilogue of one 32x32 accumulator fragment: column n, rows mbase + crow(r, hi).  All the reads the epilogue
-// needs (aux / residual / old C) are issued first, from clamped addresses, so their latencies overlap — one
-// dependent load -> store per element made the residual GEMMs 2x slower than the bare product.
-// Returns the column sum of the stored values.
-__device__ __forceinline__ float epilogue_frag(const GArgs& p, float (&v)[16], int mbase, int n, int hi) {
+// Epilogue of one 32x32 accumulator fragment: column n, rows mbase + crow(r, hi).  The reads the epilogue needs
+// (aux / residual / old C) are issued eight rows at a time, from clamped addresses, BEFORE the dependent stores, so
+// their latencies overlap — one dependent load -> store per element made the residual GEMMs 2x slower than the bare
+// product, while batching all 16 rows x 3 arrays at once cost 150 extra VGPRs (one workgroup per CU for the 64x128
+// tiles).  Returns the column sum of the stored values.
+__device__ __forceinline__ float epilogue_frag(const GArgs& p, const float (&v)[16], int mbase, int n, int hi) {
+    // 32-bit element offsets from the (wave-uniform) base pointers: one VGPR per address instead of a 64-bit pair
+    // per row and array (the launchers reject operands with more than 2^31 elements)
     const int nc = min(n, p.N - 1);
-    int mrow[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) mrow[r] = min(mbase + crow(r, hi), p.M - 1);
-    float ax[16], rs[16], co[16];
+    const int ldaux = (int)p.ldaux, ldr = (int)p.ldr, ldc = (int)p.ldc, ldc16 = (int)p.ldc16;
     const bool need_aux = p.epi == VITAE_EPI_DGELU || p.epi == VITAE_EPI_RELU_MASK;
-    if (need_aux) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ax[r] = p.aux[(long)mrow[r] * p.ldaux + nc];
-    }
-    if (p.residual) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) rs[r] = p.residual[(long)mrow[r] * p.ldr + nc];
-    }
-    if (p.C && p.accumulate) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) co[r] = p.C[(long)mrow[r] * p.ldc + nc];
-    }
+    const bool acc_c = p.C && p.accumulate;
     const float bias = p.bias ? p.bias[nc] : 0.f;
-    float csum = 0.f;
     const bool ncol = n < p.N;
+    float csum = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = mbase + crow(r, hi);
-        if (!(ncol && m < p.M)) continue;
-        float x = v[r] + bias;
-        if (p.epi == VITAE_EPI_GELU) {
-            p.aux[(long)m * p.ldaux + n] = x;
-            x = gelu_erf(x);
-        } else if (p.epi == VITAE_EPI_DGELU) {
-            x *= gelu_erf_grad(ax[r]);
-        } else if (p.epi == VITAE_EPI_RELU_MASK) {
-            x = ax[r] > 0.f ? x : 0.f;
+    for (int half = 0; half < 2; ++half) {
+        float ax[8], rs[8], co[8];
+        int mrow[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) mrow[q] = min(mbase + crow(8 * half + q, hi), p.M - 1);
+        if (need_aux) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) ax[q] = p.aux[mrow[q] * ldaux + nc];
         }
-        if (p.residual) x += rs[r];
-        if (p.C) {
-            if (p.accumulate) x += co[r];
-            p.C[(long)m * p.ldc + n] = x;
+        if (p.residual) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) rs[q] = p.residual[mrow[q] * ldr + nc];
         }
-        if (p.C16) p.C16[(long)m * p.ldc16 + n] = (__bf16)x;
-        csum += x;
+        if (acc_c) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) co[q] = p.C[mrow[q] * ldc + nc];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int m = mbase + crow(8 * half + q, hi);
+            if (!(ncol && m < p.M)) continue;
+            float x = v[8 * half + q] + bias;
+            if (p.epi == VITAE_EPI_GELU) {
+                p.aux[m * ldaux + n] = x;
+                x = gelu_erf(x);
+            } else if (p.epi == VITAE_EPI_DGELU) {
+                x *= gelu_erf_grad(ax[q]);
+            } else if (p.epi == VITAE_EPI_RELU_MASK) {
+                x = ax[q] > 0.f ? x : 0.f;
+            }
+            if (p.residual) x += rs[q];
+            if (p.C) {
+                if (acc_c) x += co[q];
+                p.C[m * ldc + n] = x;
+            }
+            if (p.C16) p.C16[m * ldc16 + n] = (__bf16)x;
+            csum += x;
+        }
+        asm volatile("" ::: "memory");   // keep the next batch's loads behind these stores (register pressure)
     }
     return csum;
 }
@@ -322,6 +331,9 @@ extern "C" int vitae_gemm_glds(int a_kcontig, int b_kcontig, const void* A16, lo
     if (!A16 || !B16 || (!C && !C16) || M <= 0 || N <= 0 || K <= 0) return VITAE_ERR_INVALID_ARG;
     if (epi != VITAE_EPI_NONE && !aux) return VITAE_ERR_INVALID_ARG;
     if (K % BK) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    if ((long)M * (ldc > N ? ldc : N) >= (1L << 31) || (long)M * ldaux >= (1L << 31) || (long)M * ldr >= (1L << 31) ||
+        (long)M * ldc16 >= (1L << 31))
+        return VITAE_ERR_UNSUPPORTED_SHAPE;   // epilogue uses 32-bit element offsets
     const int a_vec = a_kcontig ? K : M, b_vec = b_kcontig ? K : N;
     if ((a_vec & 7) || (lda & 7) || (b_vec & 7) || (ldb & 7)) return VITAE_ERR_UNSUPPORTED_SHAPE;
     if (((uintptr_t)A16 & 15) || ((uintptr_t)B16 & 15)) return VITAE_ERR_UNSUPPORTED_SHAPE;
@@ -371,6 +383,7 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
     if (!dy16 || !w16 || !x16 || (!dx && !dx16) || !dw || M <= 0 || N <= 0 || K <= 0) return VITAE_ERR_INVALID_ARG;
     if (epi != VITAE_EPI_NONE && !aux) return VITAE_ERR_INVALID_ARG;
     if ((N % BK) || (Mpad % BK) || (K & 7) || Mpad < M) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    if ((long)(M > N ? M : N) * K >= (1L << 31)) return VITAE_ERR_UNSUPPORTED_SHAPE;   // 32-bit epilogue offsets
     if (((uintptr_t)dy16 & 15) || ((uintptr_t)w16 & 15) || ((uintptr_t)x16 & 15)) return VITAE_ERR_UNSUPPORTED_SHAPE;
     GArgs p1, p2;
     p1.A = reinterpret_cast<const __bf16*>(dy16); p1.lda = N;
