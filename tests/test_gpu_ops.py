@@ -300,7 +300,8 @@ def test_sdpa(lib, B, N, H, hd):
     assert rel_err(dqkv, qr.grad) < 2e-5
 
 
-@pytest.mark.parametrize('B,N,H,hd', [(8, 55, 12, 64), (4, 217, 16, 32), (2, 17, 3, 32), (1, 130, 2, 64), (1, 300, 1, 32)])
+@pytest.mark.parametrize('B,N,H,hd', [(8, 55, 12, 64), (4, 217, 16, 32), (2, 17, 3, 32), (1, 130, 2, 64), (1, 300, 1, 32),
+                                      (1, 513, 2, 32), (1, 300, 2, 64)])   # the last two exceed the one-launch backward's LDS budget
 def test_sdpa_mfma_bf16(lib, B, N, H, hd):
     D = H * hd
     qkv, do = gen(B, N, 3 * D, seed=1), gen(B, N, D, seed=2)

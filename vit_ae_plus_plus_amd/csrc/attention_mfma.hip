@@ -16,6 +16,7 @@
 // element i of the four rows addressed by lanes 4 j .. 4 j + 3) from row-major bf16 LDS tiles.
 // LDS rows are padded to HD + 8 elements: conflict-free for both the b128 fragment reads and the
 // transpose reads.  Rows beyond N are zero-filled so stale LDS bits can never reach an MFMA.
+#include <cstdlib>
 #include "common.hpp"
 #include "vitae_hip.h"
 
@@ -407,6 +408,244 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const float* __r
         }
 }
 
+// ------------------------------------------------------------------------------- backward, one launch
+// For sequences whose whole head fits in LDS (N <= ~512 at hd 32, ~256 at hd 64 — every model of the reference):
+// Q (pre-scaled), K, V, dO of one (batch, head) are staged ONCE as bf16 tiles, delta = rowsum(O * dO) and the
+// log-sum-exp go to LDS, and the waves of the block then split the 32-row work items: dQ tiles (as the dq kernel)
+// and dK/dV tiles (as the dkv kernel).  One launch instead of two, no delta round trip through HBM, and all four
+// waves have work at N = 55 (two dQ + two dK/dV items).  qkv-bias column sums are collected with LDS atomics and
+// leave the block as one global atomic per column.
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_fused_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
+                                                             const float* __restrict__ d_o, const float* __restrict__ lse,
+                                                             float* __restrict__ dqkv, __bf16* __restrict__ dqkv16,
+                                                             float* __restrict__ dbias, int N, int H, float scale, int NP) {
+    constexpr int LD = HD + 8, NKK = HD / 16, NT = HD / 32, V4 = HD / 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+    __bf16* Qs = reinterpret_cast<__bf16*>(fsm);
+    __bf16* Ks = Qs + NP * LD;
+    __bf16* Vs = Ks + NP * LD;
+    __bf16* Gs = Vs + NP * LD;
+    float* Ls = reinterpret_cast<float*>(Gs + NP * LD);
+    float* Ds = Ls + NP;
+    float* Cs = Ds + NP;                          // [3 * HD] column sums of dq | dk | dv
+    const int b = blockIdx.z, h = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int D = H * HD;
+    const long ld = 3L * D;
+    const float* base = qkv + (long)b * N * ld + h * HD;
+    const float* gbase = d_o + (long)b * N * D + h * HD;
+    const float* obase = o + (long)b * N * D + h * HD;
+    // ---- stage the four operand tiles (rows >= N zero) and the per-row scalars
+    for (int idx = threadIdx.x; idx < NP * V4; idx += 256) {
+        const int row = idx / V4, c4 = (idx % V4) * 4;
+        f32x4 q = {0.f, 0.f, 0.f, 0.f}, k = q, v = q, g = q;
+        if (row < N) {
+            const float* r = base + (long)row * ld + c4;
+            q = *reinterpret_cast<const f32x4*>(r);
+            k = *reinterpret_cast<const f32x4*>(r + D);
+            v = *reinterpret_cast<const f32x4*>(r + 2 * D);
+            g = *reinterpret_cast<const f32x4*>(gbase + (long)row * D + c4);
+        }
+        bf16x4 q16, k16, v16, g16;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            q16[e] = (__bf16)(q[e] * (scale * LOG2E)); k16[e] = (__bf16)k[e]; v16[e] = (__bf16)v[e]; g16[e] = (__bf16)g[e];
+        }
+        *reinterpret_cast<bf16x4*>(Qs + row * LD + c4) = q16;
+        *reinterpret_cast<bf16x4*>(Ks + row * LD + c4) = k16;
+        *reinterpret_cast<bf16x4*>(Vs + row * LD + c4) = v16;
+        *reinterpret_cast<bf16x4*>(Gs + row * LD + c4) = g16;
+    }
+    for (int row = threadIdx.x; row < NP; row += 256) {
+        float dl = 0.f, L = 1e30f;                 // invalid query: P = exp2(s - huge) = 0
+        if (row < N) {
+            const float* gr = gbase + (long)row * D;
+            const float* orow = obase + (long)row * D;
+#pragma unroll
+            for (int c = 0; c < HD; c += 4) {
+                const f32x4 g = *reinterpret_cast<const f32x4*>(gr + c), ov = *reinterpret_cast<const f32x4*>(orow + c);
+                dl += g[0] * ov[0] + g[1] * ov[1] + g[2] * ov[2] + g[3] * ov[3];
+            }
+            L = lse[((long)b * H + h) * N + row] * LOG2E;
+        }
+        Ds[row] = dl; Ls[row] = L;
+    }
+    if (threadIdx.x < 3 * HD) Cs[threadIdx.x] = 0.f;
+    __syncthreads();
+
+    const int T = NP / 32;
+    for (int item = blockIdx.x * 4 + wave; item < 2 * T; item += gridDim.x * 4) {
+        if (item < T) {
+            // ---------------- dQ tile `item`
+            const int qrow = item * 32 + l31;
+            const bool qvalid = qrow < N;
+            bf16x8 qf[NKK], gf[NKK];
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                qf[kk] = *reinterpret_cast<const bf16x8*>(&Qs[qrow * LD + 16 * kk + 8 * hi]);
+                gf[kk] = *reinterpret_cast<const bf16x8*>(&Gs[qrow * LD + 16 * kk + 8 * hi]);
+            }
+            const float Lq = Ls[qrow], dl = Ds[qrow];
+            f32x16 acc[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = zero16();
+            for (int kt = 0; kt < T; ++kt) {
+                f32x16 sc = zero16(), dp = zero16();
+#pragma unroll
+                for (int kk = 0; kk < NKK; ++kk) {
+                    const bf16x8 ak = *reinterpret_cast<const bf16x8*>(&Ks[(kt * 32 + l31) * LD + 16 * kk + 8 * hi]);
+                    const bf16x8 av = *reinterpret_cast<const bf16x8*>(&Vs[(kt * 32 + l31) * LD + 16 * kk + 8 * hi]);
+                    sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ak, qf[kk], sc, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, gf[kk], dp, 0, 0, 0);
+                }
+                const bool tail = kt * 32 + 32 > N;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float p = __builtin_amdgcn_exp2f(sc[r] - Lq);
+                    if (tail && kt * 32 + crow(r, hi) >= N) p = 0.f;
+                    sc[r] = p * (dp[r] - dl);
+                }
+                bf16x8 dsf[2];
+                pack16(sc, dsf);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const bf16x8 a = tr_frag<LD>(Ks, kt * 32, s2, 32 * nt, lane);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, dsf[s2], acc[nt], 0, 0, 0);
+                    }
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nt][r] *= scale;
+            if (dbias) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float x = qvalid ? acc[nt][r] : 0.f;
+#pragma unroll
+                        for (int of = 16; of > 0; of >>= 1) x += __shfl_xor(x, of, 64);
+                        if (l31 == 0) atomicAdd(&Cs[32 * nt + 8 * (r >> 2) + 4 * hi + (r & 3)], x);
+                    }
+            }
+            if (qvalid) {
+                float* out = dqkv + ((long)b * N + qrow) * ld + h * HD;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 v = {acc[nt][4 * g], acc[nt][4 * g + 1], acc[nt][4 * g + 2], acc[nt][4 * g + 3]};
+                        *reinterpret_cast<f32x4*>(out + 32 * nt + 8 * g + 4 * hi) = v;
+                        if (dqkv16) {
+                            bf16x4 v16;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v16[e] = (__bf16)v[e];
+                            *reinterpret_cast<bf16x4*>(dqkv16 + ((long)b * N + qrow) * ld + h * HD + 32 * nt + 8 * g + 4 * hi) = v16;
+                        }
+                    }
+            }
+        } else {
+            // ---------------- dK / dV tile `item - T`
+            const int kt0 = item - T;
+            const int krow = kt0 * 32 + l31;
+            const bool kvalid = krow < N;
+            bf16x8 kf[NKK], vf[NKK];
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                kf[kk] = *reinterpret_cast<const bf16x8*>(&Ks[krow * LD + 16 * kk + 8 * hi]);
+                vf[kk] = *reinterpret_cast<const bf16x8*>(&Vs[krow * LD + 16 * kk + 8 * hi]);
+            }
+            f32x16 dk[NT], dv[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) { dk[nt] = zero16(); dv[nt] = zero16(); }
+            for (int qt = 0; qt < T; ++qt) {
+                f32x16 sc = zero16(), dp = zero16();
+#pragma unroll
+                for (int kk = 0; kk < NKK; ++kk) {
+                    const bf16x8 aq = *reinterpret_cast<const bf16x8*>(&Qs[(qt * 32 + l31) * LD + 16 * kk + 8 * hi]);
+                    const bf16x8 ag = *reinterpret_cast<const bf16x8*>(&Gs[(qt * 32 + l31) * LD + 16 * kk + 8 * hi]);
+                    sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, kf[kk], sc, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ag, vf[kk], dp, 0, 0, 0);
+                }
+                f32x16 p;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 L4 = *reinterpret_cast<const f32x4*>(&Ls[qt * 32 + 8 * g + 4 * hi]);
+                    const f32x4 D4 = *reinterpret_cast<const f32x4*>(&Ds[qt * 32 + 8 * g + 4 * hi]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float pe = __builtin_amdgcn_exp2f(sc[4 * g + e] - L4[e]);
+                        p[4 * g + e] = pe;
+                        sc[4 * g + e] = pe * (dp[4 * g + e] - D4[e]);
+                    }
+                }
+                bf16x8 pf[2], dsf[2];
+                pack16(p, pf);
+                pack16(sc, dsf);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const bf16x8 ag = tr_frag<LD>(Gs, qt * 32, s2, 32 * nt, lane);
+                        dv[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ag, pf[s2], dv[nt], 0, 0, 0);
+                        const bf16x8 aq = tr_frag<LD>(Qs, qt * 32, s2, 32 * nt, lane);
+                        dk[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, dsf[s2], dk[nt], 0, 0, 0);
+                    }
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dk[nt][r] *= LN2;     // Qs carried scale*log2e: dK = sum dS * scale * Q
+            if (dbias) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float x = kvalid ? dk[nt][r] : 0.f, y = kvalid ? dv[nt][r] : 0.f;
+#pragma unroll
+                        for (int of = 16; of > 0; of >>= 1) { x += __shfl_xor(x, of, 64); y += __shfl_xor(y, of, 64); }
+                        if (l31 == 0) {
+                            const int c = 32 * nt + 8 * (r >> 2) + 4 * hi + (r & 3);
+                            atomicAdd(&Cs[HD + c], x);
+                            atomicAdd(&Cs[2 * HD + c], y);
+                        }
+                    }
+            }
+            if (kvalid) {
+                float* out = dqkv + ((long)b * N + krow) * ld + h * HD;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int d = 32 * nt + 8 * g + 4 * hi;
+                        f32x4 vk = {dk[nt][4 * g], dk[nt][4 * g + 1], dk[nt][4 * g + 2], dk[nt][4 * g + 3]};
+                        f32x4 vv = {dv[nt][4 * g], dv[nt][4 * g + 1], dv[nt][4 * g + 2], dv[nt][4 * g + 3]};
+                        *reinterpret_cast<f32x4*>(out + D + d) = vk;
+                        *reinterpret_cast<f32x4*>(out + 2 * D + d) = vv;
+                        if (dqkv16) {
+                            bf16x4 k16, v16;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { k16[e] = (__bf16)vk[e]; v16[e] = (__bf16)vv[e]; }
+                            __bf16* o16 = dqkv16 + ((long)b * N + krow) * ld + h * HD;
+                            *reinterpret_cast<bf16x4*>(o16 + D + d) = k16;
+                            *reinterpret_cast<bf16x4*>(o16 + 2 * D + d) = v16;
+                        }
+                    }
+            }
+        }
+    }
+    if (dbias) {
+        __syncthreads();
+        if (threadIdx.x < 3 * HD) {
+            const int part = threadIdx.x / HD, c = threadIdx.x % HD;
+            atomicAdd(dbias + part * D + h * HD + c, Cs[threadIdx.x]);
+        }
+    }
+}
+
 }  // namespace
 
 // Returns VITAE_ERR_UNSUPPORTED_SHAPE for head dims without an MFMA instantiation (caller falls back
@@ -436,6 +675,30 @@ extern "C" int vitae_sdpa_mfma_bwd(const float* qkv, const float* o, const float
     dim3 grid(cdiv(N, 128), H, B);
     hipStream_t st = (hipStream_t)stream;
     __bf16* g16 = reinterpret_cast<__bf16*>(dqkv_bf16);
+    // whole head resident in LDS -> the one-launch backward
+    static const int fused_on = getenv("VITAE_ATTN_BWD_FUSED") ? atoi(getenv("VITAE_ATTN_BWD_FUSED")) : 1;
+    const int NP = cdiv(N, 32) * 32;
+    const size_t lds = (size_t)4 * NP * (head_dim + 8) * 2 + (size_t)2 * NP * 4 + (size_t)3 * head_dim * 4;
+    if (fused_on && (head_dim == 32 || head_dim == 64) && lds <= 150 * 1024) {
+        const int items = 2 * (NP / 32);
+        int G = cdiv(items, 4);                                 // one item per wave ...
+        if ((long)G * H * B > 1024) G = cdiv(items, 8);          // ... two when that many workgroups would queue up
+        dim3 fgrid(G, H, B);
+        if (head_dim == 32) {
+            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<32>),
+                                                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            (void)attr;
+            hipLaunchKernelGGL((attn_bwd_fused_kernel<32>), fgrid, dim3(256), lds, st, qkv, o, d_o, lse, dqkv, g16,
+                               dqkv_colsum_accum, N, H, scale, NP);
+        } else {
+            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<64>),
+                                                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            (void)attr;
+            hipLaunchKernelGGL((attn_bwd_fused_kernel<64>), fgrid, dim3(256), lds, st, qkv, o, d_o, lse, dqkv, g16,
+                               dqkv_colsum_accum, N, H, scale, NP);
+        }
+        return vitae_launch_status();
+    }
     if (head_dim == 32) {
         hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<32>), grid, dim3(256), 0, st, qkv, o, d_o, lse, dqkv, g16, dqkv_colsum_accum, delta_ws, N, H, scale);
         hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<32>), grid, dim3(256), 0, st, qkv, d_o, lse, delta_ws, dqkv, g16, dqkv_colsum_accum, N, H, scale);
