@@ -41,6 +41,8 @@ def parse():
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--model', default='contr', choices=['contr', 'mae'])
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--grad-comm', default=None, choices=['fp32', 'bf16'],
+                    help='wire dtype of the gradient all-reduce at >1 GPU (default: the compute precision)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=2)
     ap.add_argument('--profile-steps', type=int, default=3, help='instrumented steps for the roofline block')
@@ -120,7 +122,8 @@ def main():
     eng = model._ensure_engine(dev)
     opt = FusedAdamW(model, lr=1e-4, weight_decay=0.05, betas=(0.9, 0.95))
     _ = opt.engine
-    model.enable_data_parallel(dev, force=force_ddp)
+    grad_comm = args.grad_comm or args.precision
+    model.enable_data_parallel(dev, force=force_ddp, comm_dtype=torch.bfloat16 if grad_comm == 'bf16' else None)
     eng.set_loss_weights(0.01, 0.001 if contr else 0.0, 1, world)
 
     cpu_batches = synthetic_batches(args.batch, rank)
@@ -177,7 +180,7 @@ def main():
             torch.cuda._sleep(200_000_000)
             eng.gemm_timer = []
             if world > 1:   # keep collectives matched: other ranks idle here, so time phases locally only
-                for k in range(3):
+                for k in range(eng.N_PHASES - 1):
                     eager._phase(k)
             else:
                 eager.run()
@@ -236,7 +239,8 @@ def main():
                                       f'(fwd+loss+bwd+grad-norm+AdamW), synthetic BraTS-shape 96^3x4ch, batch '
                                       f'{args.batch}/GPU, mask 0.75 (BASELINE config 2{" / 3" if world > 1 else ""})',
                           'global_batch': world * args.batch, 'parallelism': f'dp{world}',
-                          'hip_graph': not args.no_graph, 'final_losses': [round(x, 6) for x in last[:6]]},
+                          'hip_graph': not args.no_graph,
+                          'grad_allreduce': (f'{grad_comm}, {len(model._reducer.ranges)} buckets' if model._reducer is not None else None), 'final_losses': [round(x, 6) for x in last[:6]]},
                'roofline': roof, 'cpu_baseline': cpu}
         if parity:
             out['parity'] = parity

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITAE_ABI_VERSION 12
+#define VITAE_ABI_VERSION 13
 
 /* matrix-core arithmetic of the dense contractions */
 #define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
@@ -226,6 +226,11 @@ int vitae_grad_sqnorm(const float* grads, long n, double* acc, float* norm_out, 
 /* shadow_bf16 (optional): bf16 copy of the updated parameters, written in the same pass */
 int vitae_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, long n,
                      const float* hp, const float* grad_norm, float weight_decay, void* stream);
+/* the same two passes reading the gradients as bf16 — the wire copy of a bf16 data-parallel all-reduce, consumed
+ * in place instead of being converted back into the fp32 arena first */
+int vitae_grad_sqnorm_bf16(const void* grads_bf16, long n, double* acc, float* norm_out, void* stream);
+int vitae_adamw_step_bf16g(float* params, const void* grads_bf16, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
+                           long n, const float* hp, const float* grad_norm, float weight_decay, void* stream);
 
 #ifdef __cplusplus
 }

@@ -47,10 +47,19 @@ def _worker(rank, world, port, q):
             eng.layout[k] = (off, tuple(sd[k].shape))
             off += (sd[k].numel() + 3) // 4 * 4
         eng.n_total = off
-        ranges = ddp.engine_bucket_ranges(eng)
-        covered = sorted(ranges)
-        assert covered[0][0] == 0 and covered[-1][1] == off
-        assert all(a[1] == b[0] for a, b in zip(covered, covered[1:])), covered
+        import types
+        from vit_ae_plus_plus_amd.engine import HipMAEEngine
+        eng.enc_chunk_bounds = types.MethodType(HipMAEEngine.enc_chunk_bounds, eng)
+        for chunks in (1, 2):
+            eng.enc_chunks = chunks
+            ranges = ddp.engine_bucket_ranges(eng)
+            assert len(ranges) == chunks + 2
+            covered = sorted(ranges)
+            assert covered[0][0] == 0 and covered[-1][1] == off
+            assert all(a[1] == b[0] for a, b in zip(covered, covered[1:])), covered
+        # completion order: decoder first, then encoder chunks from the top block down to offset 0, vectors last
+        assert ranges[0][0] == eng.layout['decoder_embed.weight'][0] and ranges[1][1] == ranges[0][0]
+        assert ranges[1][0] == eng.layout['blocks.1.attn.qkv.weight'][0] and ranges[2] == (0, ranges[1][0])
         # per-rank gradients from the oracle on different data, pre-scaled by 1/world like set_loss_weights
         params = R.make_leaf_params(sd)
         v1, v2 = R.synthetic_views((2, 1, 16, 16, 16), seed=10 + rank)
@@ -71,6 +80,16 @@ def _worker(rank, world, port, q):
         dist.all_gather(gathered, local)
         want = sum(gathered)          # each already carries 1/world -> mean of the raw per-rank grads
         assert torch.allclose(flat, want, rtol=1e-6, atol=1e-9)
+        # bf16 on the wire: every rank ends with the same fp32 arena, equal to the bf16-rounded sum
+        flat16 = local.clone()
+        red16 = ddp.GradBucketReducer(flat16, ranges, comm_dtype=torch.bfloat16)
+        for b in range(len(ranges)):
+            red16.launch(b)
+        red16.wait()
+        assert float((flat16 - want).norm() / want.norm()) < 1e-2     # bf16 round-off of the operands and the sum
+        both = [torch.zeros_like(flat16) for _ in range(world)]
+        dist.all_gather(both, flat16)
+        assert torch.equal(both[0], both[1])
         means = misc.all_reduce_means([float(rank), 2.0, float(total)])
         assert means[0] == pytest.approx((world - 1) / 2) and means[1] == 2.0
         assert misc.all_reduce_mean(float(rank)) == pytest.approx((world - 1) / 2)

@@ -578,3 +578,35 @@ def test_adamw_and_gradnorm(lib, C):
     gn.fill_(float('inf'))
     lib.vitae_adamw_step(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), None, n, hp.data_ptr(), gn.data_ptr(), 0.05, st())
     assert torch.equal(p, before)
+
+
+def test_adamw_and_gradnorm_from_bf16_gradients(lib, C):
+    """The bf16-gradient entry points (reduced gradients consumed from the all-reduce's wire buffer) equal the fp32
+    ones applied to the same bf16-rounded values, bit for bit."""
+    n = 100_003
+    npad = (n + 3) // 4 * 4
+    g = torch.Generator(device='cuda').manual_seed(3)
+    p0 = torch.randn(npad, device='cuda', generator=g) * 0.02
+    g16 = (torch.randn(npad, device='cuda', generator=g) * 0.01).to(torch.bfloat16)
+    g32 = g16.float()
+    hp = torch.zeros(C['VITAE_HP_COUNT'], device='cuda')
+    hp[C['VITAE_HP_LR']], hp[C['VITAE_HP_BETA1']], hp[C['VITAE_HP_BETA2']], hp[C['VITAE_HP_EPS']] = 3e-4, 0.9, 0.95, 1e-8
+    hp[C['VITAE_HP_BC1']], hp[C['VITAE_HP_BC2']], hp[C['VITAE_HP_GRAD_MUL']] = 0.1, 0.05, 1.0
+    outs = []
+    for bf in (False, True):
+        p, m, v = p0.clone(), torch.zeros(npad, device='cuda'), torch.zeros(npad, device='cuda')
+        sh = torch.zeros(npad, dtype=torch.bfloat16, device='cuda')
+        acc = torch.zeros(C['VITAE_ACC_COUNT'], dtype=torch.float64, device='cuda')
+        gn = torch.zeros(1, device='cuda')
+        if bf:
+            lib.vitae_grad_sqnorm_bf16(g16.data_ptr(), n, acc.data_ptr(), gn.data_ptr(), st())
+            lib.vitae_adamw_step_bf16g(p.data_ptr(), g16.data_ptr(), m.data_ptr(), v.data_ptr(), sh.data_ptr(), n, hp.data_ptr(),
+                                       gn.data_ptr(), 0.05, st())
+        else:
+            lib.vitae_grad_sqnorm(g32.data_ptr(), n, acc.data_ptr(), gn.data_ptr(), st())
+            lib.vitae_adamw_step(p.data_ptr(), g32.data_ptr(), m.data_ptr(), v.data_ptr(), sh.data_ptr(), n, hp.data_ptr(),
+                                 gn.data_ptr(), 0.05, st())
+        outs.append((p, m, v, sh, gn.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert abs(float(outs[0][4]) - float(g32[:n].norm())) < 1e-5 * float(g32[:n].norm())

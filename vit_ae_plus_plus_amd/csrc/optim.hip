@@ -12,16 +12,27 @@ namespace {
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void grad_sqnorm_kernel(const float* __restrict__ g, long n, double* __restrict__ acc) {
+// Gradients are read either as fp32 or as bf16 (the wire copy of a data-parallel all-reduce done in bf16: the
+// optimiser then consumes the reduced values directly instead of a converted fp32 copy).
+template <typename G> __device__ __forceinline__ f32x4 grad4(const G* g, long i);
+template <> __device__ __forceinline__ f32x4 grad4<float>(const float* g, long i) {
+    return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g) + i);
+}
+template <> __device__ __forceinline__ f32x4 grad4<__bf16>(const __bf16* g, long i) {
+    const bf16x4 h = __builtin_nontemporal_load(reinterpret_cast<const bf16x4*>(g) + i);
+    return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+}
+
+template <typename G>
+__global__ __launch_bounds__(256) void grad_sqnorm_kernel(const G* __restrict__ g, long n, double* __restrict__ acc) {
     __shared__ float red[4];
     float s = 0.f;
     const long n4 = n / 4;
-    const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-        const f32x4 v = g4[i];
+        const f32x4 v = grad4<G>(g, i);
         s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
     }
-    if (blockIdx.x == 0) for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) s += g[i] * g[i];
+    if (blockIdx.x == 0) for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) s += (float)g[i] * (float)g[i];
     s = block_sum_256(s, red);
     if (threadIdx.x == 0) atomicAdd(acc + VITAE_ACC_GRADSQ, (double)s);
 }
@@ -32,8 +43,8 @@ __global__ void grad_norm_finalize_kernel(const double* __restrict__ acc, float*
 
 // torch.optim.AdamW (single-tensor form): p *= 1 - lr*wd; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
 // p -= (lr / bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
-template <bool NT>
-__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+template <bool NT, typename G>
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const G* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, __bf16* __restrict__ shadow, long n,
                                                     const float* __restrict__ hp, const float* __restrict__ gnorm,
                                                     float weight_decay) {
@@ -44,7 +55,6 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     const float decay = 1.0f - lr * weight_decay, step = lr / bc1;
     const long n4 = n / 4;
     f32x4* p4 = reinterpret_cast<f32x4*>(p);
-    const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
     f32x4* m4 = reinterpret_cast<f32x4*>(m);
     f32x4* v4 = reinterpret_cast<f32x4*>(v);
     // two independent 16-byte groups per thread and iteration: 8 loads in flight before the first dependent use.
@@ -59,7 +69,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         pp[0] = p4[i0]; pp[1] = p4[j1];
         mm[0] = NT ? __builtin_nontemporal_load(m4 + i0) : m4[i0]; mm[1] = NT ? __builtin_nontemporal_load(m4 + j1) : m4[j1];
         vv[0] = NT ? __builtin_nontemporal_load(v4 + i0) : v4[i0]; vv[1] = NT ? __builtin_nontemporal_load(v4 + j1) : v4[j1];
-        gg[0] = NT ? __builtin_nontemporal_load(g4 + i0) : g4[i0]; gg[1] = NT ? __builtin_nontemporal_load(g4 + j1) : g4[j1];
+        gg[0] = grad4<G>(g, i0); gg[1] = grad4<G>(g, j1);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             if (u == 1 && !two) break;
@@ -85,7 +95,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     }
     if (blockIdx.x == 0) {
         for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) {
-            const float gg = g[i] * gs;
+            const float gg = (float)g[i] * gs;
             float pp = p[i] * decay;
             const float mm = m[i] + (1.f - b1) * (gg - m[i]);
             const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
@@ -98,31 +108,53 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 
 }  // namespace
 
-extern "C" int vitae_grad_sqnorm(const float* grads, long n, double* acc, float* norm_out, void* stream) {
+template <typename G>
+static int grad_sqnorm_launch(const G* grads, long n, double* acc, float* norm_out, void* stream) {
     if (!grads || !acc || n <= 0 || ((uintptr_t)grads & 15)) return VITAE_ERR_INVALID_ARG;
     long blocks = (n / 4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(grad_sqnorm_kernel, dim3((int)blocks), dim3(256), 0, st, grads, n, acc);
+    hipLaunchKernelGGL(grad_sqnorm_kernel<G>, dim3((int)blocks), dim3(256), 0, st, grads, n, acc);
     if (norm_out) hipLaunchKernelGGL(grad_norm_finalize_kernel, dim3(1), dim3(64), 0, st, acc, norm_out);
+    return vitae_launch_status();
+}
+
+extern "C" int vitae_grad_sqnorm(const float* grads, long n, double* acc, float* norm_out, void* stream) {
+    return grad_sqnorm_launch<float>(grads, n, acc, norm_out, stream);
+}
+
+extern "C" int vitae_grad_sqnorm_bf16(const void* grads_bf16, long n, double* acc, float* norm_out, void* stream) {
+    return grad_sqnorm_launch<__bf16>(reinterpret_cast<const __bf16*>(grads_bf16), n, acc, norm_out, stream);
+}
+
+template <typename G>
+static int adamw_launch(float* params, const G* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, long n,
+                        const float* hp, const float* grad_norm, float weight_decay, void* stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !hp || n <= 0) return VITAE_ERR_INVALID_ARG;
+    if (((uintptr_t)params | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return VITAE_ERR_INVALID_ARG;
+    if (((uintptr_t)grads & (4 * sizeof(G) - 1)) || ((uintptr_t)shadow_bf16 & 7)) return VITAE_ERR_INVALID_ARG;
+    long blocks = (n / 4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    // 30 B/element of HBM traffic; measured 5.0-5.2 TB/s for every grid size / cache policy tried (the read-only
+    // grad-norm pass reaches 5.4 TB/s on the same box), i.e. this kernel sits at the achievable HBM rate.
+    hipLaunchKernelGGL((adamw_kernel<true, G>), dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
+                       exp_avg_sq, reinterpret_cast<__bf16*>(shadow_bf16), n, hp, grad_norm, weight_decay);
     return vitae_launch_status();
 }
 
 extern "C" int vitae_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                                 void* shadow_bf16, long n, const float* hp, const float* grad_norm,
                                 float weight_decay, void* stream) {
-    if (!params || !grads || !exp_avg || !exp_avg_sq || !hp || n <= 0) return VITAE_ERR_INVALID_ARG;
-    if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return VITAE_ERR_INVALID_ARG;
-    if ((uintptr_t)shadow_bf16 & 7) return VITAE_ERR_INVALID_ARG;
-    long blocks = (n / 4 + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    if (blocks < 1) blocks = 1;
-    // 30 B/element of HBM traffic; measured 5.0-5.2 TB/s for every grid size / cache policy tried (the read-only
-    // grad-norm pass reaches 5.4 TB/s on the same box), i.e. this kernel sits at the achievable HBM rate.
-    hipLaunchKernelGGL(adamw_kernel<true>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
-                       exp_avg_sq, reinterpret_cast<__bf16*>(shadow_bf16), n, hp, grad_norm, weight_decay);
-    return vitae_launch_status();
+    return adamw_launch<float>(params, grads, exp_avg, exp_avg_sq, shadow_bf16, n, hp, grad_norm, weight_decay, stream);
+}
+
+extern "C" int vitae_adamw_step_bf16g(float* params, const void* grads_bf16, float* exp_avg, float* exp_avg_sq,
+                                      void* shadow_bf16, long n, const float* hp, const float* grad_norm,
+                                      float weight_decay, void* stream) {
+    return adamw_launch<__bf16>(params, reinterpret_cast<const __bf16*>(grads_bf16), exp_avg, exp_avg_sq, shadow_bf16, n, hp,
+                                grad_norm, weight_decay, stream);
 }
 
 namespace {

@@ -5,11 +5,14 @@ all-reduces exist on that path, utils/misc.py:332-340), so this is new functiona
 standard DDP contract: after the exchange every rank holds the MEAN of the per-rank gradients.
 
 Design for MI355X: the gradient arena of ``HipMAEEngine`` is laid out in forward order, and the
-hand-ordered backward finishes it in three contiguous ranges (decoder+predictor, upper encoder half,
-lower encoder half + patch embedding).  Each range is one bucket (tens to hundreds of MB — large
-messages, since xGMI rings are per-link bound): its all-reduce is issued asynchronously the moment
-the backward phase that completes it has been enqueued, so RCCL runs on its own stream underneath
-the remaining backward kernels; the small token/vector segment goes last.  The 1/world_size of the
+hand-ordered backward finishes it in contiguous ranges (decoder+predictor, then the encoder in
+``engine.enc_chunks`` groups of blocks from the top, the last with the patch embedding).  Each range is
+one bucket (50-130 MB — large messages, since xGMI rings are per-link bound): its all-reduce is issued
+asynchronously the moment the backward phase that completes it has been enqueued, so RCCL runs on its
+own stream underneath the remaining backward kernels; the small token/vector segment goes last.
+With 531 MB of fp32 gradients and ~3 ms of backward to hide them in, the exchange can optionally run
+in bf16 (``comm_dtype``; the same trade as torch's ``bf16_compress_hook``: gradients are rounded to
+bf16 for the wire and the sum, the optimiser still sees fp32).  The 1/world_size of the
 mean is folded into the loss-gradient multipliers up front (``HipMAEEngine.set_loss_weights``), so
 a SUM all-reduce yields the mean with no extra pass over the 0.5 GB arena.
 The reducer only needs a flat tensor and ranges, so it is exercised on CPU with gloo in tests.
@@ -30,9 +33,11 @@ class GradBucketReducer:
     """Asynchronous SUM all-reduce of contiguous ranges of one flat gradient tensor."""
 
     def __init__(self, flat: torch.Tensor, ranges: Sequence[Tuple[int, int]], group=None,
-                 max_bucket_elems: Optional[int] = None, force: bool = False):
+                 max_bucket_elems: Optional[int] = None, force: bool = False, comm_dtype: Optional[torch.dtype] = None):
         assert flat.dim() == 1
         self.flat, self.group = flat, group
+        self.comm_dtype = comm_dtype if comm_dtype not in (None, flat.dtype) else None
+        self.wire = torch.zeros_like(flat, dtype=self.comm_dtype) if self.comm_dtype is not None else None
         self.force = force   # exercise the exchange machinery even at world size 1 (single-GPU validation)
         self.ranges: List[List[Tuple[int, int]]] = []
         for s, e in ranges:
@@ -63,26 +68,39 @@ class GradBucketReducer:
             return
         for s, e in self.ranges[bucket]:
             if e > s:
-                self.pending.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group,
-                                                    async_op=True))
+                if self.wire is not None:
+                    self.wire[s:e].copy_(self.flat[s:e])          # round to the wire dtype (current stream)
+                    work = dist.all_reduce(self.wire[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                else:
+                    work = dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self.pending.append((work, s, e))
 
-    def wait(self):
-        """Make the current stream (or the host, for CPU backends) wait for every launched bucket."""
-        for w in self.pending:
+    def wait(self, copy_back: bool = True):
+        """Make the current stream (or the host, for CPU backends) wait for every launched bucket.  With a wire dtype,
+        ``copy_back=False`` leaves the reduced values in ``self.wire`` only (the fused optimiser reads them there);
+        the fp32 arena then still holds this rank's local gradients."""
+        for w, s, e in self.pending:
             w.wait()
+            if self.wire is not None and copy_back:
+                self.flat[s:e].copy_(self.wire[s:e])
         self.pending.clear()
 
 
 def engine_bucket_ranges(engine) -> List[Tuple[int, int]]:
-    """[decoder+predictor matrices, upper-half encoder matrices, lower half + patch embedding,
-    tokens+vectors] as element ranges of ``engine.grads`` — the completion order of
-    ``HipMAEEngine.backward``'s phases."""
+    """[decoder+predictor matrices, encoder chunks from the top (the last one down to offset 0, i.e. with the patch
+    embedding), tokens+vectors] as element ranges of ``engine.grads`` — the completion order of
+    ``HipMAEEngine.train_phase``'s backward phases."""
     lay = engine.layout
-    cfg = engine.cfg
-    mid = cfg.depth // 2
     dec0 = lay['decoder_embed.weight'][0]
-    hi0 = lay[f'blocks.{mid}.attn.qkv.weight'][0] if cfg.depth > 1 else lay['blocks.0.attn.qkv.weight'][0]
-    return [(dec0, engine.tok_off), (hi0, dec0), (0, hi0), (engine.tok_off, engine.n_total)]
+    out = [(dec0, engine.tok_off)]
+    top = dec0
+    bounds = engine.enc_chunk_bounds()
+    for i, (hi, lo) in enumerate(bounds):
+        start = 0 if i == len(bounds) - 1 else lay[f'blocks.{lo}.attn.qkv.weight'][0]
+        out.append((start, top))
+        top = start
+    out.append((engine.tok_off, engine.n_total))
+    return out
 
 
 def broadcast_parameters(engine, src: int = 0, group=None):

@@ -147,6 +147,8 @@ class HipMAEEngine:
         self.overlap_wgrad = True
         self._wg_events: Dict[str, torch.cuda.Event] = {}
         self._wg_pending = set()
+        self._wire_ready = False
+        self.grads_wire16 = None  # set by the data-parallel reducer when gradients are exchanged (and consumed) in bf16
         self.gemm_timer = None   # bench.py: list collecting (start_event, end_event, flops) per GEMM launch
         self.set_hparams(lr=0.0, beta1=0.9, beta2=0.95, eps=1e-8, bc1=1.0, bc2=1.0, grad_mul=1.0, g_recon=1.0,
                          g_edge=0.0, g_contr=0.0, edge_w=0.0, contr_w=0.0)
@@ -642,12 +644,11 @@ class HipMAEEngine:
 
     def backward(self, have_dp: bool):
         """Reverse sweep.  hp[G_RECON], hp[G_EDGE] hold d total/d recon, d total/d raw_edge; when
-        ``have_dp`` buf['dp'] holds d total / d [p1; p2].  Three phases; after phase k the gradient
+        ``have_dp`` buf['dp'] holds d total / d [p1; p2].  1 + enc_chunks phases; after phase k the gradient
         range ``ddp.engine_bucket_ranges(self)[k]`` is final (bucket k may be all-reduced)."""
-        mid = self.cfg.depth // 2
         self.backward_dec(have_dp)
-        self.backward_enc(self.cfg.depth - 1, mid)
-        self.backward_enc(mid - 1, 0)
+        for hi, lo in self.enc_chunk_bounds():
+            self.backward_enc(hi, lo)
         self.backward_tail()
 
     def backward_dec(self, have_dp: bool):
@@ -768,28 +769,55 @@ class HipMAEEngine:
         (decayed: matrices + tokens; not decayed: vectors)."""
         st = torch.cuda.current_stream(self.device).cuda_stream
         gn = self.losses.data_ptr() + 20
-        lib.vitae_grad_sqnorm(self.grads.data_ptr(), self.n_total, _ptr(self.acc), gn, st)
         s = self.opt_state
         sh = self.params16.data_ptr() if self.params16 is not None else 0
+        o = self.vec_off * 4
+        # bf16 data-parallel exchange: the reduced gradients live in the wire buffer (only on the fused-step route, which
+        # raises the flag right after the exchange it issued)
+        g16 = self.grads_wire16 if self._wire_ready else None
+        if g16 is not None:
+            lib.vitae_grad_sqnorm_bf16(g16.data_ptr(), self.n_total, _ptr(self.acc), gn, st)
+            lib.vitae_adamw_step_bf16g(self.params.data_ptr(), g16.data_ptr(), s['exp_avg'].data_ptr(),
+                                       s['exp_avg_sq'].data_ptr(), sh if sh else None, self.vec_off, _ptr(self.hp), gn,
+                                       self.weight_decay, st)
+            lib.vitae_adamw_step_bf16g(self.params.data_ptr() + o, g16.data_ptr() + o // 2, s['exp_avg'].data_ptr() + o,
+                                       s['exp_avg_sq'].data_ptr() + o, (sh + o // 2) if sh else None,
+                                       self.n_total - self.vec_off, _ptr(self.hp), gn, 0.0, st)
+            return
+        lib.vitae_grad_sqnorm(self.grads.data_ptr(), self.n_total, _ptr(self.acc), gn, st)
         lib.vitae_adamw_step(self.params.data_ptr(), self.grads.data_ptr(), s['exp_avg'].data_ptr(),
                              s['exp_avg_sq'].data_ptr(), sh if sh else None, self.vec_off, _ptr(self.hp), gn,
                              self.weight_decay, st)
-        o = self.vec_off * 4
         lib.vitae_adamw_step(self.params.data_ptr() + o, self.grads.data_ptr() + o, s['exp_avg'].data_ptr() + o,
                              s['exp_avg_sq'].data_ptr() + o, (sh + o // 2) if sh else None, self.n_total - self.vec_off,
                              _ptr(self.hp), gn, 0.0, st)
 
     # ------------------------------------------------------------------ fused training step
-    N_PHASES = 4
+    enc_chunks = 2      # encoder backward is cut into this many phases (= gradient buckets); ddp raises it
+
+    def set_backward_chunks(self, n: int):
+        """Number of encoder-backward phases.  More phases = smaller gradient buckets = an earlier start and a shorter
+        exposed tail for the data-parallel all-reduce (each phase is its own graph replay)."""
+        self.enc_chunks = max(1, min(int(n), self.cfg.depth))
+
+    @property
+    def N_PHASES(self) -> int:
+        return self.enc_chunks + 2
+
+    def enc_chunk_bounds(self):
+        """[(hi, lo)] block ranges of the encoder-backward phases, last block first; sizes differ by at most one."""
+        d, n = self.cfg.depth, self.enc_chunks
+        cuts = [round(d * i / n) for i in range(n + 1)]              # ascending block boundaries
+        return [(cuts[i + 1] - 1, cuts[i]) for i in reversed(range(n))]
 
     def train_phase(self, k: int, view1, view2, noise, mask_ratio: float, update: bool = True,
                     accumulate: bool = False):
         """Phase k of one optimisation step (only kernel launches, no host sync):
-        0 = forward + losses + backward through decoder/predictor; 1 = upper encoder half backward;
-        2 = lower half + patch embedding; 3 = grad-norm + AdamW.  Gradient bucket k (ddp) is final
-        after phase k.  Loss multipliers and lr must already be in ``hp``."""
+        0 = forward + losses + backward through decoder/predictor; 1 .. enc_chunks = encoder backward, top chunk first
+        (the last one also does the patch embedding); enc_chunks + 1 = grad-norm + AdamW.  Gradient bucket k (ddp) is
+        final after phase k.  Loss multipliers and lr must already be in ``hp``."""
         cfg = self.cfg
-        mid = cfg.depth // 2
+        n = self.enc_chunks
         if k == 0:
             self.forward(view1, view2, noise, mask_ratio, training=True)
             if cfg.contrastive:
@@ -798,12 +826,12 @@ class HipMAEEngine:
             if cfg.contrastive:
                 self.contrastive_loss_bwd()
             self.backward_dec(have_dp=cfg.contrastive)
-        elif k == 1:
-            self.backward_enc(cfg.depth - 1, mid)
-        elif k == 2:
-            self.backward_enc(mid - 1, 0)
-            self.backward_tail()
-        elif k == 3 and update:
+        elif 1 <= k <= n:
+            hi, lo = self.enc_chunk_bounds()[k - 1]
+            self.backward_enc(hi, lo)
+            if k == n:
+                self.backward_tail()
+        elif k == n + 1 and update:
             self.grad_norm_and_step()
 
     def train_step_launch(self, view1, view2, noise, mask_ratio: float, update: bool = True, accumulate: bool = False):

@@ -144,11 +144,13 @@ class _StepRunner:
 
     def run(self):
         """Enqueue one optimisation step.  Single process: one graph (or one eager launch list).
-        Data parallel: phases 0..2 each followed by the asynchronous all-reduce of the gradient bucket
-        they complete, then wait + grad-norm/AdamW (no exchange on gradient-accumulation micro-steps)."""
+        Data parallel: every backward phase is followed by the asynchronous all-reduce of the gradient bucket
+        it completes, then wait + grad-norm/AdamW (no exchange on gradient-accumulation micro-steps)."""
         eng, red = self.eng, self.model._reducer
         exchange = red is not None and red.active and self.update
-        groups = [[0], [1], [2], [3]] if exchange else [list(range(eng.N_PHASES))]
+        nph = eng.N_PHASES
+        groups = [[k] for k in range(nph)] if exchange else [list(range(nph))]
+        eng._wire_ready = exchange and eng.grads_wire16 is not None    # read at launch / capture time of the last phase
         if self.use_graph and self.graphs is None:
             self._capture(groups)
         for i, grp in enumerate(groups):
@@ -157,11 +159,11 @@ class _StepRunner:
             else:
                 for k in grp:
                     self._phase(k)
-            if exchange and i < 3:
-                red.launch(i)
-                if i == 2:
-                    red.launch(3)
-                    red.wait()
+            if exchange and i < nph - 1:
+                red.launch(i)                 # bucket i is final after phase i
+                if i == nph - 2:
+                    red.launch(nph - 1)       # tokens + vectors
+                    red.wait(copy_back=eng.grads_wire16 is None)
 
 
 class MaskedAutoencoderViT(nn.Module):
@@ -292,16 +294,24 @@ class MaskedAutoencoderViT(nn.Module):
                 self.decoder_pos_embed.data.reshape(eng.buffers['decoder_pos_embed'].shape))
         return out
 
-    def enable_data_parallel(self, device=None, group=None, force=False):
+    def enable_data_parallel(self, device=None, group=None, force=False, comm_dtype=None, enc_chunks=3):
         """One process per GPU: broadcast rank 0's replica and all-reduce gradient buckets over RCCL
-        (overlapped with backward) inside the fused step.  No-op for a single process."""
+        (overlapped with backward) inside the fused step.  No-op for a single process.
+        ``comm_dtype=torch.bfloat16`` sends the gradients rounded to bf16 (half the bytes on xGMI);
+        ``enc_chunks`` = number of encoder gradient buckets."""
         from .. import ddp
         if not ddp.is_distributed() and not (force and torch.distributed.is_initialized()):
             self._reducer = None
+            if self._engine is not None:
+                self._engine.grads_wire16 = None
             return None
         eng = self._ensure_engine(torch.device(device) if device is not None else next(self.parameters()).device)
         ddp.broadcast_parameters(eng, 0, group)
-        self._reducer = ddp.GradBucketReducer(eng.grads, ddp.engine_bucket_ranges(eng), group=group, force=force)
+        eng.set_backward_chunks(enc_chunks)
+        self._reducer = ddp.GradBucketReducer(eng.grads, ddp.engine_bucket_ranges(eng), group=group, force=force,
+                                              comm_dtype=comm_dtype)
+        # bf16 exchange: the fused grad-norm + AdamW read the reduced gradients straight from the wire buffer
+        eng.grads_wire16 = self._reducer.wire if (self._reducer.wire is not None and self._reducer.active) else None
         self._runners.clear()
         return self._reducer
 
