@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITAE_ABI_VERSION 13
+#define VITAE_ABI_VERSION 14
 
 /* matrix-core arithmetic of the dense contractions */
 #define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
@@ -195,6 +195,12 @@ int vitae_sobel_edge_fwd(const float* vol, float* edge, const float* edge_ref, d
 int vitae_sobel_edge_bwd(const float* pred_vol, const float* edge_pred, const float* edge_tgt, const float* hp,
                          float* dG_ws, float* dpred, void* dpred_bf16, long pred_bstride, int B, int C, int Lz, int Hy,
                          int Wx, int p, void* stream);
+/* forward loss terms on the prediction in one pass (model/vit_autoenc.py:221-227): pred_vol = unpatchify(pred),
+ * edge_pred = Sobel magnitude of it, acc[VITAE_ACC_RECON] += masked MSE sum / P, acc[VITAE_ACC_EDGE] += sum
+ * (edge_pred - edge_tgt)^2.  C = 4: one LDS-tiled kernel; other C: recon_loss_fwd + unpatchify + sobel_edge_fwd. */
+int vitae_loss_fwd_fused(const float* pred, long pred_bstride, const float* imgs, const float* mask, const float* edge_tgt,
+                         float* pred_vol, float* edge_pred, double* acc, int B, int C, int Lz, int Hy, int Wx, int p,
+                         void* stream);
 /* whole loss backward in one pass (model/vit_autoenc.py:224-232 differentiated):
  * dpred = mask*2*g_recon*(pred-target)/(P*mask.sum()) + d(edge mse)/d pred, fp32 and optionally bf16.
  * C in {1,4}: one LDS-tiled kernel; other C: recon_bwd + the two Sobel backward kernels (needs dG_ws). */

@@ -470,6 +470,13 @@ def test_loss_chain(lib, C, C_, vol, p):
     assert float(dpred[:, 0].abs().max()) == 0.0
     assert rel_err(dpred, pr.grad) < 3e-5
     assert torch.equal(dpred16, dpred.to(torch.bfloat16))
+    # the one-pass forward the training step uses: same volume, edge map and sums as the three kernels above
+    acc2 = torch.zeros(C['VITAE_ACC_COUNT'], dtype=torch.float64, device='cuda')
+    pv2, ep2 = torch.empty_like(pv), torch.empty_like(ep)
+    lib.vitae_loss_fwd_fused(pp, pbs, im.data_ptr(), mk.data_ptr(), et.data_ptr(), pv2.data_ptr(), ep2.data_ptr(), acc2.data_ptr(),
+                             B, C_, *vol, p, st())
+    assert torch.equal(pv2, pv) and rel_err(ep2, trace['edge_pred']) < 1e-5
+    assert torch.allclose(acc2[:2].cpu(), acc[:2].cpu(), rtol=1e-5)
     # the one-pass backward (recon + edge) the training step uses
     dfu = torch.zeros(B, L + 1, P, device='cuda')
     dfu16 = torch.zeros(B, L + 1, P, dtype=torch.bfloat16, device='cuda')

@@ -390,6 +390,98 @@ __global__ __launch_bounds__(256) void sobel_mag_tiled_kernel(const float* __res
     }
 }
 
+// Forward loss terms on the prediction in ONE pass over it (C = 4): reads pred in patchify order (one 16-byte
+// load per voxel = its four channels), writes the unpatchified volume for the backward, the Sobel edge map, and
+// accumulates both loss sums:   acc[RECON] += sum_masked (pred - img)^2 / P,   acc[EDGE] += sum (E_pred - E_tgt)^2.
+// Replaces recon_fwd + unpatchify + sobel_mag_tiled (three passes over the 57 MB prediction).
+__global__ __launch_bounds__(256) void loss_fwd_fused_kernel(const float* __restrict__ pred, const float* __restrict__ imgs,
+                                                             const float* __restrict__ mask, const float* __restrict__ Et,
+                                                             float* __restrict__ pvol, float* __restrict__ Ep,
+                                                             double* __restrict__ acc, int xtiles, VolGeom g) {
+    constexpr int RZ = TZ + 2, RY = TY_ + 2, RX = TX + 2, NV = RZ * RY * RX, NLD = (NV + 255) / 256;
+    __shared__ f32x4 sv[NV];
+    __shared__ float red[4];
+    const int Lz = g.Lz, Hy = g.Hy, Wx = g.Wx, p = g.p;
+    const long V = (long)Lz * Hy * Wx;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int x0 = (blockIdx.x % xtiles) * TX, y0 = (blockIdx.x / xtiles) * TY_, z0 = blockIdx.y * TZ, b = blockIdx.z;
+    const float* pb = pred + (long)b * g.pred_bstride;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int idx = threadIdx.x + k * 256;
+        if (idx < NV) {
+            const int xx = idx % RX, r = idx / RX, yy = r % RY, zz = r / RY;
+            const int gx = x0 - 1 + xx, gy = y0 - 1 + yy, gz = z0 - 1 + zz;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gx >= 0 && gx < Wx && gy >= 0 && gy < Hy && gz >= 0 && gz < Lz) {
+                const int l = ((gz / p) * g.g1 + gy / p) * g.g2 + gx / p;
+                const int e0 = (((gz % p) * p + gy % p) * p + gx % p) * 4;
+                v = *reinterpret_cast<const f32x4*>(pb + (long)l * g.P + e0);
+            }
+            sv[idx] = v;
+        }
+    }
+    // this thread's column: image values and mask flags of its TZ voxels (issued before the barrier)
+    const int x = x0 + tx, y = y0 + ty;
+    const bool live = x < Wx && y < Hy;
+    const int xc = min(x, Wx - 1), yc = min(y, Hy - 1);
+    float im[4][TZ], mk[TZ], et[TZ];
+#pragma unroll
+    for (int tz = 0; tz < TZ; ++tz) {
+        const int z = min(z0 + tz, Lz - 1);
+        const int l = ((z / p) * g.g1 + yc / p) * g.g2 + xc / p;
+        mk[tz] = mask[(long)b * g.L + l];
+        const long o = ((long)z * Hy + yc) * Wx + xc;
+        et[tz] = Et[(long)b * V + o];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) im[c][tz] = imgs[((long)b * 4 + c) * V + o];
+    }
+    __syncthreads();
+    auto plane = [&](int zz, f32x4& A, f32x4& Bp, f32x4& Cp) {
+        const f32x4* row = sv + (zz * RY + ty) * RX + tx;
+        const f32x4 a0 = row[0], a1 = row[1], a2 = row[2];
+        const f32x4 b0 = row[RX], b1 = row[RX + 1], b2 = row[RX + 2];
+        const f32x4 c0 = row[2 * RX], c1 = row[2 * RX + 1], c2 = row[2 * RX + 2];
+        const f32x4 sa = a0 + 2.f * a1 + a2, sb = b0 + 2.f * b1 + b2, sc = c0 + 2.f * c1 + c2;
+        const f32x4 da = a0 - a2, db = b0 - b2, dc = c0 - c2;
+        A = da + 2.f * db + dc;
+        Bp = sc - sa;
+        Cp = sa + 2.f * sb + sc;
+    };
+    f32x4 A0, B0, C0, A1, B1, C1, A2, B2, C2;
+    plane(0, A0, B0, C0);
+    plane(1, A1, B1, C1);
+    float sq = 0.f, rc = 0.f;
+#pragma unroll
+    for (int zz = 2; zz < RZ; ++zz) {
+        plane(zz, A2, B2, C2);
+        const int tz = zz - 2, z = z0 + tz;
+        const f32x4 g0 = A0 + 2.f * A1 + A2, g1 = B0 + 2.f * B1 + B2, g2 = C2 - C0;
+        const f32x4 m2 = g0 * g0 + g1 * g1 + g2 * g2;
+        const float e = sqrtf(m2[0]) + sqrtf(m2[1]) + sqrtf(m2[2]) + sqrtf(m2[3]);
+        if (live && z < Lz) {
+            const long o = ((long)z * Hy + y) * Wx + x;
+            Ep[(long)b * V + o] = e;
+            const float d = e - et[tz];
+            sq += d * d;
+            const f32x4 pv = sv[((tz + 1) * RY + ty + 1) * RX + tx + 1];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                pvol[((long)b * 4 + c) * V + o] = pv[c];
+                if (mk[tz] != 0.f) { const float dd = pv[c] - im[c][tz]; rc += dd * dd; }
+            }
+        }
+        A0 = A1; B0 = B1; C0 = C1; A1 = A2; B1 = B2; C1 = C2;
+    }
+    sq = block_sum_256(sq, red);
+    __syncthreads();
+    rc = block_sum_256(rc, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(acc + VITAE_ACC_EDGE, (double)sq);
+        atomicAdd(acc + VITAE_ACC_RECON, (double)(rc / (float)g.P));
+    }
+}
+
 // Whole loss backward in one pass over the volume:
 //   dpred = mask * 2 g_recon (pred - img) / (P mask.sum())  +  d(edge mse)/d pred          (fp32 and optional bf16)
 // Per tile and channel: pred_vol tile + 2-voxel halo -> LDS; Sobel components on tile + 1 halo, scaled by
@@ -704,6 +796,24 @@ extern "C" int vitae_sobel_edge_bwd(const float* pred_vol, const float* edge_pre
     hipLaunchKernelGGL(sobel_bwd_scatter_kernel, dim3(stream_blocks(total)), dim3(256), 0, st, dG_ws, dpred,
                        reinterpret_cast<__bf16*>(dpred_bf16), B, g);
     return vitae_launch_status();
+}
+
+extern "C" int vitae_loss_fwd_fused(const float* pred, long pred_bstride, const float* imgs, const float* mask,
+                                    const float* edge_tgt, float* pred_vol, float* edge_pred, double* acc, int B, int C,
+                                    int Lz, int Hy, int Wx, int p, void* stream) {
+    if (!pred || !imgs || !mask || !edge_tgt || !pred_vol || !edge_pred || !acc || B <= 0 || p <= 0 || Lz % p || Hy % p || Wx % p)
+        return VITAE_ERR_INVALID_ARG;
+    VolGeom g = make_geom(C, Lz, Hy, Wx, p, pred_bstride);
+    hipStream_t st = (hipStream_t)stream;
+    const int xt = cdiv(Wx, TX), yt = cdiv(Hy, TY_), zt = cdiv(Lz, TZ);
+    if (C == 4 && zt <= 65535 && B <= 65535 && ((uintptr_t)pred % 16 == 0) && pred_bstride % 4 == 0) {
+        hipLaunchKernelGGL(loss_fwd_fused_kernel, dim3(xt * yt, zt, B), dim3(256), 0, st, pred, imgs, mask, edge_tgt, pred_vol,
+                           edge_pred, acc, xt, g);
+        return vitae_launch_status();
+    }
+    hipLaunchKernelGGL(recon_fwd_kernel, dim3(g.L, B), dim3(256), 0, st, pred, imgs, mask, acc, g);
+    hipLaunchKernelGGL(unpatchify_kernel, dim3(g.L, B), dim3(256), 0, st, pred, pred_vol, g);
+    return vitae_sobel_edge_fwd(pred_vol, edge_pred, edge_tgt, acc, B, C, Lz, Hy, Wx, stream);
 }
 
 extern "C" int vitae_loss_bwd_fused(const float* pred, const float* pred_vol, const float* imgs, const float* mask, const float* edge_pred,

@@ -201,17 +201,19 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ d
 }
 
 // ------------------------------------------------------------------ BatchNorm1d (+ReLU), training mode
-// Block = 32 feature columns x 8 row groups (256 threads): rows are strided over the 8 groups,
+// Block = BN_COLS feature columns x BN_GRPS row groups (256 threads): rows are strided over the groups,
 // column partials are combined through LDS.  R rows (R = B * Ne = 220 at config 2).  Two passes
 // (mean, then centred variance) like ATen's CPU batch_norm.  Saves mean / rstd, updates the running
 // stats with momentum and the unbiased variance (nn.BatchNorm1d semantics).
-__device__ __forceinline__ float bn_col_reduce(float v, float (*red)[32], int col, int grp) {
+constexpr int BN_COLS = 16, BN_GRPS = 16;   // 16 feature columns x 16 row groups per 256-thread block: 48 blocks at D = 768
+
+__device__ __forceinline__ float bn_col_reduce(float v, float (*red)[BN_COLS], int col, int grp) {
     __syncthreads();
     red[grp][col] = v;
     __syncthreads();
     float s = 0.f;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) s += red[g][col];
+    for (int g = 0; g < BN_GRPS; ++g) s += red[g][col];
     return s;
 }
 
@@ -221,21 +223,21 @@ __global__ __launch_bounds__(256) void bn1d_relu_fwd_kernel(const float* __restr
                                                             float* __restrict__ run_mean, float* __restrict__ run_var,
                                                             long long* __restrict__ num_batches_tracked,
                                                             int R, int D, float eps, float momentum) {
-    __shared__ float red[8][32];
+    __shared__ float red[BN_GRPS][BN_COLS];
     if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
-    const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + col;
+    const int col = threadIdx.x % BN_COLS, grp = threadIdx.x / BN_COLS;
+    const int c = blockIdx.x * BN_COLS + col;
     const bool ok = c < D;
     float s = 0.f;
-    if (ok) for (int r = grp; r < R; r += 8) s += x[(long)r * D + c];
+    if (ok) for (int r = grp; r < R; r += BN_GRPS) s += x[(long)r * D + c];
     const float mean = bn_col_reduce(s, red, col, grp) / R;
     float q = 0.f;
-    if (ok) for (int r = grp; r < R; r += 8) { const float d = x[(long)r * D + c] - mean; q += d * d; }
+    if (ok) for (int r = grp; r < R; r += BN_GRPS) { const float d = x[(long)r * D + c] - mean; q += d * d; }
     q = bn_col_reduce(q, red, col, grp);
     if (!ok) return;
     const float rstd = rsqrtf(q / R + eps);
     const float g = w[c], be = b[c];
-    for (int r = grp; r < R; r += 8) {
+    for (int r = grp; r < R; r += BN_GRPS) {
         const float v = (x[(long)r * D + c] - mean) * rstd * g + be;
         y[(long)r * D + c] = v > 0.f ? v : 0.f;
     }
@@ -254,13 +256,13 @@ __global__ __launch_bounds__(256) void bn1d_relu_bwd_kernel(const float* __restr
                                                             const float* __restrict__ save_mean,
                                                             const float* __restrict__ save_rstd, float* __restrict__ dx,
                                                             float* __restrict__ dw, float* __restrict__ db, int R, int D) {
-    __shared__ float red[8][32];
-    const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + col;
+    __shared__ float red[BN_GRPS][BN_COLS];
+    const int col = threadIdx.x % BN_COLS, grp = threadIdx.x / BN_COLS;
+    const int c = blockIdx.x * BN_COLS + col;
     const bool ok = c < D;
     const float mean = ok ? save_mean[c] : 0.f, rstd = ok ? save_rstd[c] : 0.f, g = ok ? w[c] : 0.f;
     float s1 = 0.f, s2 = 0.f;
-    if (ok) for (int r = grp; r < R; r += 8) {
+    if (ok) for (int r = grp; r < R; r += BN_GRPS) {
         const long i = (long)r * D + c;
         const float d = y[i] > 0.f ? dy[i] : 0.f;
         s1 += d; s2 += d * (x[i] - mean) * rstd;
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(256) void bn1d_relu_bwd_kernel(const float* __restr
     if (!ok) return;
     if (grp == 0) { atomicAdd(dw + c, s2); atomicAdd(db + c, s1); }
     const float m1 = s1 / R, m2 = s2 / R;
-    for (int r = grp; r < R; r += 8) {
+    for (int r = grp; r < R; r += BN_GRPS) {
         const long i = (long)r * D + c;
         const float d = y[i] > 0.f ? dy[i] : 0.f;
         dx[i] = g * rstd * (d - m1 - (x[i] - mean) * rstd * m2);
@@ -319,7 +321,7 @@ extern "C" int vitae_bn1d_relu_fwd(const float* x, const float* w, const float* 
                                    long long* num_batches_tracked, int R, int D, float eps, float momentum,
                                    void* stream) {
     if (!x || !w || !b || !y || !save_mean || !save_rstd || R <= 0 || D <= 0) return VITAE_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(bn1d_relu_fwd_kernel, dim3(cdiv(D, 32)), dim3(256), 0, (hipStream_t)stream, x, w, b, y,
+    hipLaunchKernelGGL(bn1d_relu_fwd_kernel, dim3(cdiv(D, BN_COLS)), dim3(256), 0, (hipStream_t)stream, x, w, b, y,
                        save_mean, save_rstd, running_mean, running_var, num_batches_tracked, R, D, eps, momentum);
     return vitae_launch_status();
 }
@@ -329,7 +331,7 @@ extern "C" int vitae_bn1d_relu_bwd(const float* dy, const float* x, const float*
                                    float* db, int R, int D, void* stream) {
     if (!dy || !x || !y || !w || !save_mean || !save_rstd || !dx || !dw || !db || R <= 0 || D <= 0)
         return VITAE_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(bn1d_relu_bwd_kernel, dim3(cdiv(D, 32)), dim3(256), 0, (hipStream_t)stream, dy, x, y, w,
+    hipLaunchKernelGGL(bn1d_relu_bwd_kernel, dim3(cdiv(D, BN_COLS)), dim3(256), 0, (hipStream_t)stream, dy, x, y, w,
                        save_mean, save_rstd, dx, dw, db, R, D);
     return vitae_launch_status();
 }

@@ -597,11 +597,9 @@ class HipMAEEngine:
             self._lin_fwd(b['dn'], p['decoder_pred.weight'], p['decoder_pred.bias'], b['predfull'], Md, P, Dd)
         # --- loss chain on pred = predfull[:, 1:, :]
         pred_ptr, pbs = b['predfull'].data_ptr() + P * 4, Nd * P
-        lib.vitae_recon_loss_fwd(pred_ptr, pbs, _ptr(view1), _ptr(b['mask']), _ptr(self.acc), B, C, Lz, Hy, Wx, ps, st)
-        lib.vitae_unpatchify(pred_ptr, pbs, _ptr(b['pred_vol']), B, C, Lz, Hy, Wx, ps, st)
         torch.cuda.current_stream(self.device).wait_stream(self.side)   # edge map of the blurred target is ready
-        lib.vitae_sobel_edge_fwd(_ptr(b['pred_vol']), _ptr(b['edge_p']), _ptr(b['edge_t']), _ptr(self.acc), B, C, Lz, Hy,
-                                 Wx, st)
+        lib.vitae_loss_fwd_fused(pred_ptr, pbs, _ptr(view1), _ptr(b['mask']), _ptr(b['edge_t']), _ptr(b['pred_vol']),
+                                 _ptr(b['edge_p']), _ptr(self.acc), B, C, Lz, Hy, Wx, ps, st)
         lib.vitae_loss_finalize(_ptr(self.acc), _ptr(self.hp), _ptr(self.losses), self.mask_sum, self.edge_count, st)
         # --- predictor on both views (vit_autoenc.py:280-284)
         if cfg.contrastive:
