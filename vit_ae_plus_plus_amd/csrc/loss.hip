@@ -490,7 +490,7 @@ __global__ __launch_bounds__(256) void loss_fwd_fused_kernel(const float* __rest
 // All C channels of a voxel are adjacent in patchify order, so they are collected in registers and stored as
 // one vector per voxel.
 template <int CH>
-__global__ __launch_bounds__(256) void loss_bwd_fused_kernel(const float* __restrict__ pvol, const float* __restrict__ imgs,
+__global__ __launch_bounds__(256, 2) void loss_bwd_fused_kernel(const float* __restrict__ pvol, const float* __restrict__ imgs,
                                                              const float* __restrict__ mask, const float* __restrict__ Ep,
                                                              const float* __restrict__ Et, const float* __restrict__ hp,
                                                              float* __restrict__ dpred, __bf16* __restrict__ dpred16,
@@ -530,39 +530,49 @@ __global__ __launch_bounds__(256) void loss_bwd_fused_kernel(const float* __rest
     const bool live = x < Wx && y < Hy;
     const int xc = min(x, Wx - 1), yc = min(y, Hy - 1);
     // reconstruction-term inputs of this thread's TZ voxels: mask flags now, image values per channel (below)
-    float mk[TZ], im[TZ];
+    float im[TZ];
+    unsigned mkbits = 0u;
 #pragma unroll
     for (int tz = 0; tz < TZ; ++tz) {
         const int z = min(z0 + tz, Lz - 1);
         const int l = ((z / g.p) * g.g1 + yc / g.p) * g.g2 + xc / g.p;
-        mk[tz] = mask[(long)b * g.L + l];
+        mkbits |= (mask[(long)b * g.L + l] != 0.f ? 1u : 0u) << tz;
     }
+    // The pred_vol tile (+ 2-voxel halo) of a channel goes HBM -> LDS by DMA (global_load_lds, 4 B per lane, LDS
+    // destination lane-linear = the flat tile index): the element offsets are computed once and reused for every
+    // channel (the index arithmetic was a third of the kernel's instructions), no registers hold data in flight,
+    // and the next channel's tile is fetched underneath the transposed stencils.  Out-of-volume elements are zeroed
+    // once and never written again (their lanes are masked out of the DMA).
     constexpr int NLD = (VZ * VY * VX + 255) / 256;
-    float pre[NLD];
+    int off[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int idx = threadIdx.x + k * 256;
+        const int xx = idx % VX, r = idx / VX, yy = r % VY, zz = r / VY;
+        const int gx = x0 - 2 + xx, gy = y0 - 2 + yy, gz = z0 - 2 + zz;
+        const bool in = idx < VZ * VY * VX && gx >= 0 && gx < Wx && gy >= 0 && gy < Hy && gz >= 0 && gz < Lz;
+        off[k] = in ? (gz * Hy + gy) * Wx + gx : -1;
+        if (!in && idx < VZ * VY * VX) sv[idx] = 0.f;
+    }
+    const int wave_base = (threadIdx.x >> 6) * 64;
     auto fetch = [&](int c) {
         const float* src = pvol + ((long)b * g.C + c) * V;
 #pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int idx = threadIdx.x + k * 256;
-            const int xx = idx % VX, r = idx / VX, yy = r % VY, zz = r / VY;
-            const int gx = x0 - 2 + xx, gy = y0 - 2 + yy, gz = z0 - 2 + zz;
-            const bool in = idx < VZ * VY * VX && gx >= 0 && gx < Wx && gy >= 0 && gy < Hy && gz >= 0 && gz < Lz;
-            pre[k] = in ? src[((long)gz * Hy + gy) * Wx + gx] : 0.f;
-        }
+        for (int k = 0; k < NLD; ++k)
+            if (off[k] >= 0)
+                __builtin_amdgcn_global_load_lds(src + off[k], (__attribute__((address_space(3))) void*)(sv + k * 256 + wave_base),
+                                                 4, 0, 0);
     };
     fetch(0);
     for (int c = 0; c < CH; ++c) {
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int idx = threadIdx.x + k * 256;
-            if (idx < VZ * VY * VX) sv[idx] = pre[k];
-        }
-        __syncthreads();
-        if (c + 1 < CH) fetch(c + 1);    // next channel's tile flies underneath this channel's stencils
 #pragma unroll
         for (int tz = 0; tz < TZ; ++tz)
             im[tz] = imgs[((long)b * g.C + c) * V + ((long)min(z0 + tz, Lz - 1) * Hy + yc) * Wx + xc];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's DMA pieces of channel c landed
+        __syncthreads();                                     // ... everyone's; last channel's sg readers are done
+        float pvc[TZ];
+#pragma unroll
+        for (int tz = 0; tz < TZ; ++tz) pvc[tz] = sv[((tz + 2) * VY + ty + 2) * VX + tx + 2];
         // ---- dG on the halo-1 region, one (y, x) column per thread (and a second one for the first threads)
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
@@ -579,7 +589,7 @@ __global__ __launch_bounds__(256) void loss_bwd_fused_kernel(const float* __rest
                     const float g0 = A0 + 2.f * A1 + A2, g1 = B0 + 2.f * B1 + B2, g2 = C2 - C0;
                     const float d = de[ps][vz - 2];
                     const bool in = d == d;
-                    const float f = d / sqrtf(g0 * g0 + g1 * g1 + g2 * g2);
+                    const float f = d * __builtin_amdgcn_rsqf(g0 * g0 + g1 * g1 + g2 * g2);   // |g| = 0 -> inf -> NaN below
                     const int gi = ((vz - 2) * GY + cy) * GX + cx;
                     sg[0][gi] = in ? f * g0 : 0.f;
                     sg[1][gi] = in ? f * g1 : 0.f;
@@ -589,6 +599,7 @@ __global__ __launch_bounds__(256) void loss_bwd_fused_kernel(const float* __rest
             }
         }
         __syncthreads();
+        if (c + 1 < CH) fetch(c + 1);    // sv is free: next channel's tile flies underneath the transposed stencils
         // ---- transposed stencils: dvol = s(z)[ s(y)e(x) G0 + d(y)s(x) G1 ] + d(z) s(y)s(x) G2
         float Q0, P0, Q1, P1, Q2, P2;
         auto plane = [&](int gz, float& Q, float& P) {
@@ -609,7 +620,7 @@ __global__ __launch_bounds__(256) void loss_bwd_fused_kernel(const float* __rest
             plane(gz, Q2, P2);
             const int tz = gz - 2;
             float val = (Q0 + 2.f * Q1 + Q2) + (P0 - P2);
-            if (mk[tz] != 0.f) val = cr * (sv[((tz + 2) * VY + ty + 2) * VX + tx + 2] - im[tz]) + val;
+            if ((mkbits >> tz) & 1u) val = cr * (pvc[tz] - im[tz]) + val;
             o[c][tz] = val;
             Q0 = Q1; P0 = P1; Q1 = Q2; P1 = P2;
         }
