@@ -294,3 +294,61 @@ def test_checkpoint_wire_format_both_ways(tmp_path):
     k = 'decoder_pred.weight'
     upd = (tr2.state_dict()[k] - ck['model'][k]).double().norm()
     assert float((model.state_dict()[k].cpu().double() - tr2.state_dict()[k].double()).norm() / upd) < 0.05
+
+
+def _one_step_vs_oracle(cfg, B, precision, seed, loss_tol, gnorm_tol):
+    """Forward + backward of one batch through the drop-in model vs the CPU oracle on identical weights, inputs and
+    masking noise: loss scalars and per-parameter gradient norms."""
+    from vit_ae_plus_plus_amd.utils.train_one_epoch import compute_contrastive_loss
+    sd = R.init_state_dict(cfg, seed=seed)
+    model = build(cfg, sd, precision=precision)
+    model.train(True)
+    v1, v2 = R.synthetic_views((B, cfg.in_chans, *cfg.volume_size), seed=1234)
+    noises = R.masking_noise(B, cfg.num_patches, seed=77)
+    params = R.make_leaf_params(sd)
+    if cfg.contrastive:
+        loss, pred, mask, p1, p2, z1, z2 = R.contr_forward(params, v1, v2, noises[0], noises[1], cfg, 0.75, 0.01)
+        total = loss[0] + R.contrastive_loss(p1, p2, z1, z2, 0.001)
+    else:
+        loss, pred, mask = R.mae_forward(params, v1, noises[0], cfg, 0.75, 0.01)
+        total = loss[0]
+    total.backward()
+    if cfg.contrastive:
+        model.set_masking_noise(*noises)
+        out = model(view1=v1.cuda(), view2=v2.cuda(), mask_ratio=0.75, edge_map_weight=0.01)
+        gl = out[0]
+        gtotal = gl[0] + compute_contrastive_loss(argparse.Namespace(contr_weight=0.001), None, *out[3:])
+    else:
+        model.set_masking_noise(noises[0])
+        gl, gpred, gmask = model(v1.cuda(), mask_ratio=0.75, edge_map_weight=0.01)
+        gtotal = gl[0]
+        assert float(gmask.sum()) == float(mask.sum())
+    gtotal.backward()
+    for a, b in zip(gl[:3], loss[:3]):
+        close(a, b, loss_tol, 1e-7)
+    named = dict(model.named_parameters())
+    worst = 0.0
+    for k, p in params.items():
+        if not p.requires_grad or p.grad is None:
+            continue
+        ref = float(p.grad.double().norm())
+        got = float(named[k].grad.double().norm())
+        if ref > 1e-6 * max(1.0, float(total.detach())):
+            worst = max(worst, abs(got - ref) / ref)
+    assert worst < gnorm_tol, worst
+
+
+@pytest.mark.parametrize('precision,loss_tol,gnorm_tol', [('fp32', 1e-4, 2e-3), ('bf16', 2e-3, 5e-2)])
+def test_config4_vit_large_128(precision, loss_tol, gnorm_tol):
+    """BASELINE config 4: ViT-L/16 autoencoder, 128^3 x 4ch (129 encoder / 513 decoder tokens — the decoder exceeds the
+    one-launch attention backward's LDS budget, so the two-kernel path runs), B = 1, against the oracle."""
+    cfg = R.vit_large_cfg(volume_size=(128, 128, 128), patch_size=16, in_chans=4, contrastive=False)
+    _one_step_vs_oracle(cfg, 1, precision, seed=2, loss_tol=loss_tol, gnorm_tol=gnorm_tol)
+
+
+@pytest.mark.parametrize('precision,loss_tol,gnorm_tol', [('fp32', 1e-4, 2e-3), ('bf16', 2e-3, 5e-2)])
+def test_config5_anisotropic_egd_shape(precision, loss_tol, gnorm_tol):
+    """BASELINE config 5: EGD-shape 192 x 192 x 32 x 1ch volumes, ViT-B (non-cubic patch grid 12 x 12 x 2).  The reference
+    cannot construct this model, so the pin is the oracle's non-cubic generalisation."""
+    cfg = R.vit_base_cfg(volume_size=(192, 192, 32), patch_size=16, in_chans=1, contrastive=True)
+    _one_step_vs_oracle(cfg, 2, precision, seed=4, loss_tol=loss_tol, gnorm_tol=gnorm_tol)
