@@ -26,7 +26,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 #ifndef VITAE_GLDS_NS
 #define VITAE_GLDS_NS 3
 #endif
-constexpr int BM = 64, BK = 64, NS = VITAE_GLDS_NS;
+constexpr int BK = 64, NS = VITAE_GLDS_NS;
 
 struct GArgs {
     const __bf16* A; long lda;
@@ -156,14 +156,17 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BN> struct GCfg {
+// Workgroup tile BM x BN (64x64, 64x128 or 128x128), four waves in a 2 x 2 arrangement: each wave owns
+// (BM/2) x (BN/2) = FM x FN accumulator fragments of 32x32.  128x128 doubles the flop per LDS byte and per L2 byte
+// (64 flop/B from L2 instead of 32) and is picked when a GEMM has enough such tiles to fill the chip.
+template <int BM, int BN> struct GCfg {
     static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES, SMEM = NS * STAGE;
 };
 
-template <int BN, bool A_KC, bool B_KC>
+template <int BM, int BN, bool A_KC, bool B_KC>
 __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, const int zid, unsigned char* smem) {
-    constexpr int FN = BN / 64;
-    constexpr int A_BYTES = GCfg<BN>::A_BYTES, STAGE = GCfg<BN>::STAGE;
+    constexpr int FM = BM / 64, FN = BN / 64, NF = FM * FN;
+    constexpr int A_BYTES = GCfg<BM, BN>::A_BYTES, STAGE = GCfg<BM, BN>::STAGE;
     constexpr int G = (BM + BN) / 32;                      // DMA instructions per wave per stage
     const int xcd = bid & 7, local = bid >> 3;
     const int tn = xcd + 8 * (local / p.tiles_m), tm = local % p.tiles_m;
@@ -179,11 +182,11 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
 
     // two accumulators per output fragment (even / odd 16-deep k-slices): consecutive MFMAs never depend
     // on each other, so the matrix pipe is not serialised on the 32x32 accumulate latency
-    f32x16 acc[2][FN];
+    f32x16 acc[2][NF];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int f = 0; f < FN; ++f)
+        for (int f = 0; f < NF; ++f)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[h][f][i] = 0.f;
 
@@ -205,23 +208,27 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
         if (t + NS - 1 < nk) issue(t + NS - 1);   // refills the stage tile t-1 used
         const unsigned char* at = smem + (t % NS) * STAGE;
         const unsigned char* bt = at + A_BYTES;
-        bf16x8 fa[BK / 16], fb[BK / 16][FN];
+        bf16x8 fa[BK / 16][FM], fb[BK / 16][FN];
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
-            fa[kk] = frag<BM, A_KC>(at, wm * 32, kk, lane);
+#pragma unroll
+            for (int f = 0; f < FM; ++f) fa[kk][f] = frag<BM, A_KC>(at, wm * (BM / 2) + f * 32, kk, lane);
 #pragma unroll
             for (int f = 0; f < FN; ++f) fb[kk][f] = frag<BN, B_KC>(bt, wn * (BN / 2) + f * 32, kk, lane);
         }
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk)
 #pragma unroll
-            for (int f = 0; f < FN; ++f)
-                acc[kk & 1][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk], fb[kk][f], acc[kk & 1][f], 0, 0, 0);
+            for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+                for (int fn = 0; fn < FN; ++fn)
+                    acc[kk & 1][fm * FN + fn] =
+                        __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][fm], fb[kk][fn], acc[kk & 1][fm * FN + fn], 0, 0, 0);
     }
 
-    float a[FN][16];
+    float a[NF][16];
 #pragma unroll
-    for (int f = 0; f < FN; ++f)
+    for (int f = 0; f < NF; ++f)
 #pragma unroll
         for (int r = 0; r < 16; ++r) a[f][r] = acc[0][f][r] + acc[1][f][r];
 
@@ -236,7 +243,7 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
         float* part = p.ws + VITAE_GLDS_TICKETS + ((long)tile * p.splits) * (BM * BN);
         int* ticket = reinterpret_cast<int*>(p.ws) + tile;
 #pragma unroll
-        for (int f = 0; f < FN; ++f)
+        for (int f = 0; f < NF; ++f)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 __hip_atomic_store(&part[(long)zid * (BM * BN) + (f * 16 + r) * 256 + threadIdx.x], a[f][r], __ATOMIC_RELAXED,
@@ -248,12 +255,12 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
         __syncthreads();
         if (*flag != p.splits - 1) return;
 #pragma unroll
-        for (int f = 0; f < FN; ++f)
+        for (int f = 0; f < NF; ++f)
 #pragma unroll
             for (int r = 0; r < 16; ++r) a[f][r] = 0.f;
         for (int sp = 0; sp < p.splits; ++sp)
 #pragma unroll
-            for (int f = 0; f < FN; ++f)
+            for (int f = 0; f < NF; ++f)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     a[f][r] += __hip_atomic_load(&part[(long)sp * (BM * BN) + (f * 16 + r) * 256 + threadIdx.x], __ATOMIC_RELAXED,
@@ -262,9 +269,11 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
     }
 
 #pragma unroll
-    for (int f = 0; f < FN; ++f) {
-        const int n = n0 + wn * (BN / 2) + f * 32 + l31;
-        float csum = epilogue_frag(p, a[f], m0 + wm * 32, n, hi);
+    for (int fn = 0; fn < FN; ++fn) {
+        const int n = n0 + wn * (BN / 2) + fn * 32 + l31;
+        float csum = 0.f;
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) csum += epilogue_frag(p, a[fm * FN + fn], m0 + wm * (BM / 2) + fm * 32, n, hi);
         if (p.out_colsum) {
             csum += __shfl_xor(csum, 32, 64);
             if (hi == 0 && n < p.N) atomicAdd(p.out_colsum + n, csum);
@@ -272,35 +281,53 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
     }
 }
 
-template <int BN, bool A_KC, bool B_KC>
+template <int BM, int BN, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void gemm_glds_kernel(const GArgs p) {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[GCfg<BN>::SMEM];   // the ONLY LDS object
-    gemm_glds_body<BN, A_KC, B_KC>(p, blockIdx.x, blockIdx.z, smem);
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[GCfg<BM, BN>::SMEM];   // the ONLY LDS object
+    gemm_glds_body<BM, BN, A_KC, B_KC>(p, blockIdx.x, blockIdx.z, smem);
 }
 
 // dgrad (dy @ W: A k-contiguous, B = bf16 weights read row-contiguous) and wgrad (dy^T @ x: both operands
 // row-contiguous) of one Linear in one launch — they share dy, and together they double the resident
 // workgroups per CU.
-template <int BN1, int BN2>
+template <int BM1, int BN1, int BM2, int BN2>
 __global__ __launch_bounds__(256) void gemm_glds_pair_kernel(const GArgs p1, const GArgs p2, const int nb1) {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[GCfg<(BN1 > BN2 ? BN1 : BN2)>::SMEM];
+    constexpr int S1 = GCfg<BM1, BN1>::SMEM, S2 = GCfg<BM2, BN2>::SMEM;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[S1 > S2 ? S1 : S2];
     // nb1 = workgroups of one dgrad split; the dgrad's long reduction (N of the Linear) is cut into p1.splits
-    if ((int)blockIdx.x < nb1 * p1.splits) gemm_glds_body<BN1, true, false>(p1, blockIdx.x % nb1, blockIdx.x / nb1, smem);
-    else gemm_glds_body<BN2, false, false>(p2, blockIdx.x - nb1 * p1.splits, 0, smem);
+    if ((int)blockIdx.x < nb1 * p1.splits) gemm_glds_body<BM1, BN1, true, false>(p1, blockIdx.x % nb1, blockIdx.x / nb1, smem);
+    else gemm_glds_body<BM2, BN2, false, false>(p2, blockIdx.x - nb1 * p1.splits, 0, smem);
 }
 
-template <int BN>
+template <int BM, int BN>
 void launch(const GArgs& p, bool a_kc, bool b_kc, dim3 grid, hipStream_t st) {
     dim3 block(256);
-    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_glds_kernel<BN, true, true>), grid, block, 0, st, p);
-    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_glds_kernel<BN, true, false>), grid, block, 0, st, p);
-    else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_glds_kernel<BN, false, true>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((gemm_glds_kernel<BN, false, false>), grid, block, 0, st, p);
+    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, true, true>), grid, block, 0, st, p);
+    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, true, false>), grid, block, 0, st, p);
+    else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, false, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, false, false>), grid, block, 0, st, p);
 }
 
-inline int pick_bn(int M, int N) {
-    if (N < 128) return 64;
-    return (long)cdiv(M, BM) * cdiv(N, 128) >= 400 ? 128 : 64;
+struct Tile { int bm, bn, id; };
+
+// 0: 64x64, 1: 64x128, 2: 128x128 — the largest tile that still yields enough workgroups for 256 CUs.
+// 128x128 is OFF by default (VITAE_GLDS_T128 = minimum tile count to use it): with 128 accumulator + 150 other
+// registers and 96 KB of LDS only one 4-wave workgroup fits a CU, and the DMA / LDS / MFMA chain of a single workgroup
+// does not overlap with anything — measured slower than 64x128 at two workgroups per CU on every large GEMM of the
+// step (decoder_pred fwd 54.7 -> 72.5 us, its wgrad 85.7 -> 148 us).  Kept for the 8-wave version.
+inline Tile pick_tile(int M, int N) {
+    static const int t128 = getenv("VITAE_GLDS_T128") ? atoi(getenv("VITAE_GLDS_T128")) : 0;
+    if (N >= 128 && M >= 128 && t128 > 0 && (long)cdiv(M, 128) * cdiv(N, 128) >= t128) return {128, 128, 2};
+    if (N >= 128 && (long)cdiv(M, 64) * cdiv(N, 128) >= 400) return {64, 128, 1};
+    return {64, 64, 0};
+}
+
+template <int BM1, int BN1>
+void launch_pair(int id2, dim3 grid, hipStream_t st, const GArgs& p1, const GArgs& p2, int nb1) {
+    dim3 block(256);
+    if (id2 == 0) hipLaunchKernelGGL((gemm_glds_pair_kernel<BM1, BN1, 64, 64>), grid, block, 0, st, p1, p2, nb1);
+    else if (id2 == 1) hipLaunchKernelGGL((gemm_glds_pair_kernel<BM1, BN1, 64, 128>), grid, block, 0, st, p1, p2, nb1);
+    else hipLaunchKernelGGL((gemm_glds_pair_kernel<BM1, BN1, 128, 128>), grid, block, 0, st, p1, p2, nb1);
 }
 
 }  // namespace
@@ -308,8 +335,8 @@ inline int pick_bn(int M, int N) {
 extern "C" int vitae_gemm_glds_pick_split_k(int M, int N, int K) {
     static const int min_kt = getenv("VITAE_GLDS_SPLIT_MIN_KT") ? atoi(getenv("VITAE_GLDS_SPLIT_MIN_KT")) : 8;
     static const int target = getenv("VITAE_GLDS_SPLIT_BLOCKS") ? atoi(getenv("VITAE_GLDS_SPLIT_BLOCKS")) : 384;
-    const int bn = pick_bn(M, N);
-    const long tiles = (long)cdiv(M, BM) * cdiv(N, bn);
+    const Tile t = pick_tile(M, N);
+    const long tiles = (long)cdiv(M, t.bm) * cdiv(N, t.bn);
     if (tiles >= target / 2 || tiles > VITAE_GLDS_TICKETS) return 1;
     long s = (target + tiles - 1) / tiles;
     const long max_by_k = K / (BK * min_kt);   // >= min_kt k-tiles per split
@@ -320,8 +347,8 @@ extern "C" int vitae_gemm_glds_pick_split_k(int M, int N, int K) {
 
 extern "C" long vitae_gemm_glds_ws_floats(int M, int N, int split_k) {
     if (split_k <= 1) return 0;
-    const int bn = pick_bn(M, N);
-    return VITAE_GLDS_TICKETS + (long)cdiv(M, BM) * cdiv(N, bn) * split_k * BM * bn;
+    const Tile t = pick_tile(M, N);
+    return VITAE_GLDS_TICKETS + (long)cdiv(M, t.bm) * cdiv(N, t.bn) * split_k * t.bm * t.bn;
 }
 
 extern "C" int vitae_gemm_glds(int a_kcontig, int b_kcontig, const void* A16, long lda, const void* B16, long ldb,
@@ -350,13 +377,14 @@ extern "C" int vitae_gemm_glds(int a_kcontig, int b_kcontig, const void* A16, lo
     p.k_per_split = kps; p.splits = split_k;
     p.bias = bias; p.residual = residual; p.ldr = ldr; p.aux = aux; p.ldaux = ldaux;
     p.epi = epi; p.accumulate = accumulate; p.ws = splitk_ws; p.out_colsum = out_colsum_accum;
-    const int bn = pick_bn(M, N);
-    p.tiles_m = cdiv(M, BM); p.tiles_n = cdiv(N, bn);
+    const Tile t = pick_tile(M, N);
+    p.tiles_m = cdiv(M, t.bm); p.tiles_n = cdiv(N, t.bn);
     if (split_k > 1 && (long)p.tiles_m * p.tiles_n > VITAE_GLDS_TICKETS) return VITAE_ERR_UNSUPPORTED_SHAPE;
     dim3 grid(8 * cdiv(p.tiles_n, 8) * p.tiles_m, 1, split_k);
     hipStream_t st = (hipStream_t)stream;
-    if (bn == 128) launch<128>(p, a_kcontig != 0, b_kcontig != 0, grid, st);
-    else launch<64>(p, a_kcontig != 0, b_kcontig != 0, grid, st);
+    if (t.id == 2) launch<128, 128>(p, a_kcontig != 0, b_kcontig != 0, grid, st);
+    else if (t.id == 1) launch<64, 128>(p, a_kcontig != 0, b_kcontig != 0, grid, st);
+    else launch<64, 64>(p, a_kcontig != 0, b_kcontig != 0, grid, st);
     return vitae_launch_status();
 }
 
@@ -372,7 +400,8 @@ extern "C" int vitae_linear_bwd_pair_pick_split_k(int M, int Mpad, int N, int K)
     int s = (ks1 + (ks2 > target ? ks2 : target) / 2) / (ks2 > target ? ks2 : target);
     if (s > 8) s = 8;
     while (s > 1 && ks1 / s < 4) --s;
-    if ((long)cdiv(M, BM) * cdiv(K, pick_bn(M, K)) > VITAE_GLDS_TICKETS) s = 1;
+    const Tile t1 = pick_tile(M, K);
+    if ((long)cdiv(M, t1.bm) * cdiv(K, t1.bn) > VITAE_GLDS_TICKETS) s = 1;
     return s < 1 ? 1 : s;
 }
 
@@ -395,22 +424,21 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
     p1.M = M; p1.N = K; p1.K = N; p1.k_per_split = kps; p1.splits = split_k;
     p1.bias = nullptr; p1.residual = nullptr; p1.ldr = 0; p1.aux = aux; p1.ldaux = K; p1.epi = epi; p1.accumulate = 0;
     p1.ws = splitk_ws; p1.out_colsum = dx_colsum_accum;
-    const int bn1 = pick_bn(M, K);
-    p1.tiles_m = cdiv(M, BM); p1.tiles_n = cdiv(K, bn1);
+    const Tile t1 = pick_tile(M, K);
+    p1.tiles_m = cdiv(M, t1.bm); p1.tiles_n = cdiv(K, t1.bn);
     p2.A = reinterpret_cast<const __bf16*>(dy16); p2.lda = N;
     p2.B = reinterpret_cast<const __bf16*>(x16); p2.ldb = K;
     p2.C = dw; p2.ldc = K; p2.C16 = nullptr; p2.ldc16 = 0;
     p2.M = N; p2.N = K; p2.K = Mpad; p2.k_per_split = Mpad; p2.splits = 1;
     p2.bias = nullptr; p2.residual = nullptr; p2.ldr = 0; p2.aux = nullptr; p2.ldaux = 0; p2.epi = VITAE_EPI_NONE;
     p2.accumulate = dw_accumulate; p2.ws = nullptr; p2.out_colsum = nullptr;
-    const int bn2 = pick_bn(N, K);
-    p2.tiles_m = cdiv(N, BM); p2.tiles_n = cdiv(K, bn2);
+    const Tile t2 = pick_tile(N, K);
+    p2.tiles_m = cdiv(N, t2.bm); p2.tiles_n = cdiv(K, t2.bn);
     const int nb1 = 8 * cdiv(p1.tiles_n, 8) * p1.tiles_m, nb2 = 8 * cdiv(p2.tiles_n, 8) * p2.tiles_m;
-    dim3 grid(nb1 * split_k + nb2), block(256);
+    dim3 grid(nb1 * split_k + nb2);
     hipStream_t st = (hipStream_t)stream;
-    if (bn1 == 64 && bn2 == 64) hipLaunchKernelGGL((gemm_glds_pair_kernel<64, 64>), grid, block, 0, st, p1, p2, nb1);
-    else if (bn1 == 64) hipLaunchKernelGGL((gemm_glds_pair_kernel<64, 128>), grid, block, 0, st, p1, p2, nb1);
-    else if (bn2 == 64) hipLaunchKernelGGL((gemm_glds_pair_kernel<128, 64>), grid, block, 0, st, p1, p2, nb1);
-    else hipLaunchKernelGGL((gemm_glds_pair_kernel<128, 128>), grid, block, 0, st, p1, p2, nb1);
+    if (t1.id == 2) launch_pair<128, 128>(t2.id, grid, st, p1, p2, nb1);
+    else if (t1.id == 1) launch_pair<64, 128>(t2.id, grid, st, p1, p2, nb1);
+    else launch_pair<64, 64>(t2.id, grid, st, p1, p2, nb1);
     return vitae_launch_status();
 }
