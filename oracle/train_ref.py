@@ -83,7 +83,7 @@ class RefTrainer:
             norm = self.grad_norm()
             self.optimizer.step()
             self.optimizer.zero_grad()
-        return {k: float(v) for k, v in terms.items()}, norm, outs
+        return {k: float(v.detach()) for k, v in terms.items()}, norm, outs
 
 
 def train_one_stage_epoch_ref(trainer: RefTrainer, batches: Iterable, epoch: int, *, lr: float,

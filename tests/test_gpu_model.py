@@ -352,3 +352,46 @@ def test_config5_anisotropic_egd_shape(precision, loss_tol, gnorm_tol):
     cannot construct this model, so the pin is the oracle's non-cubic generalisation."""
     cfg = R.vit_base_cfg(volume_size=(192, 192, 32), patch_size=16, in_chans=1, contrastive=True)
     _one_step_vs_oracle(cfg, 2, precision, seed=4, loss_tol=loss_tol, gnorm_tol=gnorm_tol)
+
+
+ACT16 = dict(volume_size=(16, 16, 16), patch_size=4, in_chans=4, embed_dim=64, depth=2, num_heads=2,
+             decoder_embed_dim=64, decoder_depth=1, decoder_num_heads=2)   # every contraction length % 64 == 0
+
+
+@pytest.mark.parametrize('name,dims,precision,tol', [('generic', MICRO, 'fp32', 2e-4), ('act16', ACT16, 'bf16', 2e-2)])
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_gradient_accumulation_matches_oracle(name, dims, precision, tol, use_graph):
+    """accum_iter = 2 (utils/train_one_epoch.py:44-74: loss / accum_iter, optimizer step every second iteration) over
+    four iterations against the oracle loop; 'act16' exercises the bf16-operand GEMM path's accumulate flags."""
+    from vit_ae_plus_plus_amd.utils import misc
+    from vit_ae_plus_plus_amd.utils.train_one_epoch import train_one_stage_epoch
+    cfg = R.RefConfig(contrastive=True, **dims)
+    sd = R.init_state_dict(cfg, seed=9)
+    lr, wd, B = 2e-3, 0.05, 2
+    batches, noises = [], []
+    for i in range(4):
+        v1, v2 = R.synthetic_views((B, cfg.in_chans, *cfg.volume_size), seed=500 + i)
+        batches.append((v1, v2, torch.zeros(B)))
+        noises.append(R.masking_noise(B, cfg.num_patches, seed=600 + i))
+    tr = T.RefTrainer(cfg, sd, lr=lr, weight_decay=wd)
+    ref = T.train_one_stage_epoch_ref(tr, batches, 0, lr=lr, min_lr=0.0, warmup_epochs=0, epochs=50, mask_ratio=0.75,
+                                      contr_weight=0.001, edge_map_weight=0.01, accum_iter=2, noises=noises)
+    model = build(cfg, sd, precision=precision)
+    if name == 'act16':
+        model._ensure_engine(torch.device('cuda', 0))
+        assert model.engine.act16
+    model.set_masking_noise(*[n for pair in noises for n in pair])
+    named = dict(model.named_parameters())
+    opt = _ref_adamw(named, lr, wd)
+    args = argparse.Namespace(accum_iter=2, mask_ratio=0.75, contr_weight=0.001, lr=lr, min_lr=0.0, warmup_epochs=0, epochs=50,
+                              hip_graph=use_graph, no_fused_step=False)
+    stats = train_one_stage_epoch(model, batches, opt, torch.device('cuda'), 0, misc.NativeScalerWithGradNormCount(),
+                                  log_writer=None, args=args, edge_map_weight=0.01)
+    for k in ('loss', 'reconstruction_loss', 'edge_map_loss', 'lr'):
+        close(stats[k], ref[k], tol, 1e-7)
+    ref_sd = tr.state_dict()
+    for k in ('decoder_pred.weight', 'blocks.0.mlp.fc1.weight', 'blocks.1.attn.qkv.weight', 'patch_embed.proj.weight',
+              'decoder_blocks.0.attn.proj.weight', 'norm.weight'):
+        upd = (ref_sd[k] - sd[k]).double().norm()
+        err = float((model.state_dict()[k].cpu().double() - ref_sd[k].double()).norm() / upd)
+        assert err < (0.05 if precision == 'fp32' else 0.25), (k, err)
