@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITAE_ABI_VERSION 14
+#define VITAE_ABI_VERSION 15
 
 /* matrix-core arithmetic of the dense contractions */
 #define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
@@ -173,6 +173,14 @@ int vitae_decoder_assemble_fwd(const float* e, const float* mask_token, const fl
                                float* xd, int B, int L, int keep, int Dd, void* stream);
 int vitae_decoder_assemble_bwd(const float* dxd, const int* ids_shuffle, float* de, float* dmask_token_accum, int B,
                                int L, int keep, int Dd, void* stream);
+
+/* ---- input normalisation (dataset/brats_dataset/brats.py:26-37, dataset/egd_dataset/egd.py:44-55) ---------------
+ * `groups` contiguous runs of n elements, each normalised on its own: z-score with the unbiased variance, min-max
+ * to [-1, 1], or min-max to [0, 1].  ws: 3 doubles per group (scratch).  In place allowed (y == x). */
+#define VITAE_NORM_ZSCORE 0
+#define VITAE_NORM_MINMAX_PM1 1
+#define VITAE_NORM_MINMAX_01 2
+int vitae_normalize_volumes(const float* x, float* y, double* ws, int groups, long n, int mode, void* stream);
 
 /* ---- loss chain ----------------------------------------------------------------------------------
  * pred element (b,l,e) lives at pred[b*pred_bstride + l*P + e] (P = p^3*C), so the decoder output
