@@ -426,7 +426,7 @@ class HipMAEEngine:
             while s > 1 and lib.vitae_gemm_glds_ws_floats(M, N, s) > self.ws16.numel():
                 s -= 1
             self._split_cache[key] = s
-        t = self._timed(2.0 * M * N * K, 'glds')
+        t = self._timed(2.0 * M * N * K, 'glds' if N < 8192 else 'glds_wide')   # wide = the 64x128-tile instantiation
         lib.vitae_gemm_glds(1, 1, _ptr(x16), K, self._w16(w), K, _ptr(y), N, _ptr(y16), N, M, N, K, _ptr(bias), _ptr(res), N,
                             epi, _ptr(aux), N, 0, s, self.ws16.data_ptr(), None, self.stream)
         if t is not None:
@@ -441,7 +441,7 @@ class HipMAEEngine:
             while s > 1 and lib.vitae_gemm_glds_ws_floats(M, K, s) > self.ws16.numel():
                 s -= 1
             self._split_cache[key] = s
-        t = self._timed(4.0 * M * N * K, 'glds_pair')
+        t = self._timed(4.0 * M * N * K, 'glds_pair' if N < 8192 else 'glds_pair_wide')
         lib.vitae_linear_bwd_pair_glds(_ptr(dy16), self._w16(w), _ptr(x16), _ptr(dx), _ptr(dx16), _ptr(dw), M, Mpad, N, K,
                                        epi, _ptr(aux), _ptr(dx_colsum), int(self._accum), s, self.ws16.data_ptr(), self.stream)
         if t is not None:
@@ -739,7 +739,7 @@ class HipMAEEngine:
                                        _ptr(g['cls_token']), self.Be, self.keep, D, self.stream)
         if self.act16:
             # dW[D, P] = dtok16^T @ patches16 (both row-contiguous bf16, reduced over the padded token count)
-            t = self._timed(2.0 * T * D * P, 'glds')
+            t = self._timed(2.0 * T * D * P, 'glds_wide')
             lib.vitae_gemm_glds(0, 0, _ptr(b['dtok_16']), D, _ptr(b['patches_16']), P, _ptr(g['patch_embed.proj.weight']), P,
                                 None, 0, D, P, self.Mpt, None, None, 0, EPI_NONE, None, 0, int(self._accum), 1, None, None,
                                 self.stream)
