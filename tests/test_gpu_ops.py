@@ -3,6 +3,7 @@ PyTorch (CPU) statement of the same op / the oracle function that restates the r
 Tolerances: fp32-MFMA path ~1e-5 relative (accumulation order), bf16-MFMA path ~1e-2 of the output
 scale (operands rounded to 8 mantissa bits)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -215,6 +216,17 @@ def test_gemm_glds_forward_forms(lib, C, M, N, K):
     lib.vitae_gemm_glds(1, 1, x16.data_ptr(), K, w16.data_ptr(), K, None, 0, y16.data_ptr(), N, M, N, K, bd.data_ptr(), None, 0,
                         C['VITAE_EPI_GELU'], aux.data_ptr(), N, 0, 1, None, None, st())
     assert rel_err(aux, ref) < 2e-3 and rel_err(y16.float(), F.gelu(ref)) < 1e-2
+
+
+def test_gemm_glds_experimental_tiles():
+    """The 128x128 tiles (4-wave and 8-wave) are off by default; run the forward-form checks with each forced on in a
+    child process (the knobs are read once per process)."""
+    import subprocess, sys
+    for knob in ('VITAE_GLDS_T128', 'VITAE_GLDS_T128W8'):
+        env = dict(os.environ, **{knob: '1'})
+        r = subprocess.run([sys.executable, '-m', 'pytest', __file__, '-q', '-m', 'gpu', '-k', 'glds_forward_forms or linear_bwd_pair_glds',
+                            '-p', 'no:cacheprovider'], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (knob, r.stdout[-2000:], r.stderr[-2000:])
 
 
 def test_gemm_bf16_asymmetric(lib):

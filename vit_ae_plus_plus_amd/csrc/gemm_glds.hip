@@ -107,13 +107,14 @@ __device__ __forceinline__ float epilogue_frag(const GArgs& p, const float (&v)[
 
 // Issue the LDS-DMA of one operand tile (ROWS rows x 64 k, bf16) into `lds` (byte address, tile base).
 // KC tile image: [row][8 chunks]; !KC image: [k][ROWS/8 chunks]; chunk slot = chunk ^ (line & 7).
-template <int ROWS, bool KC>
+template <int ROWS, bool KC, int NW>
 __device__ __forceinline__ void dma_tile(const __bf16* __restrict__ P, long ld, int rows, int r0, int k0,
                                          unsigned char* lds, int wave, int lane) {
     constexpr int LINES = KC ? ROWS : BK;                 // LDS lines (each LINE_CH chunks of 16 B)
     constexpr int LINE_CH = KC ? BK / 8 : ROWS / 8;       // 8 (128 B) or 16 (256 B)
     constexpr int LPI = 64 / LINE_CH;                     // lines per wave-instruction (1 KB)
-    constexpr int NI = LINES / LPI / 4;                   // instructions per wave
+    constexpr int NI = LINES / LPI / NW;                  // instructions per wave
+    static_assert(NI >= 1, "tile too small for this many waves");
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int inst = wave * NI + j;
@@ -162,19 +163,24 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 #ifndef VITAE_GLDS_NS_WIDE
 #define VITAE_GLDS_NS_WIDE 2
 #endif
-template <int BM, int BN> struct GCfg {
-    // stages: 3 for 64x64 (48 KB, three workgroups per CU); the wider tiles take 2 (48 KB for 64x128 -> three
-    // workgroups per CU instead of two: decoder_pred fwd 49.8 -> 45.6 us) — occupancy beats prefetch depth here
-    static constexpr int NST = (BM * BN > 64 * 64) ? VITAE_GLDS_NS_WIDE : NS;
+#ifndef VITAE_GLDS_NS_W8
+#define VITAE_GLDS_NS_W8 4
+#endif
+template <int BM, int BN, int NW = 4> struct GCfg {
+    // stages: 3 for 64x64 (48 KB, three workgroups per CU); the wider 4-wave tiles take 2 (48 KB for 64x128 -> three
+    // workgroups per CU instead of two: decoder_pred fwd 49.8 -> 45.6 us) — occupancy beats prefetch depth there;
+    // the 8-wave 128x128 workgroup is alone on its CU and takes 4 (128 KB, three 32 KB tiles in flight)
+    static constexpr int NST = NW == 8 ? VITAE_GLDS_NS_W8 : (BM * BN > 64 * 64) ? VITAE_GLDS_NS_WIDE : NS;
     static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES, SMEM = NST * STAGE;
 };
 
-template <int BM, int BN, bool A_KC, bool B_KC>
+template <int BM, int BN, bool A_KC, bool B_KC, int NW = 4>
 __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, const int zid, unsigned char* smem) {
-    constexpr int FM = BM / 64, FN = BN / 64, NF = FM * FN;
-    constexpr int A_BYTES = GCfg<BM, BN>::A_BYTES, STAGE = GCfg<BM, BN>::STAGE;
-    constexpr int NST = GCfg<BM, BN>::NST;
-    constexpr int G = (BM + BN) / 32;                      // DMA instructions per wave per stage
+    constexpr int WAVES_M = NW / 2, NT = 64 * NW;          // waves: WAVES_M x 2
+    constexpr int FM = BM / (32 * WAVES_M), FN = BN / 64, NF = FM * FN;
+    constexpr int A_BYTES = GCfg<BM, BN, NW>::A_BYTES, STAGE = GCfg<BM, BN, NW>::STAGE;
+    constexpr int NST = GCfg<BM, BN, NW>::NST;
+    constexpr int G = (BM + BN) / (8 * NW);                // DMA instructions per wave per stage
     const int xcd = bid & 7, local = bid >> 3;
     const int tn = xcd + 8 * (local / p.tiles_m), tm = local % p.tiles_m;
     if (tn >= p.tiles_n) return;
@@ -199,8 +205,8 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
 
     auto issue = [&](int t) {
         unsigned char* st = smem + (t % NST) * STAGE;
-        dma_tile<BM, A_KC>(p.A, p.lda, p.M, m0, kbeg + t * BK, st, wave, lane);
-        dma_tile<BN, B_KC>(p.B, p.ldb, p.N, n0, kbeg + t * BK, st + A_BYTES, wave, lane);
+        dma_tile<BM, A_KC, NW>(p.A, p.lda, p.M, m0, kbeg + t * BK, st, wave, lane);
+        dma_tile<BN, B_KC, NW>(p.B, p.ldb, p.N, n0, kbeg + t * BK, st + A_BYTES, wave, lane);
     };
     const int pre = min(nk, NST - 1);
     for (int t = 0; t < pre; ++t) issue(t);
@@ -208,7 +214,8 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
     for (int t = 0; t < nk; ++t) {
         // tile t must have landed: allow the (up to two) younger stages to stay in flight
         const int younger = min(nk - 1 - t, NST - 2);
-        if (younger >= 2) wait_vmcnt<2 * G>();
+        if (younger >= 3) wait_vmcnt<3 * G>();
+        else if (younger == 2) wait_vmcnt<2 * G>();
         else if (younger == 1) wait_vmcnt<G>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();          // everyone's DMA pieces of tile t landed; tile t-1 fully consumed
@@ -219,7 +226,7 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
 #pragma unroll
-            for (int f = 0; f < FM; ++f) fa[kk][f] = frag<BM, A_KC>(at, wm * (BM / 2) + f * 32, kk, lane);
+            for (int f = 0; f < FM; ++f) fa[kk][f] = frag<BM, A_KC>(at, wm * (BM / WAVES_M) + f * 32, kk, lane);
 #pragma unroll
             for (int f = 0; f < FN; ++f) fb[kk][f] = frag<BN, B_KC>(bt, wn * (BN / 2) + f * 32, kk, lane);
         }
@@ -253,7 +260,7 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
         for (int f = 0; f < NF; ++f)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                __hip_atomic_store(&part[(long)zid * (BM * BN) + (f * 16 + r) * 256 + threadIdx.x], a[f][r], __ATOMIC_RELAXED,
+                __hip_atomic_store(&part[(long)zid * (BM * BN) + (f * 16 + r) * NT + threadIdx.x], a[f][r], __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this thread's partials are out
         __syncthreads();
@@ -270,7 +277,7 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
             for (int f = 0; f < NF; ++f)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    a[f][r] += __hip_atomic_load(&part[(long)sp * (BM * BN) + (f * 16 + r) * 256 + threadIdx.x], __ATOMIC_RELAXED,
+                    a[f][r] += __hip_atomic_load(&part[(long)sp * (BM * BN) + (f * 16 + r) * NT + threadIdx.x], __ATOMIC_RELAXED,
                                                  __HIP_MEMORY_SCOPE_AGENT);
         if (threadIdx.x == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     }
@@ -280,7 +287,7 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
         const int n = n0 + wn * (BN / 2) + fn * 32 + l31;
         float csum = 0.f;
 #pragma unroll
-        for (int fm = 0; fm < FM; ++fm) csum += epilogue_frag(p, a[fm * FN + fn], m0 + wm * (BM / 2) + fm * 32, n, hi);
+        for (int fm = 0; fm < FM; ++fm) csum += epilogue_frag(p, a[fm * FN + fn], m0 + wm * (BM / WAVES_M) + fm * 32, n, hi);
         if (p.out_colsum) {
             csum += __shfl_xor(csum, 32, 64);
             if (hi == 0 && n < p.N) atomicAdd(p.out_colsum + n, csum);
@@ -288,10 +295,10 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
     }
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256) void gemm_glds_kernel(const GArgs p) {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[GCfg<BM, BN>::SMEM];   // the ONLY LDS object
-    gemm_glds_body<BM, BN, A_KC, B_KC>(p, blockIdx.x, blockIdx.z, smem);
+template <int BM, int BN, bool A_KC, bool B_KC, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void gemm_glds_kernel(const GArgs p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[GCfg<BM, BN, NW>::SMEM];   // the ONLY LDS object
+    gemm_glds_body<BM, BN, A_KC, B_KC, NW>(p, blockIdx.x, blockIdx.z, smem);
 }
 
 // dgrad (dy @ W: A k-contiguous, B = bf16 weights read row-contiguous) and wgrad (dy^T @ x: both operands
@@ -306,13 +313,13 @@ __global__ __launch_bounds__(256) void gemm_glds_pair_kernel(const GArgs p1, con
     else gemm_glds_body<BM2, BN2, false, false>(p2, blockIdx.x - nb1 * p1.splits, 0, smem);
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int NW = 4>
 void launch(const GArgs& p, bool a_kc, bool b_kc, dim3 grid, hipStream_t st) {
-    dim3 block(256);
-    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, true, true>), grid, block, 0, st, p);
-    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, true, false>), grid, block, 0, st, p);
-    else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, false, true>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, false, false>), grid, block, 0, st, p);
+    dim3 block(64 * NW);
+    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, true, true, NW>), grid, block, 0, st, p);
+    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, true, false, NW>), grid, block, 0, st, p);
+    else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, false, true, NW>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, false, false, NW>), grid, block, 0, st, p);
 }
 
 struct Tile { int bm, bn, id; };
@@ -321,9 +328,13 @@ struct Tile { int bm, bn, id; };
 // 128x128 is OFF by default (VITAE_GLDS_T128 = minimum tile count to use it): with 128 accumulator + 150 other
 // registers and 96 KB of LDS only one 4-wave workgroup fits a CU, and the DMA / LDS / MFMA chain of a single workgroup
 // does not overlap with anything — measured slower than 64x128 at two workgroups per CU on every large GEMM of the
-// step (decoder_pred fwd 54.7 -> 72.5 us, its wgrad 85.7 -> 148 us).  Kept for the 8-wave version.
+// step (decoder_pred fwd 54.7 -> 72.5 us, its wgrad 85.7 -> 148 us).  The 8-wave 128x128 workgroup (id 3,
+// VITAE_GLDS_T128W8; four stages, 128 KB of LDS) comes closer but still loses to 64x128 (fwd 53.8 vs 49.4 us, the
+// row-contiguous wgrad 103 vs 71 us): both stay OFF and are exercised by the tests through the environment knobs.
 inline Tile pick_tile(int M, int N) {
     static const int t128 = getenv("VITAE_GLDS_T128") ? atoi(getenv("VITAE_GLDS_T128")) : 0;
+    static const int t128w8 = getenv("VITAE_GLDS_T128W8") ? atoi(getenv("VITAE_GLDS_T128W8")) : 0;
+    if (N >= 128 && M >= 128 && t128w8 > 0 && (long)cdiv(M, 128) * cdiv(N, 128) >= t128w8) return {128, 128, 3};   // 8 waves
     if (N >= 128 && M >= 128 && t128 > 0 && (long)cdiv(M, 128) * cdiv(N, 128) >= t128) return {128, 128, 2};
     if (N >= 128 && (long)cdiv(M, 64) * cdiv(N, 128) >= 400) return {64, 128, 1};
     return {64, 64, 0};
@@ -389,7 +400,8 @@ extern "C" int vitae_gemm_glds(int a_kcontig, int b_kcontig, const void* A16, lo
     if (split_k > 1 && (long)p.tiles_m * p.tiles_n > VITAE_GLDS_TICKETS) return VITAE_ERR_UNSUPPORTED_SHAPE;
     dim3 grid(8 * cdiv(p.tiles_n, 8) * p.tiles_m, 1, split_k);
     hipStream_t st = (hipStream_t)stream;
-    if (t.id == 2) launch<128, 128>(p, a_kcontig != 0, b_kcontig != 0, grid, st);
+    if (t.id == 3) launch<128, 128, 8>(p, a_kcontig != 0, b_kcontig != 0, grid, st);
+    else if (t.id == 2) launch<128, 128>(p, a_kcontig != 0, b_kcontig != 0, grid, st);
     else if (t.id == 1) launch<64, 128>(p, a_kcontig != 0, b_kcontig != 0, grid, st);
     else launch<64, 64>(p, a_kcontig != 0, b_kcontig != 0, grid, st);
     return vitae_launch_status();
@@ -407,7 +419,8 @@ extern "C" int vitae_linear_bwd_pair_pick_split_k(int M, int Mpad, int N, int K)
     int s = (ks1 + (ks2 > target ? ks2 : target) / 2) / (ks2 > target ? ks2 : target);
     if (s > 8) s = 8;
     while (s > 1 && ks1 / s < 4) --s;
-    const Tile t1 = pick_tile(M, K);
+    Tile t1 = pick_tile(M, K);
+    if (t1.id == 3) t1 = Tile{64, 128, 1};
     if ((long)cdiv(M, t1.bm) * cdiv(K, t1.bn) > VITAE_GLDS_TICKETS) s = 1;
     return s < 1 ? 1 : s;
 }
@@ -431,7 +444,8 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
     p1.M = M; p1.N = K; p1.K = N; p1.k_per_split = kps; p1.splits = split_k;
     p1.bias = nullptr; p1.residual = nullptr; p1.ldr = 0; p1.aux = aux; p1.ldaux = K; p1.epi = epi; p1.accumulate = 0;
     p1.ws = splitk_ws; p1.out_colsum = dx_colsum_accum;
-    const Tile t1 = pick_tile(M, K);
+    Tile t1 = pick_tile(M, K);
+    if (t1.id == 3) t1 = Tile{64, 128, 1};      // the paired launch is 4-wave only
     p1.tiles_m = cdiv(M, t1.bm); p1.tiles_n = cdiv(K, t1.bn);
     p2.A = reinterpret_cast<const __bf16*>(dy16); p2.lda = N;
     p2.B = reinterpret_cast<const __bf16*>(x16); p2.ldb = K;
@@ -439,7 +453,8 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
     p2.M = N; p2.N = K; p2.K = Mpad; p2.k_per_split = Mpad; p2.splits = 1;
     p2.bias = nullptr; p2.residual = nullptr; p2.ldr = 0; p2.aux = nullptr; p2.ldaux = 0; p2.epi = VITAE_EPI_NONE;
     p2.accumulate = dw_accumulate; p2.ws = nullptr; p2.out_colsum = nullptr;
-    const Tile t2 = pick_tile(N, K);
+    Tile t2 = pick_tile(N, K);
+    if (t2.id == 3) t2 = Tile{64, 128, 1};
     p2.tiles_m = cdiv(N, t2.bm); p2.tiles_n = cdiv(K, t2.bn);
     const int nb1 = 8 * cdiv(p1.tiles_n, 8) * p1.tiles_m, nb2 = 8 * cdiv(p2.tiles_n, 8) * p2.tiles_m;
     dim3 grid(nb1 * split_k + nb2);
