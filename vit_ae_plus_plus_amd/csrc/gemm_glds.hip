@@ -105,6 +105,19 @@ __device__ __forceinline__ float epilogue_frag(const GArgs& p, const float (&v)[
     return csum;
 }
 
+// XOR applied to a line's 16-byte chunk index (by the DMA through the SOURCE address, by the fragment reads directly).
+// The hardware serves a wave's LDS read in phases of 256 B, so the lanes of one phase must cover all 64 banks once:
+//   * k-contiguous tile (128-B lines, ds_read_b128, a phase = 16 lanes = 16 consecutive rows of one chunk column):
+//     rows of equal parity share their 32 banks, so the 8 such rows of a phase need 8 different slots -> (line >> 1) & 7
+//     (the earlier `line & 7` repeated every 8 rows: 2-way conflicts, 50 % of the LDS cycles by SQ_LDS_BANK_CONFLICT);
+//   * row-contiguous tile read with ds_read_b64_tr_b16 (a phase = 32 lanes = 4 consecutive k lines x 64 contiguous
+//     bytes): 128-B lines -> lines k, k + 2 share banks, flip the 64-byte half with bit 1 of k; 256-B lines -> all four
+//     lines share the 64 banks, give each its own 64-byte quarter, (k & 3) << 2.
+template <bool KC, int LINE_CH> __device__ __forceinline__ int swz(int line) {
+    if (KC) return (line >> 1) & 7;
+    return LINE_CH == 8 ? ((line >> 1) & 1) << 2 : (line & 3) << 2;
+}
+
 // Issue the LDS-DMA of one operand tile (ROWS rows x 64 k, bf16) into `lds` (byte address, tile base).
 // KC tile image: [row][8 chunks]; !KC image: [k][ROWS/8 chunks]; chunk slot = chunk ^ (line & 7).
 template <int ROWS, bool KC, int NW>
@@ -120,7 +133,7 @@ __device__ __forceinline__ void dma_tile(const __bf16* __restrict__ P, long ld, 
         const int inst = wave * NI + j;
         const int line = inst * LPI + lane / LINE_CH;
         const int slot = lane % LINE_CH;
-        const int chunk = slot ^ (line & 7);
+        const int chunk = slot ^ swz<KC, LINE_CH>(line);
         long off;
         if (KC) {
             const int gr = min(r0 + line, rows - 1);      // rows past the operand: any valid row (never stored)
@@ -138,7 +151,7 @@ template <int ROWS, bool KC>
 __device__ __forceinline__ bf16x8 frag(const unsigned char* T, int row0, int kk, int lane) {
     if (KC) {
         const int r = row0 + (lane & 31), c = 2 * kk + (lane >> 5);
-        return *reinterpret_cast<const bf16x8*>(T + r * 128 + ((c ^ (r & 7)) << 4));
+        return *reinterpret_cast<const bf16x8*>(T + r * 128 + ((c ^ swz<true, 8>(r)) << 4));
     } else {
         constexpr int LB = ROWS * 2;
         const int gg = lane >> 4, li = lane & 15;
@@ -147,8 +160,8 @@ __device__ __forceinline__ bf16x8 frag(const unsigned char* T, int row0, int kk,
         const int c = col >> 3, w = (col & 7) * 2;
         typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
         union { s16x4 s[2]; bf16x8 b; } u;
-        u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(T + k * LB + ((c ^ (k & 7)) << 4) + w));
-        u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(T + (k + 4) * LB + ((c ^ ((k + 4) & 7)) << 4) + w));
+        u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(T + k * LB + ((c ^ swz<false, ROWS / 8>(k)) << 4) + w));
+        u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(T + (k + 4) * LB + ((c ^ swz<false, ROWS / 8>(k + 4)) << 4) + w));
         return u.b;
     }
 }
