@@ -243,6 +243,9 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
 #pragma unroll
             for (int f = 0; f < FN; ++f) fb[kk][f] = frag<BN, B_KC>(bt, wn * (BN / 2) + f * 32, kk, lane);
         }
+        // all fragment reads of the tile are issued before the first MFMA (hipcc otherwise recycles three fragment
+        // registers and waits for a fresh LDS read in front of every MFMA: one LDS latency per MFMA)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk)
 #pragma unroll
