@@ -19,6 +19,8 @@ Design points that differ from the reference on purpose (same numbers, less work
 """
 from __future__ import annotations
 
+import os
+
 import math
 from collections import OrderedDict
 from dataclasses import dataclass
@@ -144,6 +146,10 @@ class HipMAEEngine:
         self.stream = 0
         self.side = torch.cuda.Stream(device=device)   # target-side loss branch runs beside the transformer
         self.wside = torch.cuda.Stream(device=device)  # weight-gradient GEMMs run beside the dgrad chain
+        self.pside = torch.cuda.Stream(device=device)  # predictor branch (fwd, cosine loss, bwd) beside the decoder
+        self.ws_side = torch.empty(1 << 22, **f32)     # its own split-K scratch
+        self.overlap_predictor = os.environ.get('VITAE_PREDICTOR_SIDE', '1') != '0'
+        self._pred_pending = False
         self.overlap_wgrad = True
         self._wg_events: Dict[str, torch.cuda.Event] = {}
         self._wg_pending = set()
@@ -291,6 +297,32 @@ class HipMAEEngine:
             b['dp'], b['dpr'], b['dph'] = f(2 * R, D), f(2 * R, D), f(2 * R, D)
         self.mask_sum = float(B * (L - keep))
         self.edge_count = B * V
+
+    # ------------------------------------------------------------------ predictor branch beside the decoder
+    class _OnPredictorStream:
+        """Launch helpers issue on ``pside`` with the branch's own split-K scratch inside this context."""
+
+        def __init__(self, eng):
+            self.eng = eng
+
+        def __enter__(self):
+            e = self.eng
+            self.saved = (e.stream, e.ws)
+            self.ctx = torch.cuda.stream(e.pside)
+            self.ctx.__enter__()
+            e.stream, e.ws = e.pside.cuda_stream, e.ws_side
+            return e
+
+        def __exit__(self, *a):
+            e = self.eng
+            e.stream, e.ws = self.saved
+            return self.ctx.__exit__(*a)
+
+    def _predictor_join(self):
+        """Main stream waits for everything issued on the predictor stream."""
+        if self._pred_pending:
+            torch.cuda.current_stream(self.device).wait_stream(self.pside)
+            self._pred_pending = False
 
     # ------------------------------------------------------------------ thin launch helpers
     def _split(self, M, N, K):
@@ -529,7 +561,7 @@ class HipMAEEngine:
 
     # ------------------------------------------------------------------ forward
     def forward(self, view1: torch.Tensor, view2: Optional[torch.Tensor], noise: torch.Tensor, mask_ratio: float,
-                training: bool = True):
+                training: bool = True, defer_predictor_join: bool = False):
         """Everything up to the four loss scalars and (contrastive) p1/p2.  ``noise`` is [Be, L]
         (view-1 rows first), the torch.rand of vit_autoenc.py:139."""
         cfg = self.cfg
@@ -581,6 +613,12 @@ class HipMAEEngine:
         for i in range(cfg.depth):
             self._block_fwd(f'blocks.{i}.', f'enc{i}.', ex[i], ex[i + 1], Be, Ne, D, cfg.num_heads, self.hd, self.Hm)
         self._ln_fwd(ex[cfg.depth], 'norm.', b['latent'], b['lat_mean'], b['lat_rstd'], Me, D)
+        if cfg.contrastive and self.overlap_predictor and self.gemm_timer is None:
+            # the predictor branch only needs the latent: it runs on its own stream beside the decoder and the loss chain
+            self.pside.wait_stream(torch.cuda.current_stream(self.device))
+            with self._OnPredictorStream(self):
+                self._predictor_fwd(training, None)
+            self._pred_pending = True
         # --- decoder (view 1 only)
         self._lin_fwd(b['latent'], p['decoder_embed.weight'], p['decoder_embed.bias'], b['e'], B * Ne, Dd, D)
         dx_ = b['decx']
@@ -601,33 +639,47 @@ class HipMAEEngine:
         lib.vitae_loss_fwd_fused(pred_ptr, pbs, _ptr(view1), _ptr(b['mask']), _ptr(b['edge_t']), _ptr(b['pred_vol']),
                                  _ptr(b['edge_p']), _ptr(self.acc), B, C, Lz, Hy, Wx, ps, st)
         lib.vitae_loss_finalize(_ptr(self.acc), _ptr(self.hp), _ptr(self.losses), self.mask_sum, self.edge_count, st)
-        # --- predictor on both views (vit_autoenc.py:280-284)
-        if cfg.contrastive:
-            R = self.R
-            self._lin_fwd(b['latent'], p['predictor.0.weight'], None, b['ph'], 2 * R, D, D)
-            for v in range(2):
-                o = v * R * D * 4
-                lib.vitae_bn1d_relu_fwd(b['ph'].data_ptr() + o, _ptr(p['predictor.1.weight']), _ptr(p['predictor.1.bias']),
-                                        b['pr'].data_ptr() + o, b['bn_mean'].data_ptr() + v * D * 4,
-                                        b['bn_rstd'].data_ptr() + v * D * 4,
-                                        _ptr(self.buffers['predictor.1.running_mean']) if training else None,
-                                        _ptr(self.buffers['predictor.1.running_var']) if training else None,
-                                        _ptr(self.buffers['predictor.1.num_batches_tracked']) if training else None,
-                                        R, D, 1e-5, 0.1, st)
-            self._lin_fwd(b['pr'], p['predictor.3.weight'], p['predictor.3.bias'], b['pout'], 2 * R, D, D)
+        if cfg.contrastive and not self._pred_pending:
+            self._predictor_fwd(training, st)            # not overlapped: in program order on the main stream
+        if not defer_predictor_join:
+            self._predictor_join()
+
+    def _predictor_fwd(self, training: bool, st):
+        """predictor on both views (vit_autoenc.py:280-284); launches on ``self.stream``."""
+        cfg, b, p = self.cfg, self.buf, self.p
+        R, D = self.R, cfg.embed_dim
+        self._lin_fwd(b['latent'], p['predictor.0.weight'], None, b['ph'], 2 * R, D, D)
+        for v in range(2):
+            o = v * R * D * 4
+            lib.vitae_bn1d_relu_fwd(b['ph'].data_ptr() + o, _ptr(p['predictor.1.weight']), _ptr(p['predictor.1.bias']),
+                                    b['pr'].data_ptr() + o, b['bn_mean'].data_ptr() + v * D * 4,
+                                    b['bn_rstd'].data_ptr() + v * D * 4,
+                                    _ptr(self.buffers['predictor.1.running_mean']) if training else None,
+                                    _ptr(self.buffers['predictor.1.running_var']) if training else None,
+                                    _ptr(self.buffers['predictor.1.num_batches_tracked']) if training else None,
+                                    R, D, 1e-5, 0.1, self.stream)
+        self._lin_fwd(b['pr'], p['predictor.3.weight'], p['predictor.3.bias'], b['pout'], 2 * R, D, D)
 
     def contrastive_loss_fwd(self):
         """utils/train_one_epoch.py:113-114 on (p1, z2), (p2, z1); result -> losses[4]."""
         b, R, D = self.buf, self.R, self.cfg.embed_dim
         o = R * D * 4
         p1, p2, z1, z2 = b['pout'].data_ptr(), b['pout'].data_ptr() + o, b['latent'].data_ptr(), b['latent'].data_ptr() + o
-        lib.vitae_cosine_loss_fwd(p1, z2, p2, z1, _ptr(self.acc), _ptr(self.hp), self.losses.data_ptr() + 16, R, D,
-                                  self.stream)
+        st = self.pside.cuda_stream if self._pred_pending else self.stream
+        lib.vitae_cosine_loss_fwd(p1, z2, p2, z1, _ptr(self.acc), _ptr(self.hp), self.losses.data_ptr() + 16, R, D, st)
 
     def contrastive_loss_bwd(self):
         b, R, D = self.buf, self.R, self.cfg.embed_dim
         o = R * D * 4
         p1, p2, z1, z2 = b['pout'].data_ptr(), b['pout'].data_ptr() + o, b['latent'].data_ptr(), b['latent'].data_ptr() + o
+        if self._pred_pending:
+            # the branch's backward accumulates into gradient slots zeroed by begin_grad_window on the main stream
+            self.pside.wait_stream(torch.cuda.current_stream(self.device))
+            with self._OnPredictorStream(self):
+                lib.vitae_cosine_loss_bwd(p1, z2, p2, z1, _ptr(self.hp), b['dp'].data_ptr(), b['dp'].data_ptr() + o, R, D,
+                                          self.stream)
+                self._predictor_bwd()
+            return
         lib.vitae_cosine_loss_bwd(p1, z2, p2, z1, _ptr(self.hp), b['dp'].data_ptr(), b['dp'].data_ptr() + o, R, D,
                                   self.stream)
 
@@ -688,15 +740,10 @@ class HipMAEEngine:
         # predictor (both views) -> dlatent ; then decoder_embed adds into the view-1 rows
         if cfg.contrastive and have_dp:
             R = self.R
-            self._lin_bwd_w(b['dp'], b['pr'], g['predictor.3.weight'], None, 2 * R, D, D)
-            self._lin_bwd_x(b['dp'], p['predictor.3.weight'], b['dpr'], 2 * R, D, D, db=g['predictor.3.bias'])
-            for v in range(2):
-                o = v * R * D * 4
-                lib.vitae_bn1d_relu_bwd(b['dpr'].data_ptr() + o, b['ph'].data_ptr() + o, b['pr'].data_ptr() + o,
-                                        _ptr(p['predictor.1.weight']), b['bn_mean'].data_ptr() + v * D * 4,
-                                        b['bn_rstd'].data_ptr() + v * D * 4, b['dph'].data_ptr() + o,
-                                        _ptr(g['predictor.1.weight']), _ptr(g['predictor.1.bias']), R, D, st)
-            self._lin_bwd_w(b['dph'], b['latent'], g['predictor.0.weight'], None, 2 * R, D, D)
+            if self._pred_pending:
+                self._predictor_join()          # dph and the predictor's parameter gradients are final
+            else:
+                self._predictor_bwd()
             self._lin_bwd_x(b['dph'], p['predictor.0.weight'], b['dlatent'], 2 * R, D, D)
             self._lin_bwd_x(b['de'], p['decoder_embed.weight'], b['dlatent'], B * Ne, Dd, D, accumulate=1,
                             db=g['decoder_embed.bias'])
@@ -714,6 +761,20 @@ class HipMAEEngine:
         else:
             self._ln_bwd(b['dlatent'], b['encx'][cfg.depth], 'norm.', b['lat_mean'], b['lat_rstd'], b['encdx'], Me, D, 0)
         self._wg_join()
+
+    def _predictor_bwd(self):
+        """dp -> predictor.3, BatchNorm+ReLU, predictor.0 weight gradients and dph (launches on ``self.stream``)."""
+        cfg, b, p, g = self.cfg, self.buf, self.p, self.g
+        R, D = self.R, cfg.embed_dim
+        self._lin_bwd_w(b['dp'], b['pr'], g['predictor.3.weight'], None, 2 * R, D, D)
+        self._lin_bwd_x(b['dp'], p['predictor.3.weight'], b['dpr'], 2 * R, D, D, db=g['predictor.3.bias'])
+        for v in range(2):
+            o = v * R * D * 4
+            lib.vitae_bn1d_relu_bwd(b['dpr'].data_ptr() + o, b['ph'].data_ptr() + o, b['pr'].data_ptr() + o,
+                                    _ptr(p['predictor.1.weight']), b['bn_mean'].data_ptr() + v * D * 4,
+                                    b['bn_rstd'].data_ptr() + v * D * 4, b['dph'].data_ptr() + o,
+                                    _ptr(g['predictor.1.weight']), _ptr(g['predictor.1.bias']), R, D, self.stream)
+        self._lin_bwd_w(b['dph'], b['latent'], g['predictor.0.weight'], None, 2 * R, D, D)
 
     def backward_enc(self, hi: int, lo: int):
         """encoder blocks hi, hi-1, ..., lo."""
@@ -817,7 +878,7 @@ class HipMAEEngine:
         cfg = self.cfg
         n = self.enc_chunks
         if k == 0:
-            self.forward(view1, view2, noise, mask_ratio, training=True)
+            self.forward(view1, view2, noise, mask_ratio, training=True, defer_predictor_join=True)
             if cfg.contrastive:
                 self.contrastive_loss_fwd()
             self.begin_grad_window(accumulate)
