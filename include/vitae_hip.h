@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITAE_ABI_VERSION 15
+#define VITAE_ABI_VERSION 16
 
 /* matrix-core arithmetic of the dense contractions */
 #define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
@@ -56,6 +56,9 @@ extern "C" {
 #define VITAE_ACC_EDGE 1
 #define VITAE_ACC_COS 2
 #define VITAE_ACC_GRADSQ 3
+#define VITAE_ACC_NONFINITE 7 /* the first 4 bytes of this slot are a FLOAT: 0 after the per-step zeroing, NaN once the loss
+                                * backward produced a non-finite gradient (the early form of GradScaler.step's inf check:
+                                * a `grad_norm` pointer for vitae_adamw_step before the global norm exists) */
 #define VITAE_ACC_COUNT 8
 
 #define VITAE_MAX_TAPS 33
@@ -214,7 +217,8 @@ int vitae_loss_fwd_fused(const float* pred, long pred_bstride, const float* imgs
  * C in {1,4}: one LDS-tiled kernel; other C: recon_bwd + the two Sobel backward kernels (needs dG_ws). */
 int vitae_loss_bwd_fused(const float* pred, const float* pred_vol, const float* imgs, const float* mask,
                          const float* edge_pred, const float* edge_tgt, const float* hp, float* dG_ws, float* dpred,
-                         void* dpred_bf16, long pred_bstride, float mask_sum, int B, int C, int Lz, int Hy, int Wx, int p,
+                         void* dpred_bf16, float* nonfinite_flag /* optional: set to NaN when a non-finite gradient is written
+                         (C in {1,4} only) */, long pred_bstride, float mask_sum, int B, int C, int Lz, int Hy, int Wx, int p,
                          void* stream);
 /* out4 = [loss, raw_edge_mse, recon, percep=0] (model/vit_autoenc.py:231-232) */
 int vitae_loss_finalize(const double* acc, const float* hp, float* out4, float mask_sum, long edge_count, void* stream);

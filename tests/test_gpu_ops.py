@@ -493,7 +493,7 @@ def test_loss_chain(lib, C, C_, vol, p):
     dfu = torch.zeros(B, L + 1, P, device='cuda')
     dfu16 = torch.zeros(B, L + 1, P, dtype=torch.bfloat16, device='cuda')
     lib.vitae_loss_bwd_fused(pp, pv.data_ptr(), im.data_ptr(), mk.data_ptr(), ep.data_ptr(), et.data_ptr(), hp.data_ptr(),
-                             dG.data_ptr(), dfu.data_ptr() + P * 4, dfu16.data_ptr() + P * 2, pbs, msum, B, C_, *vol, p, st())
+                             dG.data_ptr(), dfu.data_ptr() + P * 4, dfu16.data_ptr() + P * 2, None, pbs, msum, B, C_, *vol, p, st())
     assert float(dfu[:, 0].abs().max()) == 0.0
     assert rel_err(dfu, pr.grad) < 3e-5
     assert torch.equal(dfu16, dfu.to(torch.bfloat16))
@@ -516,13 +516,15 @@ def test_sobel_kat_and_nan_semantics(lib):
     pred = torch.ones(1, L, P, device='cuda')
     mk = torch.ones(1, L, device='cuda')
     d = torch.zeros(1, L, P, device='cuda')
+    flag = torch.zeros(1, device='cuda')
     lib.vitae_loss_bwd_fused(pred.data_ptr(), pv.data_ptr(), pv.data_ptr(), mk.data_ptr(), ep.data_ptr(), et.data_ptr(),
-                             hp.data_ptr(), None, d.data_ptr(), None, L * P, 8.0, 1, 1, *vol, p, st())
+                             hp.data_ptr(), None, d.data_ptr(), None, flag.data_ptr(), L * P, 8.0, 1, 1, *vol, p, st())
     xr = torch.ones(1, 1, *vol, requires_grad=True)
     (R.sobel_magnitude(xr) ** 2).mean().backward()
     ref = xr.grad[0, 0]
     got = R.unpatchify(d.cpu(), p, (2, 2, 2))[0, 0]
     assert torch.equal(torch.isnan(got), torch.isnan(ref)) and bool(torch.isnan(ref).any())
+    assert bool(torch.isnan(flag).all())        # the early non-finite flag the in-backward optimiser keys its skip on
 
 
 # --------------------------------------------------------------------------- predictor pieces

@@ -30,7 +30,7 @@ ops = {
     'sobel_pred+mse': lambda: lib.vitae_sobel_edge_fwd(pv.data_ptr(), ep.data_ptr(), et.data_ptr(), acc.data_ptr(), B, Cc, *vol, st),
     'loss_fwd_fused': lambda: lib.vitae_loss_fwd_fused(pp, pbs, imgs.data_ptr(), mask.data_ptr(), et.data_ptr(), pv.data_ptr(), ep.data_ptr(), acc.data_ptr(), B, Cc, *vol, p, st),
     'loss_bwd_fused': lambda: lib.vitae_loss_bwd_fused(pp, pv.data_ptr(), imgs.data_ptr(), mask.data_ptr(), ep.data_ptr(), et.data_ptr(), hp.data_ptr(), None,
-                                                      dpred.data_ptr() + P * 4, d16.data_ptr() + P * 2, pbs, msum, B, Cc, *vol, p, st),
+                                                      dpred.data_ptr() + P * 4, d16.data_ptr() + P * 2, None, pbs, msum, B, Cc, *vol, p, st),
 }
 for name, fn in ops.items():
     for _ in range(3):

@@ -497,7 +497,8 @@ __global__ __launch_bounds__(256, 2) void loss_bwd_fused_kernel(const float* __r
                                                              const float* __restrict__ mask, const float* __restrict__ Ep,
                                                              const float* __restrict__ Et, const float* __restrict__ hp,
                                                              float* __restrict__ dpred, __bf16* __restrict__ dpred16,
-                                                             float inv_count, float inv_p_masksum, int xtiles, VolGeom g) {
+                                                             float* __restrict__ nonfinite, float inv_count,
+                                                             float inv_p_masksum, int xtiles, VolGeom g) {
     constexpr int VZ = TZ + 4, VY = TY_ + 4, VX = TX + 4;      // pred_vol region (halo 2)
     constexpr int GZ = TZ + 2, GY = TY_ + 2, GX = TX + 2;      // dG region (halo 1)
     constexpr int NCOL = GY * GX, NPASS = (NCOL + 255) / 256;
@@ -629,10 +630,13 @@ __global__ __launch_bounds__(256, 2) void loss_bwd_fused_kernel(const float* __r
         }
     }
     if (!live) return;
+    bool bad = false;
 #pragma unroll
     for (int tz = 0; tz < TZ; ++tz) {
         const int z = z0 + tz;
         if (z >= Lz) break;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) bad |= !(fabsf(o[c][tz]) <= 3.4028234e38f);   // NaN or inf
         const int p = g.p;
         const int l = ((z / p) * g.g1 + y / p) * g.g2 + x / p;
         const int e0 = (((z % p) * p + y % p) * p + x % p) * CH;
@@ -652,6 +656,7 @@ __global__ __launch_bounds__(256, 2) void loss_bwd_fused_kernel(const float* __r
             }
         }
     }
+    if (bad && nonfinite) *nonfinite = __builtin_nanf("");   // benign race: every writer stores the same value
 }
 
 // ---------------------------------------------------------------- scalar finalisation
@@ -832,8 +837,8 @@ extern "C" int vitae_loss_fwd_fused(const float* pred, long pred_bstride, const 
 
 extern "C" int vitae_loss_bwd_fused(const float* pred, const float* pred_vol, const float* imgs, const float* mask, const float* edge_pred,
                                     const float* edge_tgt, const float* hp, float* dG_ws, float* dpred, void* dpred_bf16,
-                                    long pred_bstride, float mask_sum, int B, int C, int Lz, int Hy, int Wx, int p,
-                                    void* stream) {
+                                    float* nonfinite_flag, long pred_bstride, float mask_sum, int B, int C, int Lz, int Hy,
+                                    int Wx, int p, void* stream) {
     if (!pred || !pred_vol || !imgs || !mask || !edge_pred || !edge_tgt || !hp || !dpred || B <= 0 || p <= 0 || mask_sum <= 0.f ||
         Lz % p || Hy % p || Wx % p)
         return VITAE_ERR_INVALID_ARG;
@@ -847,10 +852,10 @@ extern "C" int vitae_loss_bwd_fused(const float* pred, const float* pred_vol, co
     if (zt <= 65535 && B <= 65535 && (C == 1 || (C == 4 && vec_ok))) {
         if (C == 1)
             hipLaunchKernelGGL(loss_bwd_fused_kernel<1>, dim3(xt * yt, zt, B), dim3(256), 0, st, pred_vol, imgs, mask, edge_pred,
-                               edge_tgt, hp, dpred, d16, inv_count, inv_pm, xt, g);
+                               edge_tgt, hp, dpred, d16, nonfinite_flag, inv_count, inv_pm, xt, g);
         else
             hipLaunchKernelGGL(loss_bwd_fused_kernel<4>, dim3(xt * yt, zt, B), dim3(256), 0, st, pred_vol, imgs, mask, edge_pred,
-                               edge_tgt, hp, dpred, d16, inv_count, inv_pm, xt, g);
+                               edge_tgt, hp, dpred, d16, nonfinite_flag, inv_count, inv_pm, xt, g);
         return vitae_launch_status();
     }
     // other channel counts: the three-kernel path (needs the dG scratch)

@@ -5,6 +5,7 @@
 // Hyper-parameters live in the device `hp` block (VITAE_HP_*), so a captured step graph can be
 // replayed while lr / bias corrections change.  The step is skipped when the gradient norm is not
 // finite — the effect of GradScaler.step's inf check (utils/misc.py:267).
+#include <cstdlib>
 #include "common.hpp"
 #include "vitae_hip.h"
 
@@ -112,7 +113,8 @@ template <typename G>
 static int grad_sqnorm_launch(const G* grads, long n, double* acc, float* norm_out, void* stream) {
     if (!grads || !acc || n <= 0 || ((uintptr_t)grads & 15)) return VITAE_ERR_INVALID_ARG;
     long blocks = (n / 4 + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    static const long maxg = getenv("VITAE_GRADNORM_MAX_BLOCKS") ? atol(getenv("VITAE_GRADNORM_MAX_BLOCKS")) : 2048;
+    if (blocks > maxg) blocks = maxg;
     if (blocks < 1) blocks = 1;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(grad_sqnorm_kernel<G>, dim3((int)blocks), dim3(256), 0, st, grads, n, acc);
@@ -135,10 +137,13 @@ static int adamw_launch(float* params, const G* grads, float* exp_avg, float* ex
     if (((uintptr_t)params | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return VITAE_ERR_INVALID_ARG;
     if (((uintptr_t)grads & (4 * sizeof(G) - 1)) || ((uintptr_t)shadow_bf16 & 7)) return VITAE_ERR_INVALID_ARG;
     long blocks = (n / 4 + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
+    // one 256-thread workgroup per CU: as fast alone as any larger grid (5.4-5.7 TB/s) and it leaves the CUs' other wave
+    // slots to the backward kernels this pass runs beside (in-backward optimiser); fewer workgroups lose bandwidth
+    static const long maxb = getenv("VITAE_ADAMW_MAX_BLOCKS") ? atol(getenv("VITAE_ADAMW_MAX_BLOCKS")) : 256;
+    if (blocks > maxb) blocks = maxb;
     if (blocks < 1) blocks = 1;
-    // 30 B/element of HBM traffic; measured 5.0-5.2 TB/s for every grid size / cache policy tried (the read-only
-    // grad-norm pass reaches 5.4 TB/s on the same box), i.e. this kernel sits at the achievable HBM rate.
+    // 30 B/element of HBM traffic; 5.0-5.7 TB/s for every grid size >= 256 workgroups and cache policy tried (the
+    // read-only grad-norm pass reaches 5.4 TB/s on the same box), i.e. this kernel sits at the achievable HBM rate.
     hipLaunchKernelGGL((adamw_kernel<true, G>), dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
                        exp_avg_sq, reinterpret_cast<__bf16*>(shadow_bf16), n, hp, grad_norm, weight_decay);
     return vitae_launch_status();

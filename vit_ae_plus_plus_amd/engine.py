@@ -149,6 +149,9 @@ class HipMAEEngine:
         self.pside = torch.cuda.Stream(device=device)  # predictor branch (fwd, cosine loss, bwd) beside the decoder
         self.ws_side = torch.empty(1 << 22, **f32)     # its own split-K scratch
         self.overlap_predictor = os.environ.get('VITAE_PREDICTOR_SIDE', '1') != '0'
+        self.oside = torch.cuda.Stream(device=device)  # per-bucket grad-norm + AdamW beside the rest of the backward
+        self.overlap_optimizer = os.environ.get('VITAE_OPT_IN_BACKWARD', '1') != '0'
+        self._opt_pending = False
         self._pred_pending = False
         self.overlap_wgrad = True
         self._wg_events: Dict[str, torch.cuda.Event] = {}
@@ -714,7 +717,7 @@ class HipMAEEngine:
         a16 = self.act16
         lib.vitae_loss_bwd_fused(pred_ptr, _ptr(b['pred_vol']), _ptr(view1), _ptr(b['mask']), _ptr(b['edge_p']), _ptr(b['edge_t']),
                                  _ptr(self.hp), _ptr(b.get('dG')), dpred_ptr, (b['dpred_16'].data_ptr() + P * 2) if a16 else None,
-                                 pbs, self.mask_sum, B, C, Lz, Hy, Wx, ps, st)
+                                 self.acc.data_ptr() + 8 * _C['VITAE_ACC_NONFINITE'], pbs, self.mask_sum, B, C, Lz, Hy, Wx, ps, st)
         dx_ = b['decx']
         nd = cfg.decoder_depth
         if a16:
@@ -851,6 +854,55 @@ class HipMAEEngine:
                              s['exp_avg_sq'].data_ptr() + o, (sh + o // 2) if sh else None, self.n_total - self.vec_off,
                              _ptr(self.hp), gn, 0.0, st)
 
+    # --- optimiser inside the backward (single process): the matrices of a gradient bucket are final when its backward
+    # phase ends, so their share of the grad-norm pass and their AdamW update run on a side stream underneath the
+    # remaining, latency-bound backward kernels instead of as 0.8 ms of HBM-bound work after it.  The step-skip on a
+    # non-finite gradient (GradScaler.step) cannot wait for the global norm here; it uses the early flag the loss
+    # backward raises when it writes a non-finite gradient — the only place where one originates on this path (the
+    # 0/0 of the Sobel magnitude at |g| = 0); everything downstream of it is then non-finite as well.
+    def _optimizer_in_backward_ok(self) -> bool:
+        return (self.overlap_optimizer and self.opt_state is not None and self.cfg.in_chans in (1, 4)
+                and self.grads_wire16 is None and not self._ddp_active and self.gemm_timer is None)
+
+    _ddp_active = False
+
+    def _opt_bucket(self, k: int):
+        """grad-norm share + AdamW of gradient bucket k (matrices only) on the optimiser stream."""
+        from . import ddp
+        s0, e0 = ddp.engine_bucket_ranges(self)[k]
+        n = e0 - s0
+        if n <= 0:
+            return
+        self.oside.wait_stream(torch.cuda.current_stream(self.device))
+        st = self.oside.cuda_stream
+        o = s0 * 4
+        sh = self.params16.data_ptr() if self.params16 is not None else 0
+        flag = self.acc.data_ptr() + 8 * _C['VITAE_ACC_NONFINITE']
+        lib.vitae_grad_sqnorm(self.grads.data_ptr() + o, n, _ptr(self.acc), None, st)
+        lib.vitae_adamw_step(self.params.data_ptr() + o, self.grads.data_ptr() + o, self.opt_state['exp_avg'].data_ptr() + o,
+                             self.opt_state['exp_avg_sq'].data_ptr() + o, (sh + o // 2) if sh else None, n, _ptr(self.hp), flag,
+                             self.weight_decay, st)
+        self._opt_pending = True
+
+    def _opt_tail(self):
+        """Tokens + vectors (whose gradients are accumulated atomically all through the backward) and the norm."""
+        main = torch.cuda.current_stream(self.device)
+        main.wait_stream(self.oside)
+        self._opt_pending = False
+        st = main.cuda_stream
+        gn = self.losses.data_ptr() + 20
+        s = self.opt_state
+        sh = self.params16.data_ptr() if self.params16 is not None else 0
+        ot, ov = self.tok_off * 4, self.vec_off * 4
+        lib.vitae_grad_sqnorm(self.grads.data_ptr() + ot, self.n_total - self.tok_off, _ptr(self.acc), gn, st)
+        if self.vec_off > self.tok_off:
+            lib.vitae_adamw_step(self.params.data_ptr() + ot, self.grads.data_ptr() + ot, s['exp_avg'].data_ptr() + ot,
+                                 s['exp_avg_sq'].data_ptr() + ot, (sh + ot // 2) if sh else None, self.vec_off - self.tok_off,
+                                 _ptr(self.hp), gn, self.weight_decay, st)
+        lib.vitae_adamw_step(self.params.data_ptr() + ov, self.grads.data_ptr() + ov, s['exp_avg'].data_ptr() + ov,
+                             s['exp_avg_sq'].data_ptr() + ov, (sh + ov // 2) if sh else None, self.n_total - self.vec_off,
+                             _ptr(self.hp), gn, 0.0, st)
+
     # ------------------------------------------------------------------ fused training step
     enc_chunks = 2      # encoder backward is cut into this many phases (= gradient buckets); ddp raises it
 
@@ -885,13 +937,20 @@ class HipMAEEngine:
             if cfg.contrastive:
                 self.contrastive_loss_bwd()
             self.backward_dec(have_dp=cfg.contrastive)
+            if update and self._optimizer_in_backward_ok():
+                self._opt_bucket(0)
         elif 1 <= k <= n:
             hi, lo = self.enc_chunk_bounds()[k - 1]
             self.backward_enc(hi, lo)
             if k == n:
                 self.backward_tail()
+            if update and self._optimizer_in_backward_ok():
+                self._opt_bucket(k)
         elif k == n + 1 and update:
-            self.grad_norm_and_step()
+            if self._opt_pending:
+                self._opt_tail()
+            else:
+                self.grad_norm_and_step()
 
     def train_step_launch(self, view1, view2, noise, mask_ratio: float, update: bool = True, accumulate: bool = False):
         for k in range(self.N_PHASES):

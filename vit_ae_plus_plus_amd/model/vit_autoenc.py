@@ -151,6 +151,7 @@ class _StepRunner:
         nph = eng.N_PHASES
         groups = [[k] for k in range(nph)] if exchange else [list(range(nph))]
         eng._wire_ready = exchange and eng.grads_wire16 is not None    # read at launch / capture time of the last phase
+        eng._ddp_active = exchange          # buckets still change after their phase (all-reduce): optimiser stays at the end
         if self.use_graph and self.graphs is None:
             self._capture(groups)
         for i, grp in enumerate(groups):
