@@ -10,6 +10,7 @@
 // to a double accumulator block `acc` (VITAE_ACC_*), finalised by tiny kernels; upstream gradient
 // multipliers are read from the device-resident `hp` block (VITAE_HP_*) so captured graphs can be
 // replayed while edge_map_weight / accum scaling change.
+#include <cstdlib>
 #include "common.hpp"
 #include "vitae_hip.h"
 #ifndef VITAE_BLUR_ROWS
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(256) void sobel_bwd_scatter_kernel(const float* __r
 // RAD halo rows (zero padded in x and y) in LDS, blurs along x into a second LDS buffer, then along y.
 // Summation order per axis equals blur_axis_kernel's (out-of-range taps add an exact 0).
 template <int RAD>
-__global__ __launch_bounds__(256) void blur_xy_kernel(const float* __restrict__ in, float* __restrict__ out, int Hy, int Wx,
+__device__ __forceinline__ void blur_xy_body(const dim3 blockIdx_, const float* __restrict__ in, float* __restrict__ out, int Hy, int Wx,
                                                       int TY, Taps t) {
     extern __shared__ float sm[];
     constexpr int NT = 2 * RAD + 1, XB = 4;   // XB outputs per thread along x share their NT + XB - 1 inputs
@@ -229,9 +230,9 @@ __global__ __launch_bounds__(256) void blur_xy_kernel(const float* __restrict__ 
     float* a = sm;                    // [rows][stride]  input, zero padded
     float* m = sm + rows * stride;    // [rows][Wp]      blurred along x
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int y0 = blockIdx.x * TY;
-    const float* src = in + (long)blockIdx.y * Hy * Wx;
-    float* dst = out + (long)blockIdx.y * Hy * Wx;
+    const int y0 = blockIdx_.x * TY;
+    const float* src = in + (long)blockIdx_.y * Hy * Wx;
+    float* dst = out + (long)blockIdx_.y * Hy * Wx;
     for (int r = wave; r < rows; r += 4) {
         const int yy = y0 - RAD + r;
         const bool rin = yy >= 0 && yy < Hy;
@@ -281,13 +282,13 @@ __global__ __launch_bounds__(256) void blur_xy_kernel(const float* __restrict__ 
 // Blur along z: one thread per (y,x) column and z chunk; the ZC + 2 RAD inputs are fetched up front (all loads
 // in flight together) and each output is a static-index dot product in registers.
 template <int RAD, int ZC>
-__global__ __launch_bounds__(256) void blur_z_kernel(const float* __restrict__ in, float* __restrict__ out, int Lz, long plane,
+__device__ __forceinline__ void blur_z_body(const dim3 blockIdx_, const float* __restrict__ in, float* __restrict__ out, int Lz, long plane,
                                                      Taps t) {
-    const long pos = (long)blockIdx.x * 256 + threadIdx.x;
+    const long pos = (long)blockIdx_.x * 256 + threadIdx.x;
     if (pos >= plane) return;
-    const int z0 = blockIdx.y * ZC;
-    const float* src = in + (long)blockIdx.z * Lz * plane + pos;
-    float* dst = out + (long)blockIdx.z * Lz * plane + pos;
+    const int z0 = blockIdx_.y * ZC;
+    const float* src = in + (long)blockIdx_.z * Lz * plane + pos;
+    float* dst = out + (long)blockIdx_.z * Lz * plane + pos;
     float v[ZC + 2 * RAD];
 #pragma unroll
     for (int i = 0; i < ZC + 2 * RAD; ++i) {
@@ -322,14 +323,14 @@ constexpr int TZ = 8, TY_ = 8, TX = 32;                       // output tile of 
 
 // E = sum_c |grad vol_c| on a TZ x TY x TX tile: the tile plus a 1-voxel halo of one channel sits in LDS, each
 // thread owns one (y, x) column and marches along z with a 3-plane register ring of the in-plane partials.
-__global__ __launch_bounds__(256) void sobel_mag_tiled_kernel(const float* __restrict__ vol, float* __restrict__ E,
+__device__ __forceinline__ void sobel_mag_tiled_body(const dim3 blockIdx_, const float* __restrict__ vol, float* __restrict__ E,
                                                               const float* __restrict__ E_ref, double* __restrict__ acc,
                                                               int C, int Lz, int Hy, int Wx, int xtiles) {
     constexpr int RZ = TZ + 2, RY = TY_ + 2, RX = TX + 2;
     __shared__ float sv[RZ * RY * RX];
     __shared__ float red[4];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int x0 = (blockIdx.x % xtiles) * TX, y0 = (blockIdx.x / xtiles) * TY_, z0 = blockIdx.y * TZ, b = blockIdx.z;
+    const int x0 = (blockIdx_.x % xtiles) * TX, y0 = (blockIdx_.x / xtiles) * TY_, z0 = blockIdx_.y * TZ, b = blockIdx_.z;
     const long V = (long)Lz * Hy * Wx;
     float e[TZ];
 #pragma unroll
@@ -390,6 +391,36 @@ __global__ __launch_bounds__(256) void sobel_mag_tiled_kernel(const float* __res
     if (E_ref) {
         sq = block_sum_256(sq, red);
         if (threadIdx.x == 0) atomicAdd(acc + VITAE_ACC_EDGE, (double)sq);
+    }
+}
+
+// Grid-stride forms of the three target-branch kernels (the branch only depends on the input volume and runs on a
+// side stream under the transformer).  VITAE_SIDE_MAX_BLOCKS caps their grids; measured: capping to 256-1024
+// workgroups does NOT help the step (5.73-5.78 ms vs 5.69 uncapped) because these kernels are latency-bound per
+// workgroup and slow down more than they give back, so the default is the full virtual grid.
+template <int RAD>
+__global__ __launch_bounds__(256) void blur_xy_kernel(const float* __restrict__ in, float* __restrict__ out, int Hy, int Wx,
+                                                      int TY, Taps t, int nbx, int total) {
+    for (int v = blockIdx.x; v < total; v += gridDim.x) {
+        blur_xy_body<RAD>(dim3(v % nbx, v / nbx, 0), in, out, Hy, Wx, TY, t);
+        __syncthreads();
+    }
+}
+
+template <int RAD, int ZC>
+__global__ __launch_bounds__(256) void blur_z_kernel(const float* __restrict__ in, float* __restrict__ out, int Lz, long plane,
+                                                     Taps t, int nbx, int nby, int total) {
+    for (int v = blockIdx.x; v < total; v += gridDim.x)
+        blur_z_body<RAD, ZC>(dim3(v % nbx, (v / nbx) % nby, v / (nbx * nby)), in, out, Lz, plane, t);
+}
+
+__global__ __launch_bounds__(256) void sobel_mag_tiled_kernel(const float* __restrict__ vol, float* __restrict__ E,
+                                                              const float* __restrict__ E_ref, double* __restrict__ acc,
+                                                              int C, int Lz, int Hy, int Wx, int xtiles, int nbx, int nby,
+                                                              int total) {
+    for (int v = blockIdx.x; v < total; v += gridDim.x) {
+        sobel_mag_tiled_body(dim3(v % nbx, (v / nbx) % nby, v / (nbx * nby)), vol, E, E_ref, acc, C, Lz, Hy, Wx, xtiles);
+        __syncthreads();
     }
 }
 
@@ -728,6 +759,11 @@ inline VolGeom make_geom(int C, int Lz, int Hy, int Wx, int p, long pred_bstride
     return g;
 }
 
+inline int side_blocks() {
+    static const int n = getenv("VITAE_SIDE_MAX_BLOCKS") ? atoi(getenv("VITAE_SIDE_MAX_BLOCKS")) : (1 << 30);
+    return n < 1 ? 1 : n;
+}
+
 inline int stream_blocks(long total) {
     long b = (total + 255) / 256;
     return (int)(b > 4096 ? 4096 : b);
@@ -776,10 +812,13 @@ extern "C" int vitae_gauss_blur_fwd(const float* vol, float* tmp, float* out, co
         const int TY = ROWS - 2 * RAD;
         const int Wp = (Wx + 3) / 4 * 4;
         const size_t lds = (size_t)ROWS * (2 * Wp + 2 * RAD + 2) * sizeof(float);
-        hipLaunchKernelGGL(blur_xy_kernel<RAD>, dim3(cdiv(Hy, TY), Lz * BC), dim3(256), lds, st, vol, tmp, Hy, Wx, TY, t);
+        const int nbx = cdiv(Hy, TY), tot_xy = nbx * Lz * BC;
+        hipLaunchKernelGGL(blur_xy_kernel<RAD>, dim3(min(tot_xy, side_blocks())), dim3(256), lds, st, vol, tmp, Hy, Wx, TY, t, nbx,
+                           tot_xy);
         const long plane = (long)Hy * Wx;
-        hipLaunchKernelGGL((blur_z_kernel<RAD, ZC>), dim3(cdiv(plane, 256), cdiv(Lz, ZC), BC), dim3(256), 0, st, tmp, out, Lz,
-                           plane, t);
+        const int zx = cdiv(plane, 256), zy = cdiv(Lz, ZC), tot_z = zx * zy * BC;
+        hipLaunchKernelGGL((blur_z_kernel<RAD, ZC>), dim3(min(tot_z, side_blocks())), dim3(256), 0, st, tmp, out, Lz, plane, t, zx, zy,
+                           tot_z);
         return vitae_launch_status();
     }
     hipLaunchKernelGGL(blur_axis_kernel, dim3(blocks), dim3(256), 0, st, vol, out, total, Wx, 1L, t);
@@ -793,8 +832,9 @@ extern "C" int vitae_sobel_edge_fwd(const float* vol, float* edge, const float* 
     if (!vol || !edge || B <= 0 || C <= 0 || (edge_ref && !acc)) return VITAE_ERR_INVALID_ARG;
     const int xt = cdiv(Wx, TX), yt = cdiv(Hy, TY_), zt = cdiv(Lz, TZ);
     if (zt <= 65535 && B <= 65535) {
-        hipLaunchKernelGGL(sobel_mag_tiled_kernel, dim3(xt * yt, zt, B), dim3(256), 0, (hipStream_t)stream, vol, edge,
-                           edge_ref, acc, C, Lz, Hy, Wx, xt);
+        const int tot = xt * yt * zt * B;
+        hipLaunchKernelGGL(sobel_mag_tiled_kernel, dim3(min(tot, side_blocks())), dim3(256), 0, (hipStream_t)stream, vol, edge,
+                           edge_ref, acc, C, Lz, Hy, Wx, xt, xt * yt, zt, tot);
         return vitae_launch_status();
     }
     const long total = (long)B * Lz * Hy * Wx;
