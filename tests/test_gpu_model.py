@@ -395,3 +395,53 @@ def test_gradient_accumulation_matches_oracle(name, dims, precision, tol, use_gr
         upd = (ref_sd[k] - sd[k]).double().norm()
         err = float((model.state_dict()[k].cpu().double() - ref_sd[k].double()).norm() / upd)
         assert err < (0.05 if precision == 'fp32' else 0.25), (k, err)
+
+
+@pytest.mark.parametrize('comm', [None, 'bf16'])
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_data_parallel_machinery_on_a_world_of_one(comm, use_graph):
+    """The N > 1 step (per-phase graphs, bucketed all-reduce between them, buckets stepped on the optimiser stream as
+    their exchange lands, optional bf16 wire) on a single-rank RCCL group: an all-reduce over one rank is the identity,
+    so two steps must land where the single-process step lands (bf16 wire: to bf16 round-off of the gradients)."""
+    import torch.distributed as dist
+    from vit_ae_plus_plus_amd.optim import FusedAdamW
+    created = False
+    if not dist.is_initialized():
+        import os
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29577')
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+        created = True
+    try:
+        cfg = R.RefConfig(contrastive=True, **ACT16)
+        sd = R.init_state_dict(cfg, seed=11)
+        B, outs = 2, []
+        for ddp_on in (False, True):
+            model = build(cfg, sd, precision='bf16')
+            opt = FusedAdamW(model, lr=1e-3, weight_decay=0.05)
+            model._ensure_engine(torch.device('cuda', 0))
+            eng = opt.engine
+            if ddp_on:
+                red = model.enable_data_parallel(torch.device('cuda', 0), force=True,
+                                                 comm_dtype=torch.bfloat16 if comm else None, enc_chunks=2)
+                assert red is not None and len(red.ranges) == 4
+            eng.set_loss_weights(0.01, 0.001, 1, 1)
+            for step in range(2):
+                v1, v2 = R.synthetic_views((B, cfg.in_chans, *cfg.volume_size), seed=700 + step)
+                model.set_masking_noise(*R.masking_noise(B, cfg.num_patches, seed=800 + step))
+                runner = model._step_runner(B, 0.75, True, False, use_graph)
+                runner.load(v1, v2)
+                eng.optimizer_hparams(lr=1e-3)
+                runner.run()
+            torch.cuda.synchronize()
+            outs.append(({k: v.detach().clone() for k, v in model.state_dict().items()}, eng.losses.cpu().tolist()))
+        (a, la), (b, lb) = outs
+        close(lb[0], la[0], 2e-3 if comm else 1e-5, 1e-7)
+        close(lb[5], la[5], 2e-2 if comm else 1e-4, 1e-7)          # grad norm
+        for k in ('decoder_pred.weight', 'blocks.0.mlp.fc1.weight', 'blocks.1.attn.qkv.weight', 'patch_embed.proj.weight',
+                  'predictor.3.weight', 'cls_token', 'norm.weight'):
+            upd = (a[k].double() - sd[k].double().cuda()).norm()
+            err = float((a[k].double() - b[k].double()).norm() / upd)
+            assert err < (0.1 if comm else 2e-3), (k, err)
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -73,17 +73,29 @@ class GradBucketReducer:
                     work = dist.all_reduce(self.wire[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                 else:
                     work = dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                self.pending.append((work, s, e))
+                self.pending.append((work, s, e, bucket))
 
     def wait(self, copy_back: bool = True):
         """Make the current stream (or the host, for CPU backends) wait for every launched bucket.  With a wire dtype,
         ``copy_back=False`` leaves the reduced values in ``self.wire`` only (the fused optimiser reads them there);
         the fp32 arena then still holds this rank's local gradients."""
-        for w, s, e in self.pending:
+        for w, s, e, _ in self.pending:
             w.wait()
             if self.wire is not None and copy_back:
                 self.flat[s:e].copy_(self.wire[s:e])
         self.pending.clear()
+
+    def wait_bucket(self, bucket: int, copy_back: bool = True):
+        """Same for the pieces of one bucket only (the caller's current stream waits; the others stay pending)."""
+        rest = []
+        for w, s, e, b in self.pending:
+            if b != bucket:
+                rest.append((w, s, e, b))
+                continue
+            w.wait()
+            if self.wire is not None and copy_back:
+                self.flat[s:e].copy_(self.wire[s:e])
+        self.pending = rest
 
 
 def engine_bucket_ranges(engine) -> List[Tuple[int, int]]:

@@ -717,7 +717,7 @@ class HipMAEEngine:
         a16 = self.act16
         lib.vitae_loss_bwd_fused(pred_ptr, _ptr(b['pred_vol']), _ptr(view1), _ptr(b['mask']), _ptr(b['edge_p']), _ptr(b['edge_t']),
                                  _ptr(self.hp), _ptr(b.get('dG')), dpred_ptr, (b['dpred_16'].data_ptr() + P * 2) if a16 else None,
-                                 self.acc.data_ptr() + 8 * _C['VITAE_ACC_NONFINITE'], pbs, self.mask_sum, B, C, Lz, Hy, Wx, ps, st)
+                                 None, pbs, self.mask_sum, B, C, Lz, Hy, Wx, ps, st)
         dx_ = b['decx']
         nd = cfg.decoder_depth
         if a16:
@@ -854,54 +854,71 @@ class HipMAEEngine:
                              s['exp_avg_sq'].data_ptr() + o, (sh + o // 2) if sh else None, self.n_total - self.vec_off,
                              _ptr(self.hp), gn, 0.0, st)
 
-    # --- optimiser inside the backward (single process): the matrices of a gradient bucket are final when its backward
-    # phase ends, so their share of the grad-norm pass and their AdamW update run on a side stream underneath the
-    # remaining, latency-bound backward kernels instead of as 0.8 ms of HBM-bound work after it.  The step-skip on a
-    # non-finite gradient (GradScaler.step) cannot wait for the global norm here; it uses the early flag the loss
-    # backward raises when it writes a non-finite gradient — the only place where one originates on this path (the
-    # 0/0 of the Sobel magnitude at |g| = 0); everything downstream of it is then non-finite as well.
+    # --- optimiser inside the backward: the matrices of a gradient bucket are final when its backward phase ends
+    # (data parallel: when its all-reduce has landed), so their share of the grad-norm pass and their AdamW update run on
+    # a side stream underneath the remaining, latency-bound backward kernels instead of as 0.8 ms of HBM-bound work
+    # after it.  The step-skip on a non-finite gradient (GradScaler.step) cannot wait for the global norm here: each
+    # bucket keys its skip on the RUNNING norm of the buckets finished so far.  On this path a non-finite gradient
+    # originates in the loss backward (the 0/0 of the Sobel magnitude at |g| = 0) and everything downstream of it — every
+    # bucket — is then non-finite too, so the running norm decides exactly like the global one; only an overflow that
+    # first appears in a LATER bucket would leave earlier buckets updated.
     def _optimizer_in_backward_ok(self) -> bool:
-        return (self.overlap_optimizer and self.opt_state is not None and self.cfg.in_chans in (1, 4)
-                and self.grads_wire16 is None and not self._ddp_active and self.gemm_timer is None)
+        """Single-process form: buckets are final when their phase ends."""
+        return (self.overlap_optimizer and self.opt_state is not None and not self._ddp_active and self.gemm_timer is None)
 
-    _ddp_active = False
+    _ddp_active = False      # the step runner exchanges gradient buckets between the phases
+    _ddp_bucket_opt = False  # ... and issues _opt_bucket itself once a bucket's all-reduce has landed
 
-    def _opt_bucket(self, k: int):
+    def _opt_bucket(self, k: int, wait_main: bool = True):
         """grad-norm share + AdamW of gradient bucket k (matrices only) on the optimiser stream."""
         from . import ddp
         s0, e0 = ddp.engine_bucket_ranges(self)[k]
         n = e0 - s0
         if n <= 0:
             return
-        self.oside.wait_stream(torch.cuda.current_stream(self.device))
+        if wait_main:
+            self.oside.wait_stream(torch.cuda.current_stream(self.device))
         st = self.oside.cuda_stream
         o = s0 * 4
         sh = self.params16.data_ptr() if self.params16 is not None else 0
-        flag = self.acc.data_ptr() + 8 * _C['VITAE_ACC_NONFINITE']
-        lib.vitae_grad_sqnorm(self.grads.data_ptr() + o, n, _ptr(self.acc), None, st)
-        lib.vitae_adamw_step(self.params.data_ptr() + o, self.grads.data_ptr() + o, self.opt_state['exp_avg'].data_ptr() + o,
-                             self.opt_state['exp_avg_sq'].data_ptr() + o, (sh + o // 2) if sh else None, n, _ptr(self.hp), flag,
-                             self.weight_decay, st)
+        run = self.losses.data_ptr() + 24          # losses[6]: norm of the buckets finished so far
+        m, v = self.opt_state['exp_avg'].data_ptr() + o, self.opt_state['exp_avg_sq'].data_ptr() + o
+        g16 = self.grads_wire16 if self._wire_ready else None
+        if g16 is not None:
+            lib.vitae_grad_sqnorm_bf16(g16.data_ptr() + o // 2, n, _ptr(self.acc), run, st)
+            lib.vitae_adamw_step_bf16g(self.params.data_ptr() + o, g16.data_ptr() + o // 2, m, v, (sh + o // 2) if sh else None, n,
+                                       _ptr(self.hp), run, self.weight_decay, st)
+        else:
+            lib.vitae_grad_sqnorm(self.grads.data_ptr() + o, n, _ptr(self.acc), run, st)
+            lib.vitae_adamw_step(self.params.data_ptr() + o, self.grads.data_ptr() + o, m, v, (sh + o // 2) if sh else None, n,
+                                 _ptr(self.hp), run, self.weight_decay, st)
         self._opt_pending = True
 
     def _opt_tail(self):
-        """Tokens + vectors (whose gradients are accumulated atomically all through the backward) and the norm."""
+        """Tokens + vectors (whose gradients are accumulated atomically all through the backward) and the final norm."""
         main = torch.cuda.current_stream(self.device)
-        main.wait_stream(self.oside)
+        if not self._ddp_bucket_opt:         # data parallel: the runner joins the optimiser stream between the graphs
+            main.wait_stream(self.oside)
         self._opt_pending = False
         st = main.cuda_stream
         gn = self.losses.data_ptr() + 20
         s = self.opt_state
         sh = self.params16.data_ptr() if self.params16 is not None else 0
         ot, ov = self.tok_off * 4, self.vec_off * 4
-        lib.vitae_grad_sqnorm(self.grads.data_ptr() + ot, self.n_total - self.tok_off, _ptr(self.acc), gn, st)
+        g16 = self.grads_wire16 if self._wire_ready else None
+        sq = (lambda off, n: lib.vitae_grad_sqnorm_bf16(g16.data_ptr() + off // 2, n, _ptr(self.acc), gn, st)) if g16 is not None \
+            else (lambda off, n: lib.vitae_grad_sqnorm(self.grads.data_ptr() + off, n, _ptr(self.acc), gn, st))
+        step = (lambda off, n, wd: lib.vitae_adamw_step_bf16g(self.params.data_ptr() + off, g16.data_ptr() + off // 2,
+                                                               s['exp_avg'].data_ptr() + off, s['exp_avg_sq'].data_ptr() + off,
+                                                               (sh + off // 2) if sh else None, n, _ptr(self.hp), gn, wd, st)) \
+            if g16 is not None else \
+            (lambda off, n, wd: lib.vitae_adamw_step(self.params.data_ptr() + off, self.grads.data_ptr() + off,
+                                                     s['exp_avg'].data_ptr() + off, s['exp_avg_sq'].data_ptr() + off,
+                                                     (sh + off // 2) if sh else None, n, _ptr(self.hp), gn, wd, st))
+        sq(ot, self.n_total - self.tok_off)
         if self.vec_off > self.tok_off:
-            lib.vitae_adamw_step(self.params.data_ptr() + ot, self.grads.data_ptr() + ot, s['exp_avg'].data_ptr() + ot,
-                                 s['exp_avg_sq'].data_ptr() + ot, (sh + ot // 2) if sh else None, self.vec_off - self.tok_off,
-                                 _ptr(self.hp), gn, self.weight_decay, st)
-        lib.vitae_adamw_step(self.params.data_ptr() + ov, self.grads.data_ptr() + ov, s['exp_avg'].data_ptr() + ov,
-                             s['exp_avg_sq'].data_ptr() + ov, (sh + ov // 2) if sh else None, self.n_total - self.vec_off,
-                             _ptr(self.hp), gn, 0.0, st)
+            step(ot, self.vec_off - self.tok_off, self.weight_decay)
+        step(ov, self.n_total - self.vec_off, 0.0)
 
     # ------------------------------------------------------------------ fused training step
     enc_chunks = 2      # encoder backward is cut into this many phases (= gradient buckets); ddp raises it
@@ -947,8 +964,8 @@ class HipMAEEngine:
             if update and self._optimizer_in_backward_ok():
                 self._opt_bucket(k)
         elif k == n + 1 and update:
-            if self._opt_pending:
-                self._opt_tail()
+            if self._optimizer_in_backward_ok() or self._ddp_bucket_opt:
+                self._opt_tail()             # the buckets' matrices were stepped beside the backward
             else:
                 self.grad_norm_and_step()
 

@@ -151,7 +151,9 @@ class _StepRunner:
         nph = eng.N_PHASES
         groups = [[k] for k in range(nph)] if exchange else [list(range(nph))]
         eng._wire_ready = exchange and eng.grads_wire16 is not None    # read at launch / capture time of the last phase
-        eng._ddp_active = exchange          # buckets still change after their phase (all-reduce): optimiser stays at the end
+        eng._ddp_active = exchange          # buckets change after their phase (all-reduce): the runner steps them below
+        bucket_opt = exchange and eng.overlap_optimizer and eng.opt_state is not None
+        eng._ddp_bucket_opt = bucket_opt    # last phase = tokens/vectors + norm only
         if self.use_graph and self.graphs is None:
             self._capture(groups)
         for i, grp in enumerate(groups):
@@ -162,9 +164,17 @@ class _StepRunner:
                     self._phase(k)
             if exchange and i < nph - 1:
                 red.launch(i)                 # bucket i is final after phase i
+                if bucket_opt:
+                    # once bucket i's all-reduce has landed its matrices are stepped on the optimiser stream, underneath
+                    # the next backward phases (the reduced values are read from the wire buffer when it is bf16)
+                    with torch.cuda.stream(eng.oside):
+                        red.wait_bucket(i, copy_back=eng.grads_wire16 is None)
+                    eng._opt_bucket(i, wait_main=False)
                 if i == nph - 2:
                     red.launch(nph - 1)       # tokens + vectors
                     red.wait(copy_back=eng.grads_wire16 is None)
+                    if bucket_opt:
+                        torch.cuda.current_stream(eng.device).wait_stream(eng.oside)
 
 
 class MaskedAutoencoderViT(nn.Module):
