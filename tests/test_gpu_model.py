@@ -445,3 +445,35 @@ def test_data_parallel_machinery_on_a_world_of_one(comm, use_graph):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_host_batches_are_double_buffered_and_match_device_batches():
+    """Pinned host batches go through the copy stream into alternating input slots (one captured graph per slot);
+    three graph-replayed steps must land exactly where the same steps fed from device tensors land."""
+    from vit_ae_plus_plus_amd.optim import FusedAdamW
+    cfg = R.RefConfig(contrastive=True, **ACT16)
+    sd = R.init_state_dict(cfg, seed=13)
+    B, finals = 2, []
+    for host in (False, True):
+        model = build(cfg, sd, precision='bf16')
+        opt = FusedAdamW(model, lr=1e-3, weight_decay=0.05)
+        model._ensure_engine(torch.device('cuda', 0))
+        eng = opt.engine
+        eng.set_loss_weights(0.01, 0.001, 1, 1)
+        runner = model._step_runner(B, 0.75, True, False, True)
+        slots = set()
+        for step in range(3):
+            v1, v2 = R.synthetic_views((B, cfg.in_chans, *cfg.volume_size), seed=900 + step)
+            model.set_masking_noise(*R.masking_noise(B, cfg.num_patches, seed=950 + step))
+            if host:
+                runner.load(v1.pin_memory(), v2.pin_memory())
+            else:
+                runner.load(v1.cuda(), v2.cuda())
+            slots.add(runner.st['cur'])
+            eng.optimizer_hparams(lr=1e-3)
+            runner.run()
+        torch.cuda.synchronize()
+        assert slots == ({0, 1} if host else {0})
+        finals.append((eng.losses.cpu().tolist(), model.state_dict()['blocks.0.mlp.fc1.weight'].clone()))
+    close(finals[1][0][0], finals[0][0][0], 1e-5, 1e-7)
+    assert float((finals[0][1] - finals[1][1]).abs().max()) < 1e-6

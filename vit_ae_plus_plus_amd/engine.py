@@ -921,7 +921,8 @@ class HipMAEEngine:
         step(ov, self.n_total - self.vec_off, 0.0)
 
     # ------------------------------------------------------------------ fused training step
-    enc_chunks = 2      # encoder backward is cut into this many phases (= gradient buckets); ddp raises it
+    # encoder backward is cut into this many phases (= gradient buckets = optimiser-in-backward units)
+    enc_chunks = int(os.environ.get('VITAE_ENC_CHUNKS', '2'))
 
     def set_backward_chunks(self, n: int):
         """Number of encoder-backward phases.  More phases = smaller gradient buckets = an earlier start and a shorter
