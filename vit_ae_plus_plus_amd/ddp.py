@@ -69,7 +69,9 @@ class GradBucketReducer:
         for s, e in self.ranges[bucket]:
             if e > s:
                 if self.wire is not None:
-                    self.wire[s:e].copy_(self.flat[s:e])          # round to the wire dtype (current stream)
+                    # round to the wire dtype on the CURRENT stream: moving this pass to its own stream (to hide it under
+                    # the next phase) made the step 0.35 ms slower — event hops between graph replays cost more
+                    self.wire[s:e].copy_(self.flat[s:e])
                     work = dist.all_reduce(self.wire[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                 else:
                     work = dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
