@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITAE_ABI_VERSION 16
+#define VITAE_ABI_VERSION 17
 
 /* matrix-core arithmetic of the dense contractions */
 #define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
@@ -107,7 +107,9 @@ int vitae_gemm_glds_pick_split_k(int M, int N, int K);
  * dx_colsum_accum[k] += sum_m dx(m,k); dW[N,K] (+)= dy16^T x16 reduced over Mpad (>= M, multiple of 64) token
  * rows — rows M..Mpad-1 of dy16 and x16 must be zero. */
 int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, const void* x16, float* dx, void* dx16, float* dw,
-                               int M, int Mpad, int N, int K, int epi, float* aux, float* dx_colsum_accum,
+                               void* dw16 /* optional bf16 copy of the (accumulated) dW: the wire buffer of a bf16
+                               data-parallel gradient exchange */, int M, int Mpad, int N, int K, int epi, float* aux,
+                               float* dx_colsum_accum,
                                int dw_accumulate, int split_k, float* splitk_ws, void* stream);
 /* split of the dgrad reduction for the call above (1 = none); workspace as for vitae_gemm_glds with (M, K) */
 int vitae_linear_bwd_pair_pick_split_k(int M, int Mpad, int N, int K);

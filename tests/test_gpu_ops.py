@@ -179,22 +179,24 @@ def test_linear_bwd_pair_glds(lib, C, M, N, K):
     hd_ = dev(h)
     dx, dx16 = torch.full((M, K), float('nan'), device='cuda'), torch.zeros(M, K, dtype=torch.bfloat16, device='cuda')
     dw, cs = torch.full((N, K), float('nan'), device='cuda'), torch.zeros(K, device='cuda')
+    dw16 = torch.zeros(N, K, dtype=torch.bfloat16, device='cuda')
     split = lib.vitae_linear_bwd_pair_pick_split_k(M, Mp, N, K)
     ws = torch.zeros(max(1, lib.vitae_gemm_glds_ws_floats(M, K, max(split, 3))), device='cuda')
-    lib.vitae_linear_bwd_pair_glds(dy16.data_ptr(), w16.data_ptr(), x16.data_ptr(), dx.data_ptr(), dx16.data_ptr(), dw.data_ptr(),
+    lib.vitae_linear_bwd_pair_glds(dy16.data_ptr(), w16.data_ptr(), x16.data_ptr(), dx.data_ptr(), dx16.data_ptr(), dw.data_ptr(), dw16.data_ptr(),
                                    M, Mp, N, K, C['VITAE_EPI_DGELU'], hd_.data_ptr(), cs.data_ptr(), 0, split, ws.data_ptr(), st())
     dyr, wr, xr = dy16[:M].float().cpu(), w16.float().cpu(), x16[:M].float().cpu()
     hh = h.clone().requires_grad_(True)
     F.gelu(hh).backward(dyr @ wr)
     assert rel_err(dx, hh.grad) < 2e-3 and rel_err(dw, dyr.t() @ xr) < 2e-3
     assert torch.equal(dx16, dx.to(torch.bfloat16)) and rel_err(cs, dx.sum(0)) < 1e-4
+    assert torch.equal(dw16, dw.to(torch.bfloat16))
     assert int(ws[:C['VITAE_GLDS_TICKETS']].abs().sum()) == 0      # tickets handed back
     # forced 3-way split of the dgrad reduction: same numbers as the unsplit launch up to fp32 summation order
-    lib.vitae_linear_bwd_pair_glds(dy16.data_ptr(), w16.data_ptr(), x16.data_ptr(), dx.data_ptr(), None, dw.data_ptr(),
+    lib.vitae_linear_bwd_pair_glds(dy16.data_ptr(), w16.data_ptr(), x16.data_ptr(), dx.data_ptr(), None, dw.data_ptr(), None,
                                    M, Mp, N, K, 0, None, None, 1, 3 if N >= 192 else 1, ws.data_ptr(), st())
     assert rel_err(dx, dyr @ wr) < 2e-3 and rel_err(dw, 2 * (dyr.t() @ xr)) < 2e-3
     d1 = dx.clone()
-    lib.vitae_linear_bwd_pair_glds(dy16.data_ptr(), w16.data_ptr(), x16.data_ptr(), dx.data_ptr(), None, dw.data_ptr(),
+    lib.vitae_linear_bwd_pair_glds(dy16.data_ptr(), w16.data_ptr(), x16.data_ptr(), dx.data_ptr(), None, dw.data_ptr(), None,
                                    M, Mp, N, K, 0, None, None, 0, 3 if N >= 192 else 1, ws.data_ptr(), st())
     assert torch.equal(dx, d1)                                      # split order is fixed -> bitwise reproducible
 

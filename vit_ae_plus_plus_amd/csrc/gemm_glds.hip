@@ -442,7 +442,7 @@ extern "C" int vitae_linear_bwd_pair_pick_split_k(int M, int Mpad, int N, int K)
 }
 
 extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, const void* x16, float* dx, void* dx16,
-                                          float* dw, int M, int Mpad, int N, int K, int epi, float* aux,
+                                          float* dw, void* dw16, int M, int Mpad, int N, int K, int epi, float* aux,
                                           float* dx_colsum_accum, int dw_accumulate, int split_k, float* splitk_ws,
                                           void* stream) {
     if (!dy16 || !w16 || !x16 || (!dx && !dx16) || !dw || M <= 0 || N <= 0 || K <= 0) return VITAE_ERR_INVALID_ARG;
@@ -465,7 +465,7 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
     p1.tiles_m = cdiv(M, t1.bm); p1.tiles_n = cdiv(K, t1.bn);
     p2.A = reinterpret_cast<const __bf16*>(dy16); p2.lda = N;
     p2.B = reinterpret_cast<const __bf16*>(x16); p2.ldb = K;
-    p2.C = dw; p2.ldc = K; p2.C16 = nullptr; p2.ldc16 = 0;
+    p2.C = dw; p2.ldc = K; p2.C16 = reinterpret_cast<__bf16*>(dw16); p2.ldc16 = K;
     p2.M = N; p2.N = K; p2.K = Mpad; p2.k_per_split = Mpad; p2.splits = 1;
     p2.bias = nullptr; p2.residual = nullptr; p2.ldr = 0; p2.aux = nullptr; p2.ldaux = 0; p2.epi = VITAE_EPI_NONE;
     p2.accumulate = dw_accumulate; p2.ws = nullptr; p2.out_colsum = nullptr;

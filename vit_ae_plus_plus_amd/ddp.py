@@ -33,7 +33,8 @@ class GradBucketReducer:
     """Asynchronous SUM all-reduce of contiguous ranges of one flat gradient tensor."""
 
     def __init__(self, flat: torch.Tensor, ranges: Sequence[Tuple[int, int]], group=None,
-                 max_bucket_elems: Optional[int] = None, force: bool = False, comm_dtype: Optional[torch.dtype] = None):
+                 max_bucket_elems: Optional[int] = None, force: bool = False, comm_dtype: Optional[torch.dtype] = None,
+                 cast_ranges: Optional[Sequence[Tuple[int, int]]] = None):
         assert flat.dim() == 1
         self.flat, self.group = flat, group
         self.comm_dtype = comm_dtype if comm_dtype not in (None, flat.dtype) else None
@@ -51,6 +52,9 @@ class GradBucketReducer:
             else:
                 parts.append((s, e))
             self.ranges.append(parts)
+        # with a wire dtype: the sub-ranges that still need rounding into the wire buffer at launch time (None = all;
+        # the engine's wgrad epilogues write the wire copy of the big matrices themselves)
+        self.cast_ranges = None if cast_ranges is None else sorted(cast_ranges)
         self.pending = []
 
     @property
@@ -71,7 +75,13 @@ class GradBucketReducer:
                 if self.wire is not None:
                     # round to the wire dtype on the CURRENT stream: moving this pass to its own stream (to hide it under
                     # the next phase) made the step 0.35 ms slower — event hops between graph replays cost more
-                    self.wire[s:e].copy_(self.flat[s:e])
+                    if self.cast_ranges is None:
+                        self.wire[s:e].copy_(self.flat[s:e])
+                    else:
+                        for cs, ce in self.cast_ranges:
+                            a, b = max(cs, s), min(ce, e)
+                            if b > a:
+                                self.wire[a:b].copy_(self.flat[a:b])
                     work = dist.all_reduce(self.wire[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                 else:
                     work = dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)

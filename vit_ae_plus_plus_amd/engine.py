@@ -467,6 +467,39 @@ class HipMAEEngine:
         if t is not None:
             t.record()
 
+    def _wire_of(self, gview: torch.Tensor):
+        """bf16 data-parallel exchange: address of this gradient tensor's slot in the wire buffer (same layout as the
+        arena), so the wgrad epilogue writes the rounded copy itself and the bucket needs no separate rounding pass."""
+        w = self.grads_wire16
+        if w is None:
+            return None
+        return w.data_ptr() + (gview.data_ptr() - self.grads.data_ptr()) // 2
+
+    def wire_uncovered_ranges(self):
+        """Element ranges of the arena whose bf16 wire copy is NOT written by a GEMM epilogue (the reducer rounds those)."""
+        if not self.act16:
+            return [(0, self.n_total)]
+        cfg = self.cfg
+        covered = ['patch_embed.proj.weight', 'decoder_pred.weight']
+        for pre, depth in (('blocks.', cfg.depth), ('decoder_blocks.', cfg.decoder_depth)):
+            for i in range(depth):
+                covered += [f'{pre}{i}.{n}.weight' for n in ('attn.qkv', 'attn.proj', 'mlp.fc1', 'mlp.fc2')]
+        cov = set(covered)
+        out, cur = [], None
+        for n, (o, shp) in self.layout.items():
+            k = (int(np.prod(shp)) + 3) // 4 * 4
+            if n in cov:
+                if cur is not None:
+                    out.append(tuple(cur)); cur = None
+            else:
+                if cur is None:
+                    cur = [o, o + k]
+                else:
+                    cur[1] = o + k
+        if cur is not None:
+            out.append(tuple(cur))
+        return out
+
     def _g16_bwd(self, dy16, w, x16, dw, M, Mpad, N, K, dx=None, dx16=None, epi=EPI_NONE, aux=None, dx_colsum=None):
         """dx / dx16 = epi(dy16 @ W16), dW (+)= dy16^T @ x16 in one paired launch."""
         key = ('p', M, N, K)
@@ -477,7 +510,8 @@ class HipMAEEngine:
                 s -= 1
             self._split_cache[key] = s
         t = self._timed(4.0 * M * N * K, 'glds_pair' if N < 8192 else 'glds_pair_wide')
-        lib.vitae_linear_bwd_pair_glds(_ptr(dy16), self._w16(w), _ptr(x16), _ptr(dx), _ptr(dx16), _ptr(dw), M, Mpad, N, K,
+        lib.vitae_linear_bwd_pair_glds(_ptr(dy16), self._w16(w), _ptr(x16), _ptr(dx), _ptr(dx16), _ptr(dw), self._wire_of(dw), M, Mpad,
+                                       N, K,
                                        epi, _ptr(aux), _ptr(dx_colsum), int(self._accum), s, self.ws16.data_ptr(), self.stream)
         if t is not None:
             t.record()
@@ -805,7 +839,7 @@ class HipMAEEngine:
             # dW[D, P] = dtok16^T @ patches16 (both row-contiguous bf16, reduced over the padded token count)
             t = self._timed(2.0 * T * D * P, 'glds_wide')
             lib.vitae_gemm_glds(0, 0, _ptr(b['dtok_16']), D, _ptr(b['patches_16']), P, _ptr(g['patch_embed.proj.weight']), P,
-                                None, 0, D, P, self.Mpt, None, None, 0, EPI_NONE, None, 0, int(self._accum), 1, None, None,
+                                self._wire_of(g['patch_embed.proj.weight']), P, D, P, self.Mpt, None, None, 0, EPI_NONE, None, 0, int(self._accum), 1, None, None,
                                 self.stream)
             if t is not None:
                 t.record()

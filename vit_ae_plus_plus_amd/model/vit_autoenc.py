@@ -372,6 +372,9 @@ class MaskedAutoencoderViT(nn.Module):
         eng.set_backward_chunks(enc_chunks)
         self._reducer = ddp.GradBucketReducer(eng.grads, ddp.engine_bucket_ranges(eng), group=group, force=force,
                                               comm_dtype=comm_dtype)
+        if self._reducer.wire is not None and self._reducer.active:
+            eng.grads_wire16 = self._reducer.wire
+            self._reducer.cast_ranges = eng.wire_uncovered_ranges()   # the rest is written by the wgrad epilogues
         # bf16 exchange: the fused grad-norm + AdamW read the reduced gradients straight from the wire buffer
         eng.grads_wire16 = self._reducer.wire if (self._reducer.wire is not None and self._reducer.active) else None
         self._runners.clear()
