@@ -1,8 +1,8 @@
-"""Per-step kernel time table from a rocprofv3 --kernel-trace --stats run of bench.py (steps inferred from grad_sqnorm calls)."""
+"""Per-step kernel time table from a rocprofv3 --kernel-trace --stats run of bench.py (steps = loss_finalize_kernel calls)."""
 import csv, glob, re, sys
 f = glob.glob(sys.argv[1] + '/**/*kernel_stats.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
-n = [int(r['Calls']) for r in rows if 'grad_sqnorm' in r['Name']][0]
+n = [int(r['Calls']) for r in rows if 'loss_finalize_kernel' in r['Name']][0]
 thr = float(sys.argv[2]) if len(sys.argv) > 2 else 25
 tot = 0
 for r in rows:

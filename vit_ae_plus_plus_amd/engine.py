@@ -650,7 +650,7 @@ class HipMAEEngine:
         for i in range(cfg.depth):
             self._block_fwd(f'blocks.{i}.', f'enc{i}.', ex[i], ex[i + 1], Be, Ne, D, cfg.num_heads, self.hd, self.Hm)
         self._ln_fwd(ex[cfg.depth], 'norm.', b['latent'], b['lat_mean'], b['lat_rstd'], Me, D)
-        if cfg.contrastive and self.overlap_predictor and self.gemm_timer is None:
+        if cfg.contrastive and self.overlap_predictor:
             # the predictor branch only needs the latent: it runs on its own stream beside the decoder and the loss chain
             self.pside.wait_stream(torch.cuda.current_stream(self.device))
             with self._OnPredictorStream(self):
@@ -898,7 +898,7 @@ class HipMAEEngine:
     # first appears in a LATER bucket would leave earlier buckets updated.
     def _optimizer_in_backward_ok(self) -> bool:
         """Single-process form: buckets are final when their phase ends."""
-        return (self.overlap_optimizer and self.opt_state is not None and not self._ddp_active and self.gemm_timer is None)
+        return self.overlap_optimizer and self.opt_state is not None and not self._ddp_active
 
     _ddp_active = False      # the step runner exchanges gradient buckets between the phases
     _ddp_bucket_opt = False  # ... and issues _opt_bucket itself once a bucket's all-reduce has landed
