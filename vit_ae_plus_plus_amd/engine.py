@@ -21,10 +21,9 @@ from __future__ import annotations
 
 import os
 
-import math
 from collections import OrderedDict
 from dataclasses import dataclass
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, Optional, Tuple
 
 import numpy as np
 import torch
