@@ -128,7 +128,7 @@ def test_gemm_bf16_pipeline(lib, C, b16, M, N, K):
         assert rel_err(y, F.linear(x, w, b) + res) < tol, f'fwd split {split}'
     y, aux = torch.empty(M, N, device='cuda'), torch.empty(M, N, device='cuda')
     lib.vitae_gemm_bf16(1, 1, xd.data_ptr(), K, wp.data_ptr(), K, b16, y.data_ptr(), N, M, N, K, bd.data_ptr(), None, 0,
-                        C['VITAE_EPI_GELU'], aux.data_ptr(), N, 0, 1, None, None, st())
+                        C['VITAE_EPI_GELU'], aux.data_ptr(), N, 0, 1, None, None, None, st())
     pre = F.linear(x, w, b)
     assert rel_err(aux, pre) < tol and rel_err(y, F.gelu(pre)) < tol
     dy = gen(M, N, seed=5)
@@ -180,24 +180,26 @@ def test_linear_bwd_pair_glds(lib, C, M, N, K):
     dx, dx16 = torch.full((M, K), float('nan'), device='cuda'), torch.zeros(M, K, dtype=torch.bfloat16, device='cuda')
     dw, cs = torch.full((N, K), float('nan'), device='cuda'), torch.zeros(K, device='cuda')
     dw16 = torch.zeros(N, K, dtype=torch.bfloat16, device='cuda')
+    dycs = torch.zeros(N, device='cuda')
     split = lib.vitae_linear_bwd_pair_pick_split_k(M, Mp, N, K)
     ws = torch.zeros(max(1, lib.vitae_gemm_glds_ws_floats(M, K, max(split, 3))), device='cuda')
     lib.vitae_linear_bwd_pair_glds(dy16.data_ptr(), w16.data_ptr(), x16.data_ptr(), dx.data_ptr(), dx16.data_ptr(), dw.data_ptr(), dw16.data_ptr(),
-                                   M, Mp, N, K, C['VITAE_EPI_DGELU'], hd_.data_ptr(), cs.data_ptr(), 0, split, ws.data_ptr(), st())
+                                   M, Mp, N, K, C['VITAE_EPI_DGELU'], hd_.data_ptr(), cs.data_ptr(), dycs.data_ptr(), 0, split, ws.data_ptr(), st())
     dyr, wr, xr = dy16[:M].float().cpu(), w16.float().cpu(), x16[:M].float().cpu()
     hh = h.clone().requires_grad_(True)
     F.gelu(hh).backward(dyr @ wr)
     assert rel_err(dx, hh.grad) < 2e-3 and rel_err(dw, dyr.t() @ xr) < 2e-3
     assert torch.equal(dx16, dx.to(torch.bfloat16)) and rel_err(cs, dx.sum(0)) < 1e-4
     assert torch.equal(dw16, dw.to(torch.bfloat16))
+    assert rel_err(dycs, dyr.sum(0)) < 1e-5                      # bias gradient from the wgrad workgroups
     assert int(ws[:C['VITAE_GLDS_TICKETS']].abs().sum()) == 0      # tickets handed back
     # forced 3-way split of the dgrad reduction: same numbers as the unsplit launch up to fp32 summation order
     lib.vitae_linear_bwd_pair_glds(dy16.data_ptr(), w16.data_ptr(), x16.data_ptr(), dx.data_ptr(), None, dw.data_ptr(), None,
-                                   M, Mp, N, K, 0, None, None, 1, 3 if N >= 192 else 1, ws.data_ptr(), st())
+                                   M, Mp, N, K, 0, None, None, None, 1, 3 if N >= 192 else 1, ws.data_ptr(), st())
     assert rel_err(dx, dyr @ wr) < 2e-3 and rel_err(dw, 2 * (dyr.t() @ xr)) < 2e-3
     d1 = dx.clone()
     lib.vitae_linear_bwd_pair_glds(dy16.data_ptr(), w16.data_ptr(), x16.data_ptr(), dx.data_ptr(), None, dw.data_ptr(), None,
-                                   M, Mp, N, K, 0, None, None, 0, 3 if N >= 192 else 1, ws.data_ptr(), st())
+                                   M, Mp, N, K, 0, None, None, None, 0, 3 if N >= 192 else 1, ws.data_ptr(), st())
     assert torch.equal(dx, d1)                                      # split order is fixed -> bitwise reproducible
 
 
@@ -210,13 +212,15 @@ def test_gemm_glds_forward_forms(lib, C, M, N, K):
     for split in (1, lib.vitae_gemm_glds_pick_split_k(M, N, K), 2):
         ws = torch.zeros(max(1, lib.vitae_gemm_glds_ws_floats(M, N, split)), device='cuda')
         y, y16, cs = torch.full((M, N), float('nan'), device='cuda'), torch.zeros(M, N, dtype=torch.bfloat16, device='cuda'), torch.zeros(N, device='cuda')
+        rs = torch.zeros(M, device='cuda')
         lib.vitae_gemm_glds(1, 1, x16.data_ptr(), K, w16.data_ptr(), K, y.data_ptr(), N, y16.data_ptr(), N, M, N, K, bd.data_ptr(),
-                            rd.data_ptr(), N, 0, None, 0, 0, split, ws.data_ptr(), cs.data_ptr(), st())
+                            rd.data_ptr(), N, 0, None, 0, 0, split, ws.data_ptr(), cs.data_ptr(), rs.data_ptr(), st())
         assert rel_err(y, ref + res) < 2e-3, f'split {split}'
         assert torch.equal(y16, y.to(torch.bfloat16)) and rel_err(cs, y.sum(0)) < 1e-4
+        assert rel_err(rs, x16.float().sum(1)) < 1e-5            # row sums of A via the ones-operand MFMA
     y16, aux = torch.zeros(M, N, dtype=torch.bfloat16, device='cuda'), torch.empty(M, N, device='cuda')
     lib.vitae_gemm_glds(1, 1, x16.data_ptr(), K, w16.data_ptr(), K, None, 0, y16.data_ptr(), N, M, N, K, bd.data_ptr(), None, 0,
-                        C['VITAE_EPI_GELU'], aux.data_ptr(), N, 0, 1, None, None, st())
+                        C['VITAE_EPI_GELU'], aux.data_ptr(), N, 0, 1, None, None, None, st())
     assert rel_err(aux, ref) < 2e-3 and rel_err(y16.float(), F.gelu(ref)) < 1e-2
 
 

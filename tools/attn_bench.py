@@ -1,0 +1,33 @@
+"""Attention kernel timings at the bench shapes (graph replay of 20 launches): forward, one-launch backward with and
+without the fused qkv-bias column sums, and the two-kernel fallback."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from vit_ae_plus_plus_amd import _abi
+lib = _abi.lib
+
+def timeit(fn, n=20):
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for _ in range(3): fn(s.cuda_stream)
+        s.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            for _ in range(n): fn(s.cuda_stream)
+        g.replay(); s.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(s); g.replay(); g.replay(); b.record(s); s.synchronize()
+    return a.elapsed_time(b) / (2 * n) * 1e3
+
+for B, N, H, hd in ((8, 55, 12, 64), (4, 217, 16, 32)):
+    D = H * hd
+    qkv, do = torch.randn(B, N, 3 * D, device='cuda'), torch.randn(B, N, D, device='cuda')
+    o, lse = torch.empty(B, N, D, device='cuda'), torch.empty(B, H, N, device='cuda')
+    o16 = torch.empty(B, N, D, dtype=torch.bfloat16, device='cuda')
+    dqkv, d16 = torch.empty_like(qkv), torch.empty(B, N, 3 * D, dtype=torch.bfloat16, device='cuda')
+    cs, delta = torch.zeros(3 * D, device='cuda'), torch.empty(B, H, N, device='cuda')
+    P = lambda t: t.data_ptr()
+    fwd = timeit(lambda st: lib.vitae_sdpa_mfma_fwd(P(qkv), P(o), P(o16), P(lse), B, N, H, hd, st))
+    bwd = timeit(lambda st: lib.vitae_sdpa_mfma_bwd(P(qkv), P(o), P(do), P(lse), P(dqkv), P(d16), P(cs), P(delta), B, N, H, hd, st))
+    bwd0 = timeit(lambda st: lib.vitae_sdpa_mfma_bwd(P(qkv), P(o), P(do), P(lse), P(dqkv), P(d16), None, P(delta), B, N, H, hd, st))
+    print(f'B={B} N={N} H={H} hd={hd}: fwd {fwd:.1f} us  bwd {bwd:.1f} us  bwd without bias colsum {bwd0:.1f} us')

@@ -83,7 +83,7 @@ def run_glds(name, form, M, N, K, iters=50, check=True):
         i = cnt[0] % len(As)
         lib.vitae_gemm_glds(akc, bkc, As[i].data_ptr(), lda, B16.data_ptr(), ldb, Cs[i % len(Cs)].data_ptr(), N, None, 0, M, N, Kp,
                             bias.data_ptr() if RES else None, Rs[i % len(Rs)].data_ptr() if RES else None, N, 0,
-                            None, 0, 0, split, ws.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+                            None, 0, 0, split, ws.data_ptr(), None, None, torch.cuda.current_stream().cuda_stream)
     for _ in range(5): go()
     torch.cuda.synchronize()
     err = ''
@@ -114,7 +114,7 @@ def run_pair(name, M, N, K, iters=50):
         cnt[0] += 1
         w = Ws[cnt[0] % len(Ws)]
         lib.vitae_linear_bwd_pair_glds(dy16.data_ptr(), w.data_ptr(), x16.data_ptr(), dx.data_ptr(), None, dw.data_ptr(), None, M, Mp, N, K,
-                                       0, None, None, 0, split, ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                                       0, None, None, None, 0, split, ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
     for _ in range(5): go()
     torch.cuda.synchronize()
     e1 = float((dx - dy16[:M].float() @ w0.float()).abs().max() / (dx.abs().max() + 1e-20))

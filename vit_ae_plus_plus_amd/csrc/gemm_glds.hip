@@ -41,6 +41,8 @@ struct GArgs {
     int epi, accumulate;
     float* ws;           // split-K: [VITAE_GLDS_TICKETS ints of tile tickets (zero between launches)][partial tiles]
     float* out_colsum;   // optional: out_colsum[n] += sum_m (epilogue result)(m, n)  (bias gradient of the NEXT Linear)
+    float* a_rowsum;     // optional: a_rowsum[m] += sum_k A(m, k): in a wgrad (A = dy^T) this is colsum(dy), the bias gradient
+                         // of THIS Linear, obtained with one extra MFMA against a ones operand in the tn == 0 workgroups
     int tiles_m, tiles_n;
 };
 
@@ -216,6 +218,16 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[h][f][i] = 0.f;
 
+    const bool rowsum = p.a_rowsum != nullptr && tn == 0 && wn == 0;   // wave-uniform; every k-split adds its share
+    f32x16 accx[FM];
+#pragma unroll
+    for (int f = 0; f < FM; ++f)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accx[f][i] = 0.f;
+    bf16x8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
+
     auto issue = [&](int t) {
         unsigned char* st = smem + (t % NST) * STAGE;
         dma_tile<BM, A_KC, NW>(p.A, p.lda, p.M, m0, kbeg + t * BK, st, wave, lane);
@@ -254,6 +266,23 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
                 for (int fn = 0; fn < FN; ++fn)
                     acc[kk & 1][fm * FN + fn] =
                         __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][fm], fb[kk][fn], acc[kk & 1][fm * FN + fn], 0, 0, 0);
+        if (rowsum) {
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk)
+#pragma unroll
+                for (int fm = 0; fm < FM; ++fm)
+                    accx[fm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][fm], ones, accx[fm], 0, 0, 0);
+        }
+    }
+    if (rowsum && l31 == 0) {
+        // every column of accx holds the row sums of this workgroup's k-range
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * (BM / WAVES_M) + fm * 32 + crow(r, hi);
+                if (m < p.M) atomicAdd(p.a_rowsum + m, accx[fm][r]);
+            }
     }
 
     float a[NF][16];
@@ -388,7 +417,7 @@ extern "C" long vitae_gemm_glds_ws_floats(int M, int N, int split_k) {
 extern "C" int vitae_gemm_glds(int a_kcontig, int b_kcontig, const void* A16, long lda, const void* B16, long ldb,
                                float* C, long ldc, void* C16, long ldc16, int M, int N, int K, const float* bias,
                                const float* residual, long ldr, int epi, float* aux, long ldaux, int accumulate,
-                               int split_k, float* splitk_ws, float* out_colsum_accum, void* stream) {
+                               int split_k, float* splitk_ws, float* out_colsum_accum, float* a_rowsum_accum, void* stream) {
     if (!A16 || !B16 || (!C && !C16) || M <= 0 || N <= 0 || K <= 0) return VITAE_ERR_INVALID_ARG;
     if (epi != VITAE_EPI_NONE && !aux) return VITAE_ERR_INVALID_ARG;
     if (K % BK) return VITAE_ERR_UNSUPPORTED_SHAPE;
@@ -410,7 +439,7 @@ extern "C" int vitae_gemm_glds(int a_kcontig, int b_kcontig, const void* A16, lo
     if (split_k > 1 && !splitk_ws) return VITAE_ERR_INVALID_ARG;
     p.k_per_split = kps; p.splits = split_k;
     p.bias = bias; p.residual = residual; p.ldr = ldr; p.aux = aux; p.ldaux = ldaux;
-    p.epi = epi; p.accumulate = accumulate; p.ws = splitk_ws; p.out_colsum = out_colsum_accum;
+    p.epi = epi; p.accumulate = accumulate; p.ws = splitk_ws; p.out_colsum = out_colsum_accum; p.a_rowsum = a_rowsum_accum;
     const Tile t = pick_tile(M, N);
     p.tiles_m = cdiv(M, t.bm); p.tiles_n = cdiv(N, t.bn);
     if (split_k > 1 && (long)p.tiles_m * p.tiles_n > VITAE_GLDS_TICKETS) return VITAE_ERR_UNSUPPORTED_SHAPE;
@@ -443,8 +472,8 @@ extern "C" int vitae_linear_bwd_pair_pick_split_k(int M, int Mpad, int N, int K)
 
 extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, const void* x16, float* dx, void* dx16,
                                           float* dw, void* dw16, int M, int Mpad, int N, int K, int epi, float* aux,
-                                          float* dx_colsum_accum, int dw_accumulate, int split_k, float* splitk_ws,
-                                          void* stream) {
+                                          float* dx_colsum_accum, float* dy_colsum_accum, int dw_accumulate, int split_k,
+                                          float* splitk_ws, void* stream) {
     if (!dy16 || !w16 || !x16 || (!dx && !dx16) || !dw || M <= 0 || N <= 0 || K <= 0) return VITAE_ERR_INVALID_ARG;
     if (epi != VITAE_EPI_NONE && !aux) return VITAE_ERR_INVALID_ARG;
     if ((N % BK) || (Mpad % BK) || (K & 7) || Mpad < M) return VITAE_ERR_UNSUPPORTED_SHAPE;
@@ -459,7 +488,7 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
     split_k = cdiv(N, kps);
     p1.M = M; p1.N = K; p1.K = N; p1.k_per_split = kps; p1.splits = split_k;
     p1.bias = nullptr; p1.residual = nullptr; p1.ldr = 0; p1.aux = aux; p1.ldaux = K; p1.epi = epi; p1.accumulate = 0;
-    p1.ws = splitk_ws; p1.out_colsum = dx_colsum_accum;
+    p1.ws = splitk_ws; p1.out_colsum = dx_colsum_accum; p1.a_rowsum = nullptr;
     Tile t1 = pick_tile(M, K);
     if (t1.id == 3) t1 = Tile{64, 128, 1};      // the paired launch is 4-wave only
     p1.tiles_m = cdiv(M, t1.bm); p1.tiles_n = cdiv(K, t1.bn);
@@ -468,7 +497,7 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
     p2.C = dw; p2.ldc = K; p2.C16 = reinterpret_cast<__bf16*>(dw16); p2.ldc16 = K;
     p2.M = N; p2.N = K; p2.K = Mpad; p2.k_per_split = Mpad; p2.splits = 1;
     p2.bias = nullptr; p2.residual = nullptr; p2.ldr = 0; p2.aux = nullptr; p2.ldaux = 0; p2.epi = VITAE_EPI_NONE;
-    p2.accumulate = dw_accumulate; p2.ws = nullptr; p2.out_colsum = nullptr;
+    p2.accumulate = dw_accumulate; p2.ws = nullptr; p2.out_colsum = nullptr; p2.a_rowsum = dy_colsum_accum;
     Tile t2 = pick_tile(N, K);
     if (t2.id == 3) t2 = Tile{64, 128, 1};
     p2.tiles_m = cdiv(N, t2.bm); p2.tiles_n = cdiv(K, t2.bn);

@@ -462,7 +462,7 @@ class HipMAEEngine:
             self._split_cache[key] = s
         t = self._timed(2.0 * M * N * K, 'glds' if N < 8192 else 'glds_wide')   # wide = the 64x128-tile instantiation
         lib.vitae_gemm_glds(1, 1, _ptr(x16), K, self._w16(w), K, _ptr(y), N, _ptr(y16), N, M, N, K, _ptr(bias), _ptr(res), N,
-                            epi, _ptr(aux), N, 0, s, self.ws16.data_ptr(), None, self.stream)
+                            epi, _ptr(aux), N, 0, s, self.ws16.data_ptr(), None, None, self.stream)
         if t is not None:
             t.record()
 
@@ -499,7 +499,8 @@ class HipMAEEngine:
             out.append(tuple(cur))
         return out
 
-    def _g16_bwd(self, dy16, w, x16, dw, M, Mpad, N, K, dx=None, dx16=None, epi=EPI_NONE, aux=None, dx_colsum=None):
+    def _g16_bwd(self, dy16, w, x16, dw, M, Mpad, N, K, dx=None, dx16=None, epi=EPI_NONE, aux=None, dx_colsum=None,
+                 dy_colsum=None):
         """dx / dx16 = epi(dy16 @ W16), dW (+)= dy16^T @ x16 in one paired launch."""
         key = ('p', M, N, K)
         s = self._split_cache.get(key)
@@ -511,7 +512,8 @@ class HipMAEEngine:
         t = self._timed(4.0 * M * N * K, 'glds_pair' if N < 8192 else 'glds_pair_wide')
         lib.vitae_linear_bwd_pair_glds(_ptr(dy16), self._w16(w), _ptr(x16), _ptr(dx), _ptr(dx16), _ptr(dw), self._wire_of(dw), M, Mpad,
                                        N, K,
-                                       epi, _ptr(aux), _ptr(dx_colsum), int(self._accum), s, self.ws16.data_ptr(), self.stream)
+                                       epi, _ptr(aux), _ptr(dx_colsum), _ptr(dy_colsum), int(self._accum), s, self.ws16.data_ptr(),
+                                       self.stream)
         if t is not None:
             t.record()
 
@@ -543,8 +545,10 @@ class HipMAEEngine:
                      dx_colsum=g[pre + 'attn.proj.bias'])
         self._g16_bwd(dx16, p[pre + 'attn.proj.weight'], b[q + 'o_16'], g[pre + 'attn.proj.weight'], M, Mp, d, d, dx=do)
         lib.vitae_sdpa_mfma_bwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(do), _ptr(b[q + 'lse']), _ptr(dqkv), _ptr(dqkv16),
-                                _ptr(g[pre + 'attn.qkv.bias']), _ptr(b['delta']), Bs, N, heads, hd, self.stream)
-        self._g16_bwd(dqkv16, p[pre + 'attn.qkv.weight'], b[q + 'y1_16'], g[pre + 'attn.qkv.weight'], M, Mp, 3 * d, d, dx=dy)
+                                None, _ptr(b['delta']), Bs, N, heads, hd, self.stream)
+        # the qkv bias gradient colsum(dqkv) rides on the wgrad workgroups (one extra MFMA against a ones operand)
+        self._g16_bwd(dqkv16, p[pre + 'attn.qkv.weight'], b[q + 'y1_16'], g[pre + 'attn.qkv.weight'], M, Mp, 3 * d, d, dx=dy,
+                      dy_colsum=g[pre + 'attn.qkv.bias'])
         self._ln_bwd(dy, x_in, pre + 'norm1.', b[q + 'mean1'], b[q + 'rstd1'], dx, M, d, 1, dx16=dx16,
                      dx_colsum=prev_fc2_bias)
 
@@ -755,9 +759,8 @@ class HipMAEEngine:
         nd = cfg.decoder_depth
         if a16:
             # decoder_pred (bias grad from the fp32 dpred), decoder_norm -> dx, dx_16, fc2 bias grad of the last block
-            lib.vitae_colsum_accum(_ptr(b['dpredfull']), P, _ptr(g['decoder_pred.bias']), Md, P, st)
             self._g16_bwd(b['dpred_16'], p['decoder_pred.weight'], b['dn_16'], g['decoder_pred.weight'], Md, self.Mpd, P, Dd,
-                          dx=b['ddn'])
+                          dx=b['ddn'], dy_colsum=g['decoder_pred.bias'])
             self._ln_bwd(b['ddn'], dx_[nd], 'decoder_norm.', b['dn_mean'], b['dn_rstd'], b['decdx'], Md, Dd, 0,
                          dx16=b['decdx_16'], dx_colsum=g[f'decoder_blocks.{nd - 1}.mlp.fc2.bias'])
             for i in reversed(range(nd)):
@@ -838,11 +841,10 @@ class HipMAEEngine:
             # dW[D, P] = dtok16^T @ patches16 (both row-contiguous bf16, reduced over the padded token count)
             t = self._timed(2.0 * T * D * P, 'glds_wide')
             lib.vitae_gemm_glds(0, 0, _ptr(b['dtok_16']), D, _ptr(b['patches_16']), P, _ptr(g['patch_embed.proj.weight']), P,
-                                self._wire_of(g['patch_embed.proj.weight']), P, D, P, self.Mpt, None, None, 0, EPI_NONE, None, 0, int(self._accum), 1, None, None,
-                                self.stream)
+                                self._wire_of(g['patch_embed.proj.weight']), P, D, P, self.Mpt, None, None, 0, EPI_NONE, None, 0,
+                                int(self._accum), 1, None, None, _ptr(g['patch_embed.proj.bias']), self.stream)   # + bias gradient
             if t is not None:
                 t.record()
-            lib.vitae_colsum_accum(_ptr(b['dtok']), D, _ptr(g['patch_embed.proj.bias']), T, D, self.stream)
         else:
             self._lin_bwd_w(b['dtok'], b['patches'], g['patch_embed.proj.weight'], g['patch_embed.proj.bias'], T, D, P)
 
