@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITAE_ABI_VERSION 18
+#define VITAE_ABI_VERSION 19
 
 /* matrix-core arithmetic of the dense contractions */
 #define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
@@ -101,7 +101,7 @@ long vitae_gemm_glds_ws_floats(int M, int N, int split_k);
 int vitae_gemm_glds(int a_kcontig, int b_kcontig, const void* A16, long lda, const void* B16, long ldb, float* C,
                     long ldc, void* C16, long ldc16, int M, int N, int K, const float* bias, const float* residual,
                     long ldr, int epi, float* aux, long ldaux, int accumulate, int split_k, float* splitk_ws,
-                    float* out_colsum_accum, float* a_rowsum_accum /* optional: [M] += sum_k A(m,k) */, void* stream);
+                    float* out_colsum_accum, void* stream);
 int vitae_gemm_glds_pick_split_k(int M, int N, int K);
 /* Backward of one nn.Linear on bf16 operands in one launch: dx / dx16 [M,K] = epi(dy16 W16), optional
  * dx_colsum_accum[k] += sum_m dx(m,k); dW[N,K] (+)= dy16^T x16 reduced over Mpad (>= M, multiple of 64) token
@@ -110,7 +110,8 @@ int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, const void* x1
                                void* dw16 /* optional bf16 copy of the (accumulated) dW: the wire buffer of a bf16
                                data-parallel gradient exchange */, int M, int Mpad, int N, int K, int epi, float* aux,
                                float* dx_colsum_accum, float* dy_colsum_accum /* optional: [N] += colsum(dy16) = the bias
-                               gradient of this Linear (one extra MFMA against ones in the wgrad workgroups) */,
+                               gradient of this Linear (one extra MFMA against ones in the wgrad workgroups when both halves use 64x64
+                               tiles, a separate bf16 column-sum launch otherwise) */,
                                int dw_accumulate, int split_k, float* splitk_ws, void* stream);
 /* split of the dgrad reduction for the call above (1 = none); workspace as for vitae_gemm_glds with (M, K) */
 int vitae_linear_bwd_pair_pick_split_k(int M, int Mpad, int N, int K);

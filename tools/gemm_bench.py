@@ -83,7 +83,7 @@ def run_glds(name, form, M, N, K, iters=50, check=True):
         i = cnt[0] % len(As)
         lib.vitae_gemm_glds(akc, bkc, As[i].data_ptr(), lda, B16.data_ptr(), ldb, Cs[i % len(Cs)].data_ptr(), N, None, 0, M, N, Kp,
                             bias.data_ptr() if RES else None, Rs[i % len(Rs)].data_ptr() if RES else None, N, 0,
-                            None, 0, 0, split, ws.data_ptr(), None, None, torch.cuda.current_stream().cuda_stream)
+                            None, 0, 0, split, ws.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
     for _ in range(5): go()
     torch.cuda.synchronize()
     err = ''

@@ -189,7 +189,7 @@ template <int BM, int BN, int NW = 4> struct GCfg {
     static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES, SMEM = NST * STAGE;
 };
 
-template <int BM, int BN, bool A_KC, bool B_KC, int NW = 4>
+template <int BM, int BN, bool A_KC, bool B_KC, int NW = 4, bool RS = false>
 __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, const int zid, unsigned char* smem) {
     constexpr int WAVES_M = NW / 2, NT = 64 * NW;          // waves: WAVES_M x 2
     constexpr int FM = BM / (32 * WAVES_M), FN = BN / 64, NF = FM * FN;
@@ -218,10 +218,11 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[h][f][i] = 0.f;
 
-    const bool rowsum = p.a_rowsum != nullptr && tn == 0 && wn == 0;   // wave-uniform; every k-split adds its share
-    f32x16 accx[FM];
+    // RS instantiations only (the extra accumulators cost the wide tiles a workgroup per CU)
+    const bool rowsum = RS && p.a_rowsum != nullptr && tn == 0 && wn == 0;   // wave-uniform; every k-split adds its share
+    f32x16 accx[RS ? FM : 1];
 #pragma unroll
-    for (int f = 0; f < FM; ++f)
+    for (int f = 0; f < (RS ? FM : 1); ++f)
 #pragma unroll
         for (int i = 0; i < 16; ++i) accx[f][i] = 0.f;
     bf16x8 ones;
@@ -266,22 +267,24 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
                 for (int fn = 0; fn < FN; ++fn)
                     acc[kk & 1][fm * FN + fn] =
                         __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][fm], fb[kk][fn], acc[kk & 1][fm * FN + fn], 0, 0, 0);
-        if (rowsum) {
+        if constexpr (RS) {
+            if (rowsum) {
 #pragma unroll
-            for (int kk = 0; kk < BK / 16; ++kk)
+                for (int kk = 0; kk < BK / 16; ++kk)
 #pragma unroll
-                for (int fm = 0; fm < FM; ++fm)
-                    accx[fm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][fm], ones, accx[fm], 0, 0, 0);
+                    for (int fm = 0; fm < FM; ++fm)
+                        accx[fm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][fm], ones, accx[fm], 0, 0, 0);
+            }
         }
     }
-    if (rowsum && l31 == 0) {
+    if (RS && rowsum && l31 == 0) {
         // every column of accx holds the row sums of this workgroup's k-range
 #pragma unroll
         for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * (BM / WAVES_M) + fm * 32 + crow(r, hi);
-                if (m < p.M) atomicAdd(p.a_rowsum + m, accx[fm][r]);
+                if (m < p.M) atomicAdd(p.a_rowsum + m, accx[RS ? fm : 0][r]);
             }
     }
 
@@ -349,13 +352,13 @@ __global__ __launch_bounds__(64 * NW) void gemm_glds_kernel(const GArgs p) {
 // dgrad (dy @ W: A k-contiguous, B = bf16 weights read row-contiguous) and wgrad (dy^T @ x: both operands
 // row-contiguous) of one Linear in one launch — they share dy, and together they double the resident
 // workgroups per CU.
-template <int BM1, int BN1, int BM2, int BN2>
+template <int BM1, int BN1, int BM2, int BN2, bool RS = false>
 __global__ __launch_bounds__(256) void gemm_glds_pair_kernel(const GArgs p1, const GArgs p2, const int nb1) {
     constexpr int S1 = GCfg<BM1, BN1>::SMEM, S2 = GCfg<BM2, BN2>::SMEM;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[S1 > S2 ? S1 : S2];
     // nb1 = workgroups of one dgrad split; the dgrad's long reduction (N of the Linear) is cut into p1.splits
     if ((int)blockIdx.x < nb1 * p1.splits) gemm_glds_body<BM1, BN1, true, false>(p1, blockIdx.x % nb1, blockIdx.x / nb1, smem);
-    else gemm_glds_body<BM2, BN2, false, false>(p2, blockIdx.x - nb1 * p1.splits, 0, smem);
+    else gemm_glds_body<BM2, BN2, false, false, 4, RS>(p2, blockIdx.x - nb1 * p1.splits, 0, smem);
 }
 
 template <int BM, int BN, int NW = 4>
@@ -365,6 +368,18 @@ void launch(const GArgs& p, bool a_kc, bool b_kc, dim3 grid, hipStream_t st) {
     else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, true, false, NW>), grid, block, 0, st, p);
     else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, false, true, NW>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, false, false, NW>), grid, block, 0, st, p);
+}
+
+// out[n] += sum_m dy16[m, n] (rows m < M of a [*, N] bf16 matrix): fallback for the bias gradient when the paired launch
+// has no row-sum instantiation for its tile shapes
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const __bf16* __restrict__ dy, float* __restrict__ out, int M, int N,
+                                                          int rows_per_block) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float s = 0.f;
+    for (int m = r0; m < r1; ++m) s += (float)dy[(long)m * N + n];
+    atomicAdd(out + n, s);
 }
 
 struct Tile { int bm, bn, id; };
@@ -417,7 +432,7 @@ extern "C" long vitae_gemm_glds_ws_floats(int M, int N, int split_k) {
 extern "C" int vitae_gemm_glds(int a_kcontig, int b_kcontig, const void* A16, long lda, const void* B16, long ldb,
                                float* C, long ldc, void* C16, long ldc16, int M, int N, int K, const float* bias,
                                const float* residual, long ldr, int epi, float* aux, long ldaux, int accumulate,
-                               int split_k, float* splitk_ws, float* out_colsum_accum, float* a_rowsum_accum, void* stream) {
+                               int split_k, float* splitk_ws, float* out_colsum_accum, void* stream) {
     if (!A16 || !B16 || (!C && !C16) || M <= 0 || N <= 0 || K <= 0) return VITAE_ERR_INVALID_ARG;
     if (epi != VITAE_EPI_NONE && !aux) return VITAE_ERR_INVALID_ARG;
     if (K % BK) return VITAE_ERR_UNSUPPORTED_SHAPE;
@@ -439,7 +454,7 @@ extern "C" int vitae_gemm_glds(int a_kcontig, int b_kcontig, const void* A16, lo
     if (split_k > 1 && !splitk_ws) return VITAE_ERR_INVALID_ARG;
     p.k_per_split = kps; p.splits = split_k;
     p.bias = bias; p.residual = residual; p.ldr = ldr; p.aux = aux; p.ldaux = ldaux;
-    p.epi = epi; p.accumulate = accumulate; p.ws = splitk_ws; p.out_colsum = out_colsum_accum; p.a_rowsum = a_rowsum_accum;
+    p.epi = epi; p.accumulate = accumulate; p.ws = splitk_ws; p.out_colsum = out_colsum_accum; p.a_rowsum = nullptr;
     const Tile t = pick_tile(M, N);
     p.tiles_m = cdiv(M, t.bm); p.tiles_n = cdiv(N, t.bn);
     if (split_k > 1 && (long)p.tiles_m * p.tiles_n > VITAE_GLDS_TICKETS) return VITAE_ERR_UNSUPPORTED_SHAPE;
@@ -504,8 +519,17 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
     const int nb1 = 8 * cdiv(p1.tiles_n, 8) * p1.tiles_m, nb2 = 8 * cdiv(p2.tiles_n, 8) * p2.tiles_m;
     dim3 grid(nb1 * split_k + nb2);
     hipStream_t st = (hipStream_t)stream;
+    if (dy_colsum_accum && t1.id == 0 && t2.id == 0) {
+        // bias gradient colsum(dy) on the wgrad workgroups: one extra MFMA against a ones operand
+        hipLaunchKernelGGL((gemm_glds_pair_kernel<64, 64, 64, 64, true>), grid, dim3(256), 0, st, p1, p2, nb1);
+        return vitae_launch_status();
+    }
+    p2.a_rowsum = nullptr;
     if (t1.id == 2) launch_pair<128, 128>(t2.id, grid, st, p1, p2, nb1);
     else if (t1.id == 1) launch_pair<64, 128>(t2.id, grid, st, p1, p2, nb1);
     else launch_pair<64, 64>(t2.id, grid, st, p1, p2, nb1);
+    if (dy_colsum_accum)
+        hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(N, 256), cdiv(M, 32)), dim3(256), 0, st,
+                           reinterpret_cast<const __bf16*>(dy16), dy_colsum_accum, M, N, 32);
     return vitae_launch_status();
 }

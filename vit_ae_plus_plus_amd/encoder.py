@@ -99,7 +99,7 @@ class HipEncoder:
                 s -= 1
             self._split[key] = s
         lib.vitae_gemm_glds(1, 1, _ptr(x16), K, self._bf16(wname), K, _ptr(y), N, _ptr(y16), N, M, N, K,
-                            _ptr(self._param(bname)), _ptr(res), N, epi, _ptr(aux), N, 0, s, self.buf['ws16'].data_ptr(), None, None,
+                            _ptr(self._param(bname)), _ptr(res), N, epi, _ptr(aux), N, 0, s, self.buf['ws16'].data_ptr(), None,
                             self.stream)
 
     def _lin(self, x, wname, bname, y, M, N, K, epi=EPI_NONE, aux=None, res=None):

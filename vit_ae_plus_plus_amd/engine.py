@@ -462,7 +462,7 @@ class HipMAEEngine:
             self._split_cache[key] = s
         t = self._timed(2.0 * M * N * K, 'glds' if N < 8192 else 'glds_wide')   # wide = the 64x128-tile instantiation
         lib.vitae_gemm_glds(1, 1, _ptr(x16), K, self._w16(w), K, _ptr(y), N, _ptr(y16), N, M, N, K, _ptr(bias), _ptr(res), N,
-                            epi, _ptr(aux), N, 0, s, self.ws16.data_ptr(), None, None, self.stream)
+                            epi, _ptr(aux), N, 0, s, self.ws16.data_ptr(), None, self.stream)
         if t is not None:
             t.record()
 
@@ -759,8 +759,9 @@ class HipMAEEngine:
         nd = cfg.decoder_depth
         if a16:
             # decoder_pred (bias grad from the fp32 dpred), decoder_norm -> dx, dx_16, fc2 bias grad of the last block
+            lib.vitae_colsum_accum(_ptr(b['dpredfull']), P, _ptr(g['decoder_pred.bias']), Md, P, st)
             self._g16_bwd(b['dpred_16'], p['decoder_pred.weight'], b['dn_16'], g['decoder_pred.weight'], Md, self.Mpd, P, Dd,
-                          dx=b['ddn'], dy_colsum=g['decoder_pred.bias'])
+                          dx=b['ddn'])
             self._ln_bwd(b['ddn'], dx_[nd], 'decoder_norm.', b['dn_mean'], b['dn_rstd'], b['decdx'], Md, Dd, 0,
                          dx16=b['decdx_16'], dx_colsum=g[f'decoder_blocks.{nd - 1}.mlp.fc2.bias'])
             for i in reversed(range(nd)):
@@ -842,9 +843,10 @@ class HipMAEEngine:
             t = self._timed(2.0 * T * D * P, 'glds_wide')
             lib.vitae_gemm_glds(0, 0, _ptr(b['dtok_16']), D, _ptr(b['patches_16']), P, _ptr(g['patch_embed.proj.weight']), P,
                                 self._wire_of(g['patch_embed.proj.weight']), P, D, P, self.Mpt, None, None, 0, EPI_NONE, None, 0,
-                                int(self._accum), 1, None, None, _ptr(g['patch_embed.proj.bias']), self.stream)   # + bias gradient
+                                int(self._accum), 1, None, None, self.stream)
             if t is not None:
                 t.record()
+            lib.vitae_colsum_accum(_ptr(b['dtok']), D, _ptr(g['patch_embed.proj.bias']), T, D, self.stream)
         else:
             self._lin_bwd_w(b['dtok'], b['patches'], g['patch_embed.proj.weight'], g['patch_embed.proj.bias'], T, D, P)
 
