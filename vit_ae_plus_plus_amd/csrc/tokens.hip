@@ -51,7 +51,8 @@ __global__ __launch_bounds__(256) void gather_patches_kernel(const float* __rest
     const long vstride = (long)Lz * Hy * Wx;
     const float* vb = vol + (long)b * C * vstride;
     const long rowoff = ((long)b * keep + j) * ((long)C * p * p * p);
-    for (int i = threadIdx.x; i < P4; i += 256) {
+    // blockIdx.z splits a patch row over several workgroups (keep * B alone is only ~200 of them)
+    for (int i = blockIdx.z * 256 + threadIdx.x; i < P4; i += 256 * gridDim.z) {
         const int q4 = i % p4, s = (i / p4) % p, r = (i / (p4 * p)) % p, c = i / (p4 * p * p);
         const float* src = vb + c * vstride + ((long)(gl * p + r) * Hy + (gh * p + s)) * Wx + gw * p + q4 * 4;
         const f32x4 v = *reinterpret_cast<const f32x4*>(src);
@@ -187,7 +188,10 @@ extern "C" int vitae_gather_patches(const float* vol, const int* ids_shuffle, fl
     if (!vol || !ids_shuffle || (!out && !out_bf16) || B <= 0 || C <= 0 || p <= 0 || keep <= 0) return VITAE_ERR_INVALID_ARG;
     if ((p & 3) || Lz % p || Hy % p || Wx % p || ((uintptr_t)vol & 15)) return VITAE_ERR_UNSUPPORTED_SHAPE;
     const int g0 = Lz / p, g1 = Hy / p, g2 = Wx / p;
-    hipLaunchKernelGGL(gather_patches_kernel, dim3(keep, B), dim3(256), 0, (hipStream_t)stream, vol, ids_shuffle, out,
+    const int P4 = C * p * p * (p / 4);
+    int zsplit = (keep * B < 1024) ? cdiv(1024, keep * B) : 1;
+    if (zsplit > cdiv(P4, 256)) zsplit = cdiv(P4, 256);
+    hipLaunchKernelGGL(gather_patches_kernel, dim3(keep, B, zsplit), dim3(256), 0, (hipStream_t)stream, vol, ids_shuffle, out,
                        reinterpret_cast<__bf16*>(out_bf16), C, Lz, Hy, Wx, p, g1, g2, g0 * g1 * g2, keep);
     return vitae_launch_status();
 }
