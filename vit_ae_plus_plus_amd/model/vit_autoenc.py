@@ -167,6 +167,8 @@ class _StepRunner:
         snap = [t.clone() for t in keep]
         step = eng.opt_step
         cur = torch.cuda.current_stream(eng.device)
+        # (a high-priority capture stream for the main chain was tried so that the side branches only fill free CUs:
+        # the whole step ran 2x slower, 11.9 ms — HIP's high-priority queue is not a free lunch here)
         side = torch.cuda.Stream(device=eng.device)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
