@@ -44,6 +44,7 @@ def parse():
     ap.add_argument('--grad-comm', default=None, choices=['fp32', 'bf16'],
                     help='wire dtype of the gradient all-reduce at >1 GPU (default: the compute precision)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extra', action='store_true', help='skip the secondary plain-MAE data point')
     ap.add_argument('--cpu-steps', type=int, default=2)
     ap.add_argument('--profile-steps', type=int, default=3, help='instrumented steps for the roofline block')
     return ap.parse_args()
@@ -86,6 +87,37 @@ def cpu_baseline(args, batches, sd_cpu, noises):
     return {'value': args.batch / sec, 'unit': 'volumes/s', 'cores': cores, 'kind': 'port',
             'sample': f'{args.cpu_steps} timed full steps (fwd+loss+bwd+AdamW) of the same workload, batch {args.batch}, '
                       f'fp32, torch {torch.__version__} CPU, after 1 warm-up step; {sec:.2f} s/step'}, first
+
+
+def plain_mae_point(args, dev, batches):
+    """Secondary data point: the same step for the plain (non-contrastive) `mae_vit_base_patch16` — one view, 55-token
+    encoder.  BASELINE config 2 says "autoenc"; the reference's pre-training scripts train the contrastive model, which
+    is the headline workload here (two views per volume: strictly more work per volume)."""
+    from vit_ae_plus_plus_amd.model import vit_autoenc as VA
+    from vit_ae_plus_plus_amd.optim import FusedAdamW
+    from oracle import mae_ref as R
+    cfg = R.vit_base_cfg(volume_size=(VOL,) * 3, patch_size=PATCH, in_chans=CH, contrastive=False)
+    model = VA.mae_vit_base_patch16(volume_size=VOL, in_chans=CH, patch_size=PATCH,
+                                    args=argparse.Namespace(use_imagenet=False, perceptual_weight=0), precision=args.precision)
+    model.load_state_dict(R.init_state_dict(cfg, seed=0))
+    model = model.to(dev).train()
+    eng = model._ensure_engine(dev)
+    opt = FusedAdamW(model, lr=1e-4, weight_decay=0.05, betas=(0.9, 0.95))
+    _ = opt.engine
+    eng.set_loss_weights(0.01, 0.0, 1, 1)
+    runner = model._step_runner(args.batch, 0.75, True, False, not args.no_graph)
+    warm, steps = 5, 15
+    for i in range(warm + steps):
+        if i == warm:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        runner.load(batches[i % len(batches)][0], None)
+        eng.optimizer_hparams(lr=1e-4)
+        runner.run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {'model': 'mae_vit_base_patch16 (plain MAE, one view per volume)', 'value': round(args.batch / dt, 2),
+            'unit': 'volumes/s', 'ms_per_step': round(dt * 1e3, 3), 'steps': steps}
 
 
 def main():
@@ -241,6 +273,13 @@ def main():
     if world > 1:
         dist.barrier()
 
+    also = None
+    if rank == 0 and world == 1 and contr and not force_ddp and not args.no_extra:
+        try:
+            also = plain_mae_point(args, dev, batches)
+        except Exception as e:   # a secondary point must never cost the headline line
+            also = {'error': repr(e)[:200]}
+
     cpu, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu, first_cpu = cpu_baseline(args, cpu_batches, sd_cpu, noises)
@@ -262,6 +301,8 @@ def main():
                           'hip_graph': not args.no_graph,
                           'grad_allreduce': (f'{grad_comm}, {len(model._reducer.ranges)} buckets' if model._reducer is not None else None), 'final_losses': [round(x, 6) for x in last[:6]]},
                'roofline': roof, 'cpu_baseline': cpu}
+        if also:
+            out['config']['also'] = also
         if parity:
             out['parity'] = parity
     if world > 1 or force_ddp:
