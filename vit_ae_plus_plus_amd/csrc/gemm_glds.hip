@@ -181,11 +181,17 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 #ifndef VITAE_GLDS_NS_W8
 #define VITAE_GLDS_NS_W8 4
 #endif
+#ifndef VITAE_GLDS_NS_T128
+#define VITAE_GLDS_NS_T128 2
+#endif
+#ifndef VITAE_GLDS_NACC_BIG
+#define VITAE_GLDS_NACC_BIG 1
+#endif
 template <int BM, int BN, int NW = 4> struct GCfg {
     // stages: 3 for 64x64 (48 KB, three workgroups per CU); the wider 4-wave tiles take 2 (48 KB for 64x128 -> three
     // workgroups per CU instead of two: decoder_pred fwd 49.8 -> 45.6 us) — occupancy beats prefetch depth there;
     // the 8-wave 128x128 workgroup is alone on its CU and takes 4 (128 KB, three 32 KB tiles in flight)
-    static constexpr int NST = NW == 8 ? VITAE_GLDS_NS_W8 : (BM * BN > 64 * 64) ? VITAE_GLDS_NS_WIDE : NS;
+    static constexpr int NST = NW == 8 ? VITAE_GLDS_NS_W8 : (BM * BN > 64 * 128) ? VITAE_GLDS_NS_T128 : (BM * BN > 64 * 64) ? VITAE_GLDS_NS_WIDE : NS;
     static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES, SMEM = NST * STAGE;
 };
 
@@ -210,9 +216,11 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
 
     // two accumulators per output fragment (even / odd 16-deep k-slices): consecutive MFMAs never depend
     // on each other, so the matrix pipe is not serialised on the 32x32 accumulate latency
-    f32x16 acc[2][NF];
+    // (with four or more fragments per wave the fragments themselves are the independent chains: one set)
+    constexpr int NACC = NF >= 4 ? VITAE_GLDS_NACC_BIG : 2;
+    f32x16 acc[NACC][NF];
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < NACC; ++h)
 #pragma unroll
         for (int f = 0; f < NF; ++f)
 #pragma unroll
@@ -265,8 +273,8 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
             for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
                 for (int fn = 0; fn < FN; ++fn)
-                    acc[kk & 1][fm * FN + fn] =
-                        __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][fm], fb[kk][fn], acc[kk & 1][fm * FN + fn], 0, 0, 0);
+                    acc[kk % NACC][fm * FN + fn] =
+                        __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][fm], fb[kk][fn], acc[kk % NACC][fm * FN + fn], 0, 0, 0);
         if constexpr (RS) {
             if (rowsum) {
 #pragma unroll
@@ -292,7 +300,7 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
 #pragma unroll
     for (int f = 0; f < NF; ++f)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) a[f][r] = acc[0][f][r] + acc[1][f][r];
+        for (int r = 0; r < 16; ++r) a[f][r] = NACC == 2 ? acc[0][f][r] + acc[NACC - 1][f][r] : acc[0][f][r];
 
     if (p.splits > 1) {
         // Split-K fix-up without a second launch: every split parks its partial tile (fragment order, coalesced),
@@ -396,7 +404,8 @@ inline Tile pick_tile(int M, int N) {
     static const int t128w8 = getenv("VITAE_GLDS_T128W8") ? atoi(getenv("VITAE_GLDS_T128W8")) : 0;
     if (N >= 128 && M >= 128 && t128w8 > 0 && (long)cdiv(M, 128) * cdiv(N, 128) >= t128w8) return {128, 128, 3};   // 8 waves
     if (N >= 128 && M >= 128 && t128 > 0 && (long)cdiv(M, 128) * cdiv(N, 128) >= t128) return {128, 128, 2};
-    if (N >= 128 && (long)cdiv(M, 64) * cdiv(N, 128) >= 400) return {64, 128, 1};
+    static const int wide_min = getenv("VITAE_GLDS_WIDE_MIN_TILES") ? atoi(getenv("VITAE_GLDS_WIDE_MIN_TILES")) : 400;
+    if (N >= 128 && (long)cdiv(M, 64) * cdiv(N, 128) >= wide_min) return {64, 128, 1};
     return {64, 64, 0};
 }
 
