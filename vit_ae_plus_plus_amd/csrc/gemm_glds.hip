@@ -44,7 +44,14 @@ struct GArgs {
     float* a_rowsum;     // optional: a_rowsum[m] += sum_k A(m, k): in a wgrad (A = dy^T) this is colsum(dy), the bias gradient
                          // of THIS Linear, obtained with one extra MFMA against a ones operand in the tn == 0 workgroups
     int tiles_m, tiles_n;
+    int xcd_m;           // 0: an XCD owns column tiles tn = xcd (mod 8) and walks every row tile (its L2 holds 1/8 of B and all
+                         // of A); 1: it owns row tiles tm = xcd (mod 8) instead — picked when A is the larger operand
 };
+
+// workgroups of one launch (per k-split) under either XCD mapping
+inline int glds_blocks(const GArgs& p) {
+    return p.xcd_m ? 8 * cdiv(p.tiles_m, 8) * p.tiles_n : 8 * cdiv(p.tiles_n, 8) * p.tiles_m;
+}
 
 __device__ __forceinline__ int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
@@ -203,8 +210,9 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
     constexpr int NST = GCfg<BM, BN, NW>::NST;
     constexpr int G = (BM + BN) / (8 * NW);                // DMA instructions per wave per stage
     const int xcd = bid & 7, local = bid >> 3;
-    const int tn = xcd + 8 * (local / p.tiles_m), tm = local % p.tiles_m;
-    if (tn >= p.tiles_n) return;
+    const int tn = p.xcd_m ? local % p.tiles_n : xcd + 8 * (local / p.tiles_m);
+    const int tm = p.xcd_m ? xcd + 8 * (local / p.tiles_n) : local % p.tiles_m;
+    if (tn >= p.tiles_n || tm >= p.tiles_m) return;
     const int m0 = tm * BM, n0 = tn * BN;
     const int kbeg = zid * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
@@ -392,6 +400,17 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const __bf16* __restri
 
 struct Tile { int bm, bn, id; };
 
+// Every XCD's L2 fetches its own copy of whatever its workgroups read: partition the LARGER operand across the XCDs.
+// (wgrad of qkv / fc1 / decoder_pred: A = dy^T is 3-32x the size of B = x; 8 copies of it were most of the launch's
+// memory-side traffic.)
+// (Tried as well: all workgroups of one k-split on one XCD group, so that no operand slice is fetched by more than
+// 8 / splits XCDs — less traffic again, but 5-25 % slower at K <= 3072 and only 3-5 % faster at K = 16384: not kept.)
+inline int xcd_by_rows(int M, int N) {
+    static const int mode = getenv("VITAE_GLDS_XCD_ROWS") ? atoi(getenv("VITAE_GLDS_XCD_ROWS")) : -1;
+    if (mode >= 0) return mode;
+    return M > N;
+}
+
 // 0: 64x64, 1: 64x128, 2: 128x128 — the largest tile that still yields enough workgroups for 256 CUs.
 // 128x128 is OFF by default (VITAE_GLDS_T128 = minimum tile count to use it): with 128 accumulator + 150 other
 // registers and 96 KB of LDS only one 4-wave workgroup fits a CU, and the DMA / LDS / MFMA chain of a single workgroup
@@ -466,8 +485,9 @@ extern "C" int vitae_gemm_glds(int a_kcontig, int b_kcontig, const void* A16, lo
     p.epi = epi; p.accumulate = accumulate; p.ws = splitk_ws; p.out_colsum = out_colsum_accum; p.a_rowsum = nullptr;
     const Tile t = pick_tile(M, N);
     p.tiles_m = cdiv(M, t.bm); p.tiles_n = cdiv(N, t.bn);
+    p.xcd_m = xcd_by_rows(M, N);
     if (split_k > 1 && (long)p.tiles_m * p.tiles_n > VITAE_GLDS_TICKETS) return VITAE_ERR_UNSUPPORTED_SHAPE;
-    dim3 grid(8 * cdiv(p.tiles_n, 8) * p.tiles_m, 1, split_k);
+    dim3 grid(glds_blocks(p), 1, split_k);
     hipStream_t st = (hipStream_t)stream;
     if (t.id == 3) launch<128, 128, 8>(p, a_kcontig != 0, b_kcontig != 0, grid, st);
     else if (t.id == 2) launch<128, 128>(p, a_kcontig != 0, b_kcontig != 0, grid, st);
@@ -516,6 +536,7 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
     Tile t1 = pick_tile(M, K);
     if (t1.id == 3) t1 = Tile{64, 128, 1};      // the paired launch is 4-wave only
     p1.tiles_m = cdiv(M, t1.bm); p1.tiles_n = cdiv(K, t1.bn);
+    p1.xcd_m = xcd_by_rows(M, K);
     p2.A = reinterpret_cast<const __bf16*>(dy16); p2.lda = N;
     p2.B = reinterpret_cast<const __bf16*>(x16); p2.ldb = K;
     p2.C = dw; p2.ldc = K; p2.C16 = reinterpret_cast<__bf16*>(dw16); p2.ldc16 = K;
@@ -525,7 +546,8 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
     Tile t2 = pick_tile(N, K);
     if (t2.id == 3) t2 = Tile{64, 128, 1};
     p2.tiles_m = cdiv(N, t2.bm); p2.tiles_n = cdiv(K, t2.bn);
-    const int nb1 = 8 * cdiv(p1.tiles_n, 8) * p1.tiles_m, nb2 = 8 * cdiv(p2.tiles_n, 8) * p2.tiles_m;
+    p2.xcd_m = xcd_by_rows(N, K);
+    const int nb1 = glds_blocks(p1), nb2 = glds_blocks(p2);
     dim3 grid(nb1 * split_k + nb2);
     hipStream_t st = (hipStream_t)stream;
     if (dy_colsum_accum && t1.id == 0 && t2.id == 0) {
