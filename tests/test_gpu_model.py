@@ -477,3 +477,41 @@ def test_host_batches_are_double_buffered_and_match_device_batches():
         finals.append((eng.losses.cpu().tolist(), model.state_dict()['blocks.0.mlp.fc1.weight'].clone()))
     close(finals[1][0][0], finals[0][0][0], 1e-5, 1e-7)
     assert float((finals[0][1] - finals[1][1]).abs().max()) < 1e-6
+
+
+def test_recurring_device_batches_are_read_in_place():
+    """A device batch whose tensors come back gets a graph captured on its own addresses (no staging copy) from the
+    second time on; it must read the LIVE contents of those tensors and land exactly where staged batches land."""
+    from vit_ae_plus_plus_amd.model.vit_autoenc import _DirectSlot
+    from vit_ae_plus_plus_amd.optim import FusedAdamW
+    cfg = R.RefConfig(contrastive=True, **ACT16)
+    sd = R.init_state_dict(cfg, seed=17)
+    B, finals = 2, []
+    for in_place in (False, True):
+        model = build(cfg, sd, precision='bf16')
+        opt = FusedAdamW(model, lr=1e-3, weight_decay=0.05)
+        model._ensure_engine(torch.device('cuda', 0))
+        eng = opt.engine
+        eng.set_loss_weights(0.01, 0.001, 1, 1)
+        runner = model._step_runner(B, 0.75, True, False, True)
+        shape = (B, cfg.in_chans, *cfg.volume_size)
+        buf1, buf2 = torch.empty(shape, device='cuda'), torch.empty(shape, device='cuda')
+        alive, direct = [], []
+        for step in range(4):
+            v1, v2 = R.synthetic_views(shape, seed=700 + step)
+            model.set_masking_noise(*R.masking_noise(B, cfg.num_patches, seed=750 + step))
+            if in_place:        # same tensors every step, new contents
+                buf1.copy_(v1); buf2.copy_(v2)
+                runner.load(buf1, buf2)
+            else:               # fresh addresses every step (kept alive so that the allocator cannot hand them out again)
+                alive.append((v1.cuda(), v2.cuda()))
+                runner.load(*alive[-1])
+            direct.append(isinstance(runner.slot, _DirectSlot))
+            eng.optimizer_hparams(lr=1e-3)
+            runner.run()
+        torch.cuda.synchronize()
+        assert direct == ([False, True, True, True] if in_place else [False] * 4)
+        finals.append((eng.losses.cpu().tolist(), model.state_dict()['blocks.0.mlp.fc1.weight'].clone()))
+    close(finals[1][0][0], finals[0][0][0], 1e-5, 1e-7)
+    # four Adam steps at lr 1e-3: stale or misplaced input would show at the 1e-3 level; atomics order accounts for ~1e-6
+    assert float((finals[0][1] - finals[1][1]).abs().max()) < 1e-5
