@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITAE_ABI_VERSION 19
+#define VITAE_ABI_VERSION 20
 
 /* matrix-core arithmetic of the dense contractions */
 #define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
@@ -112,7 +112,8 @@ int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, const void* x1
                                float* dx_colsum_accum, float* dy_colsum_accum /* optional: [N] += colsum(dy16) = the bias
                                gradient of this Linear (one extra MFMA against ones in the wgrad workgroups when both halves use 64x64
                                tiles, a separate bf16 column-sum launch otherwise) */,
-                               int dw_accumulate, int split_k, float* splitk_ws, void* stream);
+                               int dx_accumulate /* dx += instead of = (fp32 dx only) */, int dw_accumulate, int split_k,
+                               float* splitk_ws, void* stream);
 /* split of the dgrad reduction for the call above (1 = none); workspace as for vitae_gemm_glds with (M, K) */
 int vitae_linear_bwd_pair_pick_split_k(int M, int Mpad, int N, int K);
 /* dst_bf16[i] = bf16(src[i]) (round to nearest even) */
@@ -178,8 +179,10 @@ int vitae_mean_pool_tokens(const float* x, float* out, int B, int N, int D, int 
 /* xd[B,L+1,Dd]: mask-token fill + unshuffle + decoder_pos_embed (model/vit_autoenc.py:184-190) */
 int vitae_decoder_assemble_fwd(const float* e, const float* mask_token, const float* dpos, const int* ids_restore,
                                float* xd, int B, int L, int keep, int Dd, void* stream);
-int vitae_decoder_assemble_bwd(const float* dxd, const int* ids_shuffle, float* de, float* dmask_token_accum, int B,
-                               int L, int keep, int Dd, void* stream);
+/* de[B,keep+1,Dd] = kept rows of dxd (optional bf16 copy de_bf16: the dy operand of decoder_embed's backward on the
+ * LDS-DMA GEMM); dmask_token_accum[Dd] += sum of dxd over the masked positions.  One launch. */
+int vitae_decoder_assemble_bwd(const float* dxd, const int* ids_shuffle, float* de, void* de_bf16, float* dmask_token_accum,
+                               int B, int L, int keep, int Dd, void* stream);
 
 /* ---- input normalisation (dataset/brats_dataset/brats.py:26-37, dataset/egd_dataset/egd.py:44-55) ---------------
  * `groups` contiguous runs of n elements, each normalised on its own: z-score with the unbiased variance, min-max

@@ -184,7 +184,7 @@ def test_linear_bwd_pair_glds(lib, C, M, N, K):
     split = lib.vitae_linear_bwd_pair_pick_split_k(M, Mp, N, K)
     ws = torch.zeros(max(1, lib.vitae_gemm_glds_ws_floats(M, K, max(split, 3))), device='cuda')
     lib.vitae_linear_bwd_pair_glds(dy16.data_ptr(), w16.data_ptr(), x16.data_ptr(), dx.data_ptr(), dx16.data_ptr(), dw.data_ptr(), dw16.data_ptr(),
-                                   M, Mp, N, K, C['VITAE_EPI_DGELU'], hd_.data_ptr(), cs.data_ptr(), dycs.data_ptr(), 0, split, ws.data_ptr(), st())
+                                   M, Mp, N, K, C['VITAE_EPI_DGELU'], hd_.data_ptr(), cs.data_ptr(), dycs.data_ptr(), 0, 0, split, ws.data_ptr(), st())
     dyr, wr, xr = dy16[:M].float().cpu(), w16.float().cpu(), x16[:M].float().cpu()
     hh = h.clone().requires_grad_(True)
     F.gelu(hh).backward(dyr @ wr)
@@ -195,12 +195,16 @@ def test_linear_bwd_pair_glds(lib, C, M, N, K):
     assert int(ws[:C['VITAE_GLDS_TICKETS']].abs().sum()) == 0      # tickets handed back
     # forced 3-way split of the dgrad reduction: same numbers as the unsplit launch up to fp32 summation order
     lib.vitae_linear_bwd_pair_glds(dy16.data_ptr(), w16.data_ptr(), x16.data_ptr(), dx.data_ptr(), None, dw.data_ptr(), None,
-                                   M, Mp, N, K, 0, None, None, None, 1, 3 if N >= 192 else 1, ws.data_ptr(), st())
+                                   M, Mp, N, K, 0, None, None, None, 0, 1, 3 if N >= 192 else 1, ws.data_ptr(), st())
     assert rel_err(dx, dyr @ wr) < 2e-3 and rel_err(dw, 2 * (dyr.t() @ xr)) < 2e-3
     d1 = dx.clone()
     lib.vitae_linear_bwd_pair_glds(dy16.data_ptr(), w16.data_ptr(), x16.data_ptr(), dx.data_ptr(), None, dw.data_ptr(), None,
-                                   M, Mp, N, K, 0, None, None, None, 0, 3 if N >= 192 else 1, ws.data_ptr(), st())
+                                   M, Mp, N, K, 0, None, None, None, 0, 0, 3 if N >= 192 else 1, ws.data_ptr(), st())
     assert torch.equal(dx, d1)                                      # split order is fixed -> bitwise reproducible
+    # dx_accumulate: dx += dy16 @ W16 (decoder_embed adds into the predictor's latent gradient)
+    lib.vitae_linear_bwd_pair_glds(dy16.data_ptr(), w16.data_ptr(), x16.data_ptr(), dx.data_ptr(), None, dw.data_ptr(), None,
+                                   M, Mp, N, K, 0, None, None, None, 1, 0, split, ws.data_ptr(), st())
+    assert rel_err(dx, 2 * (dyr @ wr)) < 2e-3 and rel_err(dw, dyr.t() @ xr) < 2e-3
 
 
 @pytest.mark.parametrize('M,N,K', [(440, 2304, 768), (432, 768, 16384), (868, 16384, 512), (100, 72, 128)])
@@ -430,8 +434,10 @@ def test_gather_patches_and_assemble(lib, C_, vol, p):
                                    B, L, keep, Dd, st())
     assert torch.allclose(xd.cpu(), ref.detach(), atol=1e-6)
     de, dmt = torch.empty(B, keep + 1, Dd, device='cuda'), torch.zeros(Dd, device='cuda')
-    lib.vitae_decoder_assemble_bwd(dev(dxd).data_ptr(), sh.data_ptr(), de.data_ptr(), dmt.data_ptr(), B, L, keep, Dd, st())
-    assert torch.allclose(de.cpu(), er.grad, atol=1e-6)
+    de16 = torch.zeros(B, keep + 1, Dd, dtype=torch.bfloat16, device='cuda')
+    lib.vitae_decoder_assemble_bwd(dev(dxd).data_ptr(), sh.data_ptr(), de.data_ptr(), de16.data_ptr(), dmt.data_ptr(), B, L, keep, Dd,
+                                   st())
+    assert torch.allclose(de.cpu(), er.grad, atol=1e-6) and torch.equal(de16, de.to(torch.bfloat16))
     assert rel_err(dmt, mtr.grad) < 1e-5
 
 

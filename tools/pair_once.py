@@ -17,6 +17,6 @@ ws = torch.zeros(1 << 23, device=dev)
 split = lib.vitae_linear_bwd_pair_pick_split_k(M, Mp, N, K)
 for _ in range(reps):
     lib.vitae_linear_bwd_pair_glds(dy16.data_ptr(), w.data_ptr(), x16.data_ptr(), dx.data_ptr(), None, dw.data_ptr(), None, M, Mp, N, K,
-                                   0, None, None, None, 0, split, ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                                   0, None, None, None, 0, 0, split, ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
 torch.cuda.synchronize()
 print('split', split)

@@ -516,10 +516,11 @@ extern "C" int vitae_linear_bwd_pair_pick_split_k(int M, int Mpad, int N, int K)
 
 extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, const void* x16, float* dx, void* dx16,
                                           float* dw, void* dw16, int M, int Mpad, int N, int K, int epi, float* aux,
-                                          float* dx_colsum_accum, float* dy_colsum_accum, int dw_accumulate, int split_k,
-                                          float* splitk_ws, void* stream) {
+                                          float* dx_colsum_accum, float* dy_colsum_accum, int dx_accumulate, int dw_accumulate,
+                                          int split_k, float* splitk_ws, void* stream) {
     if (!dy16 || !w16 || !x16 || (!dx && !dx16) || !dw || M <= 0 || N <= 0 || K <= 0) return VITAE_ERR_INVALID_ARG;
     if (epi != VITAE_EPI_NONE && !aux) return VITAE_ERR_INVALID_ARG;
+    if (dx_accumulate && !dx) return VITAE_ERR_INVALID_ARG;
     if ((N % BK) || (Mpad % BK) || (K & 7) || Mpad < M) return VITAE_ERR_UNSUPPORTED_SHAPE;
     if ((long)(M > N ? M : N) * K >= (1L << 31)) return VITAE_ERR_UNSUPPORTED_SHAPE;   // 32-bit epilogue offsets
     if (((uintptr_t)dy16 & 15) || ((uintptr_t)w16 & 15) || ((uintptr_t)x16 & 15)) return VITAE_ERR_UNSUPPORTED_SHAPE;
@@ -531,7 +532,7 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
     const int kps = cdiv(cdiv(N, split_k), BK) * BK;
     split_k = cdiv(N, kps);
     p1.M = M; p1.N = K; p1.K = N; p1.k_per_split = kps; p1.splits = split_k;
-    p1.bias = nullptr; p1.residual = nullptr; p1.ldr = 0; p1.aux = aux; p1.ldaux = K; p1.epi = epi; p1.accumulate = 0;
+    p1.bias = nullptr; p1.residual = nullptr; p1.ldr = 0; p1.aux = aux; p1.ldaux = K; p1.epi = epi; p1.accumulate = dx_accumulate != 0;
     p1.ws = splitk_ws; p1.out_colsum = dx_colsum_accum; p1.a_rowsum = nullptr;
     Tile t1 = pick_tile(M, K);
     if (t1.id == 3) t1 = Tile{64, 128, 1};      // the paired launch is 4-wave only

@@ -127,24 +127,31 @@ __global__ __launch_bounds__(256) void decoder_assemble_fwd_kernel(const float* 
 }
 
 // de[b, 0] = dxd[b, 0];  de[b, 1 + r] = dxd[b, 1 + ids_shuffle[b, r]]  (r < keep)
+// One launch, two kinds of workgroup.  The first (keep + 1) * B gather the kept rows of dxd back into de (fp32, and
+// optionally a bf16 copy: the dy operand of decoder_embed's backward GEMMs).  The rest sum dxd over the masked
+// positions into dmask_token: threads own columns, each workgroup takes `per_block` entries of the (b, masked-rank) list.
 __global__ __launch_bounds__(256) void decoder_assemble_bwd_kernel(const float* __restrict__ dxd, const int* __restrict__ ids_shuffle,
-                                                                   float* __restrict__ de, int L, int keep, int Dd) {
-    const int t = blockIdx.x, b = blockIdx.y;   // t in [0, keep]
-    const int srow = t == 0 ? 0 : 1 + ids_shuffle[(long)b * L + t - 1];
-    const float* s = dxd + ((long)b * (L + 1) + srow) * Dd;
-    float* o = de + ((long)b * (keep + 1) + t) * Dd;
-    for (int d = threadIdx.x; d < Dd; d += 256) o[d] = s[d];
-}
-
-// dmask_token[d] += sum over masked positions of dxd.  Threads own columns; blockIdx.y slices the
-// (b, masked-rank) list so the sum is spread over enough blocks.
-__global__ __launch_bounds__(256) void mask_token_grad_kernel(const float* __restrict__ dxd, const int* __restrict__ ids_shuffle,
-                                                              float* __restrict__ dmask, int B, int L, int keep, int Dd,
-                                                              int per_block) {
-    const int d = blockIdx.x * 256 + threadIdx.x;
+                                                                   float* __restrict__ de, __bf16* __restrict__ de16,
+                                                                   float* __restrict__ dmask, int B, int L, int keep, int Dd,
+                                                                   int per_block, int col_blocks) {
+    const int nrow = (keep + 1) * B;
+    if ((int)blockIdx.x < nrow) {
+        const int t = blockIdx.x % (keep + 1), b = blockIdx.x / (keep + 1);   // t in [0, keep]
+        const int srow = t == 0 ? 0 : 1 + ids_shuffle[(long)b * L + t - 1];
+        const float* s = dxd + ((long)b * (L + 1) + srow) * Dd;
+        const long o = ((long)b * (keep + 1) + t) * Dd;
+        for (int d = threadIdx.x; d < Dd; d += 256) {
+            const float v = s[d];
+            de[o + d] = v;
+            if (de16) de16[o + d] = (__bf16)v;
+        }
+        return;
+    }
+    const int mb = blockIdx.x - nrow;
+    const int d = (mb % col_blocks) * 256 + threadIdx.x;
     if (d >= Dd) return;
     const int nm = L - keep;
-    const int i0 = blockIdx.y * per_block, i1 = min(B * nm, i0 + per_block);
+    const int i0 = (mb / col_blocks) * per_block, i1 = min(B * nm, i0 + per_block);
     float s = 0.f;
     for (int i = i0; i < i1; ++i) {
         const int b = i / nm, r = keep + i % nm;
@@ -222,18 +229,13 @@ extern "C" int vitae_decoder_assemble_fwd(const float* e, const float* mask_toke
     return vitae_launch_status();
 }
 
-extern "C" int vitae_decoder_assemble_bwd(const float* dxd, const int* ids_shuffle, float* de, float* dmask_token,
-                                          int B, int L, int keep, int Dd, void* stream) {
+extern "C" int vitae_decoder_assemble_bwd(const float* dxd, const int* ids_shuffle, float* de, void* de_bf16,
+                                          float* dmask_token, int B, int L, int keep, int Dd, void* stream) {
     if (!dxd || !ids_shuffle || !de || !dmask_token || B <= 0) return VITAE_ERR_INVALID_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(decoder_assemble_bwd_kernel, dim3(keep + 1, B), dim3(256), 0, st, dxd, ids_shuffle, de, L, keep,
-                       Dd);
-    const int total = B * (L - keep);
-    if (total > 0) {
-        const int per_block = 32;
-        hipLaunchKernelGGL(mask_token_grad_kernel, dim3(cdiv(Dd, 256), cdiv(total, per_block)), dim3(256), 0, st, dxd,
-                           ids_shuffle, dmask_token, B, L, keep, Dd, per_block);
-    }
+    const int total = B * (L - keep), per_block = 32, col_blocks = cdiv(Dd, 256);
+    const int blocks = (keep + 1) * B + col_blocks * cdiv(total, per_block);
+    hipLaunchKernelGGL(decoder_assemble_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dxd, ids_shuffle, de,
+                       reinterpret_cast<__bf16*>(de_bf16), dmask_token, B, L, keep, Dd, per_block, col_blocks);
     return vitae_launch_status();
 }
 

@@ -276,6 +276,11 @@ class HipMAEEngine:
             b['dn_16'] = z16(self.Mpd, Dd)
             b['dpred_16'] = z16(self.Mpd, P)
             b['patches_16'], b['dtok_16'] = z16(self.Mpt, P), z16(self.Mpt, D)
+            # decoder_embed on the LDS-DMA GEMM: its input (the view-1 rows of the latent) and its output gradient in bf16.
+            # The wgrad reduces over pad(B * Ne) rows: the pad rows of de_16 stay zero, so whatever finite rows of latent_16
+            # (view 2) sit opposite them contribute nothing.
+            self.Mpl = pad(B * Ne)
+            b['latent_16'], b['de_16'] = z16(max(self.Mpe, self.Mpl), D), z16(self.Mpl, Dd)
         for i in range(cfg.depth):
             b[f'enc{i}.lse'] = f(Be * cfg.num_heads * Ne)
         for i in range(cfg.decoder_depth):
@@ -479,7 +484,7 @@ class HipMAEEngine:
         if not self.act16:
             return [(0, self.n_total)]
         cfg = self.cfg
-        covered = ['patch_embed.proj.weight', 'decoder_pred.weight']
+        covered = ['patch_embed.proj.weight', 'decoder_pred.weight', 'decoder_embed.weight']
         for pre, depth in (('blocks.', cfg.depth), ('decoder_blocks.', cfg.decoder_depth)):
             for i in range(depth):
                 covered += [f'{pre}{i}.{n}.weight' for n in ('attn.qkv', 'attn.proj', 'mlp.fc1', 'mlp.fc2')]
@@ -500,7 +505,7 @@ class HipMAEEngine:
         return out
 
     def _g16_bwd(self, dy16, w, x16, dw, M, Mpad, N, K, dx=None, dx16=None, epi=EPI_NONE, aux=None, dx_colsum=None,
-                 dy_colsum=None):
+                 dy_colsum=None, dx_accumulate=0):
         """dx / dx16 = epi(dy16 @ W16), dW (+)= dy16^T @ x16 in one paired launch."""
         key = ('p', M, N, K)
         s = self._split_cache.get(key)
@@ -512,7 +517,8 @@ class HipMAEEngine:
         t = self._timed(4.0 * M * N * K, 'glds_pair' if N < 8192 else 'glds_pair_wide')
         lib.vitae_linear_bwd_pair_glds(_ptr(dy16), self._w16(w), _ptr(x16), _ptr(dx), _ptr(dx16), _ptr(dw), self._wire_of(dw), M, Mpad,
                                        N, K,
-                                       epi, _ptr(aux), _ptr(dx_colsum), _ptr(dy_colsum), int(self._accum), s, self.ws16.data_ptr(),
+                                       epi, _ptr(aux), _ptr(dx_colsum), _ptr(dy_colsum), int(dx_accumulate), int(self._accum), s,
+                                       self.ws16.data_ptr(),
                                        self.stream)
         if t is not None:
             t.record()
@@ -652,7 +658,7 @@ class HipMAEEngine:
                                        _ptr(b['ids_shuffle']), _ptr(ex[0]), Be, L, keep, D, st)
         for i in range(cfg.depth):
             self._block_fwd(f'blocks.{i}.', f'enc{i}.', ex[i], ex[i + 1], Be, Ne, D, cfg.num_heads, self.hd, self.Hm)
-        self._ln_fwd(ex[cfg.depth], 'norm.', b['latent'], b['lat_mean'], b['lat_rstd'], Me, D)
+        self._ln_fwd(ex[cfg.depth], 'norm.', b['latent'], b['lat_mean'], b['lat_rstd'], Me, D, y16=b.get('latent_16'))
         if cfg.contrastive and self.overlap_predictor:
             # the predictor branch only needs the latent: it runs on its own stream beside the decoder and the loss chain
             self.pside.wait_stream(torch.cuda.current_stream(self.device))
@@ -660,7 +666,10 @@ class HipMAEEngine:
                 self._predictor_fwd(training, None)
             self._pred_pending = True
         # --- decoder (view 1 only)
-        self._lin_fwd(b['latent'], p['decoder_embed.weight'], p['decoder_embed.bias'], b['e'], B * Ne, Dd, D)
+        if a16:
+            self._g16_fwd(b['latent_16'], p['decoder_embed.weight'], p['decoder_embed.bias'], B * Ne, Dd, D, y=b['e'])
+        else:
+            self._lin_fwd(b['latent'], p['decoder_embed.weight'], p['decoder_embed.bias'], b['e'], B * Ne, Dd, D)
         dx_ = b['decx']
         lib.vitae_decoder_assemble_fwd(_ptr(b['e']), _ptr(p['mask_token']), _ptr(self.buffers['decoder_pos_embed']),
                                        _ptr(b['ids_restore']), _ptr(dx_[0]), B, L, keep, Dd, st)
@@ -774,9 +783,19 @@ class HipMAEEngine:
             for i in reversed(range(nd)):
                 self._block_bwd(f'decoder_blocks.{i}.', f'dec{i}.', 'dec', dx_[i], B, Nd, Dd, cfg.decoder_num_heads, self.hdd,
                                 self.Hmd)
-        lib.vitae_decoder_assemble_bwd(_ptr(b['decdx']), _ptr(b['ids_shuffle']), _ptr(b['de']), _ptr(g['mask_token']), B, L,
-                                       keep, Dd, st)
-        self._lin_bwd_w(b['de'], b['latent'], g['decoder_embed.weight'], None, B * Ne, Dd, D)
+        lib.vitae_decoder_assemble_bwd(_ptr(b['decdx']), _ptr(b['ids_shuffle']), _ptr(b['de']), _ptr(b.get('de_16')),
+                                       _ptr(g['mask_token']), B, L, keep, Dd, st)
+
+        def dec_embed_bwd(accumulate):
+            """decoder_embed: dW, db and dlatent[view-1 rows] (+)= de @ W."""
+            if a16:     # dgrad + wgrad + bias gradient in one launch
+                self._g16_bwd(b['de_16'], p['decoder_embed.weight'], b['latent_16'], g['decoder_embed.weight'], B * Ne, self.Mpl,
+                              Dd, D, dx=b['dlatent'], dy_colsum=g['decoder_embed.bias'], dx_accumulate=accumulate)
+            else:
+                self._lin_bwd_w(b['de'], b['latent'], g['decoder_embed.weight'], None, B * Ne, Dd, D)
+                self._lin_bwd_x(b['de'], p['decoder_embed.weight'], b['dlatent'], B * Ne, Dd, D, accumulate=accumulate,
+                                db=g['decoder_embed.bias'])
+
         # predictor (both views) -> dlatent ; then decoder_embed adds into the view-1 rows
         if cfg.contrastive and have_dp:
             R = self.R
@@ -785,8 +804,7 @@ class HipMAEEngine:
             else:
                 self._predictor_bwd()
             self._lin_bwd_x(b['dph'], p['predictor.0.weight'], b['dlatent'], 2 * R, D, D)
-            self._lin_bwd_x(b['de'], p['decoder_embed.weight'], b['dlatent'], B * Ne, Dd, D, accumulate=1,
-                            db=g['decoder_embed.bias'])
+            dec_embed_bwd(1)
         else:
             if cfg.contrastive:   # predictor unused this step: its matrices get exact zeros
                 for n in ('predictor.0.weight', 'predictor.3.weight'):
@@ -794,7 +812,7 @@ class HipMAEEngine:
                         lib.vitae_memset_zero(g[n].data_ptr(), g[n].numel() * 4, st)
             if Be != B:
                 lib.vitae_memset_zero(b['dlatent'].data_ptr(), b['dlatent'].numel() * 4, st)
-            self._lin_bwd_x(b['de'], p['decoder_embed.weight'], b['dlatent'], B * Ne, Dd, D, db=g['decoder_embed.bias'])
+            dec_embed_bwd(0)
         if a16:
             self._ln_bwd(b['dlatent'], b['encx'][cfg.depth], 'norm.', b['lat_mean'], b['lat_rstd'], b['encdx'], Me, D, 0,
                          dx16=b['encdx_16'], dx_colsum=g[f'blocks.{cfg.depth - 1}.mlp.fc2.bias'])
