@@ -89,6 +89,33 @@ def cpu_baseline(args, batches, sd_cpu, noises):
                       f'fp32, torch {torch.__version__} CPU, after 1 warm-up step; {sec:.2f} s/step'}, first
 
 
+def big_batch_point(args, dev, model, eng, contr, big=32):
+    """Secondary data point: the headline model at batch 32 per GPU (what 288 GB of HBM is for).  The step stops being
+    launch-bound there; same kernels, same graph machinery, device-generated synthetic volumes of the same distribution."""
+    g = torch.Generator(device=dev).manual_seed(77)
+    batches = []
+    for _ in range(2):
+        v2 = torch.randn(big, CH, VOL, VOL, VOL, generator=g, device=dev)
+        v1 = v2 + 0.1 * torch.randn(big, CH, VOL, VOL, VOL, generator=g, device=dev)
+        v1 = (v1 - v1.mean(dim=(2, 3, 4), keepdim=True)) / v1.std(dim=(2, 3, 4), keepdim=True)
+        batches.append((v1.contiguous(), v2))
+    runner = model._step_runner(big, 0.75, True, False, not args.no_graph)
+    warm, steps = 2 * len(batches) + 2, 10
+    for i in range(warm + steps):
+        if i == warm:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        v1, v2 = batches[i % len(batches)]
+        runner.load(v1, v2 if contr else None)
+        eng.optimizer_hparams(lr=1e-4)
+        runner.run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    gf = ALGO_GFLOP_PER_VOL[args.model] * big
+    return {'batch': big, 'value': round(big / dt, 2), 'unit': 'volumes/s', 'ms_per_step': round(dt * 1e3, 3), 'steps': steps,
+            'step_tflops': round(gf / dt / 1e3, 1)}
+
+
 def plain_mae_point(args, dev, batches):
     """Secondary data point: the same step for the plain (non-contrastive) `mae_vit_base_patch16` — one view, 55-token
     encoder.  BASELINE config 2 says "autoenc"; the reference's pre-training scripts train the contrastive model, which
@@ -277,11 +304,16 @@ def main():
     if world > 1:
         dist.barrier()
 
-    also = None
+    also, also_big = None, None
+    if rank == 0 and world == 1 and not force_ddp and not args.no_extra and args.batch < 32:
+        try:
+            also_big = big_batch_point(args, dev, model, eng, contr)
+        except Exception as e:   # a secondary point must never cost the headline line
+            also_big = {'error': repr(e)[:200]}
     if rank == 0 and world == 1 and contr and not force_ddp and not args.no_extra:
         try:
             also = plain_mae_point(args, dev, batches)
-        except Exception as e:   # a secondary point must never cost the headline line
+        except Exception as e:
             also = {'error': repr(e)[:200]}
 
     cpu, parity = None, None
@@ -307,6 +339,8 @@ def main():
                'roofline': roof, 'cpu_baseline': cpu}
         if also:
             out['config']['also'] = also
+        if also_big:
+            out['config']['also_batch32'] = also_big
         if parity:
             out['parity'] = parity
     if world > 1 or force_ddp:
