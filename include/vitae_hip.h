@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITAE_ABI_VERSION 20
+#define VITAE_ABI_VERSION 21
 
 /* matrix-core arithmetic of the dense contractions */
 #define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
@@ -191,6 +191,21 @@ int vitae_decoder_assemble_bwd(const float* dxd, const int* ids_shuffle, float* 
 #define VITAE_NORM_MINMAX_PM1 1
 #define VITAE_NORM_MINMAX_01 2
 int vitae_normalize_volumes(const float* x, float* y, double* ws, int groups, long n, int mode, void* stream);
+/* ---- augmentations of the pre-training scripts as batch ops (k_fold_training_scripts/
+ * k_fold_cross_valid_combined_brats.py:93-97: tio.RandomAffine(), tio.RandomNoise(std=0.1), tio.RandomGamma(log_gamma=
+ * (-0.3, 0.3)) applied to the raw item in dataset/brats_dataset/brats.py:39-44).  torchio 0.18.73 / SimpleITK 2.2.1 are
+ * not in /root/reference: their published behaviour is restated (oracle/augment_ref.py, parity unpinned); random
+ * parameters are drawn on the host (utils/augment.py), the kernels are deterministic.
+ * vitae_volume_minmax: ws[3*g+2] <- {min, max} of each group of n elements (the 'minimum' pad value of RandomAffine).
+ * vitae_affine_resample: y[b,c,o] = linear interpolation of x[b,c,:] at the continuous index mats[b] (3x4, row-major,
+ *   axis order l,h,w) applied to (o,1); points outside [-0.5, n-0.5) get the pad value (the group minimum from minmax_ws
+ *   when given, else pad_value).  Not in place.
+ * vitae_noise_gamma: y = sign(v)|v|^gammas[b], v = x + stds[b]*noise  (noise / gammas may be NULL). */
+int vitae_volume_minmax(const float* x, double* ws, int groups, long n, void* stream);
+int vitae_affine_resample(const float* x, float* y, const float* mats, const double* minmax_ws, float pad_value, int B, int C,
+                          int Lz, int Hy, int Wx, void* stream);
+int vitae_noise_gamma(const float* x, const float* noise, float* y, const float* stds, const float* gammas, int B, long n,
+                      void* stream);
 
 /* ---- loss chain ----------------------------------------------------------------------------------
  * pred element (b,l,e) lives at pred[b*pred_bstride + l*P + e] (P = p^3*C), so the decoder output

@@ -84,7 +84,102 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
         yg[i] = (xg[i] - sub) * mul + add;
 }
 
+// ---- augmentations of the pre-training scripts (k_fold_cross_valid_combined_brats.py:93-97: torchio RandomAffine ->
+// RandomNoise -> RandomGamma on the raw item), as batch kernels.  The random parameters are drawn on the host
+// (utils/augment.py); the kernels are deterministic functions of (input, parameters, noise tensor).
+
+// Affine resampling, linear interpolation (what sitk.Resample with sitkLinear does for torchio's Affine): output voxel
+// o = (l, h, w) takes the input at the continuous index s = A_b (l, h, w, 1)^T.  A point is inside the buffer when
+// -0.5 <= s_d < n_d - 0.5 on every axis (ITK's IsInsideBuffer); outside points get the pad value; the two neighbours
+// on each axis are clamped to the valid indices (ITK's LinearInterpolateImageFunction at the half-voxel border).
+__global__ __launch_bounds__(256) void affine_resample_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                              const float* __restrict__ mats, const double* __restrict__ ws,
+                                                              float pad_const, int C, int Lz, int Hy, int Wx) {
+    const int b = blockIdx.y;
+    const long V = (long)Lz * Hy * Wx;
+    const long v = (long)blockIdx.x * 256 + threadIdx.x;
+    if (v >= V) return;
+    const int w = (int)(v % Wx), h = (int)((v / Wx) % Hy), l = (int)(v / ((long)Wx * Hy));
+    const float* A = mats + 12 * b;
+    const float fl = (float)l, fh = (float)h, fw = (float)w;
+    const float sl = A[0] * fl + A[1] * fh + A[2] * fw + A[3];
+    const float sh = A[4] * fl + A[5] * fh + A[6] * fw + A[7];
+    const float sw = A[8] * fl + A[9] * fh + A[10] * fw + A[11];
+    float pad = pad_const;
+    if (ws) pad = key_float(reinterpret_cast<const unsigned int*>(ws + 3 * b + 2)[0]);      // the sample's minimum
+    const float* xb = x + (long)b * C * V;
+    float* yb = y + (long)b * C * V;
+    const bool inside = sl >= -0.5f && sl < (float)Lz - 0.5f && sh >= -0.5f && sh < (float)Hy - 0.5f && sw >= -0.5f &&
+                        sw < (float)Wx - 0.5f;
+    if (!inside) {
+        for (int c = 0; c < C; ++c) yb[c * V + v] = pad;
+        return;
+    }
+    const float bl = floorf(sl), bh = floorf(sh), bw = floorf(sw);
+    const float tl = sl - bl, th = sh - bh, tw = sw - bw;
+    const int l0 = max((int)bl, 0), l1 = min((int)bl + 1, Lz - 1);
+    const int h0 = max((int)bh, 0), h1 = min((int)bh + 1, Hy - 1);
+    const int w0 = max((int)bw, 0), w1 = min((int)bw + 1, Wx - 1);
+    const long o00 = ((long)l0 * Hy + h0) * Wx, o01 = ((long)l0 * Hy + h1) * Wx;
+    const long o10 = ((long)l1 * Hy + h0) * Wx, o11 = ((long)l1 * Hy + h1) * Wx;
+    for (int c = 0; c < C; ++c) {
+        const float* xc = xb + c * V;
+        const float a00 = xc[o00 + w0] + tw * (xc[o00 + w1] - xc[o00 + w0]);
+        const float a01 = xc[o01 + w0] + tw * (xc[o01 + w1] - xc[o01 + w0]);
+        const float a10 = xc[o10 + w0] + tw * (xc[o10 + w1] - xc[o10 + w0]);
+        const float a11 = xc[o11 + w0] + tw * (xc[o11 + w1] - xc[o11 + w0]);
+        const float a0 = a00 + th * (a01 - a00), a1 = a10 + th * (a11 - a10);
+        yb[c * V + v] = a0 + tl * (a1 - a0);
+    }
+}
+
+// y = gamma(x + std_b * noise): RandomNoise (additive N(0, std_b)) then RandomGamma (sign(v) |v|^gamma_b, torchio's form
+// for images with negative values; gamma_b = 1 is an exact pass-through).  noise may be NULL (std ignored).
+__global__ __launch_bounds__(256) void noise_gamma_kernel(const float* __restrict__ x, const float* __restrict__ noise,
+                                                          float* __restrict__ y, const float* __restrict__ stds,
+                                                          const float* __restrict__ gammas, long n) {
+    const int b = blockIdx.y;
+    const float sd = stds ? stds[b] : 0.f, gm = gammas ? gammas[b] : 1.f;
+    const float* xb = x + (long)b * n;
+    const float* nb = noise ? noise + (long)b * n : nullptr;
+    float* yb = y + (long)b * n;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float v = xb[i];
+        if (nb) v += sd * nb[i];
+        if (gm != 1.f) v = copysignf(powf(fabsf(v), gm), v);
+        yb[i] = v;
+    }
+}
+
 }  // namespace
+
+extern "C" int vitae_volume_minmax(const float* x, double* ws, int groups, long n, void* stream) {
+    if (!x || !ws || groups <= 0 || n <= 0 || groups > 65535) return VITAE_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    long per = (n / 4 + 255) / 256;
+    int bx = (int)(per < 1 ? 1 : per > 512 ? 512 : per);
+    hipLaunchKernelGGL(norm_init_kernel, dim3(cdiv(groups, 256)), dim3(256), 0, st, ws, groups);
+    hipLaunchKernelGGL(norm_stats_kernel, dim3(bx, groups), dim3(256), 0, st, x, ws, n);
+    return vitae_launch_status();
+}
+
+extern "C" int vitae_affine_resample(const float* x, float* y, const float* mats, const double* minmax_ws, float pad_value,
+                                     int B, int C, int Lz, int Hy, int Wx, void* stream) {
+    if (!x || !y || !mats || x == y || B <= 0 || B > 65535 || C <= 0 || Lz <= 0 || Hy <= 0 || Wx <= 0) return VITAE_ERR_INVALID_ARG;
+    const long V = (long)Lz * Hy * Wx;
+    hipLaunchKernelGGL(affine_resample_kernel, dim3(cdiv(V, 256), B), dim3(256), 0, (hipStream_t)stream, x, y, mats, minmax_ws,
+                       pad_value, C, Lz, Hy, Wx);
+    return vitae_launch_status();
+}
+
+extern "C" int vitae_noise_gamma(const float* x, const float* noise, float* y, const float* stds, const float* gammas, int B,
+                                 long n, void* stream) {
+    if (!x || !y || B <= 0 || B > 65535 || n <= 0 || (noise && !stds)) return VITAE_ERR_INVALID_ARG;
+    long per = (n + 255) / 256;
+    int bx = (int)(per > 1024 ? 1024 : per);
+    hipLaunchKernelGGL(noise_gamma_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, x, noise, y, stds, gammas, n);
+    return vitae_launch_status();
+}
 
 extern "C" int vitae_normalize_volumes(const float* x, float* y, double* ws, int groups, long n, int mode, void* stream) {
     if (!x || !y || !ws || groups <= 0 || n <= 1 || groups > 65535) return VITAE_ERR_INVALID_ARG;

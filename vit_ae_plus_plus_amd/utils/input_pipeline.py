@@ -1,8 +1,9 @@
 """Volume normalisation on the GPU: what the reference's Dataset objects do per item on the CPU
 (dataset/brats_dataset/brats.py:26-37, dataset/egd_dataset/egd.py:44-55), for a whole batch already in HBM.
 
-The torchio augmentations of the training scripts (k_fold_cross_valid_combined_brats.py:93-97) are third-party code
-that is absent here; only the normalisation, which the reference defines itself, is rebuilt and pinned."""
+The torchio augmentations of the training scripts (k_fold_cross_valid_combined_brats.py:93-97) live in utils/augment.py
+(third-party behaviour restated, parity unpinned); the normalisation here is what the reference defines itself and is
+pinned against its own methods."""
 import torch
 
 from .._abi import CONSTS, VitaeError, lib
