@@ -95,7 +95,13 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void affine_resample_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                               const float* __restrict__ mats, const double* __restrict__ ws,
                                                               float pad_const, int C, int Lz, int Hy, int Wx) {
-    const int b = blockIdx.y;
+    // One thread per output voxel and channel (blockIdx.z): its eight taps are independent loads in flight together.
+    // Measured at 32 x 4 x 96^3 (453 MB in, 453 MB out): 0.83 ms = 1.1 TB/s.  A channel loop inside the thread (taps of
+    // different channels become dependent round trips) took 0.93 ms; a 64 x 4 voxel workgroup per plane with division-free
+    // 32-bit indexing 0.99 ms.  The limit is the L2 -> L1 traffic of the taps (each wave-load touches 2-3 lines), which
+    // only an LDS-staged source box would cut; at 12 k volumes/s for both views against a 0.7 k volumes/s training step
+    // that is left alone.
+    const int b = blockIdx.y, c = blockIdx.z;
     const long V = (long)Lz * Hy * Wx;
     const long v = (long)blockIdx.x * 256 + threadIdx.x;
     if (v >= V) return;
@@ -105,14 +111,12 @@ __global__ __launch_bounds__(256) void affine_resample_kernel(const float* __res
     const float sl = A[0] * fl + A[1] * fh + A[2] * fw + A[3];
     const float sh = A[4] * fl + A[5] * fh + A[6] * fw + A[7];
     const float sw = A[8] * fl + A[9] * fh + A[10] * fw + A[11];
-    float pad = pad_const;
-    if (ws) pad = key_float(reinterpret_cast<const unsigned int*>(ws + 3 * b + 2)[0]);      // the sample's minimum
-    const float* xb = x + (long)b * C * V;
-    float* yb = y + (long)b * C * V;
+    const float* xc = x + ((long)b * C + c) * V;
+    float* yc = y + ((long)b * C + c) * V;
     const bool inside = sl >= -0.5f && sl < (float)Lz - 0.5f && sh >= -0.5f && sh < (float)Hy - 0.5f && sw >= -0.5f &&
                         sw < (float)Wx - 0.5f;
     if (!inside) {
-        for (int c = 0; c < C; ++c) yb[c * V + v] = pad;
+        yc[v] = ws ? key_float(reinterpret_cast<const unsigned int*>(ws + 3 * b + 2)[0]) : pad_const;   // the sample's minimum
         return;
     }
     const float bl = floorf(sl), bh = floorf(sh), bw = floorf(sw);
@@ -122,15 +126,12 @@ __global__ __launch_bounds__(256) void affine_resample_kernel(const float* __res
     const int w0 = max((int)bw, 0), w1 = min((int)bw + 1, Wx - 1);
     const long o00 = ((long)l0 * Hy + h0) * Wx, o01 = ((long)l0 * Hy + h1) * Wx;
     const long o10 = ((long)l1 * Hy + h0) * Wx, o11 = ((long)l1 * Hy + h1) * Wx;
-    for (int c = 0; c < C; ++c) {
-        const float* xc = xb + c * V;
-        const float a00 = xc[o00 + w0] + tw * (xc[o00 + w1] - xc[o00 + w0]);
-        const float a01 = xc[o01 + w0] + tw * (xc[o01 + w1] - xc[o01 + w0]);
-        const float a10 = xc[o10 + w0] + tw * (xc[o10 + w1] - xc[o10 + w0]);
-        const float a11 = xc[o11 + w0] + tw * (xc[o11 + w1] - xc[o11 + w0]);
-        const float a0 = a00 + th * (a01 - a00), a1 = a10 + th * (a11 - a10);
-        yb[c * V + v] = a0 + tl * (a1 - a0);
-    }
+    const float p000 = xc[o00 + w0], p001 = xc[o00 + w1], p010 = xc[o01 + w0], p011 = xc[o01 + w1];
+    const float p100 = xc[o10 + w0], p101 = xc[o10 + w1], p110 = xc[o11 + w0], p111 = xc[o11 + w1];
+    const float a00 = p000 + tw * (p001 - p000), a01 = p010 + tw * (p011 - p010);
+    const float a10 = p100 + tw * (p101 - p100), a11 = p110 + tw * (p111 - p110);
+    const float a0 = a00 + th * (a01 - a00), a1 = a10 + th * (a11 - a10);
+    yc[v] = a0 + tl * (a1 - a0);
 }
 
 // y = gamma(x + std_b * noise): RandomNoise (additive N(0, std_b)) then RandomGamma (sign(v) |v|^gamma_b, torchio's form
@@ -143,12 +144,30 @@ __global__ __launch_bounds__(256) void noise_gamma_kernel(const float* __restric
     const float* xb = x + (long)b * n;
     const float* nb = noise ? noise + (long)b * n : nullptr;
     float* yb = y + (long)b * n;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        float v = xb[i];
-        if (nb) v += sd * nb[i];
-        if (gm != 1.f) v = copysignf(powf(fabsf(v), gm), v);
-        yb[i] = v;
+    // |v|^g = exp2(g log2|v|) on the transcendental units (v_log_f32 / v_exp_f32, ~1e-6 relative): powf's software
+    // path made this HBM stream VALU-bound
+    auto f = [&](float v, float z) {
+        if (nb) v += sd * z;
+        if (gm != 1.f) v = copysignf(__builtin_amdgcn_exp2f(gm * __builtin_amdgcn_logf(fabsf(v))), v);
+        return v;
+    };
+    const bool vec = (n & 3) == 0 && !((uintptr_t)xb & 15) && !((uintptr_t)yb & 15) && !(nb && ((uintptr_t)nb & 15));
+    if (vec) {
+        const f32x4* x4 = reinterpret_cast<const f32x4*>(xb);
+        const f32x4* n4 = reinterpret_cast<const f32x4*>(nb);
+        f32x4* y4 = reinterpret_cast<f32x4*>(yb);
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n / 4; i += (long)gridDim.x * 256) {
+            const f32x4 a = x4[i];
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            if (nb) z = n4[i];
+            f32x4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = f(a[e], z[e]);
+            y4[i] = r;
+        }
+        return;
     }
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) yb[i] = f(xb[i], nb ? nb[i] : 0.f);
 }
 
 }  // namespace
@@ -165,9 +184,10 @@ extern "C" int vitae_volume_minmax(const float* x, double* ws, int groups, long 
 
 extern "C" int vitae_affine_resample(const float* x, float* y, const float* mats, const double* minmax_ws, float pad_value,
                                      int B, int C, int Lz, int Hy, int Wx, void* stream) {
-    if (!x || !y || !mats || x == y || B <= 0 || B > 65535 || C <= 0 || Lz <= 0 || Hy <= 0 || Wx <= 0) return VITAE_ERR_INVALID_ARG;
+    if (!x || !y || !mats || x == y || B <= 0 || C <= 0 || Lz <= 0 || Hy <= 0 || Wx <= 0) return VITAE_ERR_INVALID_ARG;
+    if (B > 65535 || C > 65535) return VITAE_ERR_UNSUPPORTED_SHAPE;
     const long V = (long)Lz * Hy * Wx;
-    hipLaunchKernelGGL(affine_resample_kernel, dim3(cdiv(V, 256), B), dim3(256), 0, (hipStream_t)stream, x, y, mats, minmax_ws,
+    hipLaunchKernelGGL(affine_resample_kernel, dim3(cdiv(V, 256), B, C), dim3(256), 0, (hipStream_t)stream, x, y, mats, minmax_ws,
                        pad_value, C, Lz, Hy, Wx);
     return vitae_launch_status();
 }
@@ -175,8 +195,8 @@ extern "C" int vitae_affine_resample(const float* x, float* y, const float* mats
 extern "C" int vitae_noise_gamma(const float* x, const float* noise, float* y, const float* stds, const float* gammas, int B,
                                  long n, void* stream) {
     if (!x || !y || B <= 0 || B > 65535 || n <= 0 || (noise && !stds)) return VITAE_ERR_INVALID_ARG;
-    long per = (n + 255) / 256;
-    int bx = (int)(per > 1024 ? 1024 : per);
+    long per = (n / 4 + 255) / 256;
+    int bx = (int)(per > 2048 ? 2048 : per < 1 ? 1 : per);
     hipLaunchKernelGGL(noise_gamma_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, x, noise, y, stds, gammas, n);
     return vitae_launch_status();
 }
