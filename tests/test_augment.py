@@ -76,7 +76,7 @@ def test_cpu_input_fails_loudly():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('B,C,shape', [(3, 2, (12, 10, 9)), (2, 4, (32, 32, 32)), (1, 1, (24, 16, 40))])
+@pytest.mark.parametrize('B,C,shape', [(3, 2, (12, 10, 9)), (2, 4, (32, 32, 32)), (1, 1, (24, 16, 40)), (2, 1, (5, 7, 3))])
 def test_hip_augmentations_match_the_oracle(B, C, shape):
     from vit_ae_plus_plus_amd.utils.augment import Compose, RandomAffine, RandomGamma, RandomNoise
     x = _vol((B, C, *shape), 10)
