@@ -194,20 +194,26 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 #ifndef VITAE_GLDS_NACC_BIG
 #define VITAE_GLDS_NACC_BIG 1
 #endif
-template <int BM, int BN, int NW = 4> struct GCfg {
+#ifndef VITAE_GLDS_NS_PAIR
+#define VITAE_GLDS_NS_PAIR 0     // > 0: stages of the 64x64 tiles inside the paired (dgrad + wgrad) launch.  Measured in the step
+                                 // (ms): 2 stages (32 KB, four workgroups per CU) 5.85 although 7 % faster in the L2-warm
+                                 // micro-benchmark; 4 stages 5.65; 3 stages (the default) 5.52.  The same for the forward tile.
+#endif
+template <int BM, int BN, int NW = 4, bool PAIR = false> struct GCfg {
     // stages: 3 for 64x64 (48 KB, three workgroups per CU); the wider 4-wave tiles take 2 (48 KB for 64x128 -> three
     // workgroups per CU instead of two: decoder_pred fwd 49.8 -> 45.6 us) — occupancy beats prefetch depth there;
     // the 8-wave 128x128 workgroup is alone on its CU and takes 4 (128 KB, three 32 KB tiles in flight)
-    static constexpr int NST = NW == 8 ? VITAE_GLDS_NS_W8 : (BM * BN > 64 * 128) ? VITAE_GLDS_NS_T128 : (BM * BN > 64 * 64) ? VITAE_GLDS_NS_WIDE : NS;
+    static constexpr int NST = NW == 8 ? VITAE_GLDS_NS_W8 : (BM * BN > 64 * 128) ? VITAE_GLDS_NS_T128 : (BM * BN > 64 * 64) ? VITAE_GLDS_NS_WIDE
+                               : (PAIR && VITAE_GLDS_NS_PAIR > 0) ? VITAE_GLDS_NS_PAIR : NS;
     static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES, SMEM = NST * STAGE;
 };
 
-template <int BM, int BN, bool A_KC, bool B_KC, int NW = 4, bool RS = false>
+template <int BM, int BN, bool A_KC, bool B_KC, int NW = 4, bool RS = false, bool PAIR = false>
 __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, const int zid, unsigned char* smem) {
     constexpr int WAVES_M = NW / 2, NT = 64 * NW;          // waves: WAVES_M x 2
     constexpr int FM = BM / (32 * WAVES_M), FN = BN / 64, NF = FM * FN;
-    constexpr int A_BYTES = GCfg<BM, BN, NW>::A_BYTES, STAGE = GCfg<BM, BN, NW>::STAGE;
-    constexpr int NST = GCfg<BM, BN, NW>::NST;
+    constexpr int A_BYTES = GCfg<BM, BN, NW, PAIR>::A_BYTES, STAGE = GCfg<BM, BN, NW, PAIR>::STAGE;
+    constexpr int NST = GCfg<BM, BN, NW, PAIR>::NST;
     constexpr int G = (BM + BN) / (8 * NW);                // DMA instructions per wave per stage
     const int xcd = bid & 7, local = bid >> 3;
     const int tn = p.xcd_m ? local % p.tiles_n : xcd + 8 * (local / p.tiles_m);
@@ -370,11 +376,11 @@ __global__ __launch_bounds__(64 * NW) void gemm_glds_kernel(const GArgs p) {
 // workgroups per CU.
 template <int BM1, int BN1, int BM2, int BN2, bool RS = false>
 __global__ __launch_bounds__(256) void gemm_glds_pair_kernel(const GArgs p1, const GArgs p2, const int nb1) {
-    constexpr int S1 = GCfg<BM1, BN1>::SMEM, S2 = GCfg<BM2, BN2>::SMEM;
+    constexpr int S1 = GCfg<BM1, BN1, 4, true>::SMEM, S2 = GCfg<BM2, BN2, 4, true>::SMEM;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[S1 > S2 ? S1 : S2];
     // nb1 = workgroups of one dgrad split; the dgrad's long reduction (N of the Linear) is cut into p1.splits
-    if ((int)blockIdx.x < nb1 * p1.splits) gemm_glds_body<BM1, BN1, true, false>(p1, blockIdx.x % nb1, blockIdx.x / nb1, smem);
-    else gemm_glds_body<BM2, BN2, false, false, 4, RS>(p2, blockIdx.x - nb1 * p1.splits, 0, smem);
+    if ((int)blockIdx.x < nb1 * p1.splits) gemm_glds_body<BM1, BN1, true, false, 4, false, true>(p1, blockIdx.x % nb1, blockIdx.x / nb1, smem);
+    else gemm_glds_body<BM2, BN2, false, false, 4, RS, true>(p2, blockIdx.x - nb1 * p1.splits, 0, smem);
 }
 
 template <int BM, int BN, int NW = 4>
