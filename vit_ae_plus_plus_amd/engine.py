@@ -434,6 +434,20 @@ class HipMAEEngine:
         self._lin_bwd_w(dy, x, dw, None, M, N, K, tag=tag)
         self._lin_bwd_x(dy, w, dx, M, N, K, epi=epi, aux=aux, accumulate=dx_accumulate, db=db)
 
+    def _colsum_beside(self, x, ld, out, M, N, tag):
+        """out[n] += colsum(x) on the wgrad side stream: a bias gradient that nothing on the main chain waits for until
+        the end of the phase (``_wg_join``); ``tag`` names the buffer it reads, for ``_wg_fence``."""
+        if not self.overlap_wgrad or self.gemm_timer is not None:
+            lib.vitae_colsum_accum(_ptr(x), ld, _ptr(out), M, N, self.stream)
+            return
+        self.wside.wait_stream(torch.cuda.current_stream(self.device))
+        lib.vitae_colsum_accum(_ptr(x), ld, _ptr(out), M, N, self.wside.cuda_stream)
+        ev = self._wg_events.get(tag)
+        if ev is None:
+            ev = self._wg_events[tag] = torch.cuda.Event()
+        ev.record(self.wside)
+        self._wg_pending.add(tag)
+
     def _wg_fence(self, tag):
         """Make the current stream wait for the side-stream wgrad that still reads buffer ``tag``."""
         if tag in self._wg_pending:
@@ -768,7 +782,7 @@ class HipMAEEngine:
         nd = cfg.decoder_depth
         if a16:
             # decoder_pred (bias grad from the fp32 dpred), decoder_norm -> dx, dx_16, fc2 bias grad of the last block
-            lib.vitae_colsum_accum(_ptr(b['dpredfull']), P, _ptr(g['decoder_pred.bias']), Md, P, st)
+            self._colsum_beside(b['dpredfull'], P, g['decoder_pred.bias'], Md, P, 'dpredfull')
             self._g16_bwd(b['dpred_16'], p['decoder_pred.weight'], b['dn_16'], g['decoder_pred.weight'], Md, self.Mpd, P, Dd,
                           dx=b['ddn'])
             self._ln_bwd(b['ddn'], dx_[nd], 'decoder_norm.', b['dn_mean'], b['dn_rstd'], b['decdx'], Md, Dd, 0,
@@ -857,6 +871,7 @@ class HipMAEEngine:
         lib.vitae_encoder_assemble_bwd(_ptr(b['encdx']), _ptr(b['dtok']), _ptr(b['dtok_16']) if self.act16 else None,
                                        _ptr(g['cls_token']), self.Be, self.keep, D, self.stream)
         if self.act16:
+            self._colsum_beside(b['dtok'], D, g['patch_embed.proj.bias'], T, D, 'dtok')     # beside the wgrad below
             # dW[D, P] = dtok16^T @ patches16 (both row-contiguous bf16, reduced over the padded token count)
             t = self._timed(2.0 * T * D * P, 'glds_wide')
             lib.vitae_gemm_glds(0, 0, _ptr(b['dtok_16']), D, _ptr(b['patches_16']), P, _ptr(g['patch_embed.proj.weight']), P,
@@ -864,9 +879,9 @@ class HipMAEEngine:
                                 int(self._accum), 1, None, None, self.stream)
             if t is not None:
                 t.record()
-            lib.vitae_colsum_accum(_ptr(b['dtok']), D, _ptr(g['patch_embed.proj.bias']), T, D, self.stream)
         else:
             self._lin_bwd_w(b['dtok'], b['patches'], g['patch_embed.proj.weight'], g['patch_embed.proj.bias'], T, D, P)
+        self._wg_join()
 
     # ------------------------------------------------------------------ optimiser
     def init_optimizer(self, weight_decay: float = 0.05, betas=(0.9, 0.95), eps: float = 1e-8):
