@@ -50,6 +50,50 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
 }
 
+// D = 256 * NV: every lane owns NV float4 groups (columns 4 * (lane + 64 i) ..): 16-byte loads of x, w, b, 16-byte
+// stores of y and 8-byte stores of the bf16 copy instead of 4- and 2-byte ones.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                const float* __restrict__ b, float* __restrict__ y,
+                                                                __bf16* __restrict__ y16, float* __restrict__ mean_out,
+                                                                float* __restrict__ rstd_out, int M, float eps) {
+    constexpr int D = 256 * NV;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int lane = threadIdx.x & 63;
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + (long)row * D);
+    const f32x4* w4 = reinterpret_cast<const f32x4*>(w);
+    const f32x4* b4 = reinterpret_cast<const f32x4*>(b);
+    f32x4 v[NV], wv[NV], bv[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = xr[lane + 64 * i]; wv[i] = w4[lane + 64 * i]; bv[i] = b4[lane + 64 * i];
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float mean = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+    const float rstd = rsqrtf(wave_sum(q) / D + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * wv[i][e] + bv[i][e];
+        if (y) reinterpret_cast<f32x4*>(y + (long)row * D)[lane + 64 * i] = o;
+        if (y16) {
+            bf16x4 o16;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o16[e] = (__bf16)o[e];
+            reinterpret_cast<bf16x4*>(y16 + (long)row * D)[lane + 64 * i] = o16;
+        }
+    }
+    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+}
+
 // ------------------------------------------------------------------ LayerNorm backward
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w;  dw += dy * xhat;  db += dy.
 // Each wave walks rows row0, row0 + nwaves, ...; per-lane column partials are combined over the
@@ -188,6 +232,91 @@ __global__ __launch_bounds__(256) void layernorm_bwd_rows_kernel(const float* __
     }
 }
 
+// The same with 16-byte accesses for D = 256 * NV (lane owns the float4 groups lane + 64 i): 3 loads per array and row
+// instead of 12, 16-byte dx stores, 8-byte bf16 stores.
+template <int RPW, int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_rows_vec_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                     const float* __restrict__ w, const float* __restrict__ mean,
+                                                                     const float* __restrict__ rstd, float* __restrict__ dx,
+                                                                     float* __restrict__ dw, float* __restrict__ db,
+                                                                     __bf16* __restrict__ dx16, float* __restrict__ dx_colsum,
+                                                                     int M, int dx_accumulate) {
+    constexpr int D = 256 * NV;
+    extern __shared__ float red[];   // [3][4][D]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row0 = (blockIdx.x * 4 + wave) * RPW;
+    f32x4 dv[RPW][NV], xv[RPW][NV], ov[RPW][NV], wv[NV];
+    float mu[RPW], rs[RPW];
+    const f32x4* w4 = reinterpret_cast<const f32x4*>(w);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) wv[i] = w4[lane + 64 * i];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int row = min(row0 + r, M - 1);
+        mu[r] = mean[row]; rs[r] = rstd[row];
+        const f32x4* dy4 = reinterpret_cast<const f32x4*>(dy + (long)row * D);
+        const f32x4* x4 = reinterpret_cast<const f32x4*>(x + (long)row * D);
+        const f32x4* o4 = reinterpret_cast<const f32x4*>(dx + (long)row * D);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            dv[r][i] = dy4[lane + 64 * i];
+            xv[r][i] = x4[lane + 64 * i];
+            if (dx_accumulate) ov[r][i] = o4[lane + 64 * i];
+            else ov[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    f32x4 pw[NV], pb[NV], pc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { pw[i] = f32x4{0.f, 0.f, 0.f, 0.f}; pb[i] = pw[i]; pc[i] = pw[i]; }
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int row = row0 + r;
+        if (row >= M) break;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (xv[r][i][e] - mu[r]) * rs[r];
+                const float d = dv[r][i][e];
+                const float g = d * wv[i][e];
+                pw[i][e] += d * xh; pb[i][e] += d;
+                s1 += g; s2 += g * xh;
+                xv[r][i][e] = xh; dv[r][i][e] = g;
+            }
+        s1 = wave_sum(s1) / D; s2 = wave_sum(s2) / D;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = rs[r] * (dv[r][i][e] - s1 - xv[r][i][e] * s2) + ov[r][i][e];
+                pc[i][e] += o[e];
+            }
+            reinterpret_cast<f32x4*>(dx + (long)row * D)[lane + 64 * i] = o;
+            if (dx16) {
+                bf16x4 o16;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o16[e] = (__bf16)o[e];
+                reinterpret_cast<bf16x4*>(dx16 + (long)row * D)[lane + 64 * i] = o16;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = 4 * (lane + 64 * i);
+        *reinterpret_cast<f32x4*>(&red[(0 * 4 + wave) * D + c]) = pw[i];
+        *reinterpret_cast<f32x4*>(&red[(1 * 4 + wave) * D + c]) = pb[i];
+        *reinterpret_cast<f32x4*>(&red[(2 * 4 + wave) * D + c]) = pc[i];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+        atomicAdd(dw + c, red[0 * D + c] + red[1 * D + c] + red[2 * D + c] + red[3 * D + c]);
+        atomicAdd(db + c, red[4 * D + c] + red[5 * D + c] + red[6 * D + c] + red[7 * D + c]);
+        if (dx_colsum) atomicAdd(dx_colsum + c, red[8 * D + c] + red[9 * D + c] + red[10 * D + c] + red[11 * D + c]);
+    }
+}
+
 // ------------------------------------------------------------------ column sum (bias gradients)
 // out[n] += sum_m dy[m, n].  Threads own columns (coalesced rows), blocks own row slabs.
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dy, long ld, float* __restrict__ out,
@@ -285,8 +414,14 @@ extern "C" int vitae_layernorm_fwd(const float* x, const float* w, const float* 
                                    float* rstd, int M, int D, float eps, void* stream) {
     if (!x || !w || !b || (!y && !y_bf16) || !mean || !rstd || M <= 0 || D <= 0) return VITAE_ERR_INVALID_ARG;
     if (D > 64 * LN_MAX_PER_LANE) return VITAE_ERR_UNSUPPORTED_SHAPE;
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, w, b, y,
-                       reinterpret_cast<__bf16*>(y_bf16), mean, rstd, M, D, eps);
+    __bf16* y16 = reinterpret_cast<__bf16*>(y_bf16);
+    const bool aligned = !(((uintptr_t)x | (uintptr_t)w | (uintptr_t)b | (uintptr_t)y) & 15) && !((uintptr_t)y16 & 7);
+    hipStream_t st = (hipStream_t)stream;
+    if (aligned && D == 768) hipLaunchKernelGGL(layernorm_fwd_vec_kernel<3>, dim3(cdiv(M, 4)), dim3(256), 0, st, x, w, b, y, y16, mean, rstd, M, eps);
+    else if (aligned && D == 512) hipLaunchKernelGGL(layernorm_fwd_vec_kernel<2>, dim3(cdiv(M, 4)), dim3(256), 0, st, x, w, b, y, y16, mean, rstd, M, eps);
+    else if (aligned && D == 1024) hipLaunchKernelGGL(layernorm_fwd_vec_kernel<4>, dim3(cdiv(M, 4)), dim3(256), 0, st, x, w, b, y, y16, mean, rstd, M, eps);
+    else if (aligned && D == 256) hipLaunchKernelGGL(layernorm_fwd_vec_kernel<1>, dim3(cdiv(M, 4)), dim3(256), 0, st, x, w, b, y, y16, mean, rstd, M, eps);
+    else hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, x, w, b, y, y16, mean, rstd, M, D, eps);
     return vitae_launch_status();
 }
 
@@ -295,6 +430,16 @@ extern "C" int vitae_layernorm_bwd(const float* dy, const float* x, const float*
                                    float* dx_colsum_accum, int M, int D, int dx_accumulate, void* stream) {
     if (!dy || !x || !w || !mean || !rstd || !dx || !dw || !db || M <= 0 || D <= 0) return VITAE_ERR_INVALID_ARG;
     if (D > 64 * LN_MAX_PER_LANE) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    __bf16* dx16v = reinterpret_cast<__bf16*>(dx_bf16);
+    const bool aligned = !(((uintptr_t)dy | (uintptr_t)x | (uintptr_t)w | (uintptr_t)dx) & 15) && !((uintptr_t)dx16v & 7);
+    if (aligned && (D == 768 || D == 512 || D == 256)) {
+        const size_t lds = (size_t)12 * D * sizeof(float);
+        hipStream_t st = (hipStream_t)stream;
+        if (D == 768) hipLaunchKernelGGL((layernorm_bwd_rows_vec_kernel<2, 3>), dim3(cdiv(M, 8)), dim3(256), lds, st, dy, x, w, mean, rstd, dx, dw, db, dx16v, dx_colsum_accum, M, dx_accumulate);
+        else if (D == 512) hipLaunchKernelGGL((layernorm_bwd_rows_vec_kernel<2, 2>), dim3(cdiv(M, 8)), dim3(256), lds, st, dy, x, w, mean, rstd, dx, dw, db, dx16v, dx_colsum_accum, M, dx_accumulate);
+        else hipLaunchKernelGGL((layernorm_bwd_rows_vec_kernel<2, 1>), dim3(cdiv(M, 8)), dim3(256), lds, st, dy, x, w, mean, rstd, dx, dw, db, dx16v, dx_colsum_accum, M, dx_accumulate);
+        return vitae_launch_status();
+    }
     if (D <= 768) {
         hipLaunchKernelGGL(layernorm_bwd_rows_kernel<2>, dim3(cdiv(M, 8)), dim3(256), (size_t)12 * D * sizeof(float),
                            (hipStream_t)stream, dy, x, w, mean, rstd, dx, dw, db, reinterpret_cast<__bf16*>(dx_bf16),
