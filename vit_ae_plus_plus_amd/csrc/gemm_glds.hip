@@ -43,6 +43,8 @@ struct GArgs {
     float* out_colsum;   // optional: out_colsum[n] += sum_m (epilogue result)(m, n)  (bias gradient of the NEXT Linear)
     float* a_rowsum;     // optional: a_rowsum[m] += sum_k A(m, k): in a wgrad (A = dy^T) this is colsum(dy), the bias gradient
                          // of THIS Linear, obtained with one extra MFMA against a ones operand in the tn == 0 workgroups
+    int vec_epi;         // all epilogue arrays are 16-byte addressable by 4-column groups (N, the leading dimensions and the
+                         // base pointers allow it): the tile goes through LDS and leaves row-major, 16 bytes per lane
     int tiles_m, tiles_n;
     int xcd_m;           // 0: an XCD owns column tiles tn = xcd (mod 8) and walks every row tile (its L2 holds 1/8 of B and all
                          // of A); 1: it owns row tiles tm = xcd (mod 8) instead — picked when A is the larger operand
@@ -112,6 +114,98 @@ __device__ __forceinline__ float epilogue_frag(const GArgs& p, const float (&v)[
         asm volatile("" ::: "memory");   // keep the next batch's loads behind these stores (register pressure)
     }
     return csum;
+}
+
+// Row-major epilogue.  The MFMA result has one COLUMN per lane (16 rows of it), so storing from registers means 4-byte
+// accesses (2-byte for the bf16 copy), two 128-byte row pieces per instruction.  Here the finished tile is parked in
+// LDS (the stage buffers are free by then) and re-read row-major: every lane owns four consecutive columns of a row, so
+// C, the bf16 copy, the saved pre-activation, the residual and the old C all move 16 bytes per lane (8 for bf16) in
+// 256-byte contiguous runs.  Loads of PB passes are issued together before the dependent stores, as in epilogue_frag.
+template <int BM, int BN, int NW, int NF>
+__device__ __forceinline__ void epilogue_rows(const GArgs& p, const float (&a)[NF][16], int m0, int n0, int wm, int wn,
+                                              int lane, unsigned char* smem) {
+    constexpr int WAVES_M = NW / 2, FN = BN / 64, FM = BM / (32 * WAVES_M);
+    constexpr int LDT = BN + 4, NT = 64 * NW, CG = BN / 4, RPP = NT / CG, PASSES = BM / RPP, PB = BN > 64 ? 2 : 4;
+    static_assert(NF == FM * FN && PASSES % PB == 0, "tile / thread geometry");
+    float* T = reinterpret_cast<float*>(smem);
+    float* cs = T + BM * LDT;
+    const int l31 = lane & 31, hi = lane >> 5;
+    __syncthreads();                       // every wave is done with the operand stages
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                T[(wm * (BM / WAVES_M) + fm * 32 + crow(r, hi)) * LDT + wn * (BN / 2) + fn * 32 + l31] = a[fm * FN + fn][r];
+    if (p.out_colsum && (int)threadIdx.x < BN) cs[threadIdx.x] = 0.f;
+    __syncthreads();
+    const int cg = threadIdx.x % CG, r0 = threadIdx.x / CG;
+    const int n = n0 + 4 * cg;
+    const bool ncol = n < p.N;                                   // N % 4 == 0 here: the whole group is in or out
+    const int nc = ncol ? n : 0;
+    const int ldaux = (int)p.ldaux, ldr = (int)p.ldr, ldc = (int)p.ldc, ldc16 = (int)p.ldc16;
+    const bool need_aux = p.epi == VITAE_EPI_DGELU || p.epi == VITAE_EPI_RELU_MASK;
+    const bool acc_c = p.C && p.accumulate;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias && ncol) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+    f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pb = 0; pb < PASSES; pb += PB) {
+        f32x4 ax[PB], rs[PB], co[PB];
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+            const int mc = min(m0 + r0 + (pb + q) * RPP, p.M - 1);
+            if (need_aux) ax[q] = *reinterpret_cast<const f32x4*>(p.aux + mc * ldaux + nc);
+            if (p.residual) rs[q] = *reinterpret_cast<const f32x4*>(p.residual + mc * ldr + nc);
+            if (acc_c) co[q] = *reinterpret_cast<const f32x4*>(p.C + mc * ldc + nc);
+        }
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+            const int row = r0 + (pb + q) * RPP, m = m0 + row;
+            if (!(ncol && m < p.M)) continue;
+            f32x4 x = *reinterpret_cast<const f32x4*>(&T[row * LDT + 4 * cg]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] += bias4[e];
+            if (p.epi == VITAE_EPI_GELU) {
+                *reinterpret_cast<f32x4*>(p.aux + m * ldaux + n) = x;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = gelu_erf(x[e]);
+            } else if (p.epi == VITAE_EPI_DGELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] *= gelu_erf_grad(ax[q][e]);
+            } else if (p.epi == VITAE_EPI_RELU_MASK) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = ax[q][e] > 0.f ? x[e] : 0.f;
+            }
+            if (p.residual) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] += rs[q][e];
+            }
+            if (p.C) {
+                if (acc_c) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[e] += co[q][e];
+                }
+                *reinterpret_cast<f32x4*>(p.C + m * ldc + n) = x;
+            }
+            if (p.C16) {
+                bf16x4 x16;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x16[e] = (__bf16)x[e];
+                *reinterpret_cast<bf16x4*>(p.C16 + m * ldc16 + n) = x16;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) csum[e] += x[e];
+        }
+        asm volatile("" ::: "memory");   // keep the next batch's loads behind these stores (register pressure)
+    }
+    if (p.out_colsum) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(&cs[4 * cg + e], csum[e]);      // LDS: RPP-way per column
+        __syncthreads();
+        if ((int)threadIdx.x < BN && n0 + (int)threadIdx.x < p.N) atomicAdd(p.out_colsum + n0 + threadIdx.x, cs[threadIdx.x]);
+    }
 }
 
 // XOR applied to a line's 16-byte chunk index (by the DMA through the SOURCE address, by the fragment reads directly).
@@ -352,6 +446,12 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
         if (threadIdx.x == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     }
 
+    if constexpr (BM * BN <= 64 * 128 && NW == 4) {
+        if (p.vec_epi) {
+            epilogue_rows<BM, BN, NW, NF>(p, a, m0, n0, wm, wn, lane, smem);
+            return;
+        }
+    }
 #pragma unroll
     for (int fn = 0; fn < FN; ++fn) {
         const int n = n0 + wn * (BN / 2) + fn * 32 + l31;
@@ -411,6 +511,14 @@ struct Tile { int bm, bn, id; };
 // memory-side traffic.)
 // (Tried as well: all workgroups of one k-split on one XCD group, so that no operand slice is fetched by more than
 // 8 / splits XCDs — less traffic again, but 5-25 % slower at K <= 3072 and only 3-5 % faster at K = 16384: not kept.)
+// the row-major epilogue moves 4-column groups: every array it touches must be addressable that way
+inline int vec_epilogue_ok(const GArgs& p) {
+    static const int on = getenv("VITAE_GLDS_VEC_EPILOGUE") ? atoi(getenv("VITAE_GLDS_VEC_EPILOGUE")) : 1;
+    if (!on || (p.N & 3)) return 0;
+    auto ok = [](const void* ptr, long ld, int align) { return !ptr || (!(ld & 3) && !((uintptr_t)ptr & (align - 1))); };
+    return ok(p.C, p.ldc, 16) && ok(p.C16, p.ldc16, 8) && ok(p.aux, p.ldaux, 16) && ok(p.residual, p.ldr, 16) && ok(p.bias, 0, 16);
+}
+
 inline int xcd_by_rows(int M, int N) {
     static const int mode = getenv("VITAE_GLDS_XCD_ROWS") ? atoi(getenv("VITAE_GLDS_XCD_ROWS")) : -1;
     if (mode >= 0) return mode;
@@ -492,6 +600,7 @@ extern "C" int vitae_gemm_glds(int a_kcontig, int b_kcontig, const void* A16, lo
     const Tile t = pick_tile(M, N);
     p.tiles_m = cdiv(M, t.bm); p.tiles_n = cdiv(N, t.bn);
     p.xcd_m = xcd_by_rows(M, N);
+    p.vec_epi = vec_epilogue_ok(p);
     if (split_k > 1 && (long)p.tiles_m * p.tiles_n > VITAE_GLDS_TICKETS) return VITAE_ERR_UNSUPPORTED_SHAPE;
     dim3 grid(glds_blocks(p), 1, split_k);
     hipStream_t st = (hipStream_t)stream;
@@ -544,6 +653,7 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
     if (t1.id == 3) t1 = Tile{64, 128, 1};      // the paired launch is 4-wave only
     p1.tiles_m = cdiv(M, t1.bm); p1.tiles_n = cdiv(K, t1.bn);
     p1.xcd_m = xcd_by_rows(M, K);
+    p1.vec_epi = vec_epilogue_ok(p1);
     p2.A = reinterpret_cast<const __bf16*>(dy16); p2.lda = N;
     p2.B = reinterpret_cast<const __bf16*>(x16); p2.ldb = K;
     p2.C = dw; p2.ldc = K; p2.C16 = reinterpret_cast<__bf16*>(dw16); p2.ldc16 = K;
@@ -554,6 +664,7 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
     if (t2.id == 3) t2 = Tile{64, 128, 1};
     p2.tiles_m = cdiv(N, t2.bm); p2.tiles_n = cdiv(K, t2.bn);
     p2.xcd_m = xcd_by_rows(N, K);
+    p2.vec_epi = vec_epilogue_ok(p2);
     const int nb1 = glds_blocks(p1), nb2 = glds_blocks(p2);
     dim3 grid(nb1 * split_k + nb2);
     hipStream_t st = (hipStream_t)stream;

@@ -4,6 +4,7 @@
 // LayerNorm keeps the row in registers (one wave per row, 16-byte loads when D % 256 == 0),
 // statistics by wave shuffles; parameter gradients are wave-partial sums + one atomicAdd per
 // column per block into the (pre-zeroed) gradient arena.
+#include <cstdlib>
 #include "common.hpp"
 #include "vitae_hip.h"
 
@@ -415,7 +416,8 @@ extern "C" int vitae_layernorm_fwd(const float* x, const float* w, const float* 
     if (!x || !w || !b || (!y && !y_bf16) || !mean || !rstd || M <= 0 || D <= 0) return VITAE_ERR_INVALID_ARG;
     if (D > 64 * LN_MAX_PER_LANE) return VITAE_ERR_UNSUPPORTED_SHAPE;
     __bf16* y16 = reinterpret_cast<__bf16*>(y_bf16);
-    const bool aligned = !(((uintptr_t)x | (uintptr_t)w | (uintptr_t)b | (uintptr_t)y) & 15) && !((uintptr_t)y16 & 7);
+    static const int vec_on = getenv("VITAE_LN_VEC") ? atoi(getenv("VITAE_LN_VEC")) : 1;     // 0: 4-byte accesses (A/B)
+    const bool aligned = vec_on && !(((uintptr_t)x | (uintptr_t)w | (uintptr_t)b | (uintptr_t)y) & 15) && !((uintptr_t)y16 & 7);
     hipStream_t st = (hipStream_t)stream;
     if (aligned && D == 768) hipLaunchKernelGGL(layernorm_fwd_vec_kernel<3>, dim3(cdiv(M, 4)), dim3(256), 0, st, x, w, b, y, y16, mean, rstd, M, eps);
     else if (aligned && D == 512) hipLaunchKernelGGL(layernorm_fwd_vec_kernel<2>, dim3(cdiv(M, 4)), dim3(256), 0, st, x, w, b, y, y16, mean, rstd, M, eps);
@@ -431,7 +433,8 @@ extern "C" int vitae_layernorm_bwd(const float* dy, const float* x, const float*
     if (!dy || !x || !w || !mean || !rstd || !dx || !dw || !db || M <= 0 || D <= 0) return VITAE_ERR_INVALID_ARG;
     if (D > 64 * LN_MAX_PER_LANE) return VITAE_ERR_UNSUPPORTED_SHAPE;
     __bf16* dx16v = reinterpret_cast<__bf16*>(dx_bf16);
-    const bool aligned = !(((uintptr_t)dy | (uintptr_t)x | (uintptr_t)w | (uintptr_t)dx) & 15) && !((uintptr_t)dx16v & 7);
+    static const int vec_on = getenv("VITAE_LN_VEC") ? atoi(getenv("VITAE_LN_VEC")) : 1;
+    const bool aligned = vec_on && !(((uintptr_t)dy | (uintptr_t)x | (uintptr_t)w | (uintptr_t)dx) & 15) && !((uintptr_t)dx16v & 7);
     if (aligned && (D == 768 || D == 512 || D == 256)) {
         const size_t lds = (size_t)12 * D * sizeof(float);
         hipStream_t st = (hipStream_t)stream;
