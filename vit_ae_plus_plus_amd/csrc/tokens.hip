@@ -69,22 +69,58 @@ __global__ __launch_bounds__(256) void gather_patches_kernel(const float* __rest
 // ---------------------------------------------------------------- encoder sequence assembly
 // x[b, 0]     = cls_token + pos_embed[0]
 // x[b, 1 + j] = tok[b*keep + j] + pos_embed[1 + ids_shuffle[b, j]]       (tok already has the conv bias)
+// out[d] = a[d] + b[d] over one row; V: D % 4 == 0 and 16-byte aligned rows -> 16 bytes per lane
+template <bool V>
+__device__ __forceinline__ void row_add(float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ b, int D) {
+    if (V) {
+        for (int d = threadIdx.x; d < D / 4; d += 256) {
+            const f32x4 u = reinterpret_cast<const f32x4*>(a)[d], w = reinterpret_cast<const f32x4*>(b)[d];
+            reinterpret_cast<f32x4*>(out)[d] = f32x4{u[0] + w[0], u[1] + w[1], u[2] + w[2], u[3] + w[3]};
+        }
+    } else {
+        for (int d = threadIdx.x; d < D; d += 256) out[d] = a[d] + b[d];
+    }
+}
+
+// out[d] = src[d] (+ optional bf16 copy) over one row
+template <bool V>
+__device__ __forceinline__ void row_copy(float* __restrict__ out, __bf16* __restrict__ out16, const float* __restrict__ src, int D) {
+    if (V) {
+        for (int d = threadIdx.x; d < D / 4; d += 256) {
+            const f32x4 v = reinterpret_cast<const f32x4*>(src)[d];
+            if (out) reinterpret_cast<f32x4*>(out)[d] = v;
+            if (out16) {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+                reinterpret_cast<bf16x4*>(out16)[d] = o;
+            }
+        }
+    } else {
+        for (int d = threadIdx.x; d < D; d += 256) {
+            const float v = src[d];
+            if (out) out[d] = v;
+            if (out16) out16[d] = (__bf16)v;
+        }
+    }
+}
+
+template <bool V>
 __global__ __launch_bounds__(256) void encoder_assemble_fwd_kernel(const float* __restrict__ tok, const float* __restrict__ cls,
                                                                    const float* __restrict__ pos, const int* __restrict__ ids_shuffle,
                                                                    float* __restrict__ x, int L, int keep, int D) {
     const int t = blockIdx.x, b = blockIdx.y;   // t in [0, keep]
     float* xr = x + ((long)b * (keep + 1) + t) * D;
     if (t == 0) {
-        for (int d = threadIdx.x; d < D; d += 256) xr[d] = cls[d] + pos[d];
+        row_add<V>(xr, cls, pos, D);
     } else {
         const int l = ids_shuffle[(long)b * L + t - 1];
-        const float* tr = tok + ((long)b * keep + t - 1) * D;
-        const float* pr = pos + (long)(1 + l) * D;
-        for (int d = threadIdx.x; d < D; d += 256) xr[d] = tr[d] + pr[d];
+        row_add<V>(xr, tok + ((long)b * keep + t - 1) * D, pos + (long)(1 + l) * D, D);
     }
 }
 
 // dtok[b*keep + j] = dx[b, 1 + j];  dcls += sum_b dx[b, 0]
+template <bool V>
 __global__ __launch_bounds__(256) void encoder_assemble_bwd_kernel(const float* __restrict__ dx, float* __restrict__ dtok,
                                                                    __bf16* __restrict__ dtok16,
                                                                    float* __restrict__ dcls, int B, int keep, int D) {
@@ -99,11 +135,7 @@ __global__ __launch_bounds__(256) void encoder_assemble_bwd_kernel(const float* 
         }
     } else {
         const long oo = ((long)b * keep + t - 1) * D;
-        for (int d = threadIdx.x; d < D; d += 256) {
-            const float v = dr[d];
-            if (dtok) dtok[oo + d] = v;
-            if (dtok16) dtok16[oo + d] = (__bf16)v;
-        }
+        row_copy<V>(dtok ? dtok + oo : nullptr, dtok16 ? dtok16 + oo : nullptr, dr, D);
     }
 }
 
@@ -111,6 +143,7 @@ __global__ __launch_bounds__(256) void encoder_assemble_bwd_kernel(const float* 
 // e = decoder_embed(latent) [B, keep+1, Dd].
 // xd[b, 0]     = e[b, 0] + dpos[0]
 // xd[b, 1 + l] = (r = ids_restore[b, l]) < keep ? e[b, 1 + r] : mask_token) + dpos[1 + l]
+template <bool V>
 __global__ __launch_bounds__(256) void decoder_assemble_fwd_kernel(const float* __restrict__ e, const float* __restrict__ mask_token,
                                                                    const float* __restrict__ dpos, const int* __restrict__ ids_restore,
                                                                    float* __restrict__ xd, int L, int keep, int Dd) {
@@ -123,13 +156,14 @@ __global__ __launch_bounds__(256) void decoder_assemble_fwd_kernel(const float* 
         const int r = ids_restore[(long)b * L + t - 1];
         src = r < keep ? e + ((long)b * (keep + 1) + 1 + r) * Dd : mask_token;
     }
-    for (int d = threadIdx.x; d < Dd; d += 256) xr[d] = src[d] + pr[d];
+    row_add<V>(xr, src, pr, Dd);
 }
 
 // de[b, 0] = dxd[b, 0];  de[b, 1 + r] = dxd[b, 1 + ids_shuffle[b, r]]  (r < keep)
 // One launch, two kinds of workgroup.  The first (keep + 1) * B gather the kept rows of dxd back into de (fp32, and
 // optionally a bf16 copy: the dy operand of decoder_embed's backward GEMMs).  The rest sum dxd over the masked
 // positions into dmask_token: threads own columns, each workgroup takes `per_block` entries of the (b, masked-rank) list.
+template <bool V>
 __global__ __launch_bounds__(256) void decoder_assemble_bwd_kernel(const float* __restrict__ dxd, const int* __restrict__ ids_shuffle,
                                                                    float* __restrict__ de, __bf16* __restrict__ de16,
                                                                    float* __restrict__ dmask, int B, int L, int keep, int Dd,
@@ -140,11 +174,7 @@ __global__ __launch_bounds__(256) void decoder_assemble_bwd_kernel(const float* 
         const int srow = t == 0 ? 0 : 1 + ids_shuffle[(long)b * L + t - 1];
         const float* s = dxd + ((long)b * (L + 1) + srow) * Dd;
         const long o = ((long)b * (keep + 1) + t) * Dd;
-        for (int d = threadIdx.x; d < Dd; d += 256) {
-            const float v = s[d];
-            de[o + d] = v;
-            if (de16) de16[o + d] = (__bf16)v;
-        }
+        row_copy<V>(de + o, de16 ? de16 + o : nullptr, s, Dd);
         return;
     }
     const int mb = blockIdx.x - nrow;
@@ -207,16 +237,22 @@ extern "C" int vitae_encoder_assemble_fwd(const float* tok, const float* cls_tok
                                           const int* ids_shuffle, float* x, int B, int L, int keep, int D,
                                           void* stream) {
     if (!tok || !cls_token || !pos_embed || !ids_shuffle || !x || B <= 0) return VITAE_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(encoder_assemble_fwd_kernel, dim3(keep + 1, B), dim3(256), 0, (hipStream_t)stream, tok,
-                       cls_token, pos_embed, ids_shuffle, x, L, keep, D);
+    const bool v = !(D & 3) && !(((uintptr_t)tok | (uintptr_t)cls_token | (uintptr_t)pos_embed | (uintptr_t)x) & 15);
+    if (v) hipLaunchKernelGGL(encoder_assemble_fwd_kernel<true>, dim3(keep + 1, B), dim3(256), 0, (hipStream_t)stream, tok,
+                              cls_token, pos_embed, ids_shuffle, x, L, keep, D);
+    else hipLaunchKernelGGL(encoder_assemble_fwd_kernel<false>, dim3(keep + 1, B), dim3(256), 0, (hipStream_t)stream, tok,
+                            cls_token, pos_embed, ids_shuffle, x, L, keep, D);
     return vitae_launch_status();
 }
 
 extern "C" int vitae_encoder_assemble_bwd(const float* dx, float* dtok, void* dtok_bf16, float* dcls, int B, int keep,
                                           int D, void* stream) {
     if (!dx || (!dtok && !dtok_bf16) || !dcls || B <= 0) return VITAE_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(encoder_assemble_bwd_kernel, dim3(keep + 1, B), dim3(256), 0, (hipStream_t)stream, dx, dtok,
-                       reinterpret_cast<__bf16*>(dtok_bf16), dcls, B, keep, D);
+    const bool v = !(D & 3) && !(((uintptr_t)dx | (uintptr_t)dtok) & 15) && !((uintptr_t)dtok_bf16 & 7);
+    if (v) hipLaunchKernelGGL(encoder_assemble_bwd_kernel<true>, dim3(keep + 1, B), dim3(256), 0, (hipStream_t)stream, dx, dtok,
+                              reinterpret_cast<__bf16*>(dtok_bf16), dcls, B, keep, D);
+    else hipLaunchKernelGGL(encoder_assemble_bwd_kernel<false>, dim3(keep + 1, B), dim3(256), 0, (hipStream_t)stream, dx, dtok,
+                            reinterpret_cast<__bf16*>(dtok_bf16), dcls, B, keep, D);
     return vitae_launch_status();
 }
 
@@ -224,8 +260,11 @@ extern "C" int vitae_decoder_assemble_fwd(const float* e, const float* mask_toke
                                           const int* ids_restore, float* xd, int B, int L, int keep, int Dd,
                                           void* stream) {
     if (!e || !mask_token || !dpos || !ids_restore || !xd || B <= 0) return VITAE_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(decoder_assemble_fwd_kernel, dim3(L + 1, B), dim3(256), 0, (hipStream_t)stream, e, mask_token,
-                       dpos, ids_restore, xd, L, keep, Dd);
+    const bool v = !(Dd & 3) && !(((uintptr_t)e | (uintptr_t)mask_token | (uintptr_t)dpos | (uintptr_t)xd) & 15);
+    if (v) hipLaunchKernelGGL(decoder_assemble_fwd_kernel<true>, dim3(L + 1, B), dim3(256), 0, (hipStream_t)stream, e, mask_token,
+                              dpos, ids_restore, xd, L, keep, Dd);
+    else hipLaunchKernelGGL(decoder_assemble_fwd_kernel<false>, dim3(L + 1, B), dim3(256), 0, (hipStream_t)stream, e, mask_token,
+                            dpos, ids_restore, xd, L, keep, Dd);
     return vitae_launch_status();
 }
 
@@ -234,8 +273,11 @@ extern "C" int vitae_decoder_assemble_bwd(const float* dxd, const int* ids_shuff
     if (!dxd || !ids_shuffle || !de || !dmask_token || B <= 0) return VITAE_ERR_INVALID_ARG;
     const int total = B * (L - keep), per_block = 32, col_blocks = cdiv(Dd, 256);
     const int blocks = (keep + 1) * B + col_blocks * cdiv(total, per_block);
-    hipLaunchKernelGGL(decoder_assemble_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dxd, ids_shuffle, de,
-                       reinterpret_cast<__bf16*>(de_bf16), dmask_token, B, L, keep, Dd, per_block, col_blocks);
+    const bool v = !(Dd & 3) && !(((uintptr_t)dxd | (uintptr_t)de) & 15) && !((uintptr_t)de_bf16 & 7);
+    if (v) hipLaunchKernelGGL(decoder_assemble_bwd_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dxd, ids_shuffle, de,
+                              reinterpret_cast<__bf16*>(de_bf16), dmask_token, B, L, keep, Dd, per_block, col_blocks);
+    else hipLaunchKernelGGL(decoder_assemble_bwd_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dxd, ids_shuffle, de,
+                            reinterpret_cast<__bf16*>(de_bf16), dmask_token, B, L, keep, Dd, per_block, col_blocks);
     return vitae_launch_status();
 }
 
