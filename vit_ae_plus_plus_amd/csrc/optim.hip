@@ -44,7 +44,7 @@ __global__ void grad_norm_finalize_kernel(const double* __restrict__ acc, float*
 
 // torch.optim.AdamW (single-tensor form): p *= 1 - lr*wd; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
 // p -= (lr / bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
-template <bool NT, typename G>
+template <bool NT, typename G, int U = 8>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const G* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, __bf16* __restrict__ shadow, long n,
                                                     const float* __restrict__ hp, const float* __restrict__ gnorm,
@@ -61,20 +61,26 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     // two independent 16-byte groups per thread and iteration: 8 loads in flight before the first dependent use.
     // The moments stream through (nothing re-reads them for a whole step): non-temporal loads and stores keep them
     // from evicting the bf16 shadow / activations out of L2 and the MALL.
+    // U independent 16-byte groups per thread and iteration (4 U loads in flight before the first dependent use): the pass
+    // runs on one workgroup per CU, so its rate is set by the bytes each wave keeps in flight
     const long stride = (long)gridDim.x * 256;
-    for (long i0 = (long)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += 2 * stride) {
-        const long i1 = i0 + stride;
-        const bool two = i1 < n4;
-        const long j1 = two ? i1 : i0;
-        f32x4 pp[2], mm[2], vv[2], gg[2];
-        pp[0] = p4[i0]; pp[1] = p4[j1];
-        mm[0] = NT ? __builtin_nontemporal_load(m4 + i0) : m4[i0]; mm[1] = NT ? __builtin_nontemporal_load(m4 + j1) : m4[j1];
-        vv[0] = NT ? __builtin_nontemporal_load(v4 + i0) : v4[i0]; vv[1] = NT ? __builtin_nontemporal_load(v4 + j1) : v4[j1];
-        gg[0] = grad4<G>(g, i0); gg[1] = grad4<G>(g, j1);
+    for (long i0 = (long)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += U * stride) {
+        long idx[U];
+        bool live[U];
+        f32x4 pp[U], mm[U], vv[U], gg[U];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (u == 1 && !two) break;
-            const long i = u ? i1 : i0;
+        for (int u = 0; u < U; ++u) {
+            live[u] = i0 + u * stride < n4;
+            idx[u] = live[u] ? i0 + u * stride : i0;
+            pp[u] = p4[idx[u]];
+            mm[u] = NT ? __builtin_nontemporal_load(m4 + idx[u]) : m4[idx[u]];
+            vv[u] = NT ? __builtin_nontemporal_load(v4 + idx[u]) : v4[idx[u]];
+            gg[u] = grad4<G>(g, idx[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!live[u]) break;
+            const long i = idx[u];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float ge = gg[u][e] * gs;
@@ -144,8 +150,18 @@ static int adamw_launch(float* params, const G* grads, float* exp_avg, float* ex
     if (blocks < 1) blocks = 1;
     // 30 B/element of HBM traffic; 5.0-5.7 TB/s for every grid size >= 256 workgroups and cache policy tried (the
     // read-only grad-norm pass reaches 5.4 TB/s on the same box), i.e. this kernel sits at the achievable HBM rate.
-    hipLaunchKernelGGL((adamw_kernel<true, G>), dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
-                       exp_avg_sq, reinterpret_cast<__bf16*>(shadow_bf16), n, hp, grad_norm, weight_decay);
+    // groups in flight per thread: 2 -> 8 took the pass from 5.0 to 6.1 TB/s alone and the step from 5.58 to 5.18 ms (it
+    // spends less time beside the backward kernels it slows down); 12 and 16 are slower again (5.21 / 5.32 ms)
+    static const int unroll = getenv("VITAE_ADAMW_UNROLL") ? atoi(getenv("VITAE_ADAMW_UNROLL")) : 8;
+    if (unroll == 4)
+        hipLaunchKernelGGL((adamw_kernel<true, G, 4>), dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
+                           exp_avg_sq, reinterpret_cast<__bf16*>(shadow_bf16), n, hp, grad_norm, weight_decay);
+    else if (unroll == 8)
+        hipLaunchKernelGGL((adamw_kernel<true, G, 8>), dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
+                           exp_avg_sq, reinterpret_cast<__bf16*>(shadow_bf16), n, hp, grad_norm, weight_decay);
+    else
+        hipLaunchKernelGGL((adamw_kernel<true, G, 2>), dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
+                           exp_avg_sq, reinterpret_cast<__bf16*>(shadow_bf16), n, hp, grad_norm, weight_decay);
     return vitae_launch_status();
 }
 
