@@ -992,7 +992,10 @@ class HipMAEEngine:
 
     # ------------------------------------------------------------------ fused training step
     # encoder backward is cut into this many phases (= gradient buckets = optimiser-in-backward units)
-    enc_chunks = int(os.environ.get('VITAE_ENC_CHUNKS', '2'))
+    # (3: since AdamW got faster a third, smaller last bucket shortens the exposed tail: 5.15 -> 5.00 ms on one box, even on another)
+    enc_chunks = int(os.environ.get('VITAE_ENC_CHUNKS', '3'))
+    # optional explicit ascending block boundaries, e.g. "0,2,7,12" (uneven chunks: a smaller last, exposed bucket)
+    enc_cuts = [int(v) for v in os.environ['VITAE_ENC_CUTS'].split(',')] if os.environ.get('VITAE_ENC_CUTS') else None
 
     def set_backward_chunks(self, n: int):
         """Number of encoder-backward phases.  More phases = smaller gradient buckets = an earlier start and a shorter
@@ -1007,6 +1010,9 @@ class HipMAEEngine:
         """[(hi, lo)] block ranges of the encoder-backward phases, last block first; sizes differ by at most one."""
         d, n = self.cfg.depth, self.enc_chunks
         cuts = [round(d * i / n) for i in range(n + 1)]              # ascending block boundaries
+        ec = getattr(self, 'enc_cuts', None)
+        if ec and ec[0] == 0 and ec[-1] == d and len(ec) == n + 1:
+            cuts = ec
         return [(cuts[i + 1] - 1, cuts[i]) for i in reversed(range(n))]
 
     def train_phase(self, k: int, view1, view2, noise, mask_ratio: float, update: bool = True,
