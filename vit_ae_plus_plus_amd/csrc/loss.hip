@@ -223,7 +223,8 @@ __global__ __launch_bounds__(256) void sobel_bwd_scatter_kernel(const float* __r
 template <int RAD>
 __device__ __forceinline__ void blur_xy_body(const dim3 blockIdx_, const float* __restrict__ in, float* __restrict__ out, int Hy, int Wx,
                                                       int TY, Taps t) {
-    extern __shared__ float sm[];
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    static_assert((2 * RAD + 2) % 4 == 0, "row stride must stay a multiple of 4 floats for the 16-byte LDS accesses");
     constexpr int NT = 2 * RAD + 1, XB = 4;   // XB outputs per thread along x share their NT + XB - 1 inputs
     const int rows = TY + 2 * RAD;
     const int Wp = (Wx + XB - 1) / XB * XB, stride = Wp + 2 * RAD + 2;   // +2: de-phase consecutive rows' banks
@@ -246,16 +247,25 @@ __device__ __forceinline__ void blur_xy_body(const dim3 blockIdx_, const float* 
     for (int w = threadIdx.x; w < rows * groups; w += 256) {
         const int r = w / groups, x = (w - r * groups) * XB;
         const float* row = a + r * stride + x;
-        float v[NT + XB - 1];
+        // 16-byte LDS reads (x and stride are multiples of 4, the row has 2 RAD + 2 floats of slack behind Wp): with
+        // 4-byte reads at a 4-float lane stride every bank served 4 lanes (68 % of this kernel's LDS cycles were conflicts)
+        constexpr int NV4 = (NT + XB - 1 + 3) / 4;
+        static_assert(4 * NV4 <= XB + 2 * RAD + 2, "the padded row must cover the widened read");
+        float v[4 * NV4];
 #pragma unroll
-        for (int i = 0; i < NT + XB - 1; ++i) v[i] = row[i];
+        for (int i = 0; i < NV4; ++i) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(row + 4 * i);
+            v[4 * i] = q[0]; v[4 * i + 1] = q[1]; v[4 * i + 2] = q[2]; v[4 * i + 3] = q[3];
+        }
+        f32x4 res;
 #pragma unroll
         for (int o = 0; o < XB; ++o) {
             float acc = 0.f;
 #pragma unroll
             for (int i = 0; i < NT; ++i) acc += t.k[i] * v[o + i];
-            m[r * Wp + x + o] = acc;
+            res[o] = acc;
         }
+        *reinterpret_cast<f32x4*>(&m[r * Wp + x]) = res;
     }
     __syncthreads();
     // y: one thread per (column, half band); inputs fetched once into registers
