@@ -44,11 +44,14 @@ def test_no_torch_types_in_abi():
         assert set(kinds) <= {'ptr', 'int', 'long', 'longlong', 'float', 'double'}, name
 
 
-def test_code_object_is_gfx950_only(libpath, tmp_path):
+def test_code_object_is_gfx950_only(libpath):
     # llvm-objdump --offloading EXTRACTS every bundle next to its input: work on a copy so nothing lands in the package
-    import shutil
-    copy = shutil.copy(libpath, tmp_path / 'libvitae_hip.so')
-    out = subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-objdump', '--offloading', str(copy)], capture_output=True, text=True)
+    # (in a directory whose name cannot be mistaken for an architecture in the tool's output)
+    import shutil, tempfile
+    tmp = tempfile.mkdtemp(prefix='vitae_codeobj_')
+    copy = shutil.copy(libpath, os.path.join(tmp, 'lib.so'))
+    out = subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-objdump', '--offloading', copy], capture_output=True, text=True)
+    shutil.rmtree(tmp, ignore_errors=True)
     if out.returncode != 0:
         pytest.skip('llvm-objdump --offloading unavailable')
     archs = set(re.findall(r'gfx\w+', out.stdout))
