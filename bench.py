@@ -233,7 +233,7 @@ def main():
     # stream = torch's current stream) around every GEMM launch.  A spin kernel is queued first so the host
     # enqueues the whole step while the GPU is still busy: event deltas then contain no host-launch gaps.
     roof = None
-    if rank == 0:
+    if rank == 0 and args.profile_steps > 0:
         eager = model._step_runner(args.batch, 0.75, True, False, False)
         recs = []
         for i in range(args.profile_steps):
@@ -281,8 +281,10 @@ def main():
                  'glds': 'gemm_glds_kernel<64,64,..> (csrc/gemm_glds.hip)',
                  'glds_wide': 'gemm_glds_kernel<64,128,..> (csrc/gemm_glds.hip)',
                  'glds_pair_wide': 'gemm_glds_pair_kernel<..,64,128> (csrc/gemm_glds.hip)',
+                 'glds_dgrad': 'gemm_glds_kernel<64,64,true,false> (csrc/gemm_glds.hip: dgrad of one Linear)',
+                 'glds_wgrad_group': 'gemm_glds_group_kernel (csrc/gemm_glds.hip: the four weight gradients of a block in one launch)',
                  'other': ('gemm_bf16_kernel / gemm_bf16_pair_kernel (csrc/gemm_bf16.hip)' if args.precision == 'bf16'
-                           else 'gemm_kernel<0,..> (csrc/gemm.hip)')}[dom]
+                           else 'gemm_kernel<0,..> (csrc/gemm.hip)')}.get(dom, dom)
         traffic, tnote = None, None   # PMC counters cannot be read in-process: last committed rocprofv3 --pmc result
         tfile = os.path.join(ROOT, 'profiles', 'round1_gemm_traffic.json')
         if args.precision == 'bf16' and args.batch == 4 and os.path.exists(tfile):

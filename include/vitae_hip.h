@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITAE_ABI_VERSION 21
+#define VITAE_ABI_VERSION 22
 
 /* matrix-core arithmetic of the dense contractions */
 #define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
@@ -143,6 +143,39 @@ int vitae_layernorm_fwd(const float* x, const float* w, const float* b, float* y
 int vitae_layernorm_bwd(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
                         float* dx, float* dw, float* db, void* dx_bf16, float* dx_colsum_accum, int M, int D,
                         int dx_accumulate, void* stream);
+
+/* The same two on an input that still is `nslabs` partial sums (slab s at slabs + s * slab_stride, each [M, D]; the
+ * fused MLP kernels below leave their result that way): forward x_out = residual + bias + sum_s slab_s (bias may be NULL),
+ * y_bf16 = LayerNorm(x_out); backward dy = sum_s slab_s.  D in {512, 768, 1024}. */
+int vitae_layernorm_fwd_slabs(const float* slabs, int nslabs, long slab_stride, const float* residual, const float* bias,
+                              const float* w, const float* b, float* x_out, float* y /* optional fp32 copy of the LayerNorm
+                              output */, void* y_bf16, float* mean, float* rstd, int M, int D, float eps, void* stream);
+int vitae_layernorm_bwd_slabs(const float* slabs, int nslabs, long slab_stride, const float* x, const float* w,
+                              const float* mean, const float* rstd, float* dx, float* dw, float* db, void* dx_bf16,
+                              float* dx_colsum_accum, int M, int D, int dx_accumulate, void* stream);
+
+/* ---- the MLP of a transformer block in one launch (Mlp3D.forward, model/vit.py:90-96, inside Block.forward :143) --------
+ * forward : h = y16 W1^T + b1 (saved bf16 in hpre16), act16 = gelu(h) (saved: operand of fc2's weight gradient),
+ *           slabs[s] = act16[:, s-th 128-slice] W2[:, slice]^T — H/128 partial sums of the fc2 product, [Mpad, d] fp32 each
+ *           (sum them with vitae_layernorm_fwd_slabs, which also adds fc2's bias and the residual);
+ * backward: dh16 = (dxo16 W2) * gelu'(hpre16) (saved: operand of fc1's weight gradient), slabs[s] = dh16[:, slice] W1[slice, :]
+ *           — partial sums of the gradient w.r.t. the LayerNorm output (sum them with vitae_layernorm_bwd_slabs).
+ * All matrices bf16, k-contiguous as nn.Linear stores them; token rows padded to Mpad (multiple of 64), pad rows of the
+ * inputs zero, pad rows of act16 / dh16 / hpre16 written as zeros.  d in {512, 768, 1024}, H % 128 == 0. */
+int vitae_mlp_fused_supported(int d, int H);
+int vitae_mlp_fused_slabs(int H);
+/* profiling hook (tools/mlp_fused_probe.py): with a device buffer of 8 long long per workgroup set, the following launches
+ * record shader-clock stamps at their phase boundaries; NULL switches it off */
+int vitae_mlp_fused_set_debug(void* buf);
+int vitae_mlp_fused_fwd(const void* y16, const void* w1_16, const float* b1, const void* w2_16, void* hpre16, void* act16,
+                        float* slabs, int M, int Mpad, int d, int H, void* stream);
+int vitae_mlp_fused_bwd(const void* dxo16, const void* w1_16, const void* w2_16, const void* hpre16, void* dh16,
+                        float* slabs, int M, int Mpad, int d, int H, void* stream);
+/* Weight gradients of up to four Linears in ONE launch, off the critical path of the backward: for i < n,
+ * dw[i][N[i], K[i]] (+)= dy16[i][Mpad, N[i]]^T x16[i][Mpad, K[i]]; optional bf16 copy dw16[i] (NULL array or NULL entries);
+ * optional dy_colsum[i][N[i]] += column sums of dy16[i] (the bias gradient).  The pointer arrays and N / K live on the HOST. */
+int vitae_wgrad_group_glds(int n, const void* const* dy16, const void* const* x16, float* const* dw, void* const* dw16,
+                           float* const* dy_colsum, const int* N, const int* K, int Mpad, int dw_accumulate, void* stream);
 
 /* ---- attention core  softmax(q k^T / sqrt(hd)) v  (model/vit.py:117-121) -------------------------
  * qkv [B,N,3,H,hd] (output of the qkv Linear, model/vit.py:114), o [B,N,H*hd], lse/delta [B,H,N]. */

@@ -89,7 +89,7 @@ class _Lib:
     def __getattr__(self, name):
         dll = self.load()
         fn = getattr(dll, name)
-        if PROTOS[name][0] != 'int' or name == 'vitae_abi_version' or name.endswith('pick_split_k'):
+        if PROTOS[name][0] != 'int' or name in _VALUE_RETURNING or name.endswith('pick_split_k'):
             return fn
 
         def checked(*args):
@@ -102,6 +102,9 @@ class _Lib:
         setattr(self, name, checked)
         return checked
 
+
+# int-returning entry points whose result is a value, not a status
+_VALUE_RETURNING = {'vitae_abi_version', 'vitae_mlp_fused_supported', 'vitae_mlp_fused_slabs'}
 
 lib = _Lib()
 

@@ -18,15 +18,12 @@
 // pads token counts of its bf16 activation buffers to 64 with zero rows for the wgrad reductions.
 #include <cstdlib>
 #include "common.hpp"
+#include "glds_tiles.hpp"
 #include "vitae_hip.h"
 
 namespace {
 
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-#ifndef VITAE_GLDS_NS
-#define VITAE_GLDS_NS 3
-#endif
-constexpr int BK = 64, NS = VITAE_GLDS_NS;
+using namespace vglds;
 
 struct GArgs {
     const __bf16* A; long lda;
@@ -54,8 +51,6 @@ struct GArgs {
 inline int glds_blocks(const GArgs& p) {
     return p.xcd_m ? 8 * cdiv(p.tiles_m, 8) * p.tiles_n : 8 * cdiv(p.tiles_n, 8) * p.tiles_m;
 }
-
-__device__ __forceinline__ int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
 // Epilogue of one 32x32 accumulator fragment: column n, rows mbase + crow(r, hi).  The reads the epilogue needs
 // (aux / residual / old C) are issued eight rows at a time, from clamped addresses, BEFORE the dependent stores, so
@@ -208,71 +203,6 @@ __device__ __forceinline__ void epilogue_rows(const GArgs& p, const float (&a)[N
     }
 }
 
-// XOR applied to a line's 16-byte chunk index (by the DMA through the SOURCE address, by the fragment reads directly).
-// The hardware serves a wave's LDS read in phases of 256 B, so the lanes of one phase must cover all 64 banks once:
-//   * k-contiguous tile (128-B lines, ds_read_b128, a phase = 16 lanes = 16 consecutive rows of one chunk column):
-//     rows of equal parity share their 32 banks, so the 8 such rows of a phase need 8 different slots -> (line >> 1) & 7
-//     (the earlier `line & 7` repeated every 8 rows: 2-way conflicts, 50 % of the LDS cycles by SQ_LDS_BANK_CONFLICT);
-//   * row-contiguous tile read with ds_read_b64_tr_b16 (a phase = 32 lanes = 4 consecutive k lines x 64 contiguous
-//     bytes): 128-B lines -> lines k, k + 2 share banks, flip the 64-byte half with bit 1 of k; 256-B lines -> all four
-//     lines share the 64 banks, give each its own 64-byte quarter, (k & 3) << 2.
-template <bool KC, int LINE_CH> __device__ __forceinline__ int swz(int line) {
-    if (KC) return (line >> 1) & 7;
-    return LINE_CH == 8 ? ((line >> 1) & 1) << 2 : (line & 3) << 2;
-}
-
-// Issue the LDS-DMA of one operand tile (ROWS rows x 64 k, bf16) into `lds` (byte address, tile base).
-// KC tile image: [row][8 chunks]; !KC image: [k][ROWS/8 chunks]; chunk slot = chunk ^ (line & 7).
-template <int ROWS, bool KC, int NW>
-__device__ __forceinline__ void dma_tile(const __bf16* __restrict__ P, long ld, int rows, int r0, int k0,
-                                         unsigned char* lds, int wave, int lane) {
-    constexpr int LINES = KC ? ROWS : BK;                 // LDS lines (each LINE_CH chunks of 16 B)
-    constexpr int LINE_CH = KC ? BK / 8 : ROWS / 8;       // 8 (128 B) or 16 (256 B)
-    constexpr int LPI = 64 / LINE_CH;                     // lines per wave-instruction (1 KB)
-    constexpr int NI = LINES / LPI / NW;                  // instructions per wave
-    static_assert(NI >= 1, "tile too small for this many waves");
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int inst = wave * NI + j;
-        const int line = inst * LPI + lane / LINE_CH;
-        const int slot = lane % LINE_CH;
-        const int chunk = slot ^ swz<KC, LINE_CH>(line);
-        long off;
-        if (KC) {
-            const int gr = min(r0 + line, rows - 1);      // rows past the operand: any valid row (never stored)
-            off = (long)gr * ld + k0 + chunk * 8;
-        } else {
-            const int gr = min(r0 + chunk * 8, rows - 8);
-            off = (long)(k0 + line) * ld + gr;
-        }
-        __builtin_amdgcn_global_load_lds(P + off, (__attribute__((address_space(3))) void*)(lds + inst * 1024), 16, 0, 0);
-    }
-}
-
-// MFMA operand fragment (32 rows x 16 k): rows row0 + (lane & 31), k-slots kk*16 + 8*hi + e
-template <int ROWS, bool KC>
-__device__ __forceinline__ bf16x8 frag(const unsigned char* T, int row0, int kk, int lane) {
-    if (KC) {
-        const int r = row0 + (lane & 31), c = 2 * kk + (lane >> 5);
-        return *reinterpret_cast<const bf16x8*>(T + r * 128 + ((c ^ swz<true, 8>(r)) << 4));
-    } else {
-        constexpr int LB = ROWS * 2;
-        const int gg = lane >> 4, li = lane & 15;
-        const int k = kk * 16 + 8 * (gg >> 1) + (li >> 2);
-        const int col = row0 + 16 * (gg & 1) + 4 * (li & 3);
-        const int c = col >> 3, w = (col & 7) * 2;
-        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-        union { s16x4 s[2]; bf16x8 b; } u;
-        u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(T + k * LB + ((c ^ swz<false, ROWS / 8>(k)) << 4) + w));
-        u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(T + (k + 4) * LB + ((c ^ swz<false, ROWS / 8>(k + 4)) << 4) + w));
-        return u.b;
-    }
-}
-
-template <int N> __device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
 // Workgroup tile BM x BN (64x64, 64x128 or 128x128), four waves in a 2 x 2 arrangement: each wave owns
 // (BM/2) x (BN/2) = FM x FN accumulator fragments of 32x32.  128x128 doubles the flop per LDS byte and per L2 byte
 // (64 flop/B from L2 instead of 32) and is picked when a GEMM has enough such tiles to fill the chip.
@@ -374,6 +304,16 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
         }
         // all fragment reads of the tile are issued before the first MFMA (hipcc otherwise recycles three fragment
         // registers and waits for a fresh LDS read in front of every MFMA: one LDS latency per MFMA)
+        if constexpr (!A_KC || !B_KC) {     // transposing reads are inline asm (glds_tiles.hpp): order them by hand
+            frags_ready();
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+#pragma unroll
+                for (int f = 0; f < FM; ++f) frag_tie(fa[kk][f]);
+#pragma unroll
+                for (int f = 0; f < FN; ++f) frag_tie(fb[kk][f]);
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk)
@@ -481,6 +421,21 @@ __global__ __launch_bounds__(256) void gemm_glds_pair_kernel(const GArgs p1, con
     // nb1 = workgroups of one dgrad split; the dgrad's long reduction (N of the Linear) is cut into p1.splits
     if ((int)blockIdx.x < nb1 * p1.splits) gemm_glds_body<BM1, BN1, true, false, 4, false, true>(p1, blockIdx.x % nb1, blockIdx.x / nb1, smem);
     else gemm_glds_body<BM2, BN2, false, false, 4, RS, true>(p2, blockIdx.x - nb1 * p1.splits, 0, smem);
+}
+
+// Up to four independent wgrad problems dW_i[N_i, K_i] (+)= dy_i^T x_i (64x64 tiles, both operands row-contiguous, reduced over
+// the padded token count) in ONE launch: the weight gradients of a transformer block are off the critical path of the backward
+// (nothing reads them before the optimiser), so the engine defers them to a side stream and issues them as one fat launch per
+// block instead of pairing each with its dgrad.  Block ranges start at multiples of 8, so the XCD mapping of every problem holds.
+struct GGroup { GArgs p[4]; int start[5]; };
+
+__global__ __launch_bounds__(256) void gemm_glds_group_kernel(const GGroup g) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[GCfg<64, 64, 4>::SMEM];
+    const int b = blockIdx.x;
+    if (b < g.start[1]) gemm_glds_body<64, 64, false, false, 4, true>(g.p[0], b, 0, smem);
+    else if (b < g.start[2]) gemm_glds_body<64, 64, false, false, 4, true>(g.p[1], b - g.start[1], 0, smem);
+    else if (b < g.start[3]) gemm_glds_body<64, 64, false, false, 4, true>(g.p[2], b - g.start[2], 0, smem);
+    else gemm_glds_body<64, 64, false, false, 4, true>(g.p[3], b - g.start[3], 0, smem);
 }
 
 template <int BM, int BN, int NW = 4>
@@ -680,5 +635,41 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
     if (dy_colsum_accum)
         hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(N, 256), cdiv(M, 32)), dim3(256), 0, st,
                            reinterpret_cast<const __bf16*>(dy16), dy_colsum_accum, M, N, 32);
+    return vitae_launch_status();
+}
+
+// Weight gradients of up to four Linears in one launch (see gemm_glds_group_kernel): for each i,
+// dw[i][N[i], K[i]] (+)= dy16[i][Mpad, N[i]]^T @ x16[i][Mpad, K[i]], optional bf16 copy dw16[i], optional
+// dy_colsum[i][N[i]] += column sums of dy16[i] (the bias gradient).  Rows M..Mpad-1 of every operand must be zero.
+extern "C" int vitae_wgrad_group_glds(int n, const void* const* dy16, const void* const* x16, float* const* dw, void* const* dw16,
+                                      float* const* dy_colsum, const int* N, const int* K, int Mpad, int dw_accumulate,
+                                      void* stream) {
+    if (n < 1 || n > 4 || !dy16 || !x16 || !dw || !N || !K || Mpad <= 0) return VITAE_ERR_INVALID_ARG;
+    if (Mpad % BK) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    GGroup g;
+    int total = 0;
+    for (int i = 0; i < 4; ++i) {
+        g.start[i] = total;
+        if (i >= n) { g.p[i] = g.p[0]; continue; }
+        if (!dy16[i] || !x16[i] || !dw[i] || N[i] <= 0 || K[i] <= 0) return VITAE_ERR_INVALID_ARG;
+        if ((N[i] & 7) || (K[i] & 7) || (long)N[i] * K[i] >= (1L << 31)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+        if (((uintptr_t)dy16[i] & 15) || ((uintptr_t)x16[i] & 15)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+        GArgs& p = g.p[i];
+        p.A = reinterpret_cast<const __bf16*>(dy16[i]); p.lda = N[i];
+        p.B = reinterpret_cast<const __bf16*>(x16[i]); p.ldb = K[i];
+        p.C = dw[i]; p.ldc = K[i];
+        p.C16 = reinterpret_cast<__bf16*>(dw16 ? dw16[i] : nullptr); p.ldc16 = K[i];
+        p.M = N[i]; p.N = K[i]; p.K = Mpad; p.k_per_split = Mpad; p.splits = 1;
+        p.bias = nullptr; p.residual = nullptr; p.ldr = 0; p.aux = nullptr; p.ldaux = 0; p.epi = VITAE_EPI_NONE;
+        p.accumulate = dw_accumulate; p.ws = nullptr; p.out_colsum = nullptr;
+        p.a_rowsum = dy_colsum ? dy_colsum[i] : nullptr;
+        p.tiles_m = cdiv(N[i], 64); p.tiles_n = cdiv(K[i], 64);
+        p.xcd_m = xcd_by_rows(N[i], K[i]);
+        p.vec_epi = vec_epilogue_ok(p);
+        total += glds_blocks(p);
+    }
+    g.start[4] = total;
+    for (int i = n; i < 4; ++i) g.start[i] = total;      // unused slots: empty ranges
+    hipLaunchKernelGGL(gemm_glds_group_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, g);
     return vitae_launch_status();
 }

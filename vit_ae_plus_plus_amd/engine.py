@@ -122,6 +122,13 @@ class HipMAEEngine:
         dims = (D, Dd, self.Hm, self.Hmd, cfg.patch_dim)
         self.act16 = (self.prec == PREC['bf16'] and all(v % 64 == 0 for v in dims)
                       and self.hd in (32, 64) and self.hdd in (32, 64))
+        # fused MLP launches (csrc/mlp_fused.hip) + weight gradients deferred to one grouped launch per block on a side
+        # stream: fewer and shorter kernels on the dependent chain; both stacks must be eligible
+        # (measured round 2, B = 4: the fused chain is NOT faster than the paired launches — 5.2-5.35 vs 4.86 ms/step — so it is
+        # opt-in: VITAE_FUSE_MLP=1; DESIGN.md §3c has the numbers and the reason: the per-CU texture-addresser rate)
+        self.fuse_mlp = (self.act16 and os.environ.get('VITAE_FUSE_MLP', '0') != '0'
+                         and bool(lib.vitae_mlp_fused_supported(D, self.Hm)) and bool(lib.vitae_mlp_fused_supported(Dd, self.Hmd)))
+        self.wgrad_side = os.environ.get('VITAE_WGRAD_SIDE', '1') != '0'
         self.buffers = buffers   # pos_embed, decoder_pos_embed, BN running stats (device tensors)
         f32 = dict(dtype=torch.float32, device=device)
         # ring of pinned staging buffers: the host may run a few steps ahead of the stream, so the
@@ -257,7 +264,8 @@ class HipMAEEngine:
                 b[q + 'y1'], b[q + 'mean1'], b[q + 'rstd1'] = f(M, d), f(M), f(M)
                 b[q + 'qkv'], b[q + 'o'] = f(M, 3 * d), f(M, d)
                 b[q + 'xmid'], b[q + 'y2'], b[q + 'mean2'], b[q + 'rstd2'] = f(M, d), f(M, d), f(M), f(M)
-                b[q + 'hpre'], b[q + 'act'] = f(M, h), f(M, h)
+                if not self.fuse_mlp:     # the fused MLP keeps its pre-activation / activation in bf16 only
+                    b[q + 'hpre'], b[q + 'act'] = f(M, h), f(M, h)
             b[pre + 'dx'], b[pre + 'dy'], b[pre + 'do'] = f(M, d), f(M, d), f(M, d)
             b[pre + 'dh'], b[pre + 'dqkv'] = f(M, h), f(M, 3 * d)
 
@@ -273,6 +281,13 @@ class HipMAEEngine:
                     q = f'{pre}{i}.'
                     b[q + 'y1_16'], b[q + 'o_16'], b[q + 'y2_16'], b[q + 'act_16'] = z16(Mp, d), z16(Mp, d), z16(Mp, d), z16(Mp, h)
                 b[pre + 'dx_16'], b[pre + 'dh_16'], b[pre + 'dqkv_16'] = z16(Mp, d), z16(Mp, h), z16(Mp, 3 * d)
+                if self.fuse_mlp:
+                    # per block: the four dy operands of its (deferred) weight gradients + the saved fc1 pre-activation
+                    for i in range(depth):
+                        q = f'{pre}{i}.'
+                        b[q + 'gout_16'], b[q + 'gmid_16'] = z16(Mp, d), z16(Mp, d)
+                        b[q + 'dh_16'], b[q + 'dqkv_16'], b[q + 'hpre_16'] = z16(Mp, h), z16(Mp, 3 * d), z16(Mp, h)
+                    b[pre + 'slabs'] = torch.empty(lib.vitae_mlp_fused_slabs(h), Mp, d, dtype=torch.float32, device=dev)
             b['dn_16'] = z16(self.Mpd, Dd)
             b['dpred_16'] = z16(self.Mpd, P)
             b['patches_16'], b['dtok_16'] = z16(self.Mpt, P), z16(self.Mpt, D)
@@ -537,6 +552,100 @@ class HipMAEEngine:
         if t is not None:
             t.record()
 
+    # ------------------------------------------------------------------ fused-MLP block chain (csrc/mlp_fused.hip)
+    def _ln_fwd_slabs(self, s, res, bias, pre, x_out, mean, rstd, M, D, y16, y=None):
+        """x_out = res + bias + sum of the stack's MLP slabs; y16 (and y) = LayerNorm(x_out)."""
+        sl = self.buf[s + 'slabs']
+        lib.vitae_layernorm_fwd_slabs(sl.data_ptr(), sl.shape[0], sl.stride(0), _ptr(res), _ptr(bias), _ptr(self.p[pre + 'weight']),
+                                      _ptr(self.p[pre + 'bias']), _ptr(x_out), _ptr(y), _ptr(y16), _ptr(mean), _ptr(rstd), M, D,
+                                      self.cfg.ln_eps, self.stream)
+
+    def _g16_dgrad(self, dy16, w, M, N, K, dx=None, dx16=None, epi=EPI_NONE, aux=None, dx_colsum=None, accumulate=0):
+        """dx / dx16 [M, K] = epi(dy16[M, N] @ W16[N, K]) on the LDS-DMA GEMM (dgrad only: the weight gradient is deferred)."""
+        key = ('d', M, N, K)
+        sp = self._split_cache.get(key)
+        if sp is None:
+            sp = lib.vitae_gemm_glds_pick_split_k(M, K, N)
+            while sp > 1 and lib.vitae_gemm_glds_ws_floats(M, K, sp) > self.ws16.numel():
+                sp -= 1
+            self._split_cache[key] = sp
+        t = self._timed(2.0 * M * N * K, 'glds_dgrad')
+        lib.vitae_gemm_glds(1, 0, _ptr(dy16), N, self._w16(w), K, _ptr(dx), K, _ptr(dx16), K, M, K, N, None, None, 0, epi, _ptr(aux), K,
+                            int(accumulate), sp, self.ws16.data_ptr(), _ptr(dx_colsum), self.stream)
+        if t is not None:
+            t.record()
+
+    def _wgrad_group(self, items, Mp):
+        """Weight gradients of up to four Linears as ONE launch; items = [(dy16, x16, dw, dbias | None, N, K)].  They are off
+        the critical path (nothing reads dW before the optimiser), so the launch goes to the wgrad side stream and is joined
+        at the end of the backward phase (``_wg_join``)."""
+        n = len(items)
+        arr = lambda vals: np.array(list(vals) + [0] * (4 - n), dtype=np.uint64)
+        dy = arr(t[0].data_ptr() for t in items)
+        x = arr(t[1].data_ptr() for t in items)
+        dw = arr(t[2].data_ptr() for t in items)
+        w16 = arr((self._wire_of(t[2]) or 0) for t in items)
+        db = arr((0 if t[3] is None else t[3].data_ptr()) for t in items)
+        N = np.array([t[4] for t in items] + [0] * (4 - n), dtype=np.int32)
+        K = np.array([t[5] for t in items] + [0] * (4 - n), dtype=np.int32)
+        side = self.wgrad_side and self.gemm_timer is None
+        if side:
+            self.wside.wait_stream(torch.cuda.current_stream(self.device))
+            stream = self.wside.cuda_stream
+        else:
+            stream = self.stream
+        t = self._timed(sum(2.0 * Mp * it[4] * it[5] for it in items), 'glds_wgrad_group')
+        lib.vitae_wgrad_group_glds(n, dy.ctypes.data, x.ctypes.data, dw.ctypes.data, w16.ctypes.data, db.ctypes.data,
+                                   N.ctypes.data, K.ctypes.data, Mp, int(self._accum), stream)
+        if t is not None:
+            t.record()
+        if side:
+            self._wg_pending.add('group')
+
+    def _block_fwd_fused(self, pre, q, s, prev, x_in, Bs, N, d, heads, hd, hid, Mp):
+        """model/vit.py:139-144 as 6 launches.  ``prev`` = (state-dict prefix, workspace prefix) of the block below, whose MLP
+        result still sits in the stack's slabs: this block's first LayerNorm sums them into ``x_in`` (the launch-boundary
+        reduce); None for the first block of a stack (``x_in`` is final)."""
+        b, p, M = self.buf, self.p, Bs * N
+        if prev is None:
+            self._ln_fwd(x_in, pre + 'norm1.', None, b[q + 'mean1'], b[q + 'rstd1'], M, d, y16=b[q + 'y1_16'])
+        else:
+            self._ln_fwd_slabs(s, b[prev[1] + 'xmid'], p[prev[0] + 'mlp.fc2.bias'], pre + 'norm1.', x_in, b[q + 'mean1'],
+                               b[q + 'rstd1'], M, d, b[q + 'y1_16'])
+        self._g16_fwd(b[q + 'y1_16'], p[pre + 'attn.qkv.weight'], p[pre + 'attn.qkv.bias'], M, 3 * d, d, y=b[q + 'qkv'])
+        lib.vitae_sdpa_mfma_fwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(b[q + 'o_16']), _ptr(b[q + 'lse']), Bs, N, heads, hd,
+                                self.stream)
+        self._g16_fwd(b[q + 'o_16'], p[pre + 'attn.proj.weight'], p[pre + 'attn.proj.bias'], M, d, d, y=b[q + 'xmid'], res=x_in)
+        self._ln_fwd(b[q + 'xmid'], pre + 'norm2.', None, b[q + 'mean2'], b[q + 'rstd2'], M, d, y16=b[q + 'y2_16'])
+        lib.vitae_mlp_fused_fwd(_ptr(b[q + 'y2_16']), self._w16(p[pre + 'mlp.fc1.weight']), _ptr(p[pre + 'mlp.fc1.bias']),
+                                self._w16(p[pre + 'mlp.fc2.weight']), _ptr(b[q + 'hpre_16']), _ptr(b[q + 'act_16']),
+                                _ptr(b[s + 'slabs']), M, Mp, d, hid, self.stream)
+
+    def _block_bwd_fused(self, pre, q, s, x_in, Bs, N, d, heads, hd, hid, Mp, prev_q, prev_fc2_bias):
+        """Backward of one block, 7 launches on the chain + one grouped weight-gradient launch beside it.  On entry
+        buf[s+'dx'] (fp32) and buf[q+'gout_16'] hold the gradient of the block's output; the gradient of its input leaves in
+        buf[s+'dx'] and, in bf16, in the block below's ``gout_16`` (``prev_q``)."""
+        b, p, g, M = self.buf, self.p, self.g, Bs * N
+        dx, dy, do, dqkv = b[s + 'dx'], b[s + 'dy'], b[s + 'do'], b[s + 'dqkv']
+        sl = b[s + 'slabs']
+        lib.vitae_mlp_fused_bwd(_ptr(b[q + 'gout_16']), self._w16(p[pre + 'mlp.fc1.weight']), self._w16(p[pre + 'mlp.fc2.weight']),
+                                _ptr(b[q + 'hpre_16']), _ptr(b[q + 'dh_16']), _ptr(sl), M, Mp, d, hid, self.stream)
+        lib.vitae_layernorm_bwd_slabs(sl.data_ptr(), sl.shape[0], sl.stride(0), _ptr(b[q + 'xmid']), _ptr(p[pre + 'norm2.weight']),
+                                      _ptr(b[q + 'mean2']), _ptr(b[q + 'rstd2']), _ptr(dx), _ptr(g[pre + 'norm2.weight']),
+                                      _ptr(g[pre + 'norm2.bias']), _ptr(b[q + 'gmid_16']), _ptr(g[pre + 'attn.proj.bias']), M, d, 1,
+                                      self.stream)
+        self._g16_dgrad(b[q + 'gmid_16'], p[pre + 'attn.proj.weight'], M, d, d, dx=do)
+        lib.vitae_sdpa_mfma_bwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(do), _ptr(b[q + 'lse']), _ptr(dqkv), _ptr(b[q + 'dqkv_16']),
+                                None, _ptr(b['delta']), Bs, N, heads, hd, self.stream)
+        self._wgrad_group([
+            (b[q + 'gout_16'], b[q + 'act_16'], g[pre + 'mlp.fc2.weight'], None, d, hid),
+            (b[q + 'dh_16'], b[q + 'y2_16'], g[pre + 'mlp.fc1.weight'], g[pre + 'mlp.fc1.bias'], hid, d),
+            (b[q + 'gmid_16'], b[q + 'o_16'], g[pre + 'attn.proj.weight'], None, d, d),
+            (b[q + 'dqkv_16'], b[q + 'y1_16'], g[pre + 'attn.qkv.weight'], g[pre + 'attn.qkv.bias'], 3 * d, d)], Mp)
+        self._g16_dgrad(b[q + 'dqkv_16'], p[pre + 'attn.qkv.weight'], M, 3 * d, d, dx=dy)
+        self._ln_bwd(dy, x_in, pre + 'norm1.', b[q + 'mean1'], b[q + 'rstd1'], dx, M, d, 1,
+                     dx16=b[prev_q + 'gout_16'] if prev_q is not None else None, dx_colsum=prev_fc2_bias)
+
     # ------------------------------------------------------------------ transformer block
     def _block_fwd16(self, pre, q, x_in, x_out, Bs, N, d, heads, hd, hid):
         """model/vit.py:139-144 with bf16 GEMM operands written by their producers."""
@@ -670,9 +779,17 @@ class HipMAEEngine:
         ex = b['encx']
         lib.vitae_encoder_assemble_fwd(_ptr(b['tok']), _ptr(p['cls_token']), _ptr(self.buffers['pos_embed']),
                                        _ptr(b['ids_shuffle']), _ptr(ex[0]), Be, L, keep, D, st)
-        for i in range(cfg.depth):
-            self._block_fwd(f'blocks.{i}.', f'enc{i}.', ex[i], ex[i + 1], Be, Ne, D, cfg.num_heads, self.hd, self.Hm)
-        self._ln_fwd(ex[cfg.depth], 'norm.', b['latent'], b['lat_mean'], b['lat_rstd'], Me, D, y16=b.get('latent_16'))
+        if self.fuse_mlp:
+            for i in range(cfg.depth):
+                self._block_fwd_fused(f'blocks.{i}.', f'enc{i}.', 'enc', (f'blocks.{i - 1}.', f'enc{i - 1}.') if i else None, ex[i],
+                                      Be, Ne, D, cfg.num_heads, self.hd, self.Hm, self.Mpe)
+            last = cfg.depth - 1
+            self._ln_fwd_slabs('enc', b[f'enc{last}.xmid'], p[f'blocks.{last}.mlp.fc2.bias'], 'norm.', ex[cfg.depth], b['lat_mean'],
+                               b['lat_rstd'], Me, D, b['latent_16'], y=b['latent'])
+        else:
+            for i in range(cfg.depth):
+                self._block_fwd(f'blocks.{i}.', f'enc{i}.', ex[i], ex[i + 1], Be, Ne, D, cfg.num_heads, self.hd, self.Hm)
+            self._ln_fwd(ex[cfg.depth], 'norm.', b['latent'], b['lat_mean'], b['lat_rstd'], Me, D, y16=b.get('latent_16'))
         if cfg.contrastive and self.overlap_predictor:
             # the predictor branch only needs the latent: it runs on its own stream beside the decoder and the loss chain
             self.pside.wait_stream(torch.cuda.current_stream(self.device))
@@ -687,11 +804,21 @@ class HipMAEEngine:
         dx_ = b['decx']
         lib.vitae_decoder_assemble_fwd(_ptr(b['e']), _ptr(p['mask_token']), _ptr(self.buffers['decoder_pos_embed']),
                                        _ptr(b['ids_restore']), _ptr(dx_[0]), B, L, keep, Dd, st)
-        for i in range(cfg.decoder_depth):
-            self._block_fwd(f'decoder_blocks.{i}.', f'dec{i}.', dx_[i], dx_[i + 1], B, Nd, Dd, cfg.decoder_num_heads,
-                            self.hdd, self.Hmd)
+        if self.fuse_mlp:
+            for i in range(cfg.decoder_depth):
+                self._block_fwd_fused(f'decoder_blocks.{i}.', f'dec{i}.', 'dec',
+                                      (f'decoder_blocks.{i - 1}.', f'dec{i - 1}.') if i else None, dx_[i], B, Nd, Dd,
+                                      cfg.decoder_num_heads, self.hdd, self.Hmd, self.Mpd)
+            last = cfg.decoder_depth - 1
+            self._ln_fwd_slabs('dec', b[f'dec{last}.xmid'], p[f'decoder_blocks.{last}.mlp.fc2.bias'], 'decoder_norm.',
+                               dx_[cfg.decoder_depth], b['dn_mean'], b['dn_rstd'], Md, Dd, b['dn_16'])
+        else:
+            for i in range(cfg.decoder_depth):
+                self._block_fwd(f'decoder_blocks.{i}.', f'dec{i}.', dx_[i], dx_[i + 1], B, Nd, Dd, cfg.decoder_num_heads,
+                                self.hdd, self.Hmd)
         if a16:
-            self._ln_fwd(dx_[cfg.decoder_depth], 'decoder_norm.', None, b['dn_mean'], b['dn_rstd'], Md, Dd, y16=b['dn_16'])
+            if not self.fuse_mlp:
+                self._ln_fwd(dx_[cfg.decoder_depth], 'decoder_norm.', None, b['dn_mean'], b['dn_rstd'], Md, Dd, y16=b['dn_16'])
             self._g16_fwd(b['dn_16'], p['decoder_pred.weight'], p['decoder_pred.bias'], Md, P, Dd, y=b['predfull'])
         else:
             self._ln_fwd(dx_[cfg.decoder_depth], 'decoder_norm.', b['dn'], b['dn_mean'], b['dn_rstd'], Md, Dd)
@@ -786,10 +913,16 @@ class HipMAEEngine:
             self._g16_bwd(b['dpred_16'], p['decoder_pred.weight'], b['dn_16'], g['decoder_pred.weight'], Md, self.Mpd, P, Dd,
                           dx=b['ddn'])
             self._ln_bwd(b['ddn'], dx_[nd], 'decoder_norm.', b['dn_mean'], b['dn_rstd'], b['decdx'], Md, Dd, 0,
-                         dx16=b['decdx_16'], dx_colsum=g[f'decoder_blocks.{nd - 1}.mlp.fc2.bias'])
+                         dx16=b[f'dec{nd - 1}.gout_16'] if self.fuse_mlp else b['decdx_16'],
+                         dx_colsum=g[f'decoder_blocks.{nd - 1}.mlp.fc2.bias'])
             for i in reversed(range(nd)):
-                self._block_bwd16(f'decoder_blocks.{i}.', f'dec{i}.', 'dec', dx_[i], B, Nd, Dd, cfg.decoder_num_heads, self.hdd,
-                                  self.Hmd, self.Mpd, g[f'decoder_blocks.{i - 1}.mlp.fc2.bias'] if i > 0 else None)
+                if self.fuse_mlp:
+                    self._block_bwd_fused(f'decoder_blocks.{i}.', f'dec{i}.', 'dec', dx_[i], B, Nd, Dd, cfg.decoder_num_heads,
+                                          self.hdd, self.Hmd, self.Mpd, f'dec{i - 1}.' if i > 0 else None,
+                                          g[f'decoder_blocks.{i - 1}.mlp.fc2.bias'] if i > 0 else None)
+                else:
+                    self._block_bwd16(f'decoder_blocks.{i}.', f'dec{i}.', 'dec', dx_[i], B, Nd, Dd, cfg.decoder_num_heads, self.hdd,
+                                      self.Hmd, self.Mpd, g[f'decoder_blocks.{i - 1}.mlp.fc2.bias'] if i > 0 else None)
         else:
             self._lin_bwd(b['dpredfull'], p['decoder_pred.weight'], b['dn'], b['ddn'], g['decoder_pred.weight'],
                           g['decoder_pred.bias'], Md, P, Dd)
@@ -829,7 +962,8 @@ class HipMAEEngine:
             dec_embed_bwd(0)
         if a16:
             self._ln_bwd(b['dlatent'], b['encx'][cfg.depth], 'norm.', b['lat_mean'], b['lat_rstd'], b['encdx'], Me, D, 0,
-                         dx16=b['encdx_16'], dx_colsum=g[f'blocks.{cfg.depth - 1}.mlp.fc2.bias'])
+                         dx16=b[f'enc{cfg.depth - 1}.gout_16'] if self.fuse_mlp else b['encdx_16'],
+                         dx_colsum=g[f'blocks.{cfg.depth - 1}.mlp.fc2.bias'])
         else:
             self._ln_bwd(b['dlatent'], b['encx'][cfg.depth], 'norm.', b['lat_mean'], b['lat_rstd'], b['encdx'], Me, D, 0)
         self._wg_join()
@@ -854,7 +988,11 @@ class HipMAEEngine:
         self.stream = torch.cuda.current_stream(self.device).cuda_stream
         ex = self.buf['encx']
         for i in range(hi, lo - 1, -1):
-            if self.act16:
+            if self.fuse_mlp:
+                self._block_bwd_fused(f'blocks.{i}.', f'enc{i}.', 'enc', ex[i], self.Be, self.Ne, cfg.embed_dim, cfg.num_heads,
+                                      self.hd, self.Hm, self.Mpe, f'enc{i - 1}.' if i > 0 else None,
+                                      self.g[f'blocks.{i - 1}.mlp.fc2.bias'] if i > 0 else None)
+            elif self.act16:
                 self._block_bwd16(f'blocks.{i}.', f'enc{i}.', 'enc', ex[i], self.Be, self.Ne, cfg.embed_dim, cfg.num_heads,
                                   self.hd, self.Hm, self.Mpe, self.g[f'blocks.{i - 1}.mlp.fc2.bias'] if i > 0 else None)
             else:
