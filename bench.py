@@ -1,6 +1,6 @@
 """Headline benchmark: pre-training volumes/sec of the ViT-B/16^3 (contrastive) MAE step on MI355X.
 
-    python bench.py --gpus 1 --steps 30 --warmup 10
+    python bench.py --gpus N --steps K --warmup W            (N > 1 without a launcher: spawns N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -8,15 +8,20 @@ A "step" = one full optimisation step of BASELINE config 2 (ViT-B/16^3 autoenc a
 scripts train it, i.e. ``contr_mae_vit_base_patch16``; synthetic BraTS-shape 96^3 x 4ch volumes,
 batch 4 per GPU, mask 0.75): forward (both views) + loss chain + backward + global grad norm +
 AdamW, with the gradient all-reduce over RCCL at N > 1.  Inputs are resident in HBM before the timed
-region.  Rank 0 prints ONE JSON line (contract in the task statement) carrying ``roofline`` (the
-GEMM kernel family, timed with HIP events on the launch stream in instrumented steps right after
-the timed region) and, at N = 1, ``cpu_baseline`` (the oracle's CPU step on the same workload).
+region.  Weights come from the product's own ``initialize_weights`` (seed 0); the same state dict is
+handed to the CPU oracle for the ``cpu_baseline`` / ``parity`` legs, the only place ``oracle/`` is
+imported.  Rank 0 prints ONE JSON line (contract in the task statement) carrying ``roofline`` (the
+GEMM kernel the step spends most time in, timed with HIP events on the launch stream in
+instrumented steps right after the timed region; plus ``encoder_attn_mlp_b8``, the north-star
+sub-total at batch 8) and, at N = 1, ``cpu_baseline``.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,13 +35,21 @@ if ROOT not in sys.path:
 VOL, CH, PATCH = 96, 4, 16
 PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
 ALGO_GFLOP_PER_VOL = {'contr': 136.3, 'mae': 90.8}   # BASELINE.md §4 (fwd+bwd, reference formulation)
+ENC_ATTN_MLP_GFLOP_PER_VOL = 9.45 * 3                # encoder blocks fwd+bwd, one view per volume
+KNAMES = {'glds_pair': 'gemm_glds_pair_kernel<64,64,64,64> (csrc/gemm_glds.hip: dgrad + wgrad of one Linear per launch)',
+          'glds': 'gemm_glds_kernel<64,64,..> (csrc/gemm_glds.hip)',
+          'glds_wide': 'gemm_glds_kernel<64,128,..> (csrc/gemm_glds.hip)',
+          'glds_pair_wide': 'gemm_glds_pair_kernel<..,64,128> (csrc/gemm_glds.hip)',
+          'glds_dgrad': 'gemm_glds_kernel<64,64,true,false> (csrc/gemm_glds.hip: dgrad of one Linear)',
+          'glds_wgrad_group': 'gemm_glds_group_kernel (csrc/gemm_glds.hip: the four weight gradients of a block in one launch)',
+          'attn': 'attn_fwd_mfma_kernel / attn_bwd_fused_kernel (csrc/attention_mfma.hip)'}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=30)
-    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--batch', type=int, default=4, help='volumes per GPU per step (BASELINE config 2: 4)')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--model', default='contr', choices=['contr', 'mae'])
@@ -44,12 +57,47 @@ def parse():
     ap.add_argument('--grad-comm', default=None, choices=['fp32', 'bf16'],
                     help='wire dtype of the gradient all-reduce at >1 GPU (default: the compute precision)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-extra', action='store_true', help='skip the secondary plain-MAE data point')
-    ap.add_argument('--cpu-steps', type=int, default=2)
+    ap.add_argument('--no-extra', action='store_true', help='skip the secondary data points (plain MAE, batch 8 / 32, fp32 mode)')
+    ap.add_argument('--cpu-steps', type=int, default=3)
     ap.add_argument('--profile-steps', type=int, default=3, help='instrumented steps for the roofline block')
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
+# ----------------------------------------------------------------------------- ranks
+def spawn_command(args, argv, n_visible, port):
+    """The torch.distributed.run command `python bench.py --gpus N` re-executes itself under when no launcher is around it
+    (one process per GPU over RCCL), or None when this process is already a rank / N == 1.  Raises SystemExit when fewer
+    than N GPUs are visible: a dp-N number from fewer ranks would be a lie."""
+    if args.gpus <= 1 or 'WORLD_SIZE' in os.environ:
+        return None
+    if n_visible < args.gpus:
+        raise SystemExit(f'bench.py --gpus {args.gpus}: only {n_visible} GPU(s) visible on this node; refusing to report a '
+                         f'{args.gpus}-GPU number from fewer ranks')
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def rank_layout(args, env=None):
+    """-> (world, rank, local).  The number of ranks RCCL will see must be the number asked for."""
+    env = os.environ if env is None else env
+    world = int(env.get('WORLD_SIZE', '1'))
+    rank = int(env.get('RANK', '0'))
+    local = int(env.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'bench.py --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU '
+                         f'(torch.distributed.run --nproc-per-node {args.gpus}) or drop the launcher')
+    return world, rank, local
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+# ----------------------------------------------------------------------------- data / model
 def synthetic_batches(batch, rank, n_batches=4):
     """view2 ~ N(0,1), view1 = z-score(view2 + 0.1 N(0,1)); CPU generator 1234+rank."""
     out = []
@@ -61,6 +109,156 @@ def synthetic_batches(batch, rank, n_batches=4):
         v1 = (v1 - v1.mean(dim=dims, keepdim=True)) / v1.std(dim=dims, keepdim=True)
         out.append((v1.contiguous(), v2.contiguous()))
     return out
+
+
+def masking_noise(batch, num_patches, seed):
+    """two independent U[0,1) [B, L] noises from a CPU generator (the torch.rand of vit_autoenc.py:139, one per view)"""
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    return [torch.rand(batch, num_patches, generator=g) for _ in range(2)]
+
+
+def build_model(kind, precision, dev, seed=0):
+    """The product's own constructor + initialize_weights under a fixed seed; returns (model, cpu state dict, engine)."""
+    from vit_ae_plus_plus_amd.model import vit_autoenc as VA
+    from vit_ae_plus_plus_amd.optim import FusedAdamW
+    torch.manual_seed(seed)
+    margs = argparse.Namespace(use_imagenet=False, perceptual_weight=0)
+    ctor = VA.contr_mae_vit_base_patch16 if kind == 'contr' else VA.mae_vit_base_patch16
+    model = ctor(volume_size=VOL, in_chans=CH, patch_size=PATCH, args=margs, precision=precision)
+    sd_cpu = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(dev).train()
+    eng = model._ensure_engine(dev)
+    opt = FusedAdamW(model, lr=1e-4, weight_decay=0.05, betas=(0.9, 0.95))
+    _ = opt.engine
+    return model, sd_cpu, eng
+
+
+def device_batches(batch, dev, n=2, seed=77):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    out = []
+    for _ in range(n):
+        v2 = torch.randn(batch, CH, VOL, VOL, VOL, generator=g, device=dev)
+        v1 = v2 + 0.1 * torch.randn(batch, CH, VOL, VOL, VOL, generator=g, device=dev)
+        v1 = (v1 - v1.mean(dim=(2, 3, 4), keepdim=True)) / v1.std(dim=(2, 3, 4), keepdim=True)
+        out.append((v1.contiguous(), v2))
+    return out
+
+
+def run_steps(model, eng, batches, contr, batch, graph, warm, steps):
+    runner = model._step_runner(batch, 0.75, True, False, graph)
+    t0 = 0.0
+    for i in range(warm + steps):
+        if i == warm:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        v1, v2 = batches[i % len(batches)]
+        runner.load(v1, v2 if contr else None)
+        eng.optimizer_hparams(lr=1e-4)
+        runner.run()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+# ----------------------------------------------------------------------------- instrumentation
+def instrumented_steps(model, eng, batches, contr, batch, n_steps, dev, phases_only=False):
+    """Eager steps with HIP events (torch.cuda.Event on the launch stream = torch's current stream) around every GEMM /
+    attention launch.  A spin kernel is queued first so the host enqueues the whole step while the GPU is still busy: the
+    event deltas then contain no host-launch gaps.  -> ([(ms, flops, tag, scope, raw ms)], event-pair overhead in ms)"""
+    from vit_ae_plus_plus_amd._abi import lib as _lib
+    eager = model._step_runner(batch, 0.75, True, False, False)
+    recs = []
+    for i in range(n_steps):
+        v1, v2 = batches[i % len(batches)]
+        eager.load(v1, v2 if contr else None)
+        eng.optimizer_hparams(lr=1e-4)
+        torch.cuda._sleep(200_000_000)
+        eng.gemm_timer = []
+        if phases_only:   # N > 1: keep collectives matched — other ranks idle here, so time the phases locally only
+            for k in range(eng.N_PHASES - 1):
+                eager._phase(k)
+        else:
+            eager.run()
+        torch.cuda.synchronize()
+        recs += eng.gemm_timer
+        eng.gemm_timer = None
+    # calibration of the event pair itself: the same record / tiny kernel / record pattern behind a spin kernel.  A
+    # 16-byte fill runs for ~2 us (rocprofv3: the launch floor of this box); whatever the events report beyond that is
+    # command-processor time around the kernel, not kernel time, and is removed.
+    scratch = torch.zeros(64, device=dev)
+    torch.cuda._sleep(50_000_000)
+    cal = []
+    for _ in range(64):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        _lib.vitae_memset_zero(scratch.data_ptr(), 16, torch.cuda.current_stream(dev).cuda_stream)
+        b.record()
+        cal.append((a, b))
+    torch.cuda.synchronize()
+    null_ms = sorted(x.elapsed_time(y) for x, y in cal)[len(cal) // 2]
+    overhead = max(0.0, null_ms - 0.002)
+    out = []
+    for a, b, f, tag, scope in recs:
+        raw = a.elapsed_time(b)
+        out.append((max(raw - overhead, 0.25 * raw), f, tag, scope, raw))
+    return out, overhead
+
+
+def roofline_block(args, recs, overhead_ms, ms_step, world):
+    fam = {}
+    for ms, f, tag, scope, raw in recs:
+        if tag == 'attn':
+            continue
+        d = fam.setdefault(tag, [0.0, 0.0, 0, 0.0])
+        d[0] += ms; d[1] += f; d[2] += 1; d[3] += raw
+    n = args.profile_steps
+    tot_ms = sum(d[0] for d in fam.values())
+    tot_fl = sum(d[1] for d in fam.values())
+    dom = max(fam, key=lambda k: fam[k][0])          # the kernel the step spends most GEMM time in
+    d_ms, d_fl, d_n, d_raw = fam[dom]
+    ach = d_fl / (d_ms * 1e-3) / 1e12
+    peak = PEAK_TFLOPS[args.precision]
+    traffic, tnote = None, None   # PMC counters cannot be read in-process: last committed rocprofv3 --pmc result
+    for name in ('round2_gemm_traffic.json', 'round1_gemm_traffic.json'):
+        tfile = os.path.join(ROOT, 'profiles', name)
+        if args.precision == 'bf16' and args.batch == 4 and os.path.exists(tfile):
+            traffic = json.load(open(tfile)).get('bytes_per_launch', {}).get(dom)
+            tnote = f'HBM-side bytes per launch of that kernel (2*FETCH_SIZE + WRITE_SIZE, profiles/{name})'
+            if traffic is not None:
+                break
+    exe_gflop = tot_fl / n / 1e9        # GEMM flops the step actually executes (masked patches are not embedded)
+    ref_gflop = world * args.batch * ALGO_GFLOP_PER_VOL[args.model]
+    sec = ms_step * 1e-3
+    return {'bound': 'mfma', 'kernel': KNAMES.get(dom, dom), 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
+            'frac': round(ach / peak, 4), 'traffic': traffic, 'traffic_unit': tnote,
+            'launches_per_step': d_n / n, 'gflop_per_launch': round(d_fl / d_n / 1e9, 3), 'avg_launch_us': round(d_ms * 1e3 / d_n, 2),
+            'avg_launch_us_events_raw': round(d_raw * 1e3 / d_n, 2), 'event_pair_overhead_us': round(overhead_ms * 1e3, 2),
+            'gemm_family': {'launches_per_step': sum(d[2] for d in fam.values()) / n, 'gflop_per_step': round(exe_gflop, 2),
+                            'ms_per_step': round(tot_ms / n, 3), 'tflops': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
+                            'by_kernel_ms_per_step': {k: round(v[0] / n, 3) for k, v in fam.items()}},
+            # whole step against the MFMA peak, on the FLOPs it executes and on the reference formulation (which embeds
+            # the masked patches too: 136.3 vs 106.1 GFLOP per volume for the contrastive model)
+            'step_frac_of_peak_executed': round(exe_gflop * 1e9 / sec / 1e12 / peak, 4),
+            'step_frac_of_peak_reference_formulation': round(ref_gflop * 1e9 / sec / 1e12 / (peak * world), 4)}
+
+
+def encoder_attn_mlp_point(args, dev, model, eng, contr, batch=8):
+    """North-star sub-total: the encoder's attention + MLP kernels (qkv / proj / fc1 / fc2 GEMMs forward and backward and
+    the attention kernels of the 12 encoder blocks) at batch 8: executed FLOPs / sum of their HIP-event durations."""
+    batches = device_batches(batch, dev)
+    dt = run_steps(model, eng, batches, contr, batch, not args.no_graph, 2 * len(batches) + 2, 10)
+    recs, ov = instrumented_steps(model, eng, batches, contr, batch, 2, dev)
+    enc = [r for r in recs if r[3] == 'enc']
+    ms = sum(r[0] for r in enc) / 2
+    fl = sum(r[1] for r in enc) / 2
+    peak = PEAK_TFLOPS[args.precision]
+    views = 2 if contr else 1
+    return ({'batch': batch, 'value': round(batch / dt, 2), 'unit': 'volumes/s', 'ms_per_step': round(dt * 1e3, 3), 'steps': 10},
+            {'batch': batch, 'kernels': 'encoder blocks: qkv/proj/fc1/fc2 GEMMs fwd + dgrad/wgrad, attention fwd + bwd',
+             'launches_per_step': len(enc) / 2, 'gflop_executed': round(fl / 1e9, 1),
+             'gflop_reference_formulation_one_view': round(batch * ENC_ATTN_MLP_GFLOP_PER_VOL, 1), 'views': views,
+             'sum_kernel_ms': round(ms, 3), 'achieved': round(fl / (ms * 1e-3) / 1e12, 1), 'peak': peak, 'unit': 'TFLOP/s',
+             'frac': round(fl / (ms * 1e-3) / 1e12 / peak, 4), 'target_frac': 0.40,
+             'event_pair_overhead_us': round(ov * 1e3, 2)})
 
 
 def cpu_baseline(args, batches, sd_cpu, noises):
@@ -89,73 +287,28 @@ def cpu_baseline(args, batches, sd_cpu, noises):
                       f'fp32, torch {torch.__version__} CPU, after 1 warm-up step; {sec:.2f} s/step'}, first
 
 
-def big_batch_point(args, dev, model, eng, contr, big=32):
-    """Secondary data point: the headline model at batch 32 per GPU (what 288 GB of HBM is for).  The step stops being
-    launch-bound there; same kernels, same graph machinery, device-generated synthetic volumes of the same distribution."""
-    g = torch.Generator(device=dev).manual_seed(77)
-    batches = []
-    for _ in range(2):
-        v2 = torch.randn(big, CH, VOL, VOL, VOL, generator=g, device=dev)
-        v1 = v2 + 0.1 * torch.randn(big, CH, VOL, VOL, VOL, generator=g, device=dev)
-        v1 = (v1 - v1.mean(dim=(2, 3, 4), keepdim=True)) / v1.std(dim=(2, 3, 4), keepdim=True)
-        batches.append((v1.contiguous(), v2))
-    runner = model._step_runner(big, 0.75, True, False, not args.no_graph)
-    warm, steps = 2 * len(batches) + 2, 10
-    for i in range(warm + steps):
-        if i == warm:
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-        v1, v2 = batches[i % len(batches)]
-        runner.load(v1, v2 if contr else None)
-        eng.optimizer_hparams(lr=1e-4)
-        runner.run()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    gf = ALGO_GFLOP_PER_VOL[args.model] * big
-    return {'batch': big, 'value': round(big / dt, 2), 'unit': 'volumes/s', 'ms_per_step': round(dt * 1e3, 3), 'steps': steps,
-            'step_tflops': round(gf / dt / 1e3, 1)}
-
-
-def plain_mae_point(args, dev, batches):
-    """Secondary data point: the same step for the plain (non-contrastive) `mae_vit_base_patch16` — one view, 55-token
-    encoder.  BASELINE config 2 says "autoenc"; the reference's pre-training scripts train the contrastive model, which
-    is the headline workload here (two views per volume: strictly more work per volume)."""
-    from vit_ae_plus_plus_amd.model import vit_autoenc as VA
-    from vit_ae_plus_plus_amd.optim import FusedAdamW
-    from oracle import mae_ref as R
-    cfg = R.vit_base_cfg(volume_size=(VOL,) * 3, patch_size=PATCH, in_chans=CH, contrastive=False)
-    model = VA.mae_vit_base_patch16(volume_size=VOL, in_chans=CH, patch_size=PATCH,
-                                    args=argparse.Namespace(use_imagenet=False, perceptual_weight=0), precision=args.precision)
-    model.load_state_dict(R.init_state_dict(cfg, seed=0))
-    model = model.to(dev).train()
-    eng = model._ensure_engine(dev)
-    opt = FusedAdamW(model, lr=1e-4, weight_decay=0.05, betas=(0.9, 0.95))
-    _ = opt.engine
-    eng.set_loss_weights(0.01, 0.0, 1, 1)
-    runner = model._step_runner(args.batch, 0.75, True, False, not args.no_graph)
-    warm, steps = 2 * len(batches) + 2, 15      # each device batch gets its in-place graph on second sight: before the clock
-    for i in range(warm + steps):
-        if i == warm:
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-        runner.load(batches[i % len(batches)][0], None)
-        eng.optimizer_hparams(lr=1e-4)
-        runner.run()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    return {'model': 'mae_vit_base_patch16 (plain MAE, one view per volume)', 'value': round(args.batch / dt, 2),
-            'unit': 'volumes/s', 'ms_per_step': round(dt * 1e3, 3), 'steps': steps}
+def secondary_model_point(args, dev, kind, precision, batches, label):
+    """Another model / precision through the same step machinery (own instance, own graphs)."""
+    model, _, eng = build_model(kind, precision, dev)
+    eng.set_loss_weights(0.01, 0.001 if kind == 'contr' else 0.0, 1, 1)
+    dt = run_steps(model, eng, batches, kind == 'contr', args.batch, not args.no_graph, 2 * len(batches) + 2, 15)
+    return {'model': label, 'precision': precision, 'value': round(args.batch / dt, 2), 'unit': 'volumes/s',
+            'ms_per_step': round(dt * 1e3, 3), 'steps': 15}
 
 
 def main():
     args = parse()
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
+    cmd = spawn_command(args, sys.argv[1:], torch.cuda.device_count(), free_port())
+    if cmd is not None:
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        raise SystemExit(subprocess.call(cmd, env=env))
+    world, rank, local = rank_layout(args)
     if rank != 0:   # only rank 0 talks on stdout (the contract is ONE JSON line)
         sys.stdout = open(os.devnull, 'w')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (the HIP path has no CPU fallback)')
+    if torch.cuda.device_count() <= local:
+        raise SystemExit(f'rank {rank}: no GPU {local} on this node ({torch.cuda.device_count()} visible)')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     force_ddp = os.environ.get('VITAE_FORCE_DDP') == '1' and world == 1   # single-GPU check of the N>1 machinery
@@ -165,30 +318,18 @@ def main():
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=dev)
-
-    from vit_ae_plus_plus_amd.model import vit_autoenc as VA
-    from vit_ae_plus_plus_amd.optim import FusedAdamW
-    from oracle import mae_ref as R   # weights by state-dict from the oracle's seed-0 init
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     contr = args.model == 'contr'
-    cfg = R.vit_base_cfg(volume_size=(VOL,) * 3, patch_size=PATCH, in_chans=CH, contrastive=contr)
-    sd_cpu = R.init_state_dict(cfg, seed=0)
-    margs = argparse.Namespace(use_imagenet=False, perceptual_weight=0)
-    ctor = VA.contr_mae_vit_base_patch16 if contr else VA.mae_vit_base_patch16
-    model = ctor(volume_size=VOL, in_chans=CH, patch_size=PATCH, args=margs, precision=args.precision)
-    model.load_state_dict(sd_cpu)
-    model = model.to(dev).train()
-    eng = model._ensure_engine(dev)
-    opt = FusedAdamW(model, lr=1e-4, weight_decay=0.05, betas=(0.9, 0.95))
-    _ = opt.engine
+    model, sd_cpu, eng = build_model(args.model, args.precision, dev)
     grad_comm = args.grad_comm or args.precision
     model.enable_data_parallel(dev, force=force_ddp, comm_dtype=torch.bfloat16 if grad_comm == 'bf16' else None)
     eng.set_loss_weights(0.01, 0.001 if contr else 0.0, 1, world)
 
     cpu_batches = synthetic_batches(args.batch, rank)
     batches = [(a.to(dev), b.to(dev)) for a, b in cpu_batches]
-    L = cfg.num_patches
-    noises = [R.masking_noise(args.batch, L, seed=4321 + rank + i) for i in range(len(batches))]
+    L = eng.cfg.num_patches
+    noises = [masking_noise(args.batch, L, seed=4321 + rank + i) for i in range(len(batches))]
     runner = model._step_runner(args.batch, 0.75, True, False, not args.no_graph)
 
     def step(i):
@@ -228,95 +369,45 @@ def main():
     ms = elapsed / args.steps * 1e3
     value = world * args.batch * args.steps / elapsed
 
-    # ---- roofline of the dominant kernel (the MFMA GEMM kernels of csrc/gemm_glds.hip / gemm_bf16.hip / gemm.hip):
-    # instrumented eager steps right after the timed region, HIP events (torch.cuda.Event on the launch
-    # stream = torch's current stream) around every GEMM launch.  A spin kernel is queued first so the host
-    # enqueues the whole step while the GPU is still busy: event deltas then contain no host-launch gaps.
+    # ---- roofline of the dominant kernel (the MFMA GEMM kernels of csrc/gemm_glds.hip / gemm_bf16.hip / gemm.hip)
     roof = None
     if rank == 0 and args.profile_steps > 0:
-        eager = model._step_runner(args.batch, 0.75, True, False, False)
-        recs = []
-        for i in range(args.profile_steps):
-            v1, v2 = batches[i % len(batches)]
-            eager.load(v1, v2 if contr else None)
-            eng.optimizer_hparams(lr=1e-4)
-            torch.cuda._sleep(200_000_000)
-            eng.gemm_timer = []
-            if world > 1:   # keep collectives matched: other ranks idle here, so time phases locally only
-                for k in range(eng.N_PHASES - 1):
-                    eager._phase(k)
-            else:
-                eager.run()
-            torch.cuda.synchronize()
-            recs += eng.gemm_timer
-            eng.gemm_timer = None
-        # calibration of the event pair itself: the same record / tiny kernel / record pattern, queued behind a spin
-        # kernel like the steps.  A 16-byte fill runs for ~2 us (rocprofv3: the launch floor of this box); whatever the
-        # events report beyond that is command-processor time around the kernel, not kernel time, and is removed.
-        from vit_ae_plus_plus_amd._abi import lib as _lib
-        scratch = torch.zeros(64, device=dev)
-        torch.cuda._sleep(50_000_000)
-        cal = []
-        for _ in range(64):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            _lib.vitae_memset_zero(scratch.data_ptr(), 16, torch.cuda.current_stream(dev).cuda_stream)
-            b.record()
-            cal.append((a, b))
-        torch.cuda.synchronize()
-        null_ms = sorted(x.elapsed_time(y) for x, y in cal)[len(cal) // 2]
-        overhead_ms = max(0.0, null_ms - 0.002)
-        fam = {}
-        for a, b, f, tag in recs:
-            d = fam.setdefault(tag, [0.0, 0.0, 0, 0.0])
-            raw = a.elapsed_time(b)
-            d[0] += max(raw - overhead_ms, 0.25 * raw); d[1] += f; d[2] += 1; d[3] += raw
-        tot_ms = sum(d[0] for d in fam.values())
-        tot_fl = sum(d[1] for d in fam.values())
-        dom = max(fam, key=lambda k: fam[k][0])          # the kernel the step spends most GEMM time in
-        d_ms, d_fl, d_n, d_raw = fam[dom]
-        ach = d_fl / (d_ms * 1e-3) / 1e12
-        peak = PEAK_TFLOPS[args.precision]
-        kname = {'glds_pair': 'gemm_glds_pair_kernel<64,64,64,64> (csrc/gemm_glds.hip: dgrad + wgrad of one Linear per launch)',
-                 'glds': 'gemm_glds_kernel<64,64,..> (csrc/gemm_glds.hip)',
-                 'glds_wide': 'gemm_glds_kernel<64,128,..> (csrc/gemm_glds.hip)',
-                 'glds_pair_wide': 'gemm_glds_pair_kernel<..,64,128> (csrc/gemm_glds.hip)',
-                 'glds_dgrad': 'gemm_glds_kernel<64,64,true,false> (csrc/gemm_glds.hip: dgrad of one Linear)',
-                 'glds_wgrad_group': 'gemm_glds_group_kernel (csrc/gemm_glds.hip: the four weight gradients of a block in one launch)',
-                 'other': ('gemm_bf16_kernel / gemm_bf16_pair_kernel (csrc/gemm_bf16.hip)' if args.precision == 'bf16'
-                           else 'gemm_kernel<0,..> (csrc/gemm.hip)')}.get(dom, dom)
-        traffic, tnote = None, None   # PMC counters cannot be read in-process: last committed rocprofv3 --pmc result
-        tfile = os.path.join(ROOT, 'profiles', 'round1_gemm_traffic.json')
-        if args.precision == 'bf16' and args.batch == 4 and os.path.exists(tfile):
-            tj = json.load(open(tfile))
-            traffic = tj.get('bytes_per_launch', {}).get(dom)
-            tnote = 'HBM-side bytes per launch of that kernel (2*FETCH_SIZE + WRITE_SIZE, profiles/round1_gemm_traffic.json)'
-        roof = {'bound': 'mfma', 'kernel': kname, 'achieved': round(ach, 2),
-                'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': traffic,
-                'traffic_unit': tnote,
-                'launches_per_step': d_n / args.profile_steps, 'gflop_per_launch': round(d_fl / d_n / 1e9, 3),
-                'avg_launch_us': round(d_ms * 1e3 / d_n, 2),
-                'avg_launch_us_events_raw': round(d_raw * 1e3 / d_n, 2), 'event_pair_overhead_us': round(overhead_ms * 1e3, 2),
-                'gemm_family': {'launches_per_step': len(recs) / args.profile_steps,
-                                'gflop_per_step': round(tot_fl / args.profile_steps / 1e9, 2),
-                                'ms_per_step': round(tot_ms / args.profile_steps, 3),
-                                'tflops': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
-                                'by_kernel_ms_per_step': {k: round(v[0] / args.profile_steps, 3) for k, v in fam.items()}},
-                'step_frac_of_peak': round(world * args.batch * ALGO_GFLOP_PER_VOL[args.model] * 1e9 / (ms * 1e-3) / 1e12 / (peak * world), 4)}
+        recs, overhead = instrumented_steps(model, eng, batches, contr, args.batch, args.profile_steps, dev,
+                                            phases_only=world > 1)
+        roof = roofline_block(args, recs, overhead, ms, world)
     if world > 1:
         dist.barrier()
 
-    also, also_big = None, None
-    if rank == 0 and world == 1 and not force_ddp and not args.no_extra and args.batch < 32:
+    extra = {}
+    single = rank == 0 and world == 1 and not force_ddp and not args.no_extra
+    if single and args.batch != 8 and args.precision == 'bf16':
         try:
-            also_big = big_batch_point(args, dev, model, eng, contr)
+            extra['also_batch8'], enc = encoder_attn_mlp_point(args, dev, model, eng, contr)
+            if roof is not None:
+                roof['encoder_attn_mlp_b8'] = enc
         except Exception as e:   # a secondary point must never cost the headline line
-            also_big = {'error': repr(e)[:200]}
-    if rank == 0 and world == 1 and contr and not force_ddp and not args.no_extra:
+            extra['also_batch8'] = {'error': repr(e)[:200]}
+    if single and args.batch < 32:
         try:
-            also = plain_mae_point(args, dev, batches)
+            b32 = device_batches(32, dev)
+            dt = run_steps(model, eng, b32, contr, 32, not args.no_graph, 2 * len(b32) + 2, 10)
+            extra['also_batch32'] = {'batch': 32, 'value': round(32 / dt, 2), 'unit': 'volumes/s', 'ms_per_step': round(dt * 1e3, 3),
+                                     'steps': 10, 'step_tflops': round(ALGO_GFLOP_PER_VOL[args.model] * 32 / dt / 1e3, 1)}
+            del b32
         except Exception as e:
-            also = {'error': repr(e)[:200]}
+            extra['also_batch32'] = {'error': repr(e)[:200]}
+    if single and contr:
+        try:
+            extra['also'] = secondary_model_point(args, dev, 'mae', args.precision, batches,
+                                                  'mae_vit_base_patch16 (plain MAE, one view per volume)')
+        except Exception as e:
+            extra['also'] = {'error': repr(e)[:200]}
+    if single and args.precision == 'bf16':
+        try:
+            extra['also_fp32'] = secondary_model_point(args, dev, args.model, 'fp32', batches,
+                                                       'the headline model in fp32 mode (exact-fp32 MFMA: the parity mode)')
+        except Exception as e:
+            extra['also_fp32'] = {'error': repr(e)[:200]}
 
     cpu, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -336,13 +427,12 @@ def main():
                                       f'(fwd+loss+bwd+grad-norm+AdamW), synthetic BraTS-shape 96^3x4ch, batch '
                                       f'{args.batch}/GPU, mask 0.75 (BASELINE config 2{" / 3" if world > 1 else ""})',
                           'global_batch': world * args.batch, 'parallelism': f'dp{world}',
-                          'hip_graph': not args.no_graph,
-                          'grad_allreduce': (f'{grad_comm}, {len(model._reducer.ranges)} buckets' if model._reducer is not None else None), 'final_losses': [round(x, 6) for x in last[:6]]},
+                          'rccl_ranks': dist.get_world_size() if (world > 1 or force_ddp) else 1,
+                          'hip_graph': not args.no_graph, 'weights': 'product initialize_weights, seed 0',
+                          'grad_allreduce': (f'{grad_comm}, {len(model._reducer.ranges)} buckets' if model._reducer is not None else None),
+                          'final_losses': [round(x, 6) for x in last[:6]]},
                'roofline': roof, 'cpu_baseline': cpu}
-        if also:
-            out['config']['also'] = also
-        if also_big:
-            out['config']['also_batch32'] = also_big
+        out['config'].update(extra)
         if parity:
             out['parity'] = parity
     if world > 1 or force_ddp:

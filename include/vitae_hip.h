@@ -284,6 +284,9 @@ int vitae_loss_finalize(const double* acc, const float* hp, float* out4, float m
 int vitae_bn1d_relu_fwd(const float* x, const float* w, const float* b, float* y, float* save_mean, float* save_rstd,
                         float* running_mean, float* running_var, long long* num_batches_tracked, int R, int D,
                         float eps, float momentum, void* stream);
+/* the same in eval mode (model.eval()): y = relu((x - running_mean) / sqrt(running_var + eps) * w + b) */
+int vitae_bn1d_relu_eval(const float* x, const float* w, const float* b, const float* running_mean,
+                         const float* running_var, float* y, int R, int D, float eps, void* stream);
 int vitae_bn1d_relu_bwd(const float* dy, const float* x, const float* y, const float* w, const float* save_mean,
                         const float* save_rstd, float* dx, float* dw_accum, float* db_accum, int R, int D, void* stream);
 /* contr = contr_w * (-(mean cos(p1,z2) + mean cos(p2,z1))/2)  (utils/train_one_epoch.py:113-114) */

@@ -18,7 +18,7 @@ def _free_port():
 
 
 def _worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         from oracle import mae_ref as R
@@ -93,6 +93,20 @@ def _worker(rank, world, port, q):
         means = misc.all_reduce_means([float(rank), 2.0, float(total)])
         assert means[0] == pytest.approx((world - 1) / 2) and means[1] == 2.0
         assert misc.all_reduce_mean(float(rank)) == pytest.approx((world - 1) / 2)
+        # one metric collective per logging window (utils/train_one_epoch.py): rows of per-iteration scalars
+        rows = misc.all_reduce_mean_rows([[float(rank), 1.0], [2.0 * rank, 3.0], [5.0, float(rank + 1)]])
+        assert rows[0] == pytest.approx([(world - 1) / 2, 1.0]) and rows[1] == pytest.approx([world - 1.0, 3.0])
+        assert rows[2] == pytest.approx([5.0, (world + 1) / 2])
+        # generic (non-fused) route: whole-arena exchange leaving the mean of the unscaled per-rank gradients
+        arena = torch.full((off,), float(rank + 1))
+        red2 = ddp.GradBucketReducer(arena, ranges)
+        ddp.allreduce_mean_now(red2)
+        assert torch.allclose(arena, torch.full((off,), (world + 1) / 2))
+        # bench.py's rank plumbing as torch.distributed.run would drive it: the group must have --gpus ranks
+        import bench
+        bargs = bench.parse(['--gpus', str(world)])
+        assert bench.rank_layout(bargs) == (world, rank, rank)
+        assert dist.get_world_size() == bargs.gpus
         sv = misc.SmoothedValue()
         sv.update(float(rank + 1), n=rank + 1)
         sv.synchronize_between_processes()

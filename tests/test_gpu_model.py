@@ -515,3 +515,141 @@ def test_recurring_device_batches_are_read_in_place():
     close(finals[1][0][0], finals[0][0][0], 1e-5, 1e-7)
     # four Adam steps at lr 1e-3: stale or misplaced input would show at the 1e-3 level; atomics order accounts for ~1e-6
     assert float((finals[0][1] - finals[1][1]).abs().max()) < 1e-5
+
+
+# --------------------------------------------------------------------------- the benchmarked path itself, pinned
+def _b4_batch(cfg, it):
+    v1, v2 = R.synthetic_views((4, 4, 96, 96, 96), seed=1234 + it)
+    return v1, v2, R.masking_noise(4, cfg.num_patches, seed=4321 + it)
+
+
+# Tolerances of precision='bf16' against the fp32 reference pins (tests/golden/vitb_b4.npz, produced by the reference model
+# itself): operands of every dense contraction are rounded to 8 mantissa bits, accumulation / master weights / optimiser
+# state stay fp32.  At the first step the prediction is ~0, so the losses are insensitive to the model (observed 4e-6 /
+# 2e-5); after AdamW steps (lr 1e-4, the bench's) the prediction carries the rounding.  Gradient norms: 5e-3 per parameter.
+B4_LOSS_RTOL_STEP0, B4_LOSS_RTOL_LATER, B4_EDGE_RTOL, B4_CONTR_RTOL, B4_GRAD_RTOL = 1e-4, 5e-4, 2e-3, 2e-2, 5e-3
+# (observed on MI355X, round 2: total loss 2e-5 at the first step and <= 1.6e-4 later, reconstruction loss <= 4e-6, raw edge loss
+# <= 6.4e-4, contrastive term (magnitude 1e-5) <= 5.7e-3, gradient norms <= 1.2e-3; the fp32 mode: everything <= 7e-7)
+
+
+@pytest.mark.parametrize('precision', ['bf16', 'fp32'])
+def test_bench_workload_b4_fused_graph_vs_reference_pins(precision):
+    """BASELINE config 2 at the batch the metric is quoted on (B = 4, contrastive ViT-B/16, 96^3 x 4ch) through the
+    route bench.py times — the fused optimisation step replayed from a HIP graph: first-step loss scalars, per-parameter
+    gradient norms and the loss trajectory of three AdamW steps against pins from the reference's own model (SURVEY §8c
+    item 2; reference model/vit_autoenc.py:205-238, utils/train_one_epoch.py:52-75)."""
+    from vit_ae_plus_plus_amd.optim import FusedAdamW
+    g = load_golden('vitb_b4.npz')
+    B, steps, lr, wd, mask_ratio, edge_w, contr_w = [float(v) for v in g['hp']]
+    B, steps = int(B), int(steps)
+    cfg = R.vit_base_cfg(contrastive=True, **VITB)
+    model = build(cfg, R.init_state_dict(cfg, seed=0), precision=precision).train()
+    opt = FusedAdamW(model, lr=lr, weight_decay=wd, betas=(0.9, 0.95))
+    model._ensure_engine(torch.device('cuda', 0))
+    eng = opt.engine
+    eng.set_loss_weights(edge_w, contr_w, 1)
+    bf = precision == 'bf16'
+    # gradients of the first step: one graph-replayed step WITHOUT the optimiser
+    v1, v2, (n1, n2) = _b4_batch(cfg, 0)
+    model.set_masking_noise(n1, n2)
+    r0 = model._step_runner(B, mask_ratio, False, False, True)
+    r0.load(v1.cuda(), v2.cuda())
+    r0.run()
+    torch.cuda.synchronize()
+    assert torch.equal(eng.buf['mask'][:B].sum(1).cpu(), t(g['mask_sum']))
+    named = dict(model._trainable_named)
+    worst = 0.0
+    for k, ref in zip(g['grad_names'], g['grad_norms']):
+        got = float(eng.g[str(k)].double().norm())
+        worst = max(worst, abs(got - ref) / (ref + 1e-12))
+        assert abs(got - ref) <= (B4_GRAD_RTOL if bf else 2e-3) * ref + 1e-9, (str(k), got, ref)
+    # the trajectory: three optimiser steps, then the losses of a fourth batch
+    runner = model._step_runner(B, mask_ratio, True, False, True)
+    errs = []
+    for it in range(steps + 1):
+        v1, v2, (n1, n2) = _b4_batch(cfg, it)
+        model.set_masking_noise(n1, n2)
+        runner.load(v1.cuda(), v2.cuda())
+        eng.optimizer_hparams(lr=lr)
+        runner.run()
+        got = eng.losses.cpu().tolist()
+        want = g['losses'][it]           # [loss, raw edge, recon, percep, contr]
+        rt = (B4_LOSS_RTOL_STEP0 if it == 0 else B4_LOSS_RTOL_LATER) if bf else 1e-4
+        for i in (0, 2):
+            assert abs(got[i] - want[i]) <= rt * abs(want[i]), (it, i, got, want)
+        assert abs(got[1] - want[1]) <= (B4_EDGE_RTOL if bf else 1e-4) * abs(want[1]) + 1e-9, (it, got, want)
+        assert abs(got[4] - want[4]) <= (B4_CONTR_RTOL if bf else 1e-4) * abs(want[4]) + 1e-8, (it, got, want)
+        errs.append([abs(got[i] - want[i]) / (abs(want[i]) + 1e-12) for i in (0, 1, 2, 4)])
+    print(f'{precision}: worst grad-norm error {worst:.2e}; loss errors per step [loss, edge, recon, contr] {errs}')
+
+
+def test_two_batch_sizes_on_one_engine_keep_their_graphs_valid():
+    """a captured graph holds raw workspace addresses; a step at another batch size (smaller last batch, an eval
+    call) must not leave the first runner replaying into freed memory.  Workspaces are kept per (batch, keep) and evicting
+    one drops the graphs."""
+    from vit_ae_plus_plus_amd.optim import FusedAdamW
+    cfg = R.RefConfig(contrastive=True, **MICRO)
+    sd = R.init_state_dict(cfg, seed=5)
+
+    def run(seq, ws_max=None):
+        model = build(cfg, sd)
+        opt = FusedAdamW(model, lr=1e-3, weight_decay=0.05)
+        model._ensure_engine(torch.device('cuda', 0))
+        eng = opt.engine
+        if ws_max is not None:
+            eng._WS_MAX = ws_max
+        eng.set_loss_weights(0.01, 0.001, 1)
+        out = []
+        for i, B in enumerate(seq):
+            v1, v2 = R.synthetic_views((B, cfg.in_chans, *cfg.volume_size), seed=100 + i)
+            n1, n2 = R.masking_noise(B, cfg.num_patches, seed=200 + i)
+            model.set_masking_noise(n1, n2)
+            runner = model._step_runner(B, 0.75, True, False, True)
+            runner.load(v1, v2)
+            eng.optimizer_hparams(lr=1e-3)
+            runner.run()
+            # churn the caching allocator so that a stale graph would scribble over something visible
+            junk = [torch.randn(1 << 18, device='cuda') for _ in range(4)]
+            del junk
+            out.append(eng.losses.cpu().tolist()[:6])
+        return out, eng
+
+    seq = [2, 2, 3, 2, 1, 3, 2]
+    want, _ = run(seq)                      # workspaces cached: graphs stay valid
+    got, eng = run(seq, ws_max=1)           # every switch evicts: graphs dropped and recaptured
+    assert eng.ws_gen > 0
+    for a, b in zip(want, got):
+        close(a, b, 1e-6, 1e-9)
+    # eager reference of the same sequence
+    model = build(cfg, sd)
+    tr = T.RefTrainer(cfg, sd, lr=1e-3, weight_decay=0.05)
+    for i, B in enumerate(seq):
+        v1, v2 = R.synthetic_views((B, cfg.in_chans, *cfg.volume_size), seed=100 + i)
+        n1, n2 = R.masking_noise(B, cfg.num_patches, seed=200 + i)
+        terms, norm, _ = tr.step(v1, v2, n1, n2, lr=1e-3, mask_ratio=0.75, edge_map_weight=0.01, contr_weight=0.001)
+        close(want[i][0] + want[i][4], terms['loss'], 5e-4, 1e-7)
+
+
+def test_fused_mlp_chain_matches_the_paired_launches(monkeypatch):
+    """The opt-in fused-MLP block chain (csrc/mlp_fused.hip + slab LayerNorm + grouped weight gradients) against the default
+    paired-launch chain on ViT-B/16 (bf16): same losses and gradients up to the bf16 rounding of the saved pre-activation."""
+    cfg = R.vit_base_cfg(contrastive=True, **VITB)
+    sd = R.init_state_dict(cfg, seed=0)
+    v1, v2 = R.synthetic_views((2, 4, 96, 96, 96), seed=1234)
+    n1, n2 = R.masking_noise(2, cfg.num_patches, seed=4321)
+    res = {}
+    for fuse in ('0', '1'):
+        monkeypatch.setenv('VITAE_FUSE_MLP', fuse)
+        model = build(cfg, sd, precision='bf16').train()
+        model.set_masking_noise(n1, n2)
+        loss, pred, mask, p1, p2, z1, z2 = model(view1=v1.cuda(), view2=v2.cuda(), mask_ratio=0.75, edge_map_weight=0.01)
+        assert model.engine.fuse_mlp == (fuse == '1')
+        loss[0].backward()
+        torch.cuda.synchronize()
+        res[fuse] = ([float(x) for x in loss], {k: p.grad.double().norm().item() for k, p in model.named_parameters() if p.requires_grad},
+                     pred.float().cpu().clone())
+        del model
+    close(res['0'][0], res['1'][0], 2e-4, 1e-7)
+    assert float((res['0'][2] - res['1'][2]).abs().max()) <= 2e-2 * float(res['0'][2].abs().max())
+    for k, a in res['0'][1].items():
+        assert abs(a - res['1'][1][k]) <= 2e-2 * a + 1e-9, (k, a, res['1'][1][k])

@@ -2,6 +2,7 @@
 factories / state-dict keys, arena layout rules, drop-in aliases, loud failure on CPU tensors."""
 import argparse
 import math
+import os
 
 import numpy as np
 import pytest
@@ -160,3 +161,44 @@ def test_fused_adamw_param_groups_follow_timm_rule():
     assert [names[id(p)] for p in opt.param_groups[0]['params']] == ref[0]['names']
     assert [names[id(p)] for p in opt.param_groups[1]['params']] == ref[1]['names']
     assert 'cls_token' in ref[1]['names'] and 'norm.weight' in ref[0]['names']
+
+
+def test_pos_embed_matches_reference_kat(golden):
+    """get_3d_sincos_pos_embed against the table the reference's own function produced (tests/golden/kats.npz),
+    not against itself."""
+    from vit_ae_plus_plus_amd.model.model_utils.vit_helpers import get_3d_sincos_pos_embed
+    g = golden('kats.npz')
+    keys = [k for k in g.files if 'pos' in k.lower()]
+    assert keys, g.files
+    checked = 0
+    for k in keys:
+        ref = g[k]
+        if ref.ndim != 2:
+            continue
+        rows, dim = ref.shape
+        n = round((rows - 1) ** (1 / 3))
+        if n ** 3 != rows - 1:
+            continue
+        got = get_3d_sincos_pos_embed(dim, n, cls_token=True)
+        np.testing.assert_allclose(np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64), rtol=0, atol=1e-7)
+        checked += 1
+    assert checked >= 1
+
+
+def test_bench_rank_plumbing():
+    """bench.py --gpus N: spawns N ranks when no launcher is around, refuses fewer visible GPUs, and refuses a launcher that
+    provides a different number of ranks (`--gpus 8` silently ran dp1)."""
+    import bench
+    args = bench.parse(['--gpus', '2', '--steps', '3'])
+    os.environ.pop('WORLD_SIZE', None)
+    with pytest.raises(SystemExit) as e:
+        bench.spawn_command(args, ['--gpus', '2'], n_visible=1, port=12345)
+    assert 'only 1 GPU' in str(e.value)
+    cmd = bench.spawn_command(args, ['--gpus', '2', '--steps', '3'], n_visible=2, port=12345)
+    assert '--nproc-per-node=2' in cmd and '127.0.0.1' in cmd and cmd[-4:] == ['--gpus', '2', '--steps', '3']
+    assert bench.spawn_command(bench.parse(['--gpus', '1']), [], n_visible=0, port=1) is None
+    with pytest.raises(SystemExit):
+        bench.rank_layout(args, env={'WORLD_SIZE': '1'})
+    with pytest.raises(SystemExit):
+        bench.rank_layout(bench.parse(['--gpus', '1']), env={'WORLD_SIZE': '8', 'RANK': '3', 'LOCAL_RANK': '3'})
+    assert bench.rank_layout(args, env={'WORLD_SIZE': '2', 'RANK': '1', 'LOCAL_RANK': '1'}) == (2, 1, 1)

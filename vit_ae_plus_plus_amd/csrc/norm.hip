@@ -529,6 +529,18 @@ __global__ __launch_bounds__(256) void bn1d_relu_fwd_kernel(const float* __restr
     }
 }
 
+// eval mode (nn.BatchNorm1d with track_running_stats, model.eval()): normalise with the RUNNING statistics
+__global__ __launch_bounds__(256) void bn1d_relu_eval_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ b, const float* __restrict__ run_mean,
+                                                             const float* __restrict__ run_var, float* __restrict__ y,
+                                                             long n, int D, float eps) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % D);
+    const float v = (x[i] - run_mean[c]) * rsqrtf(run_var[c] + eps) * w[c] + b[c];
+    y[i] = v > 0.f ? v : 0.f;
+}
+
 // dy arrives for the ReLU output y; ReLU mask = (y > 0).  dx = w*rstd*(g - mean(g) - xhat*mean(g*xhat)).
 __global__ __launch_bounds__(256) void bn1d_relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ y, const float* __restrict__ w,
@@ -653,6 +665,15 @@ extern "C" int vitae_bn1d_relu_fwd(const float* x, const float* w, const float* 
     if (!x || !w || !b || !y || !save_mean || !save_rstd || R <= 0 || D <= 0) return VITAE_ERR_INVALID_ARG;
     hipLaunchKernelGGL(bn1d_relu_fwd_kernel, dim3(cdiv(D, BN_COLS)), dim3(256), 0, (hipStream_t)stream, x, w, b, y,
                        save_mean, save_rstd, running_mean, running_var, num_batches_tracked, R, D, eps, momentum);
+    return vitae_launch_status();
+}
+
+extern "C" int vitae_bn1d_relu_eval(const float* x, const float* w, const float* b, const float* running_mean,
+                                    const float* running_var, float* y, int R, int D, float eps, void* stream) {
+    if (!x || !w || !b || !running_mean || !running_var || !y || R <= 0 || D <= 0) return VITAE_ERR_INVALID_ARG;
+    const long n = (long)R * D;
+    hipLaunchKernelGGL(bn1d_relu_eval_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, w, b, running_mean,
+                       running_var, y, n, D, eps);
     return vitae_launch_status();
 }
 

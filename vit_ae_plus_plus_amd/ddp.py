@@ -110,6 +110,20 @@ class GradBucketReducer:
         self.pending = rest
 
 
+def allreduce_mean_now(reducer: "GradBucketReducer"):
+    """Generic (non-fused) route: all-reduce every bucket and leave the MEAN of the per-rank gradients in the arena.  The
+    fused step folds 1/world into the loss multipliers instead; here the gradients were produced unscaled, so they are
+    divided after the SUM."""
+    if reducer is None or not reducer.active:
+        return
+    for b in range(len(reducer.ranges)):
+        reducer.launch(b)
+    reducer.wait(copy_back=True)
+    ws = reducer.world_size
+    if ws > 1:
+        reducer.flat.mul_(1.0 / ws)
+
+
 def engine_bucket_ranges(engine) -> List[Tuple[int, int]]:
     """[decoder+predictor matrices, encoder chunks from the top (the last one down to offset 0, i.e. with the patch
     embedding), tokens+vectors] as element ranges of ``engine.grads`` — the completion order of

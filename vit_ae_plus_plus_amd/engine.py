@@ -145,6 +145,10 @@ class HipMAEEngine:
         self.ws16 = torch.zeros(1 << 23, **f32)  # LDS-DMA GEMMs: tile tickets (kept zero by the kernels) + partial tiles
         self.B = None
         self.buf: Dict[str, torch.Tensor] = {}
+        # one workspace per (batch, kept patches), kept alive while captured graphs may hold its addresses; evicting one
+        # bumps ``ws_gen`` and every step runner drops its graphs (model/vit_autoenc.py: _StepRunner.run)
+        self._ws_cache: "OrderedDict[Tuple[int, int], dict]" = OrderedDict()
+        self.ws_gen = 0
         self.opt_state = None
         self.opt_step = 0
         self._accum = False
@@ -164,7 +168,8 @@ class HipMAEEngine:
         self._wg_pending = set()
         self._wire_ready = False
         self.grads_wire16 = None  # set by the data-parallel reducer when gradients are exchanged (and consumed) in bf16
-        self.gemm_timer = None   # bench.py: list collecting (start_event, end_event, flops) per GEMM launch
+        self.gemm_timer = None   # bench.py: list collecting (start_event, end_event, flops, kernel tag, scope) per launch
+        self._scope = None       # 'enc' / 'dec' while the launches of a transformer block of that stack are issued
         self.set_hparams(lr=0.0, beta1=0.9, beta2=0.95, eps=1e-8, bc1=1.0, bc2=1.0, grad_mul=1.0, g_recon=1.0,
                          g_edge=0.0, g_contr=0.0, edge_w=0.0, contr_w=0.0)
 
@@ -231,6 +236,9 @@ class HipMAEEngine:
         self.hp.copy_(host, non_blocking=True)
 
     # ------------------------------------------------------------------ workspace
+    _WS_ATTRS = ('B', 'keep', 'Be', 'Ne', 'Nd', 'Me', 'Md', 'Mpe', 'Mpd', 'Mpt', 'Mpl', 'R', 'mask_sum', 'edge_count', 'buf')
+    _WS_MAX = int(os.environ.get('VITAE_WORKSPACES', '4'))
+
     def _alloc(self, B: int, mask_ratio: float):
         cfg = self.cfg
         keep = cfg.len_keep(mask_ratio)
@@ -238,6 +246,17 @@ class HipMAEEngine:
             raise VitaeError(f'mask_ratio {mask_ratio} leaves {keep} of {cfg.num_patches} patches')
         if self.B == B and self.keep == keep:
             return
+        if self.B is not None:      # park the current workspace: graphs captured on it stay valid
+            self._ws_cache[(self.B, self.keep)] = {k: getattr(self, k) for k in self._WS_ATTRS if hasattr(self, k)}
+            self._ws_cache.move_to_end((self.B, self.keep))
+        hit = self._ws_cache.get((B, keep))
+        if hit is not None:
+            for k, v in hit.items():
+                setattr(self, k, v)
+            return
+        while len(self._ws_cache) >= self._WS_MAX:
+            self._ws_cache.popitem(last=False)      # its buffers go back to the allocator: graphs holding them are stale
+            self.ws_gen += 1
         self.B, self.keep = B, keep
         self.Be = 2 * B if cfg.contrastive else B
         L, P, D, Dd = cfg.num_patches, cfg.patch_dim, cfg.embed_dim, cfg.decoder_embed_dim
@@ -370,7 +389,7 @@ class HipMAEEngine:
         if self.gemm_timer is None:
             return None
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        self.gemm_timer.append((a, b, flops, tag))
+        self.gemm_timer.append((a, b, flops, tag, self._scope))
         a.record()
         return b
 
@@ -652,8 +671,11 @@ class HipMAEEngine:
         b, p, M = self.buf, self.p, Bs * N
         self._ln_fwd(x_in, pre + 'norm1.', None, b[q + 'mean1'], b[q + 'rstd1'], M, d, y16=b[q + 'y1_16'])
         self._g16_fwd(b[q + 'y1_16'], p[pre + 'attn.qkv.weight'], p[pre + 'attn.qkv.bias'], M, 3 * d, d, y=b[q + 'qkv'])
+        t = self._timed(4.0 * Bs * heads * N * N * hd, 'attn')
         lib.vitae_sdpa_mfma_fwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(b[q + 'o_16']), _ptr(b[q + 'lse']), Bs, N, heads, hd,
                                 self.stream)
+        if t is not None:
+            t.record()
         self._g16_fwd(b[q + 'o_16'], p[pre + 'attn.proj.weight'], p[pre + 'attn.proj.bias'], M, d, d, y=b[q + 'xmid'], res=x_in)
         self._ln_fwd(b[q + 'xmid'], pre + 'norm2.', None, b[q + 'mean2'], b[q + 'rstd2'], M, d, y16=b[q + 'y2_16'])
         self._g16_fwd(b[q + 'y2_16'], p[pre + 'mlp.fc1.weight'], p[pre + 'mlp.fc1.bias'], M, hid, d, y16=b[q + 'act_16'],
@@ -665,6 +687,7 @@ class HipMAEEngine:
         output gradient and the fc2 bias gradient has already been produced by whoever wrote dx.
         ``prev_fc2_bias``: gradient slot of the fc2 bias of the block this one feeds INTO dx for (block i-1)."""
         b, p, g, M = self.buf, self.p, self.g, Bs * N
+        self._scope = s
         dx, dx16, dh16, dy, do, dqkv, dqkv16 = (b[s + 'dx'], b[s + 'dx_16'], b[s + 'dh_16'], b[s + 'dy'], b[s + 'do'],
                                                   b[s + 'dqkv'], b[s + 'dqkv_16'])
         self._g16_bwd(dx16, p[pre + 'mlp.fc2.weight'], b[q + 'act_16'], g[pre + 'mlp.fc2.weight'], M, Mp, d, hid,
@@ -673,18 +696,26 @@ class HipMAEEngine:
         self._ln_bwd(dy, b[q + 'xmid'], pre + 'norm2.', b[q + 'mean2'], b[q + 'rstd2'], dx, M, d, 1, dx16=dx16,
                      dx_colsum=g[pre + 'attn.proj.bias'])
         self._g16_bwd(dx16, p[pre + 'attn.proj.weight'], b[q + 'o_16'], g[pre + 'attn.proj.weight'], M, Mp, d, d, dx=do)
+        t = self._timed(10.0 * Bs * heads * N * N * hd, 'attn')
         lib.vitae_sdpa_mfma_bwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(do), _ptr(b[q + 'lse']), _ptr(dqkv), _ptr(dqkv16),
                                 None, _ptr(b['delta']), Bs, N, heads, hd, self.stream)
+        if t is not None:
+            t.record()
         # the qkv bias gradient colsum(dqkv) rides on the wgrad workgroups (one extra MFMA against a ones operand)
         self._g16_bwd(dqkv16, p[pre + 'attn.qkv.weight'], b[q + 'y1_16'], g[pre + 'attn.qkv.weight'], M, Mp, 3 * d, d, dx=dy,
                       dy_colsum=g[pre + 'attn.qkv.bias'])
         self._ln_bwd(dy, x_in, pre + 'norm1.', b[q + 'mean1'], b[q + 'rstd1'], dx, M, d, 1, dx16=dx16,
                      dx_colsum=prev_fc2_bias)
+        self._scope = None
 
     def _block_fwd(self, pre, q, x_in, x_out, Bs, N, d, heads, hd, hid):
         """model/vit.py:139-144.  pre = state-dict prefix, q = workspace prefix."""
         if self.act16:
-            return self._block_fwd16(pre, q, x_in, x_out, Bs, N, d, heads, hd, hid)
+            self._scope = q[:3]
+            try:
+                return self._block_fwd16(pre, q, x_in, x_out, Bs, N, d, heads, hd, hid)
+            finally:
+                self._scope = None
         b, p, M = self.buf, self.p, Bs * N
         self._ln_fwd(x_in, pre + 'norm1.', b[q + 'y1'], b[q + 'mean1'], b[q + 'rstd1'], M, d)
         self._lin_fwd(b[q + 'y1'], p[pre + 'attn.qkv.weight'], p[pre + 'attn.qkv.bias'], b[q + 'qkv'], M, 3 * d, d)
@@ -841,6 +872,12 @@ class HipMAEEngine:
         self._lin_fwd(b['latent'], p['predictor.0.weight'], None, b['ph'], 2 * R, D, D)
         for v in range(2):
             o = v * R * D * 4
+            if not training:     # model.eval(): nn.BatchNorm1d normalises with its running statistics (vit_autoenc.py:263-268)
+                lib.vitae_bn1d_relu_eval(b['ph'].data_ptr() + o, _ptr(p['predictor.1.weight']), _ptr(p['predictor.1.bias']),
+                                         _ptr(self.buffers['predictor.1.running_mean']),
+                                         _ptr(self.buffers['predictor.1.running_var']), b['pr'].data_ptr() + o, R, D, 1e-5,
+                                         self.stream)
+                continue
             lib.vitae_bn1d_relu_fwd(b['ph'].data_ptr() + o, _ptr(p['predictor.1.weight']), _ptr(p['predictor.1.bias']),
                                     b['pr'].data_ptr() + o, b['bn_mean'].data_ptr() + v * D * 4,
                                     b['bn_rstd'].data_ptr() + v * D * 4,

@@ -131,6 +131,7 @@ class _StepRunner:
         self.graphs = {}              # slot index, or ('direct', ptr1, ptr2) -> captured graph(s)
         self.use_graph = use_graph
         self._direct, self._seen = None, {}
+        self._ws_gen = self.eng.ws_gen
 
     @property
     def slot(self):
@@ -253,6 +254,10 @@ class _StepRunner:
         sl = self.slot
         main = torch.cuda.current_stream(eng.device)
         main.wait_event(sl.loaded)                     # this slot's batch has landed
+        if self._ws_gen != eng.ws_gen:                 # the engine freed a workspace some captured graph may point into
+            self.graphs.clear()
+            self._ws_gen = eng.ws_gen
+        eng._alloc(self.B, self.mask_ratio)            # this runner's workspace is the current one (replays bypass forward())
         if self.use_graph and self.graphs.get(self._gkey) is None:
             self._capture(groups)
         graphs = self.graphs.get(self._gkey)

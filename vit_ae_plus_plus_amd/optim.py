@@ -124,7 +124,9 @@ class _AdoptedAdamW:
                                   'exp_avg_sq': eng.opt_state['exp_avg_sq'][o:o + k].view(shp)}
         eng.opt_step = step
         self.engine = eng
-        optimizer.register_state_dict_pre_hook(self._publish_step)
+        if not getattr(optimizer, '_vitae_hooked', False):
+            optimizer.register_state_dict_pre_hook(lambda opt: opt._vitae_adopter._publish_step(opt))
+            optimizer._vitae_hooked = True
         self._orig_step = optimizer.step
         optimizer.step = self.step
         optimizer.engine = eng
@@ -142,17 +144,46 @@ class _AdoptedAdamW:
         eng.grad_norm_and_step()
 
 
+def _adoptable_weight_decay(optimizer, model):
+    """The single non-zero weight decay of a torch.optim.AdamW whose groups follow the arena's decay / no-decay split
+    (timm add_weight_decay: no decay iff ndim <= 1 or name ends with '.bias'), or None when the optimiser cannot be
+    re-routed without changing results."""
+    ids_decay = {id(p) for n, p in model._trainable_named if not (p.ndim <= 1 or n.endswith('.bias'))}
+    ids_all = {id(p) for p in model._trainable}
+    wds, seen = set(), set()
+    g0 = optimizer.param_groups[0]
+    for g in optimizer.param_groups:
+        if g.get('amsgrad') or g.get('maximize') or 'lr_scale' in g:
+            return None
+        if g['lr'] != g0['lr'] or tuple(g['betas']) != tuple(g0['betas']) or g['eps'] != g0['eps']:
+            return None
+        for p in g['params']:
+            if id(p) not in ids_all or id(p) in seen:
+                return None
+            seen.add(id(p))
+            if (id(p) in ids_decay) != (g['weight_decay'] != 0.0):
+                return None         # e.g. a plain AdamW(model.parameters(), weight_decay=wd): biases in a decayed group
+        if g['weight_decay'] != 0.0:
+            wds.add(g['weight_decay'])
+    if seen != ids_all or len(wds) > 1:
+        return None
+    return wds.pop() if wds else 0.0
+
+
 def adopt(optimizer, model) -> Optional[object]:
     """Make ``optimizer.step()`` run on the HIP engine when that is possible without changing results:
-    FusedAdamW is returned as is; a plain torch.optim.AdamW over exactly the model's parameters is
-    re-routed in place; anything else is left alone (returns None: the caller keeps torch's own step)."""
+    FusedAdamW is returned as is; a plain torch.optim.AdamW over exactly the model's parameters, grouped like
+    timm's add_weight_decay, is re-routed in place (again, with its state migrated, when the model rebuilt its engine after
+    ``set_precision()`` / ``.to()``); anything else is left alone (returns None: the caller keeps torch's own step)."""
     if isinstance(optimizer, FusedAdamW):
         return optimizer
-    if getattr(optimizer, 'engine', None) is not None:
+    if model.engine is None:
+        return None
+    if getattr(optimizer, 'engine', None) is model.engine:
         return optimizer
-    if type(optimizer) is torch.optim.AdamW and model.engine is not None:
-        lrs = {g['lr'] for g in optimizer.param_groups}
-        if len(lrs) == 1 and not any('lr_scale' in g for g in optimizer.param_groups):
-            _AdoptedAdamW(optimizer, model)
-            return optimizer
+    if type(optimizer) is torch.optim.AdamW and _adoptable_weight_decay(optimizer, model) is not None:
+        if getattr(optimizer, 'engine', None) is not None:      # adopted for an engine that no longer exists
+            optimizer.step = optimizer._vitae_adopter._orig_step
+        optimizer._vitae_adopter = _AdoptedAdamW(optimizer, model)
+        return optimizer
     return None

@@ -224,6 +224,16 @@ def all_reduce_mean(x):
     return all_reduce_means([float(x)])[0]
 
 
+def all_reduce_mean_rows(rows):
+    """Mean over ranks of a list of equally long rows of python scalars with ONE collective (the per-iteration metric
+    rows of a logging window, utils/train_one_epoch.py)."""
+    if get_world_size() == 1 or not rows:
+        return [list(r) for r in rows]
+    n = len(rows[0])
+    flat = all_reduce_means([v for r in rows for v in r])
+    return [flat[i * n:(i + 1) * n] for i in range(len(rows))]
+
+
 # ----------------------------------------------------------------------------- scaler / grad norm
 def get_grad_norm_(parameters, norm_type: float = 2.0) -> torch.Tensor:
     """Global gradient norm (reference utils/misc.py:280-292).  For parameters living in a
@@ -258,6 +268,9 @@ class NativeScalerWithGradNormCount:
     def __init__(self):
         self._state = {'scale': 1.0, 'growth_factor': 2.0, 'backoff_factor': 0.5, 'growth_interval': 2000,
                        '_growth_tracker': 0}
+        # data parallel, generic (non-fused) route: called after backward and before the norm / the step so that every
+        # rank steps on the mean gradient (set by train_one_stage_epoch; the fused step exchanges inside its launch list)
+        self.grad_sync = None
 
     def __call__(self, loss, optimizer, clip_grad=None, parameters=None, create_graph=False, update_grad=True):
         loss.backward(create_graph=create_graph)
@@ -265,6 +278,8 @@ class NativeScalerWithGradNormCount:
             return None
         params = list(parameters) if parameters is not None else [p for g in optimizer.param_groups for p in g['params']]
         engine = getattr(optimizer, 'engine', None)
+        if self.grad_sync is not None:
+            self.grad_sync()
         if clip_grad is not None:
             norm = torch.nn.utils.clip_grad_norm_(params, clip_grad)
         elif engine is not None:

@@ -122,17 +122,39 @@ def _fused_epoch(model, data_loader, optimizer, device, epoch, log_writer, args,
     contr_w = float(getattr(args, 'contr_weight', 0.0)) if contr else 0.0
     world = model._reducer.world_size if model._reducer is not None else 1
     eng.set_loss_weights(edge_map_weight, contr_w, accum_iter, world)
+    world = misc.get_world_size()        # metric collectives follow the process group, exchanged gradients or not
     use_graph = bool(getattr(args, 'hip_graph', True))
     rb = _Readback()
     n_iter = len(data_loader)
 
+    rows = []      # (iteration, lr, [loss, recon, edge, percep, contr]) not yet written to the log writer
+
+    def emit(block):
+        """Tensorboard scalars of a window of iterations; under data parallelism the window is averaged over the ranks
+        with ONE collective.  Every rank calls this at the same iterations (``flush`` below), so the metric collective
+        sits at the same place in every rank's sequence of collectives — the reference's five blocking all-reduces per
+        step (utils/train_one_epoch.py:83-88), issued here whenever a read-back happened to be ready, could interleave
+        differently with the gradient buckets on different ranks."""
+        red = misc.all_reduce_mean_rows([r[2] for r in block])
+        if log_writer is None:
+            return
+        for (it, lr, _), v in zip(block, red):
+            if (it + 1) % accum_iter == 0:
+                x = int((it / n_iter + epoch) * 1000)
+                log_writer.add_scalar('train_loss', v[0], x)
+                log_writer.add_scalar('lr', lr, x)
+                log_writer.add_scalar('reconstruction_loss', v[1], x)
+                log_writer.add_scalar('sobel_loss', v[2], x)
+                log_writer.add_scalar('perceptual_loss', v[3], x)
+                log_writer.add_scalar('contr_loss', v[4], x)
+
     def consume(limit):
-        """Process finished read-backs; block only while more than ``limit`` steps are in flight."""
+        """Process finished read-backs; block only while more than ``limit`` steps are in flight.  No collective here."""
         while rb.pending:
             got = rb.pop(block=len(rb.pending) > limit)
             if got is None:
                 return
-            vals, (it, lr) = got
+            vals, (it, lr, stepped) = got
             weighted, edge, recon, percep, contr_loss = vals[0], vals[1], vals[2], vals[3], vals[4] if contr else 0.0
             loss_value = weighted + contr_loss
             metric_logger.update(edge_map_loss=edge, reconstruction_loss=recon, perceptual_loss=percep,
@@ -140,17 +162,21 @@ def _fused_epoch(model, data_loader, optimizer, device, epoch, log_writer, args,
             if not math.isfinite(loss_value):
                 print("Loss is {}, stopping training".format(loss_value))
                 sys.exit(1)
+            if stepped and not math.isfinite(vals[5]):
+                eng.opt_step -= 1        # the AdamW kernel skipped this step (GradScaler.step semantics): do not count it
             metric_logger.update(loss=loss_value)
             metric_logger.update(lr=lr)
-            red = misc.all_reduce_means([loss_value, recon, edge, percep, contr_loss])
-            if log_writer is not None and (it + 1) % accum_iter == 0:
-                x = int((it / n_iter + epoch) * 1000)
-                log_writer.add_scalar('train_loss', red[0], x)
-                log_writer.add_scalar('lr', lr, x)
-                log_writer.add_scalar('reconstruction_loss', red[1], x)
-                log_writer.add_scalar('sobel_loss', red[2], x)
-                log_writer.add_scalar('perceptual_loss', red[3], x)
-                log_writer.add_scalar('contr_loss', red[4], x)
+            rows.append((it, lr, [loss_value, recon, edge, percep, contr_loss]))
+            if world == 1:
+                emit(rows)
+                rows.clear()
+
+    def flush():
+        """Deterministic point (same iteration on every rank): drain the read-backs, then one metric collective."""
+        consume(limit=0)
+        if world > 1:
+            emit(rows)
+            rows.clear()
 
     for it, (sample, original_volume, _) in enumerate(metric_logger.log_every(data_loader, print_freq, header)):
         if it % accum_iter == 0:
@@ -166,9 +192,12 @@ def _fused_epoch(model, data_loader, optimizer, device, epoch, log_writer, args,
         if update:
             for p in model._trainable:   # mirror optimizer.zero_grad(): grads are consumed
                 p.grad = None
-        rb.push(eng.losses, (it, lr))
-        consume(limit=2)
-    consume(limit=0)
+        rb.push(eng.losses, (it, lr, update))
+        if world > 1 and (it + 1) % print_freq == 0:
+            flush()
+        else:
+            consume(limit=2)
+    flush()
 
 
 def optimizer_hparams(optimizer, eng, lr):
@@ -204,6 +233,16 @@ def train_one_stage_epoch(model: torch.nn.Module, data_loader: Iterable, optimiz
     else:
         criterion = torch.nn.CosineSimilarity(dim=1)
         n_iter = len(data_loader)
+        red = getattr(model, '_reducer', None)
+        if red is not None and red.active:
+            # generic route under data parallelism: the exchange the fused step does inside its launch list happens here,
+            # between backward and the optimiser step (every bucket, blocking, then the 1/world of the mean)
+            from .. import ddp
+            if not hasattr(loss_scaler, 'grad_sync'):
+                raise RuntimeError('data parallel without the fused step needs utils.misc.NativeScalerWithGradNormCount '
+                                   '(its grad_sync hook all-reduces the gradients before optimizer.step())')
+            loss_scaler.grad_sync = lambda: ddp.allreduce_mean_now(red)
+        rows = []
         for it, (sample, original_volume, _) in enumerate(metric_logger.log_every(data_loader, print_freq, header)):
             if it % accum_iter == 0:
                 lr_sched.adjust_learning_rate(optimizer, it / n_iter + epoch, args)
@@ -229,15 +268,23 @@ def train_one_stage_epoch(model: torch.nn.Module, data_loader: Iterable, optimiz
             metric_logger.update(loss=loss_value)
             lr = optimizer.param_groups[0]["lr"]
             metric_logger.update(lr=lr)
-            red = misc.all_reduce_means([loss_value, vals[2], vals[1], vals[3], vals[4]])
-            if log_writer is not None and (it + 1) % accum_iter == 0:
-                x = int((it / n_iter + epoch) * 1000)
-                log_writer.add_scalar('train_loss', red[0], x)
-                log_writer.add_scalar('lr', lr, x)
-                log_writer.add_scalar('reconstruction_loss', red[1], x)
-                log_writer.add_scalar('sobel_loss', red[2], x)
-                log_writer.add_scalar('perceptual_loss', red[3], x)
-                log_writer.add_scalar('contr_loss', red[4], x)
+            rows.append((it, lr, [loss_value, vals[2], vals[1], vals[3], vals[4]]))
+            if misc.get_world_size() == 1 or (it + 1) % print_freq == 0 or it + 1 == n_iter:
+                # one metric collective per logging window, at the same iteration on every rank
+                block = misc.all_reduce_mean_rows([r[2] for r in rows])
+                if log_writer is not None:
+                    for (i2, lr2, _), v in zip(rows, block):
+                        if (i2 + 1) % accum_iter == 0:
+                            x = int((i2 / n_iter + epoch) * 1000)
+                            log_writer.add_scalar('train_loss', v[0], x)
+                            log_writer.add_scalar('lr', lr2, x)
+                            log_writer.add_scalar('reconstruction_loss', v[1], x)
+                            log_writer.add_scalar('sobel_loss', v[2], x)
+                            log_writer.add_scalar('perceptual_loss', v[3], x)
+                            log_writer.add_scalar('contr_loss', v[4], x)
+                rows.clear()
+        if hasattr(loss_scaler, 'grad_sync'):
+            loss_scaler.grad_sync = None
 
     metric_logger.synchronize_between_processes()
     print("Averaged stats:", metric_logger)
