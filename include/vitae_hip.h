@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITAE_ABI_VERSION 22
+#define VITAE_ABI_VERSION 23
 
 /* matrix-core arithmetic of the dense contractions */
 #define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
@@ -216,6 +216,25 @@ int vitae_decoder_assemble_fwd(const float* e, const float* mask_token, const fl
  * LDS-DMA GEMM); dmask_token_accum[Dd] += sum of dxd over the masked positions.  One launch. */
 int vitae_decoder_assemble_bwd(const float* dxd, const int* ids_shuffle, float* de, void* de_bf16, float* dmask_token_accum,
                                int B, int L, int keep, int Dd, void* stream);
+
+/* ---- data-parallel gradient exchange (the reference itself only all-reduces logging scalars,
+ * utils/misc.py:332-340) -------------------------------------------------------------------------------------------------
+ * RCCL all-reduce (SUM) of one gradient bucket on a side stream, forked from / joined to the compute stream with events
+ * created at init — capturable inside a HIP graph, so a data-parallel optimisation step is ONE graph replay.  RCCL is bound
+ * at run time (the librccl.so already in the process, e.g. PyTorch's).  Rendezvous belongs to the caller: rank 0 obtains the
+ * 128-byte id, ships it to the other ranks (torch.distributed broadcast, file, MPI ...), every rank calls vitae_ddp_init.
+ * One communicator per process.  The caller folds 1/world_size into the loss-gradient multipliers (VITAE_HP_G_*), so the
+ * SUM is the mean. */
+int vitae_ddp_available(void);                       /* 1 when RCCL could be bound */
+int vitae_ddp_unique_id(void* out128);               /* HOST buffer of 128 bytes */
+int vitae_ddp_init(const void* unique_id128, int world_size, int rank);
+int vitae_ddp_world_size(void);                      /* 0 before init */
+/* buf[0..count) (fp32, or bf16 when is_bf16) <- sum over ranks, in place, on comm_stream, ordered after everything enqueued
+ * on compute_stream so far */
+int vitae_ddp_allreduce_bucket(void* buf, long count, int is_bf16, void* compute_stream, void* comm_stream);
+/* compute_stream waits for every bucket launched on comm_stream so far */
+int vitae_ddp_wait(void* compute_stream, void* comm_stream);
+int vitae_ddp_destroy(void);
 
 /* ---- input normalisation (dataset/brats_dataset/brats.py:26-37, dataset/egd_dataset/egd.py:44-55) ---------------
  * `groups` contiguous runs of n elements, each normalised on its own: z-score with the unbiased variance, min-max

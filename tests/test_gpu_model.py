@@ -653,3 +653,47 @@ def test_fused_mlp_chain_matches_the_paired_launches(monkeypatch):
     assert float((res['0'][2] - res['1'][2]).abs().max()) <= 2e-2 * float(res['0'][2].abs().max())
     for k, a in res['0'][1].items():
         assert abs(a - res['1'][1][k]) <= 2e-2 * a + 1e-9, (k, a, res['1'][1][k])
+
+
+@pytest.mark.parametrize('comm', [False, True])
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_native_rccl_exchange_inside_the_step_graph(comm, use_graph):
+    """the C-ABI exchange (vitae_ddp_init / _allreduce_bucket / _wait: RCCL called directly on a side HIP
+    stream) on a communicator of ONE rank.  With the graph route the collectives are nodes of the single captured step graph.
+    An all-reduce over one rank is the identity: two steps must land where the single-process step lands."""
+    from vit_ae_plus_plus_amd._abi import lib
+    from vit_ae_plus_plus_amd.optim import FusedAdamW
+    assert lib.vitae_ddp_available()
+    cfg = R.RefConfig(contrastive=True, **ACT16)
+    sd = R.init_state_dict(cfg, seed=11)
+    B, outs = 2, []
+    for ddp_on in (False, True):
+        model = build(cfg, sd, precision='bf16')
+        opt = FusedAdamW(model, lr=1e-3, weight_decay=0.05)
+        model._ensure_engine(torch.device('cuda', 0))
+        eng = opt.engine
+        if ddp_on:
+            red = model.enable_data_parallel(torch.device('cuda', 0), force=True, comm_dtype=torch.bfloat16 if comm else None,
+                                             enc_chunks=2, native=True)
+            assert red is not None and red.native and len(red.ranges) == 4 and lib.vitae_ddp_world_size() == 1
+        eng.set_loss_weights(0.01, 0.001, 1, 1)
+        for step in range(3):
+            v1, v2 = R.synthetic_views((B, cfg.in_chans, *cfg.volume_size), seed=700 + step)
+            model.set_masking_noise(*R.masking_noise(B, cfg.num_patches, seed=800 + step))
+            runner = model._step_runner(B, 0.75, True, False, use_graph)
+            runner.load(v1, v2)
+            eng.optimizer_hparams(lr=1e-3)
+            runner.run()
+        torch.cuda.synchronize()
+        if ddp_on and use_graph:
+            assert all(len(g) == 1 for g in runner.graphs.values())      # ONE graph per step, collectives inside
+        outs.append(({k: v.detach().clone() for k, v in model.state_dict().items()}, eng.losses.cpu().tolist()))
+    lib.vitae_ddp_destroy()
+    (a, la), (b, lb) = outs
+    close(lb[0], la[0], 2e-3 if comm else 1e-5, 1e-7)
+    close(lb[5], la[5], 2e-2 if comm else 1e-4, 1e-7)          # grad norm
+    for k in ('decoder_pred.weight', 'blocks.0.mlp.fc1.weight', 'blocks.1.attn.qkv.weight', 'patch_embed.proj.weight',
+              'predictor.3.weight', 'cls_token', 'norm.weight'):
+        upd = (a[k].double() - sd[k].double().cuda()).norm()
+        err = float((a[k].double() - b[k].double()).norm() / upd)
+        assert err < (0.1 if comm else 2e-3), (k, err)

@@ -104,7 +104,8 @@ class _Lib:
 
 
 # int-returning entry points whose result is a value, not a status
-_VALUE_RETURNING = {'vitae_abi_version', 'vitae_mlp_fused_supported', 'vitae_mlp_fused_slabs'}
+_VALUE_RETURNING = {'vitae_abi_version', 'vitae_mlp_fused_supported', 'vitae_mlp_fused_slabs', 'vitae_ddp_available',
+                    'vitae_ddp_world_size'}
 
 lib = _Lib()
 

@@ -18,7 +18,7 @@ CSRC = os.path.join(PKG, 'csrc')
 OBJ = os.path.join(CSRC, '_obj')
 LIB = os.path.join(PKG, 'libvitae_hip.so')
 SOURCES = ['gemm.hip', 'gemm_bf16.hip', 'gemm_glds.hip', 'mlp_fused.hip', 'norm.hip', 'attention.hip', 'attention_mfma.hip', 'tokens.hip', 'loss.hip',
-           'optim.hip', 'input.hip']
+           'optim.hip', 'input.hip', 'ddp.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast',
          '-I', os.path.join(ROOT, 'include'), '-I', CSRC]
 
@@ -61,7 +61,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
     if jobs or not _newer(LIB, objs):
-        run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB, *objs])
+        run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB, *objs, '-ldl'])
     return LIB
 
 

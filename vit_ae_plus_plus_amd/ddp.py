@@ -110,6 +110,84 @@ class GradBucketReducer:
         self.pending = rest
 
 
+class RcclBucketReducer(GradBucketReducer):
+    """The same contract through the C ABI (``vitae_ddp_*``, csrc/ddp.hip): RCCL called directly on a side HIP stream that is
+    forked from / joined to the compute stream with events, so the collectives are graph nodes of the captured step (one
+    replay per optimisation step) instead of host-issued work between five graph replays.  ``torch.distributed`` is used for
+    the rendezvous only (the 128-byte RCCL id travels by ``broadcast_object_list``)."""
+    native = True
+
+    def __init__(self, flat, ranges, device, comm_dtype=None, cast_ranges=None, force=False, max_bucket_elems=None):
+        super().__init__(flat, ranges, max_bucket_elems=max_bucket_elems, force=force, comm_dtype=comm_dtype, cast_ranges=cast_ranges)
+        from ._abi import VitaeError, lib
+        import ctypes
+        self._lib, self.device = lib, torch.device(device)
+        if not lib.vitae_ddp_available():
+            raise VitaeError('RCCL could not be bound (librccl.so): the native gradient exchange is unavailable')
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        rank = dist.get_rank() if world > 1 else 0
+        buf = ctypes.create_string_buffer(128)
+        if rank == 0:
+            lib.vitae_ddp_unique_id(ctypes.addressof(buf))
+        if world > 1:
+            box = [bytes(buf.raw)]
+            dist.broadcast_object_list(box, src=0)
+            buf = ctypes.create_string_buffer(box[0], 128)
+        with torch.cuda.device(self.device):
+            lib.vitae_ddp_init(ctypes.addressof(buf), world, rank)
+        self._world = world
+        self.comm_stream = torch.cuda.Stream(device=self.device)
+
+    @property
+    def world_size(self) -> int:
+        return self._world
+
+    @property
+    def active(self) -> bool:
+        return self._world > 1 or self.force
+
+    def launch(self, bucket: int):
+        if not self.active:
+            return
+        cs = torch.cuda.current_stream(self.device).cuda_stream
+        for s, e in self.ranges[bucket]:
+            if e <= s:
+                continue
+            if self.wire is not None:
+                if self.cast_ranges is None:
+                    self.wire[s:e].copy_(self.flat[s:e])
+                else:
+                    for c0, c1 in self.cast_ranges:
+                        a, b = max(c0, s), min(c1, e)
+                        if b > a:
+                            self.wire[a:b].copy_(self.flat[a:b])
+                self._lib.vitae_ddp_allreduce_bucket(self.wire.data_ptr() + 2 * s, e - s, 1, cs, self.comm_stream.cuda_stream)
+            else:
+                self._lib.vitae_ddp_allreduce_bucket(self.flat.data_ptr() + 4 * s, e - s, 0, cs, self.comm_stream.cuda_stream)
+            self.pending.append((None, s, e, bucket))
+
+    def _join(self):
+        self._lib.vitae_ddp_wait(torch.cuda.current_stream(self.device).cuda_stream, self.comm_stream.cuda_stream)
+
+    def wait(self, copy_back: bool = True):
+        if self.pending:
+            self._join()
+        for _, s, e, _b in self.pending:
+            if self.wire is not None and copy_back:
+                self.flat[s:e].copy_(self.wire[s:e])
+        self.pending.clear()
+
+    def wait_bucket(self, bucket: int, copy_back: bool = True):
+        """Buckets complete in launch order on the one communication stream: joining it covers this bucket."""
+        mine = [p for p in self.pending if p[3] == bucket]
+        if mine:
+            self._join()
+        for _, s, e, _b in mine:
+            if self.wire is not None and copy_back:
+                self.flat[s:e].copy_(self.wire[s:e])
+        self.pending = [p for p in self.pending if p[3] != bucket]
+
+
 def allreduce_mean_now(reducer: "GradBucketReducer"):
     """Generic (non-fused) route: all-reduce every bucket and leave the MEAN of the per-rank gradients in the arena.  The
     fused step folds 1/world into the loss multipliers instead; here the gradients were produced unscaled, so they are

@@ -208,9 +208,40 @@ class _StepRunner:
         sl = self.slot
         self.eng.train_phase(k, sl.v1, sl.v2, sl.noise, self.mask_ratio, update=self.update, accumulate=self.accumulate)
 
-    def _capture(self, groups):
+    def _exchange(self):
+        red = self.model._reducer
+        return red is not None and red.active and self.update
+
+    def _after_phase(self, i):
+        """Data parallel: bucket i is final after phase i — launch its all-reduce; once it has landed its matrices are stepped
+        on the optimiser stream underneath the next backward phases (the reduced values are read from the wire buffer when it
+        is bf16); after the last backward phase the token / vector tail goes and everything is joined."""
+        eng, red = self.eng, self.model._reducer
+        nph = eng.N_PHASES
+        if i >= nph - 1:
+            return
+        bucket_opt = eng._ddp_bucket_opt
+        red.launch(i)
+        if bucket_opt:
+            with torch.cuda.stream(eng.oside):
+                red.wait_bucket(i, copy_back=eng.grads_wire16 is None)
+            eng._opt_bucket(i, wait_main=False)
+        if i == nph - 2:
+            red.launch(nph - 1)       # tokens + vectors
+            red.wait(copy_back=eng.grads_wire16 is None)
+            if bucket_opt:
+                torch.cuda.current_stream(eng.device).wait_stream(eng.oside)
+
+    def _run_group(self, grp, inside):
+        for k in grp:
+            self._phase(k)
+            if inside:
+                self._after_phase(k)
+
+    def _capture(self, groups, inside):
         """Warm up once (loads code objects, sizes the workspace; state restored afterwards), then
-        capture each group of phases as one HIP graph."""
+        capture each group of phases as one HIP graph.  ``inside``: the gradient exchange is part of the launch list (the
+        RCCL C-ABI reducer), i.e. captured with it."""
         eng = self.eng
         keep = [eng.params, eng.grads] + ([eng.opt_state['exp_avg'], eng.opt_state['exp_avg_sq']] if eng.opt_state else [])
         keep += [t for k, t in eng.buffers.items() if k.startswith('predictor.1.')]
@@ -222,8 +253,7 @@ class _StepRunner:
         side = torch.cuda.Stream(device=eng.device)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            for k in range(eng.N_PHASES):
-                self._phase(k)
+            self._run_group(range(eng.N_PHASES), inside)
         cur.wait_stream(side)
         for t, s in zip(keep, snap):
             t.copy_(s)
@@ -234,19 +264,21 @@ class _StepRunner:
         for grp in groups:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=side, capture_error_mode='thread_local'):
-                for k in grp:
-                    self._phase(k)
+                self._run_group(grp, inside)
             graphs.append(g)
         self.graphs[self._gkey] = graphs
 
     def run(self):
         """Enqueue one optimisation step.  Single process: one graph (or one eager launch list).
         Data parallel: every backward phase is followed by the asynchronous all-reduce of the gradient bucket
-        it completes, then wait + grad-norm/AdamW (no exchange on gradient-accumulation micro-steps)."""
+        it completes, then wait + grad-norm/AdamW (no exchange on gradient-accumulation micro-steps).  With torch's
+        process group the collectives are host-issued between per-phase graphs; with the RCCL C-ABI reducer they are nodes
+        of ONE graph."""
         eng, red = self.eng, self.model._reducer
-        exchange = red is not None and red.active and self.update
+        exchange = self._exchange()
+        inside = exchange and getattr(red, 'native', False)
         nph = eng.N_PHASES
-        groups = [[k] for k in range(nph)] if exchange else [list(range(nph))]
+        groups = [[k] for k in range(nph)] if (exchange and not inside) else [list(range(nph))]
         eng._wire_ready = exchange and eng.grads_wire16 is not None    # read at launch / capture time of the last phase
         eng._ddp_active = exchange          # buckets change after their phase (all-reduce): the runner steps them below
         bucket_opt = exchange and eng.overlap_optimizer and eng.opt_state is not None
@@ -259,27 +291,15 @@ class _StepRunner:
             self._ws_gen = eng.ws_gen
         eng._alloc(self.B, self.mask_ratio)            # this runner's workspace is the current one (replays bypass forward())
         if self.use_graph and self.graphs.get(self._gkey) is None:
-            self._capture(groups)
+            self._capture(groups, inside)
         graphs = self.graphs.get(self._gkey)
         for i, grp in enumerate(groups):
             if self.use_graph:
                 graphs[i].replay()
             else:
-                for k in grp:
-                    self._phase(k)
-            if exchange and i < nph - 1:
-                red.launch(i)                 # bucket i is final after phase i
-                if bucket_opt:
-                    # once bucket i's all-reduce has landed its matrices are stepped on the optimiser stream, underneath
-                    # the next backward phases (the reduced values are read from the wire buffer when it is bf16)
-                    with torch.cuda.stream(eng.oside):
-                        red.wait_bucket(i, copy_back=eng.grads_wire16 is None)
-                    eng._opt_bucket(i, wait_main=False)
-                if i == nph - 2:
-                    red.launch(nph - 1)       # tokens + vectors
-                    red.wait(copy_back=eng.grads_wire16 is None)
-                    if bucket_opt:
-                        torch.cuda.current_stream(eng.device).wait_stream(eng.oside)
+                self._run_group(grp, inside)
+            if exchange and not inside:
+                self._after_phase(i)
         sl.free = torch.cuda.Event()
         sl.free.record(main)
 
@@ -412,12 +432,29 @@ class MaskedAutoencoderViT(nn.Module):
                 self.decoder_pos_embed.data.reshape(eng.buffers['decoder_pos_embed'].shape))
         return out
 
-    def enable_data_parallel(self, device=None, group=None, force=False, comm_dtype=None, enc_chunks=3):
+    def enable_data_parallel(self, device=None, group=None, force=False, comm_dtype=None, enc_chunks=3, native=None):
         """One process per GPU: broadcast rank 0's replica and all-reduce gradient buckets over RCCL
         (overlapped with backward) inside the fused step.  No-op for a single process.
         ``comm_dtype=torch.bfloat16`` sends the gradients rounded to bf16 (half the bytes on xGMI);
-        ``enc_chunks`` = number of encoder gradient buckets."""
+        ``enc_chunks`` = number of encoder gradient buckets.  ``native`` (default: environment VITAE_DDP_NATIVE=1): exchange
+        through the C ABI (``vitae_ddp_*``: RCCL on a side HIP stream, captured inside the step graph) instead of through
+        torch.distributed's process group (collectives issued by the host between per-phase graphs)."""
         from .. import ddp
+        if native is None:
+            native = os.environ.get('VITAE_DDP_NATIVE', '0') == '1'
+        if native and (ddp.is_distributed() or force):
+            eng = self._ensure_engine(torch.device(device) if device is not None else next(self.parameters()).device)
+            ddp.broadcast_parameters(eng, 0, group)
+            eng.set_backward_chunks(enc_chunks)
+            self._reducer = ddp.RcclBucketReducer(eng.grads, ddp.engine_bucket_ranges(eng), eng.device, comm_dtype=comm_dtype,
+                                                  force=force)
+            wired = self._reducer.wire is not None and self._reducer.active
+            if wired:
+                eng.grads_wire16 = self._reducer.wire
+                self._reducer.cast_ranges = eng.wire_uncovered_ranges()
+            eng.grads_wire16 = self._reducer.wire if wired else None
+            self._runners.clear()
+            return self._reducer
         if not ddp.is_distributed() and not (force and torch.distributed.is_initialized()):
             self._reducer = None
             if self._engine is not None:
