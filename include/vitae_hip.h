@@ -35,6 +35,7 @@ extern "C" {
 #define VITAE_EPI_GELU 1      /* aux <- pre-activation, out <- exact-erf GELU (nn.GELU, model/vit.py:85-92) */
 #define VITAE_EPI_DGELU 2     /* out <- acc * GELU'(aux) */
 #define VITAE_EPI_RELU_MASK 3 /* out <- aux > 0 ? acc : 0 */
+#define VITAE_EPI_RELU 4      /* out <- max(acc + bias, 0) (vitae_gemm_glds only; no aux) */
 
 /* device-resident hyper-parameter block `hp` (float[VITAE_HP_COUNT]) */
 #define VITAE_HP_LR 0
@@ -216,6 +217,20 @@ int vitae_decoder_assemble_fwd(const float* e, const float* mask_token, const fl
  * LDS-DMA GEMM); dmask_token_accum[Dd] += sum of dxd over the masked positions.  One launch. */
 int vitae_decoder_assemble_bwd(const float* dxd, const int* ids_shuffle, float* de, void* de_bf16, float* dmask_token_accum,
                                int B, int L, int keep, int Dd, void* stream);
+
+/* ---- perceptual-loss hook, forward only (model/model_utils/perceptual_loss.py:46-77; a no-gradient logging term,
+ * model/vit_autoenc.py:229-230).  VGG16's convolutions run as vitae_gemm_glds (bias + VITAE_EPI_RELU) over im2col matrices in
+ * NHWC bf16; these are the index kernels around them.
+ * im2col_first: every (batch, z) slice of ONE channel of the predicted and of the target volume [B, C, Z, H, W] -> rows
+ *   [2 * n_img * H * W, 64] holding the 3x3 neighbourhood (9 taps, zero padded to K = 64), images img0 .. img0 + n_img - 1 of
+ *   the prediction first, then the same images of the target;
+ * im2col: NHWC bf16 [n_img, H, W, Cin] -> [n_img * H * W, 9 * Cin], tap-major then channel;
+ * maxpool2: 2x2 stride 2; sqdiff: acc[0] += sum (a - b)^2 (double). */
+int vitae_percep_im2col_first(const float* vol_pred, const float* vol_target, void* A16, int B, int C, int channel, int Z, int H,
+                              int W, int img0, int n_img, void* stream);
+int vitae_percep_im2col(const void* in16, void* A16, long n_img, int H, int W, int Cin, void* stream);
+int vitae_percep_maxpool2(const void* in16, void* out16, long n_img, int H, int W, int C, void* stream);
+int vitae_percep_sqdiff(const void* a16, const void* b16, long n, double* acc, void* stream);
 
 /* ---- data-parallel gradient exchange (the reference itself only all-reduces logging scalars,
  * utils/misc.py:332-340) -------------------------------------------------------------------------------------------------

@@ -132,8 +132,10 @@ def test_cpu_forward_fails_loudly_instead_of_falling_back():
 
 
 def test_unsupported_options_are_rejected():
-    with pytest.raises(VitaeError):
-        vit_autoenc.mae_vit_tiny_patch16(volume_size=64, in_chans=1, patch_size=16, args=_args(perceptual_weight=1))
+    # a perceptual weight builds the VGG hook with the reference's keys (it was refused in round 1)
+    m = vit_autoenc.mae_vit_tiny_patch16(volume_size=64, in_chans=1, patch_size=16, args=_args(perceptual_weight=1))
+    assert 'perceptual_loss.slice3.14.weight' in m.state_dict()
+    assert not any(k.startswith('perceptual_loss.') for k, p in m.named_parameters() if p.requires_grad)
     with pytest.raises(VitaeError):
         vit_autoenc.mae_vit_tiny_patch16(volume_size=64, in_chans=1, patch_size=16, args=_args(), norm_pix_loss=True)
     with pytest.raises(NotImplementedError):

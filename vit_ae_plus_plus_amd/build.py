@@ -18,7 +18,7 @@ CSRC = os.path.join(PKG, 'csrc')
 OBJ = os.path.join(CSRC, '_obj')
 LIB = os.path.join(PKG, 'libvitae_hip.so')
 SOURCES = ['gemm.hip', 'gemm_bf16.hip', 'gemm_glds.hip', 'mlp_fused.hip', 'norm.hip', 'attention.hip', 'attention_mfma.hip', 'tokens.hip', 'loss.hip',
-           'optim.hip', 'input.hip', 'ddp.hip']
+           'optim.hip', 'input.hip', 'ddp.hip', 'percep.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast',
          '-I', os.path.join(ROOT, 'include'), '-I', CSRC]
 

@@ -97,6 +97,8 @@ __device__ __forceinline__ float epilogue_frag(const GArgs& p, const float (&v)[
                 x *= gelu_erf_grad(ax[q]);
             } else if (p.epi == VITAE_EPI_RELU_MASK) {
                 x = ax[q] > 0.f ? x : 0.f;
+            } else if (p.epi == VITAE_EPI_RELU) {
+                x = fmaxf(x, 0.f);
             }
             if (p.residual) x += rs[q];
             if (p.C) {
@@ -172,6 +174,9 @@ __device__ __forceinline__ void epilogue_rows(const GArgs& p, const float (&a)[N
             } else if (p.epi == VITAE_EPI_RELU_MASK) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) x[e] = ax[q][e] > 0.f ? x[e] : 0.f;
+            } else if (p.epi == VITAE_EPI_RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = fmaxf(x[e], 0.f);
             }
             if (p.residual) {
 #pragma unroll
@@ -531,7 +536,7 @@ extern "C" int vitae_gemm_glds(int a_kcontig, int b_kcontig, const void* A16, lo
                                const float* residual, long ldr, int epi, float* aux, long ldaux, int accumulate,
                                int split_k, float* splitk_ws, float* out_colsum_accum, void* stream) {
     if (!A16 || !B16 || (!C && !C16) || M <= 0 || N <= 0 || K <= 0) return VITAE_ERR_INVALID_ARG;
-    if (epi != VITAE_EPI_NONE && !aux) return VITAE_ERR_INVALID_ARG;
+    if (epi != VITAE_EPI_NONE && epi != VITAE_EPI_RELU && !aux) return VITAE_ERR_INVALID_ARG;
     if (K % BK) return VITAE_ERR_UNSUPPORTED_SHAPE;
     if ((long)M * (ldc > N ? ldc : N) >= (1L << 31) || (long)M * ldaux >= (1L << 31) || (long)M * ldr >= (1L << 31) ||
         (long)M * ldc16 >= (1L << 31))

@@ -26,6 +26,13 @@ from .model_utils.vit_helpers import get_3d_sincos_pos_embed
 from .vit import Block, PatchEmbed3D
 
 
+class _NoPerceptualLoss(nn.Module):
+    """perceptual_weight == 0: the term is zero whatever the network (reference vit_autoenc.py:229-230)."""
+
+    def forward(self, pred_vol, target_vol):
+        return torch.zeros((), device=pred_vol.device)
+
+
 class _MAEStep(torch.autograd.Function):
     """(anchor, model, view1, view2, noise, mask_ratio, edge_w) ->
     (losses[5], pred, mask, p1, p2).  Gradients flow to the parameters as a side effect
@@ -40,6 +47,12 @@ class _MAEStep(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         b, cfg, B = eng.buf, eng.cfg, view1.shape[0]
         losses = eng.losses[:4].clone()
+        if model.perceptual_weight:
+            # no-gradient logging term on (unpatchified prediction, target volume) — reference vit_autoenc.py:228-231;
+            # unpatchify(patchify(x)) == x, so the target volume is the input itself
+            percep = model.perceptual_weight * model.perceptual_loss(b['pred_vol'], view1)
+            losses[3] = percep
+            losses[0] = losses[0] + percep
         pred = b['predfull'][:, 1:, :]
         mask = b['mask'][:B]
         if cfg.contrastive:
@@ -333,12 +346,14 @@ class MaskedAutoencoderViT(nn.Module):
         p = self.patch_embed.patch_size[0]
         self.decoder_pred = nn.Linear(decoder_embed_dim, p ** 3 * in_chans, bias=True)
         self.sobel_filter3D = SobelFilter3d()
-        self.perceptual_loss = vgg_perceptual_loss(use_imagenet=getattr(args, 'use_imagenet', False))
         self.args = args
         self.perceptual_weight = 1 if args is None else args.perceptual_weight
-        if self.perceptual_weight:
-            raise VitaeError('perceptual_weight != 0 needs torchvision VGG16 + ckp-399.pth (out of scope, SURVEY D9); '
-                             'the reference configuration uses 0')
+        # reference vit_autoenc.py:55-58.  With weight 0 (the shipped configuration) the term is identically zero and the
+        # hook carries no VGG tensors, so state-dict keys equal SURVEY A.5; with a weight, the VGG16 feature stack is built
+        # (keys perceptual_loss.slice*.*, like the real reference) and the caller loads its weights — neither torchvision's
+        # nor the reference's ckp-399.pth exist here (parity with those weights unpinned).
+        self.perceptual_loss = (vgg_perceptual_loss(use_imagenet=getattr(args, 'use_imagenet', False)) if self.perceptual_weight
+                                else _NoPerceptualLoss())
         print(f"Using perceptual weight of {self.perceptual_weight}")
         self.norm_pix_loss = norm_pix_loss
         eps = getattr(self.norm, 'eps', 1e-6)
@@ -422,8 +437,9 @@ class MaskedAutoencoderViT(nn.Module):
         return r
 
     def load_state_dict(self, state_dict, strict=True, **kw):
-        # tolerate the real reference's extra VGG tensors (perceptual_loss.*), SURVEY §8b
-        sd = {k: v for k, v in state_dict.items() if not k.startswith('perceptual_loss.')}
+        # tolerate the real reference's extra VGG tensors (perceptual_loss.*) when the hook is off, SURVEY §8b
+        own = any(k.startswith('perceptual_loss.') for k in self.state_dict().keys())
+        sd = {k: v for k, v in state_dict.items() if own or not k.startswith('perceptual_loss.')}
         out = super().load_state_dict(sd, strict=strict, **kw)
         eng = self._engine
         if eng is not None:   # frozen tables are engine-side copies

@@ -224,7 +224,9 @@ def train_one_stage_epoch(model: torch.nn.Module, data_loader: Iterable, optimiz
         print('log_dir: {}'.format(log_writer.log_dir))
 
     fused = False
-    if _is_hip_mae(model) and device.type == 'cuda' and not getattr(args, 'no_fused_step', False):
+    # (a perceptual weight keeps the generic route: the VGG hook is evaluated outside the captured step)
+    if (_is_hip_mae(model) and device.type == 'cuda' and not getattr(args, 'no_fused_step', False)
+            and not getattr(model, 'perceptual_weight', 0)):
         model._ensure_engine(device)
         fused = fused_optim.adopt(optimizer, model) is not None
     if fused:
