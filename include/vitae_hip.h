@@ -104,6 +104,8 @@ int vitae_gemm_glds(int a_kcontig, int b_kcontig, const void* A16, long lda, con
                     long ldr, int epi, float* aux, long ldaux, int accumulate, int split_k, float* splitk_ws,
                     float* out_colsum_accum, void* stream);
 int vitae_gemm_glds_pick_split_k(int M, int N, int K);
+/* profiling hook (tools/gemm_phase_probe.py): 8 long long per workgroup; NULL = off */
+int vitae_gemm_glds_set_debug(void* buf);
 /* Backward of one nn.Linear on bf16 operands in one launch: dx / dx16 [M,K] = epi(dy16 W16), optional
  * dx_colsum_accum[k] += sum_m dx(m,k); dW[N,K] (+)= dy16^T x16 reduced over Mpad (>= M, multiple of 64) token
  * rows — rows M..Mpad-1 of dy16 and x16 must be zero. */

@@ -53,3 +53,22 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
     return cdf + x * pdf;
 }
+
+// Phi(x) (the GELU gate) and phi(x) from ONE exponential, branch-free: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 —
+// far below the bf16 rounding of the results it is used for; the exact-fp32 parity mode keeps erff above).  ocml's erff
+// costs ~140 clocks per value in a GEMM epilogue (32 values per lane were 5 us of a 21 us kernel); this is ~20 VALU
+// operations.  For x < 0 the tail form 0.5 * poly * e is used directly, so small gates keep their relative precision.
+__device__ __forceinline__ void gelu_gate(float x, float& cdf, float& pdf) {
+    const float ax = fabsf(x);
+    const float e = __expf(-0.5f * x * x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float tail = 0.5f * poly * t * e;          // 1 - Phi(|x|)
+    cdf = x >= 0.f ? 1.0f - tail : tail;
+    pdf = 0.39894228040143267794f * e;
+}
+__device__ __forceinline__ float gelu_fast(float x) { float c, d; gelu_gate(x, c, d); return x * c; }
+__device__ __forceinline__ float gelu_fast_grad(float x) { float c, d; gelu_gate(x, c, d); return fmaf(x, d, c); }

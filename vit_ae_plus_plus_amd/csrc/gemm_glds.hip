@@ -43,9 +43,12 @@ struct GArgs {
     int vec_epi;         // all epilogue arrays are 16-byte addressable by 4-column groups (N, the leading dimensions and the
                          // base pointers allow it): the tile goes through LDS and leaves row-major, 16 bytes per lane
     int tiles_m, tiles_n;
+    long long* dbg;      // optional (tools/gemm_phase_probe.py): 8 s_memtime stamps per workgroup
     int xcd_m;           // 0: an XCD owns column tiles tn = xcd (mod 8) and walks every row tile (its L2 holds 1/8 of B and all
                          // of A); 1: it owns row tiles tm = xcd (mod 8) instead — picked when A is the larger operand
 };
+
+long long* g_gemm_dbg = nullptr;
 
 // workgroups of one launch (per k-split) under either XCD mapping
 inline int glds_blocks(const GArgs& p) {
@@ -92,9 +95,9 @@ __device__ __forceinline__ float epilogue_frag(const GArgs& p, const float (&v)[
             float x = v[8 * half + q] + bias;
             if (p.epi == VITAE_EPI_GELU) {
                 p.aux[m * ldaux + n] = x;
-                x = gelu_erf(x);
+                x = gelu_fast(x);
             } else if (p.epi == VITAE_EPI_DGELU) {
-                x *= gelu_erf_grad(ax[q]);
+                x *= gelu_fast_grad(ax[q]);
             } else if (p.epi == VITAE_EPI_RELU_MASK) {
                 x = ax[q] > 0.f ? x : 0.f;
             } else if (p.epi == VITAE_EPI_RELU) {
@@ -167,10 +170,10 @@ __device__ __forceinline__ void epilogue_rows(const GArgs& p, const float (&a)[N
             if (p.epi == VITAE_EPI_GELU) {
                 *reinterpret_cast<f32x4*>(p.aux + m * ldaux + n) = x;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) x[e] = gelu_erf(x[e]);
+                for (int e = 0; e < 4; ++e) x[e] = gelu_fast(x[e]);
             } else if (p.epi == VITAE_EPI_DGELU) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) x[e] *= gelu_erf_grad(ax[q][e]);
+                for (int e = 0; e < 4; ++e) x[e] *= gelu_fast_grad(ax[q][e]);
             } else if (p.epi == VITAE_EPI_RELU_MASK) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) x[e] = ax[q][e] > 0.f ? x[e] : 0.f;
@@ -223,6 +226,9 @@ __device__ __forceinline__ void epilogue_rows(const GArgs& p, const float (&a)[N
 #ifndef VITAE_GLDS_NACC_BIG
 #define VITAE_GLDS_NACC_BIG 1
 #endif
+#ifndef VITAE_GLDS_INTERLEAVE
+#define VITAE_GLDS_INTERLEAVE 0  // (measured round 2: 4.91 vs 4.87 ms/step with it — the GEMMs mostly share a CU) DMA pieces of the stage being refilled are issued one by one between the MFMAs of a k-step
+#endif
 #ifndef VITAE_GLDS_NS_PAIR
 #define VITAE_GLDS_NS_PAIR 0     // > 0: stages of the 64x64 tiles inside the paired (dgrad + wgrad) launch.  Measured in the step
                                  // (ms): 2 stages (32 KB, four workgroups per CU) 5.85 although 7 % faster in the L2-warm
@@ -249,6 +255,10 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
     const int tm = p.xcd_m ? xcd + 8 * (local / p.tiles_n) : local % p.tiles_m;
     if (tn >= p.tiles_n || tm >= p.tiles_m) return;
     const int m0 = tm * BM, n0 = tn * BN;
+    auto stamp = [&](int i) {
+        if (p.dbg && threadIdx.x == 0) p.dbg[((long)zid * gridDim.x + bid) * 16 + i] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
     const int kbeg = zid * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
     const int nk = (kend - kbeg) / BK;
@@ -285,8 +295,17 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
         dma_tile<BM, A_KC, NW>(p.A, p.lda, p.M, m0, kbeg + t * BK, st, wave, lane);
         dma_tile<BN, B_KC, NW>(p.B, p.ldb, p.N, n0, kbeg + t * BK, st + A_BYTES, wave, lane);
     };
+    // one DMA instruction (1 KB) of the stage of tile t: pieces 0..NA-1 belong to A, the rest to B
+    constexpr int NA = pieces<BM, A_KC, NW>(), NB = pieces<BN, B_KC, NW>();
+    static_assert(NA + NB == G, "DMA pieces per wave and stage");
+    auto piece = [&](int t, int i) {
+        unsigned char* st = smem + (t % NST) * STAGE;
+        if (i < NA) dma_piece<BM, A_KC, NW>(p.A, p.lda, p.M, m0, kbeg + t * BK, st, wave, lane, i);
+        else dma_piece<BN, B_KC, NW>(p.B, p.ldb, p.N, n0, kbeg + t * BK, st + A_BYTES, wave, lane, i - NA);
+    };
     const int pre = min(nk, NST - 1);
     for (int t = 0; t < pre; ++t) issue(t);
+    stamp(1);
 
     for (int t = 0; t < nk; ++t) {
         // tile t must have landed: allow the (up to two) younger stages to stay in flight
@@ -295,8 +314,15 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
         else if (younger == 2) wait_vmcnt<2 * G>();
         else if (younger == 1) wait_vmcnt<G>();
         else wait_vmcnt<0>();
+        if (t == 4) stamp(8);
         __builtin_amdgcn_s_barrier();          // everyone's DMA pieces of tile t landed; tile t-1 fully consumed
-        if (t + NST - 1 < nk) issue(t + NST - 1);   // refills the stage tile t-1 used
+        if (t == 0) stamp(2);
+        if (t == 4) stamp(9);
+        const bool more = t + NST - 1 < nk;    // the stage tile t-1 used is refilled with tile t + NST - 1 ...
+#if !VITAE_GLDS_INTERLEAVE
+        if (more) issue(t + NST - 1);
+#endif
+        if (t == 4) stamp(10);
         const unsigned char* at = smem + (t % NST) * STAGE;
         const unsigned char* bt = at + A_BYTES;
         bf16x8 fa[BK / 16][FM], fb[BK / 16][FN];
@@ -319,15 +345,37 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
                 for (int f = 0; f < FN; ++f) frag_tie(fb[kk][f]);
             }
         }
+        if (t == 4 && p.dbg) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp(11); }
         __builtin_amdgcn_sched_barrier(0);
+        // ... one DMA piece after each MFMA: a piece occupies the wave while the texture addresser takes its 64 lanes
+        // (16-100 clocks), the matrix pipe runs beside it.  With ONE workgroup on a CU (every GEMM of the step with fewer
+        // than ~256 tiles) nobody else overlaps the two: issued as a block in front of the fragment reads, the pieces
+        // of a stage cost as much wave time as its MFMAs (measured on the fused MLP kernel).
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk)
 #pragma unroll
             for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
-                for (int fn = 0; fn < FN; ++fn)
+                for (int fn = 0; fn < FN; ++fn) {
                     acc[kk % NACC][fm * FN + fn] =
                         __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][fm], fb[kk][fn], acc[kk % NACC][fm * FN + fn], 0, 0, 0);
+#if VITAE_GLDS_INTERLEAVE
+                    constexpr int NMF = (BK / 16) * FM * FN;
+                    const int i = (kk * FM + fm) * FN + fn;
+                    // spread the G pieces over the NMF MFMAs (NMF >= G for every tile shape)
+                    if (i < G || (NMF < G && i == NMF - 1)) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (more) {
+                            piece(t + NST - 1, i);
+                            if (NMF < G && i == NMF - 1)
+                                for (int r = NMF; r < G; ++r) piece(t + NST - 1, r);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#endif
+                }
+        if (t == 3) stamp(12);
+        if (t == 4) stamp(13);
         if constexpr (RS) {
             if (rowsum) {
 #pragma unroll
@@ -338,6 +386,7 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
             }
         }
     }
+    stamp(3);
     if (RS && rowsum && l31 == 0) {
         // every column of accx holds the row sums of this workgroup's k-range
 #pragma unroll
@@ -376,6 +425,7 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
         int* flag = reinterpret_cast<int*>(smem);
         if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
+        stamp(4);
         if (*flag != p.splits - 1) return;
 #pragma unroll
         for (int f = 0; f < NF; ++f)
@@ -391,9 +441,12 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
         if (threadIdx.x == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     }
 
+    stamp(5);
     if constexpr (BM * BN <= 64 * 128 && NW == 4) {
         if (p.vec_epi) {
             epilogue_rows<BM, BN, NW, NF>(p, a, m0, n0, wm, wn, lane, smem);
+            stamp(6);
+            if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(7); }
             return;
         }
     }
@@ -557,6 +610,7 @@ extern "C" int vitae_gemm_glds(int a_kcontig, int b_kcontig, const void* A16, lo
     p.k_per_split = kps; p.splits = split_k;
     p.bias = bias; p.residual = residual; p.ldr = ldr; p.aux = aux; p.ldaux = ldaux;
     p.epi = epi; p.accumulate = accumulate; p.ws = splitk_ws; p.out_colsum = out_colsum_accum; p.a_rowsum = nullptr;
+    p.dbg = g_gemm_dbg;
     const Tile t = pick_tile(M, N);
     p.tiles_m = cdiv(M, t.bm); p.tiles_n = cdiv(N, t.bn);
     p.xcd_m = xcd_by_rows(M, N);
@@ -608,7 +662,7 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
     split_k = cdiv(N, kps);
     p1.M = M; p1.N = K; p1.K = N; p1.k_per_split = kps; p1.splits = split_k;
     p1.bias = nullptr; p1.residual = nullptr; p1.ldr = 0; p1.aux = aux; p1.ldaux = K; p1.epi = epi; p1.accumulate = dx_accumulate != 0;
-    p1.ws = splitk_ws; p1.out_colsum = dx_colsum_accum; p1.a_rowsum = nullptr;
+    p1.ws = splitk_ws; p1.out_colsum = dx_colsum_accum; p1.a_rowsum = nullptr; p1.dbg = nullptr; p2.dbg = nullptr;
     Tile t1 = pick_tile(M, K);
     if (t1.id == 3) t1 = Tile{64, 128, 1};      // the paired launch is 4-wave only
     p1.tiles_m = cdiv(M, t1.bm); p1.tiles_n = cdiv(K, t1.bn);
@@ -667,7 +721,7 @@ extern "C" int vitae_wgrad_group_glds(int n, const void* const* dy16, const void
         p.M = N[i]; p.N = K[i]; p.K = Mpad; p.k_per_split = Mpad; p.splits = 1;
         p.bias = nullptr; p.residual = nullptr; p.ldr = 0; p.aux = nullptr; p.ldaux = 0; p.epi = VITAE_EPI_NONE;
         p.accumulate = dw_accumulate; p.ws = nullptr; p.out_colsum = nullptr;
-        p.a_rowsum = dy_colsum ? dy_colsum[i] : nullptr;
+        p.a_rowsum = dy_colsum ? dy_colsum[i] : nullptr; p.dbg = nullptr;
         p.tiles_m = cdiv(N[i], 64); p.tiles_n = cdiv(K[i], 64);
         p.xcd_m = xcd_by_rows(N[i], K[i]);
         p.vec_epi = vec_epilogue_ok(p);
@@ -678,3 +732,7 @@ extern "C" int vitae_wgrad_group_glds(int n, const void* const* dy16, const void
     hipLaunchKernelGGL(gemm_glds_group_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, g);
     return vitae_launch_status();
 }
+
+// profiling hook (tools/gemm_phase_probe.py): with a device buffer of 8 long long per workgroup set, vitae_gemm_glds launches
+// record shader-clock stamps at their phase boundaries; NULL switches it off
+extern "C" int vitae_gemm_glds_set_debug(void* buf) { g_gemm_dbg = reinterpret_cast<long long*>(buf); return VITAE_OK; }

@@ -62,23 +62,6 @@ __device__ __forceinline__ int img_off(int kt, int m, int c, int hi) {
     return kt * (64 * 128) + m * 128 + ((c ^ swz<true, 8>(m)) << 4) + hi * 8;
 }
 
-// Phi(x) (the GELU gate) and phi(x) from ONE exponential: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the
-// bf16 rounding of the results) — branch-free, ~20 VALU operations instead of ocml's erff (the 32 values a lane owns cost
-// 5 us of a 21 us kernel with it).  The tail form 0.5 * poly * e is used directly for x < 0, so small gates keep their
-// relative precision.
-__device__ __forceinline__ void gelu_gate(float x, float& cdf, float& pdf) {
-    const float ax = fabsf(x);
-    const float e = __expf(-0.5f * x * x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    const float tail = 0.5f * poly * t * e;          // 1 - Phi(|x|)
-    cdf = x >= 0.f ? 1.0f - tail : tail;
-    pdf = 0.39894228040143267794f * e;
-}
-
 template <bool BWD, int NT>   // NT = d / 64
 __global__ __launch_bounds__(256) void mlp_fused_kernel(const MlpArgs p) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];   // the ONLY LDS object
