@@ -42,6 +42,8 @@ KNAMES = {'glds_pair': 'gemm_glds_pair_kernel<64,64,64,64> (csrc/gemm_glds.hip: 
           'glds_pair_wide': 'gemm_glds_pair_kernel<..,64,128> (csrc/gemm_glds.hip)',
           'glds_dgrad': 'gemm_glds_kernel<64,64,true,false> (csrc/gemm_glds.hip: dgrad of one Linear)',
           'glds_wgrad_group': 'gemm_glds_group_kernel (csrc/gemm_glds.hip: the four weight gradients of a block in one launch)',
+          'glds_slab': 'gemm_glds_kernel<64,64,true,true> in slab mode (csrc/gemm_glds.hip: split-K summed by the consuming LayerNorm)',
+          'glds_pair_slab': 'gemm_glds_pair_kernel<64,64,64,64> with the dgrad in slab mode (csrc/gemm_glds.hip)',
           'attn': 'attn_fwd_mfma_kernel / attn_bwd_fused_kernel (csrc/attention_mfma.hip)'}
 
 

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITAE_ABI_VERSION 23
+#define VITAE_ABI_VERSION 24
 
 /* matrix-core arithmetic of the dense contractions */
 #define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
@@ -106,6 +106,18 @@ int vitae_gemm_glds(int a_kcontig, int b_kcontig, const void* A16, long lda, con
 int vitae_gemm_glds_pick_split_k(int M, int N, int K);
 /* profiling hook (tools/gemm_phase_probe.py): 8 long long per workgroup; NULL = off */
 int vitae_gemm_glds_set_debug(void* buf);
+/* Split-K whose partial sums leave the launch as separate matrices ("slabs", z-th at slabs + z * slab_stride floats, each
+ * [M, N] fp32) and are summed by the LayerNorm that consumes the result anyway (vitae_layernorm_{fwd,bwd}_slabs) — the
+ * launch-boundary reduce: no tickets, no partial round trip inside the launch, no bias / residual / epilogue here.
+ * vitae_gemm_glds_slab_count(K, split_k) = the number of slabs produced (k-ranges are multiples of 64). */
+int vitae_gemm_glds_slab_count(int K, int split_k);
+int vitae_gemm_glds_slabs(int a_kcontig, int b_kcontig, const void* A16, long lda, const void* B16, long ldb, float* slabs,
+                          long slab_stride, int M, int N, int K, int split_k, void* stream);
+/* vitae_linear_bwd_pair_glds with the input gradient in slab form (dx_slabs[z][M, K], z over N-ranges of the reduction):
+ * for Linears whose input gradient goes straight into a LayerNorm backward (fc1, qkv). */
+int vitae_linear_bwd_pair_glds_slabs(const void* dy16, const void* w16, const void* x16, float* dx_slabs, long slab_stride,
+                                     float* dw, void* dw16, int M, int Mpad, int N, int K, float* dy_colsum_accum,
+                                     int dw_accumulate, int split_k, void* stream);
 /* Backward of one nn.Linear on bf16 operands in one launch: dx / dx16 [M,K] = epi(dy16 W16), optional
  * dx_colsum_accum[k] += sum_m dx(m,k); dW[N,K] (+)= dy16^T x16 reduced over Mpad (>= M, multiple of 64) token
  * rows — rows M..Mpad-1 of dy16 and x16 must be zero. */

@@ -754,3 +754,29 @@ def test_wgrad_group(lib):
     keep[0][2].fill_(float('nan'))
     lib.vitae_wgrad_group_glds(1, a_dy.ctypes.data, a_x.ctypes.data, a_dw.ctypes.data, None, None, Ns.ctypes.data, Ks.ctypes.data, Mp, 0, st())
     assert rel_err(keep[0][2], want[0][0]) < 1e-2
+
+
+@pytest.mark.parametrize('M,N,K,split', [(440, 768, 768, 3), (440, 768, 3072, 5), (868, 512, 2048, 4), (70, 512, 512, 1), (130, 1024, 4096, 16)])
+def test_gemm_slab_mode(lib, M, N, K, split):
+    """Split-K whose k-ranges leave the launch as separate matrices (summed by the consuming LayerNorm in the step, by torch here):
+    forward form and the paired backward form with the input gradient in slabs."""
+    Mp = (M + 63) // 64 * 64
+    x, w = _bf(gen(M, K, seed=1)).float(), _bf(gen(N, K, seed=2, scale=K ** -0.5)).float()
+    x16 = torch.zeros(Mp, K, dtype=torch.bfloat16, device='cuda'); x16[:M] = _bf(x).cuda()
+    w16 = dev(_bf(w))
+    n = lib.vitae_gemm_glds_slab_count(K, split)
+    assert 1 <= n <= split
+    slabs = torch.full((n, Mp, N), float('nan'), device='cuda')
+    lib.vitae_gemm_glds_slabs(1, 1, x16.data_ptr(), K, w16.data_ptr(), K, slabs.data_ptr(), Mp * N, M, N, K, split, st())
+    assert rel_err(slabs[:, :M].sum(0), x @ w.t()) < 1e-2
+    # backward pair: dx slabs over the N-ranges of the reduction, dW, bias gradient
+    dy = _bf(gen(M, N, seed=3)).float()
+    dy16 = torch.zeros(Mp, N, dtype=torch.bfloat16, device='cuda'); dy16[:M] = _bf(dy).cuda()
+    nb = lib.vitae_gemm_glds_slab_count(N, split)
+    dxs = torch.full((nb, Mp, K), float('nan'), device='cuda')
+    dw = torch.full((N, K), float('nan'), device='cuda')
+    db = torch.zeros(N, device='cuda')
+    lib.vitae_linear_bwd_pair_glds_slabs(dy16.data_ptr(), w16.data_ptr(), x16.data_ptr(), dxs.data_ptr(), Mp * K, dw.data_ptr(), None,
+                                         M, Mp, N, K, db.data_ptr(), 0, split, st())
+    assert rel_err(dxs[:, :M].sum(0), dy @ w) < 1e-2
+    assert rel_err(dw, dy.t() @ x) < 1e-2 and rel_err(db, dy.sum(0)) < 1e-2

@@ -43,6 +43,9 @@ struct GArgs {
     int vec_epi;         // all epilogue arrays are 16-byte addressable by 4-column groups (N, the leading dimensions and the
                          // base pointers allow it): the tile goes through LDS and leaves row-major, 16 bytes per lane
     int tiles_m, tiles_n;
+    long slab_stride;    // != 0 ("slab mode"): k-split z stores its partial tile at C + z * slab_stride and is done — the splits
+                         // are summed by the kernel that consumes the result anyway (vitae_layernorm_{fwd,bwd}_slabs: the
+                         // launch-boundary reduce); no tickets, no partial round trip inside the launch
     long long* dbg;      // optional (tools/gemm_phase_probe.py): 8 s_memtime stamps per workgroup
     int xcd_m;           // 0: an XCD owns column tiles tn = xcd (mod 8) and walks every row tile (its L2 holds 1/8 of B and all
                          // of A); 1: it owns row tiles tm = xcd (mod 8) instead — picked when A is the larger operand
@@ -404,7 +407,7 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
 #pragma unroll
         for (int r = 0; r < 16; ++r) a[f][r] = NACC == 2 ? acc[0][f][r] + acc[NACC - 1][f][r] : acc[0][f][r];
 
-    if (p.splits > 1) {
+    if (p.splits > 1 && p.slab_stride == 0) {
         // Split-K fix-up without a second launch: every split parks its partial tile (fragment order, coalesced),
         // takes a ticket, and the LAST one to arrive sums all partials in split order (bitwise reproducible whatever
         // the arrival order) and runs the epilogue.  Fences: release before the ticket, acquire after it.
@@ -442,9 +445,11 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
     }
 
     stamp(5);
+    GArgs q = p;
+    if (p.slab_stride != 0) q.C = p.C + (long)zid * p.slab_stride;      // slab mode: this split's own result matrix
     if constexpr (BM * BN <= 64 * 128 && NW == 4) {
         if (p.vec_epi) {
-            epilogue_rows<BM, BN, NW, NF>(p, a, m0, n0, wm, wn, lane, smem);
+            epilogue_rows<BM, BN, NW, NF>(q, a, m0, n0, wm, wn, lane, smem);
             stamp(6);
             if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(7); }
             return;
@@ -455,7 +460,7 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
         const int n = n0 + wn * (BN / 2) + fn * 32 + l31;
         float csum = 0.f;
 #pragma unroll
-        for (int fm = 0; fm < FM; ++fm) csum += epilogue_frag(p, a[fm * FN + fn], m0 + wm * (BM / WAVES_M) + fm * 32, n, hi);
+        for (int fm = 0; fm < FM; ++fm) csum += epilogue_frag(q, a[fm * FN + fn], m0 + wm * (BM / WAVES_M) + fm * 32, n, hi);
         if (p.out_colsum) {
             csum += __shfl_xor(csum, 32, 64);
             if (hi == 0 && n < p.N) atomicAdd(p.out_colsum + n, csum);
@@ -610,7 +615,7 @@ extern "C" int vitae_gemm_glds(int a_kcontig, int b_kcontig, const void* A16, lo
     p.k_per_split = kps; p.splits = split_k;
     p.bias = bias; p.residual = residual; p.ldr = ldr; p.aux = aux; p.ldaux = ldaux;
     p.epi = epi; p.accumulate = accumulate; p.ws = splitk_ws; p.out_colsum = out_colsum_accum; p.a_rowsum = nullptr;
-    p.dbg = g_gemm_dbg;
+    p.dbg = g_gemm_dbg; p.slab_stride = 0;
     const Tile t = pick_tile(M, N);
     p.tiles_m = cdiv(M, t.bm); p.tiles_n = cdiv(N, t.bn);
     p.xcd_m = xcd_by_rows(M, N);
@@ -662,7 +667,7 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
     split_k = cdiv(N, kps);
     p1.M = M; p1.N = K; p1.K = N; p1.k_per_split = kps; p1.splits = split_k;
     p1.bias = nullptr; p1.residual = nullptr; p1.ldr = 0; p1.aux = aux; p1.ldaux = K; p1.epi = epi; p1.accumulate = dx_accumulate != 0;
-    p1.ws = splitk_ws; p1.out_colsum = dx_colsum_accum; p1.a_rowsum = nullptr; p1.dbg = nullptr; p2.dbg = nullptr;
+    p1.ws = splitk_ws; p1.out_colsum = dx_colsum_accum; p1.a_rowsum = nullptr; p1.dbg = nullptr; p2.dbg = nullptr; p1.slab_stride = 0; p2.slab_stride = 0;
     Tile t1 = pick_tile(M, K);
     if (t1.id == 3) t1 = Tile{64, 128, 1};      // the paired launch is 4-wave only
     p1.tiles_m = cdiv(M, t1.bm); p1.tiles_n = cdiv(K, t1.bn);
@@ -721,7 +726,7 @@ extern "C" int vitae_wgrad_group_glds(int n, const void* const* dy16, const void
         p.M = N[i]; p.N = K[i]; p.K = Mpad; p.k_per_split = Mpad; p.splits = 1;
         p.bias = nullptr; p.residual = nullptr; p.ldr = 0; p.aux = nullptr; p.ldaux = 0; p.epi = VITAE_EPI_NONE;
         p.accumulate = dw_accumulate; p.ws = nullptr; p.out_colsum = nullptr;
-        p.a_rowsum = dy_colsum ? dy_colsum[i] : nullptr; p.dbg = nullptr;
+        p.a_rowsum = dy_colsum ? dy_colsum[i] : nullptr; p.dbg = nullptr; p.slab_stride = 0;
         p.tiles_m = cdiv(N[i], 64); p.tiles_n = cdiv(K[i], 64);
         p.xcd_m = xcd_by_rows(N[i], K[i]);
         p.vec_epi = vec_epilogue_ok(p);
@@ -736,3 +741,76 @@ extern "C" int vitae_wgrad_group_glds(int n, const void* const* dy16, const void
 // profiling hook (tools/gemm_phase_probe.py): with a device buffer of 8 long long per workgroup set, vitae_gemm_glds launches
 // record shader-clock stamps at their phase boundaries; NULL switches it off
 extern "C" int vitae_gemm_glds_set_debug(void* buf) { g_gemm_dbg = reinterpret_cast<long long*>(buf); return VITAE_OK; }
+
+// ---- split-K whose partial sums leave the launch as separate matrices ("slabs"), summed by the consumer ----------------
+// number of slabs vitae_gemm_glds_slabs / vitae_linear_bwd_pair_glds_slabs produce for a reduction length and a requested split
+extern "C" int vitae_gemm_glds_slab_count(int K, int split_k) {
+    if (K <= 0 || (K % BK)) return 0;
+    if (split_k < 1) split_k = 1;
+    const int kps = cdiv(cdiv(K, split_k), BK) * BK;
+    return cdiv(K, kps);
+}
+
+// slabs[z][M, N] (z-th at slabs + z * slab_stride floats) = A(:, k-range z) @ B(:, k-range z)^T: no bias, no residual, no
+// epilogue — the LayerNorm that consumes the sum adds those (vitae_layernorm_fwd_slabs) — and no in-launch reduction.
+extern "C" int vitae_gemm_glds_slabs(int a_kcontig, int b_kcontig, const void* A16, long lda, const void* B16, long ldb, float* slabs,
+                                     long slab_stride, int M, int N, int K, int split_k, void* stream) {
+    if (!A16 || !B16 || !slabs || M <= 0 || N <= 0 || K <= 0 || split_k < 1) return VITAE_ERR_INVALID_ARG;
+    if ((K % BK) || slab_stride < (long)M * N || (slab_stride & 3)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    if ((long)M * N >= (1L << 31)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    const int a_vec = a_kcontig ? K : M, b_vec = b_kcontig ? K : N;
+    if ((a_vec & 7) || (lda & 7) || (b_vec & 7) || (ldb & 7)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    if (((uintptr_t)A16 & 15) || ((uintptr_t)B16 & 15) || ((uintptr_t)slabs & 15)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    GArgs p;
+    p.A = reinterpret_cast<const __bf16*>(A16); p.lda = lda;
+    p.B = reinterpret_cast<const __bf16*>(B16); p.ldb = ldb;
+    p.C = slabs; p.ldc = N; p.C16 = nullptr; p.ldc16 = 0;
+    p.M = M; p.N = N; p.K = K;
+    const int kps = cdiv(cdiv(K, split_k), BK) * BK;
+    p.k_per_split = kps; p.splits = cdiv(K, kps);
+    p.bias = nullptr; p.residual = nullptr; p.ldr = 0; p.aux = nullptr; p.ldaux = 0; p.epi = VITAE_EPI_NONE; p.accumulate = 0;
+    p.ws = nullptr; p.out_colsum = nullptr; p.a_rowsum = nullptr; p.dbg = g_gemm_dbg; p.slab_stride = slab_stride;
+    p.tiles_m = cdiv(M, 64); p.tiles_n = cdiv(N, 64);
+    p.xcd_m = xcd_by_rows(M, N);
+    p.vec_epi = vec_epilogue_ok(p);
+    dim3 grid(glds_blocks(p), 1, p.splits);
+    launch<64, 64>(p, a_kcontig != 0, b_kcontig != 0, grid, (hipStream_t)stream);
+    return vitae_launch_status();
+}
+
+// Backward of one nn.Linear whose input gradient feeds a LayerNorm backward: dx leaves as split-K slabs
+// (dx_slabs[z][M, K] = dy16(:, n-range z) @ W16(n-range z, :)), dW[N, K] (+)= dy16^T x16 and the bias gradient as in
+// vitae_linear_bwd_pair_glds.  One launch, no in-launch reduction.
+extern "C" int vitae_linear_bwd_pair_glds_slabs(const void* dy16, const void* w16, const void* x16, float* dx_slabs, long slab_stride,
+                                                float* dw, void* dw16, int M, int Mpad, int N, int K, float* dy_colsum_accum,
+                                                int dw_accumulate, int split_k, void* stream) {
+    if (!dy16 || !w16 || !x16 || !dx_slabs || !dw || M <= 0 || N <= 0 || K <= 0 || split_k < 1) return VITAE_ERR_INVALID_ARG;
+    if ((N % BK) || (Mpad % BK) || (K & 7) || Mpad < M || slab_stride < (long)M * K || (slab_stride & 3)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    if ((long)(M > N ? M : N) * K >= (1L << 31)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    if (((uintptr_t)dy16 & 15) || ((uintptr_t)w16 & 15) || ((uintptr_t)x16 & 15) || ((uintptr_t)dx_slabs & 15)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    GArgs p1, p2;
+    p1.A = reinterpret_cast<const __bf16*>(dy16); p1.lda = N;
+    p1.B = reinterpret_cast<const __bf16*>(w16); p1.ldb = K;
+    p1.C = dx_slabs; p1.ldc = K; p1.C16 = nullptr; p1.ldc16 = 0;
+    const int kps = cdiv(cdiv(N, split_k), BK) * BK;
+    p1.M = M; p1.N = K; p1.K = N; p1.k_per_split = kps; p1.splits = cdiv(N, kps);
+    p1.bias = nullptr; p1.residual = nullptr; p1.ldr = 0; p1.aux = nullptr; p1.ldaux = 0; p1.epi = VITAE_EPI_NONE; p1.accumulate = 0;
+    p1.ws = nullptr; p1.out_colsum = nullptr; p1.a_rowsum = nullptr; p1.dbg = nullptr; p1.slab_stride = slab_stride;
+    p1.tiles_m = cdiv(M, 64); p1.tiles_n = cdiv(K, 64);
+    p1.xcd_m = xcd_by_rows(M, K);
+    p1.vec_epi = vec_epilogue_ok(p1);
+    p2.A = reinterpret_cast<const __bf16*>(dy16); p2.lda = N;
+    p2.B = reinterpret_cast<const __bf16*>(x16); p2.ldb = K;
+    p2.C = dw; p2.ldc = K; p2.C16 = reinterpret_cast<__bf16*>(dw16); p2.ldc16 = K;
+    p2.M = N; p2.N = K; p2.K = Mpad; p2.k_per_split = Mpad; p2.splits = 1;
+    p2.bias = nullptr; p2.residual = nullptr; p2.ldr = 0; p2.aux = nullptr; p2.ldaux = 0; p2.epi = VITAE_EPI_NONE;
+    p2.accumulate = dw_accumulate; p2.ws = nullptr; p2.out_colsum = nullptr; p2.a_rowsum = dy_colsum_accum; p2.dbg = nullptr;
+    p2.slab_stride = 0;
+    p2.tiles_m = cdiv(N, 64); p2.tiles_n = cdiv(K, 64);
+    p2.xcd_m = xcd_by_rows(N, K);
+    p2.vec_epi = vec_epilogue_ok(p2);
+    const int nb1 = glds_blocks(p1), nb2 = glds_blocks(p2);
+    dim3 grid(nb1 * p1.splits + nb2);
+    hipLaunchKernelGGL((gemm_glds_pair_kernel<64, 64, 64, 64, true>), grid, dim3(256), 0, (hipStream_t)stream, p1, p2, nb1);
+    return vitae_launch_status();
+}

@@ -129,6 +129,19 @@ class HipMAEEngine:
         self.fuse_mlp = (self.act16 and os.environ.get('VITAE_FUSE_MLP', '0') != '0'
                          and bool(lib.vitae_mlp_fused_supported(D, self.Hm)) and bool(lib.vitae_mlp_fused_supported(Dd, self.Hmd)))
         self.wgrad_side = os.environ.get('VITAE_WGRAD_SIDE', '1') != '0'
+        # split-K reduced at the launch boundary: the GEMMs whose result goes straight into a LayerNorm (proj and fc2 forward,
+        # the input gradients of fc1 and qkv backward) leave their k-splits as separate fp32 slabs and the LayerNorm sums them
+        # while it reads — no tickets / partial round trip inside the GEMM launch
+        self.slab_k = (self.act16 and not self.fuse_mlp and os.environ.get('VITAE_SLAB_SPLITK', '0') != '0'
+                       and D in (512, 768, 1024) and Dd in (512, 768, 1024))
+        # OPT-IN (VITAE_SLAB_SPLITK=1): measured round 2 at batch 4 / 8 / 32: 4.78 vs 4.81, 6.43 vs 6.30, 16.2 vs 16.0 ms/step.
+        # (per encoder block: forward 66 -> 61.6 us — proj 9.4 -> 7.6, fc2 16.4 -> 12.1, the two LayerNorms +0.5
+        # and +1.1; backward +3 us — the paired launches are not shortened by dropping the dgrad half's in-launch reduction, their
+        # wgrad half and the 900-workgroup grid set their duration, while the slab-summing LayerNorm backward costs 1.5 us
+        # more: so the backward keeps the in-launch reduction unless VITAE_SLAB_SPLITK_BWD=1)
+        self.slab_k_bwd = self.slab_k and os.environ.get('VITAE_SLAB_SPLITK_BWD', '0') != '0'
+        self._slabk_target = int(os.environ.get('VITAE_SLABK_TARGET', '384'))
+        self._slabk_min_kt = int(os.environ.get('VITAE_SLABK_MIN_KT', '4'))
         self.buffers = buffers   # pos_embed, decoder_pos_embed, BN running stats (device tensors)
         f32 = dict(dtype=torch.float32, device=device)
         # ring of pinned staging buffers: the host may run a few steps ahead of the stream, so the
@@ -307,6 +320,9 @@ class HipMAEEngine:
                         b[q + 'gout_16'], b[q + 'gmid_16'] = z16(Mp, d), z16(Mp, d)
                         b[q + 'dh_16'], b[q + 'dqkv_16'], b[q + 'hpre_16'] = z16(Mp, h), z16(Mp, 3 * d), z16(Mp, h)
                     b[pre + 'slabs'] = torch.empty(lib.vitae_mlp_fused_slabs(h), Mp, d, dtype=torch.float32, device=dev)
+                if self.slab_k:
+                    smax = max(self._slab_split(Me if pre == 'enc' else Md, d, k) for k in (d, h, 3 * d))
+                    b[pre + 'kslab'] = torch.empty(smax, Mp, d, dtype=torch.float32, device=dev)
             b['dn_16'] = z16(self.Mpd, Dd)
             b['dpred_16'] = z16(self.Mpd, P)
             b['patches_16'], b['dtok_16'] = z16(self.Mpt, P), z16(self.Mpt, D)
@@ -665,6 +681,96 @@ class HipMAEEngine:
         self._ln_bwd(dy, x_in, pre + 'norm1.', b[q + 'mean1'], b[q + 'rstd1'], dx, M, d, 1,
                      dx16=b[prev_q + 'gout_16'] if prev_q is not None else None, dx_colsum=prev_fc2_bias)
 
+    # ------------------------------------------------------------------ split-K slabs summed by the consuming LayerNorm
+    def _slab_split(self, M, N, K):
+        """k-splits of a slab-mode GEMM with an [M, N] result reduced over K: enough workgroups to fill the chip, at least
+        ``_slabk_min_kt`` 64-deep k-tiles each (the per-split fix-up is gone, so shorter splits than the in-launch reduction
+        allows pay off)."""
+        tiles = ((M + 63) // 64) * ((N + 63) // 64)
+        want = max(1, -(-self._slabk_target // tiles))
+        by_k = max(1, (K // 64) // self._slabk_min_kt)
+        return int(lib.vitae_gemm_glds_slab_count(K, min(want, by_k, 16)))
+
+    def _g16_fwd_slabs(self, x16, w, s, M, N, K):
+        """slabs of (x16 @ W16^T) in buf[s+'kslab']; -> number of slabs"""
+        sl = self.buf[s + 'kslab']
+        n = self._slab_split(M, N, K)
+        t = self._timed(2.0 * M * N * K, 'glds_slab')
+        lib.vitae_gemm_glds_slabs(1, 1, _ptr(x16), K, self._w16(w), K, sl.data_ptr(), sl.stride(0), M, N, K, n, self.stream)
+        if t is not None:
+            t.record()
+        return n
+
+    def _g16_bwd_slabs(self, dy16, w, x16, dw, s, M, Mpad, N, K, dy_colsum=None):
+        """dW (+)= dy16^T x16 and the slabs of dx = dy16 @ W16 in buf[s+'kslab'] (one paired launch); -> number of slabs"""
+        sl = self.buf[s + 'kslab']
+        n = self._slab_split(M, K, N)
+        t = self._timed(4.0 * M * N * K, 'glds_pair_slab')
+        lib.vitae_linear_bwd_pair_glds_slabs(_ptr(dy16), self._w16(w), _ptr(x16), sl.data_ptr(), sl.stride(0), _ptr(dw), self._wire_of(dw),
+                                             M, Mpad, N, K, _ptr(dy_colsum), int(self._accum), n, self.stream)
+        if t is not None:
+            t.record()
+        return n
+
+    def _ln_fwd_kslab(self, s, n, res, bias, pre, x_out, mean, rstd, M, D, y16, y=None):
+        sl = self.buf[s + 'kslab']
+        lib.vitae_layernorm_fwd_slabs(sl.data_ptr(), n, sl.stride(0), _ptr(res), _ptr(bias), _ptr(self.p[pre + 'weight']),
+                                      _ptr(self.p[pre + 'bias']), _ptr(x_out), _ptr(y), _ptr(y16), _ptr(mean), _ptr(rstd), M, D,
+                                      self.cfg.ln_eps, self.stream)
+
+    def _ln_bwd_kslab(self, s, n, x, pre, mean, rstd, dx, M, D, dx16, dx_colsum):
+        sl, g = self.buf[s + 'kslab'], self.g
+        lib.vitae_layernorm_bwd_slabs(sl.data_ptr(), n, sl.stride(0), _ptr(x), _ptr(self.p[pre + 'weight']), _ptr(mean), _ptr(rstd),
+                                      _ptr(dx), _ptr(g[pre + 'weight']), _ptr(g[pre + 'bias']), _ptr(dx16), _ptr(dx_colsum), M, D, 1,
+                                      self.stream)
+
+    def _block_fwd_slabk(self, pre, q, s, prev, x_in, Bs, N, d, heads, hd, hid):
+        """model/vit.py:139-144, 7 launches like ``_block_fwd16`` — but proj and fc2 are split-K GEMMs in slab mode and the two
+        LayerNorms sum their slabs (+ bias + residual).  ``prev`` = (state-dict prefix, workspace prefix, slab count) of the
+        block below, whose fc2 result still sits in the stack's slabs; None for the first block.  -> this block's fc2 slab count"""
+        b, p, M = self.buf, self.p, Bs * N
+        self._scope = s
+        if prev is None:
+            self._ln_fwd(x_in, pre + 'norm1.', None, b[q + 'mean1'], b[q + 'rstd1'], M, d, y16=b[q + 'y1_16'])
+        else:
+            self._ln_fwd_kslab(s, prev[2], b[prev[1] + 'xmid'], p[prev[0] + 'mlp.fc2.bias'], pre + 'norm1.', x_in, b[q + 'mean1'],
+                               b[q + 'rstd1'], M, d, b[q + 'y1_16'])
+        self._g16_fwd(b[q + 'y1_16'], p[pre + 'attn.qkv.weight'], p[pre + 'attn.qkv.bias'], M, 3 * d, d, y=b[q + 'qkv'])
+        t = self._timed(4.0 * Bs * heads * N * N * hd, 'attn')
+        lib.vitae_sdpa_mfma_fwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(b[q + 'o_16']), _ptr(b[q + 'lse']), Bs, N, heads, hd,
+                                self.stream)
+        if t is not None:
+            t.record()
+        n = self._g16_fwd_slabs(b[q + 'o_16'], p[pre + 'attn.proj.weight'], s, M, d, d)
+        self._ln_fwd_kslab(s, n, x_in, p[pre + 'attn.proj.bias'], pre + 'norm2.', b[q + 'xmid'], b[q + 'mean2'], b[q + 'rstd2'], M, d,
+                           b[q + 'y2_16'])
+        self._g16_fwd(b[q + 'y2_16'], p[pre + 'mlp.fc1.weight'], p[pre + 'mlp.fc1.bias'], M, hid, d, y16=b[q + 'act_16'],
+                      epi=EPI_GELU, aux=b[q + 'hpre'])
+        n = self._g16_fwd_slabs(b[q + 'act_16'], p[pre + 'mlp.fc2.weight'], s, M, d, hid)
+        self._scope = None
+        return n
+
+    def _block_bwd_slabk(self, pre, q, s, x_in, Bs, N, d, heads, hd, hid, Mp, prev_fc2_bias):
+        """Backward of one block like ``_block_bwd16``; the input gradients of fc1 and qkv leave their paired launches as
+        slabs and are summed by the LayerNorm backward that consumes them."""
+        b, p, g, M = self.buf, self.p, self.g, Bs * N
+        self._scope = s
+        dx, dx16, dh16, do, dqkv, dqkv16 = b[s + 'dx'], b[s + 'dx_16'], b[s + 'dh_16'], b[s + 'do'], b[s + 'dqkv'], b[s + 'dqkv_16']
+        self._g16_bwd(dx16, p[pre + 'mlp.fc2.weight'], b[q + 'act_16'], g[pre + 'mlp.fc2.weight'], M, Mp, d, hid,
+                      dx16=dh16, epi=EPI_DGELU, aux=b[q + 'hpre'], dx_colsum=g[pre + 'mlp.fc1.bias'])
+        n = self._g16_bwd_slabs(dh16, p[pre + 'mlp.fc1.weight'], b[q + 'y2_16'], g[pre + 'mlp.fc1.weight'], s, M, Mp, hid, d)
+        self._ln_bwd_kslab(s, n, b[q + 'xmid'], pre + 'norm2.', b[q + 'mean2'], b[q + 'rstd2'], dx, M, d, dx16, g[pre + 'attn.proj.bias'])
+        self._g16_bwd(dx16, p[pre + 'attn.proj.weight'], b[q + 'o_16'], g[pre + 'attn.proj.weight'], M, Mp, d, d, dx=do)
+        t = self._timed(10.0 * Bs * heads * N * N * hd, 'attn')
+        lib.vitae_sdpa_mfma_bwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(do), _ptr(b[q + 'lse']), _ptr(dqkv), _ptr(dqkv16),
+                                None, _ptr(b['delta']), Bs, N, heads, hd, self.stream)
+        if t is not None:
+            t.record()
+        n = self._g16_bwd_slabs(dqkv16, p[pre + 'attn.qkv.weight'], b[q + 'y1_16'], g[pre + 'attn.qkv.weight'], s, M, Mp, 3 * d, d,
+                                dy_colsum=g[pre + 'attn.qkv.bias'])
+        self._ln_bwd_kslab(s, n, x_in, pre + 'norm1.', b[q + 'mean1'], b[q + 'rstd1'], dx, M, d, dx16, prev_fc2_bias)
+        self._scope = None
+
     # ------------------------------------------------------------------ transformer block
     def _block_fwd16(self, pre, q, x_in, x_out, Bs, N, d, heads, hd, hid):
         """model/vit.py:139-144 with bf16 GEMM operands written by their producers."""
@@ -810,7 +916,14 @@ class HipMAEEngine:
         ex = b['encx']
         lib.vitae_encoder_assemble_fwd(_ptr(b['tok']), _ptr(p['cls_token']), _ptr(self.buffers['pos_embed']),
                                        _ptr(b['ids_shuffle']), _ptr(ex[0]), Be, L, keep, D, st)
-        if self.fuse_mlp:
+        if self.slab_k:
+            prev = None
+            for i in range(cfg.depth):
+                n = self._block_fwd_slabk(f'blocks.{i}.', f'enc{i}.', 'enc', prev, ex[i], Be, Ne, D, cfg.num_heads, self.hd, self.Hm)
+                prev = (f'blocks.{i}.', f'enc{i}.', n)
+            self._ln_fwd_kslab('enc', prev[2], b[prev[1] + 'xmid'], p[prev[0] + 'mlp.fc2.bias'], 'norm.', ex[cfg.depth], b['lat_mean'],
+                               b['lat_rstd'], Me, D, b['latent_16'], y=b['latent'])
+        elif self.fuse_mlp:
             for i in range(cfg.depth):
                 self._block_fwd_fused(f'blocks.{i}.', f'enc{i}.', 'enc', (f'blocks.{i - 1}.', f'enc{i - 1}.') if i else None, ex[i],
                                       Be, Ne, D, cfg.num_heads, self.hd, self.Hm, self.Mpe)
@@ -835,7 +948,15 @@ class HipMAEEngine:
         dx_ = b['decx']
         lib.vitae_decoder_assemble_fwd(_ptr(b['e']), _ptr(p['mask_token']), _ptr(self.buffers['decoder_pos_embed']),
                                        _ptr(b['ids_restore']), _ptr(dx_[0]), B, L, keep, Dd, st)
-        if self.fuse_mlp:
+        if self.slab_k:
+            prev = None
+            for i in range(cfg.decoder_depth):
+                n = self._block_fwd_slabk(f'decoder_blocks.{i}.', f'dec{i}.', 'dec', prev, dx_[i], B, Nd, Dd, cfg.decoder_num_heads,
+                                          self.hdd, self.Hmd)
+                prev = (f'decoder_blocks.{i}.', f'dec{i}.', n)
+            self._ln_fwd_kslab('dec', prev[2], b[prev[1] + 'xmid'], p[prev[0] + 'mlp.fc2.bias'], 'decoder_norm.',
+                               dx_[cfg.decoder_depth], b['dn_mean'], b['dn_rstd'], Md, Dd, b['dn_16'])
+        elif self.fuse_mlp:
             for i in range(cfg.decoder_depth):
                 self._block_fwd_fused(f'decoder_blocks.{i}.', f'dec{i}.', 'dec',
                                       (f'decoder_blocks.{i - 1}.', f'dec{i - 1}.') if i else None, dx_[i], B, Nd, Dd,
@@ -848,7 +969,7 @@ class HipMAEEngine:
                 self._block_fwd(f'decoder_blocks.{i}.', f'dec{i}.', dx_[i], dx_[i + 1], B, Nd, Dd, cfg.decoder_num_heads,
                                 self.hdd, self.Hmd)
         if a16:
-            if not self.fuse_mlp:
+            if not (self.fuse_mlp or self.slab_k):
                 self._ln_fwd(dx_[cfg.decoder_depth], 'decoder_norm.', None, b['dn_mean'], b['dn_rstd'], Md, Dd, y16=b['dn_16'])
             self._g16_fwd(b['dn_16'], p['decoder_pred.weight'], p['decoder_pred.bias'], Md, P, Dd, y=b['predfull'])
         else:
@@ -953,7 +1074,10 @@ class HipMAEEngine:
                          dx16=b[f'dec{nd - 1}.gout_16'] if self.fuse_mlp else b['decdx_16'],
                          dx_colsum=g[f'decoder_blocks.{nd - 1}.mlp.fc2.bias'])
             for i in reversed(range(nd)):
-                if self.fuse_mlp:
+                if self.slab_k_bwd:
+                    self._block_bwd_slabk(f'decoder_blocks.{i}.', f'dec{i}.', 'dec', dx_[i], B, Nd, Dd, cfg.decoder_num_heads,
+                                          self.hdd, self.Hmd, self.Mpd, g[f'decoder_blocks.{i - 1}.mlp.fc2.bias'] if i > 0 else None)
+                elif self.fuse_mlp:
                     self._block_bwd_fused(f'decoder_blocks.{i}.', f'dec{i}.', 'dec', dx_[i], B, Nd, Dd, cfg.decoder_num_heads,
                                           self.hdd, self.Hmd, self.Mpd, f'dec{i - 1}.' if i > 0 else None,
                                           g[f'decoder_blocks.{i - 1}.mlp.fc2.bias'] if i > 0 else None)
@@ -1025,7 +1149,10 @@ class HipMAEEngine:
         self.stream = torch.cuda.current_stream(self.device).cuda_stream
         ex = self.buf['encx']
         for i in range(hi, lo - 1, -1):
-            if self.fuse_mlp:
+            if self.slab_k_bwd:
+                self._block_bwd_slabk(f'blocks.{i}.', f'enc{i}.', 'enc', ex[i], self.Be, self.Ne, cfg.embed_dim, cfg.num_heads,
+                                      self.hd, self.Hm, self.Mpe, self.g[f'blocks.{i - 1}.mlp.fc2.bias'] if i > 0 else None)
+            elif self.fuse_mlp:
                 self._block_bwd_fused(f'blocks.{i}.', f'enc{i}.', 'enc', ex[i], self.Be, self.Ne, cfg.embed_dim, cfg.num_heads,
                                       self.hd, self.Hm, self.Mpe, f'enc{i - 1}.' if i > 0 else None,
                                       self.g[f'blocks.{i - 1}.mlp.fc2.bias'] if i > 0 else None)
