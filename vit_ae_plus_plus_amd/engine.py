@@ -129,6 +129,7 @@ class HipMAEEngine:
         self.fuse_mlp = (self.act16 and os.environ.get('VITAE_FUSE_MLP', '0') != '0'
                          and bool(lib.vitae_mlp_fused_supported(D, self.Hm)) and bool(lib.vitae_mlp_fused_supported(Dd, self.Hmd)))
         self.wgrad_side = os.environ.get('VITAE_WGRAD_SIDE', '1') != '0'
+        self.target_fork = os.environ.get('VITAE_TARGET_FORK', 'start')
         # split-K reduced at the launch boundary: the GEMMs whose result goes straight into a LayerNorm (proj and fc2 forward,
         # the input gradients of fc1 and qkv backward) leave their k-splits as separate fp32 slabs and the LayerNorm sums them
         # while it reads — no tickets / partial round trip inside the GEMM launch
@@ -892,12 +893,20 @@ class HipMAEEngine:
         # --- target branch of the edge loss (blur + Sobel of the input, vit_autoenc.py:221-223) depends on the
         # data only: it runs on a side stream underneath the encoder/decoder and is joined before the edge MSE
         main = torch.cuda.current_stream(self.device)
-        self.side.wait_stream(main)
-        with torch.cuda.stream(self.side):
-            ss = self.side.cuda_stream
-            lib.vitae_gauss_blur_fwd(_ptr(view1), _ptr(b['blur_tmp']), _ptr(b['blurred']), self._taps_c, len(self.taps),
-                                     B * C, Lz, Hy, Wx, ss)
-            lib.vitae_sobel_edge_fwd(_ptr(b['blurred']), _ptr(b['edge_t']), None, None, B, C, Lz, Hy, Wx, ss)
+
+        def target_branch():
+            self.side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self.side):
+                ss = self.side.cuda_stream
+                lib.vitae_gauss_blur_fwd(_ptr(view1), _ptr(b['blur_tmp']), _ptr(b['blurred']), self._taps_c, len(self.taps),
+                                         B * C, Lz, Hy, Wx, ss)
+                lib.vitae_sobel_edge_fwd(_ptr(b['blurred']), _ptr(b['edge_t']), None, None, B, C, Lz, Hy, Wx, ss)
+
+        # where the branch forks off the main chain: 'start' (beside masking / gather / patch embedding), 'embed' (after the
+        # patch-embedding GEMM, beside the first encoder blocks), 'decoder' (beside the first decoder blocks)
+        fork = self.target_fork
+        if fork == 'start':
+            target_branch()
         # --- masking, kept-patch gather, patch embedding, sequence assembly
         lib.vitae_random_masking(_ptr(noise), _ptr(b['ids_shuffle']), _ptr(b['ids_restore']), _ptr(b['mask']),
                                  _ptr(b['ids_restore64']), Be, L, keep, st)
@@ -913,6 +922,8 @@ class HipMAEEngine:
             self._g16_fwd(pat16, p['patch_embed.proj.weight'], p['patch_embed.proj.bias'], Be * keep, D, P, y=b['tok'])
         else:
             self._lin_fwd(b['patches'], p['patch_embed.proj.weight'], p['patch_embed.proj.bias'], b['tok'], Be * keep, D, P)
+        if fork == 'embed':
+            target_branch()
         ex = b['encx']
         lib.vitae_encoder_assemble_fwd(_ptr(b['tok']), _ptr(p['cls_token']), _ptr(self.buffers['pos_embed']),
                                        _ptr(b['ids_shuffle']), _ptr(ex[0]), Be, L, keep, D, st)
@@ -940,6 +951,8 @@ class HipMAEEngine:
             with self._OnPredictorStream(self):
                 self._predictor_fwd(training, None)
             self._pred_pending = True
+        if fork == 'decoder':
+            target_branch()
         # --- decoder (view 1 only)
         if a16:
             self._g16_fwd(b['latent_16'], p['decoder_embed.weight'], p['decoder_embed.bias'], B * Ne, Dd, D, y=b['e'])
