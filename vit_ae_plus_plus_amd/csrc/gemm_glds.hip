@@ -124,9 +124,33 @@ __device__ __forceinline__ float epilogue_frag(const GArgs& p, const float (&v)[
 // LDS (the stage buffers are free by then) and re-read row-major: every lane owns four consecutive columns of a row, so
 // C, the bf16 copy, the saved pre-activation, the residual and the old C all move 16 bytes per lane (8 for bf16) in
 // 256-byte contiguous runs.  Loads of PB passes are issued together before the dependent stores, as in epilogue_frag.
+// Operands of the row-major epilogue that do not depend on the product (bias, residual), fetched at KERNEL START for 64x64
+// tiles: issued after the k-loop they cost one exposed memory latency (~800-1500 clocks of a ~5000-clock epilogue).
+struct EpiPre { f32x4 bias, res[4]; bool have; };
+
+template <int BM, int BN, int NW>
+__device__ __forceinline__ void epilogue_prefetch(const GArgs& p, int m0, int n0, EpiPre& e) {
+    constexpr int NT = 64 * NW, CG = BN / 4, RPP = NT / CG, PASSES = BM / RPP;
+    e.have = false;
+    if constexpr (BM == 64 && BN == 64 && NW == 4) {
+        static_assert(PASSES == 4, "prefetch geometry");
+        if (!p.vec_epi) return;
+        e.have = true;
+        const int cg = threadIdx.x % CG, r0 = threadIdx.x / CG;
+        const int n = n0 + 4 * cg, nc = n < p.N ? n : 0;
+        e.bias = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) e.bias = *reinterpret_cast<const f32x4*>(p.bias + nc);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            e.res[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.residual) e.res[q] = *reinterpret_cast<const f32x4*>(p.residual + min(m0 + r0 + q * RPP, p.M - 1) * (int)p.ldr + nc);
+        }
+    }
+}
+
 template <int BM, int BN, int NW, int NF>
 __device__ __forceinline__ void epilogue_rows(const GArgs& p, const float (&a)[NF][16], int m0, int n0, int wm, int wn,
-                                              int lane, unsigned char* smem) {
+                                              int lane, unsigned char* smem, const EpiPre& pre) {
     constexpr int WAVES_M = NW / 2, FN = BN / 64, FM = BM / (32 * WAVES_M);
     constexpr int LDT = BN + 4, NT = 64 * NW, CG = BN / 4, RPP = NT / CG, PASSES = BM / RPP, PB = BN > 64 ? 2 : 4;
     static_assert(NF == FM * FN && PASSES % PB == 0, "tile / thread geometry");
@@ -151,7 +175,8 @@ __device__ __forceinline__ void epilogue_rows(const GArgs& p, const float (&a)[N
     const bool need_aux = p.epi == VITAE_EPI_DGELU || p.epi == VITAE_EPI_RELU_MASK;
     const bool acc_c = p.C && p.accumulate;
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias && ncol) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+    if (pre.have) bias4 = pre.bias;
+    else if (p.bias && ncol) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
     f32x4 csum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int pb = 0; pb < PASSES; pb += PB) {
@@ -160,7 +185,10 @@ __device__ __forceinline__ void epilogue_rows(const GArgs& p, const float (&a)[N
         for (int q = 0; q < PB; ++q) {
             const int mc = min(m0 + r0 + (pb + q) * RPP, p.M - 1);
             if (need_aux) ax[q] = *reinterpret_cast<const f32x4*>(p.aux + mc * ldaux + nc);
-            if (p.residual) rs[q] = *reinterpret_cast<const f32x4*>(p.residual + mc * ldr + nc);
+            if (p.residual) {
+                if (pre.have) rs[q] = pre.res[(pb + q) & 3];
+                else rs[q] = *reinterpret_cast<const f32x4*>(p.residual + mc * ldr + nc);
+            }
             if (acc_c) co[q] = *reinterpret_cast<const f32x4*>(p.C + mc * ldc + nc);
         }
 #pragma unroll
@@ -246,12 +274,13 @@ template <int BM, int BN, int NW = 4, bool PAIR = false> struct GCfg {
     static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES, SMEM = NST * STAGE;
 };
 
-template <int BM, int BN, bool A_KC, bool B_KC, int NW = 4, bool RS = false, bool PAIR = false>
+template <int BM, int BN, bool A_KC, bool B_KC, int NW = 4, bool RS = false, bool PAIR = false, int PIPE = 0>
 __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, const int zid, unsigned char* smem) {
     constexpr int WAVES_M = NW / 2, NT = 64 * NW;          // waves: WAVES_M x 2
     constexpr int FM = BM / (32 * WAVES_M), FN = BN / 64, NF = FM * FN;
     constexpr int A_BYTES = GCfg<BM, BN, NW, PAIR>::A_BYTES, STAGE = GCfg<BM, BN, NW, PAIR>::STAGE;
-    constexpr int NST = GCfg<BM, BN, NW, PAIR>::NST;
+    constexpr int NST = PIPE ? PIPE : GCfg<BM, BN, NW, PAIR>::NST;
+    static_assert(!PIPE || (A_KC && B_KC && PIPE >= 4 && !RS), "the pipelined loop: k-contiguous operands, >= 4 stages");
     constexpr int G = (BM + BN) / (8 * NW);                // DMA instructions per wave per stage
     const int xcd = bid & 7, local = bid >> 3;
     const int tn = p.xcd_m ? local % p.tiles_n : xcd + 8 * (local / p.tiles_m);
@@ -306,10 +335,71 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
         if (i < NA) dma_piece<BM, A_KC, NW>(p.A, p.lda, p.M, m0, kbeg + t * BK, st, wave, lane, i);
         else dma_piece<BN, B_KC, NW>(p.B, p.ldb, p.N, n0, kbeg + t * BK, st + A_BYTES, wave, lane, i - NA);
     };
+    EpiPre epre;
+    epilogue_prefetch<BM, BN, NW>(p, m0, n0, epre);     // older than every DMA: the counted waits below never see these loads
     const int pre = min(nk, NST - 1);
     for (int t = 0; t < pre; ++t) issue(t);
     stamp(1);
 
+    if constexpr (PIPE != 0) {
+        // Software-pipelined k-loop for launches with ONE (or two) workgroups per CU, where nothing else overlaps a
+        // workgroup's phases: the fragments of tile t + 1 are read from LDS while the MFMAs of tile t run from registers
+        // (two fragment sets), so the LDS read latency (~250 clocks per step for a 64x64 tile: 32 KB through a 256 B/clk
+        // LDS) and the wait for the next tile's DMA are no longer in series with the MFMAs.  Needs tile t + 1 landed one
+        // step earlier than the classic loop, hence one more stage (NST = 4) to keep two tiles in flight.
+        bf16x8 f0a[BK / 16][FM], f0b[BK / 16][FN], f1a[BK / 16][FM], f1b[BK / 16][FN];
+        auto rd = [&](int t, bf16x8 (&fa)[BK / 16][FM], bf16x8 (&fb)[BK / 16][FN]) {
+            const unsigned char* at = smem + (t % NST) * STAGE;
+            const unsigned char* bt = at + A_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+#pragma unroll
+                for (int f = 0; f < FM; ++f) fa[kk][f] = frag<BM, true>(at, wm * (BM / WAVES_M) + f * 32, kk, lane);
+#pragma unroll
+                for (int f = 0; f < FN; ++f) fb[kk][f] = frag<BN, true>(bt, wn * (BN / 2) + f * 32, kk, lane);
+            }
+        };
+        auto mm = [&](bf16x8 (&fa)[BK / 16][FM], bf16x8 (&fb)[BK / 16][FN]) {
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk)
+#pragma unroll
+                for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+                    for (int fn = 0; fn < FN; ++fn)
+                        acc[kk % NACC][fm * FN + fn] =
+                            __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][fm], fb[kk][fn], acc[kk % NACC][fm * FN + fn], 0, 0, 0);
+        };
+        // tile 0
+        {
+            const int younger = min(nk - 1, NST - 2);
+            if (younger >= 2) wait_vmcnt<2 * G>();
+            else if (younger == 1) wait_vmcnt<G>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            stamp(2);
+            rd(0, f0a, f0b);
+        }
+        auto step = [&](int t, bf16x8 (&ca)[BK / 16][FM], bf16x8 (&cb)[BK / 16][FN], bf16x8 (&na)[BK / 16][FM],
+                        bf16x8 (&nb)[BK / 16][FN]) {
+            const bool next = t + 1 < nk;
+            if (next) {
+                // tile t + 1 must have landed; issued and younger: tiles t + 2 .. min(nk - 1, t + NST - 2)
+                if (min(nk - 2 - t, NST - 3) >= 1) wait_vmcnt<G>();
+                else wait_vmcnt<0>();
+            }
+            __builtin_amdgcn_s_barrier();      // everyone's pieces of tile t + 1 landed; the stage of tile t - 1 is free
+            if (t + NST - 1 < nk) issue(t + NST - 1);
+            if (next) rd(t + 1, na, nb);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(ca, cb);
+        };
+        int t = 0;
+        for (; t + 1 < nk; t += 2) {
+            step(t, f0a, f0b, f1a, f1b);
+            step(t + 1, f1a, f1b, f0a, f0b);
+        }
+        if (t < nk) step(t, f0a, f0b, f1a, f1b);
+    } else
     for (int t = 0; t < nk; ++t) {
         // tile t must have landed: allow the (up to two) younger stages to stay in flight
         const int younger = min(nk - 1 - t, NST - 2);
@@ -449,7 +539,7 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
     if (p.slab_stride != 0) q.C = p.C + (long)zid * p.slab_stride;      // slab mode: this split's own result matrix
     if constexpr (BM * BN <= 64 * 128 && NW == 4) {
         if (p.vec_epi) {
-            epilogue_rows<BM, BN, NW, NF>(q, a, m0, n0, wm, wn, lane, smem);
+            epilogue_rows<BM, BN, NW, NF>(q, a, m0, n0, wm, wn, lane, smem, epre);
             stamp(6);
             if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(7); }
             return;
@@ -472,6 +562,15 @@ template <int BM, int BN, bool A_KC, bool B_KC, int NW = 4>
 __global__ __launch_bounds__(64 * NW) void gemm_glds_kernel(const GArgs p) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[GCfg<BM, BN, NW>::SMEM];   // the ONLY LDS object
     gemm_glds_body<BM, BN, A_KC, B_KC, NW>(p, blockIdx.x, blockIdx.z, smem);
+}
+
+// forward form (both operands k-contiguous) with the software-pipelined k-loop: launches of at most ~2 workgroups per CU
+#ifndef VITAE_GLDS_PIPE_STAGES
+#define VITAE_GLDS_PIPE_STAGES 4
+#endif
+__global__ __launch_bounds__(256) void gemm_glds_pipe_kernel(const GArgs p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[VITAE_GLDS_PIPE_STAGES * GCfg<64, 64, 4>::STAGE];   // the ONLY LDS object
+    gemm_glds_body<64, 64, true, true, 4, false, false, VITAE_GLDS_PIPE_STAGES>(p, blockIdx.x, blockIdx.z, smem);
 }
 
 // dgrad (dy @ W: A k-contiguous, B = bf16 weights read row-contiguous) and wgrad (dy^T @ x: both operands
@@ -623,6 +722,11 @@ extern "C" int vitae_gemm_glds(int a_kcontig, int b_kcontig, const void* A16, lo
     if (split_k > 1 && (long)p.tiles_m * p.tiles_n > VITAE_GLDS_TICKETS) return VITAE_ERR_UNSUPPORTED_SHAPE;
     dim3 grid(glds_blocks(p), 1, split_k);
     hipStream_t st = (hipStream_t)stream;
+    static const int pipe_max = getenv("VITAE_GLDS_PIPE_MAX_WGS") ? atoi(getenv("VITAE_GLDS_PIPE_MAX_WGS")) : 512;
+    if (t.id == 0 && a_kcontig && b_kcontig && (long)grid.x * split_k <= pipe_max) {
+        hipLaunchKernelGGL(gemm_glds_pipe_kernel, grid, dim3(256), 0, st, p);
+        return vitae_launch_status();
+    }
     if (t.id == 3) launch<128, 128, 8>(p, a_kcontig != 0, b_kcontig != 0, grid, st);
     else if (t.id == 2) launch<128, 128>(p, a_kcontig != 0, b_kcontig != 0, grid, st);
     else if (t.id == 1) launch<64, 128>(p, a_kcontig != 0, b_kcontig != 0, grid, st);
