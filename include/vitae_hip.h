@@ -202,7 +202,8 @@ int vitae_sdpa_bwd(const float* qkv, const float* o, const float* d_o, const flo
  * fp32 softmax / accumulation); VITAE_ERR_UNSUPPORTED_SHAPE for other head dims. */
 int vitae_sdpa_mfma_fwd(const float* qkv, float* o, void* o_bf16, float* lse, int B, int N, int H, int head_dim,
                         void* stream);
-int vitae_sdpa_mfma_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv,
+int vitae_sdpa_mfma_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv /* may be NULL when
+                        dqkv_bf16 is given and the head fits the one-launch backward (N <= 512 at hd 32, 256 at hd 64) */,
                         void* dqkv_bf16, float* dqkv_colsum_accum /* [3*H*hd] += column sums of dqkv, or NULL */,
                         float* delta_ws, int B, int N, int H, int head_dim, void* stream);
 

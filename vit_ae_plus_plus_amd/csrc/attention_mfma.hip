@@ -538,7 +538,7 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(const float* __rest
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         f32x4 v = {acc[nt][4 * g], acc[nt][4 * g + 1], acc[nt][4 * g + 2], acc[nt][4 * g + 3]};
-                        *reinterpret_cast<f32x4*>(out + 32 * nt + 8 * g + 4 * hi) = v;
+                        if (dqkv) *reinterpret_cast<f32x4*>(out + 32 * nt + 8 * g + 4 * hi) = v;
                         if (dqkv16) {
                             bf16x4 v16;
 #pragma unroll
@@ -623,8 +623,10 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(const float* __rest
                         const int d = 32 * nt + 8 * g + 4 * hi;
                         f32x4 vk = {dk[nt][4 * g], dk[nt][4 * g + 1], dk[nt][4 * g + 2], dk[nt][4 * g + 3]};
                         f32x4 vv = {dv[nt][4 * g], dv[nt][4 * g + 1], dv[nt][4 * g + 2], dv[nt][4 * g + 3]};
-                        *reinterpret_cast<f32x4*>(out + D + d) = vk;
-                        *reinterpret_cast<f32x4*>(out + 2 * D + d) = vv;
+                        if (dqkv) {
+                            *reinterpret_cast<f32x4*>(out + D + d) = vk;
+                            *reinterpret_cast<f32x4*>(out + 2 * D + d) = vv;
+                        }
                         if (dqkv16) {
                             bf16x4 k16, v16;
 #pragma unroll
@@ -667,7 +669,8 @@ extern "C" int vitae_sdpa_mfma_fwd(const float* qkv, float* o, void* o_bf16, flo
 extern "C" int vitae_sdpa_mfma_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv,
                                    void* dqkv_bf16, float* dqkv_colsum_accum, float* delta_ws, int B, int N, int H,
                                    int head_dim, void* stream) {
-    if (!qkv || !o || !d_o || !lse || !dqkv || !delta_ws || B <= 0 || N <= 0 || H <= 0) return VITAE_ERR_INVALID_ARG;
+    // dqkv (fp32) may be NULL when the bf16 copy is all the caller consumes (the one-launch backward only)
+    if (!qkv || !o || !d_o || !lse || (!dqkv && !dqkv_bf16) || !delta_ws || B <= 0 || N <= 0 || H <= 0) return VITAE_ERR_INVALID_ARG;
     if ((((long)H * head_dim) & 3) || ((uintptr_t)qkv & 15) || ((uintptr_t)o & 15) || ((uintptr_t)d_o & 15) ||
         ((uintptr_t)dqkv & 15))
         return VITAE_ERR_UNSUPPORTED_SHAPE;
@@ -699,6 +702,7 @@ extern "C" int vitae_sdpa_mfma_bwd(const float* qkv, const float* o, const float
         }
         return vitae_launch_status();
     }
+    if (!dqkv) return VITAE_ERR_UNSUPPORTED_SHAPE;      // the two-kernel fallback writes the fp32 gradient
     if (head_dim == 32) {
         hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<32>), grid, dim3(256), 0, st, qkv, o, d_o, lse, dqkv, g16, dqkv_colsum_accum, delta_ws, N, H, scale);
         hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<32>), grid, dim3(256), 0, st, qkv, d_o, lse, delta_ws, dqkv, g16, dqkv_colsum_accum, N, H, scale);

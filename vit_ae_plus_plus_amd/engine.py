@@ -671,7 +671,7 @@ class HipMAEEngine:
                                       _ptr(g[pre + 'norm2.bias']), _ptr(b[q + 'gmid_16']), _ptr(g[pre + 'attn.proj.bias']), M, d, 1,
                                       self.stream)
         self._g16_dgrad(b[q + 'gmid_16'], p[pre + 'attn.proj.weight'], M, d, d, dx=do)
-        lib.vitae_sdpa_mfma_bwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(do), _ptr(b[q + 'lse']), _ptr(dqkv), _ptr(b[q + 'dqkv_16']),
+        lib.vitae_sdpa_mfma_bwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(do), _ptr(b[q + 'lse']), _ptr(self._dqkv32(dqkv, N, hd)), _ptr(b[q + 'dqkv_16']),
                                 None, _ptr(b['delta']), Bs, N, heads, hd, self.stream)
         self._wgrad_group([
             (b[q + 'gout_16'], b[q + 'act_16'], g[pre + 'mlp.fc2.weight'], None, d, hid),
@@ -763,7 +763,7 @@ class HipMAEEngine:
         self._ln_bwd_kslab(s, n, b[q + 'xmid'], pre + 'norm2.', b[q + 'mean2'], b[q + 'rstd2'], dx, M, d, dx16, g[pre + 'attn.proj.bias'])
         self._g16_bwd(dx16, p[pre + 'attn.proj.weight'], b[q + 'o_16'], g[pre + 'attn.proj.weight'], M, Mp, d, d, dx=do)
         t = self._timed(10.0 * Bs * heads * N * N * hd, 'attn')
-        lib.vitae_sdpa_mfma_bwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(do), _ptr(b[q + 'lse']), _ptr(dqkv), _ptr(dqkv16),
+        lib.vitae_sdpa_mfma_bwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(do), _ptr(b[q + 'lse']), _ptr(self._dqkv32(dqkv, N, hd)), _ptr(dqkv16),
                                 None, _ptr(b['delta']), Bs, N, heads, hd, self.stream)
         if t is not None:
             t.record()
@@ -789,6 +789,13 @@ class HipMAEEngine:
                       epi=EPI_GELU, aux=b[q + 'hpre'])
         self._g16_fwd(b[q + 'act_16'], p[pre + 'mlp.fc2.weight'], p[pre + 'mlp.fc2.bias'], M, d, hid, y=x_out, res=b[q + 'xmid'])
 
+    def _dqkv32(self, dqkv, N, hd):
+        """fp32 dqkv is write-only on the bf16-operand path (the qkv weight / input gradients read the bf16 copy): skip it
+        whenever the one-launch attention backward applies (its LDS budget: whole head resident)."""
+        NP = (N + 31) // 32 * 32
+        lds = 4 * NP * (hd + 8) * 2 + 2 * NP * 4 + 3 * hd * 4
+        return None if (lds <= 150 * 1024 and os.environ.get('VITAE_ATTN_BWD_FUSED', '1') != '0') else dqkv
+
     def _block_bwd16(self, pre, q, s, x_in, Bs, N, d, heads, hd, hid, Mp, prev_fc2_bias):
         """Backward of one block on bf16 operands.  On entry buf[s+'dx'] (fp32) and buf[s+'dx_16'] hold the
         output gradient and the fc2 bias gradient has already been produced by whoever wrote dx.
@@ -804,7 +811,7 @@ class HipMAEEngine:
                      dx_colsum=g[pre + 'attn.proj.bias'])
         self._g16_bwd(dx16, p[pre + 'attn.proj.weight'], b[q + 'o_16'], g[pre + 'attn.proj.weight'], M, Mp, d, d, dx=do)
         t = self._timed(10.0 * Bs * heads * N * N * hd, 'attn')
-        lib.vitae_sdpa_mfma_bwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(do), _ptr(b[q + 'lse']), _ptr(dqkv), _ptr(dqkv16),
+        lib.vitae_sdpa_mfma_bwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(do), _ptr(b[q + 'lse']), _ptr(self._dqkv32(dqkv, N, hd)), _ptr(dqkv16),
                                 None, _ptr(b['delta']), Bs, N, heads, hd, self.stream)
         if t is not None:
             t.record()
