@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/final2; mkdir -p $O
 ( time python bench.py ) > $O/bench_default.log 2>&1
-tail -1 $O/bench_default.log | grep '^{' > $O/bench_line.json
+grep '^{' $O/bench_default.log | tail -1 > $O/bench_line.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --no-cpu-baseline --no-extra --steps 30 --warmup 5 > $O/stats.log 2>&1
 python tools/timeline.py $(ls $O/stats/*/*kernel_trace.csv | head -1) 25 > $O/timeline.txt 2>&1
 cp $(ls $O/stats/*/*kernel_stats.csv | head -1) $O/kernel_stats.csv
