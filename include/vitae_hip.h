@@ -217,6 +217,9 @@ int vitae_random_masking(const float* noise, int* ids_shuffle, int* ids_restore,
  * order (model/vit.py:65,72-74 + model/vit_autoenc.py:147-148) */
 int vitae_gather_patches(const float* vol, const int* ids_shuffle, float* out, void* out_bf16, int B, int C, int Lz,
                          int Hy, int Wx, int p, int keep, void* stream);
+/* both views of the contrastive model (model/vit_autoenc.py:272,277) in one launch: ids_shuffle [2B, L], out [2B*keep, C*p^3] */
+int vitae_gather_patches_2views(const float* vol1, const float* vol2, const int* ids_shuffle, float* out, void* out_bf16, int B,
+                                int C, int Lz, int Hy, int Wx, int p, int keep, void* stream);
 /* x[B,keep+1,D]: + pos_embed, cls token (model/vit_autoenc.py:162-170) */
 int vitae_encoder_assemble_fwd(const float* tok, const float* cls_token, const float* pos_embed,
                                const int* ids_shuffle, float* x, int B, int L, int keep, int D, void* stream);

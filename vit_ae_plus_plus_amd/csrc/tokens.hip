@@ -39,7 +39,9 @@ __global__ __launch_bounds__(256) void random_masking_kernel(const float* __rest
 // ---------------------------------------------------------------- kept-patch gather (im2col rows)
 // out[(b*keep + j), c*p^3 + r*p^2 + s*p + q] = vol[b, c, gl*p + r, gh*p + s, gw*p + q]
 // for patch l = ids_shuffle[b, j] = (gl, gh, gw): the Conv3d weight's (C, p, p, p) flattening.
-__global__ __launch_bounds__(256) void gather_patches_kernel(const float* __restrict__ vol, const int* __restrict__ ids_shuffle,
+// (two views in one launch: samples b >= B1 come from vol2 — the contrastive model's second view, vit_autoenc.py:272,277)
+__global__ __launch_bounds__(256) void gather_patches_kernel(const float* __restrict__ vol, const float* __restrict__ vol2, int B1,
+                                                             const int* __restrict__ ids_shuffle,
                                                              float* __restrict__ out, __bf16* __restrict__ out16,
                                                              int C, int Lz, int Hy, int Wx, int p,
                                                              int g1, int g2, int L, int keep) {
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(256) void gather_patches_kernel(const float* __rest
     const int p4 = p / 4;
     const int P4 = C * p * p * p4;
     const long vstride = (long)Lz * Hy * Wx;
-    const float* vb = vol + (long)b * C * vstride;
+    const float* vb = b < B1 ? vol + (long)b * C * vstride : vol2 + (long)(b - B1) * C * vstride;
     const long rowoff = ((long)b * keep + j) * ((long)C * p * p * p);
     // blockIdx.z splits a patch row over several workgroups (keep * B alone is only ~200 of them)
     for (int i = blockIdx.z * 256 + threadIdx.x; i < P4; i += 256 * gridDim.z) {
@@ -228,8 +230,23 @@ extern "C" int vitae_gather_patches(const float* vol, const int* ids_shuffle, fl
     const int P4 = C * p * p * (p / 4);
     int zsplit = (keep * B < 1024) ? cdiv(1024, keep * B) : 1;
     if (zsplit > cdiv(P4, 256)) zsplit = cdiv(P4, 256);
-    hipLaunchKernelGGL(gather_patches_kernel, dim3(keep, B, zsplit), dim3(256), 0, (hipStream_t)stream, vol, ids_shuffle, out,
+    hipLaunchKernelGGL(gather_patches_kernel, dim3(keep, B, zsplit), dim3(256), 0, (hipStream_t)stream, vol, vol, B, ids_shuffle, out,
                        reinterpret_cast<__bf16*>(out_bf16), C, Lz, Hy, Wx, p, g1, g2, g0 * g1 * g2, keep);
+    return vitae_launch_status();
+}
+
+// both views of the contrastive model in one launch: rows [0, B*keep) from vol1 with ids_shuffle[0:B], rows [B*keep, 2*B*keep)
+// from vol2 with ids_shuffle[B:2B]
+extern "C" int vitae_gather_patches_2views(const float* vol1, const float* vol2, const int* ids_shuffle, float* out, void* out_bf16,
+                                           int B, int C, int Lz, int Hy, int Wx, int p, int keep, void* stream) {
+    if (!vol1 || !vol2 || !ids_shuffle || (!out && !out_bf16) || B <= 0 || C <= 0 || p <= 0 || keep <= 0) return VITAE_ERR_INVALID_ARG;
+    if ((p & 3) || Lz % p || Hy % p || Wx % p || ((uintptr_t)vol1 & 15) || ((uintptr_t)vol2 & 15)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    const int g0 = Lz / p, g1 = Hy / p, g2 = Wx / p;
+    const int P4 = C * p * p * (p / 4);
+    int zsplit = (keep * 2 * B < 1024) ? cdiv(1024, keep * 2 * B) : 1;
+    if (zsplit > cdiv(P4, 256)) zsplit = cdiv(P4, 256);
+    hipLaunchKernelGGL(gather_patches_kernel, dim3(keep, 2 * B, zsplit), dim3(256), 0, (hipStream_t)stream, vol1, vol2, B, ids_shuffle,
+                       out, reinterpret_cast<__bf16*>(out_bf16), C, Lz, Hy, Wx, p, g1, g2, g0 * g1 * g2, keep);
     return vitae_launch_status();
 }
 

@@ -875,7 +875,7 @@ class HipMAEEngine:
 
     # ------------------------------------------------------------------ forward
     def forward(self, view1: torch.Tensor, view2: Optional[torch.Tensor], noise: torch.Tensor, mask_ratio: float,
-                training: bool = True, defer_predictor_join: bool = False):
+                training: bool = True, defer_predictor_join: bool = False, defer_finalize: bool = False):
         """Everything up to the four loss scalars and (contrastive) p1/p2.  ``noise`` is [Be, L]
         (view-1 rows first), the torch.rand of vit_autoenc.py:139."""
         cfg = self.cfg
@@ -919,12 +919,11 @@ class HipMAEEngine:
                                  _ptr(b['ids_restore64']), Be, L, keep, st)
         a16 = self.act16
         pat, pat16 = (None, b['patches_16']) if a16 else (b['patches'], None)
-        lib.vitae_gather_patches(_ptr(view1), _ptr(b['ids_shuffle']), _ptr(pat), _ptr(pat16), B, C, Lz, Hy, Wx, ps, keep, st)
         if cfg.contrastive:
-            o = B * keep * P
-            lib.vitae_gather_patches(_ptr(view2), b['ids_shuffle'].data_ptr() + B * L * 4,
-                                     None if a16 else pat.data_ptr() + o * 4, pat16.data_ptr() + o * 2 if a16 else None,
-                                     B, C, Lz, Hy, Wx, ps, keep, st)
+            lib.vitae_gather_patches_2views(_ptr(view1), _ptr(view2), _ptr(b['ids_shuffle']), _ptr(pat), _ptr(pat16), B, C, Lz, Hy, Wx,
+                                            ps, keep, st)
+        else:
+            lib.vitae_gather_patches(_ptr(view1), _ptr(b['ids_shuffle']), _ptr(pat), _ptr(pat16), B, C, Lz, Hy, Wx, ps, keep, st)
         if a16:
             self._g16_fwd(pat16, p['patch_embed.proj.weight'], p['patch_embed.proj.bias'], Be * keep, D, P, y=b['tok'])
         else:
@@ -1000,11 +999,17 @@ class HipMAEEngine:
         torch.cuda.current_stream(self.device).wait_stream(self.side)   # edge map of the blurred target is ready
         lib.vitae_loss_fwd_fused(pred_ptr, pbs, _ptr(view1), _ptr(b['mask']), _ptr(b['edge_t']), _ptr(b['pred_vol']),
                                  _ptr(b['edge_p']), _ptr(self.acc), B, C, Lz, Hy, Wx, ps, st)
-        lib.vitae_loss_finalize(_ptr(self.acc), _ptr(self.hp), _ptr(self.losses), self.mask_sum, self.edge_count, st)
+        if not defer_finalize:
+            self.loss_finalize()
         if cfg.contrastive and not self._pred_pending:
             self._predictor_fwd(training, st)            # not overlapped: in program order on the main stream
         if not defer_predictor_join:
             self._predictor_join()
+
+    def loss_finalize(self):
+        """acc -> losses[0:4] (vit_autoenc.py:231-232); nothing on the step's dependent chain reads it"""
+        lib.vitae_loss_finalize(_ptr(self.acc), _ptr(self.hp), _ptr(self.losses), self.mask_sum, self.edge_count,
+                                torch.cuda.current_stream(self.device).cuda_stream)
 
     def _predictor_fwd(self, training: bool, st):
         """predictor on both views (vit_autoenc.py:280-284); launches on ``self.stream``."""
@@ -1346,13 +1351,15 @@ class HipMAEEngine:
         cfg = self.cfg
         n = self.enc_chunks
         if k == 0:
-            self.forward(view1, view2, noise, mask_ratio, training=True, defer_predictor_join=True)
+            # the zeroing of the token / vector gradient segment and the loss finalisation are not on the dependent chain:
+            # the first goes in front of the forward, the second behind the decoder backward (12 us between the loss kernels)
+            self.begin_grad_window(accumulate)
+            self.forward(view1, view2, noise, mask_ratio, training=True, defer_predictor_join=True, defer_finalize=True)
             if cfg.contrastive:
                 self.contrastive_loss_fwd()
-            self.begin_grad_window(accumulate)
-            if cfg.contrastive:
                 self.contrastive_loss_bwd()
             self.backward_dec(have_dp=cfg.contrastive)
+            self.loss_finalize()
             if update and self._optimizer_in_backward_ok():
                 self._opt_bucket(0)
         elif 1 <= k <= n:
