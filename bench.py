@@ -32,6 +32,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# Plumbing check only (never a reported number): VITAE_BENCH_ONE_GPU=1 lets N ranks share cuda:0 and exchange over gloo, so the
+# whole N > 1 flow (rank spawn, per-phase graphs, bucketed exchange, barriers, max-over-ranks clock, rank-0 instrumentation)
+# can be run on a one-GPU box.  The printed line says so in config.parallelism.
+ONE_GPU = os.environ.get('VITAE_BENCH_ONE_GPU') == '1'
 VOL, CH, PATCH = 96, 4, 16
 PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
 ALGO_GFLOP_PER_VOL = {'contr': 136.3, 'mae': 90.8}   # BASELINE.md §4 (fwd+bwd, reference formulation)
@@ -72,7 +76,7 @@ def spawn_command(args, argv, n_visible, port):
     than N GPUs are visible: a dp-N number from fewer ranks would be a lie."""
     if args.gpus <= 1 or 'WORLD_SIZE' in os.environ:
         return None
-    if n_visible < args.gpus:
+    if n_visible < args.gpus and not ONE_GPU:
         raise SystemExit(f'bench.py --gpus {args.gpus}: only {n_visible} GPU(s) visible on this node; refusing to report a '
                          f'{args.gpus}-GPU number from fewer ranks')
     return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
@@ -309,6 +313,8 @@ def main():
         sys.stdout = open(os.devnull, 'w')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (the HIP path has no CPU fallback)')
+    if ONE_GPU:
+        local = 0
     if torch.cuda.device_count() <= local:
         raise SystemExit(f'rank {rank}: no GPU {local} on this node ({torch.cuda.device_count()} visible)')
     torch.cuda.set_device(local)
@@ -319,7 +325,10 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
-        dist.init_process_group('nccl', device_id=dev)
+        if ONE_GPU:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     contr = args.model == 'contr'
@@ -428,7 +437,8 @@ def main():
                'config': {'workload': f'ViT-B/16^3 {"contrastive " if contr else ""}MAE full optimisation step '
                                       f'(fwd+loss+bwd+grad-norm+AdamW), synthetic BraTS-shape 96^3x4ch, batch '
                                       f'{args.batch}/GPU, mask 0.75 (BASELINE config 2{" / 3" if world > 1 else ""})',
-                          'global_batch': world * args.batch, 'parallelism': f'dp{world}',
+                          'global_batch': world * args.batch,
+                          'parallelism': f'dp{world}' + (' (PLUMBING CHECK: all ranks on ONE GPU, gloo transport)' if ONE_GPU else ''),
                           'rccl_ranks': dist.get_world_size() if (world > 1 or force_ddp) else 1,
                           'hip_graph': not args.no_graph, 'weights': 'product initialize_weights, seed 0',
                           'grad_allreduce': (f'{grad_comm}, {len(model._reducer.ranges)} buckets' if model._reducer is not None else None),
