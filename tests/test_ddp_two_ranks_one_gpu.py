@@ -140,3 +140,84 @@ def test_two_ranks_equal_gradient_accumulation(comm, use_graph):
         p.join(timeout=120)
     assert all(r[1] == 'ok' for r in res), res
     print('worst relative update error vs accumulation:', [r[2] for r in res if r[2] is not None])
+
+
+class _Writer:
+    log_dir = 'none'
+
+    def __init__(self):
+        self.rows = []
+
+    def add_scalar(self, tag, value, step):
+        self.rows.append((tag, float(value), int(step)))
+
+
+def _epoch_worker(rank, world, port, fused, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    try:
+        import argparse
+        torch.cuda.set_device(0)
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        from oracle import mae_ref as R
+        from vit_ae_plus_plus_amd.utils import misc
+        from vit_ae_plus_plus_amd.utils.train_one_epoch import train_one_stage_epoch
+        cfg = R.RefConfig(contrastive=True, **ACT16)
+        sd = R.init_state_dict(cfg, seed=11)
+        dev = torch.device('cuda', 0)
+        model = _build(cfg, sd, 'bf16')
+        model._ensure_engine(dev)
+        model.enable_data_parallel(dev, enc_chunks=2)
+        n_it = 23                                    # crosses one logging window (print_freq = 20) + a ragged tail
+        loader, noises = [], []
+        for i in range(n_it):
+            v1, v2 = R.synthetic_views((B, cfg.in_chans, *cfg.volume_size), seed=2000 + 10 * i + rank)
+            loader.append((v1, v2, torch.zeros(B)))
+            noises += R.masking_noise(B, cfg.num_patches, seed=3000 + 10 * i + rank)
+        model.set_masking_noise(*noises)
+        groups = R.param_groups(dict(model.named_parameters()), 0.05)
+        named = dict(model.named_parameters())
+        opt = torch.optim.AdamW([{'params': [named[n] for n in g['names']], 'weight_decay': g['weight_decay']} for g in groups],
+                                lr=LR, betas=(0.9, 0.95))
+        args = argparse.Namespace(accum_iter=1, mask_ratio=0.75, contr_weight=0.001, lr=LR, min_lr=0.0, warmup_epochs=0, epochs=50,
+                                  hip_graph=True, no_fused_step=not fused)
+        w = _Writer()
+        stats = train_one_stage_epoch(model, loader, opt, dev, 0, misc.NativeScalerWithGradNormCount(), log_writer=w, args=args,
+                                      edge_map_weight=0.01)
+        torch.cuda.synchronize()
+        # replicas identical, epoch statistics identical (synchronize_between_processes), logged scalars identical (they are
+        # means over the ranks, reduced once per logging window at the same iteration on every rank)
+        for k in KEYS:
+            v = model.state_dict()[k].detach().float().cpu()
+            both = [torch.zeros_like(v) for _ in range(world)]
+            dist.all_gather(both, v)
+            assert torch.equal(both[0], both[1]), k
+        mine = [stats, w.rows]
+        box = [None] * world
+        dist.all_gather_object(box, mine)
+        assert box[0][0] == box[1][0], (box[0][0], box[1][0])
+        assert len(box[0][1]) == 6 * n_it and box[0][1] == box[1][1]
+        q.put((rank, 'ok', float(stats['loss'])))
+    except Exception:   # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc(), None))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('fused', [True, False])
+def test_epoch_loop_two_ranks(fused):
+    """utils.train_one_epoch.train_one_stage_epoch under two ranks: the fused step exchanges gradient buckets inside its launch
+    list, the generic route between backward and optimizer.step() (NativeScalerWithGradNormCount.grad_sync); the metric
+    collective happens once per logging window at the same place on every rank (it used to be issued whenever a
+    read-back happened to be ready)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_epoch_worker, args=(r, 2, port, fused, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    assert all(r[1] == 'ok' for r in res), res
