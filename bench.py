@@ -442,6 +442,7 @@ def main():
                           'rccl_ranks': dist.get_world_size() if (world > 1 or force_ddp) else 1,
                           'hip_graph': not args.no_graph, 'weights': 'product initialize_weights, seed 0',
                           'grad_allreduce': (f'{grad_comm}, {len(model._reducer.ranges)} buckets' if model._reducer is not None else None),
+                          'ddp_streams_on_own_hw_queues': (getattr(model, '_stream_report', None) or {}).get('ok'),
                           'final_losses': [round(x, 6) for x in last[:6]]},
                'roofline': roof, 'cpu_baseline': cpu}
         out['config'].update(extra)

@@ -19,6 +19,7 @@ The reducer only needs a flat tensor and ranges, so it is exercised on CPU with 
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -27,6 +28,100 @@ import torch.distributed as dist
 
 def is_distributed() -> bool:
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+class _ModelledRing:
+    """DESIGN AID, never a measurement: on a world of ONE rank (``force``) the all-reduce costs nothing, so the shape of the
+    exchange (how many buckets, which one is exposed behind the backward, which hardware queue the collective sits on) cannot
+    be tuned on a one-GPU box.  With ``VITAE_DDP_SIM_BUSBW=<GB/s>`` every bucket additionally occupies the communication
+    stream for the time a ring all-reduce over ``VITAE_DDP_SIM_WORLD`` (default 8) ranks would take at that bus bandwidth,
+    2 (N-1)/N * bytes / busbw + a fixed latency.  It models the exposure only — not the CUs and HBM bandwidth RCCL's kernels
+    take from the step."""
+
+    def __init__(self, device):
+        self.busbw = float(os.environ['VITAE_DDP_SIM_BUSBW']) * 1e9
+        self.world = int(os.environ.get('VITAE_DDP_SIM_WORLD', '8'))
+        self.latency = float(os.environ.get('VITAE_DDP_SIM_LATENCY_US', '30')) * 1e-6
+        self.cycles_per_s = _spin_rate(device)
+
+    def occupy(self, nbytes: int):
+        """Called with the communication stream current."""
+        t = 2.0 * (self.world - 1) / self.world * nbytes / self.busbw + self.latency
+        torch.cuda._sleep(int(t * self.cycles_per_s))
+
+
+def _spin_rate(device) -> float:
+    """torch.cuda._sleep cycles per second."""
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(device)
+    with torch.cuda.device(device):
+        a.record()
+        torch.cuda._sleep(10_000_000)
+        b.record()
+    torch.cuda.synchronize(device)
+    return 10_000_000 / (a.elapsed_time(b) * 1e-3)
+
+
+class _StreamWork:
+    """Completion of a collective that ran on a stream of ours: waiting = the current stream waits for its event."""
+
+    def __init__(self, ev):
+        self.ev = ev
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.ev)
+
+
+def held_back_by(busy: "torch.cuda.Stream", candidates, spin_ms: float = 4.0, rate: Optional[float] = None):
+    """[bool per candidate]: does a kernel on the candidate stream wait for a long kernel on ``busy``?  HIP multiplexes its
+    streams over GPU_MAX_HW_QUEUES (4) hardware queues; two streams on one queue run strictly one after the other, so a
+    0.4 ms all-reduce kernel holds back every launch of a stream that shares its queue (tools/probes/hwq_probe.py: classes of
+    three streams each on this runtime; raising GPU_MAX_HW_QUEUES makes the whole step 3x slower).  Measured, not derived: a
+    spin on ``busy``, a tiny kernel + event on every candidate, event times compared."""
+    dev = busy.device
+    rate = rate or _spin_rate(dev)
+    x = torch.zeros(64, device=dev)
+    torch.cuda.synchronize(dev)
+    t0, done = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in candidates]
+    with torch.cuda.stream(busy):
+        t0.record()
+        torch.cuda._sleep(int(spin_ms * 1e-3 * rate))
+        done.record()
+    for s, ev in zip(candidates, evs):
+        if s is busy or s.cuda_stream == busy.cuda_stream:
+            continue
+        with torch.cuda.stream(s):
+            x.add_(1.0)
+            ev.record()
+    torch.cuda.synchronize(dev)
+    total = t0.elapsed_time(done)
+    return [True if (s is busy or s.cuda_stream == busy.cuda_stream) else t0.elapsed_time(ev) > 0.5 * total
+            for s, ev in zip(candidates, evs)]
+
+
+def pick_streams(device, main: Optional["torch.cuda.Stream"] = None, n_candidates: int = 8):
+    """(optimiser stream, communication stream, report): two streams that share a hardware queue neither with ``main`` (the
+    stream the step is launched on; default: the current one) nor with each other — so that the gradient all-reduce, the
+    per-bucket AdamW and the backward really run side by side.  Falls back to fresh streams if no such pair is found."""
+    device = torch.device(device)
+    main = main or torch.cuda.current_stream(device)
+    cand = [torch.cuda.Stream(device=device) for _ in range(n_candidates)]
+    x = torch.zeros(64, device=device)
+    for s in cand:                         # bind every candidate to its hardware queue (first use)
+        with torch.cuda.stream(s):
+            x.add_(1.0)
+    rate = _spin_rate(device)
+    with_main = held_back_by(main, cand, rate=rate)
+    free = [s for s, hb in zip(cand, with_main) if not hb]
+    if not free:
+        return cand[0], cand[1], {'ok': False, 'with_main': with_main}
+    opt = free[0]
+    with_opt = held_back_by(opt, free, rate=rate)
+    rest = [s for s, hb in zip(free, with_opt) if not hb]
+    if not rest:
+        return opt, free[-1], {'ok': False, 'with_main': with_main, 'with_opt': with_opt}
+    return opt, rest[0], {'ok': True, 'with_main': with_main, 'with_opt': with_opt}
 
 
 class GradBucketReducer:
@@ -56,6 +151,13 @@ class GradBucketReducer:
         # the engine's wgrad epilogues write the wire copy of the big matrices themselves)
         self.cast_ranges = None if cast_ranges is None else sorted(cast_ranges)
         self.pending = []
+        self._model = _ModelledRing(flat.device) if (force and flat.is_cuda and os.environ.get('VITAE_DDP_SIM_BUSBW')
+                                                     and not is_distributed()) else None
+        # CUDA tensors: the collectives run on THIS stream (a synchronous torch.distributed call runs on the caller's current
+        # stream — torch >= 2.7, checked on this image by tools/probes/hwq_probe2.py — so the stream, and with it the hardware
+        # queue the all-reduce kernel occupies, is ours to choose: ``pick_streams``); None = asynchronous Work objects
+        # (CPU / gloo, where there is no stream)
+        self.comm_stream = torch.cuda.Stream(device=flat.device) if flat.is_cuda else None
 
     @property
     def world_size(self) -> int:
@@ -82,10 +184,23 @@ class GradBucketReducer:
                             a, b = max(cs, s), min(ce, e)
                             if b > a:
                                 self.wire[a:b].copy_(self.flat[a:b])
-                    work = dist.all_reduce(self.wire[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    work = self._all_reduce(self.wire[s:e])
                 else:
-                    work = dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    work = self._all_reduce(self.flat[s:e])
                 self.pending.append((work, s, e, bucket))
+
+    def _all_reduce(self, t: torch.Tensor):
+        if self.comm_stream is None:
+            return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        cs = self.comm_stream
+        cs.wait_stream(torch.cuda.current_stream(t.device))      # ordered after the kernels that produced the bucket
+        with torch.cuda.stream(cs):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            if self._model is not None:
+                self._model.occupy(t.numel() * t.element_size())
+            ev = torch.cuda.Event()
+            ev.record()
+        return _StreamWork(ev)
 
     def wait(self, copy_back: bool = True):
         """Make the current stream (or the host, for CPU backends) wait for every launched bucket.  With a wire dtype,
@@ -136,7 +251,6 @@ class RcclBucketReducer(GradBucketReducer):
         with torch.cuda.device(self.device):
             lib.vitae_ddp_init(ctypes.addressof(buf), world, rank)
         self._world = world
-        self.comm_stream = torch.cuda.Stream(device=self.device)
 
     @property
     def world_size(self) -> int:

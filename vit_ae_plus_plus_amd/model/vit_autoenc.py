@@ -448,11 +448,27 @@ class MaskedAutoencoderViT(nn.Module):
                 self.decoder_pos_embed.data.reshape(eng.buffers['decoder_pos_embed'].shape))
         return out
 
-    def enable_data_parallel(self, device=None, group=None, force=False, comm_dtype=None, enc_chunks=3, native=None):
+    @staticmethod
+    def _set_exchange_buckets(eng, enc_chunks):
+        """Encoder gradient buckets of the data-parallel step.  Explicit ``enc_chunks``: that many, even.  Otherwise (and unless
+        VITAE_ENC_CHUNKS / VITAE_ENC_CUTS say something else): four, the LAST one only block 0 + the patch embedding — it is the
+        bucket whose all-reduce nothing can hide, so it is the small one (ring all-reduce modelled on one GPU at 150 / 300 GB/s
+        bus bandwidth, tools/probes/r2_ddp_model.sh: 5.63 / 5.07 ms against 5.80 / 5.27 ms with three even buckets)."""
+        if enc_chunks is not None:
+            eng.set_backward_chunks(enc_chunks)
+            return
+        if os.environ.get('VITAE_ENC_CHUNKS') or os.environ.get('VITAE_ENC_CUTS'):
+            return
+        d = eng.cfg.depth
+        n = min(4, d)
+        eng.set_backward_chunks(n)
+        eng.enc_cuts = [0, d] if n == 1 else [0] + [1 + (d - 1) * i // (n - 1) for i in range(n)]
+
+    def enable_data_parallel(self, device=None, group=None, force=False, comm_dtype=None, enc_chunks=None, native=None):
         """One process per GPU: broadcast rank 0's replica and all-reduce gradient buckets over RCCL
         (overlapped with backward) inside the fused step.  No-op for a single process.
         ``comm_dtype=torch.bfloat16`` sends the gradients rounded to bf16 (half the bytes on xGMI);
-        ``enc_chunks`` = number of encoder gradient buckets.  ``native`` (default: environment VITAE_DDP_NATIVE=1): exchange
+        ``enc_chunks`` = number of (even) encoder gradient buckets (default: ``_set_exchange_buckets``).  ``native`` (default: environment VITAE_DDP_NATIVE=1): exchange
         through the C ABI (``vitae_ddp_*``: RCCL on a side HIP stream, captured inside the step graph) instead of through
         torch.distributed's process group (collectives issued by the host between per-phase graphs)."""
         from .. import ddp
@@ -461,7 +477,7 @@ class MaskedAutoencoderViT(nn.Module):
         if native and (ddp.is_distributed() or force):
             eng = self._ensure_engine(torch.device(device) if device is not None else next(self.parameters()).device)
             ddp.broadcast_parameters(eng, 0, group)
-            eng.set_backward_chunks(enc_chunks)
+            self._set_exchange_buckets(eng, enc_chunks)
             self._reducer = ddp.RcclBucketReducer(eng.grads, ddp.engine_bucket_ranges(eng), eng.device, comm_dtype=comm_dtype,
                                                   force=force)
             wired = self._reducer.wire is not None and self._reducer.active
@@ -478,9 +494,16 @@ class MaskedAutoencoderViT(nn.Module):
             return None
         eng = self._ensure_engine(torch.device(device) if device is not None else next(self.parameters()).device)
         ddp.broadcast_parameters(eng, 0, group)
-        eng.set_backward_chunks(enc_chunks)
+        self._set_exchange_buckets(eng, enc_chunks)
         self._reducer = ddp.GradBucketReducer(eng.grads, ddp.engine_bucket_ranges(eng), group=group, force=force,
                                               comm_dtype=comm_dtype)
+        if eng.device.type == 'cuda' and self._reducer.active and os.environ.get('VITAE_DDP_PICK_STREAMS', '1') != '0':
+            # the all-reduce kernels and the per-bucket AdamW must not share a hardware queue with the backward (or with each
+            # other): measured once, here (ddp.pick_streams)
+            try:
+                eng.oside, self._reducer.comm_stream, self._stream_report = ddp.pick_streams(eng.device)
+            except Exception as e:   # pragma: no cover - never let a tuning probe cost the run
+                self._stream_report = {'ok': False, 'error': repr(e)[:200]}
         if self._reducer.wire is not None and self._reducer.active:
             eng.grads_wire16 = self._reducer.wire
             self._reducer.cast_ranges = eng.wire_uncovered_ranges()   # the rest is written by the wgrad epilogues
