@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITAE_ABI_VERSION 24
+#define VITAE_ABI_VERSION 25
 
 /* matrix-core arithmetic of the dense contractions */
 #define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
@@ -103,6 +103,25 @@ int vitae_gemm_glds(int a_kcontig, int b_kcontig, const void* A16, long lda, con
                     long ldc, void* C16, long ldc16, int M, int N, int K, const float* bias, const float* residual,
                     long ldr, int epi, float* aux, long ldaux, int accumulate, int split_k, float* splitk_ws,
                     float* out_colsum_accum, void* stream);
+/* The same GEMM, additionally leaving the LayerNorm statistics of its result rows for the op that follows (model/vit.py:141,143:
+ * the residual stream goes into norm1 / norm2), in 64-column partials: out_rowstats[s][m] = (sum, sum of squares) of
+ * C(m, 64 s .. 64 s + 63), s < ceil(N / 64), [ceil(N / 64)][M][2] floats, 8-byte aligned (plain stores: nothing to zero).  Row-major epilogue only (N % 4 == 0, 16-byte
+ * aligned operands, 64x64 / 64x128 tiles), else VITAE_ERR_UNSUPPORTED_SHAPE. */
+int vitae_gemm_glds_stats(int a_kcontig, int b_kcontig, const void* A16, long lda, const void* B16, long ldb, float* C,
+                          long ldc, void* C16, long ldc16, int M, int N, int K, const float* bias, const float* residual,
+                          long ldr, int epi, float* aux, long ldaux, int accumulate, int split_k, float* splitk_ws,
+                          float* out_colsum_accum, float* out_rowstats, void* stream);
+/* LayerNorm folded into the Linear that consumes it (nn.LayerNorm + nn.Linear of model/vit.py:141,143 in ONE launch):
+ * C / C16 [M, N] = epi( LN(X)[M, K] @ W16[N, K]^T + bias ),  LN(X)(m, k) = (X(m, k) - mean_m) rstd_m gamma_k + beta_k, with
+ * mean / rstd from stats[stat_parts][M][2] = partial (sum, sum of squares) of X's rows (vitae_gemm_glds_stats with
+ * stat_parts = K / 64, or any producer of X).  X is read
+ * as fp32 through registers and normalised on its way into LDS; W16 arrives by LDS-DMA.  y16_out (row stride ldy; must have
+ * ceil(M / 64) * 64 rows), mean_out, rstd_out — all or none: the bf16 LayerNorm output and row statistics the backward needs,
+ * stored by the workgroups of column tile 0 (the pad rows of y16_out are written with zeros).  K in {512, 768, 1024}; epi as vitae_gemm_glds. */
+int vitae_gemm_glds_lnfold(const float* X, long ldx, const float* stats, int stat_parts, const float* gamma, const float* beta, float eps,
+                           const void* W16, long ldw, float* C, long ldc, void* C16, long ldc16, int M, int N, int K,
+                           const float* bias, int epi, float* aux, long ldaux, void* y16_out, long ldy, float* mean_out,
+                           float* rstd_out, void* stream);
 int vitae_gemm_glds_pick_split_k(int M, int N, int K);
 /* profiling hook (tools/gemm_phase_probe.py): 8 long long per workgroup; NULL = off */
 int vitae_gemm_glds_set_debug(void* buf);

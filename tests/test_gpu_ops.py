@@ -780,3 +780,65 @@ def test_gemm_slab_mode(lib, M, N, K, split):
                                          M, Mp, N, K, db.data_ptr(), 0, split, st())
     assert rel_err(dxs[:, :M].sum(0), dy @ w) < 1e-2
     assert rel_err(dw, dy.t() @ x) < 1e-2 and rel_err(db, dy.sum(0)) < 1e-2
+
+
+@pytest.mark.parametrize('M,N,K,split', [(440, 768, 768, 1), (440, 768, 3072, 5), (868, 512, 2048, 4), (55, 1024, 1024, 1), (130, 768, 768, 1)])
+def test_gemm_rowstats(lib, M, N, K, split):
+    """The producer half of the folded LayerNorm: a residual GEMM that leaves (sum, sum of squares) of its result rows."""
+    x, w = _bf(gen(M, K, seed=1)).float(), _bf(gen(N, K, seed=2, scale=K ** -0.5)).float()
+    bias, res = gen(N, seed=3), gen(M, N, seed=4)
+    y = torch.full((M, N), float('nan'), device='cuda')
+    stats = torch.full((N // 64, M, 2), float('nan'), device='cuda')
+    ws = torch.zeros(max(1, lib.vitae_gemm_glds_ws_floats(M, N, split)), device='cuda')
+    lib.vitae_gemm_glds_stats(1, 1, dev(_bf(x)).data_ptr(), K, dev(_bf(w)).data_ptr(), K, y.data_ptr(), N, None, 0, M, N, K,
+                              dev(bias).data_ptr(), dev(res).data_ptr(), N, 0, None, 0, 0, split, ws.data_ptr(), None, stats.data_ptr(), st())
+    want = x @ w.t() + bias + res
+    assert rel_err(y, want) < 1e-2
+    got = stats.cpu().double()
+    yc = y.cpu().double().reshape(M, N // 64, 64).permute(1, 0, 2)
+    assert torch.allclose(got[..., 0], yc.sum(2), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(got[..., 1], (yc * yc).sum(2), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize('M,N,K,epi', [(440, 2304, 768, 0), (440, 3072, 768, 1), (868, 1536, 512, 0), (868, 2048, 512, 1), (129, 1024, 1024, 0),
+                                       (55, 192, 768, 0)])
+def test_gemm_lnfold(lib, C, M, N, K, epi):
+    """nn.LayerNorm + nn.Linear (model/vit.py:141,143) in one launch: X is normalised on its way into LDS.  Reference: fp32
+    LayerNorm, rounded to bf16 (what the standalone kernel hands the GEMM), times the bf16 weights in fp32."""
+    Mp = (M + 63) // 64 * 64
+    x = gen(M, K, seed=1) * 2.0 + 0.3 * gen(M, 1, seed=5)            # rows with different means
+    gamma, beta = 1.0 + 0.1 * gen(K, seed=6), 0.1 * gen(K, seed=7)
+    w, bias = _bf(gen(N, K, seed=2, scale=K ** -0.5)).float(), gen(N, seed=3)
+    eps = 1e-6
+    xs = x.reshape(M, K // 64, 64).permute(1, 0, 2)
+    stats = torch.stack([xs.sum(2), (xs * xs).sum(2)], 2).contiguous()          # [K / 64, M, 2]
+    y = torch.full((M, N), float('nan'), device='cuda')
+    y16o = torch.full((M, N), float('nan'), device='cuda', dtype=torch.bfloat16)
+    aux = torch.full((M, N), float('nan'), device='cuda') if epi else None
+    ln16 = torch.zeros(Mp, K, device='cuda', dtype=torch.bfloat16)
+    mean, rstd = torch.full((M,), float('nan'), device='cuda'), torch.full((M,), float('nan'), device='cuda')
+    lib.vitae_gemm_glds_lnfold(dev(x).data_ptr(), K, dev(stats).data_ptr(), K // 64, dev(gamma).data_ptr(), dev(beta).data_ptr(), eps,
+                               dev(_bf(w)).data_ptr(), K, y.data_ptr(), N, y16o.data_ptr(), N, M, N, K, dev(bias).data_ptr(),
+                               C['VITAE_EPI_GELU'] if epi else C['VITAE_EPI_NONE'], None if aux is None else aux.data_ptr(), N,
+                               ln16.data_ptr(), K, mean.data_ptr(), rstd.data_ptr(), st())
+    ln = torch.nn.functional.layer_norm(x, (K,), gamma, beta, eps)
+    pre = _bf(ln).float() @ w.t() + bias
+    want = torch.nn.functional.gelu(pre) if epi else pre
+    assert rel_err(y, want) < 1e-2
+    assert rel_err(y16o.float(), want) < 2e-2
+    if epi:
+        assert rel_err(aux, pre) < 1e-2
+    # what the backward reads: bf16 LayerNorm output (one bf16 ulp where the statistics differ in the last bit), mean, rstd
+    got = ln16[:M].float().cpu()
+    assert (got - _bf(ln).float()).abs().max() <= 2.0 ** -6 * ln.abs().max() and rel_err(got, ln) < 5e-3
+    assert torch.all(ln16[M:] == 0)
+    mu = x.mean(1)
+    assert torch.allclose(mean.cpu(), mu, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(rstd.cpu(), (x.var(1, unbiased=False) + eps).rsqrt(), rtol=1e-4, atol=1e-5)
+    # without the backward outputs: same product
+    y2 = torch.full((M, N), float('nan'), device='cuda')
+    lib.vitae_gemm_glds_lnfold(dev(x).data_ptr(), K, dev(stats).data_ptr(), K // 64, dev(gamma).data_ptr(), dev(beta).data_ptr(), eps,
+                               dev(_bf(w)).data_ptr(), K, y2.data_ptr(), N, None, 0, M, N, K, dev(bias).data_ptr(),
+                               C['VITAE_EPI_GELU'] if epi else C['VITAE_EPI_NONE'], None if aux is None else aux.data_ptr(), N,
+                               None, 0, None, None, st())
+    assert torch.equal(y2, y)

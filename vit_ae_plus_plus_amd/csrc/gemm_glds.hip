@@ -46,6 +46,8 @@ struct GArgs {
     long slab_stride;    // != 0 ("slab mode"): k-split z stores its partial tile at C + z * slab_stride and is done — the splits
                          // are summed by the kernel that consumes the result anyway (vitae_layernorm_{fwd,bwd}_slabs: the
                          // launch-boundary reduce); no tickets, no partial round trip inside the launch
+    float* rowstats = nullptr;   // optional (row-major epilogue only): rowstats[n / 64][m] = (sum, sum of squares) of result(m, 64-column
+                         // slot) — the LayerNorm statistics of the NEXT op, taken while the rows pass through (vitae_gemm_glds_lnfold)
     long long* dbg;      // optional (tools/gemm_phase_probe.py): 8 s_memtime stamps per workgroup
     int xcd_m;           // 0: an XCD owns column tiles tn = xcd (mod 8) and walks every row tile (its L2 holds 1/8 of B and all
                          // of A); 1: it owns row tiles tm = xcd (mod 8) instead — picked when A is the larger operand
@@ -178,6 +180,9 @@ __device__ __forceinline__ void epilogue_rows(const GArgs& p, const float (&a)[N
     if (pre.have) bias4 = pre.bias;
     else if (p.bias && ncol) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
     f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+    float rsum[PASSES], rsq[PASSES];
+#pragma unroll
+    for (int q = 0; q < PASSES; ++q) rsum[q] = rsq[q] = 0.f;
 #pragma unroll
     for (int pb = 0; pb < PASSES; pb += PB) {
         f32x4 ax[PB], rs[PB], co[PB];
@@ -231,8 +236,25 @@ __device__ __forceinline__ void epilogue_rows(const GArgs& p, const float (&a)[N
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) csum[e] += x[e];
+            if (p.rowstats) { rsum[pb + q] = (x[0] + x[1]) + (x[2] + x[3]); rsq[pb + q] = (x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3]); }
         }
         asm volatile("" ::: "memory");   // keep the next batch's loads behind these stores (register pressure)
+    }
+    if (p.rowstats) {
+        // 64 columns of a row are held by 16 consecutive lanes (4 columns each): butterfly over them, then ONE 8-byte store per
+        // row and 64-column slot — rowstats[slot][m] = (sum, sum of squares); the consumer adds the N / 64 slots of its rows
+        // (no atomics: they cost the launch ~2 us of memory-side round trips at its very end; no zeroing either)
+#pragma unroll
+        for (int q = 0; q < PASSES; ++q) {
+            float a0 = rsum[q], a1 = rsq[q];
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) { a0 += __shfl_xor(a0, d, 64); a1 += __shfl_xor(a1, d, 64); }
+            const int m = m0 + r0 + q * RPP;
+            if ((cg & 15) == 0 && m < p.M && ncol) {
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<f32x2*>(p.rowstats + ((long)(n >> 6) * p.M + m) * 2) = f32x2{a0, a1};
+            }
+        }
     }
     if (p.out_colsum) {
 #pragma unroll
@@ -573,6 +595,265 @@ __global__ __launch_bounds__(256) void gemm_glds_pipe_kernel(const GArgs p) {
     gemm_glds_body<64, 64, true, true, 4, false, false, VITAE_GLDS_PIPE_STAGES>(p, blockIdx.x, blockIdx.z, smem);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// LayerNorm folded into the GEMM that consumes it (model/vit.py:141, 143: qkv(norm1(x)), fc1(norm2(x))):
+//   C[M, N] = epi( LN(X)[M, K] @ W16[N, K]^T + bias ),   LN(X)(m, k) = (X(m, k) - mean_m) * rstd_m * gamma_k + beta_k
+// X is the fp32 residual stream; its row statistics (sum, sum of squares) were left by the epilogue of the GEMM that produced
+// it (vitae_gemm_glds_stats).  The A operand therefore never exists in HBM as a GEMM operand: every workgroup loads its
+// 64 x 64 slice of X through registers (16 floats per thread and k-step, two k-steps ahead), normalises, rounds to bf16 and
+// writes the slice into the LDS stage in the very image the LDS-DMA path produces (chunk slot = chunk ^ swz(row)), so the
+// fragment reads and the MFMA loop are the pipelined loop of gemm_glds_pipe_kernel; W still arrives by LDS-DMA.  The
+// workgroups of column tile 0 also store what they normalised (Y16: the wgrad operand of the backward) and the row's mean / rstd
+// (LayerNorm backward) — so the standalone LayerNorm launch (4.9 us x 38 per step) disappears and nothing is computed twice
+// that is stored.  One 64 x 64 tile per workgroup, 4 stages, no split-K (K = 512 .. 1024 here).
+// Register-path global loads of a loop that also keeps LDS-DMA in flight, as INLINE ASM: hipcc treats every global_load_lds as
+// a FLAT access that may hit LDS ("pending flat": results may return out of order), so its own wait for any compiler-visible VMEM
+// load issued in such a loop is s_waitcnt vmcnt(0) — which drains the whole DMA prefetch each time the loaded registers are
+// used (seen in the ISA of the first versions of lnfold_loop).  The compiler cannot see these loads, so the CALLER orders them:
+// a counted wait_vmcnt_n() and vm_tie() on every destination before its first use.
+template <int OFF> __device__ __forceinline__ void gload16(f32x4& r, const float* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(r) : "v"(p), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void vm_tie(f32x4& r) { asm volatile("" : "+v"(r)); }
+__device__ __forceinline__ void wait_vmcnt_n(int n) {     // n is a compile-time constant after unrolling
+    switch (n) {
+#define VITAE_W(i) case i: wait_vmcnt<i>(); break;
+        VITAE_W(0) VITAE_W(1) VITAE_W(2) VITAE_W(3) VITAE_W(4) VITAE_W(5) VITAE_W(6) VITAE_W(7) VITAE_W(8) VITAE_W(9) VITAE_W(10)
+        VITAE_W(11) VITAE_W(12) VITAE_W(13) VITAE_W(14) VITAE_W(15) VITAE_W(16) VITAE_W(17) VITAE_W(18) VITAE_W(19) VITAE_W(20)
+        VITAE_W(21) VITAE_W(22) VITAE_W(23) VITAE_W(24) VITAE_W(25) VITAE_W(26) VITAE_W(27) VITAE_W(28) VITAE_W(29) VITAE_W(30)
+        VITAE_W(31) VITAE_W(32) VITAE_W(33) VITAE_W(34) VITAE_W(35) VITAE_W(36) VITAE_W(37) VITAE_W(38) VITAE_W(39) VITAE_W(40)
+#undef VITAE_W
+        default: wait_vmcnt<0>(); break;
+    }
+}
+
+// VMEM issue order of lnfold_loop (per wave), for the counted waits.  Prologue: W0, W1 (GB each), X0, X1 (GA each), Y0, Y1 (YS
+// each: the four Y16 stores of a writer), X2, W2, X3.  Step s: W(s + 3), Y(s + 2), X(s + 4) — each only while that tile exists.
+template <bool WRITER, int NK> struct LnfSeq {
+    static constexpr int GA = 4, GB = 2, YS = WRITER ? 4 : 0;
+    static constexpr int ys(int s) { return s + 2 < NK ? YS : 0; }
+    static constexpr int al(int s) { return s + 4 < NK ? GA : 0; }
+    static constexpr int bd(int s) { return s + 3 < NK ? GB : 0; }
+    static constexpr int step_ops(int s) { return bd(s) + ys(s) + al(s); }
+    // operations younger than X(t + 2) (the LAST thing step t - 2 issued) when step t, having issued W(t + 3), writes it to LDS
+    static constexpr int after_x(int t) { return t == 0 ? GB + GA + bd(0) : step_ops(t - 1) + bd(t); }
+    // operations younger than W(t + 1) (the FIRST thing step t - 2 issued) once step t has issued W(t + 3)
+    static constexpr int after_w(int t) {
+        return t == 0 ? (4 * GA + 2 * YS + GB) + bd(0)          // X0 X1 Y0 Y1 X2 W2 X3 | W3
+             : t == 1 ? GA + step_ops(0) + bd(1)               // X3 | step 0 | W4
+             : ys(t - 2) + al(t - 2) + step_ops(t - 1) + bd(t);
+    }
+};
+
+struct LArgs {
+    const float* X; long ldx;
+    const float* stats; int nparts;      // stats[s][M][2], s < nparts: partial (sum, sum of squares) of the rows of X
+    const float* gamma; const float* beta;
+    float eps;
+    __bf16* Y16; long ldy;
+    float* mean; float* rstd;
+};
+
+constexpr int LNF_KMAX = 1024;
+
+template <bool WRITER, int NK>
+__device__ __forceinline__ void lnfold_loop(const GArgs& p, const LArgs& l, unsigned char* smem, f32x16 (&acc)[2][1], const int m0,
+                                            const int n0, const int wave, const int lane, const int wm, const int wn) {
+    constexpr int NST = 4, STAGE = GCfg<64, 64, 4>::STAGE, A_BYTES = GCfg<64, 64, 4>::A_BYTES, GB = 2, GA = 4;
+    const float* gb = reinterpret_cast<const float*>(smem + NST * STAGE);
+    // X slice (64 rows x 64 k, fp32) -> registers: lane l of wave w takes the 16-byte segment seg = l & 7 of a 128-byte half
+    // row, rows w * 16 + (l >> 3) and + 8: every load instruction covers 8 rows x one whole 128-byte line (a first version
+    // with 64 contiguous bytes per THREAD touched every line from four instructions and cost +0.4 us per k-step in the
+    // texture addresser).  Load j: row (j >> 1), half (j & 1).
+    const int seg = lane & 7, rw0 = wave * 16 + (lane >> 3);
+    float mu[2], rs[2];                      // filled in the prologue, behind the first operand loads
+    const int mrow[2] = {m0 + rw0, m0 + rw0 + 8};
+    const float* xsrc[2] = {l.X + (long)min(mrow[0], p.M - 1) * l.ldx + 4 * seg, l.X + (long)min(mrow[1], p.M - 1) * l.ldx + 4 * seg};
+    // LDS image of the k-contiguous tile: [row][8 chunks of 16 B], chunk slot = chunk ^ swz(row); this thread's 4 bf16 of
+    // (row i, half h) are the (seg & 1) half of chunk 4 h + (seg >> 1)
+    unsigned a_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = rw0 + 8 * (j >> 1), c = 4 * (j & 1) + (seg >> 1);
+        a_off[j] = r * 128 + ((c ^ ((r >> 1) & 7)) << 4) + (seg & 1) * 8;
+    }
+    auto aload = [&](int t, f32x4 (&ra)[GA]) {
+        const float* s0 = xsrc[0] + t * BK;
+        const float* s1 = xsrc[1] + t * BK;
+        gload16<0>(ra[0], s0); gload16<128>(ra[1], s0); gload16<0>(ra[2], s1); gload16<128>(ra[3], s1);
+    };
+    auto aready = [&](int younger, f32x4 (&ra)[GA]) {          // the loads into ra are complete once <= `younger` VMEM ops are out
+        wait_vmcnt_n(younger);
+#pragma unroll
+        for (int j = 0; j < GA; ++j) vm_tie(ra[j]);
+    };
+    auto awrite = [&](int t, const f32x4 (&ra)[GA]) {
+        const float* g = gb + t * BK + 4 * seg;
+        const f32x4 gg[2] = {*reinterpret_cast<const f32x4*>(g), *reinterpret_cast<const f32x4*>(g + 32)};
+        const f32x4 bb[2] = {*reinterpret_cast<const f32x4*>(g + p.K), *reinterpret_cast<const f32x4*>(g + p.K + 32)};
+        unsigned char* st = smem + (t % NST) * STAGE;
+#pragma unroll
+        for (int j = 0; j < GA; ++j) {
+            const int i = j >> 1, h = j & 1;
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (__bf16)((ra[j][e] - mu[i]) * rs[i] * gg[h][e] + bb[h][e]);
+            *reinterpret_cast<bf16x4*>(st + a_off[j]) = o;
+            if (WRITER) {
+                // UNCONDITIONAL (the wait counts of LnfSeq assume these stores from every wave: a wave whose rows all lie
+                // beyond M must not branch around them): rows >= M of the 64-row padded Y16 receive zeros, which is what the
+                // padding holds anyway (the wgrad reduces over the padded rows)
+                if (mrow[i] >= p.M) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (__bf16)0.f;
+                }
+                *reinterpret_cast<bf16x4*>(l.Y16 + (long)mrow[i] * l.ldy + t * BK + 32 * h + 4 * seg) = o;
+            }
+        }
+    };
+    auto bdma = [&](int t) {
+        dma_tile<64, true, 4>(p.B, p.ldb, p.N, n0, t * BK, smem + (t % NST) * STAGE + A_BYTES, wave, lane);
+    };
+    bf16x8 fa[2][BK / 16][1], fb[2][BK / 16][1];
+    auto rd = [&](int t, bf16x8 (&xa)[BK / 16][1], bf16x8 (&xb)[BK / 16][1]) {
+        const unsigned char* at = smem + (t % NST) * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            xa[kk][0] = frag<64, true>(at, wm * 32, kk, lane);
+            xb[kk][0] = frag<64, true>(at + A_BYTES, wn * 32, kk, lane);
+        }
+    };
+    auto mm = [&](bf16x8 (&xa)[BK / 16][1], bf16x8 (&xb)[BK / 16][1]) {
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk)
+            acc[kk & 1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[kk][0], xb[kk][0], acc[kk & 1][0], 0, 0, 0);
+    };
+    // ---- prologue: W tiles 0, 1 by DMA, X slices 0, 1 through registers into their stages, then the steady-state pattern
+    static_assert(NK >= 4, "k-steps");
+    f32x4 ra[2][GA];
+    using Seq = LnfSeq<WRITER, NK>;
+    static_assert(Seq::GA == GA && Seq::GB == GB, "issue bookkeeping");
+    auto stamp = [&](int i) {
+        if (p.dbg && threadIdx.x == 0) p.dbg[(long)blockIdx.x * 16 + i] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
+    bdma(0);
+    bdma(1);
+    aload(0, ra[0]);
+    aload(1, ra[1]);
+    stamp(1);
+    // behind the first operand loads (one memory latency for everything the k-loop needs): gamma | beta -> LDS, and the row
+    // statistics -> mean, rstd of this thread's two rows
+    {
+        float* gbw = reinterpret_cast<float*>(smem + NST * STAGE);
+        const int i4 = threadIdx.x * 4;                            // K <= 1024: one 16-byte piece of each per thread
+        f32x4 gv = {0.f, 0.f, 0.f, 0.f}, bv = gv;
+        if (i4 < p.K) { gv = *reinterpret_cast<const f32x4*>(l.gamma + i4); bv = *reinterpret_cast<const f32x4*>(l.beta + i4); }
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 part[2][NK];                   // X has K = 64 NK columns: NK partial slots per row
+        const float invk = 1.f / (float)p.K;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int mc = min(mrow[i], p.M - 1);
+#pragma unroll
+            for (int sl = 0; sl < NK; ++sl) part[i][sl] = *reinterpret_cast<const f32x2*>(l.stats + ((long)sl * p.M + mc) * 2);
+        }
+        if (i4 < p.K) { *reinterpret_cast<f32x4*>(gbw + i4) = gv; *reinterpret_cast<f32x4*>(gbw + p.K + i4) = bv; }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int sl = 0; sl < NK; ++sl) { s0 += part[i][sl][0]; s1 += part[i][sl][1]; }
+            mu[i] = s0 * invk;
+            rs[i] = rsqrtf(fmaxf(s1 * invk - mu[i] * mu[i], 0.f) + l.eps);
+            if (WRITER && seg == 0 && mrow[i] < p.M && l.mean) { l.mean[mrow[i]] = mu[i]; l.rstd[mrow[i]] = rs[i]; }
+        }
+        __syncthreads();                     // gamma | beta visible to everyone (drains the VMEM queue: every load above landed)
+    }
+    stamp(2);
+    aready(GA, ra[0]);                     // younger than X0: X1
+    awrite(0, ra[0]);
+    aready(Seq::YS, ra[1]);                // younger than X1: the Y16 stores of slice 0
+    awrite(1, ra[1]);
+    aload(2, ra[0]);
+    bdma(2);
+    aload(3, ra[1]);
+    // (W tiles 0 and 1 are older than X1: landed)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    rd(0, fa[0], fb[0]);
+    stamp(3);
+    // Step t: DMA W tile t + 3; W tile t + 1 landed -> barrier -> its fragments; the MFMAs of tile t; and BEHIND them (the matrix
+    // pipe works on its own while the wave issues VALU) X slice t + 2 is normalised into its stage from the registers loaded
+    // two steps ago, which are then refilled with slice t + 4.  The X loads are invisible to the compiler (gload16): the
+    // wait counts are constants of the step (LnfSeq).  Steps 0, 1 (prologue-dependent counts) and the last four (the pipeline
+    // drains) are peeled; the steady state is a ROLLED loop of two steps (the two register sets alternate) — fully unrolled,
+    // the kernel is ~1000 instructions per variant, and a launch that short pays for its instruction fetches.
+#define LNF_STEP(T, P, AW, AL, BD, NEXT, WAITW, WAITX)                                                                 \
+    {                                                                                                                  \
+        if (BD) bdma((T) + 3);                                                                                         \
+        if (NEXT) wait_vmcnt<(WAITW)>();                                                                               \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                             \
+        __builtin_amdgcn_s_barrier();                                                                                  \
+        if (NEXT) rd((T) + 1, fa[(P) ^ 1], fb[(P) ^ 1]);                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        mm(fa[P], fb[P]);                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        if (AW) {                                                                                                      \
+            wait_vmcnt<(WAITX)>();                                                                                     \
+            for (int j_ = 0; j_ < GA; ++j_) vm_tie(ra[P][j_]);                                                         \
+            awrite((T) + 2, ra[P]);                                                                                    \
+        }                                                                                                              \
+        if (AL) aload((T) + 4, ra[P]);                                                                                 \
+    }
+    static_assert(NK >= 8 && NK % 2 == 0, "k-steps");
+    LNF_STEP(0, 0, true, true, true, true, Seq::after_w(0), Seq::after_x(0))
+    LNF_STEP(1, 1, true, true, true, true, Seq::after_w(1), Seq::after_x(1))
+    stamp(4);
+#pragma unroll 1
+    for (int t = 2; t < NK - 4; t += 2) {
+        LNF_STEP(t, 0, true, true, true, true, Seq::after_w(2), Seq::after_x(2))
+        LNF_STEP(t + 1, 1, true, true, true, true, Seq::after_w(2), Seq::after_x(2))
+    }
+    static_assert(Seq::after_w(2) == Seq::after_w(NK - 5) && Seq::after_x(3) == Seq::after_x(NK - 5), "steady state");
+    stamp(5);
+    LNF_STEP(NK - 4, 0, true, false, true, true, Seq::after_w(NK - 4), Seq::after_x(NK - 4))
+    LNF_STEP(NK - 3, 1, true, false, false, true, Seq::after_w(NK - 3), Seq::after_x(NK - 3))
+    LNF_STEP(NK - 2, 0, false, false, false, true, Seq::after_w(NK - 2), 0)
+    LNF_STEP(NK - 1, 1, false, false, false, false, 0, 0)
+    stamp(6);
+#undef LNF_STEP
+}
+
+template <int NK>
+__global__ __launch_bounds__(256) void gemm_glds_lnfold_kernel(const GArgs p, const LArgs l) {
+    constexpr int NST = 4, STAGE = GCfg<64, 64, 4>::STAGE;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE + 2 * LNF_KMAX * 4];
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, local = bid >> 3;
+    const int tn = p.xcd_m ? local % p.tiles_n : xcd + 8 * (local / p.tiles_m);
+    const int tm = p.xcd_m ? xcd + 8 * (local / p.tiles_n) : local % p.tiles_m;
+    if (tn >= p.tiles_n || tm >= p.tiles_m) return;
+    const int m0 = tm * 64, n0 = tn * 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    EpiPre epre;
+    epilogue_prefetch<64, 64, 4>(p, m0, n0, epre);
+    f32x16 acc[2][1];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[h][0][i] = 0.f;
+    if (tn == 0 && l.Y16) lnfold_loop<true, NK>(p, l, smem, acc, m0, n0, wave, lane, wm, wn);
+    else lnfold_loop<false, NK>(p, l, smem, acc, m0, n0, wave, lane, wm, wn);
+    float a[1][16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[0][r] = acc[0][0][r] + acc[1][0][r];
+    epilogue_rows<64, 64, 4, 1>(p, a, m0, n0, wm, wn, lane, smem, epre);
+    if (p.dbg && threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p.dbg[(long)blockIdx.x * 16 + 7] = __builtin_amdgcn_s_memtime(); }
+}
+
 // dgrad (dy @ W: A k-contiguous, B = bf16 weights read row-contiguous) and wgrad (dy^T @ x: both operands
 // row-contiguous) of one Linear in one launch — they share dy, and together they double the resident
 // workgroups per CU.
@@ -688,10 +969,10 @@ extern "C" long vitae_gemm_glds_ws_floats(int M, int N, int split_k) {
     return VITAE_GLDS_TICKETS + (long)cdiv(M, t.bm) * cdiv(N, t.bn) * split_k * t.bm * t.bn;
 }
 
-extern "C" int vitae_gemm_glds(int a_kcontig, int b_kcontig, const void* A16, long lda, const void* B16, long ldb,
-                               float* C, long ldc, void* C16, long ldc16, int M, int N, int K, const float* bias,
-                               const float* residual, long ldr, int epi, float* aux, long ldaux, int accumulate,
-                               int split_k, float* splitk_ws, float* out_colsum_accum, void* stream) {
+static int gemm_glds_launch(int a_kcontig, int b_kcontig, const void* A16, long lda, const void* B16, long ldb,
+                            float* C, long ldc, void* C16, long ldc16, int M, int N, int K, const float* bias,
+                            const float* residual, long ldr, int epi, float* aux, long ldaux, int accumulate,
+                            int split_k, float* splitk_ws, float* out_colsum_accum, float* out_rowstats, void* stream) {
     if (!A16 || !B16 || (!C && !C16) || M <= 0 || N <= 0 || K <= 0) return VITAE_ERR_INVALID_ARG;
     if (epi != VITAE_EPI_NONE && epi != VITAE_EPI_RELU && !aux) return VITAE_ERR_INVALID_ARG;
     if (K % BK) return VITAE_ERR_UNSUPPORTED_SHAPE;
@@ -719,6 +1000,8 @@ extern "C" int vitae_gemm_glds(int a_kcontig, int b_kcontig, const void* A16, lo
     p.tiles_m = cdiv(M, t.bm); p.tiles_n = cdiv(N, t.bn);
     p.xcd_m = xcd_by_rows(M, N);
     p.vec_epi = vec_epilogue_ok(p);
+    p.rowstats = out_rowstats;
+    if (out_rowstats && (!p.vec_epi || t.id > 1)) return VITAE_ERR_UNSUPPORTED_SHAPE;   // taken in the row-major epilogue only
     if (split_k > 1 && (long)p.tiles_m * p.tiles_n > VITAE_GLDS_TICKETS) return VITAE_ERR_UNSUPPORTED_SHAPE;
     dim3 grid(glds_blocks(p), 1, split_k);
     hipStream_t st = (hipStream_t)stream;
@@ -731,6 +1014,66 @@ extern "C" int vitae_gemm_glds(int a_kcontig, int b_kcontig, const void* A16, lo
     else if (t.id == 2) launch<128, 128>(p, a_kcontig != 0, b_kcontig != 0, grid, st);
     else if (t.id == 1) launch<64, 128>(p, a_kcontig != 0, b_kcontig != 0, grid, st);
     else launch<64, 64>(p, a_kcontig != 0, b_kcontig != 0, grid, st);
+    return vitae_launch_status();
+}
+
+extern "C" int vitae_gemm_glds(int a_kcontig, int b_kcontig, const void* A16, long lda, const void* B16, long ldb,
+                               float* C, long ldc, void* C16, long ldc16, int M, int N, int K, const float* bias,
+                               const float* residual, long ldr, int epi, float* aux, long ldaux, int accumulate,
+                               int split_k, float* splitk_ws, float* out_colsum_accum, void* stream) {
+    return gemm_glds_launch(a_kcontig, b_kcontig, A16, lda, B16, ldb, C, ldc, C16, ldc16, M, N, K, bias, residual, ldr, epi, aux, ldaux,
+                            accumulate, split_k, splitk_ws, out_colsum_accum, nullptr, stream);
+}
+
+// The same GEMM, additionally leaving the LayerNorm statistics of its result rows in 64-column partials:
+// out_rowstats[s][m] = (sum, sum of squares) of C(m, 64 s .. 64 s + 63), s < ceil(N / 64) (plain stores: every slot of every row is
+// written, nothing to zero).  Consumed by vitae_gemm_glds_lnfold, which normalises the rows while it loads them.
+extern "C" int vitae_gemm_glds_stats(int a_kcontig, int b_kcontig, const void* A16, long lda, const void* B16, long ldb,
+                                     float* C, long ldc, void* C16, long ldc16, int M, int N, int K, const float* bias,
+                                     const float* residual, long ldr, int epi, float* aux, long ldaux, int accumulate,
+                                     int split_k, float* splitk_ws, float* out_colsum_accum, float* out_rowstats, void* stream) {
+    if (!out_rowstats) return VITAE_ERR_INVALID_ARG;
+    return gemm_glds_launch(a_kcontig, b_kcontig, A16, lda, B16, ldb, C, ldc, C16, ldc16, M, N, K, bias, residual, ldr, epi, aux, ldaux,
+                            accumulate, split_k, splitk_ws, out_colsum_accum, out_rowstats, stream);
+}
+
+// C / C16 [M, N] = epi( LayerNorm(X)[M, K] @ W16[N, K]^T + bias ) with the LayerNorm applied while X is loaded (see
+// gemm_glds_lnfold_kernel).  stats[stat_parts][M][2] = partial (sum, sum of squares) of X's rows (vitae_gemm_glds_stats leaves
+// them, stat_parts = K / 64).  y16_out /
+// mean_out / rstd_out (all or none): the bf16 LayerNorm output (row stride ldy, ceil(M / 64) * 64 rows: the pad rows are
+// written with zeros) and the row statistics for the backward.
+extern "C" int vitae_gemm_glds_lnfold(const float* X, long ldx, const float* stats, int stat_parts, const float* gamma, const float* beta, float eps,
+                                      const void* W16, long ldw, float* C, long ldc, void* C16, long ldc16, int M, int N, int K,
+                                      const float* bias, int epi, float* aux, long ldaux, void* y16_out, long ldy, float* mean_out,
+                                      float* rstd_out, void* stream) {
+    if (!X || !stats || stat_parts <= 0 || !gamma || !beta || !W16 || (!C && !C16) || M <= 0 || N <= 0 || K <= 0) return VITAE_ERR_INVALID_ARG;
+    if ((uintptr_t)stats & 7) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    if (epi != VITAE_EPI_NONE && epi != VITAE_EPI_RELU && !aux) return VITAE_ERR_INVALID_ARG;
+    if ((y16_out != nullptr) != (mean_out != nullptr) || (mean_out != nullptr) != (rstd_out != nullptr)) return VITAE_ERR_INVALID_ARG;
+    if ((K != 512 && K != 768 && K != 1024) || (ldx & 3) || (ldw & 7) || (ldy & 7)) return VITAE_ERR_UNSUPPORTED_SHAPE;   // unrolled k-loops
+    if (((uintptr_t)X & 15) || ((uintptr_t)W16 & 15) || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15) || ((uintptr_t)y16_out & 15))
+        return VITAE_ERR_UNSUPPORTED_SHAPE;
+    if ((long)M * (ldc > N ? ldc : N) >= (1L << 31) || (long)M * ldaux >= (1L << 31) || (long)M * ldc16 >= (1L << 31))
+        return VITAE_ERR_UNSUPPORTED_SHAPE;
+    GArgs p;
+    p.A = nullptr; p.lda = 0;
+    p.B = reinterpret_cast<const __bf16*>(W16); p.ldb = ldw;
+    p.C = C; p.ldc = ldc; p.C16 = reinterpret_cast<__bf16*>(C16); p.ldc16 = ldc16;
+    p.M = M; p.N = N; p.K = K; p.k_per_split = K; p.splits = 1;
+    p.bias = bias; p.residual = nullptr; p.ldr = 0; p.aux = aux; p.ldaux = ldaux;
+    p.epi = epi; p.accumulate = 0; p.ws = nullptr; p.out_colsum = nullptr; p.a_rowsum = nullptr;
+    p.dbg = g_gemm_dbg; p.slab_stride = 0;
+    p.tiles_m = cdiv(M, 64); p.tiles_n = cdiv(N, 64);
+    p.xcd_m = xcd_by_rows(M, N);
+    p.vec_epi = vec_epilogue_ok(p);
+    if (!p.vec_epi) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    LArgs l;
+    l.X = X; l.ldx = ldx; l.stats = stats; l.nparts = stat_parts; l.gamma = gamma; l.beta = beta; l.eps = eps;
+    l.Y16 = reinterpret_cast<__bf16*>(y16_out); l.ldy = ldy; l.mean = mean_out; l.rstd = rstd_out;
+    const dim3 grid(glds_blocks(p));
+    if (K == 512) hipLaunchKernelGGL(gemm_glds_lnfold_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, p, l);
+    else if (K == 768) hipLaunchKernelGGL(gemm_glds_lnfold_kernel<12>, grid, dim3(256), 0, (hipStream_t)stream, p, l);
+    else hipLaunchKernelGGL(gemm_glds_lnfold_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, p, l);
     return vitae_launch_status();
 }
 

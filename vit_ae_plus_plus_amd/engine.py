@@ -98,6 +98,9 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
+_ABLATE_LN_FWD = os.environ.get('VITAE_ABLATE_LN_FWD') == '1'
+
+
 class HipMAEEngine:
     """Owns arenas + workspace for one model instance on one GPU and sequences the kernels."""
 
@@ -141,6 +144,11 @@ class HipMAEEngine:
         # wgrad half and the 900-workgroup grid set their duration, while the slab-summing LayerNorm backward costs 1.5 us
         # more: so the backward keeps the in-launch reduction unless VITAE_SLAB_SPLITK_BWD=1)
         self.slab_k_bwd = self.slab_k and os.environ.get('VITAE_SLAB_SPLITK_BWD', '0') != '0'
+        # OPT-IN (measured: 4.83-4.88 vs 4.81-4.87 ms at batch 4, slower at batch 8 / 32 — DESIGN.md section 3c): LayerNorm folded
+        # into the GEMM that consumes it (csrc/gemm_glds.hip: vitae_gemm_glds_stats leaves the row statistics of the residual
+        # stream, vitae_gemm_glds_lnfold normalises while it loads): no standalone norm1 / norm2 launch except in front of the
+        # first block of a stack
+        self.fold_ln = (self.act16 and not self.fuse_mlp and not self.slab_k and os.environ.get('VITAE_FOLD_LN', '0') == '1')
         self._slabk_target = int(os.environ.get('VITAE_SLABK_TARGET', '384'))
         self._slabk_min_kt = int(os.environ.get('VITAE_SLABK_MIN_KT', '4'))
         self.buffers = buffers   # pos_embed, decoder_pos_embed, BN running stats (device tensors)
@@ -324,6 +332,13 @@ class HipMAEEngine:
                 if self.slab_k:
                     smax = max(self._slab_split(Me if pre == 'enc' else Md, d, k) for k in (d, h, 3 * d))
                     b[pre + 'kslab'] = torch.empty(smax, Mp, d, dtype=torch.float32, device=dev)
+            if self.fold_ln:
+                # (sum, sum of squares) of the residual-stream rows in front of every folded LayerNorm;
+                # st1 of block i is filled by the fc2 GEMM of block i - 1, st2 by the block's own proj GEMM
+                for pre, depth, M, d in (('enc', cfg.depth, Me, D), ('dec', cfg.decoder_depth, Md, Dd)):
+                    for i in range(depth):
+                        for nm in ('st1', 'st2'):
+                            b[f'{pre}{i}.{nm}'] = f((d + 63) // 64, M, 2)      # 64-column partials, all written every step
             b['dn_16'] = z16(self.Mpd, Dd)
             b['dpred_16'] = z16(self.Mpd, P)
             b['patches_16'], b['dtok_16'] = z16(self.Mpt, P), z16(self.Mpt, D)
@@ -512,6 +527,8 @@ class HipMAEEngine:
             self._wg_pending.clear()
 
     def _ln_fwd(self, x, pre, y, mean, rstd, M, D, y16=None):
+        if _ABLATE_LN_FWD and pre.startswith(('blocks.', 'decoder_blocks.')):   # timing ablation only (results are garbage)
+            return
         lib.vitae_layernorm_fwd(_ptr(x), _ptr(self.p[pre + 'weight']), _ptr(self.p[pre + 'bias']), _ptr(y), _ptr(y16),
                                 _ptr(mean), _ptr(rstd), M, D, self.cfg.ln_eps, self.stream)
 
@@ -521,8 +538,9 @@ class HipMAEEngine:
                                 M, D, dx_accumulate, self.stream)
 
     # ------------------------------------------------------------------ bf16-activation GEMM helpers (LDS-DMA kernel)
-    def _g16_fwd(self, x16, w, bias, M, N, K, y=None, y16=None, epi=EPI_NONE, aux=None, res=None):
-        """y / y16 = epi(x16 @ W16^T + b) (+ res) on the LDS-DMA GEMM (bf16 operands in HBM)."""
+    def _g16_fwd(self, x16, w, bias, M, N, K, y=None, y16=None, epi=EPI_NONE, aux=None, res=None, rowstats=None):
+        """y / y16 = epi(x16 @ W16^T + b) (+ res) on the LDS-DMA GEMM (bf16 operands in HBM).  ``rowstats``:
+        [N / 64, M, 2] array that receives (sum, sum of squares) of the result rows per 64-column slot — the statistics of the LayerNorm that follows."""
         key = ('g', M, N, K)
         s = self._split_cache.get(key)
         if s is None:
@@ -531,8 +549,22 @@ class HipMAEEngine:
                 s -= 1
             self._split_cache[key] = s
         t = self._timed(2.0 * M * N * K, 'glds' if N < 8192 else 'glds_wide')   # wide = the 64x128-tile instantiation
-        lib.vitae_gemm_glds(1, 1, _ptr(x16), K, self._w16(w), K, _ptr(y), N, _ptr(y16), N, M, N, K, _ptr(bias), _ptr(res), N,
-                            epi, _ptr(aux), N, 0, s, self.ws16.data_ptr(), None, self.stream)
+        if rowstats is not None:
+            lib.vitae_gemm_glds_stats(1, 1, _ptr(x16), K, self._w16(w), K, _ptr(y), N, _ptr(y16), N, M, N, K, _ptr(bias), _ptr(res), N,
+                                      epi, _ptr(aux), N, 0, s, self.ws16.data_ptr(), None, _ptr(rowstats), self.stream)
+        else:
+            lib.vitae_gemm_glds(1, 1, _ptr(x16), K, self._w16(w), K, _ptr(y), N, _ptr(y16), N, M, N, K, _ptr(bias), _ptr(res), N,
+                                epi, _ptr(aux), N, 0, s, self.ws16.data_ptr(), None, self.stream)
+        if t is not None:
+            t.record()
+
+    def _g16_fwd_ln(self, x, stats, pre_ln, w, bias, M, N, K, y16_ln, mean, rstd, y=None, y16=None, epi=EPI_NONE, aux=None):
+        """y / y16 = epi(LayerNorm(x) @ W16^T + b) in one launch (x fp32 [M, K] with row statistics ``stats``); the bf16 LayerNorm
+        output and mean / rstd (what the backward reads) are stored on the way."""
+        t = self._timed(2.0 * M * N * K, 'glds')
+        lib.vitae_gemm_glds_lnfold(_ptr(x), K, _ptr(stats), stats.shape[0], _ptr(self.p[pre_ln + 'weight']), _ptr(self.p[pre_ln + 'bias']),
+                                   self.cfg.ln_eps, self._w16(w), K, _ptr(y), N, _ptr(y16), N, M, N, K, _ptr(bias), epi, _ptr(aux), N,
+                                   _ptr(y16_ln), K, _ptr(mean), _ptr(rstd), self.stream)
         if t is not None:
             t.record()
 
@@ -776,18 +808,33 @@ class HipMAEEngine:
     def _block_fwd16(self, pre, q, x_in, x_out, Bs, N, d, heads, hd, hid):
         """model/vit.py:139-144 with bf16 GEMM operands written by their producers."""
         b, p, M = self.buf, self.p, Bs * N
-        self._ln_fwd(x_in, pre + 'norm1.', None, b[q + 'mean1'], b[q + 'rstd1'], M, d, y16=b[q + 'y1_16'])
-        self._g16_fwd(b[q + 'y1_16'], p[pre + 'attn.qkv.weight'], p[pre + 'attn.qkv.bias'], M, 3 * d, d, y=b[q + 'qkv'])
+        fold = self.fold_ln and d in (512, 768, 1024)
+        i = int(q[3:-1])
+        st_in = b[q + 'st1'] if (fold and i > 0) else None                 # statistics of x_in (left by the block below)
+        st_out = b.get(f'{q[:3]}{i + 1}.st1') if fold else None           # ... of x_out for the block above (None: last block)
+        if st_in is not None:
+            self._g16_fwd_ln(x_in, st_in, pre + 'norm1.', p[pre + 'attn.qkv.weight'], p[pre + 'attn.qkv.bias'], M, 3 * d, d,
+                             b[q + 'y1_16'], b[q + 'mean1'], b[q + 'rstd1'], y=b[q + 'qkv'])
+        else:
+            self._ln_fwd(x_in, pre + 'norm1.', None, b[q + 'mean1'], b[q + 'rstd1'], M, d, y16=b[q + 'y1_16'])
+            self._g16_fwd(b[q + 'y1_16'], p[pre + 'attn.qkv.weight'], p[pre + 'attn.qkv.bias'], M, 3 * d, d, y=b[q + 'qkv'])
         t = self._timed(4.0 * Bs * heads * N * N * hd, 'attn')
         lib.vitae_sdpa_mfma_fwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(b[q + 'o_16']), _ptr(b[q + 'lse']), Bs, N, heads, hd,
                                 self.stream)
         if t is not None:
             t.record()
-        self._g16_fwd(b[q + 'o_16'], p[pre + 'attn.proj.weight'], p[pre + 'attn.proj.bias'], M, d, d, y=b[q + 'xmid'], res=x_in)
-        self._ln_fwd(b[q + 'xmid'], pre + 'norm2.', None, b[q + 'mean2'], b[q + 'rstd2'], M, d, y16=b[q + 'y2_16'])
-        self._g16_fwd(b[q + 'y2_16'], p[pre + 'mlp.fc1.weight'], p[pre + 'mlp.fc1.bias'], M, hid, d, y16=b[q + 'act_16'],
-                      epi=EPI_GELU, aux=b[q + 'hpre'])
-        self._g16_fwd(b[q + 'act_16'], p[pre + 'mlp.fc2.weight'], p[pre + 'mlp.fc2.bias'], M, d, hid, y=x_out, res=b[q + 'xmid'])
+        if fold:
+            self._g16_fwd(b[q + 'o_16'], p[pre + 'attn.proj.weight'], p[pre + 'attn.proj.bias'], M, d, d, y=b[q + 'xmid'], res=x_in,
+                          rowstats=b[q + 'st2'])
+            self._g16_fwd_ln(b[q + 'xmid'], b[q + 'st2'], pre + 'norm2.', p[pre + 'mlp.fc1.weight'], p[pre + 'mlp.fc1.bias'], M, hid, d,
+                             b[q + 'y2_16'], b[q + 'mean2'], b[q + 'rstd2'], y16=b[q + 'act_16'], epi=EPI_GELU, aux=b[q + 'hpre'])
+        else:
+            self._g16_fwd(b[q + 'o_16'], p[pre + 'attn.proj.weight'], p[pre + 'attn.proj.bias'], M, d, d, y=b[q + 'xmid'], res=x_in)
+            self._ln_fwd(b[q + 'xmid'], pre + 'norm2.', None, b[q + 'mean2'], b[q + 'rstd2'], M, d, y16=b[q + 'y2_16'])
+            self._g16_fwd(b[q + 'y2_16'], p[pre + 'mlp.fc1.weight'], p[pre + 'mlp.fc1.bias'], M, hid, d, y16=b[q + 'act_16'],
+                          epi=EPI_GELU, aux=b[q + 'hpre'])
+        self._g16_fwd(b[q + 'act_16'], p[pre + 'mlp.fc2.weight'], p[pre + 'mlp.fc2.bias'], M, d, hid, y=x_out, res=b[q + 'xmid'],
+                      rowstats=st_out)
 
     def _dqkv32(self, dqkv, N, hd):
         """fp32 dqkv is write-only on the bf16-operand path (the qkv weight / input gradients read the bf16 copy): skip it
