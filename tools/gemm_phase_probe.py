@@ -54,7 +54,8 @@ def run(name, M, N, K, akc=1, bkc=1, res=True, epi=0, split=None, cold=False):
           f'kernel span {float(last - first):.0f} clk; start skew {float(t[:, 0].max() - first):.0f}; '
           f'prologue issue {med(t[:, 1] - t[:, 0]):.0f}, first tile wait {med(t[:, 2] - t[:, 1]):.0f}, k-loop {med(t[:, 3] - t[:, 2]):.0f}'
           + f'; step 4: wait {med(t[:, 8] - t[:, 12]):.0f} barrier {med(t[:, 9] - t[:, 8]):.0f} issue {med(t[:, 10] - t[:, 9]):.0f} ds_read {med(t[:, 11] - t[:, 10]):.0f} mfma issue {med(t[:, 13] - t[:, 11]):.0f}'
-          + (f', to epilogue {med(fin[:, 5] - fin[:, 3]):.0f}, epilogue {med(fin[:, 6] - fin[:, 5]):.0f}, drain {med(fin[:, 7] - fin[:, 6]):.0f}' if len(fin) else ''))
+          + (f', to epilogue {med(fin[:, 5] - fin[:, 3]):.0f}, epilogue {med(fin[:, 6] - fin[:, 5]):.0f} (first barrier {med(fin[:, 12] - fin[:, 5]):.0f}, '
+             f'tile -> LDS + barrier {med(fin[:, 13] - fin[:, 12]):.0f}, rows out {med(fin[:, 6] - fin[:, 13]):.0f}), drain {med(fin[:, 7] - fin[:, 6]):.0f}' if len(fin) else ''))
 
 GELU = CONSTS['VITAE_EPI_GELU']
 for cold in (False,):

@@ -159,7 +159,11 @@ __device__ __forceinline__ void epilogue_rows(const GArgs& p, const float (&a)[N
     float* T = reinterpret_cast<float*>(smem);
     float* cs = T + BM * LDT;
     const int l31 = lane & 31, hi = lane >> 5;
+    auto estamp = [&](int i) {             // tools/gemm_phase_probe.py: epilogue phases (one launch, z = 0 only)
+        if (p.dbg && threadIdx.x == 0 && blockIdx.z == 0) p.dbg[(long)blockIdx.x * 16 + i] = __builtin_amdgcn_s_memtime();
+    };
     __syncthreads();                       // every wave is done with the operand stages
+    estamp(12);
 #pragma unroll
     for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
@@ -169,6 +173,7 @@ __device__ __forceinline__ void epilogue_rows(const GArgs& p, const float (&a)[N
                 T[(wm * (BM / WAVES_M) + fm * 32 + crow(r, hi)) * LDT + wn * (BN / 2) + fn * 32 + l31] = a[fm * FN + fn][r];
     if (p.out_colsum && (int)threadIdx.x < BN) cs[threadIdx.x] = 0.f;
     __syncthreads();
+    estamp(13);
     const int cg = threadIdx.x % CG, r0 = threadIdx.x / CG;
     const int n = n0 + 4 * cg;
     const bool ncol = n < p.N;                                   // N % 4 == 0 here: the whole group is in or out
@@ -221,14 +226,17 @@ __device__ __forceinline__ void epilogue_rows(const GArgs& p, const float (&a)[N
 #pragma unroll
                 for (int e = 0; e < 4; ++e) x[e] += rs[q][e];
             }
+#ifndef VITAE_EPI_ABLATE
+#define VITAE_EPI_ABLATE 0       // timing ablations of the row-major epilogue: 1 = no global stores, 2 = fp32 store only
+#endif
             if (p.C) {
                 if (acc_c) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) x[e] += co[q][e];
                 }
-                *reinterpret_cast<f32x4*>(p.C + m * ldc + n) = x;
+                if (VITAE_EPI_ABLATE != 1) *reinterpret_cast<f32x4*>(p.C + m * ldc + n) = x;
             }
-            if (p.C16) {
+            if (p.C16 && VITAE_EPI_ABLATE == 0) {
                 bf16x4 x16;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) x16[e] = (__bf16)x[e];
