@@ -317,12 +317,17 @@ def allreduce_mean_now(reducer: "GradBucketReducer"):
 
 
 def engine_bucket_ranges(engine) -> List[Tuple[int, int]]:
-    """[decoder+predictor matrices, encoder chunks from the top (the last one down to offset 0, i.e. with the patch
+    """[decoder+predictor matrices (one or two buckets: ``engine.dec_cut``), encoder chunks from the top (the last one down to offset 0, i.e. with the patch
     embedding), tokens+vectors] as element ranges of ``engine.grads`` — the completion order of
     ``HipMAEEngine.train_phase``'s backward phases."""
     lay = engine.layout
     dec0 = lay['decoder_embed.weight'][0]
-    out = [(dec0, engine.tok_off)]
+    cut = getattr(engine, 'dec_cut', 0)
+    if cut > 0:     # two decoder buckets: [top blocks, decoder_pred, predictor], then [decoder_embed, bottom blocks]
+        mid = lay[f'decoder_blocks.{cut}.attn.qkv.weight'][0]
+        out = [(mid, engine.tok_off), (dec0, mid)]
+    else:
+        out = [(dec0, engine.tok_off)]
     top = dec0
     bounds = engine.enc_chunk_bounds()
     for i, (hi, lo) in enumerate(bounds):

@@ -185,6 +185,7 @@ class HipMAEEngine:
         self.overlap_optimizer = os.environ.get('VITAE_OPT_IN_BACKWARD', '1') != '0'
         self._opt_pending = False
         self._pred_pending = False
+        self._pred_joined = False   # the predictor branch was joined by backward_dec(part='top')
         self.overlap_wgrad = True
         self._wg_events: Dict[str, torch.cuda.Event] = {}
         self._wg_pending = set()
@@ -1121,9 +1122,15 @@ class HipMAEEngine:
             self.backward_enc(hi, lo)
         self.backward_tail()
 
-    def backward_dec(self, have_dp: bool):
-        """loss chain, decoder, predictor, final encoder norm."""
+    def backward_dec(self, have_dp: bool, part: Optional[str] = None):
+        """loss chain, decoder, predictor, final encoder norm.  ``part``: None = all of it; 'top' = loss chain, decoder_pred,
+        decoder_norm and the decoder blocks down to ``dec_cut`` (and the join of the predictor branch: a stream forked inside a
+        captured phase must come back inside it); 'bottom' = the remaining blocks, sequence assembly, predictor / decoder_embed
+        into the latent gradient, final encoder norm.  After 'top' the gradients of decoder_pred, the top blocks and the
+        predictor are final (data-parallel bucket 0 of a two-bucket decoder)."""
         cfg = self.cfg
+        top, bottom = part in (None, 'top'), part in (None, 'bottom')
+        cut = self.dec_cut if part is not None else 0
         self.stream = torch.cuda.current_stream(self.device).cuda_stream
         st, b, p, g = self.stream, self.buf, self.p, self.g
         B, Be, keep, L, D, Dd, P = self.B, self.Be, self.keep, cfg.num_patches, cfg.embed_dim, cfg.decoder_embed_dim, cfg.patch_dim
@@ -1132,20 +1139,23 @@ class HipMAEEngine:
         view1 = self.view1
         pred_ptr, dpred_ptr, pbs = b['predfull'].data_ptr() + P * 4, b['dpredfull'].data_ptr() + P * 4, Nd * P
         a16 = self.act16
-        lib.vitae_loss_bwd_fused(pred_ptr, _ptr(b['pred_vol']), _ptr(view1), _ptr(b['mask']), _ptr(b['edge_p']), _ptr(b['edge_t']),
-                                 _ptr(self.hp), _ptr(b.get('dG')), dpred_ptr, (b['dpred_16'].data_ptr() + P * 2) if a16 else None,
-                                 None, pbs, self.mask_sum, B, C, Lz, Hy, Wx, ps, st)
         dx_ = b['decx']
         nd = cfg.decoder_depth
+        blocks = [i for i in reversed(range(nd)) if (i >= cut and top) or (i < cut and bottom)]
+        if top:
+            lib.vitae_loss_bwd_fused(pred_ptr, _ptr(b['pred_vol']), _ptr(view1), _ptr(b['mask']), _ptr(b['edge_p']), _ptr(b['edge_t']),
+                                     _ptr(self.hp), _ptr(b.get('dG')), dpred_ptr, (b['dpred_16'].data_ptr() + P * 2) if a16 else None,
+                                     None, pbs, self.mask_sum, B, C, Lz, Hy, Wx, ps, st)
         if a16:
-            # decoder_pred (bias grad from the fp32 dpred), decoder_norm -> dx, dx_16, fc2 bias grad of the last block
-            self._colsum_beside(b['dpredfull'], P, g['decoder_pred.bias'], Md, P, 'dpredfull')
-            self._g16_bwd(b['dpred_16'], p['decoder_pred.weight'], b['dn_16'], g['decoder_pred.weight'], Md, self.Mpd, P, Dd,
-                          dx=b['ddn'])
-            self._ln_bwd(b['ddn'], dx_[nd], 'decoder_norm.', b['dn_mean'], b['dn_rstd'], b['decdx'], Md, Dd, 0,
-                         dx16=b[f'dec{nd - 1}.gout_16'] if self.fuse_mlp else b['decdx_16'],
-                         dx_colsum=g[f'decoder_blocks.{nd - 1}.mlp.fc2.bias'])
-            for i in reversed(range(nd)):
+            if top:
+                # decoder_pred (bias grad from the fp32 dpred), decoder_norm -> dx, dx_16, fc2 bias grad of the last block
+                self._colsum_beside(b['dpredfull'], P, g['decoder_pred.bias'], Md, P, 'dpredfull')
+                self._g16_bwd(b['dpred_16'], p['decoder_pred.weight'], b['dn_16'], g['decoder_pred.weight'], Md, self.Mpd, P, Dd,
+                              dx=b['ddn'])
+                self._ln_bwd(b['ddn'], dx_[nd], 'decoder_norm.', b['dn_mean'], b['dn_rstd'], b['decdx'], Md, Dd, 0,
+                             dx16=b[f'dec{nd - 1}.gout_16'] if self.fuse_mlp else b['decdx_16'],
+                             dx_colsum=g[f'decoder_blocks.{nd - 1}.mlp.fc2.bias'])
+            for i in blocks:
                 if self.slab_k_bwd:
                     self._block_bwd_slabk(f'decoder_blocks.{i}.', f'dec{i}.', 'dec', dx_[i], B, Nd, Dd, cfg.decoder_num_heads,
                                           self.hdd, self.Hmd, self.Mpd, g[f'decoder_blocks.{i - 1}.mlp.fc2.bias'] if i > 0 else None)
@@ -1157,12 +1167,19 @@ class HipMAEEngine:
                     self._block_bwd16(f'decoder_blocks.{i}.', f'dec{i}.', 'dec', dx_[i], B, Nd, Dd, cfg.decoder_num_heads, self.hdd,
                                       self.Hmd, self.Mpd, g[f'decoder_blocks.{i - 1}.mlp.fc2.bias'] if i > 0 else None)
         else:
-            self._lin_bwd(b['dpredfull'], p['decoder_pred.weight'], b['dn'], b['ddn'], g['decoder_pred.weight'],
-                          g['decoder_pred.bias'], Md, P, Dd)
-            self._ln_bwd(b['ddn'], dx_[nd], 'decoder_norm.', b['dn_mean'], b['dn_rstd'], b['decdx'], Md, Dd, 0)
-            for i in reversed(range(nd)):
+            if top:
+                self._lin_bwd(b['dpredfull'], p['decoder_pred.weight'], b['dn'], b['ddn'], g['decoder_pred.weight'],
+                              g['decoder_pred.bias'], Md, P, Dd)
+                self._ln_bwd(b['ddn'], dx_[nd], 'decoder_norm.', b['dn_mean'], b['dn_rstd'], b['decdx'], Md, Dd, 0)
+            for i in blocks:
                 self._block_bwd(f'decoder_blocks.{i}.', f'dec{i}.', 'dec', dx_[i], B, Nd, Dd, cfg.decoder_num_heads, self.hdd,
                                 self.Hmd)
+        if part == 'top':
+            if cfg.contrastive and have_dp and self._pred_pending:
+                self._predictor_join()          # dph and the predictor's parameter gradients are final
+                self._pred_joined = True
+            self._wg_join()
+            return
         lib.vitae_decoder_assemble_bwd(_ptr(b['decdx']), _ptr(b['ids_shuffle']), _ptr(b['de']), _ptr(b.get('de_16')),
                                        _ptr(g['mask_token']), B, L, keep, Dd, st)
 
@@ -1181,8 +1198,9 @@ class HipMAEEngine:
             R = self.R
             if self._pred_pending:
                 self._predictor_join()          # dph and the predictor's parameter gradients are final
-            else:
+            elif not self._pred_joined:
                 self._predictor_bwd()
+            self._pred_joined = False
             self._lin_bwd_x(b['dph'], p['predictor.0.weight'], b['dlatent'], 2 * R, D, D)
             dec_embed_bwd(1)
         else:
@@ -1376,9 +1394,21 @@ class HipMAEEngine:
         exposed tail for the data-parallel all-reduce (each phase is its own graph replay)."""
         self.enc_chunks = max(1, min(int(n), self.cfg.depth))
 
+    # decoder backward in one phase (default) or two (data parallel: the gradients of decoder_pred, the top half of the decoder
+    # blocks and the predictor form a bucket of their own, whose all-reduce starts ~0.35 ms earlier)
+    dec_chunks = 1
+
+    @property
+    def dec_cut(self) -> int:
+        """first decoder block of the 'top' part (0 = everything in one phase)"""
+        return self.cfg.decoder_depth // 2 if self.dec_chunks == 2 else 0
+
+    def set_decoder_chunks(self, n: int):
+        self.dec_chunks = 2 if (int(n) >= 2 and self.cfg.decoder_depth >= 2) else 1
+
     @property
     def N_PHASES(self) -> int:
-        return self.enc_chunks + 2
+        return self.dec_chunks + self.enc_chunks + 1
 
     def enc_chunk_bounds(self):
         """[(hi, lo)] block ranges of the encoder-backward phases, last block first; sizes differ by at most one."""
@@ -1392,11 +1422,11 @@ class HipMAEEngine:
     def train_phase(self, k: int, view1, view2, noise, mask_ratio: float, update: bool = True,
                     accumulate: bool = False):
         """Phase k of one optimisation step (only kernel launches, no host sync):
-        0 = forward + losses + backward through decoder/predictor; 1 .. enc_chunks = encoder backward, top chunk first
-        (the last one also does the patch embedding); enc_chunks + 1 = grad-norm + AdamW.  Gradient bucket k (ddp) is
+        0 (.. dec_chunks - 1) = forward + losses + backward through decoder/predictor; then enc_chunks phases of encoder backward,
+        top chunk first (the last one also does the patch embedding); the last phase = grad-norm + AdamW.  Gradient bucket k (ddp) is
         final after phase k.  Loss multipliers and lr must already be in ``hp``."""
         cfg = self.cfg
-        n = self.enc_chunks
+        n, nd = self.enc_chunks, self.dec_chunks
         if k == 0:
             # the zeroing of the token / vector gradient segment and the loss finalisation are not on the dependent chain:
             # the first goes in front of the forward, the second behind the decoder backward (12 us between the loss kernels)
@@ -1405,18 +1435,22 @@ class HipMAEEngine:
             if cfg.contrastive:
                 self.contrastive_loss_fwd()
                 self.contrastive_loss_bwd()
-            self.backward_dec(have_dp=cfg.contrastive)
+            self.backward_dec(have_dp=cfg.contrastive, part='top' if nd == 2 else None)
             self.loss_finalize()
             if update and self._optimizer_in_backward_ok():
                 self._opt_bucket(0)
-        elif 1 <= k <= n:
-            hi, lo = self.enc_chunk_bounds()[k - 1]
+        elif k == 1 and nd == 2:
+            self.backward_dec(have_dp=cfg.contrastive, part='bottom')
+            if update and self._optimizer_in_backward_ok():
+                self._opt_bucket(1)
+        elif nd <= k < nd + n:
+            hi, lo = self.enc_chunk_bounds()[k - nd]
             self.backward_enc(hi, lo)
-            if k == n:
+            if k == nd + n - 1:
                 self.backward_tail()
             if update and self._optimizer_in_backward_ok():
                 self._opt_bucket(k)
-        elif k == n + 1 and update:
+        elif k == nd + n and update:
             if self._optimizer_in_backward_ok() or self._ddp_bucket_opt:
                 self._opt_tail()             # the buckets' matrices were stepped beside the backward
             else:

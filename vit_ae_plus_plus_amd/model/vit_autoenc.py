@@ -456,7 +456,12 @@ class MaskedAutoencoderViT(nn.Module):
         bus bandwidth, tools/probes/r2_ddp_model.sh: 5.63 / 5.07 ms against 5.80 / 5.27 ms with three even buckets)."""
         if enc_chunks is not None:
             eng.set_backward_chunks(enc_chunks)
+            eng.set_decoder_chunks(1)
             return
+        # decoder: optionally two buckets (VITAE_DEC_CHUNKS=2: decoder_pred + top blocks + predictor first, its all-reduce starts
+        # ~0.35 ms earlier).  Modelled ring (tools/probes/r2_ddp_model4.sh): 5.64 vs 5.78 ms at 150 GB/s bus bandwidth, but 5.26 vs
+        # 5.22 at 200 and 5.14 vs 5.11 at 300 (one more graph replay and bucket) — off unless the links turn out slow
+        eng.set_decoder_chunks(int(os.environ.get('VITAE_DEC_CHUNKS', '1')))
         if os.environ.get('VITAE_ENC_CHUNKS') or os.environ.get('VITAE_ENC_CUTS'):
             return
         d = eng.cfg.depth
