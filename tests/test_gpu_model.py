@@ -397,9 +397,9 @@ def test_gradient_accumulation_matches_oracle(name, dims, precision, tol, use_gr
         assert err < (0.05 if precision == 'fp32' else 0.25), (k, err)
 
 
-@pytest.mark.parametrize('comm', [None, 'bf16'])
-@pytest.mark.parametrize('use_graph', [False, True])
-def test_data_parallel_machinery_on_a_world_of_one(comm, use_graph):
+@pytest.mark.parametrize('comm,use_graph,dec_chunks', [(None, False, 1), (None, True, 1), ('bf16', False, 1), ('bf16', True, 1),
+                                                       (None, True, 2), ('bf16', False, 2)])
+def test_data_parallel_machinery_on_a_world_of_one(comm, use_graph, dec_chunks, monkeypatch):
     """The N > 1 step (per-phase graphs, bucketed all-reduce between them, buckets stepped on the optimiser stream as
     their exchange lands, optional bf16 wire) on a single-rank RCCL group: an all-reduce over one rank is the identity,
     so two steps must land where the single-process step lands (bf16 wire: to bf16 round-off of the gradients)."""
@@ -412,7 +412,7 @@ def test_data_parallel_machinery_on_a_world_of_one(comm, use_graph):
         dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
         created = True
     try:
-        cfg = R.RefConfig(contrastive=True, **ACT16)
+        cfg = R.RefConfig(contrastive=True, **dict(ACT16, decoder_depth=2 if dec_chunks == 2 else ACT16['decoder_depth']))
         sd = R.init_state_dict(cfg, seed=11)
         B, outs = 2, []
         for ddp_on in (False, True):
@@ -420,7 +420,14 @@ def test_data_parallel_machinery_on_a_world_of_one(comm, use_graph):
             opt = FusedAdamW(model, lr=1e-3, weight_decay=0.05)
             model._ensure_engine(torch.device('cuda', 0))
             eng = opt.engine
-            if ddp_on:
+            if ddp_on and dec_chunks == 2:
+                # default bucket structure (encoder: small last bucket) + the decoder backward in two phases / buckets
+                monkeypatch.setenv('VITAE_DEC_CHUNKS', '2')
+                red = model.enable_data_parallel(torch.device('cuda', 0), force=True, comm_dtype=torch.bfloat16 if comm else None)
+                assert eng.dec_chunks == 2 and eng.N_PHASES == 2 + eng.enc_chunks + 1 and len(red.ranges) == eng.N_PHASES
+                flat = sorted(r for parts in red.ranges for r in parts)
+                assert flat[0][0] == 0 and flat[-1][1] == eng.n_total and all(a[1] == b[0] for a, b in zip(flat, flat[1:]))
+            elif ddp_on:
                 red = model.enable_data_parallel(torch.device('cuda', 0), force=True,
                                                  comm_dtype=torch.bfloat16 if comm else None, enc_chunks=2)
                 assert red is not None and len(red.ranges) == 4

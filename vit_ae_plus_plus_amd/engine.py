@@ -1177,6 +1177,9 @@ class HipMAEEngine:
         if part == 'top':
             if cfg.contrastive and have_dp and self._pred_pending:
                 self._predictor_join()          # dph and the predictor's parameter gradients are final
+                # ... and dph goes through predictor.0 HERE: this phase's bucket holds that weight, and its AdamW runs beside
+                # the next phase
+                self._lin_bwd_x(b['dph'], p['predictor.0.weight'], b['dlatent'], 2 * self.R, D, D)
                 self._pred_joined = True
             self._wg_join()
             return
@@ -1196,12 +1199,14 @@ class HipMAEEngine:
         # predictor (both views) -> dlatent ; then decoder_embed adds into the view-1 rows
         if cfg.contrastive and have_dp:
             R = self.R
-            if self._pred_pending:
-                self._predictor_join()          # dph and the predictor's parameter gradients are final
-            elif not self._pred_joined:
-                self._predictor_bwd()
-            self._pred_joined = False
-            self._lin_bwd_x(b['dph'], p['predictor.0.weight'], b['dlatent'], 2 * R, D, D)
+            if self._pred_joined:               # part 'top' joined the branch and took dph through predictor.0 already
+                self._pred_joined = False
+            else:
+                if self._pred_pending:
+                    self._predictor_join()      # dph and the predictor's parameter gradients are final
+                else:
+                    self._predictor_bwd()
+                self._lin_bwd_x(b['dph'], p['predictor.0.weight'], b['dlatent'], 2 * R, D, D)
             dec_embed_bwd(1)
         else:
             if cfg.contrastive:   # predictor unused this step: its matrices get exact zeros
