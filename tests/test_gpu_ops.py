@@ -842,3 +842,42 @@ def test_gemm_lnfold(lib, C, M, N, K, epi):
                                C['VITAE_EPI_GELU'] if epi else C['VITAE_EPI_NONE'], None if aux is None else aux.data_ptr(), N,
                                None, 0, None, None, st())
     assert torch.equal(y2, y)
+
+
+@pytest.mark.parametrize('B,N,H,hd', [(8, 55, 12, 64), (4, 217, 16, 32), (2, 129, 16, 64), (1, 17, 4, 32)])
+def test_sdpa_mfma_bf16_input(lib, B, N, H, hd):
+    """Attention forward + one-launch backward reading q | k | v from the bf16 copy the qkv GEMM writes: same results as the
+    fp32-input kernels fed the bf16-rounded values (they round while staging; only q's softmax scale is applied after the rounding
+    here), and the reference within the usual bf16 bounds."""
+    D = H * hd
+    qkv = _bf(gen(B, N, 3 * D, seed=1)).float()
+    do = gen(B, N, D, seed=2)
+    assert lib.vitae_sdpa_bwd_fused_fits(N, hd) == 1
+    qd, q16, dod = dev(qkv), dev(_bf(qkv)), dev(do)
+    outs = []
+    for bf in (False, True):
+        o, lse = torch.full((B, N, D), float('nan'), device='cuda'), torch.empty(B * H * N, device='cuda')
+        o16 = torch.empty(B, N, D, dtype=torch.bfloat16, device='cuda')
+        g16 = torch.empty(B, N, 3 * D, dtype=torch.bfloat16, device='cuda')
+        cs = torch.zeros(3 * D, device='cuda')
+        if bf:
+            lib.vitae_sdpa_mfma_fwd_bf16in(q16.data_ptr(), o.data_ptr(), o16.data_ptr(), lse.data_ptr(), B, N, H, hd, st())
+            lib.vitae_sdpa_mfma_bwd_bf16in(q16.data_ptr(), o.data_ptr(), dod.data_ptr(), lse.data_ptr(), None, g16.data_ptr(), cs.data_ptr(),
+                                           B, N, H, hd, st())
+        else:
+            delta = torch.empty(B * H * N, device='cuda')
+            lib.vitae_sdpa_mfma_fwd(qd.data_ptr(), o.data_ptr(), o16.data_ptr(), lse.data_ptr(), B, N, H, hd, st())
+            lib.vitae_sdpa_mfma_bwd(qd.data_ptr(), o.data_ptr(), dod.data_ptr(), lse.data_ptr(), None, g16.data_ptr(), cs.data_ptr(),
+                                    delta.data_ptr(), B, N, H, hd, st())
+        outs.append((o.cpu(), lse.cpu(), g16.float().cpu(), cs.cpu()))
+    (o0, l0, g0, c0), (o1, l1, g1, c1) = outs
+    assert rel_err(o1, o0) < 1e-2 and float((l1 - l0).abs().max()) < 2e-2
+    assert rel_err(g1, g0) < 2e-2 and rel_err(c1, c0) < 2e-2
+    qr = qkv.clone().requires_grad_(True)
+    q, k, v = qr.reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    ref = (((q @ k.transpose(-2, -1)) * hd ** -0.5).softmax(-1) @ v).transpose(1, 2).reshape(B, N, D)
+    ref.backward(do)
+    assert rel_err(o1, ref) < 2e-2
+    g, got = qr.grad.reshape(B, N, 3, D), g1.reshape(B, N, 3, D)
+    for i, name in enumerate('qkv'):
+        assert rel_err(got[:, :, i], g[:, :, i]) < 3e-2, name

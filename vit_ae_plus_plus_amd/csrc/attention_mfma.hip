@@ -43,6 +43,29 @@ __device__ __forceinline__ bf16x8 load_frag(const float* __restrict__ p, bool va
     return cvt8(a, b, mul);
 }
 
+// the same from a bf16 source (the qkv GEMM's bf16 copy): one 16-byte load, no conversion unless a scale is folded in
+__device__ __forceinline__ bf16x8 load_frag(const __bf16* __restrict__ p, bool valid, float mul) {
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
+    if (valid) v = *reinterpret_cast<const bf16x8*>(p);
+    if (mul != 1.f) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (__bf16)((float)v[e] * mul);
+    }
+    return v;
+}
+
+// rows [r0, r0 + CH) of a [*, HD] bf16 matrix (row stride ld) -> bf16 LDS tile [CH][HD + 8]: 16-byte copies
+template <int HD>
+__device__ __forceinline__ void stage_bf16(__bf16* dst, const __bf16* __restrict__ src, long ld, int r0, int N, float mul) {
+    constexpr int LD = HD + 8, V = HD / 8;
+    for (int idx = threadIdx.x; idx < CH * V; idx += 256) {
+        const int row = idx / V, c8 = idx % V;
+        *reinterpret_cast<bf16x8*>(dst + row * LD + c8 * 8) = load_frag(src + (long)(r0 + row) * ld + c8 * 8, r0 + row < N, mul);
+    }
+}
+
 // rows [r0, r0 + CH) of a [*, HD] fp32 matrix (row stride ld) -> bf16 LDS tile [CH][HD + 8]
 template <int HD>
 __device__ __forceinline__ void stage_bf16(__bf16* dst, const float* __restrict__ src, long ld, int r0, int N, float mul) {
@@ -115,8 +138,8 @@ __device__ __forceinline__ void colsum_to(float (&v)[NV], bool valid, float* __r
 }
 
 // ------------------------------------------------------------------------------- forward
-template <int HD>
-__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ o,
+template <int HD, typename QT = float>
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const QT* __restrict__ qkv, float* __restrict__ o,
                                                             __bf16* __restrict__ o16,
                                                             float* __restrict__ lse, int N, int H, float scale) {
     constexpr int LD = HD + 8, NKK = HD / 16, NT = HD / 32;
@@ -126,7 +149,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float* __restr
     const int l31 = lane & 31, hi = lane >> 5;
     const int D = H * HD;
     const long ld = 3L * D;
-    const float* base = qkv + (long)b * N * ld + h * HD;
+    const QT* base = qkv + (long)b * N * ld + h * HD;
     const int q0 = (blockIdx.x * 4 + wave) * 32, qrow = q0 + l31;
     const bool qvalid = qrow < N, wave_live = q0 < N;
     bf16x8 qf[NKK];
@@ -415,8 +438,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const float* __r
 // and dK/dV tiles (as the dkv kernel).  One launch instead of two, no delta round trip through HBM, and all four
 // waves have work at N = 55 (two dQ + two dK/dV items).  qkv-bias column sums are collected with LDS atomics and
 // leave the block as one global atomic per column.
-template <int HD>
-__global__ __launch_bounds__(256) void attn_bwd_fused_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
+template <int HD, typename QT = float>
+__global__ __launch_bounds__(256) void attn_bwd_fused_kernel(const QT* __restrict__ qkv, const float* __restrict__ o,
                                                              const float* __restrict__ d_o, const float* __restrict__ lse,
                                                              float* __restrict__ dqkv, __bf16* __restrict__ dqkv16,
                                                              float* __restrict__ dbias, int N, int H, float scale, int NP) {
@@ -433,24 +456,40 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(const float* __rest
     const int l31 = lane & 31, hi = lane >> 5;
     const int D = H * HD;
     const long ld = 3L * D;
-    const float* base = qkv + (long)b * N * ld + h * HD;
+    const QT* base = qkv + (long)b * N * ld + h * HD;
     const float* gbase = d_o + (long)b * N * D + h * HD;
     const float* obase = o + (long)b * N * D + h * HD;
     // ---- stage the four operand tiles (rows >= N zero) and the per-row scalars
     for (int idx = threadIdx.x; idx < NP * V4; idx += 256) {
         const int row = idx / V4, c4 = (idx % V4) * 4;
-        f32x4 q = {0.f, 0.f, 0.f, 0.f}, k = q, v = q, g = q;
-        if (row < N) {
-            const float* r = base + (long)row * ld + c4;
-            q = *reinterpret_cast<const f32x4*>(r);
-            k = *reinterpret_cast<const f32x4*>(r + D);
-            v = *reinterpret_cast<const f32x4*>(r + 2 * D);
-            g = *reinterpret_cast<const f32x4*>(gbase + (long)row * D + c4);
-        }
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
         bf16x4 q16, k16, v16, g16;
+        if constexpr (sizeof(QT) == 2) {
+            // bf16 qkv (the GEMM's own bf16 copy): k and v pass through, q takes the softmax scale
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            q16[e] = (__bf16)(q[e] * (scale * LOG2E)); k16[e] = (__bf16)k[e]; v16[e] = (__bf16)v[e]; g16[e] = (__bf16)g[e];
+            for (int e = 0; e < 4; ++e) { q16[e] = (__bf16)0.f; k16[e] = (__bf16)0.f; v16[e] = (__bf16)0.f; }
+            if (row < N) {
+                const QT* r = base + (long)row * ld + c4;
+                q16 = *reinterpret_cast<const bf16x4*>(r);
+                k16 = *reinterpret_cast<const bf16x4*>(r + D);
+                v16 = *reinterpret_cast<const bf16x4*>(r + 2 * D);
+                g = *reinterpret_cast<const f32x4*>(gbase + (long)row * D + c4);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { q16[e] = (__bf16)((float)q16[e] * (scale * LOG2E)); g16[e] = (__bf16)g[e]; }
+        } else {
+            f32x4 q = {0.f, 0.f, 0.f, 0.f}, k = q, v = q;
+            if (row < N) {
+                const QT* r = base + (long)row * ld + c4;
+                q = *reinterpret_cast<const f32x4*>(r);
+                k = *reinterpret_cast<const f32x4*>(r + D);
+                v = *reinterpret_cast<const f32x4*>(r + 2 * D);
+                g = *reinterpret_cast<const f32x4*>(gbase + (long)row * D + c4);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                q16[e] = (__bf16)(q[e] * (scale * LOG2E)); k16[e] = (__bf16)k[e]; v16[e] = (__bf16)v[e]; g16[e] = (__bf16)g[e];
+            }
         }
         *reinterpret_cast<bf16x4*>(Qs + row * LD + c4) = q16;
         *reinterpret_cast<bf16x4*>(Ks + row * LD + c4) = k16;
@@ -652,17 +691,70 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(const float* __rest
 
 // Returns VITAE_ERR_UNSUPPORTED_SHAPE for head dims without an MFMA instantiation (caller falls back
 // to the fp32 VALU kernels of attention.hip — same results to bf16 round-off).
-extern "C" int vitae_sdpa_mfma_fwd(const float* qkv, float* o, void* o_bf16, float* lse, int B, int N, int H, int head_dim,
-                                   void* stream) {
+template <typename QT>
+static int sdpa_mfma_fwd_launch(const QT* qkv, float* o, void* o_bf16, float* lse, int B, int N, int H, int head_dim, void* stream) {
     if (!qkv || !o || !lse || B <= 0 || N <= 0 || H <= 0) return VITAE_ERR_INVALID_ARG;
-    if ((((long)H * head_dim) & 3) || ((uintptr_t)qkv & 15) || ((uintptr_t)o & 15)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    if ((((long)H * head_dim) & 7) || ((uintptr_t)qkv & 15) || ((uintptr_t)o & 15)) return VITAE_ERR_UNSUPPORTED_SHAPE;
     const float scale = 1.0f / sqrtf((float)head_dim);
     dim3 grid(cdiv(N, 128), H, B);
     hipStream_t st = (hipStream_t)stream;
     __bf16* o16 = reinterpret_cast<__bf16*>(o_bf16);
-    if (head_dim == 32) hipLaunchKernelGGL((attn_fwd_mfma_kernel<32>), grid, dim3(256), 0, st, qkv, o, o16, lse, N, H, scale);
-    else if (head_dim == 64) hipLaunchKernelGGL((attn_fwd_mfma_kernel<64>), grid, dim3(256), 0, st, qkv, o, o16, lse, N, H, scale);
+    if (head_dim == 32) hipLaunchKernelGGL((attn_fwd_mfma_kernel<32, QT>), grid, dim3(256), 0, st, qkv, o, o16, lse, N, H, scale);
+    else if (head_dim == 64) hipLaunchKernelGGL((attn_fwd_mfma_kernel<64, QT>), grid, dim3(256), 0, st, qkv, o, o16, lse, N, H, scale);
     else return VITAE_ERR_UNSUPPORTED_SHAPE;
+    return vitae_launch_status();
+}
+
+extern "C" int vitae_sdpa_mfma_fwd(const float* qkv, float* o, void* o_bf16, float* lse, int B, int N, int H, int head_dim,
+                                   void* stream) {
+    return sdpa_mfma_fwd_launch<float>(qkv, o, o_bf16, lse, B, N, H, head_dim, stream);
+}
+
+// the same with q | k | v read from the bf16 copy the qkv GEMM writes (no fp32 qkv in HBM at all)
+extern "C" int vitae_sdpa_mfma_fwd_bf16in(const void* qkv_bf16, float* o, void* o_bf16, float* lse, int B, int N, int H,
+                                          int head_dim, void* stream) {
+    return sdpa_mfma_fwd_launch<__bf16>(reinterpret_cast<const __bf16*>(qkv_bf16), o, o_bf16, lse, B, N, H, head_dim, stream);
+}
+
+// one-launch backward from bf16 q | k | v; VITAE_ERR_UNSUPPORTED_SHAPE when the head does not fit LDS (the caller then keeps an
+// fp32 qkv and uses vitae_sdpa_mfma_bwd).  vitae_sdpa_bwd_fused_fits() answers that up front.
+extern "C" int vitae_sdpa_bwd_fused_fits(int N, int head_dim) {
+    static const int fused_on = getenv("VITAE_ATTN_BWD_FUSED") ? atoi(getenv("VITAE_ATTN_BWD_FUSED")) : 1;
+    const int NP = cdiv(N, 32) * 32;
+    const size_t lds = (size_t)4 * NP * (head_dim + 8) * 2 + (size_t)2 * NP * 4 + (size_t)3 * head_dim * 4;
+    return fused_on && (head_dim == 32 || head_dim == 64) && lds <= 150 * 1024;
+}
+
+extern "C" int vitae_sdpa_mfma_bwd_bf16in(const void* qkv_bf16, const float* o, const float* d_o, const float* lse, float* dqkv,
+                                          void* dqkv_bf16, float* dqkv_colsum_accum, int B, int N, int H, int head_dim,
+                                          void* stream) {
+    if (!qkv_bf16 || !o || !d_o || !lse || (!dqkv && !dqkv_bf16) || B <= 0 || N <= 0 || H <= 0) return VITAE_ERR_INVALID_ARG;
+    if ((((long)H * head_dim) & 7) || ((uintptr_t)qkv_bf16 & 15) || ((uintptr_t)o & 15) || ((uintptr_t)d_o & 15) ||
+        ((uintptr_t)dqkv & 15) || !vitae_sdpa_bwd_fused_fits(N, head_dim))
+        return VITAE_ERR_UNSUPPORTED_SHAPE;
+    const float scale = 1.0f / sqrtf((float)head_dim);
+    const int NP = cdiv(N, 32) * 32;
+    const size_t lds = (size_t)4 * NP * (head_dim + 8) * 2 + (size_t)2 * NP * 4 + (size_t)3 * head_dim * 4;
+    const int items = 2 * (NP / 32);
+    int G = cdiv(items, 4);
+    if ((long)G * H * B > 1024) G = cdiv(items, 8);
+    dim3 fgrid(G, H, B);
+    hipStream_t st = (hipStream_t)stream;
+    const __bf16* q16 = reinterpret_cast<const __bf16*>(qkv_bf16);
+    __bf16* g16 = reinterpret_cast<__bf16*>(dqkv_bf16);
+    if (head_dim == 32) {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<32, __bf16>),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)attr;
+        hipLaunchKernelGGL((attn_bwd_fused_kernel<32, __bf16>), fgrid, dim3(256), lds, st, q16, o, d_o, lse, dqkv, g16,
+                           dqkv_colsum_accum, N, H, scale, NP);
+    } else {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<64, __bf16>),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)attr;
+        hipLaunchKernelGGL((attn_bwd_fused_kernel<64, __bf16>), fgrid, dim3(256), lds, st, q16, o, d_o, lse, dqkv, g16,
+                           dqkv_colsum_accum, N, H, scale, NP);
+    }
     return vitae_launch_status();
 }
 

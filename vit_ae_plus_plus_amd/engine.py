@@ -144,6 +144,9 @@ class HipMAEEngine:
         # wgrad half and the 900-workgroup grid set their duration, while the slab-summing LayerNorm backward costs 1.5 us
         # more: so the backward keeps the in-launch reduction unless VITAE_SLAB_SPLITK_BWD=1)
         self.slab_k_bwd = self.slab_k and os.environ.get('VITAE_SLAB_SPLITK_BWD', '0') != '0'
+        # q | k | v leave the qkv GEMM in bf16 only and the attention kernels read that (no fp32 qkv in HBM: the GEMM epilogue is
+        # bound by its output bytes, and the kernels no longer convert while staging); needs the one-launch attention backward
+        self.qkv16 = self.act16 and not self.fuse_mlp and not self.slab_k and os.environ.get('VITAE_QKV_BF16', '1') != '0'
         # OPT-IN (measured: 4.83-4.88 vs 4.81-4.87 ms at batch 4, slower at batch 8 / 32 — DESIGN.md section 3c): LayerNorm folded
         # into the GEMM that consumes it (csrc/gemm_glds.hip: vitae_gemm_glds_stats leaves the row statistics of the residual
         # stream, vitae_gemm_glds_lnfold normalises while it loads): no standalone norm1 / norm2 launch except in front of the
@@ -322,6 +325,8 @@ class HipMAEEngine:
                 for i in range(depth):
                     q = f'{pre}{i}.'
                     b[q + 'y1_16'], b[q + 'o_16'], b[q + 'y2_16'], b[q + 'act_16'] = z16(Mp, d), z16(Mp, d), z16(Mp, d), z16(Mp, h)
+                    if self.qkv16:
+                        b[q + 'qkv_16'] = z16(Mp, 3 * d)
                 b[pre + 'dx_16'], b[pre + 'dh_16'], b[pre + 'dqkv_16'] = z16(Mp, d), z16(Mp, h), z16(Mp, 3 * d)
                 if self.fuse_mlp:
                     # per block: the four dy operands of its (deferred) weight gradients + the saved fc1 pre-activation
@@ -813,15 +818,21 @@ class HipMAEEngine:
         i = int(q[3:-1])
         st_in = b[q + 'st1'] if (fold and i > 0) else None                 # statistics of x_in (left by the block below)
         st_out = b.get(f'{q[:3]}{i + 1}.st1') if fold else None           # ... of x_out for the block above (None: last block)
+        q16 = self._qkv16_ok(N, hd)
+        qkv32, qkv16 = (None, b[q + 'qkv_16']) if q16 else (b[q + 'qkv'], None)
         if st_in is not None:
             self._g16_fwd_ln(x_in, st_in, pre + 'norm1.', p[pre + 'attn.qkv.weight'], p[pre + 'attn.qkv.bias'], M, 3 * d, d,
-                             b[q + 'y1_16'], b[q + 'mean1'], b[q + 'rstd1'], y=b[q + 'qkv'])
+                             b[q + 'y1_16'], b[q + 'mean1'], b[q + 'rstd1'], y=qkv32, y16=qkv16)
         else:
             self._ln_fwd(x_in, pre + 'norm1.', None, b[q + 'mean1'], b[q + 'rstd1'], M, d, y16=b[q + 'y1_16'])
-            self._g16_fwd(b[q + 'y1_16'], p[pre + 'attn.qkv.weight'], p[pre + 'attn.qkv.bias'], M, 3 * d, d, y=b[q + 'qkv'])
+            self._g16_fwd(b[q + 'y1_16'], p[pre + 'attn.qkv.weight'], p[pre + 'attn.qkv.bias'], M, 3 * d, d, y=qkv32, y16=qkv16)
         t = self._timed(4.0 * Bs * heads * N * N * hd, 'attn')
-        lib.vitae_sdpa_mfma_fwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(b[q + 'o_16']), _ptr(b[q + 'lse']), Bs, N, heads, hd,
-                                self.stream)
+        if q16:
+            lib.vitae_sdpa_mfma_fwd_bf16in(_ptr(qkv16), _ptr(b[q + 'o']), _ptr(b[q + 'o_16']), _ptr(b[q + 'lse']), Bs, N, heads, hd,
+                                           self.stream)
+        else:
+            lib.vitae_sdpa_mfma_fwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(b[q + 'o_16']), _ptr(b[q + 'lse']), Bs, N, heads, hd,
+                                    self.stream)
         if t is not None:
             t.record()
         if fold:
@@ -836,6 +847,10 @@ class HipMAEEngine:
                           epi=EPI_GELU, aux=b[q + 'hpre'])
         self._g16_fwd(b[q + 'act_16'], p[pre + 'mlp.fc2.weight'], p[pre + 'mlp.fc2.bias'], M, d, hid, y=x_out, res=b[q + 'xmid'],
                       rowstats=st_out)
+
+    def _qkv16_ok(self, N, hd) -> bool:
+        """bf16-only qkv for this stack: the flag, an MFMA head size, and the whole head fitting the one-launch backward"""
+        return bool(self.qkv16 and hd in (32, 64) and lib.vitae_sdpa_bwd_fused_fits(N, hd))
 
     def _dqkv32(self, dqkv, N, hd):
         """fp32 dqkv is write-only on the bf16-operand path (the qkv weight / input gradients read the bf16 copy): skip it
@@ -859,8 +874,12 @@ class HipMAEEngine:
                      dx_colsum=g[pre + 'attn.proj.bias'])
         self._g16_bwd(dx16, p[pre + 'attn.proj.weight'], b[q + 'o_16'], g[pre + 'attn.proj.weight'], M, Mp, d, d, dx=do)
         t = self._timed(10.0 * Bs * heads * N * N * hd, 'attn')
-        lib.vitae_sdpa_mfma_bwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(do), _ptr(b[q + 'lse']), _ptr(self._dqkv32(dqkv, N, hd)), _ptr(dqkv16),
-                                None, _ptr(b['delta']), Bs, N, heads, hd, self.stream)
+        if self._qkv16_ok(N, hd):
+            lib.vitae_sdpa_mfma_bwd_bf16in(_ptr(b[q + 'qkv_16']), _ptr(b[q + 'o']), _ptr(do), _ptr(b[q + 'lse']), None, _ptr(dqkv16), None,
+                                           Bs, N, heads, hd, self.stream)
+        else:
+            lib.vitae_sdpa_mfma_bwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(do), _ptr(b[q + 'lse']), _ptr(self._dqkv32(dqkv, N, hd)),
+                                    _ptr(dqkv16), None, _ptr(b['delta']), Bs, N, heads, hd, self.stream)
         if t is not None:
             t.record()
         # the qkv bias gradient colsum(dqkv) rides on the wgrad workgroups (one extra MFMA against a ones operand)
