@@ -881,3 +881,34 @@ def test_sdpa_mfma_bf16_input(lib, B, N, H, hd):
     g, got = qr.grad.reshape(B, N, 3, D), g1.reshape(B, N, 3, D)
     for i, name in enumerate('qkv'):
         assert rel_err(got[:, :, i], g[:, :, i]) < 3e-2, name
+
+
+@pytest.mark.parametrize('M,N,K', [(440, 3072, 768), (868, 2048, 512), (70, 512, 512)])
+def test_gemm_bf16_saved_preactivation(lib, C, M, N, K):
+    """VITAE_EPI_AUX_BF16: the fc1 epilogue saves its pre-activation in bf16 and the fc2 input gradient's GELU' reads that."""
+    Mp = (M + 63) // 64 * 64
+    x, w, bias = _bf(gen(M, K, seed=1)).float(), _bf(gen(N, K, seed=2, scale=K ** -0.5)).float(), gen(N, seed=3)
+    x16 = torch.zeros(Mp, K, dtype=torch.bfloat16, device='cuda'); x16[:M] = _bf(x).cuda()
+    w16 = dev(_bf(w))
+    y16 = torch.zeros(Mp, N, dtype=torch.bfloat16, device='cuda')
+    aux16 = torch.full((M, N), float('nan'), dtype=torch.bfloat16, device='cuda')
+    lib.vitae_gemm_glds(1, 1, x16.data_ptr(), K, w16.data_ptr(), K, None, 0, y16.data_ptr(), N, M, N, K, dev(bias).data_ptr(), None, 0,
+                        C['VITAE_EPI_GELU'] | C['VITAE_EPI_AUX_BF16'], aux16.data_ptr(), N, 0, 1, None, None, st())
+    pre = x @ w.t() + bias
+    assert rel_err(aux16.float(), pre) < 1e-2
+    assert rel_err(y16[:M].float(), F.gelu(pre)) < 2e-2
+    # backward of the NEXT Linear (fc2): dh = (dy @ W2) * gelu'(pre), pre read from the bf16 copy
+    D2 = 256
+    dy, w2 = _bf(gen(M, D2, seed=4)).float(), _bf(gen(D2, N, seed=5, scale=N ** -0.5)).float()
+    dy16 = torch.zeros(Mp, D2, dtype=torch.bfloat16, device='cuda'); dy16[:M] = _bf(dy).cuda()
+    dh16 = torch.zeros(Mp, N, dtype=torch.bfloat16, device='cuda')
+    dw = torch.full((D2, N), float('nan'), device='cuda')
+    sp = lib.vitae_linear_bwd_pair_pick_split_k(M, Mp, D2, N)
+    ws = torch.zeros(max(1, lib.vitae_gemm_glds_ws_floats(M, N, max(sp, 1))), device='cuda')
+    lib.vitae_linear_bwd_pair_glds(dy16.data_ptr(), dev(_bf(w2)).data_ptr(), y16.data_ptr(), None, dh16.data_ptr(), dw.data_ptr(), None,
+                                   M, Mp, D2, N, C['VITAE_EPI_DGELU'] | C['VITAE_EPI_AUX_BF16'], aux16.data_ptr(), None, None, 0, 0, sp,
+                                   ws.data_ptr(), st())
+    p = aux16.float().cpu().requires_grad_(True)
+    F.gelu(p).backward(dy @ w2)
+    assert rel_err(dh16[:M].float(), p.grad) < 2e-2
+    assert rel_err(dw, dy.t() @ y16[:M].float().cpu()) < 1e-2

@@ -46,6 +46,7 @@ struct GArgs {
     long slab_stride;    // != 0 ("slab mode"): k-split z stores its partial tile at C + z * slab_stride and is done — the splits
                          // are summed by the kernel that consumes the result anyway (vitae_layernorm_{fwd,bwd}_slabs: the
                          // launch-boundary reduce); no tickets, no partial round trip inside the launch
+    int aux16 = 0;               // aux holds bf16 (VITAE_EPI_AUX_BF16): the saved GELU pre-activation at half the bytes
     float* rowstats = nullptr;   // optional (row-major epilogue only): rowstats[n / 64][m] = (sum, sum of squares) of result(m, 64-column
                          // slot) — the LayerNorm statistics of the NEXT op, taken while the rows pass through (vitae_gemm_glds_lnfold)
     long long* dbg;      // optional (tools/gemm_phase_probe.py): 8 s_memtime stamps per workgroup
@@ -83,7 +84,8 @@ __device__ __forceinline__ float epilogue_frag(const GArgs& p, const float (&v)[
         for (int q = 0; q < 8; ++q) mrow[q] = min(mbase + crow(8 * half + q, hi), p.M - 1);
         if (need_aux) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) ax[q] = p.aux[mrow[q] * ldaux + nc];
+            for (int q = 0; q < 8; ++q)
+                ax[q] = p.aux16 ? (float)reinterpret_cast<const __bf16*>(p.aux)[mrow[q] * ldaux + nc] : p.aux[mrow[q] * ldaux + nc];
         }
         if (p.residual) {
 #pragma unroll
@@ -99,7 +101,8 @@ __device__ __forceinline__ float epilogue_frag(const GArgs& p, const float (&v)[
             if (!(ncol && m < p.M)) continue;
             float x = v[8 * half + q] + bias;
             if (p.epi == VITAE_EPI_GELU) {
-                p.aux[m * ldaux + n] = x;
+                if (p.aux16) reinterpret_cast<__bf16*>(p.aux)[m * ldaux + n] = (__bf16)x;
+                else p.aux[m * ldaux + n] = x;
                 x = gelu_fast(x);
             } else if (p.epi == VITAE_EPI_DGELU) {
                 x *= gelu_fast_grad(ax[q]);
@@ -194,7 +197,14 @@ __device__ __forceinline__ void epilogue_rows(const GArgs& p, const float (&a)[N
 #pragma unroll
         for (int q = 0; q < PB; ++q) {
             const int mc = min(m0 + r0 + (pb + q) * RPP, p.M - 1);
-            if (need_aux) ax[q] = *reinterpret_cast<const f32x4*>(p.aux + mc * ldaux + nc);
+            if (need_aux) {
+                if (p.aux16) {
+                    const bf16x4 h = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(p.aux) + mc * ldaux + nc);
+                    ax[q] = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+                } else {
+                    ax[q] = *reinterpret_cast<const f32x4*>(p.aux + mc * ldaux + nc);
+                }
+            }
             if (p.residual) {
                 if (pre.have) rs[q] = pre.res[(pb + q) & 3];
                 else rs[q] = *reinterpret_cast<const f32x4*>(p.residual + mc * ldr + nc);
@@ -209,7 +219,14 @@ __device__ __forceinline__ void epilogue_rows(const GArgs& p, const float (&a)[N
 #pragma unroll
             for (int e = 0; e < 4; ++e) x[e] += bias4[e];
             if (p.epi == VITAE_EPI_GELU) {
-                *reinterpret_cast<f32x4*>(p.aux + m * ldaux + n) = x;
+                if (p.aux16) {
+                    bf16x4 h;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) h[e] = (__bf16)x[e];
+                    *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.aux) + m * ldaux + n) = h;
+                } else {
+                    *reinterpret_cast<f32x4*>(p.aux + m * ldaux + n) = x;
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) x[e] = gelu_fast(x[e]);
             } else if (p.epi == VITAE_EPI_DGELU) {
@@ -982,6 +999,8 @@ static int gemm_glds_launch(int a_kcontig, int b_kcontig, const void* A16, long 
                             const float* residual, long ldr, int epi, float* aux, long ldaux, int accumulate,
                             int split_k, float* splitk_ws, float* out_colsum_accum, float* out_rowstats, void* stream) {
     if (!A16 || !B16 || (!C && !C16) || M <= 0 || N <= 0 || K <= 0) return VITAE_ERR_INVALID_ARG;
+    const int aux16 = (epi & VITAE_EPI_AUX_BF16) != 0;
+    epi &= ~VITAE_EPI_AUX_BF16;
     if (epi != VITAE_EPI_NONE && epi != VITAE_EPI_RELU && !aux) return VITAE_ERR_INVALID_ARG;
     if (K % BK) return VITAE_ERR_UNSUPPORTED_SHAPE;
     if ((long)M * (ldc > N ? ldc : N) >= (1L << 31) || (long)M * ldaux >= (1L << 31) || (long)M * ldr >= (1L << 31) ||
@@ -1002,7 +1021,7 @@ static int gemm_glds_launch(int a_kcontig, int b_kcontig, const void* A16, long 
     if (split_k > 1 && !splitk_ws) return VITAE_ERR_INVALID_ARG;
     p.k_per_split = kps; p.splits = split_k;
     p.bias = bias; p.residual = residual; p.ldr = ldr; p.aux = aux; p.ldaux = ldaux;
-    p.epi = epi; p.accumulate = accumulate; p.ws = splitk_ws; p.out_colsum = out_colsum_accum; p.a_rowsum = nullptr;
+    p.epi = epi; p.aux16 = aux16; p.accumulate = accumulate; p.ws = splitk_ws; p.out_colsum = out_colsum_accum; p.a_rowsum = nullptr;
     p.dbg = g_gemm_dbg; p.slab_stride = 0;
     const Tile t = pick_tile(M, N);
     p.tiles_m = cdiv(M, t.bm); p.tiles_n = cdiv(N, t.bn);
@@ -1055,6 +1074,8 @@ extern "C" int vitae_gemm_glds_lnfold(const float* X, long ldx, const float* sta
                                       const float* bias, int epi, float* aux, long ldaux, void* y16_out, long ldy, float* mean_out,
                                       float* rstd_out, void* stream) {
     if (!X || !stats || stat_parts <= 0 || !gamma || !beta || !W16 || (!C && !C16) || M <= 0 || N <= 0 || K <= 0) return VITAE_ERR_INVALID_ARG;
+    const int aux16 = (epi & VITAE_EPI_AUX_BF16) != 0;
+    epi &= ~VITAE_EPI_AUX_BF16;
     if ((uintptr_t)stats & 7) return VITAE_ERR_UNSUPPORTED_SHAPE;
     if (epi != VITAE_EPI_NONE && epi != VITAE_EPI_RELU && !aux) return VITAE_ERR_INVALID_ARG;
     if ((y16_out != nullptr) != (mean_out != nullptr) || (mean_out != nullptr) != (rstd_out != nullptr)) return VITAE_ERR_INVALID_ARG;
@@ -1069,7 +1090,7 @@ extern "C" int vitae_gemm_glds_lnfold(const float* X, long ldx, const float* sta
     p.C = C; p.ldc = ldc; p.C16 = reinterpret_cast<__bf16*>(C16); p.ldc16 = ldc16;
     p.M = M; p.N = N; p.K = K; p.k_per_split = K; p.splits = 1;
     p.bias = bias; p.residual = nullptr; p.ldr = 0; p.aux = aux; p.ldaux = ldaux;
-    p.epi = epi; p.accumulate = 0; p.ws = nullptr; p.out_colsum = nullptr; p.a_rowsum = nullptr;
+    p.epi = epi; p.aux16 = aux16; p.accumulate = 0; p.ws = nullptr; p.out_colsum = nullptr; p.a_rowsum = nullptr;
     p.dbg = g_gemm_dbg; p.slab_stride = 0;
     p.tiles_m = cdiv(M, 64); p.tiles_n = cdiv(N, 64);
     p.xcd_m = xcd_by_rows(M, N);
@@ -1108,6 +1129,8 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
                                           float* dx_colsum_accum, float* dy_colsum_accum, int dx_accumulate, int dw_accumulate,
                                           int split_k, float* splitk_ws, void* stream) {
     if (!dy16 || !w16 || !x16 || (!dx && !dx16) || !dw || M <= 0 || N <= 0 || K <= 0) return VITAE_ERR_INVALID_ARG;
+    const int aux16 = (epi & VITAE_EPI_AUX_BF16) != 0;
+    epi &= ~VITAE_EPI_AUX_BF16;
     if (epi != VITAE_EPI_NONE && !aux) return VITAE_ERR_INVALID_ARG;
     if (dx_accumulate && !dx) return VITAE_ERR_INVALID_ARG;
     if ((N % BK) || (Mpad % BK) || (K & 7) || Mpad < M) return VITAE_ERR_UNSUPPORTED_SHAPE;
@@ -1121,7 +1144,7 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
     const int kps = cdiv(cdiv(N, split_k), BK) * BK;
     split_k = cdiv(N, kps);
     p1.M = M; p1.N = K; p1.K = N; p1.k_per_split = kps; p1.splits = split_k;
-    p1.bias = nullptr; p1.residual = nullptr; p1.ldr = 0; p1.aux = aux; p1.ldaux = K; p1.epi = epi; p1.accumulate = dx_accumulate != 0;
+    p1.bias = nullptr; p1.residual = nullptr; p1.ldr = 0; p1.aux = aux; p1.ldaux = K; p1.epi = epi; p1.aux16 = aux16; p1.accumulate = dx_accumulate != 0;
     p1.ws = splitk_ws; p1.out_colsum = dx_colsum_accum; p1.a_rowsum = nullptr; p1.dbg = nullptr; p2.dbg = nullptr; p1.slab_stride = 0; p2.slab_stride = 0;
     Tile t1 = pick_tile(M, K);
     if (t1.id == 3) t1 = Tile{64, 128, 1};      // the paired launch is 4-wave only

@@ -144,6 +144,11 @@ class HipMAEEngine:
         # wgrad half and the 900-workgroup grid set their duration, while the slab-summing LayerNorm backward costs 1.5 us
         # more: so the backward keeps the in-launch reduction unless VITAE_SLAB_SPLITK_BWD=1)
         self.slab_k_bwd = self.slab_k and os.environ.get('VITAE_SLAB_SPLITK_BWD', '0') != '0'
+        # OPT-IN (measured: no gain — 4.81-4.84 vs 4.82-4.84 ms at batch 4, 15.96 vs 15.94 at batch 32): the saved fc1
+        # pre-activation (read once, by the GELU' of the fc2 input gradient) in bf16: half the bytes of the fc1 epilogue's largest
+        # store and of the fc2 backward's largest epilogue read
+        self.hpre16 = self.act16 and not self.fuse_mlp and os.environ.get('VITAE_HPRE_BF16', '0') == '1'
+        self._aux16 = CONSTS['VITAE_EPI_AUX_BF16'] if self.hpre16 else 0
         # q | k | v leave the qkv GEMM in bf16 only and the attention kernels read that (no fp32 qkv in HBM: the GEMM epilogue is
         # bound by its output bytes, and the kernels no longer convert while staging); needs the one-launch attention backward
         self.qkv16 = self.act16 and not self.fuse_mlp and not self.slab_k and os.environ.get('VITAE_QKV_BF16', '1') != '0'
@@ -310,7 +315,8 @@ class HipMAEEngine:
                 b[q + 'qkv'], b[q + 'o'] = f(M, 3 * d), f(M, d)
                 b[q + 'xmid'], b[q + 'y2'], b[q + 'mean2'], b[q + 'rstd2'] = f(M, d), f(M, d), f(M), f(M)
                 if not self.fuse_mlp:     # the fused MLP keeps its pre-activation / activation in bf16 only
-                    b[q + 'hpre'], b[q + 'act'] = f(M, h), f(M, h)
+                    b[q + 'hpre'] = torch.empty(M, h, dtype=torch.bfloat16, device=dev) if self.hpre16 else f(M, h)
+                    b[q + 'act'] = f(M, h)
             b[pre + 'dx'], b[pre + 'dy'], b[pre + 'do'] = f(M, d), f(M, d), f(M, d)
             b[pre + 'dh'], b[pre + 'dqkv'] = f(M, h), f(M, 3 * d)
 
@@ -550,7 +556,7 @@ class HipMAEEngine:
         key = ('g', M, N, K)
         s = self._split_cache.get(key)
         if s is None:
-            s = 1 if epi == EPI_GELU else lib.vitae_gemm_glds_pick_split_k(M, N, K)
+            s = 1 if (epi & 15) == EPI_GELU else lib.vitae_gemm_glds_pick_split_k(M, N, K)
             while s > 1 and lib.vitae_gemm_glds_ws_floats(M, N, s) > self.ws16.numel():
                 s -= 1
             self._split_cache[key] = s
@@ -784,7 +790,7 @@ class HipMAEEngine:
         self._ln_fwd_kslab(s, n, x_in, p[pre + 'attn.proj.bias'], pre + 'norm2.', b[q + 'xmid'], b[q + 'mean2'], b[q + 'rstd2'], M, d,
                            b[q + 'y2_16'])
         self._g16_fwd(b[q + 'y2_16'], p[pre + 'mlp.fc1.weight'], p[pre + 'mlp.fc1.bias'], M, hid, d, y16=b[q + 'act_16'],
-                      epi=EPI_GELU, aux=b[q + 'hpre'])
+                      epi=EPI_GELU | self._aux16, aux=b[q + 'hpre'])
         n = self._g16_fwd_slabs(b[q + 'act_16'], p[pre + 'mlp.fc2.weight'], s, M, d, hid)
         self._scope = None
         return n
@@ -796,7 +802,7 @@ class HipMAEEngine:
         self._scope = s
         dx, dx16, dh16, do, dqkv, dqkv16 = b[s + 'dx'], b[s + 'dx_16'], b[s + 'dh_16'], b[s + 'do'], b[s + 'dqkv'], b[s + 'dqkv_16']
         self._g16_bwd(dx16, p[pre + 'mlp.fc2.weight'], b[q + 'act_16'], g[pre + 'mlp.fc2.weight'], M, Mp, d, hid,
-                      dx16=dh16, epi=EPI_DGELU, aux=b[q + 'hpre'], dx_colsum=g[pre + 'mlp.fc1.bias'])
+                      dx16=dh16, epi=EPI_DGELU | self._aux16, aux=b[q + 'hpre'], dx_colsum=g[pre + 'mlp.fc1.bias'])
         n = self._g16_bwd_slabs(dh16, p[pre + 'mlp.fc1.weight'], b[q + 'y2_16'], g[pre + 'mlp.fc1.weight'], s, M, Mp, hid, d)
         self._ln_bwd_kslab(s, n, b[q + 'xmid'], pre + 'norm2.', b[q + 'mean2'], b[q + 'rstd2'], dx, M, d, dx16, g[pre + 'attn.proj.bias'])
         self._g16_bwd(dx16, p[pre + 'attn.proj.weight'], b[q + 'o_16'], g[pre + 'attn.proj.weight'], M, Mp, d, d, dx=do)
@@ -839,12 +845,12 @@ class HipMAEEngine:
             self._g16_fwd(b[q + 'o_16'], p[pre + 'attn.proj.weight'], p[pre + 'attn.proj.bias'], M, d, d, y=b[q + 'xmid'], res=x_in,
                           rowstats=b[q + 'st2'])
             self._g16_fwd_ln(b[q + 'xmid'], b[q + 'st2'], pre + 'norm2.', p[pre + 'mlp.fc1.weight'], p[pre + 'mlp.fc1.bias'], M, hid, d,
-                             b[q + 'y2_16'], b[q + 'mean2'], b[q + 'rstd2'], y16=b[q + 'act_16'], epi=EPI_GELU, aux=b[q + 'hpre'])
+                             b[q + 'y2_16'], b[q + 'mean2'], b[q + 'rstd2'], y16=b[q + 'act_16'], epi=EPI_GELU | self._aux16, aux=b[q + 'hpre'])
         else:
             self._g16_fwd(b[q + 'o_16'], p[pre + 'attn.proj.weight'], p[pre + 'attn.proj.bias'], M, d, d, y=b[q + 'xmid'], res=x_in)
             self._ln_fwd(b[q + 'xmid'], pre + 'norm2.', None, b[q + 'mean2'], b[q + 'rstd2'], M, d, y16=b[q + 'y2_16'])
             self._g16_fwd(b[q + 'y2_16'], p[pre + 'mlp.fc1.weight'], p[pre + 'mlp.fc1.bias'], M, hid, d, y16=b[q + 'act_16'],
-                          epi=EPI_GELU, aux=b[q + 'hpre'])
+                          epi=EPI_GELU | self._aux16, aux=b[q + 'hpre'])
         self._g16_fwd(b[q + 'act_16'], p[pre + 'mlp.fc2.weight'], p[pre + 'mlp.fc2.bias'], M, d, hid, y=x_out, res=b[q + 'xmid'],
                       rowstats=st_out)
 
@@ -868,7 +874,7 @@ class HipMAEEngine:
         dx, dx16, dh16, dy, do, dqkv, dqkv16 = (b[s + 'dx'], b[s + 'dx_16'], b[s + 'dh_16'], b[s + 'dy'], b[s + 'do'],
                                                   b[s + 'dqkv'], b[s + 'dqkv_16'])
         self._g16_bwd(dx16, p[pre + 'mlp.fc2.weight'], b[q + 'act_16'], g[pre + 'mlp.fc2.weight'], M, Mp, d, hid,
-                      dx16=dh16, epi=EPI_DGELU, aux=b[q + 'hpre'], dx_colsum=g[pre + 'mlp.fc1.bias'])
+                      dx16=dh16, epi=EPI_DGELU | self._aux16, aux=b[q + 'hpre'], dx_colsum=g[pre + 'mlp.fc1.bias'])
         self._g16_bwd(dh16, p[pre + 'mlp.fc1.weight'], b[q + 'y2_16'], g[pre + 'mlp.fc1.weight'], M, Mp, hid, d, dx=dy)
         self._ln_bwd(dy, b[q + 'xmid'], pre + 'norm2.', b[q + 'mean2'], b[q + 'rstd2'], dx, M, d, 1, dx16=dx16,
                      dx_colsum=g[pre + 'attn.proj.bias'])
