@@ -462,7 +462,8 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(const QT* __restric
     // ---- stage the four operand tiles (rows >= N zero) and the per-row scalars
     for (int idx = threadIdx.x; idx < NP * V4; idx += 256) {
         const int row = idx / V4, c4 = (idx % V4) * 4;
-        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        f32x4 g = {0.f, 0.f, 0.f, 0.f}, ov = g;
+        if (row < N) ov = *reinterpret_cast<const f32x4*>(obase + (long)row * D + c4);
         bf16x4 q16, k16, v16, g16;
         if constexpr (sizeof(QT) == 2) {
             // bf16 qkv (the GEMM's own bf16 copy): k and v pass through, q takes the softmax scale
@@ -495,21 +496,16 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(const QT* __restric
         *reinterpret_cast<bf16x4*>(Ks + row * LD + c4) = k16;
         *reinterpret_cast<bf16x4*>(Vs + row * LD + c4) = v16;
         *reinterpret_cast<bf16x4*>(Gs + row * LD + c4) = g16;
-    }
-    for (int row = threadIdx.x; row < NP; row += 256) {
-        float dl = 0.f, L = 1e30f;                 // invalid query: P = exp2(s - huge) = 0
-        if (row < N) {
-            const float* gr = gbase + (long)row * D;
-            const float* orow = obase + (long)row * D;
+        // delta = rowsum(O * dO) on the way: a row's V4 pieces sit in V4 consecutive lanes (NP * V4 is a multiple of 256: every
+        // lane of every wave takes part), so O is read as coalesced as dO — a per-row loop with one thread per row read 2 x HD
+        // floats per lane at a row stride and cost the launch a microsecond or two
+        float dl = g[0] * ov[0] + g[1] * ov[1] + g[2] * ov[2] + g[3] * ov[3];
 #pragma unroll
-            for (int c = 0; c < HD; c += 4) {
-                const f32x4 g = *reinterpret_cast<const f32x4*>(gr + c), ov = *reinterpret_cast<const f32x4*>(orow + c);
-                dl += g[0] * ov[0] + g[1] * ov[1] + g[2] * ov[2] + g[3] * ov[3];
-            }
-            L = lse[((long)b * H + h) * N + row] * LOG2E;
-        }
-        Ds[row] = dl; Ls[row] = L;
+        for (int of = 1; of < V4; of <<= 1) dl += __shfl_xor(dl, of, 64);
+        if ((idx % V4) == 0) Ds[row] = dl;         // rows >= N: 0
     }
+    for (int row = threadIdx.x; row < NP; row += 256)
+        Ls[row] = row < N ? lse[((long)b * H + h) * N + row] * LOG2E : 1e30f;      // invalid query: P = exp2(s - huge) = 0
     if (threadIdx.x < 3 * HD) Cs[threadIdx.x] = 0.f;
     __syncthreads();
 
