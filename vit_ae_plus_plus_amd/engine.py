@@ -974,8 +974,11 @@ class HipMAEEngine:
         # data only: it runs on a side stream underneath the encoder/decoder and is joined before the edge MSE
         main = torch.cuda.current_stream(self.device)
 
-        def target_branch():
-            self.side.wait_stream(torch.cuda.current_stream(self.device))
+        def target_branch(after=None):
+            if after is not None:
+                self.side.wait_event(after)
+            else:
+                self.side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.side):
                 ss = self.side.cuda_stream
                 lib.vitae_gauss_blur_fwd(_ptr(view1), _ptr(b['blur_tmp']), _ptr(b['blurred']), self._taps_c, len(self.taps),
@@ -985,11 +988,22 @@ class HipMAEEngine:
         # where the branch forks off the main chain: 'start' (beside masking / gather / patch embedding), 'embed' (after the
         # patch-embedding GEMM, beside the first encoder blocks), 'decoder' (beside the first decoder blocks)
         fork = self.target_fork
+        # 'start1' (experiment, measured WORSE): the same fork point, but the branch is ENQUEUED after the main chain's next kernel.
+        # In a captured graph the child node created first keeps the parent's hardware queue and the other one pays a ~7-12 us
+        # cross-queue hop; created second, the main chain does stay on its queue (and the patch-embedding GEMM runs 49 instead of
+        # 91 us without the blur beside it) — but the graph executor then parks the branch on a queue whose earlier entries wait
+        # for the latent: blur + Sobel only start at 1.75 ms, the loss waits for them, the step goes 4.72 -> 4.96 ms
+        fork_ev = None
         if fork == 'start':
             target_branch()
+        elif fork == 'start1':
+            fork_ev = torch.cuda.Event()
+            fork_ev.record(main)
         # --- masking, kept-patch gather, patch embedding, sequence assembly
         lib.vitae_random_masking(_ptr(noise), _ptr(b['ids_shuffle']), _ptr(b['ids_restore']), _ptr(b['mask']),
                                  _ptr(b['ids_restore64']), Be, L, keep, st)
+        if fork_ev is not None:
+            target_branch(after=fork_ev)
         a16 = self.act16
         pat, pat16 = (None, b['patches_16']) if a16 else (b['patches'], None)
         if cfg.contrastive:
