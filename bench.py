@@ -345,7 +345,7 @@ def main():
 
     def step(i):
         v1, v2 = batches[i % len(batches)]
-        runner.load(v1, v2 if contr else None)     # device-resident batch: staged once, read in place when it comes back
+        runner.load(v1, v2 if contr else None, ready=True)     # device-resident batch (static since set-up): staged once, read in place when it comes back
         eng.optimizer_hparams(lr=1e-4)
         runner.run()
 

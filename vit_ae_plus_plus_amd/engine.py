@@ -192,6 +192,8 @@ class HipMAEEngine:
         self.oside = torch.cuda.Stream(device=device)  # per-bucket grad-norm + AdamW beside the rest of the backward
         self.overlap_optimizer = os.environ.get('VITAE_OPT_IN_BACKWARD', '1') != '0'
         self._opt_pending = False
+        self._main_done = None       # split step: event behind the forward + backward of the latest step (workspace free for a prologue)
+        self._prologue_owner = None  # split step: (runner, graph key) whose input prologue is in the workspace / in flight
         self._pred_pending = False
         self._pred_joined = False   # the predictor branch was joined by backward_dec(part='top')
         self.overlap_wgrad = True
@@ -947,10 +949,32 @@ class HipMAEEngine:
         self._ln_bwd(dy, x_in, pre + 'norm1.', b[q + 'mean1'], b[q + 'rstd1'], dx, M, d, 1)
 
     # ------------------------------------------------------------------ forward
+    def input_prologue(self, view1: torch.Tensor, view2: Optional[torch.Tensor], noise: torch.Tensor, mask_ratio: float):
+        """The part of a step that depends on the BATCH only, not on the weights: random masking, kept-patch gather (both views),
+        blur + Sobel of the target volume — one chain on the current stream.  ``forward(..., prologue_done=True)`` then starts at the
+        patch-embedding GEMM.  The split step (``_StepRunner``) replays this for batch i + 1 beside the optimiser tail of step i."""
+        cfg = self.cfg
+        B = view1.shape[0]
+        self._alloc(B, mask_ratio)
+        st, b = torch.cuda.current_stream(self.device).cuda_stream, self.buf
+        Be, keep, L = self.Be, self.keep, cfg.num_patches
+        C, (Lz, Hy, Wx), ps = cfg.in_chans, cfg.volume_size, cfg.patch_size
+        lib.vitae_random_masking(_ptr(noise), _ptr(b['ids_shuffle']), _ptr(b['ids_restore']), _ptr(b['mask']),
+                                 _ptr(b['ids_restore64']), Be, L, keep, st)
+        pat, pat16 = (None, b['patches_16']) if self.act16 else (b['patches'], None)
+        if cfg.contrastive:
+            lib.vitae_gather_patches_2views(_ptr(view1), _ptr(view2), _ptr(b['ids_shuffle']), _ptr(pat), _ptr(pat16), B, C, Lz, Hy, Wx,
+                                            ps, keep, st)
+        else:
+            lib.vitae_gather_patches(_ptr(view1), _ptr(b['ids_shuffle']), _ptr(pat), _ptr(pat16), B, C, Lz, Hy, Wx, ps, keep, st)
+        lib.vitae_gauss_blur_fwd(_ptr(view1), _ptr(b['blur_tmp']), _ptr(b['blurred']), self._taps_c, len(self.taps), B * C, Lz, Hy, Wx, st)
+        lib.vitae_sobel_edge_fwd(_ptr(b['blurred']), _ptr(b['edge_t']), None, None, B, C, Lz, Hy, Wx, st)
+
     def forward(self, view1: torch.Tensor, view2: Optional[torch.Tensor], noise: torch.Tensor, mask_ratio: float,
-                training: bool = True, defer_predictor_join: bool = False, defer_finalize: bool = False):
+                training: bool = True, defer_predictor_join: bool = False, defer_finalize: bool = False, prologue_done: bool = False):
         """Everything up to the four loss scalars and (contrastive) p1/p2.  ``noise`` is [Be, L]
-        (view-1 rows first), the torch.rand of vit_autoenc.py:139."""
+        (view-1 rows first), the torch.rand of vit_autoenc.py:139.  ``prologue_done``: ``input_prologue`` already ran for this
+        batch (masking, gather and the target's edge map are in the workspace)."""
         cfg = self.cfg
         B = view1.shape[0]
         self._alloc(B, mask_ratio)
@@ -987,7 +1011,7 @@ class HipMAEEngine:
 
         # where the branch forks off the main chain: 'start' (beside masking / gather / patch embedding), 'embed' (after the
         # patch-embedding GEMM, beside the first encoder blocks), 'decoder' (beside the first decoder blocks)
-        fork = self.target_fork
+        fork = 'done' if prologue_done else self.target_fork
         # 'start1' (experiment, measured WORSE): the same fork point, but the branch is ENQUEUED after the main chain's next kernel.
         # In a captured graph the child node created first keeps the parent's hardware queue and the other one pays a ~7-12 us
         # cross-queue hop; created second, the main chain does stay on its queue (and the patch-embedding GEMM runs 49 instead of
@@ -1000,17 +1024,18 @@ class HipMAEEngine:
             fork_ev = torch.cuda.Event()
             fork_ev.record(main)
         # --- masking, kept-patch gather, patch embedding, sequence assembly
-        lib.vitae_random_masking(_ptr(noise), _ptr(b['ids_shuffle']), _ptr(b['ids_restore']), _ptr(b['mask']),
-                                 _ptr(b['ids_restore64']), Be, L, keep, st)
-        if fork_ev is not None:
-            target_branch(after=fork_ev)
         a16 = self.act16
         pat, pat16 = (None, b['patches_16']) if a16 else (b['patches'], None)
-        if cfg.contrastive:
-            lib.vitae_gather_patches_2views(_ptr(view1), _ptr(view2), _ptr(b['ids_shuffle']), _ptr(pat), _ptr(pat16), B, C, Lz, Hy, Wx,
-                                            ps, keep, st)
-        else:
-            lib.vitae_gather_patches(_ptr(view1), _ptr(b['ids_shuffle']), _ptr(pat), _ptr(pat16), B, C, Lz, Hy, Wx, ps, keep, st)
+        if not prologue_done:
+            lib.vitae_random_masking(_ptr(noise), _ptr(b['ids_shuffle']), _ptr(b['ids_restore']), _ptr(b['mask']),
+                                     _ptr(b['ids_restore64']), Be, L, keep, st)
+            if fork_ev is not None:
+                target_branch(after=fork_ev)
+            if cfg.contrastive:
+                lib.vitae_gather_patches_2views(_ptr(view1), _ptr(view2), _ptr(b['ids_shuffle']), _ptr(pat), _ptr(pat16), B, C, Lz, Hy, Wx,
+                                                ps, keep, st)
+            else:
+                lib.vitae_gather_patches(_ptr(view1), _ptr(b['ids_shuffle']), _ptr(pat), _ptr(pat16), B, C, Lz, Hy, Wx, ps, keep, st)
         if a16:
             self._g16_fwd(pat16, p['patch_embed.proj.weight'], p['patch_embed.proj.bias'], Be * keep, D, P, y=b['tok'])
         else:
@@ -1083,7 +1108,8 @@ class HipMAEEngine:
             self._lin_fwd(b['dn'], p['decoder_pred.weight'], p['decoder_pred.bias'], b['predfull'], Md, P, Dd)
         # --- loss chain on pred = predfull[:, 1:, :]
         pred_ptr, pbs = b['predfull'].data_ptr() + P * 4, Nd * P
-        torch.cuda.current_stream(self.device).wait_stream(self.side)   # edge map of the blurred target is ready
+        if not prologue_done:
+            torch.cuda.current_stream(self.device).wait_stream(self.side)   # edge map of the blurred target is ready
         lib.vitae_loss_fwd_fused(pred_ptr, pbs, _ptr(view1), _ptr(b['mask']), _ptr(b['edge_t']), _ptr(b['pred_vol']),
                                  _ptr(b['edge_p']), _ptr(self.acc), B, C, Lz, Hy, Wx, ps, st)
         if not defer_finalize:
@@ -1464,7 +1490,7 @@ class HipMAEEngine:
         return [(cuts[i + 1] - 1, cuts[i]) for i in reversed(range(n))]
 
     def train_phase(self, k: int, view1, view2, noise, mask_ratio: float, update: bool = True,
-                    accumulate: bool = False):
+                    accumulate: bool = False, prologue_done: bool = False, defer_last_bucket: bool = False):
         """Phase k of one optimisation step (only kernel launches, no host sync):
         0 (.. dec_chunks - 1) = forward + losses + backward through decoder/predictor; then enc_chunks phases of encoder backward,
         top chunk first (the last one also does the patch embedding); the last phase = grad-norm + AdamW.  Gradient bucket k (ddp) is
@@ -1475,7 +1501,8 @@ class HipMAEEngine:
             # the zeroing of the token / vector gradient segment and the loss finalisation are not on the dependent chain:
             # the first goes in front of the forward, the second behind the decoder backward (12 us between the loss kernels)
             self.begin_grad_window(accumulate)
-            self.forward(view1, view2, noise, mask_ratio, training=True, defer_predictor_join=True, defer_finalize=True)
+            self.forward(view1, view2, noise, mask_ratio, training=True, defer_predictor_join=True, defer_finalize=True,
+                         prologue_done=prologue_done)
             if cfg.contrastive:
                 self.contrastive_loss_fwd()
                 self.contrastive_loss_bwd()
@@ -1492,9 +1519,14 @@ class HipMAEEngine:
             self.backward_enc(hi, lo)
             if k == nd + n - 1:
                 self.backward_tail()
-            if update and self._optimizer_in_backward_ok():
+            if update and self._optimizer_in_backward_ok() and not (defer_last_bucket and k == nd + n - 1):
                 self._opt_bucket(k)
+            if defer_last_bucket and k == nd + n - 1 and update and self._optimizer_in_backward_ok():
+                # this launch ends here: the optimiser stream forked inside it must come back inside it
+                torch.cuda.current_stream(self.device).wait_stream(self.oside)
         elif k == nd + n and update:
+            if defer_last_bucket and self._optimizer_in_backward_ok():
+                self._opt_bucket(nd + n - 1)      # the split step keeps the exposed optimiser tail in a launch of its own
             if self._optimizer_in_backward_ok() or self._ddp_bucket_opt:
                 self._opt_tail()             # the buckets' matrices were stepped beside the backward
             else:
