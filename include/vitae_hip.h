@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITAE_ABI_VERSION 27
+#define VITAE_ABI_VERSION 28
 
 /* matrix-core arithmetic of the dense contractions */
 #define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
@@ -126,6 +126,12 @@ int vitae_gemm_glds_lnfold(const float* X, long ldx, const float* stats, int sta
 int vitae_gemm_glds_pick_split_k(int M, int N, int K);
 /* profiling hook (tools/gemm_phase_probe.py): 8 long long per workgroup; NULL = off */
 int vitae_gemm_glds_set_debug(void* buf);
+/* Gradient norm without a pass over the gradients: while `slot` is set (NULL clears), every weight-gradient launch
+ * (vitae_linear_bwd_pair_glds' wgrad half; vitae_gemm_glds called with a_kcontig = b_kcontig = 0) adds the sum of squares
+ * of the tile it stores to *slot (double; the step's acc[VITAE_ACC_GRADSQ]).  Process-global, launch-time. */
+int vitae_gemm_glds_set_wgrad_sqnorm(double* slot);
+/* norm_out[0] = sqrt(acc[VITAE_ACC_GRADSQ]) (the finalisation vitae_grad_sqnorm appends, on its own) */
+int vitae_grad_norm_finalize(const double* acc, float* norm_out, void* stream);
 /* Split-K whose partial sums leave the launch as separate matrices ("slabs", z-th at slabs + z * slab_stride floats, each
  * [M, N] fp32) and are summed by the LayerNorm that consumes the result anyway (vitae_layernorm_{fwd,bwd}_slabs) — the
  * launch-boundary reduce: no tickets, no partial round trip inside the launch, no bias / residual / epilogue here.

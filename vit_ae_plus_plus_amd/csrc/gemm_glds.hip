@@ -46,6 +46,7 @@ struct GArgs {
     long slab_stride;    // != 0 ("slab mode"): k-split z stores its partial tile at C + z * slab_stride and is done — the splits
                          // are summed by the kernel that consumes the result anyway (vitae_layernorm_{fwd,bwd}_slabs: the
                          // launch-boundary reduce); no tickets, no partial round trip inside the launch
+    double* sqacc = nullptr;     // optional: *sqacc += sum of squares of the stored result (the gradient norm's share of a wgrad)
     int aux16 = 0;               // aux holds bf16 (VITAE_EPI_AUX_BF16): the saved GELU pre-activation at half the bytes
     float* rowstats = nullptr;   // optional (row-major epilogue only): rowstats[n / 64][m] = (sum, sum of squares) of result(m, 64-column
                          // slot) — the LayerNorm statistics of the NEXT op, taken while the rows pass through (vitae_gemm_glds_lnfold)
@@ -55,6 +56,7 @@ struct GArgs {
 };
 
 long long* g_gemm_dbg = nullptr;
+double* g_wgrad_sqacc = nullptr;   // vitae_gemm_glds_set_wgrad_sqnorm: picked up by every weight-gradient launch while set
 
 // workgroups of one launch (per k-split) under either XCD mapping
 inline int glds_blocks(const GArgs& p) {
@@ -66,7 +68,7 @@ inline int glds_blocks(const GArgs& p) {
 // their latencies overlap — one dependent load -> store per element made the residual GEMMs 2x slower than the bare
 // product, while batching all 16 rows x 3 arrays at once cost 150 extra VGPRs (one workgroup per CU for the 64x128
 // tiles).  Returns the column sum of the stored values.
-__device__ __forceinline__ float epilogue_frag(const GArgs& p, const float (&v)[16], int mbase, int n, int hi) {
+__device__ __forceinline__ float epilogue_frag(const GArgs& p, const float (&v)[16], int mbase, int n, int hi, float& sqsum) {
     // 32-bit element offsets from the (wave-uniform) base pointers: one VGPR per address instead of a 64-bit pair
     // per row and array (the launchers reject operands with more than 2^31 elements)
     const int nc = min(n, p.N - 1);
@@ -118,6 +120,7 @@ __device__ __forceinline__ float epilogue_frag(const GArgs& p, const float (&v)[
             }
             if (p.C16) p.C16[m * ldc16 + n] = (__bf16)x;
             csum += x;
+            sqsum += x * x;
         }
         asm volatile("" ::: "memory");   // keep the next batch's loads behind these stores (register pressure)
     }
@@ -188,6 +191,7 @@ __device__ __forceinline__ void epilogue_rows(const GArgs& p, const float (&a)[N
     if (pre.have) bias4 = pre.bias;
     else if (p.bias && ncol) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
     f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+    float sqs = 0.f;
     float rsum[PASSES], rsq[PASSES];
 #pragma unroll
     for (int q = 0; q < PASSES; ++q) rsum[q] = rsq[q] = 0.f;
@@ -261,6 +265,7 @@ __device__ __forceinline__ void epilogue_rows(const GArgs& p, const float (&a)[N
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) csum[e] += x[e];
+            if (p.sqacc) sqs += (x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3]);
             if (p.rowstats) { rsum[pb + q] = (x[0] + x[1]) + (x[2] + x[3]); rsq[pb + q] = (x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3]); }
         }
         asm volatile("" ::: "memory");   // keep the next batch's loads behind these stores (register pressure)
@@ -280,6 +285,12 @@ __device__ __forceinline__ void epilogue_rows(const GArgs& p, const float (&a)[N
                 *reinterpret_cast<f32x2*>(p.rowstats + ((long)(n >> 6) * p.M + m) * 2) = f32x2{a0, a1};
             }
         }
+    }
+    if (p.sqacc) {
+        // the gradient norm's share of this tile (every stored element exactly once): one double atomic per workgroup, instead
+        // of a separate pass over the 0.5 GB gradient arena (grad_sqnorm_kernel: 45 us per bucket, the last one exposed)
+        const float tot = block_sum_256(sqs, cs + BN);
+        if (threadIdx.x == 0) atomicAdd(p.sqacc, (double)tot);
     }
     if (p.out_colsum) {
 #pragma unroll
@@ -592,16 +603,21 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
             return;
         }
     }
+    float sqsum = 0.f;
 #pragma unroll
     for (int fn = 0; fn < FN; ++fn) {
         const int n = n0 + wn * (BN / 2) + fn * 32 + l31;
         float csum = 0.f;
 #pragma unroll
-        for (int fm = 0; fm < FM; ++fm) csum += epilogue_frag(q, a[fm * FN + fn], m0 + wm * (BM / WAVES_M) + fm * 32, n, hi);
+        for (int fm = 0; fm < FM; ++fm) csum += epilogue_frag(q, a[fm * FN + fn], m0 + wm * (BM / WAVES_M) + fm * 32, n, hi, sqsum);
         if (p.out_colsum) {
             csum += __shfl_xor(csum, 32, 64);
             if (hi == 0 && n < p.N) atomicAdd(p.out_colsum + n, csum);
         }
+    }
+    if (p.sqacc) {
+        sqsum = wave_sum(sqsum);
+        if (lane == 0) atomicAdd(p.sqacc, (double)sqsum);
     }
 }
 
@@ -1028,6 +1044,7 @@ static int gemm_glds_launch(int a_kcontig, int b_kcontig, const void* A16, long 
     p.xcd_m = xcd_by_rows(M, N);
     p.vec_epi = vec_epilogue_ok(p);
     p.rowstats = out_rowstats;
+    if (!a_kcontig && !b_kcontig) p.sqacc = g_wgrad_sqacc;      // the weight-gradient form (dy^T @ x)
     if (out_rowstats && (!p.vec_epi || t.id > 1)) return VITAE_ERR_UNSUPPORTED_SHAPE;   // taken in the row-major epilogue only
     if (split_k > 1 && (long)p.tiles_m * p.tiles_n > VITAE_GLDS_TICKETS) return VITAE_ERR_UNSUPPORTED_SHAPE;
     dim3 grid(glds_blocks(p), 1, split_k);
@@ -1157,6 +1174,7 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
     p2.M = N; p2.N = K; p2.K = Mpad; p2.k_per_split = Mpad; p2.splits = 1;
     p2.bias = nullptr; p2.residual = nullptr; p2.ldr = 0; p2.aux = nullptr; p2.ldaux = 0; p2.epi = VITAE_EPI_NONE;
     p2.accumulate = dw_accumulate; p2.ws = nullptr; p2.out_colsum = nullptr; p2.a_rowsum = dy_colsum_accum;
+    p2.sqacc = g_wgrad_sqacc;
     Tile t2 = pick_tile(N, K);
     if (t2.id == 3) t2 = Tile{64, 128, 1};
     p2.tiles_m = cdiv(N, t2.bm); p2.tiles_n = cdiv(K, t2.bn);
@@ -1219,6 +1237,12 @@ extern "C" int vitae_wgrad_group_glds(int n, const void* const* dy16, const void
 // profiling hook (tools/gemm_phase_probe.py): with a device buffer of 8 long long per workgroup set, vitae_gemm_glds launches
 // record shader-clock stamps at their phase boundaries; NULL switches it off
 extern "C" int vitae_gemm_glds_set_debug(void* buf) { g_gemm_dbg = reinterpret_cast<long long*>(buf); return VITAE_OK; }
+
+// While set (NULL clears): every weight-gradient launch of this file — the wgrad half of vitae_linear_bwd_pair_glds, and
+// vitae_gemm_glds in its dy^T @ x form — adds the sum of squares of the gradient tile it stores to *slot (a double: the caller's
+// acc[VITAE_ACC_GRADSQ]).  Process-global launch-time state of the (single) thread that issues the step; captured graphs keep
+// the value it had at capture.  Not for split-K wgrads (the paired launch never splits its wgrad half).
+extern "C" int vitae_gemm_glds_set_wgrad_sqnorm(double* slot) { g_wgrad_sqacc = slot; return VITAE_OK; }
 
 // ---- split-K whose partial sums leave the launch as separate matrices ("slabs"), summed by the consumer ----------------
 // number of slabs vitae_gemm_glds_slabs / vitae_linear_bwd_pair_glds_slabs produce for a reduction length and a requested split

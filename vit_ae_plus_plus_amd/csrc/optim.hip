@@ -128,6 +128,12 @@ static int grad_sqnorm_launch(const G* grads, long n, double* acc, float* norm_o
     return vitae_launch_status();
 }
 
+extern "C" int vitae_grad_norm_finalize(const double* acc, float* norm_out, void* stream) {
+    if (!acc || !norm_out) return VITAE_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(grad_norm_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, acc, norm_out);
+    return vitae_launch_status();
+}
+
 extern "C" int vitae_grad_sqnorm(const float* grads, long n, double* acc, float* norm_out, void* stream) {
     return grad_sqnorm_launch<float>(grads, n, acc, norm_out, stream);
 }

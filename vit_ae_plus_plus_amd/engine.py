@@ -149,6 +149,10 @@ class HipMAEEngine:
         # store and of the fc2 backward's largest epilogue read
         self.hpre16 = self.act16 and not self.fuse_mlp and os.environ.get('VITAE_HPRE_BF16', '0') == '1'
         self._aux16 = CONSTS['VITAE_EPI_AUX_BF16'] if self.hpre16 else 0
+        # the gradient norm's matrix share is accumulated by the weight-gradient epilogues themselves (vitae_gemm_glds_set_wgrad_sqnorm)
+        # instead of a pass over each bucket (45 us per bucket, the last one exposed behind the backward); single process only — a
+        # data-parallel norm is the norm of the REDUCED gradients
+        self.epi_norm = self.act16 and not self.fuse_mlp and not self.slab_k and os.environ.get('VITAE_EPI_GRADNORM', '1') != '0'
         # q | k | v leave the qkv GEMM in bf16 only and the attention kernels read that (no fp32 qkv in HBM: the GEMM epilogue is
         # bound by its output bytes, and the kernels no longer convert while staging); needs the one-launch attention backward
         self.qkv16 = self.act16 and not self.fuse_mlp and not self.slab_k and os.environ.get('VITAE_QKV_BF16', '1') != '0'
@@ -1421,10 +1425,28 @@ class HipMAEEngine:
             lib.vitae_adamw_step_bf16g(self.params.data_ptr() + o, g16.data_ptr() + o // 2, m, v, (sh + o // 2) if sh else None, n,
                                        _ptr(self.hp), run, self.weight_decay, st)
         else:
-            lib.vitae_grad_sqnorm(self.grads.data_ptr() + o, n, _ptr(self.acc), run, st)
+            if self._epi_norm_on:
+                # the weight-gradient epilogues of this bucket already added their squares; only what no such epilogue writes
+                # (the predictor's matrices) is still read here
+                for a, e in self._epi_norm_uncovered():
+                    a, e = max(a, s0), min(e, e0)
+                    if e > a:
+                        lib.vitae_grad_sqnorm(self.grads.data_ptr() + 4 * a, e - a, _ptr(self.acc), None, st)
+                lib.vitae_grad_norm_finalize(_ptr(self.acc), run, st)
+            else:
+                lib.vitae_grad_sqnorm(self.grads.data_ptr() + o, n, _ptr(self.acc), run, st)
             lib.vitae_adamw_step(self.params.data_ptr() + o, self.grads.data_ptr() + o, m, v, (sh + o // 2) if sh else None, n,
                                  _ptr(self.hp), run, self.weight_decay, st)
         self._opt_pending = True
+
+    _epi_norm_on = False
+
+    def _epi_norm_uncovered(self):
+        """matrix ranges of the arena that no LDS-DMA weight-gradient epilogue writes (cached)"""
+        u = getattr(self, '_epi_unc', None)
+        if u is None:
+            u = self._epi_unc = [(a, min(e, self.tok_off)) for a, e in self.wire_uncovered_ranges() if a < self.tok_off]
+        return u
 
     def _opt_tail(self):
         """Tokens + vectors (whose gradients are accumulated atomically all through the backward) and the final norm."""
@@ -1495,6 +1517,16 @@ class HipMAEEngine:
         0 (.. dec_chunks - 1) = forward + losses + backward through decoder/predictor; then enc_chunks phases of encoder backward,
         top chunk first (the last one also does the patch embedding); the last phase = grad-norm + AdamW.  Gradient bucket k (ddp) is
         final after phase k.  Loss multipliers and lr must already be in ``hp``."""
+        cfg = self.cfg
+        n, nd = self.enc_chunks, self.dec_chunks
+        self._epi_norm_on = bool(self.epi_norm and update and self._optimizer_in_backward_ok())
+        lib.vitae_gemm_glds_set_wgrad_sqnorm(self.acc.data_ptr() + 8 * _C['VITAE_ACC_GRADSQ'] if self._epi_norm_on else None)
+        try:
+            self._train_phase(k, view1, view2, noise, mask_ratio, update, accumulate, prologue_done, defer_last_bucket)
+        finally:
+            lib.vitae_gemm_glds_set_wgrad_sqnorm(None)
+
+    def _train_phase(self, k, view1, view2, noise, mask_ratio, update, accumulate, prologue_done, defer_last_bucket):
         cfg = self.cfg
         n, nd = self.enc_chunks, self.dec_chunks
         if k == 0:
