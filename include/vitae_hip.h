@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITAE_ABI_VERSION 28
+#define VITAE_ABI_VERSION 29
 
 /* matrix-core arithmetic of the dense contractions */
 #define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
@@ -124,6 +124,15 @@ int vitae_gemm_glds_lnfold(const float* X, long ldx, const float* stats, int sta
                            const float* bias, int epi, float* aux, long ldaux, void* y16_out, long ldy, float* mean_out,
                            float* rstd_out, void* stream);
 int vitae_gemm_glds_pick_split_k(int M, int N, int K);
+/* Big-tile kernels (csrc/gemm_bt.hip; 0: 256x256 on 8 waves, 3: 128x128 on 4 waves, in-launch split-K) behind vitae_gemm_glds and
+ * vitae_linear_bwd_pair_glds (whose halves then go out as two launches).  mode -1 (default): picked per problem by the cost
+ * model together with the split (vitae_gemm_glds_pick_split_k returns the split of the plan: pass it on unchanged); -2: never;
+ * 0 / 3: that tile for every eligible problem (tests, tools).  vitae_gemm_glds_bt_choice = the tile a problem would get (-1 = none).
+ * vitae_gemm_glds_set_ws_capacity: floats the split-K workspace handed to these calls holds (default 2^23) — plans that need more
+ * are not made. */
+int vitae_gemm_glds_set_bt_tile(int mode);
+int vitae_gemm_glds_bt_choice(int a_kcontig, int b_kcontig, int M, int N, int K);
+int vitae_gemm_glds_set_ws_capacity(long floats);
 /* profiling hook (tools/gemm_phase_probe.py): 8 long long per workgroup; NULL = off */
 int vitae_gemm_glds_set_debug(void* buf);
 /* Gradient norm without a pass over the gradients: while `slot` is set (NULL clears), every weight-gradient launch

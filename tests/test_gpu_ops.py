@@ -912,3 +912,160 @@ def test_gemm_bf16_saved_preactivation(lib, C, M, N, K):
     F.gelu(p).backward(dy @ w2)
     assert rel_err(dh16[:M].float(), p.grad) < 2e-2
     assert rel_err(dw, dy.t() @ y16[:M].float().cpu()) < 1e-2
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# big-tile GEMM family (csrc/gemm_bt.hip) behind vitae_gemm_glds / vitae_linear_bwd_pair_glds
+@pytest.fixture
+def bt_mode(lib):
+    yield lib.vitae_gemm_glds_set_bt_tile
+    lib.vitae_gemm_glds_set_bt_tile(-1)
+    lib.vitae_gemm_glds_set_ws_capacity(0)
+
+
+def _bt_operands(form, M, N, K, seed=0):
+    akc, bkc = {'fwd': (1, 1), 'dgrad': (1, 0), 'wgrad': (0, 0)}[form]
+    A = gen(*((M, K) if akc else (K, M)), seed=seed + 1).cuda().to(torch.bfloat16)
+    B = gen(*((N, K) if bkc else (K, N)), seed=seed + 2, scale=K ** -0.5).cuda().to(torch.bfloat16)
+    Af = A.float().cpu() if akc else A.float().cpu().t()
+    Bf = B.float().cpu() if bkc else B.float().cpu().t()
+    return akc, bkc, A, B, Af @ Bf.t()
+
+
+@pytest.mark.parametrize('tile', [0, 3])
+@pytest.mark.parametrize('form', ['fwd', 'dgrad', 'wgrad'])
+@pytest.mark.parametrize('M,N,K', [(868, 16384, 512), (440, 776, 192), (1000, 520, 128), (300, 264, 640), (130, 128, 1024)])
+def test_gemm_bt_forms_and_epilogues(lib, C, bt_mode, tile, form, M, N, K):
+    """Every operand form of the big tiles on ragged shapes (rows / columns that do not fill the last tile, tiles with a whole
+    half outside the matrix), with each epilogue kind of the row-major epilogue: bias + residual + bf16 copy + column sums,
+    accumulate into C, GELU with the saved pre-activation (fp32 and bf16), GELU', ReLU mask, ReLU, bf16-only output."""
+    if form == 'wgrad':
+        M = M // 8 * 8            # row-contiguous operands move in 16-byte chunks of rows
+    akc, bkc, A, B, prod = _bt_operands(form, M, N, K)
+    lda, ldb = (K if akc else M), (K if bkc else N)
+    bt_mode(tile)
+    if lib.vitae_gemm_glds_bt_choice(akc, bkc, M, N, K) != tile:
+        pytest.skip('tile not eligible for this shape')
+    b, res, old, aux = gen(N, seed=3), gen(M, N, seed=4), gen(M, N, seed=5), gen(M, N, seed=6)
+    bd, rd, auxd = dev(b), dev(res), dev(aux)
+    aux16 = aux.cuda().to(torch.bfloat16)
+    nan = lambda: torch.full((M, N), float('nan'), device='cuda')
+
+    def run(C_, C16, bias, resid, epi, auxp, acc, colsum=None):
+        lib.vitae_gemm_glds(akc, bkc, A.data_ptr(), lda, B.data_ptr(), ldb, None if C_ is None else C_.data_ptr(), N,
+                            None if C16 is None else C16.data_ptr(), N, M, N, K, None if bias is None else bias.data_ptr(),
+                            None if resid is None else resid.data_ptr(), N, epi, None if auxp is None else auxp.data_ptr(), N, acc, 1, None,
+                            None if colsum is None else colsum.data_ptr(), st())
+    # kind 1: bias + residual, bf16 copy, column sums
+    y, y16, cs = nan(), torch.zeros(M, N, dtype=torch.bfloat16, device='cuda'), torch.zeros(N, device='cuda')
+    run(y, y16, bd, rd, 0, None, 0, cs)
+    assert rel_err(y, prod + b + res) < 2e-3
+    assert torch.equal(y16, y.to(torch.bfloat16)) and rel_err(cs, y.sum(0)) < 1e-4
+    # kind 0 and 2: plain, then accumulate on top
+    y = nan(); run(y, None, None, None, 0, None, 0)
+    assert rel_err(y, prod) < 2e-3
+    y2 = dev(old); run(y2, None, None, None, 0, None, 1)
+    assert rel_err(y2, prod + old) < 2e-3
+    # kind 7 (generic): residual AND accumulate
+    y2 = dev(old); run(y2, None, bd, rd, 0, None, 1)
+    assert rel_err(y2, prod + b + res + old) < 2e-3
+    # kind 3: GELU, pre-activation saved in fp32 / bf16, bf16-only result
+    pre, y16 = nan(), torch.zeros(M, N, dtype=torch.bfloat16, device='cuda')
+    run(None, y16, bd, None, C['VITAE_EPI_GELU'], pre, 0)
+    assert rel_err(pre, prod + b) < 2e-3 and rel_err(y16.float(), F.gelu(prod + b)) < 1e-2
+    pre16 = torch.zeros(M, N, dtype=torch.bfloat16, device='cuda')
+    run(None, y16, bd, None, C['VITAE_EPI_GELU'] | C['VITAE_EPI_AUX_BF16'], pre16, 0)
+    assert rel_err(pre16.float(), prod + b) < 1e-2 and rel_err(y16.float(), F.gelu(prod + b)) < 1e-2
+    # kind 4: GELU'(aux) (fp32 and bf16 aux), kind 5: ReLU mask, kind 6: ReLU
+    a_ = aux.clone().requires_grad_(True)
+    F.gelu(a_).backward(prod)
+    y = nan(); run(y, None, None, None, C['VITAE_EPI_DGELU'], auxd, 0)
+    assert rel_err(y, a_.grad) < 2e-3
+    a16 = aux16.float().cpu().requires_grad_(True)
+    F.gelu(a16).backward(prod)
+    y = nan(); run(y, None, None, None, C['VITAE_EPI_DGELU'] | C['VITAE_EPI_AUX_BF16'], aux16, 0)
+    assert rel_err(y, a16.grad) < 2e-3
+    y = nan(); run(y, None, None, None, C['VITAE_EPI_RELU_MASK'], auxd, 0)
+    assert rel_err(y, torch.where(aux > 0, prod, torch.zeros(()))) < 2e-3
+    y = nan(); run(y, None, bd, None, C['VITAE_EPI_RELU'], None, 0)
+    assert rel_err(y, F.relu(prod + b)) < 2e-3
+
+
+@pytest.mark.parametrize('form', ['fwd', 'dgrad', 'wgrad'])
+@pytest.mark.parametrize('M,N,K,split', [(880, 768, 3072, 6), (440, 520, 1024, 2), (3456, 768, 4096, 3), (300, 264, 640, 2)])
+def test_gemm_bt_split_k(lib, C, bt_mode, form, M, N, K, split):
+    """In-launch split-K of the 128x128 tile: partials through write-through stores, last arriver sums in split order —
+    equal to the unsplit launch up to fp32 summation order, bitwise reproducible, tickets handed back, epilogue applied once."""
+    if form == 'wgrad':
+        M = M // 8 * 8
+    akc, bkc, A, B, prod = _bt_operands(form, M, N, K, seed=7)
+    lda, ldb = (K if akc else M), (K if bkc else N)
+    bt_mode(3)
+    res, bd = dev(gen(M, N, seed=4)), dev(gen(N, seed=3))
+    ws = torch.zeros(lib.vitae_gemm_glds_ws_floats(M, N, split), device='cuda')
+    outs = []
+    sq = torch.zeros(1, dtype=torch.float64, device='cuda')
+    for rep in range(2):
+        y, cs = torch.full((M, N), float('nan'), device='cuda'), torch.zeros(N, device='cuda')
+        if form == 'wgrad':
+            lib.vitae_gemm_glds_set_wgrad_sqnorm(sq.data_ptr())
+        try:
+            lib.vitae_gemm_glds(akc, bkc, A.data_ptr(), lda, B.data_ptr(), ldb, y.data_ptr(), N, None, 0, M, N, K, bd.data_ptr(), res.data_ptr(), N,
+                                0, None, 0, 0, split, ws.data_ptr(), cs.data_ptr(), st())
+        finally:
+            lib.vitae_gemm_glds_set_wgrad_sqnorm(None)
+        assert rel_err(y, prod + bd.cpu() + res.cpu()) < 2e-3 and rel_err(cs, y.sum(0)) < 1e-4
+        assert int(ws[:C['VITAE_GLDS_TICKETS']].abs().sum()) == 0
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1])
+    if form == 'wgrad':
+        assert abs(float(sq) - 2 * float(outs[0].double().pow(2).sum())) < 1e-4 * float(sq)      # one share per launch, every element once
+
+
+@pytest.mark.parametrize('tile', [0, 3])
+@pytest.mark.parametrize('M,N,K', [(868, 16384, 512), (3464, 768, 768), (880, 3072, 768)])
+def test_linear_bwd_pair_on_big_tiles(lib, C, bt_mode, tile, M, N, K):
+    """vitae_linear_bwd_pair_glds when the planner serves a half with a big tile: the halves leave as two launches — same
+    results as the paired launch (dx with GELU', its bf16 copy and column sums; dW, its bf16 copy; the bias gradient)."""
+    Mp = (M + 63) // 64 * 64
+    x, w, dy, h = gen(M, K, seed=1), gen(N, K, seed=2, scale=K ** -0.5), gen(M, N, seed=5), gen(M, K, seed=6)
+    x16 = torch.zeros(Mp, K, dtype=torch.bfloat16, device='cuda'); x16[:M] = x.cuda().to(torch.bfloat16)
+    dy16 = torch.zeros(Mp, N, dtype=torch.bfloat16, device='cuda'); dy16[:M] = dy.cuda().to(torch.bfloat16)
+    w16, hd_ = w.cuda().to(torch.bfloat16), dev(h)
+    ws = torch.zeros(1 << 24, device='cuda')
+    lib.vitae_gemm_glds_set_ws_capacity(ws.numel())
+    outs = {}
+    for mode in (-2, tile):
+        bt_mode(mode)
+        dx, dx16 = torch.full((M, K), float('nan'), device='cuda'), torch.zeros(M, K, dtype=torch.bfloat16, device='cuda')
+        dw, dw16 = torch.full((N, K), float('nan'), device='cuda'), torch.zeros(N, K, dtype=torch.bfloat16, device='cuda')
+        cs, dycs = torch.zeros(K, device='cuda'), torch.zeros(N, device='cuda')
+        split = lib.vitae_linear_bwd_pair_pick_split_k(M, Mp, N, K)
+        lib.vitae_linear_bwd_pair_glds(dy16.data_ptr(), w16.data_ptr(), x16.data_ptr(), dx.data_ptr(), dx16.data_ptr(), dw.data_ptr(), dw16.data_ptr(),
+                                       M, Mp, N, K, C['VITAE_EPI_DGELU'], hd_.data_ptr(), cs.data_ptr(), dycs.data_ptr(), 0, 0, split, ws.data_ptr(), st())
+        assert torch.equal(dx16, dx.to(torch.bfloat16)) and torch.equal(dw16, dw.to(torch.bfloat16))
+        assert int(ws[:C['VITAE_GLDS_TICKETS']].abs().sum()) == 0
+        outs[mode] = (dx, dw, cs, dycs)
+    dyr, wr, xr = dy16[:M].float().cpu(), w16.float().cpu(), x16[:M].float().cpu()
+    hh = h.clone().requires_grad_(True)
+    F.gelu(hh).backward(dyr @ wr)
+    for mode, (dx, dw, cs, dycs) in outs.items():
+        assert rel_err(dx, hh.grad) < 2e-3 and rel_err(dw, dyr.t() @ xr) < 2e-3, mode
+        assert rel_err(cs, dx.sum(0)) < 1e-4 and rel_err(dycs, dyr.sum(0)) < 1e-5, mode
+    for a, b in zip(outs[-2], outs[tile]):
+        assert rel_err(a, b) < 1e-5           # the two routes differ in fp32 summation order only
+
+
+def test_gemm_bt_planner_is_consistent(lib, bt_mode):
+    """vitae_gemm_glds_pick_split_k returns the split of the plan the launcher will follow; forcing a tile changes the plan;
+    -2 switches the family off."""
+    bt_mode(-1)
+    assert lib.vitae_gemm_glds_bt_choice(1, 1, 868, 16384, 512) == 0 and lib.vitae_gemm_glds_pick_split_k(868, 16384, 512) == 1
+    assert lib.vitae_gemm_glds_bt_choice(1, 1, 440, 768, 768) == -1                 # a batch-4 encoder shape stays on the 64-row tiles
+    assert lib.vitae_gemm_glds_bt_choice(1, 1, 3456, 768, 16384) == 3 and lib.vitae_gemm_glds_pick_split_k(3456, 768, 16384) > 1
+    bt_mode(-2)
+    assert lib.vitae_gemm_glds_bt_choice(1, 1, 868, 16384, 512) == -1
+    bt_mode(3)
+    assert lib.vitae_gemm_glds_bt_choice(1, 1, 868, 16384, 512) == 3
+    with pytest.raises(Exception):
+        lib.vitae_gemm_glds_set_bt_tile(1)

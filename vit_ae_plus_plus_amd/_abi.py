@@ -19,7 +19,7 @@ import torch  # noqa: F401  (import order matters)
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 HEADER = os.path.join(ROOT, 'include', 'vitae_hip.h')
-LIB_PATH = os.path.join(PKG, 'libvitae_hip.so')
+LIB_PATH = os.environ.get('VITAE_HIP_LIB') or os.path.join(PKG, 'libvitae_hip.so')   # the override: kernel experiments (tools/)
 
 _ERRORS = {-1: 'VITAE_ERR_INVALID_ARG', -2: 'VITAE_ERR_UNSUPPORTED_SHAPE', -3: 'VITAE_ERR_LAUNCH'}
 
@@ -105,7 +105,7 @@ class _Lib:
 
 # int-returning entry points whose result is a value, not a status
 _VALUE_RETURNING = {'vitae_abi_version', 'vitae_sdpa_bwd_fused_fits', 'vitae_mlp_fused_supported', 'vitae_mlp_fused_slabs', 'vitae_ddp_available',
-                    'vitae_ddp_world_size', 'vitae_gemm_glds_slab_count'}
+                    'vitae_ddp_world_size', 'vitae_gemm_glds_slab_count', 'vitae_gemm_glds_bt_choice'}
 
 lib = _Lib()
 

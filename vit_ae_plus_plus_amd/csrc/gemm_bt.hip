@@ -1,0 +1,582 @@
+// Big-tile bf16 GEMM (128x128 ... 256x256 per workgroup) for the launches that have enough rows to fill the chip with such
+// tiles: decoder_pred at every batch size, every Linear of the step from batch 8-16 up, the patch-8 model.
+//   C[M,N] (+)= epi( sum_k A(m,k) * B(n,k) + bias[n] ) (+ residual)      (operand storage flags as in gemm_glds.hip)
+//
+// Why a second kernel family: a 64x64 tile moves 16 KB of operands L2 -> LDS per 64-deep k-step for 64x64x64 MACs, and a CU
+// takes at most ~46-56 B/clk from L2 (profiles/round2_probe_dma_pattern.txt; the L2's 34.5 TB/s over 256 CUs): ~330 clocks
+// of feed for 128 clocks of MFMA.  A 256x256 tile moves 64 KB for 16x the MACs (1300 clocks of feed under 2048 of MFMA).
+//
+// Schedule (the 8-phase structure of cdna_hip_programming.md §5 "256^2 template", re-derived for this operand layout):
+//   * a k-tile (64 deep) of each operand is staged as TWO half-tiles (A-lo | A-hi, B-lo | B-hi: HM = BM/2, HN = BN/2 rows
+//     each), and every wave owns rows of BOTH halves: its (BM/WM) x (BN/WN) outputs are four quadrants (A-half x B-half);
+//   * a k-tile is four phases, one quadrant each: P1 reads A-lo + B-lo fragments, P2 B-hi, P3 A-hi, P4 nothing (B-lo kept):
+//     (A0,B0) (A0,B1) (A1,B1) (A1,B0) — at most A-half + 2 B-half fragments live (64 VGPRs at 256x256);
+//   * two LDS buffers only, yet ~5 phases of prefetch distance: a half-tile's slot is free two phases after its last
+//     fragment read, so the DMA of k-tile t + 2 starts in P3 of k-tile t, half-tile by half-tile (A-lo, B-lo, then B-hi and
+//     A-hi in P1 / P2 of k-tile t + 1), always 4 half-tiles (64 KB at 256x256) in flight, retired by COUNTED vmcnt waits;
+//   * 8-wave workgroups run as two groups of four waves (one per SIMD each) staggered by one barrier: while one group
+//     issues its 8 MFMAs of a quadrant, the other issues DMA + fragment reads, so a SIMD's matrix pipe always has one of
+//     its two waves in an MFMA segment.  4-wave workgroups (128x128) are not staggered: two of them share a CU.
+// Hazards, by barrier count (slot = interval between two workgroup barriers; a phase = load slot + MFMA slot; group 1 runs one
+// slot behind group 0): a half-tile needed by the reads of phase g + 1 is waited for (each wave: its own DMA pieces) in the
+// load slot of phase g, i.e. >= 1 barrier before anyone reads it; a half-tile is re-staged >= 2 phases after its last read,
+// i.e. >= 2 barriers after the lgkmcnt(0) that retired the slower group's reads.
+#include <cstdlib>
+#include <type_traits>
+#include "glds_gemm.hpp"
+
+namespace vglds {
+
+template <int BM, int BN, int WM, int WN> struct BtCfg {
+    static constexpr int NW = WM * WN, NT = 64 * NW;
+    static constexpr int HM = BM / 2, HN = BN / 2;                          // rows of a half-tile
+    static constexpr int FM = HM / (32 * WM), FN = HN / (32 * WN);          // 32x32 fragments of a wave inside one half
+    static constexpr int A_HALF = HM * BK * 2, B_HALF = HN * BK * 2;        // bytes
+    static constexpr int BUF = 2 * A_HALF + 2 * B_HALF, SMEM = 2 * BUF;
+    static_assert(FM >= 1 && FN >= 1 && HM == 32 * WM * FM && HN == 32 * WN * FN, "wave arrangement does not tile the halves");
+};
+
+// Epilogue of ONE wave's part of a quadrant ((32 FM) x (32 FN) outputs), WAVE-PRIVATE: the wave parks its fragments in its own LDS
+// region (Tw, row stride 32 FN floats: conflict-free for the ds_write_b32 of the MFMA layout — 32 consecutive columns per half
+// wave — and for the ds_read_b128 lane groups of the row-major read-back), and re-reads them row-major: 8 FN lanes own one row
+// (four consecutive columns each), so C, the bf16 copy, aux, residual and the old C move 16 bytes per lane in whole 128-byte
+// (FN = 1) lines.  No workgroup barrier anywhere: a wave's LDS operations execute in order, and nobody else touches Tw.
+// History (tools/bt_phase_probe.py, 256x256 tile, clocks per quadrant): workgroup-wide staging with every epilogue kind behind
+// run-time branches: park 1900 + rows 5800 (5100 with the global stores removed: instruction-latency bound); specialised on the
+// epilogue kind / full tiles: 1900 + 3200; wave-private: see DESIGN.md.
+// KIND: which epilogue (one instantiation each, so that NO load in the row loop sits behind a run-time condition: hipcc waits
+// vmcnt(0) in front of every conditionally executed load, and on gfx9 that also waits for every global store issued before —
+// the first version spent ~4000 clocks per quadrant waiting for its own stores):
+//   0 plain (bias), 1 + residual, 2 + old C (accumulate), 3 GELU (aux <- pre-activation), 4 GELU' (aux read), 5 ReLU mask (aux
+//   read), 6 ReLU, 7 anything else (every option behind run-time checks: correct, slow).
+// All global loads of the wave's part (one 16-byte load per row pass) are issued BEFORE the first store.
+template <int FM, int FN, int KIND, bool FULL>
+__device__ __forceinline__ void bt_wave_rows(const GArgs& p, int mb, int nb, const float* Tw, int lane, float& sqs, f32x4& csum, const f32x4 bias4) {
+    constexpr int S = 32 * FN, LPR = 8 * FN, RPI = 64 / LPR, PASSES = 32 * FM / RPI, PB = PASSES >= 4 ? 4 : PASSES;
+    const int cg = lane % LPR, rr = lane / LPR;
+    const int n = nb + 4 * cg;
+    const bool ncol = FULL || n < p.N;
+    const int nc = ncol ? n : 0;
+    const int ldaux = (int)p.ldaux, ldr = (int)p.ldr, ldc = (int)p.ldc, ldc16 = (int)p.ldc16;
+    const int epi = KIND == 7 ? p.epi : KIND == 3 ? VITAE_EPI_GELU : KIND == 4 ? VITAE_EPI_DGELU : KIND == 5 ? VITAE_EPI_RELU_MASK
+                  : KIND == 6 ? VITAE_EPI_RELU : VITAE_EPI_NONE;
+    const bool need_aux = KIND == 7 ? (p.epi == VITAE_EPI_DGELU || p.epi == VITAE_EPI_RELU_MASK) : (KIND == 4 || KIND == 5);
+    const bool has_res = KIND == 7 ? p.residual != nullptr : KIND == 1;
+    const bool acc_c = KIND == 7 ? (p.C && p.accumulate) : KIND == 2;
+    // one array per operand kind; an instantiation other than 7 uses at most one of them (and loads all its passes up front;
+    // kind 7 loads batch by batch: three arrays of all passes would spill next to 128 live accumulators)
+    constexpr int LDN = KIND == 7 ? PB : PASSES;
+    f32x4 ax[LDN], rs[LDN], co[LDN];
+    auto load_ops = [&](int q0) {
+#pragma unroll
+        for (int q = 0; q < LDN; ++q) {
+            const int mr = mb + rr + (q0 + q) * RPI;
+            const int mc = FULL ? mr : min(mr, p.M - 1);
+            if (need_aux) {
+                if (p.aux16) {
+                    const bf16x4 h = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(p.aux) + mc * ldaux + nc);
+                    ax[q] = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+                } else {
+                    ax[q] = *reinterpret_cast<const f32x4*>(p.aux + mc * ldaux + nc);
+                }
+            }
+            if (has_res) rs[q] = *reinterpret_cast<const f32x4*>(p.residual + mc * ldr + nc);
+            if (acc_c) co[q] = *reinterpret_cast<const f32x4*>(p.C + mc * ldc + nc);
+        }
+    };
+    if constexpr (KIND != 7) load_ops(0);
+    const float* Trow = Tw + rr * S + 4 * cg;
+    // LDS reads ahead of the first store: the whole part when it is four passes, else batch by batch (eight passes of x next to
+    // the 128 live accumulators of the 256x256 tile spill)
+    constexpr bool XALL = PASSES <= 4;
+    f32x4 x[XALL ? PASSES : PB];
+    if constexpr (XALL) {
+#pragma unroll
+        for (int q = 0; q < PASSES; ++q) x[q] = *reinterpret_cast<const f32x4*>(Trow + q * RPI * S);
+    }
+#pragma unroll
+    for (int pb = 0; pb < PASSES; pb += PB) {
+        if constexpr (KIND == 7) load_ops(pb);
+        constexpr int LB = KIND == 7 ? 0 : 1;      // index of this batch's first pass in the operand arrays: pb * LB
+        constexpr int XB = XALL ? 1 : 0;
+        if constexpr (!XALL) {
+#pragma unroll
+            for (int q = 0; q < PB; ++q) x[q] = *reinterpret_cast<const f32x4*>(Trow + (pb + q) * RPI * S);
+        }
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+            const int m = mb + rr + (pb + q) * RPI;
+            const bool ok = FULL || (ncol && m < p.M);
+            f32x4 v = x[pb * XB + q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += bias4[e];
+            if (epi == VITAE_EPI_GELU) {
+                if (ok) {
+                    if (p.aux16) {
+                        bf16x4 h;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) h[e] = (__bf16)v[e];
+                        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.aux) + m * ldaux + n) = h;
+                    } else {
+                        *reinterpret_cast<f32x4*>(p.aux + m * ldaux + n) = v;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
+            } else if (epi == VITAE_EPI_DGELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= gelu_fast_grad(ax[pb * LB + q][e]);
+            } else if (epi == VITAE_EPI_RELU_MASK) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = ax[pb * LB + q][e] > 0.f ? v[e] : 0.f;
+            } else if (epi == VITAE_EPI_RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if (has_res) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += rs[pb * LB + q][e];
+            }
+            if (acc_c) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += co[pb * LB + q][e];
+            }
+            if (ok) {
+#ifndef VITAE_BT_STORE
+#define VITAE_BT_STORE 0          // experiments: 1 = no fp32 store (the value is kept alive), 2 = non-temporal store
+#endif
+                if (p.C) {
+                    if (VITAE_BT_STORE == 1) asm volatile("" ::"v"(v));
+                    else if (VITAE_BT_STORE == 2) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p.C + m * ldc + n));
+                    else *reinterpret_cast<f32x4*>(p.C + m * ldc + n) = v;
+                }
+                if (p.C16) {
+                    bf16x4 v16;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v16[e] = (__bf16)v[e];
+                    *reinterpret_cast<bf16x4*>(p.C16 + m * ldc16 + n) = v16;
+                }
+                if (p.out_colsum) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) csum[e] += v[e];
+                }
+                if (p.sqacc) sqs += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ int bt_epilogue_kind(const GArgs& p) {
+    const bool res = p.residual != nullptr, accc = p.C && p.accumulate;
+    if (p.epi == VITAE_EPI_NONE) return res && accc ? 7 : res ? 1 : accc ? 2 : 0;
+    if (res || accc) return 7;
+    return p.epi == VITAE_EPI_GELU ? 3 : p.epi == VITAE_EPI_DGELU ? 4 : p.epi == VITAE_EPI_RELU_MASK ? 5 : p.epi == VITAE_EPI_RELU ? 6 : 7;
+}
+
+template <int FM, int FN>
+__device__ __forceinline__ void bt_wave_epilogue(const GArgs& p, int kind, int mb, int nb, const float* Tw, int lane, float& sqs, const f32x4 bias4) {
+    constexpr int LPR = 8 * FN;
+    f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+    const bool full = mb + 32 * FM <= p.M && nb + 32 * FN <= p.N;
+#define VITAE_BT_ROWS(E)                                                              \
+    case E:                                                                           \
+        if (full) bt_wave_rows<FM, FN, E, true>(p, mb, nb, Tw, lane, sqs, csum, bias4); \
+        else bt_wave_rows<FM, FN, E, false>(p, mb, nb, Tw, lane, sqs, csum, bias4);     \
+        break;
+    switch (kind) {
+        VITAE_BT_ROWS(0) VITAE_BT_ROWS(1) VITAE_BT_ROWS(2) VITAE_BT_ROWS(3) VITAE_BT_ROWS(4) VITAE_BT_ROWS(5) VITAE_BT_ROWS(6)
+        default: bt_wave_rows<FM, FN, 7, false>(p, mb, nb, Tw, lane, sqs, csum, bias4); break;
+    }
+#undef VITAE_BT_ROWS
+    if (p.out_colsum) {
+        // lanes with equal (lane % LPR) hold the same four columns: fold the row groups, then one atomic per column
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int d = LPR; d < 64; d <<= 1) csum[e] += __shfl_xor(csum[e], d, 64);
+        const int n = nb + 4 * (lane % LPR);
+        if (lane < LPR && n < p.N) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(p.out_colsum + n + e, csum[e]);
+        }
+    }
+}
+
+// the fragments of one quadrant -> the wave's own LDS region
+template <int FM, int FN, int NACC>
+__device__ __forceinline__ void bt_park_quadrant(const f32x16 (&acc)[NACC][FM * FN], int lane, float* Tw) {
+    constexpr int S = 32 * FN;
+    const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[0][fm * FN + fn][r];
+                if (NACC == 2) v += acc[NACC - 1][fm * FN + fn][r];
+                Tw[(fm * 32 + crow(r, hi)) * S + fn * 32 + l31] = v;
+            }
+}
+
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bt_kernel(const GArgs p) {
+    using Cf = BtCfg<BM, BN, WM, WN>;
+    constexpr int NW = Cf::NW, HM = Cf::HM, HN = Cf::HN, FM = Cf::FM, FN = Cf::FN, NF = FM * FN;
+    constexpr int A_HALF = Cf::A_HALF, B_HALF = Cf::B_HALF, BUF = Cf::BUF;
+    constexpr bool STAGGER = NW == 8;
+    constexpr int PA = pieces<HM, A_KC, NW>(), PB = pieces<HN, B_KC, NW>();
+    constexpr int NACC = NF == 1 ? 2 : 1;          // one fragment per quadrant: even / odd k-slices on separate accumulators
+    constexpr bool ASM_READS = !A_KC || !B_KC;     // transposing reads are inline asm: ordered by hand
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[Cf::SMEM];      // the ONLY LDS object
+
+    // XCD-aware AND balanced tile map (block b runs on XCD b % 8): the T = tiles_m * tiles_n tiles are cut into eight contiguous
+    // chunks of the linear order (sizes differ by at most one), XCD x takes chunk x.  The linear order walks the SHORTER operand's
+    // tiles fastest, so a chunk covers whole column tiles (all row tiles under them) — or whole row tiles when A is the larger
+    // operand (xcd_m): an XCD's L2 holds 1/8 of one operand and streams the other.  (The 64-row kernels give XCD x the column
+    // tiles x, x + 8, ...: with 18 column tiles two XCDs get three columns and six get two — a 1.5x longer tail.)
+    const int bid = blockIdx.x;
+    const int T = p.tiles_m * p.tiles_n;
+    const int xq = T >> 3, xr = T & 7, xcd = bid & 7;
+    const int lin = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    if ((bid >> 3) >= xq + (xcd < xr ? 1 : 0)) return;
+    const int tn = p.xcd_m ? lin % p.tiles_n : lin / p.tiles_m;
+    const int tm = p.xcd_m ? lin / p.tiles_n : lin % p.tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int zid = blockIdx.z;
+    const int kbeg = zid * p.k_per_split;
+    const int nk = (min(p.K, kbeg + p.k_per_split) - kbeg) / BK;         // >= 2 (launcher)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const bool late = STAGGER && wave >= 4;         // group 1: one barrier behind
+    // tools/bt_phase_probe.py: shader-clock stamps of wave 0 / wave 4 (one per stagger group), 32 per (workgroup, group)
+    auto stamp = [&](int i) {
+        if (p.dbg && lane == 0 && (wave & 3) == 0) p.dbg[(((long)zid * gridDim.x + bid) * 2 + (wave >> 2)) * 32 + i] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
+
+    f32x16 acc[2][2][NACC][NF];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int h = 0; h < NACC; ++h)
+#pragma unroll
+                for (int f = 0; f < NF; ++f)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[a][b][h][f][i] = 0.f;
+
+    // half-tile positions in issue order: 0 A-lo, 1 B-lo, 2 B-hi, 3 A-hi; LDS image of a buffer: [A-lo][A-hi][B-lo][B-hi]
+    // one DMA instruction (piece j of this wave) of a half-tile
+    auto issue_piece = [&](auto pos_c, int tile, int buf, int j) {
+        constexpr int POS = decltype(pos_c)::value;
+        constexpr int OFF = POS == 0 ? 0 : POS == 3 ? A_HALF : POS == 1 ? 2 * A_HALF : 2 * A_HALF + B_HALF;
+        unsigned char* dst = smem + buf * BUF + OFF;
+        const int k0 = kbeg + tile * BK;
+        if constexpr (POS == 0 || POS == 3) dma_piece<HM, A_KC, NW>(p.A, p.lda, p.M, m0 + (POS == 3 ? HM : 0), k0, dst, wave, lane, j);
+        else dma_piece<HN, B_KC, NW>(p.B, p.ldb, p.N, n0 + (POS == 2 ? HN : 0), k0, dst, wave, lane, j);
+    };
+    auto issue = [&](auto pos_c, int tile, int buf) {
+        constexpr int POS = decltype(pos_c)::value;
+#pragma unroll
+        for (int j = 0; j < ((POS == 0 || POS == 3) ? PA : PB); ++j) issue_piece(pos_c, tile, buf, j);
+    };
+    bf16x8 fa[FM][BK / 16], fb0[FN][BK / 16], fb1[FN][BK / 16];
+    auto read_a = [&](int buf, int half) {
+        const unsigned char* T = smem + buf * BUF + half * A_HALF;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk)
+#pragma unroll
+            for (int f = 0; f < FM; ++f) fa[f][kk] = frag<HM, A_KC>(T, wm * 32 * FM + f * 32, kk, lane);
+    };
+    auto read_b = [&](int buf, int half, bf16x8 (&fb)[FN][BK / 16]) {
+        const unsigned char* T = smem + buf * BUF + 2 * A_HALF + half * B_HALF;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk)
+#pragma unroll
+            for (int f = 0; f < FN; ++f) fb[f][kk] = frag<HN, B_KC>(T, wn * 32 * FN + f * 32, kk, lane);
+    };
+    // MFMA slot of one quadrant; the DMA pieces of half-tile POS (k-tile `tile`, buffer `buf`; POS < 0: none) are issued BETWEEN
+    // the MFMAs: a piece costs the wave 60-180 clocks of issue, which the matrix pipe spends on the MFMAs already queued —
+    // in the load slot the same pieces made that slot (DMA + up to 12 fragment reads) longer than the partner group's 256
+    // clocks of MFMA, and the matrix pipe idled at every other barrier (tools/bt_phase_probe.py: 3500 -> clocks per k-tile)
+    auto mma = [&](f32x16 (&c)[NACC][NF], bf16x8 (&fb)[FN][BK / 16], auto pos_c, int tile, int buf, int st = -1) {
+        constexpr int POS = decltype(pos_c)::value;
+        constexpr int NP = POS < 0 ? 0 : (POS == 0 || POS == 3) ? PA : PB, NM = (BK / 16) * NF;
+        constexpr int NPD = NP > 0 ? NP : 1, STEP = NM / NPD > 0 ? NM / NPD : 1;
+        if (st >= 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp(st); }
+        if constexpr (ASM_READS) {
+            frags_ready();
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+#pragma unroll
+                for (int f = 0; f < FM; ++f) frag_tie(fa[f][kk]);
+#pragma unroll
+                for (int f = 0; f < FN; ++f) frag_tie(fb[f][kk]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk)
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+                for (int fn = 0; fn < FN; ++fn) {
+                    c[kk % NACC][fm * FN + fn] =
+                        __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[fm][kk], fb[fn][kk], c[kk % NACC][fm * FN + fn], 0, 0, 0);
+                    if constexpr (NP > 0) {
+                        const int m = (kk * FM + fm) * FN + fn;
+                        if (m % STEP == 0 && m / STEP < NP) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            issue_piece(pos_c, tile, buf, m / STEP);
+                            if (m / STEP == NP - 1 || m == NM - 1)
+                                for (int r = m / STEP + 1; r < NP && m == NM - 1; ++r) issue_piece(pos_c, tile, buf, r);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+        __builtin_amdgcn_s_setprio(0);
+        if (st >= 0) stamp(st + 1);
+    };
+    // the barrier that ends a load slot; the MFMA slot of a staggered workgroup ends with a second one
+    auto load_done = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mma_done = [&]() {
+        if constexpr (STAGGER) {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    constexpr int W4 = 2 * (PA + PB);               // DMA instructions of four consecutive half-tiles
+    using NoDma = std::integral_constant<int, -1>;
+
+    // one k-tile = four phases.  MODE 0: steady state (k-tiles t + 1 and t + 2 exist); 1: t == nk - 2; 2: t == nk - 1.
+    // Issue order of the half-tiles: ... A-lo(t) B-lo(t) B-hi(t) A-hi(t) A-lo(t+1) ...; phase g = 4 t + p issues element g + 6 (in its
+    // MFMA slot) and waits (in its load slot, i.e. BEFORE that issue) for element g + 2, which phase g + 1 reads: the three
+    // elements g + 3 .. g + 5 stay in flight.
+#ifndef VITAE_BT_LMASK
+#define VITAE_BT_LMASK 0          // bit p set: the DMA of phase p + 1 is issued in its LOAD slot (before the counted wait), else between
+                                  // the MFMAs.  Measured (256x256, clocks per k-tile): 0 (all between the MFMAs) 2880; 8: 3150; 2: 3080; 10: 3370; 15: 3530 — a DMA
+                                  // issued by the wave in its load slot stalls the MFMA issue of its SIMD partner (that partner's MFMA slot: 320 -> 560)
+#endif
+    constexpr bool L1 = VITAE_BT_LMASK & 1, L2 = VITAE_BT_LMASK & 2, L3 = VITAE_BT_LMASK & 4, L4 = VITAE_BT_LMASK & 8;
+    constexpr int PB_HI = PB, PA_HI = PA, PA_LO = PA, PB_LO = PB;
+    auto ktile = [&](auto mode_c, int t) {
+        constexpr int MODE = decltype(mode_c)::value;
+        const int buf = t & 1;
+        const int sb = (MODE == 0 && p.dbg && t == 2) ? 3 : -100;       // stamps 3..14 in k-tile 2
+        // P1: (A-lo, B-lo); issues B-hi(t + 1); needs B-hi(t) for P2: younger A-hi(t), A-lo(t+1), B-lo(t+1) (+ its own)
+        if constexpr (MODE <= 1 && L1) issue(std::integral_constant<int, 2>{}, t + 1, buf ^ 1);
+        read_a(buf, 0);
+        read_b(buf, 0, fb0);
+        if constexpr (MODE <= 1) wait_vmcnt<2 * PA + PB + (L1 ? PB_HI : 0)>(); else wait_vmcnt<PA>();
+        load_done();
+        if constexpr (MODE <= 1 && !L1) mma(acc[0][0], fb0, std::integral_constant<int, 2>{}, t + 1, buf ^ 1, sb);
+        else mma(acc[0][0], fb0, NoDma{}, 0, 0, sb);
+        mma_done();
+        if (sb >= 0) stamp(sb + 2);
+        // P2: (A-lo, B-hi); issues A-hi(t + 1); needs A-hi(t) for P3: younger A-lo(t+1), B-lo(t+1), B-hi(t+1) (+ its own)
+        if constexpr (MODE <= 1 && L2) issue(std::integral_constant<int, 3>{}, t + 1, buf ^ 1);
+        read_b(buf, 1, fb1);
+        if constexpr (MODE <= 1) wait_vmcnt<PA + 2 * PB + (L2 ? PA_HI : 0)>(); else wait_vmcnt<0>();
+        load_done();
+        if constexpr (MODE <= 1 && !L2) mma(acc[0][1], fb1, std::integral_constant<int, 3>{}, t + 1, buf ^ 1, sb + 3);
+        else mma(acc[0][1], fb1, NoDma{}, 0, 0, sb + 3);
+        mma_done();
+        if (sb >= 0) stamp(sb + 5);
+        // P3: (A-hi, B-hi); issues A-lo(t + 2); P4 reads nothing
+        if constexpr (MODE == 0 && L3) issue(std::integral_constant<int, 0>{}, t + 2, buf);
+        read_a(buf, 1);
+        load_done();
+        if constexpr (MODE == 0 && !L3) mma(acc[1][1], fb1, std::integral_constant<int, 0>{}, t + 2, buf, sb + 6);
+        else mma(acc[1][1], fb1, NoDma{}, 0, 0, sb + 6);
+        mma_done();
+        if (sb >= 0) stamp(sb + 8);
+        // P4: (A-hi, B-lo); issues B-lo(t + 2); needs A-lo, B-lo(t+1) for P1: younger B-hi(t+1), A-hi(t+1), A-lo(t+2) (+ its own)
+        if constexpr (MODE == 0 && L4) issue(std::integral_constant<int, 1>{}, t + 2, buf);
+        if constexpr (MODE == 0) wait_vmcnt<2 * PA + PB + (L4 ? PB_LO : 0)>(); else if constexpr (MODE == 1) wait_vmcnt<PA + PB>();
+        load_done();
+        if constexpr (MODE == 0 && !L4) mma(acc[1][0], fb0, std::integral_constant<int, 1>{}, t + 2, buf, sb + 9);
+        else mma(acc[1][0], fb0, NoDma{}, 0, 0, sb + 9);
+        mma_done();
+        if (sb >= 0) stamp(sb + 11);
+    };
+
+    // prologue: k-tile 0 completely, A-lo and B-lo of k-tile 1
+    issue(std::integral_constant<int, 0>{}, 0, 0);
+    issue(std::integral_constant<int, 1>{}, 0, 0);
+    issue(std::integral_constant<int, 2>{}, 0, 0);
+    issue(std::integral_constant<int, 3>{}, 0, 0);
+    issue(std::integral_constant<int, 0>{}, 1, 1);
+    issue(std::integral_constant<int, 1>{}, 1, 1);
+    stamp(1);
+    wait_vmcnt<W4>();                               // A-lo(0), B-lo(0) landed
+    load_done();
+    if (late) load_done();                          // group 1 starts one barrier later
+    stamp(2);
+#pragma unroll 1
+    for (int t = 0; t < nk - 2; ++t) {
+        if (t == 2) stamp(15);
+        ktile(std::integral_constant<int, 0>{}, t);
+    }
+    ktile(std::integral_constant<int, 1>{}, nk - 2);
+    ktile(std::integral_constant<int, 2>{}, nk - 1);
+    stamp(16);
+    if (STAGGER && !late) load_done();              // group 0 meets group 1's last barrier
+
+    // epilogue: every wave on its own, quadrant by quadrant through its own 32 FM x 32 FN floats of LDS (the stages are free once
+    // everybody has left the k-loop).  The loop over quadrants is ROLLED; only the register -> LDS part depends on which
+    // accumulators are meant.
+    constexpr int TW = 32 * FM * 32 * FN;          // floats per wave
+    static_assert(NW * TW * 4 <= Cf::SMEM, "wave-private staging fits the operand stages");
+    float* Tw = reinterpret_cast<float*>(smem) + wave * TW;
+    float sqs = 0.f;
+    const int kind = bt_epilogue_kind(p);
+    if constexpr (BM * BN < 256 * 256) if (p.splits > 1) {     // (the 256x256 tile: 256 KB of partials per split and workgroup - not offered)
+        // Split-K inside the launch: every split parks its partial tile in the workspace (fragment order: 16 bytes per lane,
+        // lane-contiguous, WRITE-THROUGH stores — sc1 — so the data is on the memory side of the eight L2s without a release
+        // fence), drains, takes a ticket; the LAST arriver of a tile re-reads all partials with sc1 loads in split order
+        // (bitwise reproducible whatever the arrival order) and runs the epilogue.  cdna_hip_programming.md §6 Guideline 16 R1.
+        constexpr int NT = 64 * NW, GROUPS = 4 * NF * 4;                  // 16-byte groups per lane: quadrants x fragments x 4
+        const int tile = tm * p.tiles_n + tn;
+        float* part = p.ws + VITAE_GLDS_TICKETS + (long)tile * p.splits * (NT * GROUPS * 4);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(part, 0, p.splits * (NT * GROUPS * 16), 0x00020000);
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const int toff = (int)threadIdx.x * 16;
+        if constexpr (NACC == 2) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int f = 0; f < NF; ++f)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) acc[a][b][0][f][i] += acc[a][b][NACC - 1][f][i];
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int f = 0; f < NF; ++f)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[a][b][0][f][4 * g + e];
+                        const int grp = ((a * 2 + b) * NF + f) * 4 + g;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (zid * GROUPS + grp) * (NT * 16) + toff, 0, 16);
+                    }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its own stores
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(smem);
+        if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(reinterpret_cast<int*>(p.ws) + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*flag != p.splits - 1) return;
+        __syncthreads();                                          // everyone has read the flag before the staging area is reused
+        // all GROUPS loads of one split in flight together (a first version with one quadrant's four at a time cost the last
+        // arriver 4 x splits dependent round trips to the memory side, ~1 us each)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int f = 0; f < NF; ++f)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        acc[a][b][0][f][i] = 0.f;
+                        if (NACC == 2) acc[a][b][NACC - 1][f][i] = 0.f;
+                    }
+#pragma unroll 1
+        for (int sp = 0; sp < p.splits; ++sp) {
+            f32x4 v[GROUPS];
+#pragma unroll
+            for (int i = 0; i < GROUPS; ++i)
+                v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (sp * GROUPS + i) * (NT * 16) + toff, 0, 16));
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int f = 0; f < NF; ++f)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[a][b][0][f][4 * g + e] += v[((a * 2 + b) * NF + f) * 4 + g][e];
+        }
+        if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<int*>(p.ws) + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+    // the bias of the wave's two column ranges, fetched under the barrier (issued inside the quadrant loop it cost every
+    // quadrant one exposed memory latency)
+    f32x4 biasq[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int n = n0 + b * HN + wn * 32 * FN + 4 * (lane % (8 * FN));
+        biasq[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias && n < p.N) biasq[b] = *reinterpret_cast<const f32x4*>(p.bias + n);
+    }
+    __syncthreads();                               // every wave is done with the operand stages
+    stamp(17);
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+        switch (q) {
+            case 0: bt_park_quadrant<FM, FN, NACC>(acc[0][0], lane, Tw); break;
+            case 1: bt_park_quadrant<FM, FN, NACC>(acc[0][1], lane, Tw); break;
+            case 2: bt_park_quadrant<FM, FN, NACC>(acc[1][0], lane, Tw); break;
+            default: bt_park_quadrant<FM, FN, NACC>(acc[1][1], lane, Tw); break;
+        }
+        __builtin_amdgcn_wave_barrier();           // compiler-only: the lanes' writes stay in front of the other lanes' reads
+        bt_wave_epilogue<FM, FN>(p, kind, m0 + (q >> 1) * HM + wm * 32 * FM, n0 + (q & 1) * HN + wn * 32 * FN, Tw, lane, sqs, (q & 1) ? biasq[1] : biasq[0]);
+        __builtin_amdgcn_wave_barrier();
+        stamp(18 + q);
+    }
+    if (p.sqacc) {
+        sqs = wave_sum(sqs);
+        if (lane == 0) atomicAdd(p.sqacc, (double)sqs);
+    }
+    if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(25); }
+}
+
+template <int BM, int BN, int WM, int WN>
+static void bt_launch_cfg(const GArgs& p, bool a_kc, bool b_kc, hipStream_t st) {
+    const dim3 grid(8 * cdiv((long)p.tiles_m * p.tiles_n, 8), 1, p.splits), block(64 * WM * WN);
+    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_bt_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, st, p);
+    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_bt_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, st, p);
+    else if (!a_kc && !b_kc) hipLaunchKernelGGL((gemm_bt_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, st, p);
+}
+
+bool bt_tile_dims(int id, int& bm, int& bn) {
+    switch (id) {
+        case 0: bm = 256; bn = 256; return true;
+        case 3: bm = 128; bn = 128; return true;
+        default: return false;
+    }
+}
+
+// p: a complete problem descriptor (splits == 1, slab_stride == 0, no a_rowsum); tiles_m / tiles_n are set here
+int bt_launch(GArgs p, int a_kc, int b_kc, int id, hipStream_t st) {
+    int bm, bn;
+    if (!bt_tile_dims(id, bm, bn)) return VITAE_ERR_INVALID_ARG;
+    if (!p.vec_epi || p.slab_stride != 0 || p.a_rowsum || p.rowstats || (p.K % BK) || p.splits < 1) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    if (!a_kc && b_kc) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    // every split gets k_per_split (a multiple of 64) except the last; each needs >= 2 k-tiles
+    p.k_per_split = cdiv(cdiv(p.K, p.splits), BK) * BK;
+    p.splits = cdiv(p.K, p.k_per_split);
+    if (p.K - (p.splits - 1) * p.k_per_split < 2 * BK || p.k_per_split < 2 * BK) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    p.tiles_m = cdiv(p.M, bm); p.tiles_n = cdiv(p.N, bn);
+    if (p.splits > 1 && (!p.ws || id == 0 || (long)p.tiles_m * p.tiles_n > VITAE_GLDS_TICKETS || p.epi == VITAE_EPI_GELU)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    // (256x128 and 128x256 on eight waves were built and measured too: four MFMAs per phase against the same barrier / DMA
+    // overhead as eight — 2150 clocks per k-tile for 1024 of MFMA — never the best tile on any shape of the step: not kept)
+    if (id == 0) bt_launch_cfg<256, 256, 2, 4>(p, a_kc, b_kc, st);
+    else bt_launch_cfg<128, 128, 2, 2>(p, a_kc, b_kc, st);
+    return vitae_launch_status();
+}
+
+}  // namespace vglds

@@ -19,113 +19,15 @@
 #include <cstdlib>
 #include "common.hpp"
 #include "glds_tiles.hpp"
+#include "glds_gemm.hpp"
 #include "vitae_hip.h"
 
 namespace {
 
 using namespace vglds;
 
-struct GArgs {
-    const __bf16* A; long lda;
-    const __bf16* B; long ldb;
-    float* C; long ldc;
-    __bf16* C16; long ldc16;
-    int M, N, K;
-    int k_per_split, splits;
-    const float* bias;
-    const float* residual; long ldr;
-    float* aux; long ldaux;
-    int epi, accumulate;
-    float* ws;           // split-K: [VITAE_GLDS_TICKETS ints of tile tickets (zero between launches)][partial tiles]
-    float* out_colsum;   // optional: out_colsum[n] += sum_m (epilogue result)(m, n)  (bias gradient of the NEXT Linear)
-    float* a_rowsum;     // optional: a_rowsum[m] += sum_k A(m, k): in a wgrad (A = dy^T) this is colsum(dy), the bias gradient
-                         // of THIS Linear, obtained with one extra MFMA against a ones operand in the tn == 0 workgroups
-    int vec_epi;         // all epilogue arrays are 16-byte addressable by 4-column groups (N, the leading dimensions and the
-                         // base pointers allow it): the tile goes through LDS and leaves row-major, 16 bytes per lane
-    int tiles_m, tiles_n;
-    long slab_stride;    // != 0 ("slab mode"): k-split z stores its partial tile at C + z * slab_stride and is done — the splits
-                         // are summed by the kernel that consumes the result anyway (vitae_layernorm_{fwd,bwd}_slabs: the
-                         // launch-boundary reduce); no tickets, no partial round trip inside the launch
-    double* sqacc = nullptr;     // optional: *sqacc += sum of squares of the stored result (the gradient norm's share of a wgrad)
-    int aux16 = 0;               // aux holds bf16 (VITAE_EPI_AUX_BF16): the saved GELU pre-activation at half the bytes
-    float* rowstats = nullptr;   // optional (row-major epilogue only): rowstats[n / 64][m] = (sum, sum of squares) of result(m, 64-column
-                         // slot) — the LayerNorm statistics of the NEXT op, taken while the rows pass through (vitae_gemm_glds_lnfold)
-    long long* dbg;      // optional (tools/gemm_phase_probe.py): 8 s_memtime stamps per workgroup
-    int xcd_m;           // 0: an XCD owns column tiles tn = xcd (mod 8) and walks every row tile (its L2 holds 1/8 of B and all
-                         // of A); 1: it owns row tiles tm = xcd (mod 8) instead — picked when A is the larger operand
-};
-
 long long* g_gemm_dbg = nullptr;
 double* g_wgrad_sqacc = nullptr;   // vitae_gemm_glds_set_wgrad_sqnorm: picked up by every weight-gradient launch while set
-
-// workgroups of one launch (per k-split) under either XCD mapping
-inline int glds_blocks(const GArgs& p) {
-    return p.xcd_m ? 8 * cdiv(p.tiles_m, 8) * p.tiles_n : 8 * cdiv(p.tiles_n, 8) * p.tiles_m;
-}
-
-// Epilogue of one 32x32 accumulator fragment: column n, rows mbase + crow(r, hi).  The reads the epilogue needs
-// (aux / residual / old C) are issued eight rows at a time, from clamped addresses, BEFORE the dependent stores, so
-// their latencies overlap — one dependent load -> store per element made the residual GEMMs 2x slower than the bare
-// product, while batching all 16 rows x 3 arrays at once cost 150 extra VGPRs (one workgroup per CU for the 64x128
-// tiles).  Returns the column sum of the stored values.
-__device__ __forceinline__ float epilogue_frag(const GArgs& p, const float (&v)[16], int mbase, int n, int hi, float& sqsum) {
-    // 32-bit element offsets from the (wave-uniform) base pointers: one VGPR per address instead of a 64-bit pair
-    // per row and array (the launchers reject operands with more than 2^31 elements)
-    const int nc = min(n, p.N - 1);
-    const int ldaux = (int)p.ldaux, ldr = (int)p.ldr, ldc = (int)p.ldc, ldc16 = (int)p.ldc16;
-    const bool need_aux = p.epi == VITAE_EPI_DGELU || p.epi == VITAE_EPI_RELU_MASK;
-    const bool acc_c = p.C && p.accumulate;
-    const float bias = p.bias ? p.bias[nc] : 0.f;
-    const bool ncol = n < p.N;
-    float csum = 0.f;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        float ax[8], rs[8], co[8];
-        int mrow[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) mrow[q] = min(mbase + crow(8 * half + q, hi), p.M - 1);
-        if (need_aux) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                ax[q] = p.aux16 ? (float)reinterpret_cast<const __bf16*>(p.aux)[mrow[q] * ldaux + nc] : p.aux[mrow[q] * ldaux + nc];
-        }
-        if (p.residual) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) rs[q] = p.residual[mrow[q] * ldr + nc];
-        }
-        if (acc_c) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) co[q] = p.C[mrow[q] * ldc + nc];
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int m = mbase + crow(8 * half + q, hi);
-            if (!(ncol && m < p.M)) continue;
-            float x = v[8 * half + q] + bias;
-            if (p.epi == VITAE_EPI_GELU) {
-                if (p.aux16) reinterpret_cast<__bf16*>(p.aux)[m * ldaux + n] = (__bf16)x;
-                else p.aux[m * ldaux + n] = x;
-                x = gelu_fast(x);
-            } else if (p.epi == VITAE_EPI_DGELU) {
-                x *= gelu_fast_grad(ax[q]);
-            } else if (p.epi == VITAE_EPI_RELU_MASK) {
-                x = ax[q] > 0.f ? x : 0.f;
-            } else if (p.epi == VITAE_EPI_RELU) {
-                x = fmaxf(x, 0.f);
-            }
-            if (p.residual) x += rs[q];
-            if (p.C) {
-                if (acc_c) x += co[q];
-                p.C[m * ldc + n] = x;
-            }
-            if (p.C16) p.C16[m * ldc16 + n] = (__bf16)x;
-            csum += x;
-            sqsum += x * x;
-        }
-        asm volatile("" ::: "memory");   // keep the next batch's loads behind these stores (register pressure)
-    }
-    return csum;
-}
 
 // Row-major epilogue.  The MFMA result has one COLUMN per lane (16 rows of it), so storing from registers means 4-byte
 // accesses (2-byte for the bf16 copy), two 128-byte row pieces per instruction.  Here the finished tile is parked in
@@ -981,17 +883,20 @@ inline Tile pick_tile(int M, int N) {
     return {64, 64, 0};
 }
 
-template <int BM1, int BN1>
-void launch_pair(int id2, dim3 grid, hipStream_t st, const GArgs& p1, const GArgs& p2, int nb1) {
-    dim3 block(256);
-    if (id2 == 0) hipLaunchKernelGGL((gemm_glds_pair_kernel<BM1, BN1, 64, 64>), grid, block, 0, st, p1, p2, nb1);
-    else if (id2 == 1) hipLaunchKernelGGL((gemm_glds_pair_kernel<BM1, BN1, 64, 128>), grid, block, 0, st, p1, p2, nb1);
-    else hipLaunchKernelGGL((gemm_glds_pair_kernel<BM1, BN1, 128, 128>), grid, block, 0, st, p1, p2, nb1);
-}
+// ---- which kernel family serves a problem: the 64-row tiles of this file or the big tiles of gemm_bt.hip ---------------------
+// A cost model in shader clocks, fitted to tools/bt_bench.py / tools/bt_phase_probe.py measurements:
+//   big tile, per workgroup: prologue + k-tiles x clocks per 64-deep k-tile + epilogue (+ split-K fix-up); a launch takes
+//   ceil(workgroups / resident slots) rounds of that.  256x256: 3000 + 2950 nk + 14500, one workgroup per CU; 128x128: 4500 +
+//   1800 nk + 7500, two per CU, split-K fix-up 6000 + 2200 per split (write-through drain, ticket, one round trip per split).
+//   64-row tiles: throughput bound tiles x (5100 + 400 nk) / 256 (64x64; 2800 + 930 nk for 64x128) or, with few tiles, the
+//   latency of one workgroup 8000 + 760 nk (+ 7000 for the in-launch split-K fix-up).
+// g_bt_mode: -1 the model decides, -2 never, 0 / 3: that tile wherever it is eligible (vitae_gemm_glds_set_bt_tile; VITAE_BT_TILE).
+int g_bt_mode = getenv("VITAE_BT_TILE") ? atoi(getenv("VITAE_BT_TILE")) : -1;
+long g_ws_capacity = 0;              // floats the caller's split-K workspace holds (vitae_gemm_glds_set_ws_capacity); 0: not told
 
-}  // namespace
+struct BtPlan { int tile, split; double clocks; };
 
-extern "C" int vitae_gemm_glds_pick_split_k(int M, int N, int K) {
+inline int old_split_rule(int M, int N, int K) {
     static const int min_kt = getenv("VITAE_GLDS_SPLIT_MIN_KT") ? atoi(getenv("VITAE_GLDS_SPLIT_MIN_KT")) : 8;
     static const int target = getenv("VITAE_GLDS_SPLIT_BLOCKS") ? atoi(getenv("VITAE_GLDS_SPLIT_BLOCKS")) : 384;
     const Tile t = pick_tile(M, N);
@@ -1004,16 +909,88 @@ extern "C" int vitae_gemm_glds_pick_split_k(int M, int N, int K) {
     return s < 1 ? 1 : (int)s;
 }
 
+inline double est_64row(int M, int N, int K, bool allow_split) {
+    const Tile t = pick_tile(M, N);
+    const int s = allow_split ? old_split_rule(M, N, K) : 1;
+    const double nk = (double)K / BK / s, wgs = (double)cdiv(M, t.bm) * cdiv(N, t.bn) * s;
+    const double c = t.id == 1 ? 2800 + 930 * nk : 5100 + 400 * nk;
+    const double lat = 8000 + (t.id == 1 ? 1000 : 760) * nk + (s > 1 ? 7000 : 0);
+    const double thr = wgs * c / 256;
+    return thr > lat ? thr : lat;
+}
+
+// cap: floats of split-K workspace a plan may need (< 0: no limit — the caller sizes the workspace from the plan's split)
+inline BtPlan bt_plan(int M, int N, int K, int a_kc, int b_kc, bool allow_split, long cap = -1) {
+    BtPlan best{-1, 1, 1e30};
+    if (g_bt_mode == -2 || K < 2 * BK || (K % BK) || (!a_kc && b_kc) || (N & 3)) return best;
+    const int nkt = K / BK;
+    for (int id : {0, 3}) {
+        if (g_bt_mode >= 0 && id != g_bt_mode) continue;
+        int bm, bn;
+        bt_tile_dims(id, bm, bn);
+        if (M < bm / 2 || N < bn / 2) continue;
+        const long tiles = (long)cdiv(M, bm) * cdiv(N, bn);
+        for (int s = 1; s <= (id == 3 && allow_split ? 8 : 1); ++s) {
+            const int kps = cdiv(cdiv(K, s), BK) * BK;
+            if (cdiv(K, kps) != s || kps < 4 * BK || K - (s - 1) * kps < 2 * BK) continue;
+            if (s > 1 && (tiles > VITAE_GLDS_TICKETS || (cap >= 0 && VITAE_GLDS_TICKETS + tiles * s * bm * bn > cap))) continue;
+            const double wgs = (double)tiles * s, slots = id == 0 ? 256 : 512;
+            const double rounds = (double)cdiv((long)wgs, (long)slots);
+            const double nk = (double)nkt / s;
+            const double per = id == 0 ? 3000 + 2950 * nk + 14500 : 4500 + 1800 * nk + 7500 + (s > 1 ? 6000 + 2200 * s : 0);
+            const double clk = rounds * per;
+            if (clk < best.clocks) best = BtPlan{id, s, clk};
+        }
+    }
+    if (best.tile < 0 || g_bt_mode >= 0) return best;
+    if (best.clocks >= 0.92 * est_64row(M, N, K, allow_split)) return BtPlan{-1, 1, 0.0};
+    return best;
+}
+
+template <int BM1, int BN1>
+void launch_pair(int id2, dim3 grid, hipStream_t st, const GArgs& p1, const GArgs& p2, int nb1) {
+    dim3 block(256);
+    if (id2 == 0) hipLaunchKernelGGL((gemm_glds_pair_kernel<BM1, BN1, 64, 64>), grid, block, 0, st, p1, p2, nb1);
+    else if (id2 == 1) hipLaunchKernelGGL((gemm_glds_pair_kernel<BM1, BN1, 64, 128>), grid, block, 0, st, p1, p2, nb1);
+    else hipLaunchKernelGGL((gemm_glds_pair_kernel<BM1, BN1, 128, 128>), grid, block, 0, st, p1, p2, nb1);
+}
+
+}  // namespace
+
+extern "C" int vitae_gemm_glds_set_bt_tile(int mode) {
+    if (mode < -2 || mode > 3 || mode == 1 || mode == 2) return VITAE_ERR_INVALID_ARG;
+    g_bt_mode = mode;
+    return VITAE_OK;
+}
+
+extern "C" int vitae_gemm_glds_bt_choice(int a_kcontig, int b_kcontig, int M, int N, int K) { return bt_plan(M, N, K, a_kcontig, b_kcontig, true).tile; }
+
+extern "C" int vitae_gemm_glds_pick_split_k(int M, int N, int K) {
+    // (the forward / dgrad / wgrad forms share one plan: the model does not depend on the operand storage)
+    const BtPlan bp = bt_plan(M, N, K, 1, 1, true);
+    if (bp.tile >= 0) return bp.split;
+    return old_split_rule(M, N, K);
+}
+
 extern "C" long vitae_gemm_glds_ws_floats(int M, int N, int split_k) {
     if (split_k <= 1) return 0;
     const Tile t = pick_tile(M, N);
-    return VITAE_GLDS_TICKETS + (long)cdiv(M, t.bm) * cdiv(N, t.bn) * split_k * t.bm * t.bn;
+    // whichever family serves the problem: the 128-row padding of the big tiles covers the 64-row one
+    const long small = (long)cdiv(M, t.bm) * cdiv(N, t.bn) * t.bm * t.bn, big = (long)cdiv(M, 128) * cdiv(N, 128) * 128 * 128;
+    return VITAE_GLDS_TICKETS + (small > big ? small : big) * split_k;
+}
+
+extern "C" int vitae_gemm_glds_set_ws_capacity(long floats) {
+    if (floats < 0) return VITAE_ERR_INVALID_ARG;
+    g_ws_capacity = floats;
+    return VITAE_OK;
 }
 
 static int gemm_glds_launch(int a_kcontig, int b_kcontig, const void* A16, long lda, const void* B16, long ldb,
                             float* C, long ldc, void* C16, long ldc16, int M, int N, int K, const float* bias,
                             const float* residual, long ldr, int epi, float* aux, long ldaux, int accumulate,
-                            int split_k, float* splitk_ws, float* out_colsum_accum, float* out_rowstats, void* stream) {
+                            int split_k, float* splitk_ws, float* out_colsum_accum, float* out_rowstats, void* stream,
+                            const BtPlan* forced = nullptr) {
     if (!A16 || !B16 || (!C && !C16) || M <= 0 || N <= 0 || K <= 0) return VITAE_ERR_INVALID_ARG;
     const int aux16 = (epi & VITAE_EPI_AUX_BF16) != 0;
     epi &= ~VITAE_EPI_AUX_BF16;
@@ -1045,6 +1022,13 @@ static int gemm_glds_launch(int a_kcontig, int b_kcontig, const void* A16, long 
     p.vec_epi = vec_epilogue_ok(p);
     p.rowstats = out_rowstats;
     if (!a_kcontig && !b_kcontig) p.sqacc = g_wgrad_sqacc;      // the weight-gradient form (dy^T @ x)
+    if (!out_rowstats && p.vec_epi) {
+        const BtPlan bp = forced ? *forced : bt_plan(M, N, K, a_kcontig, b_kcontig, epi != VITAE_EPI_GELU);
+        if (bp.tile >= 0 && bp.split == split_k) {
+            p.splits = split_k;
+            return bt_launch(p, a_kcontig, b_kcontig, bp.tile, (hipStream_t)stream);
+        }
+    }
     if (out_rowstats && (!p.vec_epi || t.id > 1)) return VITAE_ERR_UNSUPPORTED_SHAPE;   // taken in the row-major epilogue only
     if (split_k > 1 && (long)p.tiles_m * p.tiles_n > VITAE_GLDS_TICKETS) return VITAE_ERR_UNSUPPORTED_SHAPE;
     dim3 grid(glds_blocks(p), 1, split_k);
@@ -1153,6 +1137,34 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
     if ((N % BK) || (Mpad % BK) || (K & 7) || Mpad < M) return VITAE_ERR_UNSUPPORTED_SHAPE;
     if ((long)(M > N ? M : N) * K >= (1L << 31)) return VITAE_ERR_UNSUPPORTED_SHAPE;   // 32-bit epilogue offsets
     if (((uintptr_t)dy16 & 15) || ((uintptr_t)w16 & 15) || ((uintptr_t)x16 & 15)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    if (g_bt_mode != -2) {
+        // When the big tiles serve either half, the halves go out as two launches of their own (each fills the chip; the
+        // paired launch exists to double the resident workgroups of two SMALL problems): dx = epi(dy16 @ W16) and
+        // dW (+)= dy16^T @ x16 through the planner of vitae_gemm_glds, bias gradient by the column-sum kernel.
+        // workspace the halves may use: what the caller said it holds, else what this entry point documents (as for
+        // vitae_gemm_glds with (M, K) and the split it was handed)
+        const long cap = !splitk_ws ? 0 : g_ws_capacity > 0 ? g_ws_capacity : vitae_gemm_glds_ws_floats(M, K, split_k);
+        const BtPlan pd = bt_plan(M, K, N, 1, 0, true, cap), pw = bt_plan(N, K, Mpad, 0, 0, true, cap);
+        if (pd.tile >= 0 || pw.tile >= 0) {
+            // each half: the plan's split when the plan is a big tile, else the 64-row family's own rule, shrunk to the workspace
+            auto fit = [&](const BtPlan& bp, int m, int n, int k) {
+                if (bp.tile >= 0) return bp.split;
+                int sp = old_split_rule(m, n, k);
+                while (sp > 1 && vitae_gemm_glds_ws_floats(m, n, sp) > cap) --sp;
+                return sp;
+            };
+            int rc = gemm_glds_launch(1, 0, dy16, N, w16, K, dx, K, dx16, K, M, K, N, nullptr, nullptr, 0, epi | (aux16 ? VITAE_EPI_AUX_BF16 : 0),
+                                      aux, K, dx_accumulate, fit(pd, M, K, N), splitk_ws, dx_colsum_accum, nullptr, stream, &pd);
+            if (rc != VITAE_OK) return rc;
+            rc = gemm_glds_launch(0, 0, dy16, N, x16, K, dw, K, dw16, K, N, K, Mpad, nullptr, nullptr, 0, VITAE_EPI_NONE, nullptr, 0,
+                                  dw_accumulate, fit(pw, N, K, Mpad), splitk_ws, nullptr, nullptr, stream, &pw);
+            if (rc != VITAE_OK) return rc;
+            if (dy_colsum_accum)
+                hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(N, 256), cdiv(M, 32)), dim3(256), 0, (hipStream_t)stream,
+                                   reinterpret_cast<const __bf16*>(dy16), dy_colsum_accum, M, N, 32);
+            return vitae_launch_status();
+        }
+    }
     GArgs p1, p2;
     p1.A = reinterpret_cast<const __bf16*>(dy16); p1.lda = N;
     p1.B = reinterpret_cast<const __bf16*>(w16); p1.ldb = K;

@@ -1,0 +1,114 @@
+// What the LDS-DMA GEMM kernels share: the launch descriptor of one GEMM problem, the XCD-aware workgroup count and the
+// register-level epilogue of one 32x32 accumulator fragment (gemm_glds.hip: 64-row tiles; gemm_bt.hip: the big tiles).
+#pragma once
+#include "common.hpp"
+#include "glds_tiles.hpp"
+#include "vitae_hip.h"
+
+namespace vglds {
+
+struct GArgs {
+    const __bf16* A; long lda;
+    const __bf16* B; long ldb;
+    float* C; long ldc;
+    __bf16* C16; long ldc16;
+    int M, N, K;
+    int k_per_split, splits;
+    const float* bias;
+    const float* residual; long ldr;
+    float* aux; long ldaux;
+    int epi, accumulate;
+    float* ws;           // split-K: [VITAE_GLDS_TICKETS ints of tile tickets (zero between launches)][partial tiles]
+    float* out_colsum;   // optional: out_colsum[n] += sum_m (epilogue result)(m, n)  (bias gradient of the NEXT Linear)
+    float* a_rowsum;     // optional: a_rowsum[m] += sum_k A(m, k): in a wgrad (A = dy^T) this is colsum(dy), the bias gradient
+                         // of THIS Linear, obtained with one extra MFMA against a ones operand in the tn == 0 workgroups
+    int vec_epi;         // all epilogue arrays are 16-byte addressable by 4-column groups (N, the leading dimensions and the
+                         // base pointers allow it): the tile goes through LDS and leaves row-major, 16 bytes per lane
+    int tiles_m, tiles_n;
+    long slab_stride;    // != 0 ("slab mode"): k-split z stores its partial tile at C + z * slab_stride and is done — the splits
+                         // are summed by the kernel that consumes the result anyway (vitae_layernorm_{fwd,bwd}_slabs: the
+                         // launch-boundary reduce); no tickets, no partial round trip inside the launch
+    double* sqacc = nullptr;     // optional: *sqacc += sum of squares of the stored result (the gradient norm's share of a wgrad)
+    int aux16 = 0;               // aux holds bf16 (VITAE_EPI_AUX_BF16): the saved GELU pre-activation at half the bytes
+    float* rowstats = nullptr;   // optional (row-major epilogue only): rowstats[n / 64][m] = (sum, sum of squares) of result(m, 64-column
+                         // slot) — the LayerNorm statistics of the NEXT op, taken while the rows pass through (vitae_gemm_glds_lnfold)
+    long long* dbg;      // optional (tools/gemm_phase_probe.py): 8 s_memtime stamps per workgroup
+    int xcd_m;           // 0: an XCD owns column tiles tn = xcd (mod 8) and walks every row tile (its L2 holds 1/8 of B and all
+                         // of A); 1: it owns row tiles tm = xcd (mod 8) instead — picked when A is the larger operand
+};
+
+// workgroups of one launch (per k-split) under either XCD mapping
+inline int glds_blocks(const GArgs& p) {
+    return p.xcd_m ? 8 * cdiv(p.tiles_m, 8) * p.tiles_n : 8 * cdiv(p.tiles_n, 8) * p.tiles_m;
+}
+
+// Epilogue of one 32x32 accumulator fragment: column n, rows mbase + crow(r, hi).  The reads the epilogue needs
+// (aux / residual / old C) are issued eight rows at a time, from clamped addresses, BEFORE the dependent stores, so
+// their latencies overlap — one dependent load -> store per element made the residual GEMMs 2x slower than the bare
+// product, while batching all 16 rows x 3 arrays at once cost 150 extra VGPRs (one workgroup per CU for the 64x128
+// tiles).  Returns the column sum of the stored values.
+__device__ __forceinline__ float epilogue_frag(const GArgs& p, const float (&v)[16], int mbase, int n, int hi, float& sqsum) {
+    // 32-bit element offsets from the (wave-uniform) base pointers: one VGPR per address instead of a 64-bit pair
+    // per row and array (the launchers reject operands with more than 2^31 elements)
+    const int nc = min(n, p.N - 1);
+    const int ldaux = (int)p.ldaux, ldr = (int)p.ldr, ldc = (int)p.ldc, ldc16 = (int)p.ldc16;
+    const bool need_aux = p.epi == VITAE_EPI_DGELU || p.epi == VITAE_EPI_RELU_MASK;
+    const bool acc_c = p.C && p.accumulate;
+    const float bias = p.bias ? p.bias[nc] : 0.f;
+    const bool ncol = n < p.N;
+    float csum = 0.f;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        float ax[8], rs[8], co[8];
+        int mrow[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) mrow[q] = min(mbase + crow(8 * half + q, hi), p.M - 1);
+        if (need_aux) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                ax[q] = p.aux16 ? (float)reinterpret_cast<const __bf16*>(p.aux)[mrow[q] * ldaux + nc] : p.aux[mrow[q] * ldaux + nc];
+        }
+        if (p.residual) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) rs[q] = p.residual[mrow[q] * ldr + nc];
+        }
+        if (acc_c) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) co[q] = p.C[mrow[q] * ldc + nc];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int m = mbase + crow(8 * half + q, hi);
+            if (!(ncol && m < p.M)) continue;
+            float x = v[8 * half + q] + bias;
+            if (p.epi == VITAE_EPI_GELU) {
+                if (p.aux16) reinterpret_cast<__bf16*>(p.aux)[m * ldaux + n] = (__bf16)x;
+                else p.aux[m * ldaux + n] = x;
+                x = gelu_fast(x);
+            } else if (p.epi == VITAE_EPI_DGELU) {
+                x *= gelu_fast_grad(ax[q]);
+            } else if (p.epi == VITAE_EPI_RELU_MASK) {
+                x = ax[q] > 0.f ? x : 0.f;
+            } else if (p.epi == VITAE_EPI_RELU) {
+                x = fmaxf(x, 0.f);
+            }
+            if (p.residual) x += rs[q];
+            if (p.C) {
+                if (acc_c) x += co[q];
+                p.C[m * ldc + n] = x;
+            }
+            if (p.C16) p.C16[m * ldc16 + n] = (__bf16)x;
+            csum += x;
+            sqsum += x * x;
+        }
+        asm volatile("" ::: "memory");   // keep the next batch's loads behind these stores (register pressure)
+    }
+    return csum;
+}
+
+// gemm_bt.hip: the big-tile kernels (id 0: 256x256, 1: 256x128, 2: 128x256 on 8 waves; 3: 128x128 on 4 waves).  `p` is a complete
+// descriptor of ONE unsplit problem; tiles_m / tiles_n are set by the launcher.
+bool bt_tile_dims(int id, int& bm, int& bn);
+int bt_launch(GArgs p, int a_kc, int b_kc, int id, hipStream_t st);
+
+}  // namespace vglds

@@ -176,7 +176,8 @@ class HipMAEEngine:
         self.taps = gaussian_taps_host(2.0)
         self._taps_c = self.taps.ctypes.data
         self.ws = torch.empty(1 << 24, **f32)   # split-K scratch (64 MiB)
-        self.ws16 = torch.zeros(1 << 23, **f32)  # LDS-DMA GEMMs: tile tickets (kept zero by the kernels) + partial tiles
+        self.ws16 = torch.zeros(1 << 24, **f32)  # LDS-DMA GEMMs: tile tickets (kept zero by the kernels) + partial tiles
+        lib.vitae_gemm_glds_set_ws_capacity(self.ws16.numel())   # (process-global: every engine allocates the same size)
         self.B = None
         self.buf: Dict[str, torch.Tensor] = {}
         # one workspace per (batch, kept patches), kept alive while captured graphs may hold its addresses; evicting one
