@@ -324,6 +324,7 @@ def _one_step_vs_oracle(cfg, B, precision, seed, loss_tol, gnorm_tol):
         gtotal = gl[0]
         assert float(gmask.sum()) == float(mask.sum())
     gtotal.backward()
+    lerr = max(abs(float(a.detach()) - float(b.detach())) / abs(float(b.detach())) for a, b in zip(gl[:3], loss[:3]))
     for a, b in zip(gl[:3], loss[:3]):
         close(a, b, loss_tol, 1e-7)
     named = dict(model.named_parameters())
@@ -335,10 +336,65 @@ def _one_step_vs_oracle(cfg, B, precision, seed, loss_tol, gnorm_tol):
         got = float(named[k].grad.double().norm())
         if ref > 1e-6 * max(1.0, float(total.detach())):
             worst = max(worst, abs(got - ref) / ref)
+    print(f'{type(model).__name__} {cfg.volume_size} {precision}: worst loss error {lerr:.2e}, worst gradient-norm error {worst:.2e}')
     assert worst < gnorm_tol, worst
 
 
-@pytest.mark.parametrize('precision,loss_tol,gnorm_tol', [('fp32', 1e-4, 2e-3), ('bf16', 2e-3, 5e-2)])
+def _one_step_vs_reference_pins(fixture, cfg, B, seeds, precision, loss_tol, gnorm_tol, pred_tol):
+    """One forward + backward of the drop-in model against pins produced by the REFERENCE model (oracle/gen_golden.py
+    _one_step_pins): the loss scalars, mask sums, prediction samples, per-parameter gradient norms."""
+    from vit_ae_plus_plus_amd.utils.train_one_epoch import compute_contrastive_loss
+    g = load_golden(fixture)
+    model = build(cfg, R.init_state_dict(cfg, seed=seeds[0]), precision=precision)
+    model.train(True)
+    v1, v2 = R.synthetic_views((B, cfg.in_chans, *cfg.volume_size), seed=seeds[1])
+    n1, n2 = R.masking_noise(B, cfg.num_patches, seed=seeds[2])
+    if cfg.contrastive:
+        model.set_masking_noise(n1, n2)
+        loss, pred, mask, p1, p2, z1, z2 = model(view1=v1.cuda(), view2=v2.cuda(), mask_ratio=0.75, edge_map_weight=0.01)
+        contr = compute_contrastive_loss(argparse.Namespace(contr_weight=0.001), None, p1, p2, z1, z2)
+        close(contr, g['contr_loss'], 20 * loss_tol, 1e-8)
+    else:
+        model.set_masking_noise(n1)
+        loss, pred, mask = model(v1.cuda(), mask_ratio=0.75, edge_map_weight=0.01)
+        contr = torch.zeros((), device='cuda')
+    got, ref = torch.stack(loss).detach().double().cpu().numpy(), g['losses']
+    errs = np.abs(got[:3] - ref[:3]) / np.abs(ref[:3])
+    assert (errs <= loss_tol).all(), (got, ref, errs)
+    assert torch.equal(mask.sum(1).cpu(), t(g['mask_sum']))
+    ps = pred[:, ::37, ::(1021 if pred.shape[-1] > 4096 else 127)].detach().double().cpu().numpy()
+    assert np.abs(ps - g['pred_slice']).max() <= pred_tol * np.abs(g['pred_slice']).max()      # max-norm, relative to the prediction's scale
+    (loss[0] + contr).backward()
+    named = dict(model.named_parameters())
+    worst = 0.0
+    for k, refn in zip(list(g['grad_names']), g['grad_norms']):
+        gotn = float(named[str(k)].grad.double().norm())
+        if refn > 1e-6 * max(1.0, float(ref[0])):
+            worst = max(worst, abs(gotn - refn) / refn)
+    assert worst < gnorm_tol, worst
+    print(f'{fixture} {precision}: worst loss error {errs.max():.2e}, worst gradient-norm error {worst:.2e}')
+    return float(errs.max()), worst
+
+
+@pytest.mark.parametrize('precision,loss_tol,gnorm_tol,pred_tol', [('fp32', 1e-4, 2e-3, 1e-3), ('bf16', 1e-3, 6e-3, 3e-2)])   # bf16: 3x observed (2.8e-4 / 1.6e-3)
+def test_vitb_patch8_vs_reference_pins(precision, loss_tol, gnorm_tol, pred_tol):
+    """The reference's SHIPPED configuration (config.ini:33 patch_size = 8 -> read_configs.py:38 -> model_factory.py:12):
+    contrastive ViT-B on 96^3 x 4ch is 1728 patches, 433 encoder tokens (head dim 64) and 1729 decoder tokens (head dim 32: beyond
+    the one-launch attention backward's LDS budget, so the two-kernel backward runs), decoder_pred 512 -> 2048.  Pins from the
+    reference model itself (tests/golden/vitb_p8.npz): fp32 mode at the north-star tolerance, bf16 at its round-off."""
+    cfg = R.vit_base_cfg(volume_size=(96, 96, 96), patch_size=8, in_chans=4, contrastive=True)
+    _one_step_vs_reference_pins('vitb_p8.npz', cfg, 1, (0, 1234, 4321), precision, loss_tol, gnorm_tol, pred_tol)
+
+
+@pytest.mark.parametrize('precision,loss_tol,gnorm_tol,pred_tol', [('fp32', 1e-4, 2e-3, 1e-3), ('bf16', 1e-4, 6e-3, 3e-2)])   # bf16: 3x observed (2.8e-5 / 1.9e-3)
+def test_config4_vs_reference_pins(precision, loss_tol, gnorm_tol, pred_tol):
+    """BASELINE config 4 (mae_vit_large_patch16 on 128^3 x 4ch, B = 1) against the reference model's own numbers
+    (tests/golden/vitl_128.npz) — round 2 checked this configuration against the live oracle only."""
+    cfg = R.vit_large_cfg(volume_size=(128, 128, 128), patch_size=16, in_chans=4, contrastive=False)
+    _one_step_vs_reference_pins('vitl_128.npz', cfg, 1, (2, 1234, 77), precision, loss_tol, gnorm_tol, pred_tol)
+
+
+@pytest.mark.parametrize('precision,loss_tol,gnorm_tol', [('fp32', 1e-4, 2e-3), ('bf16', 1e-4, 6e-3)])     # bf16: 3x observed (2.8e-5 / 1.9e-3)
 def test_config4_vit_large_128(precision, loss_tol, gnorm_tol):
     """BASELINE config 4: ViT-L/16 autoencoder, 128^3 x 4ch (129 encoder / 513 decoder tokens — the decoder exceeds the
     one-launch attention backward's LDS budget, so the two-kernel path runs), B = 1, against the oracle."""
@@ -346,7 +402,7 @@ def test_config4_vit_large_128(precision, loss_tol, gnorm_tol):
     _one_step_vs_oracle(cfg, 1, precision, seed=2, loss_tol=loss_tol, gnorm_tol=gnorm_tol)
 
 
-@pytest.mark.parametrize('precision,loss_tol,gnorm_tol', [('fp32', 1e-4, 2e-3), ('bf16', 2e-3, 5e-2)])
+@pytest.mark.parametrize('precision,loss_tol,gnorm_tol', [('fp32', 1e-4, 2e-3), ('bf16', 6e-4, 7e-3)])     # bf16: 3x observed (2.0e-4 / 2.1e-3)
 def test_config5_anisotropic_egd_shape(precision, loss_tol, gnorm_tol):
     """BASELINE config 5: EGD-shape 192 x 192 x 32 x 1ch volumes, ViT-B (non-cubic patch grid 12 x 12 x 2).  The reference
     cannot construct this model, so the pin is the oracle's non-cubic generalisation."""

@@ -301,7 +301,8 @@ def test_layernorm(lib, M, D):
 
 
 # --------------------------------------------------------------------------- attention
-@pytest.mark.parametrize('B,N,H,hd', [(8, 55, 12, 64), (4, 217, 16, 32), (2, 17, 3, 16), (1, 130, 2, 64), (2, 70, 2, 128)])
+@pytest.mark.parametrize('B,N,H,hd', [(8, 55, 12, 64), (4, 217, 16, 32), (2, 17, 3, 16), (1, 130, 2, 64), (2, 70, 2, 128),
+                                      (1, 433, 2, 64), (1, 1729, 2, 32)])       # patch-8 sequence lengths
 def test_sdpa(lib, B, N, H, hd):
     D = H * hd
     qkv, do = gen(B, N, 3 * D, seed=1), gen(B, N, D, seed=2)
@@ -321,6 +322,7 @@ def test_sdpa(lib, B, N, H, hd):
 
 
 @pytest.mark.parametrize('B,N,H,hd', [(8, 55, 12, 64), (4, 217, 16, 32), (2, 17, 3, 32), (1, 130, 2, 64), (1, 300, 1, 32),
+                                      (2, 433, 12, 64), (1, 1729, 16, 32),      # patch 8 (config.ini:33): encoder / decoder sequences
                                       (1, 513, 2, 32), (1, 300, 2, 64)])   # the last two exceed the one-launch backward's LDS budget
 def test_sdpa_mfma_bf16(lib, B, N, H, hd):
     D = H * hd

@@ -192,3 +192,27 @@ def test_vitb_forward_pins(tag):
     close([float(l) for l in loss], g[f'{tag}/losses'], 1e-5, 1e-7)
     np.testing.assert_array_equal(mask.sum(1).numpy(), g[f'{tag}/mask_sum'])
     close(pred[:, ::37, ::1021].numpy(), g[f'{tag}/pred_slice'], 1e-3, 1e-5)
+
+
+# --------------------------------------------------------------------------- the reference's shipped shape (patch 8) and config 4
+@pytest.mark.parametrize('fixture,cfgf,B,seeds', [
+    ('vitb_p8.npz', lambda: R.vit_base_cfg(volume_size=(96, 96, 96), patch_size=8, in_chans=4, contrastive=True), 1, (0, 1234, 4321)),
+    ('vitl_128.npz', lambda: R.vit_large_cfg(volume_size=(128, 128, 128), patch_size=16, in_chans=4, contrastive=False), 1, (2, 1234, 77))])
+def test_oracle_forward_at_p8_and_vitl_pins(fixture, cfgf, B, seeds):
+    """Forward of the oracle against the pins taken from the reference's own model at config.ini's patch_size = 8 (L = 1728,
+    433 / 1729 tokens) and at BASELINE config 4 (ViT-L/16, 128^3): loss scalars, mask sums, prediction samples."""
+    g = load_golden(fixture)
+    cfg = cfgf()
+    sd = R.init_state_dict(cfg, seed=seeds[0])
+    v1, v2 = R.synthetic_views((B, cfg.in_chans, *cfg.volume_size), seed=seeds[1])
+    n1, n2 = R.masking_noise(B, cfg.num_patches, seed=seeds[2])
+    with torch.no_grad():
+        if cfg.contrastive:
+            loss, pred, mask, p1, p2, z1, z2 = R.contr_forward(sd, v1, v2, n1, n2, cfg, 0.75, 0.01)
+            close(float(R.contrastive_loss(p1, p2, z1, z2, 0.001)), g['contr_loss'], 1e-3, 1e-9)
+            close(p1[::11, ::97].numpy(), g['p1_slice'], 2e-3, 1e-4)
+        else:
+            loss, pred, mask = R.mae_forward(sd, v1, n1, cfg, 0.75, 0.01)
+    close([float(l) for l in loss], g['losses'], 2e-5, 1e-7)
+    np.testing.assert_array_equal(mask.sum(1).numpy(), g['mask_sum'])
+    close(pred[:, ::37, ::(1021 if pred.shape[-1] > 4096 else 127)].numpy(), g['pred_slice'], 1e-3, 1e-5)

@@ -86,3 +86,24 @@ def test_mae_forward_with_a_perceptual_weight():
     assert abs(float(loss[0]) - (0.01 * float(loss[1]) + float(loss[2]) + float(loss[3]))) <= 1e-5 * abs(float(loss[0]))
     loss[0].backward()        # the term contributes no gradient and does not break the backward
     assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.requires_grad)
+
+
+def test_random_vgg_weights_are_announced():
+    """with no VGG16 weights loaded (the reference reads model/ckp-399.pth, absent here) the term is computed with
+    random convolutions — the module says so once, and stops saying it after a state dict supplied slice*.* (CPU: no launch)."""
+    import warnings
+    from vit_ae_plus_plus_amd.model.model_utils.perceptual_loss import vgg_perceptual_loss
+    m = vgg_perceptual_loss()
+    assert not m._weights_loaded
+    with pytest.warns(RuntimeWarning, match='RANDOM convolution weights'):
+        m._warn_if_random()
+    m2 = vgg_perceptual_loss()
+    m2.load_state_dict({k: v.clone() for k, v in m.state_dict().items()})
+    assert m2._weights_loaded
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        m2._warn_if_random()
+    holder = torch.nn.Module()
+    holder.perceptual_loss = vgg_perceptual_loss()
+    holder.load_state_dict({'perceptual_loss.' + k: v.clone() for k, v in m.state_dict().items()})
+    assert holder.perceptual_loss._weights_loaded

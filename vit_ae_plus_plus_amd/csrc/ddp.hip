@@ -58,7 +58,20 @@ bool bind() {
     return g.get_id && g.init_rank && g.destroy && g.all_reduce;
 }
 
-hipEvent_t next_event() {
+// Fork / join events come from a ring created at init (nothing allocates later).  Eagerly, and inside a capture, an event is
+// recorded and waited for back to back, so re-using ring entries is harmless in itself — but a captured step that needs more than
+// the whole ring is a step this file was not sized for (NEV / 2 buckets): refuse it loudly instead of wrapping silently.
+unsigned long long g_capture_id = 0;
+int g_capture_used = 0;
+
+hipEvent_t next_event(hipStream_t on, bool* ok) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    unsigned long long id = 0;
+    *ok = true;
+    if (on && hipStreamGetCaptureInfo(on, &st, &id) == hipSuccess && st == hipStreamCaptureStatusActive) {
+        if (id != g_capture_id) { g_capture_id = id; g_capture_used = 0; }
+        if (++g_capture_used > State::NEV) *ok = false;
+    }
     hipEvent_t e = g.ev[g.next];
     g.next = (g.next + 1) % State::NEV;
     return e;
@@ -99,7 +112,9 @@ extern "C" int vitae_ddp_allreduce_bucket(void* buf, long count, int is_bf16, vo
     if (!buf || count <= 0 || !comm_stream) return VITAE_ERR_INVALID_ARG;
     if (!g.comm) return VITAE_ERR_INVALID_ARG;
     hipStream_t cs = (hipStream_t)compute_stream, ns = (hipStream_t)comm_stream;
-    hipEvent_t e = next_event();
+    bool ring_ok;
+    hipEvent_t e = next_event(cs, &ring_ok);
+    if (!ring_ok) return VITAE_ERR_UNSUPPORTED_SHAPE;      // more fork / join points in one captured step than the event ring holds
     // fork: the bucket is final once everything enqueued on the compute stream so far has run
     if (hipEventRecord(e, cs) != hipSuccess || hipStreamWaitEvent(ns, e, 0) != hipSuccess) return VITAE_ERR_LAUNCH;
     if (g.all_reduce(buf, buf, (size_t)count, is_bf16 ? NCCL_BF16 : NCCL_F32, NCCL_SUM, g.comm, ns) != 0) return VITAE_ERR_LAUNCH;
@@ -108,7 +123,9 @@ extern "C" int vitae_ddp_allreduce_bucket(void* buf, long count, int is_bf16, vo
 
 extern "C" int vitae_ddp_wait(void* compute_stream, void* comm_stream) {
     if (!comm_stream || !g.events) return VITAE_ERR_INVALID_ARG;
-    hipEvent_t e = next_event();
+    bool ring_ok;
+    hipEvent_t e = next_event((hipStream_t)compute_stream, &ring_ok);
+    if (!ring_ok) return VITAE_ERR_UNSUPPORTED_SHAPE;
     // join: whatever the compute stream does next sees every bucket reduced so far
     if (hipEventRecord(e, (hipStream_t)comm_stream) != hipSuccess ||
         hipStreamWaitEvent((hipStream_t)compute_stream, e, 0) != hipSuccess)

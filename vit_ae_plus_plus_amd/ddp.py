@@ -63,13 +63,14 @@ def _spin_rate(device) -> float:
 
 
 class _StreamWork:
-    """Completion of a collective that ran on a stream of ours: waiting = the current stream waits for its event."""
+    """Completion of a collective that ran on a stream of ours: waiting = the current stream OF THE BUCKET'S DEVICE waits for
+    its event (the process's current device need not be the one the gradients live on)."""
 
-    def __init__(self, ev):
-        self.ev = ev
+    def __init__(self, ev, device=None):
+        self.ev, self.device = ev, device
 
     def wait(self):
-        torch.cuda.current_stream().wait_event(self.ev)
+        torch.cuda.current_stream(self.device).wait_event(self.ev)
 
 
 def held_back_by(busy: "torch.cuda.Stream", candidates, spin_ms: float = 4.0, rate: Optional[float] = None):
@@ -200,7 +201,7 @@ class GradBucketReducer:
                 self._model.occupy(t.numel() * t.element_size())
             ev = torch.cuda.Event()
             ev.record()
-        return _StreamWork(ev)
+        return _StreamWork(ev, self.flat.device)
 
     def wait(self, copy_back: bool = True):
         """Make the current stream (or the host, for CPU backends) wait for every launched bucket.  With a wire dtype,
@@ -232,11 +233,28 @@ class RcclBucketReducer(GradBucketReducer):
     the rendezvous only (the 128-byte RCCL id travels by ``broadcast_object_list``)."""
     native = True
 
-    def __init__(self, flat, ranges, device, comm_dtype=None, cast_ranges=None, force=False, max_bucket_elems=None):
-        super().__init__(flat, ranges, max_bucket_elems=max_bucket_elems, force=force, comm_dtype=comm_dtype, cast_ranges=cast_ranges)
+    _live = None         # weak reference to the reducer that owns the process's ONE communicator (csrc/ddp.hip keeps a single one)
+
+    def __init__(self, flat, ranges, device, comm_dtype=None, cast_ranges=None, force=False, max_bucket_elems=None, group=None):
         from ._abi import VitaeError, lib
         import ctypes
+        import weakref
+        # the C ABI knows two wire formats (vitae_ddp_allreduce_bucket: fp32 or bf16); anything else would be summed with the wrong type
+        if comm_dtype not in (None, torch.float32, torch.bfloat16):
+            raise VitaeError(f'the native gradient exchange sends fp32 or bf16, not {comm_dtype}')
+        if comm_dtype is torch.bfloat16 and flat.dtype is not torch.float32:
+            raise VitaeError('bf16 wire format needs an fp32 gradient arena')
+        # the communicator spans the WORLD (rendezvous below): a sub-group would broadcast parameters inside the group and
+        # reduce gradients over everybody
+        if group is not None and dist.is_available() and dist.is_initialized() and group is not dist.group.WORLD:
+            raise VitaeError('the native gradient exchange runs over the default (world) process group only')
+        prev = RcclBucketReducer._live() if RcclBucketReducer._live is not None else None
+        if prev is not None and prev is not self and not getattr(prev, '_closed', False):
+            raise VitaeError('a native gradient reducer (and step graphs captured with its communicator) is still alive: '
+                             'close() it (model.disable_data_parallel()) before creating another one')
+        super().__init__(flat, ranges, max_bucket_elems=max_bucket_elems, force=force, comm_dtype=comm_dtype, cast_ranges=cast_ranges)
         self._lib, self.device = lib, torch.device(device)
+        self._closed = False
         if not lib.vitae_ddp_available():
             raise VitaeError('RCCL could not be bound (librccl.so): the native gradient exchange is unavailable')
         world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
@@ -251,6 +269,14 @@ class RcclBucketReducer(GradBucketReducer):
         with torch.cuda.device(self.device):
             lib.vitae_ddp_init(ctypes.addressof(buf), world, rank)
         self._world = world
+        RcclBucketReducer._live = weakref.ref(self)
+
+    def close(self):
+        """Give the process's communicator back (graphs captured with this reducer must not be replayed afterwards)."""
+        if not self._closed:
+            self._closed = True
+            self.pending.clear()
+            self._lib.vitae_ddp_destroy()
 
     @property
     def world_size(self) -> int:

@@ -46,6 +46,19 @@ class vgg_perceptual_loss(nn.Module):
             getattr(self, f'slice{s}').add_module(str(idx), conv)
         self._packed = None
         self.chunk_bytes = 2 << 30          # im2col scratch budget per chunk of images
+        # The reference fills this stack from model/ckp-399.pth (perceptual_loss.py:20-23) or torchvision's ImageNet weights
+        # (use_imagenet) — neither ships with it nor with this image.  Until load_state_dict() has supplied `slice*.*`, the
+        # convolutions hold torch's default random initialisation and the term is a number without meaning.
+        self._weights_loaded = False
+        self._warned = False
+        self.register_load_state_dict_post_hook(self._note_loaded)
+
+    @staticmethod
+    def _note_loaded(module, incompatible):
+        import re
+        mine = [k for k in incompatible.missing_keys if re.search(r'(^|\.)slice\d\.\d+\.(weight|bias)$', k)]
+        module._weights_loaded = not mine
+        module._packed = None
 
     def convs(self):
         return [(s, idx, getattr(getattr(self, f'slice{s}'), str(idx))) for s, idx, _, _ in _VGG]
@@ -70,7 +83,19 @@ class vgg_perceptual_loss(nn.Module):
         return out
 
     @torch.no_grad()
+    def _warn_if_random(self):
+        if not self._weights_loaded and not self._warned:
+            import warnings
+            self._warned = True
+            warnings.warn('vgg_perceptual_loss: no VGG16 weights have been loaded (the reference reads model/ckp-399.pth'
+                          + (' / torchvision ImageNet weights, use_imagenet=True' if self.use_imagenet else '') +
+                          '): the perceptual term is computed with RANDOM convolution weights and is folded into the reported '
+                          'loss as is; load a reference-format state dict (keys perceptual_loss.slice*.*) first.  Note that a '
+                          'non-zero perceptual_weight also takes the model off the fused (captured) step: the generic route runs.',
+                          RuntimeWarning, stacklevel=3)
+
     def forward(self, X1, X2):
+        self._warn_if_random()
         """mean over channels of mean over the four slices of MSE(features(X1 slices), features(X2 slices)); X: [B, C, Z, H, W]"""
         if not X1.is_cuda:
             raise VitaeError('vgg_perceptual_loss: MI355X only (no CPU fallback; the CPU restatement is oracle/percep_ref.py)')

@@ -550,12 +550,13 @@ class MaskedAutoencoderViT(nn.Module):
         from .. import ddp
         if native is None:
             native = os.environ.get('VITAE_DDP_NATIVE', '0') == '1'
+        self.disable_data_parallel()        # a previous reducer's communicator / captured graphs go first
         if native and (ddp.is_distributed() or force):
             eng = self._ensure_engine(torch.device(device) if device is not None else next(self.parameters()).device)
             ddp.broadcast_parameters(eng, 0, group)
             self._set_exchange_buckets(eng, enc_chunks)
             self._reducer = ddp.RcclBucketReducer(eng.grads, ddp.engine_bucket_ranges(eng), eng.device, comm_dtype=comm_dtype,
-                                                  force=force)
+                                                  force=force, group=group)
             wired = self._reducer.wire is not None and self._reducer.active
             if wired:
                 eng.grads_wire16 = self._reducer.wire
@@ -587,6 +588,18 @@ class MaskedAutoencoderViT(nn.Module):
         eng.grads_wire16 = self._reducer.wire if (self._reducer.wire is not None and self._reducer.active) else None
         self._runners.clear()
         return self._reducer
+
+    def disable_data_parallel(self):
+        """Drop the gradient exchange (and every step graph captured with it); a native reducer gives RCCL's communicator back."""
+        red = self._reducer
+        if red is not None:
+            self._runners.clear()
+            if getattr(red, 'native', False):
+                torch.cuda.synchronize()
+                red.close()
+        self._reducer = None
+        if self._engine is not None:
+            self._engine.grads_wire16 = None
 
     @property
     def engine(self) -> Optional[HipMAEEngine]:

@@ -183,6 +183,9 @@ def adopt(optimizer, model) -> Optional[object]:
         return optimizer
     if type(optimizer) is torch.optim.AdamW and _adoptable_weight_decay(optimizer, model) is not None:
         if getattr(optimizer, 'engine', None) is not None:      # adopted for an engine that no longer exists
+            # the per-parameter 'step' tensors are only refreshed by the state_dict pre-hook: publish the old engine's count
+            # now, so that the new adopter resumes from it (else the bias corrections restart next to warmed-up moments)
+            optimizer._vitae_adopter._publish_step(optimizer)
             optimizer.step = optimizer._vitae_adopter._orig_step
         optimizer._vitae_adopter = _AdoptedAdamW(optimizer, model)
         return optimizer
