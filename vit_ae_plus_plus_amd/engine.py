@@ -567,7 +567,7 @@ class HipMAEEngine:
             while s > 1 and lib.vitae_gemm_glds_ws_floats(M, N, s) > self.ws16.numel():
                 s -= 1
             self._split_cache[key] = s
-        t = self._timed(2.0 * M * N * K, 'glds' if N < 8192 else 'glds_wide')   # wide = the 64x128-tile instantiation
+        t = self._timed(2.0 * M * N * K, self._gemm_tag(1, 1, M, N, K, s, 'glds' if N < 8192 else 'glds_wide'))   # wide = the 64x128-tile instantiation
         if rowstats is not None:
             lib.vitae_gemm_glds_stats(1, 1, _ptr(x16), K, self._w16(w), K, _ptr(y), N, _ptr(y16), N, M, N, K, _ptr(bias), _ptr(res), N,
                                       epi, _ptr(aux), N, 0, s, self.ws16.data_ptr(), None, _ptr(rowstats), self.stream)
@@ -576,6 +576,18 @@ class HipMAEEngine:
                                 epi, _ptr(aux), N, 0, s, self.ws16.data_ptr(), None, self.stream)
         if t is not None:
             t.record()
+
+    def _gemm_tag(self, akc, bkc, M, N, K, split, default):
+        """Instrumentation only: which kernel family serves this problem (csrc/gemm_glds.hip's planner)."""
+        if self.gemm_timer is None:
+            return default
+        key = ('tag', akc, bkc, M, N, K, split)
+        tag = self._split_cache.get(key)
+        if tag is None:
+            c = lib.vitae_gemm_glds_bt_choice(akc, bkc, M, N, K)
+            tag = default if (c < 0 or lib.vitae_gemm_glds_pick_split_k(M, N, K) != split) else ('bt256' if c == 0 else 'bt128')
+            self._split_cache[key] = tag
+        return tag
 
     def _g16_fwd_ln(self, x, stats, pre_ln, w, bias, M, N, K, y16_ln, mean, rstd, y=None, y16=None, epi=EPI_NONE, aux=None):
         """y / y16 = epi(LayerNorm(x) @ W16^T + b) in one launch (x fp32 [M, K] with row statistics ``stats``); the bf16 LayerNorm
@@ -630,7 +642,10 @@ class HipMAEEngine:
             while s > 1 and lib.vitae_gemm_glds_ws_floats(M, K, s) > self.ws16.numel():
                 s -= 1
             self._split_cache[key] = s
-        t = self._timed(4.0 * M * N * K, 'glds_pair' if N < 8192 else 'glds_pair_wide')
+        tag = 'glds_pair' if N < 8192 else 'glds_pair_wide'
+        if self.gemm_timer is not None and (lib.vitae_gemm_glds_bt_choice(1, 0, M, K, N) >= 0 or lib.vitae_gemm_glds_bt_choice(0, 0, N, K, Mpad) >= 0):
+            tag = 'bt_bwd'      # the halves leave as two launches, at least one of them on a big tile
+        t = self._timed(4.0 * M * N * K, tag)
         lib.vitae_linear_bwd_pair_glds(_ptr(dy16), self._w16(w), _ptr(x16), _ptr(dx), _ptr(dx16), _ptr(dw), self._wire_of(dw), M, Mpad,
                                        N, K,
                                        epi, _ptr(aux), _ptr(dx_colsum), _ptr(dy_colsum), int(dx_accumulate), int(self._accum), s,
