@@ -51,6 +51,12 @@ extern "C" {
 #define VITAE_HP_G_CONTR 9   /* d total / d (mean-cosine term), includes contr_weight */
 #define VITAE_HP_EDGE_W 10   /* edge_map_weight (model/vit_autoenc.py:225) */
 #define VITAE_HP_CONTR_W 11  /* args.contr_weight (utils/train_one_epoch.py:114) */
+#define VITAE_HP_HOST_COUNT 13 /* slots [0, 13) are the HOST's (uploaded every step); the rest of the block is device-owned state */
+#define VITAE_HP_STEP 13     /* number of AdamW steps APPLIED so far (a float holding an integer): bumped on the device by the last
+                              * AdamW launch of a step unless the gradient norm was not finite (GradScaler.step's skip).  With
+                              * hp[BC1] == 0 the AdamW kernels derive the bias corrections 1 - beta^t from t = hp[STEP] + 1, so a
+                              * skipped step never advances them and the host needs no late correction */
+#define VITAE_HP_NOISE_KEEP 12 /* host slot: != 0 = the masking noise buffer was filled by the caller (injected noise): vitae_step_prologue leaves it alone */
 #define VITAE_HP_COUNT 16
 
 /* device-resident scalar accumulators `acc` (double[VITAE_ACC_COUNT]); caller zeroes them per step */
@@ -58,6 +64,8 @@ extern "C" {
 #define VITAE_ACC_EDGE 1
 #define VITAE_ACC_COS 2
 #define VITAE_ACC_GRADSQ 3
+#define VITAE_ACC_TICKET_A 4  /* first 4 bytes: workgroup arrival counter of vitae_opt_tail's norm pass (zero after the per-step zeroing) */
+#define VITAE_ACC_TICKET_B 5  /* ... of its AdamW pass */
 #define VITAE_ACC_NONFINITE 7 /* the first 4 bytes of this slot are a FLOAT: 0 after the per-step zeroing, NaN once the loss
                                 * backward produced a non-finite gradient (the early form of GradScaler.step's inf check:
                                 * a `grad_norm` pointer for vitae_adamw_step before the global norm exists) */
@@ -403,6 +411,25 @@ int vitae_adamw_step(float* params, const float* grads, float* exp_avg, float* e
 int vitae_grad_sqnorm_bf16(const void* grads_bf16, long n, double* acc, float* norm_out, void* stream);
 int vitae_adamw_step_bf16g(float* params, const void* grads_bf16, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
                            long n, const float* hp, const float* grad_norm, float weight_decay, void* stream);
+/* hp[VITAE_HP_STEP] += 1 unless grad_norm[0] is not finite: the end of an optimiser step issued as separate vitae_adamw_step calls */
+int vitae_opt_count_bump(float* hp, const float* grad_norm, void* stream);
+/* The tail of one optimisation step in TWO launches (was: norm pass, finalisation, two AdamW launches): the last n_decay +
+ * n_plain elements of the arena — tokens (weight decay) then vectors (none), whose gradients are only final when the whole
+ * backward is — (1) add their squares to acc[VITAE_ACC_GRADSQ]; the last workgroup to arrive (acc[VITAE_ACC_TICKET_A]) writes
+ * norm_out[0] = sqrt(acc[GRADSQ]): the global gradient norm of utils/misc.py:265-266; (2) AdamW over both segments, skipped
+ * when that norm is not finite; the last workgroup (acc[VITAE_ACC_TICKET_B]) bumps hp[VITAE_HP_STEP].  grads: fp32, or bf16 when
+ * grads_bf16 != 0 (the wire copy of a bf16 gradient exchange).  All pointers at the first of the n_decay elements. */
+int vitae_opt_tail(float* params, const void* grads, int grads_bf16, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
+                   long n_decay, long n_plain, float* hp, double* acc, float* norm_out, float weight_decay, void* stream);
+/* The head of one optimisation step as ONE launch inside the captured step (was, between two graph replays: torch's uniform_,
+ * a host-to-device copy of hp, and two zeroing launches): hp[0 .. VITAE_HP_HOST_COUNT) <- hp_ring[(*step_seq) % ring_slots] (a
+ * pinned host ring the caller filled for this step), noise[0 .. n_noise) <- U[0, 1) from Philox4x32-10 keyed by (seed, *step_seq)
+ * unless the ring slot says VITAE_HP_NOISE_KEEP, acc[0 .. VITAE_ACC_COUNT) <- 0, zero_ptr[0 .. zero_bytes) <- 0 (the token / vector
+ * gradient segment; may be NULL).  *step_seq is advanced by vitae_step_epilogue (the last launch of the step), never here: every
+ * workgroup of this launch reads it. */
+int vitae_step_prologue(float* hp, const float* hp_ring, int ring_slots, const long long* step_seq, float* noise, long n_noise,
+                        long long seed, double* acc, void* zero_ptr, long zero_bytes, void* stream);
+int vitae_step_epilogue(long long* step_seq, void* stream);
 
 #ifdef __cplusplus
 }

@@ -51,7 +51,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     float weight_decay) {
     if (gnorm) { const float gn = gnorm[0]; if (!(gn == gn) || fabsf(gn) == INFINITY) return; }
     const float lr = hp[VITAE_HP_LR], b1 = hp[VITAE_HP_BETA1], b2 = hp[VITAE_HP_BETA2], eps = hp[VITAE_HP_EPS];
-    const float bc1 = hp[VITAE_HP_BC1], sq_bc2 = sqrtf(hp[VITAE_HP_BC2]);
+    float bc1 = hp[VITAE_HP_BC1], bc2 = hp[VITAE_HP_BC2];
+    if (bc1 == 0.f) {            // the host left the bias corrections to the device: t = applied steps + 1 (vitae_hip.h VITAE_HP_STEP)
+        const float t = hp[VITAE_HP_STEP] + 1.f;
+        bc1 = 1.f - powf(b1, t);
+        bc2 = 1.f - powf(b2, t);
+    }
+    const float sq_bc2 = sqrtf(bc2);
     const float gs = hp[VITAE_HP_GRAD_MUL];
     const float decay = 1.0f - lr * weight_decay, step = lr / bc1;
     const long n4 = n / 4;
@@ -111,6 +117,133 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
             if (shadow) shadow[i] = (__bf16)pp;
         }
     }
+}
+
+__global__ void opt_count_bump_kernel(float* __restrict__ hp, const float* __restrict__ gnorm) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const float gn = gnorm ? gnorm[0] : 0.f;
+        if (gn == gn && fabsf(gn) != INFINITY) hp[VITAE_HP_STEP] += 1.f;
+    }
+}
+
+// ---- the tail of a step: tokens + vectors (0.2 M elements) in two launches
+template <typename G>
+__global__ __launch_bounds__(256) void opt_tail_norm_kernel(const G* __restrict__ g, long n, double* __restrict__ acc, float* __restrict__ out) {
+    __shared__ float red[4];
+    __shared__ int last;
+    float s = 0.f;
+    const long n4 = n / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 v = grad4<G>(g, i);
+        s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    if (blockIdx.x == 0) for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) s += (float)g[i] * (float)g[i];
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(acc + VITAE_ACC_GRADSQ, (double)s);
+        __threadfence();
+        last = atomicAdd(reinterpret_cast<int*>(acc + VITAE_ACC_TICKET_A), 1) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        // every other workgroup's double atomic is ordered before its ticket: read the total through the atomic unit too
+        const double tot = atomicAdd(acc + VITAE_ACC_GRADSQ, 0.0);
+        out[0] = (float)sqrt(tot);
+    }
+}
+
+template <typename G>
+__global__ __launch_bounds__(256) void opt_tail_adamw_kernel(float* __restrict__ p, const G* __restrict__ g, float* __restrict__ m,
+                                                             float* __restrict__ v, __bf16* __restrict__ shadow, long n_decay, long n_plain,
+                                                             float* __restrict__ hp, double* __restrict__ acc,
+                                                             const float* __restrict__ gnorm, float weight_decay) {
+    const float gn = gnorm[0];
+    const bool finite = gn == gn && fabsf(gn) != INFINITY;
+    if (finite) {
+        const float lr = hp[VITAE_HP_LR], b1 = hp[VITAE_HP_BETA1], b2 = hp[VITAE_HP_BETA2], eps = hp[VITAE_HP_EPS];
+        float bc1 = hp[VITAE_HP_BC1], bc2 = hp[VITAE_HP_BC2];
+        if (bc1 == 0.f) {
+            const float t = hp[VITAE_HP_STEP] + 1.f;
+            bc1 = 1.f - powf(b1, t);
+            bc2 = 1.f - powf(b2, t);
+        }
+        const float sq_bc2 = sqrtf(bc2), gs = hp[VITAE_HP_GRAD_MUL], step = lr / bc1;
+        const long n = n_decay + n_plain;                  // both segment lengths are multiples of 4 (arena alignment)
+        for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+            const float decay = 1.0f - lr * (i < n_decay ? weight_decay : 0.f);
+            f32x4 pp = *reinterpret_cast<f32x4*>(p + i), mm = *reinterpret_cast<f32x4*>(m + i), vv = *reinterpret_cast<f32x4*>(v + i);
+            const f32x4 gg = grad4<G>(g, i / 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float ge = gg[e] * gs;
+                pp[e] *= decay;
+                mm[e] = mm[e] + (1.f - b1) * (ge - mm[e]);
+                vv[e] = b2 * vv[e] + (1.f - b2) * ge * ge;
+                pp[e] -= step * (mm[e] / (sqrtf(vv[e]) / sq_bc2 + eps));
+            }
+            *reinterpret_cast<f32x4*>(p + i) = pp;
+            *reinterpret_cast<f32x4*>(m + i) = mm;
+            *reinterpret_cast<f32x4*>(v + i) = vv;
+            if (shadow) {
+                bf16x4 sh;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sh[e] = (__bf16)pp[e];
+                *reinterpret_cast<bf16x4*>(shadow + i) = sh;
+            }
+        }
+    }
+    // the LAST workgroup to get here counts the step (every workgroup has read hp[STEP] by then)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const bool last = atomicAdd(reinterpret_cast<int*>(acc + VITAE_ACC_TICKET_B), 1) == (int)gridDim.x - 1;
+        if (last && finite) hp[VITAE_HP_STEP] += 1.f;
+    }
+}
+
+// ---- the head of a step: hp upload from the pinned ring, masking noise, zeroing — one launch inside the captured step
+__device__ __forceinline__ void philox4x32_10(unsigned k0, unsigned k1, unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__global__ __launch_bounds__(256) void step_prologue_kernel(float* __restrict__ hp, const float* __restrict__ ring, int slots,
+                                                            const long long* __restrict__ seq, float* __restrict__ noise, long n_noise,
+                                                            unsigned long long seed, double* __restrict__ acc,
+                                                            unsigned int* __restrict__ zp, long zwords) {
+    const long long s = *seq;
+    const float* src = ring + (s % slots) * VITAE_HP_COUNT;      // pinned host memory, read over the link (64 bytes)
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < VITAE_HP_HOST_COUNT) hp[threadIdx.x] = src[threadIdx.x];
+        if (threadIdx.x >= 64 && threadIdx.x < 64 + VITAE_ACC_COUNT) acc[threadIdx.x - 64] = 0.0;
+    }
+    const long tid = (long)blockIdx.x * 256 + threadIdx.x, nth = (long)gridDim.x * 256;
+    if (noise && src[VITAE_HP_NOISE_KEEP] == 0.f) {
+        // four uniforms per Philox call: counter = (group index, step sequence number), key = seed; [0, 1) with 24 random bits
+        for (long i = tid; i * 4 < n_noise; i += nth) {
+            unsigned r[4];
+            philox4x32_10((unsigned)seed, (unsigned)(seed >> 32), (unsigned)i, (unsigned)(i >> 32), (unsigned)s, (unsigned)(s >> 32), r);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (i * 4 + e < n_noise) noise[i * 4 + e] = (float)(r[e] >> 8) * (1.0f / 16777216.0f);
+        }
+    }
+    if (zp) {
+        const long n4 = zwords / 4;
+        u32x4_t* z4 = reinterpret_cast<u32x4_t*>(zp);
+        const u32x4_t z = {0u, 0u, 0u, 0u};
+        for (long i = tid; i < n4; i += nth) z4[i] = z;
+        if (blockIdx.x == 0) for (long i = n4 * 4 + threadIdx.x; i < zwords; i += 256) zp[i] = 0u;
+    }
+}
+
+__global__ void step_epilogue_kernel(long long* __restrict__ seq) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *seq += 1;
 }
 
 }  // namespace
@@ -182,6 +315,57 @@ extern "C" int vitae_adamw_step_bf16g(float* params, const void* grads_bf16, flo
                                       float weight_decay, void* stream) {
     return adamw_launch<__bf16>(params, reinterpret_cast<const __bf16*>(grads_bf16), exp_avg, exp_avg_sq, shadow_bf16, n, hp,
                                 grad_norm, weight_decay, stream);
+}
+
+extern "C" int vitae_opt_count_bump(float* hp, const float* grad_norm, void* stream) {
+    if (!hp) return VITAE_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(opt_count_bump_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, hp, grad_norm);
+    return vitae_launch_status();
+}
+
+extern "C" int vitae_opt_tail(float* params, const void* grads, int grads_bf16, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
+                              long n_decay, long n_plain, float* hp, double* acc, float* norm_out, float weight_decay, void* stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !hp || !acc || !norm_out || n_decay < 0 || n_plain < 0 || n_decay + n_plain <= 0)
+        return VITAE_ERR_INVALID_ARG;
+    if ((n_decay & 3) || (n_plain & 3) || (((uintptr_t)params | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq | (uintptr_t)grads) & 15) ||
+        ((uintptr_t)shadow_bf16 & 7))
+        return VITAE_ERR_UNSUPPORTED_SHAPE;
+    const long n = n_decay + n_plain;
+    long blocks = (n / 4 + 255) / 256;
+    if (blocks > 256) blocks = 256;
+    hipStream_t st = (hipStream_t)stream;
+    if (grads_bf16) {
+        const __bf16* g = reinterpret_cast<const __bf16*>(grads);
+        hipLaunchKernelGGL(opt_tail_norm_kernel<__bf16>, dim3((int)blocks), dim3(256), 0, st, g, n, acc, norm_out);
+        hipLaunchKernelGGL(opt_tail_adamw_kernel<__bf16>, dim3((int)blocks), dim3(256), 0, st, params, g, exp_avg, exp_avg_sq,
+                           reinterpret_cast<__bf16*>(shadow_bf16), n_decay, n_plain, hp, acc, norm_out, weight_decay);
+    } else {
+        const float* g = reinterpret_cast<const float*>(grads);
+        hipLaunchKernelGGL(opt_tail_norm_kernel<float>, dim3((int)blocks), dim3(256), 0, st, g, n, acc, norm_out);
+        hipLaunchKernelGGL(opt_tail_adamw_kernel<float>, dim3((int)blocks), dim3(256), 0, st, params, g, exp_avg, exp_avg_sq,
+                           reinterpret_cast<__bf16*>(shadow_bf16), n_decay, n_plain, hp, acc, norm_out, weight_decay);
+    }
+    return vitae_launch_status();
+}
+
+extern "C" int vitae_step_prologue(float* hp, const float* hp_ring, int ring_slots, const long long* step_seq, float* noise, long n_noise,
+                                   long long seed, double* acc, void* zero_ptr, long zero_bytes, void* stream) {
+    if (!hp || !hp_ring || ring_slots <= 0 || !step_seq || !acc || n_noise < 0 || zero_bytes < 0 || (zero_bytes & 3) ||
+        ((uintptr_t)zero_ptr & 15))
+        return VITAE_ERR_INVALID_ARG;
+    const long work = (n_noise / 4 > zero_bytes / 16 ? n_noise / 4 : zero_bytes / 16);
+    long blocks = (work + 255) / 256;
+    if (blocks > 512) blocks = 512;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(step_prologue_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, hp, hp_ring, ring_slots, step_seq,
+                       noise, n_noise, (unsigned long long)seed, acc, reinterpret_cast<unsigned int*>(zero_ptr), zero_bytes / 4);
+    return vitae_launch_status();
+}
+
+extern "C" int vitae_step_epilogue(long long* step_seq, void* stream) {
+    if (!step_seq) return VITAE_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(step_epilogue_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_seq);
+    return vitae_launch_status();
 }
 
 namespace {

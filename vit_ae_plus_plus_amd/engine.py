@@ -168,8 +168,16 @@ class HipMAEEngine:
         # ring of pinned staging buffers: the host may run a few steps ahead of the stream, so the
         # buffer an in-flight async copy reads from must not be rewritten by the next step
         self.hp_vals = [0.0] * _C['VITAE_HP_COUNT']
-        self.hp_ring = [torch.zeros(_C['VITAE_HP_COUNT'], dtype=torch.float32).pin_memory() for _ in range(16)]
-        self.hp_slot = 0
+        # Host -> device channel of the per-step scalars (lr, betas, loss multipliers, "keep the injected masking noise"): a
+        # pinned ring of 16 blocks.  The fused step fetches block (step_seq mod 16) with its first launch (vitae_step_prologue,
+        # inside the captured graph) — step_seq lives on the device and is advanced by the step's last launch, the host counts
+        # the steps it has launched (step_seq_host): no host-to-device copy sits between two graph replays.  Everything else
+        # that reads hp (generic autograd route, stand-alone forward) gets it by ``flush_hparams`` (an ordinary copy).
+        self.hp_ring = torch.zeros(16, _C['VITAE_HP_COUNT'], dtype=torch.float32).pin_memory()
+        self.step_seq_host = 0
+        self.step_seq = torch.zeros(1, dtype=torch.int64, device=device)
+        self._hp_dirty = True
+        self.noise_seed = int(torch.initial_seed()) & ((1 << 63) - 1)
         self.hp = torch.zeros(_C['VITAE_HP_COUNT'], **f32)
         self.acc = torch.zeros(_C['VITAE_ACC_COUNT'], dtype=torch.float64, device=device)
         self.losses = torch.zeros(8, **f32)   # [loss, raw_edge, recon, percep, contr, grad_norm, -, -]
@@ -197,8 +205,6 @@ class HipMAEEngine:
         self.oside = torch.cuda.Stream(device=device)  # per-bucket grad-norm + AdamW beside the rest of the backward
         self.overlap_optimizer = os.environ.get('VITAE_OPT_IN_BACKWARD', '1') != '0'
         self._opt_pending = False
-        self._main_done = None       # split step: event behind the forward + backward of the latest step (workspace free for a prologue)
-        self._prologue_owner = None  # split step: (runner, graph key) whose input prologue is in the workspace / in flight
         self._pred_pending = False
         self._pred_joined = False   # the predictor branch was joined by backward_dec(part='top')
         self.overlap_wgrad = True
@@ -266,12 +272,53 @@ class HipMAEEngine:
 
     # ------------------------------------------------------------------ hyper-parameters
     def set_hparams(self, **kw):
+        """Host values of hp[0 .. VITAE_HP_HOST_COUNT): published in the ring block of the NEXT step to be launched."""
         for k, v in kw.items():
             self.hp_vals[HP[k.upper()]] = float(v)
-        host = self.hp_ring[self.hp_slot % len(self.hp_ring)]
-        self.hp_slot += 1
-        host.copy_(torch.tensor(self.hp_vals, dtype=torch.float32))
-        self.hp.copy_(host, non_blocking=True)
+        self.hp_ring[self.step_seq_host % self.hp_ring.shape[0]].copy_(torch.tensor(self.hp_vals, dtype=torch.float32))
+        self._hp_dirty = True
+
+    def flush_hparams(self):
+        """For launches outside the fused step: the host slots of the device block by an ordinary (stream-ordered) copy."""
+        if self._hp_dirty:
+            n = _C['VITAE_HP_HOST_COUNT']
+            stage = self.hp_ring[self.step_seq_host % self.hp_ring.shape[0]]
+            self.hp[:n].copy_(stage[:n], non_blocking=True)
+            self._hp_dirty = False
+
+    def step_prologue(self, noise: torch.Tensor, accumulate: bool):
+        """First launch of a fused step (captured with it): hp <- ring, masking noise, acc <- 0, token / vector gradients <- 0."""
+        self._accum = bool(accumulate)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        n = self.n_total - self.tok_off
+        lib.vitae_step_prologue(self.hp.data_ptr(), self.hp_ring.data_ptr(), self.hp_ring.shape[0], self.step_seq.data_ptr(),
+                                noise.data_ptr(), noise.numel(), self.noise_seed, self.acc.data_ptr(),
+                                None if accumulate else self.grads.data_ptr() + self.tok_off * 4, 0 if accumulate else n * 4, st)
+        self._hp_dirty = False
+        self._head_done = True
+
+    def step_epilogue(self):
+        """Last launch of a fused step: the device's step sequence number moves on (the host's: ``end_step_host``)."""
+        lib.vitae_step_epilogue(self.step_seq.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream)
+
+    def end_step_host(self):
+        """Called once per LAUNCHED fused step (graph replay or eager): the next step reads the next ring block, which starts out
+        as a copy of the current values."""
+        self.step_seq_host += 1
+        self.hp_ring[self.step_seq_host % self.hp_ring.shape[0]].copy_(torch.tensor(self.hp_vals, dtype=torch.float32))
+
+    _head_done = False
+
+    def read_opt_step(self) -> int:
+        """Number of AdamW steps actually applied (device-side count: a step skipped for a non-finite gradient norm is not in it)."""
+        if self.opt_state is None:
+            return 0
+        self.opt_step = int(round(float(self.hp[_C['VITAE_HP_STEP']].item())))
+        return self.opt_step
+
+    def write_opt_step(self, step: int):
+        self.opt_step = int(step)
+        self.hp[_C['VITAE_HP_STEP']] = float(step)
 
     # ------------------------------------------------------------------ workspace
     _WS_ATTRS = ('B', 'keep', 'Be', 'Ne', 'Nd', 'Me', 'Md', 'Mpe', 'Mpd', 'Mpt', 'Mpl', 'R', 'mask_sum', 'edge_count', 'buf')
@@ -969,32 +1016,10 @@ class HipMAEEngine:
         self._ln_bwd(dy, x_in, pre + 'norm1.', b[q + 'mean1'], b[q + 'rstd1'], dx, M, d, 1)
 
     # ------------------------------------------------------------------ forward
-    def input_prologue(self, view1: torch.Tensor, view2: Optional[torch.Tensor], noise: torch.Tensor, mask_ratio: float):
-        """The part of a step that depends on the BATCH only, not on the weights: random masking, kept-patch gather (both views),
-        blur + Sobel of the target volume — one chain on the current stream.  ``forward(..., prologue_done=True)`` then starts at the
-        patch-embedding GEMM.  The split step (``_StepRunner``) replays this for batch i + 1 beside the optimiser tail of step i."""
-        cfg = self.cfg
-        B = view1.shape[0]
-        self._alloc(B, mask_ratio)
-        st, b = torch.cuda.current_stream(self.device).cuda_stream, self.buf
-        Be, keep, L = self.Be, self.keep, cfg.num_patches
-        C, (Lz, Hy, Wx), ps = cfg.in_chans, cfg.volume_size, cfg.patch_size
-        lib.vitae_random_masking(_ptr(noise), _ptr(b['ids_shuffle']), _ptr(b['ids_restore']), _ptr(b['mask']),
-                                 _ptr(b['ids_restore64']), Be, L, keep, st)
-        pat, pat16 = (None, b['patches_16']) if self.act16 else (b['patches'], None)
-        if cfg.contrastive:
-            lib.vitae_gather_patches_2views(_ptr(view1), _ptr(view2), _ptr(b['ids_shuffle']), _ptr(pat), _ptr(pat16), B, C, Lz, Hy, Wx,
-                                            ps, keep, st)
-        else:
-            lib.vitae_gather_patches(_ptr(view1), _ptr(b['ids_shuffle']), _ptr(pat), _ptr(pat16), B, C, Lz, Hy, Wx, ps, keep, st)
-        lib.vitae_gauss_blur_fwd(_ptr(view1), _ptr(b['blur_tmp']), _ptr(b['blurred']), self._taps_c, len(self.taps), B * C, Lz, Hy, Wx, st)
-        lib.vitae_sobel_edge_fwd(_ptr(b['blurred']), _ptr(b['edge_t']), None, None, B, C, Lz, Hy, Wx, st)
-
     def forward(self, view1: torch.Tensor, view2: Optional[torch.Tensor], noise: torch.Tensor, mask_ratio: float,
-                training: bool = True, defer_predictor_join: bool = False, defer_finalize: bool = False, prologue_done: bool = False):
+                training: bool = True, defer_predictor_join: bool = False, defer_finalize: bool = False):
         """Everything up to the four loss scalars and (contrastive) p1/p2.  ``noise`` is [Be, L]
-        (view-1 rows first), the torch.rand of vit_autoenc.py:139.  ``prologue_done``: ``input_prologue`` already ran for this
-        batch (masking, gather and the target's edge map are in the workspace)."""
+        (view-1 rows first), the torch.rand of vit_autoenc.py:139."""
         cfg = self.cfg
         B = view1.shape[0]
         self._alloc(B, mask_ratio)
@@ -1013,7 +1038,11 @@ class HipMAEEngine:
             raise VitaeError(f'noise must be contiguous fp32 [{Be},{L}]')
         self.view1 = view1
         self.refresh_shadow()
-        lib.vitae_memset_zero(self.acc.data_ptr(), self.acc.numel() * 8, st)
+        if self._head_done:
+            self._head_done = False          # vitae_step_prologue zeroed acc and fetched hp for this step
+        else:
+            self.flush_hparams()
+            lib.vitae_memset_zero(self.acc.data_ptr(), self.acc.numel() * 8, st)
         # --- target branch of the edge loss (blur + Sobel of the input, vit_autoenc.py:221-223) depends on the
         # data only: it runs on a side stream underneath the encoder/decoder and is joined before the edge MSE
         main = torch.cuda.current_stream(self.device)
@@ -1031,7 +1060,7 @@ class HipMAEEngine:
 
         # where the branch forks off the main chain: 'start' (beside masking / gather / patch embedding), 'embed' (after the
         # patch-embedding GEMM, beside the first encoder blocks), 'decoder' (beside the first decoder blocks)
-        fork = 'done' if prologue_done else self.target_fork
+        fork = self.target_fork
         # 'start1' (experiment, measured WORSE): the same fork point, but the branch is ENQUEUED after the main chain's next kernel.
         # In a captured graph the child node created first keeps the parent's hardware queue and the other one pays a ~7-12 us
         # cross-queue hop; created second, the main chain does stay on its queue (and the patch-embedding GEMM runs 49 instead of
@@ -1046,16 +1075,15 @@ class HipMAEEngine:
         # --- masking, kept-patch gather, patch embedding, sequence assembly
         a16 = self.act16
         pat, pat16 = (None, b['patches_16']) if a16 else (b['patches'], None)
-        if not prologue_done:
-            lib.vitae_random_masking(_ptr(noise), _ptr(b['ids_shuffle']), _ptr(b['ids_restore']), _ptr(b['mask']),
-                                     _ptr(b['ids_restore64']), Be, L, keep, st)
-            if fork_ev is not None:
-                target_branch(after=fork_ev)
-            if cfg.contrastive:
-                lib.vitae_gather_patches_2views(_ptr(view1), _ptr(view2), _ptr(b['ids_shuffle']), _ptr(pat), _ptr(pat16), B, C, Lz, Hy, Wx,
-                                                ps, keep, st)
-            else:
-                lib.vitae_gather_patches(_ptr(view1), _ptr(b['ids_shuffle']), _ptr(pat), _ptr(pat16), B, C, Lz, Hy, Wx, ps, keep, st)
+        lib.vitae_random_masking(_ptr(noise), _ptr(b['ids_shuffle']), _ptr(b['ids_restore']), _ptr(b['mask']),
+                                 _ptr(b['ids_restore64']), Be, L, keep, st)
+        if fork_ev is not None:
+            target_branch(after=fork_ev)
+        if cfg.contrastive:
+            lib.vitae_gather_patches_2views(_ptr(view1), _ptr(view2), _ptr(b['ids_shuffle']), _ptr(pat), _ptr(pat16), B, C, Lz, Hy, Wx,
+                                            ps, keep, st)
+        else:
+            lib.vitae_gather_patches(_ptr(view1), _ptr(b['ids_shuffle']), _ptr(pat), _ptr(pat16), B, C, Lz, Hy, Wx, ps, keep, st)
         if a16:
             self._g16_fwd(pat16, p['patch_embed.proj.weight'], p['patch_embed.proj.bias'], Be * keep, D, P, y=b['tok'])
         else:
@@ -1128,8 +1156,7 @@ class HipMAEEngine:
             self._lin_fwd(b['dn'], p['decoder_pred.weight'], p['decoder_pred.bias'], b['predfull'], Md, P, Dd)
         # --- loss chain on pred = predfull[:, 1:, :]
         pred_ptr, pbs = b['predfull'].data_ptr() + P * 4, Nd * P
-        if not prologue_done:
-            torch.cuda.current_stream(self.device).wait_stream(self.side)   # edge map of the blurred target is ready
+        torch.cuda.current_stream(self.device).wait_stream(self.side)   # edge map of the blurred target is ready
         lib.vitae_loss_fwd_fused(pred_ptr, pbs, _ptr(view1), _ptr(b['mask']), _ptr(b['edge_t']), _ptr(b['pred_vol']),
                                  _ptr(b['edge_p']), _ptr(self.acc), B, C, Lz, Hy, Wx, ps, st)
         if not defer_finalize:
@@ -1369,19 +1396,20 @@ class HipMAEEngine:
     def init_optimizer(self, weight_decay: float = 0.05, betas=(0.9, 0.95), eps: float = 1e-8):
         self.opt_state = {'exp_avg': torch.zeros_like(self.params), 'exp_avg_sq': torch.zeros_like(self.params)}
         self.weight_decay, self.betas, self.eps = weight_decay, betas, eps
-        self.opt_step = 0
+        self.write_opt_step(0)
 
     def optimizer_hparams(self, lr: float):
         """Host side of one AdamW step: advances the step count, refreshes lr / bias corrections."""
-        self.opt_step += 1
+        self.opt_step += 1          # the host's belief; the device count (hp[VITAE_HP_STEP], read_opt_step) is the truth
         b1, b2 = self.betas
-        self.set_hparams(lr=lr, beta1=b1, beta2=b2, eps=self.eps, bc1=1 - b1 ** self.opt_step,
-                         bc2=1 - b2 ** self.opt_step)
+        # bc1 = bc2 = 0: the AdamW kernels derive 1 - beta^t from the device-side count of APPLIED steps
+        self.set_hparams(lr=lr, beta1=b1, beta2=b2, eps=self.eps, bc1=0.0, bc2=0.0)
 
     def grad_norm_and_step(self):
         """utils/misc.py:265-267: global grad L2 norm -> losses[5]; AdamW over the arena
         (decayed: matrices + tokens; not decayed: vectors)."""
         st = torch.cuda.current_stream(self.device).cuda_stream
+        self.flush_hparams()
         gn = self.losses.data_ptr() + 20
         s = self.opt_state
         sh = self.params16.data_ptr() if self.params16 is not None else 0
@@ -1397,6 +1425,7 @@ class HipMAEEngine:
             lib.vitae_adamw_step_bf16g(self.params.data_ptr() + o, g16.data_ptr() + o // 2, s['exp_avg'].data_ptr() + o,
                                        s['exp_avg_sq'].data_ptr() + o, (sh + o // 2) if sh else None,
                                        self.n_total - self.vec_off, _ptr(self.hp), gn, 0.0, st)
+            lib.vitae_opt_count_bump(_ptr(self.hp), gn, st)
             return
         lib.vitae_grad_sqnorm(self.grads.data_ptr(), self.n_total, _ptr(self.acc), gn, st)
         lib.vitae_adamw_step(self.params.data_ptr(), self.grads.data_ptr(), s['exp_avg'].data_ptr(),
@@ -1405,6 +1434,7 @@ class HipMAEEngine:
         lib.vitae_adamw_step(self.params.data_ptr() + o, self.grads.data_ptr() + o, s['exp_avg'].data_ptr() + o,
                              s['exp_avg_sq'].data_ptr() + o, (sh + o // 2) if sh else None, self.n_total - self.vec_off,
                              _ptr(self.hp), gn, 0.0, st)
+        lib.vitae_opt_count_bump(_ptr(self.hp), gn, st)
 
     # --- optimiser inside the backward: the matrices of a gradient bucket are final when its backward phase ends
     # (data parallel: when its all-reduce has landed), so their share of the grad-norm pass and their AdamW update run on
@@ -1474,21 +1504,13 @@ class HipMAEEngine:
         gn = self.losses.data_ptr() + 20
         s = self.opt_state
         sh = self.params16.data_ptr() if self.params16 is not None else 0
-        ot, ov = self.tok_off * 4, self.vec_off * 4
+        ot = self.tok_off * 4
         g16 = self.grads_wire16 if self._wire_ready else None
-        sq = (lambda off, n: lib.vitae_grad_sqnorm_bf16(g16.data_ptr() + off // 2, n, _ptr(self.acc), gn, st)) if g16 is not None \
-            else (lambda off, n: lib.vitae_grad_sqnorm(self.grads.data_ptr() + off, n, _ptr(self.acc), gn, st))
-        step = (lambda off, n, wd: lib.vitae_adamw_step_bf16g(self.params.data_ptr() + off, g16.data_ptr() + off // 2,
-                                                               s['exp_avg'].data_ptr() + off, s['exp_avg_sq'].data_ptr() + off,
-                                                               (sh + off // 2) if sh else None, n, _ptr(self.hp), gn, wd, st)) \
-            if g16 is not None else \
-            (lambda off, n, wd: lib.vitae_adamw_step(self.params.data_ptr() + off, self.grads.data_ptr() + off,
-                                                     s['exp_avg'].data_ptr() + off, s['exp_avg_sq'].data_ptr() + off,
-                                                     (sh + off // 2) if sh else None, n, _ptr(self.hp), gn, wd, st))
-        sq(ot, self.n_total - self.tok_off)
-        if self.vec_off > self.tok_off:
-            step(ot, self.vec_off - self.tok_off, self.weight_decay)
-        step(ov, self.n_total - self.vec_off, 0.0)
+        # norm share of tokens + vectors, the global norm (last workgroup), AdamW over both segments, the step count: 2 launches
+        lib.vitae_opt_tail(self.params.data_ptr() + ot, (g16.data_ptr() + ot // 2) if g16 is not None else self.grads.data_ptr() + ot,
+                           1 if g16 is not None else 0, s['exp_avg'].data_ptr() + ot, s['exp_avg_sq'].data_ptr() + ot,
+                           (sh + ot // 2) if sh else None, self.vec_off - self.tok_off, self.n_total - self.vec_off, _ptr(self.hp),
+                           _ptr(self.acc), gn, self.weight_decay, st)
 
     # ------------------------------------------------------------------ fused training step
     # encoder backward is cut into this many phases (= gradient buckets = optimiser-in-backward units)
@@ -1528,7 +1550,7 @@ class HipMAEEngine:
         return [(cuts[i + 1] - 1, cuts[i]) for i in reversed(range(n))]
 
     def train_phase(self, k: int, view1, view2, noise, mask_ratio: float, update: bool = True,
-                    accumulate: bool = False, prologue_done: bool = False, defer_last_bucket: bool = False):
+                    accumulate: bool = False):
         """Phase k of one optimisation step (only kernel launches, no host sync):
         0 (.. dec_chunks - 1) = forward + losses + backward through decoder/predictor; then enc_chunks phases of encoder backward,
         top chunk first (the last one also does the patch embedding); the last phase = grad-norm + AdamW.  Gradient bucket k (ddp) is
@@ -1538,19 +1560,18 @@ class HipMAEEngine:
         self._epi_norm_on = bool(self.epi_norm and update and self._optimizer_in_backward_ok())
         lib.vitae_gemm_glds_set_wgrad_sqnorm(self.acc.data_ptr() + 8 * _C['VITAE_ACC_GRADSQ'] if self._epi_norm_on else None)
         try:
-            self._train_phase(k, view1, view2, noise, mask_ratio, update, accumulate, prologue_done, defer_last_bucket)
+            self._train_phase(k, view1, view2, noise, mask_ratio, update, accumulate)
         finally:
             lib.vitae_gemm_glds_set_wgrad_sqnorm(None)
 
-    def _train_phase(self, k, view1, view2, noise, mask_ratio, update, accumulate, prologue_done, defer_last_bucket):
+    def _train_phase(self, k, view1, view2, noise, mask_ratio, update, accumulate):
         cfg = self.cfg
         n, nd = self.enc_chunks, self.dec_chunks
         if k == 0:
             # the zeroing of the token / vector gradient segment and the loss finalisation are not on the dependent chain:
             # the first goes in front of the forward, the second behind the decoder backward (12 us between the loss kernels)
-            self.begin_grad_window(accumulate)
-            self.forward(view1, view2, noise, mask_ratio, training=True, defer_predictor_join=True, defer_finalize=True,
-                         prologue_done=prologue_done)
+            self.step_prologue(noise, accumulate)
+            self.forward(view1, view2, noise, mask_ratio, training=True, defer_predictor_join=True, defer_finalize=True)
             if cfg.contrastive:
                 self.contrastive_loss_fwd()
                 self.contrastive_loss_bwd()
@@ -1567,22 +1588,20 @@ class HipMAEEngine:
             self.backward_enc(hi, lo)
             if k == nd + n - 1:
                 self.backward_tail()
-            if update and self._optimizer_in_backward_ok() and not (defer_last_bucket and k == nd + n - 1):
+            if update and self._optimizer_in_backward_ok():
                 self._opt_bucket(k)
-            if defer_last_bucket and k == nd + n - 1 and update and self._optimizer_in_backward_ok():
-                # this launch ends here: the optimiser stream forked inside it must come back inside it
-                torch.cuda.current_stream(self.device).wait_stream(self.oside)
         elif k == nd + n and update:
-            if defer_last_bucket and self._optimizer_in_backward_ok():
-                self._opt_bucket(nd + n - 1)      # the split step keeps the exposed optimiser tail in a launch of its own
             if self._optimizer_in_backward_ok() or self._ddp_bucket_opt:
                 self._opt_tail()             # the buckets' matrices were stepped beside the backward
             else:
                 self.grad_norm_and_step()
+        if k == nd + n:
+            self.step_epilogue()             # every micro-step, update or not: the device's ring position follows the host's
 
     def train_step_launch(self, view1, view2, noise, mask_ratio: float, update: bool = True, accumulate: bool = False):
         for k in range(self.N_PHASES):
             self.train_phase(k, view1, view2, noise, mask_ratio, update, accumulate)
+        self.end_step_host()
 
     def set_loss_weights(self, edge_map_weight: float, contr_weight: float, accum_iter: int = 1, world_size: int = 1):
         """Loss weights + upstream gradient multipliers; 1/(accum_iter*world_size) makes a SUM

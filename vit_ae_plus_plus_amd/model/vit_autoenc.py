@@ -96,7 +96,6 @@ class _MAEStep(torch.autograd.Function):
 
 _SLOTS = int(os.environ.get('VITAE_INPUT_SLOTS', '2'))     # host batches: 2 = double-buffered on a copy stream, 1 = one slot, 0 = main stream
 _DOUBLE_BUFFER = _SLOTS >= 2
-_SPLIT_STEP = os.environ.get('VITAE_SPLIT_STEP', '0') == '1'   # the next batch's input-only prologue under this step's optimiser tail
 _MAX_DIRECT = int(os.environ.get('VITAE_DIRECT_GRAPHS', '4'))   # device batches read in place: graphs kept per runner (0 = always stage)
 
 
@@ -143,13 +142,9 @@ class _StepRunner:
                                      'copy': torch.cuda.Stream(device=dev)}
         self.st = st
         self.graphs = {}              # slot index, or ('direct', ptr1, ptr2) -> captured graph(s)
-        self.pgraphs = {}             # split step: the same keys -> captured input-only prologue
         self.use_graph = use_graph
         self._direct, self._seen = None, {}
         self._ws_gen = self.eng.ws_gen
-        if 'pro' not in st:
-            st['pro'] = torch.cuda.Stream(device=dev)
-        self._split_flags = False     # True while the phases are issued for the split step (capture / warm-up)
 
     @property
     def slot(self):
@@ -182,8 +177,7 @@ class _StepRunner:
           ``run`` reads, alternating between two slots, so the host-to-device transfer of batch i+1 overlaps step i.
         * DEVICE tensors: copied on the current stream into the current slot — measured: a device-to-device copy
           that overlaps the step gains nothing (it competes for HBM with the kernels: 5.82 vs 5.81 ms) and costs
-          0.35 ms in the data-parallel step, so it stays in program order.  ``ready``: the device tensors are complete
-          (nothing on the current stream still writes them) — lets the split step start this batch's prologue early."""
+          0.35 ms in the data-parallel step, so it stays in program order.  ``ready``: kept for callers (no effect)."""
         st = self.st
         main = torch.cuda.current_stream(self.eng.device)
         host = not view1.is_cuda and (view2 is None or not view2.is_cuda) and _SLOTS >= 1
@@ -207,62 +201,30 @@ class _StepRunner:
                 direct = self._seen[key] >= 2 and sum(isinstance(k, tuple) for k in self.graphs) < _MAX_DIRECT
             if direct:
                 slot = self._direct = _DirectSlot(view1, view2, st['slots'][0].noise)
-                # split step + ``ready`` (the caller vouches that the tensors are complete — a dataset resident in HBM): the
-                # masking noise is drawn on the prologue stream, so nothing of this batch is ordered behind the step that is
-                # still running on the main stream and its prologue can start under that step's optimiser tail
-                ns = st['pro'] if (ready and self._split()) else main
-                with torch.cuda.stream(ns):
-                    if m._noise_queue:
-                        slot.noise.copy_(m._draw_noise(2 if m._contrastive else 1, self.B, slot.noise.device))
-                    else:
-                        slot.noise.uniform_()
-                    slot.loaded.record(ns)
-                self._prologue_ahead(slot)
+                self._stage_noise(slot)
+                slot.loaded.record(main)
                 return
         with torch.cuda.stream(copy):
             slot.v1.copy_(view1, non_blocking=True)
             if slot.v2 is not None:
                 slot.v2.copy_(view2, non_blocking=True)
-            if m._noise_queue:
-                slot.noise.copy_(m._draw_noise(2 if m._contrastive else 1, self.B, slot.noise.device))
-            else:
-                slot.noise.uniform_()   # torch.rand of vit_autoenc.py:139
+            self._stage_noise(slot)
             slot.loaded.record(copy)
-        self._prologue_ahead(slot)
 
-    def _prologue_ahead(self, slot):
-        """split step: the batch is staged — start its prologue now (it will wait for the running step's backward)"""
-        eng = self.eng
-        if not self._split() or self._ws_gen != eng.ws_gen or eng._prologue_owner is not None:
-            return
-        key = self._gkey
-        if key in self.pgraphs and eng.B == self.B and eng.keep == eng.cfg.len_keep(self.mask_ratio):
-            self._launch_prologue(slot, key)
+    def _stage_noise(self, slot):
+        """The torch.rand of vit_autoenc.py:139.  Fused step: the masking noise is drawn by the step's own first launch
+        (vitae_step_prologue: Philox keyed by the engine's seed and the step number) — nothing is launched here; injected noise
+        (``set_masking_noise``: parity tests) is copied into the slot and the step is told to keep it."""
+        m, eng = self.model, self.eng
+        if m._noise_queue:
+            slot.noise.copy_(m._draw_noise(2 if m._contrastive else 1, self.B, slot.noise.device))
+            eng.set_hparams(noise_keep=1.0)
+        else:
+            eng.set_hparams(noise_keep=0.0)
 
     def _phase(self, k):
         sl = self.slot
-        self.eng.train_phase(k, sl.v1, sl.v2, sl.noise, self.mask_ratio, update=self.update, accumulate=self.accumulate,
-                             prologue_done=self._split_flags, defer_last_bucket=self._split_flags)
-
-    # ---- split step (VITAE_SPLIT_STEP=1, single process, captured): three launches per step.  P = what depends on the batch only
-    # (masking, patch gather, blur + Sobel of the target: ~250 us of kernel time that otherwise runs beside — and slows — the
-    # patch-embedding GEMM and the first encoder block), A = everything else up to the end of the backward, B = the exposed
-    # optimiser tail (the last bucket's AdamW + tokens / vectors, ~0.3 ms that only stream HBM).  P of batch i + 1 is launched by
-    # ``load`` on its own stream, waits for A of step i (the workspace is single-buffered) and so runs beside B of step i.
-    def _split(self) -> bool:
-        return _SPLIT_STEP and self.use_graph and not self._exchange()
-
-    def _launch_prologue(self, sl, key):
-        eng, ps = self.eng, self.st['pro']
-        ps.wait_event(sl.loaded)
-        if eng._main_done is not None:
-            ps.wait_event(eng._main_done)      # the previous step's forward + backward are done with the workspace
-        if getattr(sl, 'pro_done', None) is None:
-            sl.pro_done = torch.cuda.Event()
-        with torch.cuda.stream(ps):
-            self.pgraphs[key].replay()
-            sl.pro_done.record(ps)
-        eng._prologue_owner = (id(self), key)
+        self.eng.train_phase(k, sl.v1, sl.v2, sl.noise, self.mask_ratio, update=self.update, accumulate=self.accumulate)
 
     def _exchange(self):
         red = self.model._reducer
@@ -301,6 +263,7 @@ class _StepRunner:
         eng = self.eng
         keep = [eng.params, eng.grads] + ([eng.opt_state['exp_avg'], eng.opt_state['exp_avg_sq']] if eng.opt_state else [])
         keep += [t for k, t in eng.buffers.items() if k.startswith('predictor.1.')]
+        keep.append(eng.hp)                    # (the device-side count of applied AdamW steps lives in it)
         snap = [t.clone() for t in keep]
         step = eng.opt_step
         cur = torch.cuda.current_stream(eng.device)
@@ -309,23 +272,15 @@ class _StepRunner:
         side = torch.cuda.Stream(device=eng.device)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            if self._split_flags:
-                sl = self.slot
-                eng.input_prologue(sl.v1, sl.v2, sl.noise, self.mask_ratio)
             self._run_group(range(eng.N_PHASES), inside)
         cur.wait_stream(side)
+        eng.end_step_host()                    # the warm-up was a launched step: the ring position moved on both sides
         for t, s in zip(keep, snap):
             t.copy_(s)
         eng.opt_step = step
         eng.refresh_shadow(force=True)     # restoring bumped the arena's version: re-cast now, not inside the graph
         torch.cuda.synchronize(eng.device)
         graphs = []
-        if self._split_flags:
-            sl = self.slot
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side, capture_error_mode='thread_local'):
-                eng.input_prologue(sl.v1, sl.v2, sl.noise, self.mask_ratio)
-            self.pgraphs[self._gkey] = g
         for grp in groups:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=side, capture_error_mode='thread_local'):
@@ -343,10 +298,7 @@ class _StepRunner:
         exchange = self._exchange()
         inside = exchange and getattr(red, 'native', False)
         nph = eng.N_PHASES
-        split = self._split()
-        self._split_flags = split
-        groups = [[k] for k in range(nph)] if (exchange and not inside) else \
-            ([list(range(nph - 1)), [nph - 1]] if split else [list(range(nph))])
+        groups = [[k] for k in range(nph)] if (exchange and not inside) else [list(range(nph))]
         eng._wire_ready = exchange and eng.grads_wire16 is not None    # read at launch / capture time of the last phase
         eng._ddp_active = exchange          # buckets change after their phase (all-reduce): the runner steps them below
         bucket_opt = exchange and eng.overlap_optimizer and eng.opt_state is not None
@@ -356,27 +308,11 @@ class _StepRunner:
         main.wait_event(sl.loaded)                     # this slot's batch has landed
         if self._ws_gen != eng.ws_gen:                 # the engine freed a workspace some captured graph may point into
             self.graphs.clear()
-            self.pgraphs.clear()
             self._ws_gen = eng.ws_gen
         eng._alloc(self.B, self.mask_ratio)            # this runner's workspace is the current one (replays bypass forward())
         if self.use_graph and self.graphs.get(self._gkey) is None:
             self._capture(groups, inside)
         graphs = self.graphs.get(self._gkey)
-        if split:
-            key = self._gkey
-            if eng._prologue_owner != (id(self), key):     # not started ahead (first step, or another runner came between)
-                eng._prologue_owner = None
-                self._launch_prologue(sl, key)
-            main.wait_event(sl.pro_done)
-            eng._prologue_owner = None
-            graphs[0].replay()
-            eng._main_done = torch.cuda.Event()
-            eng._main_done.record(main)
-            graphs[1].replay()
-            sl.free = torch.cuda.Event()
-            sl.free.record(main)
-            return
-        eng._prologue_owner = None
         for i, grp in enumerate(groups):
             if self.use_graph:
                 graphs[i].replay()
@@ -384,6 +320,7 @@ class _StepRunner:
                 self._run_group(grp, inside)
             if exchange and not inside:
                 self._after_phase(i)
+        eng.end_step_host()
         sl.free = torch.cuda.Event()
         sl.free.record(main)
 

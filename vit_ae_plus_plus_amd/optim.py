@@ -64,7 +64,7 @@ class FusedAdamW:
         eng = self.engine
         state = {'step': 0, 'exp_avg': None, 'exp_avg_sq': None}
         if eng is not None:
-            state = {'step': eng.opt_step, 'exp_avg': eng.opt_state['exp_avg'].detach().cpu(),
+            state = {'step': eng.read_opt_step(), 'exp_avg': eng.opt_state['exp_avg'].detach().cpu(),
                      'exp_avg_sq': eng.opt_state['exp_avg_sq'].detach().cpu(),
                      'layout': {k: (o, list(s)) for k, (o, s) in eng.layout.items()}}
         groups = [{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups]
@@ -74,7 +74,7 @@ class FusedAdamW:
         if state.get('exp_avg') is not None:
             eng.opt_state['exp_avg'].copy_(state['exp_avg'])
             eng.opt_state['exp_avg_sq'].copy_(state['exp_avg_sq'])
-        eng.opt_step = int(state.get('step', 0))
+        eng.write_opt_step(int(state.get('step', 0)))
 
     def load_state_dict(self, sd):
         for g, s in zip(self.param_groups, sd.get('param_groups', [])):
@@ -122,7 +122,7 @@ class _AdoptedAdamW:
             optimizer.state[p] = {'step': torch.tensor(float(step)),
                                   'exp_avg': eng.opt_state['exp_avg'][o:o + k].view(shp),
                                   'exp_avg_sq': eng.opt_state['exp_avg_sq'][o:o + k].view(shp)}
-        eng.opt_step = step
+        eng.write_opt_step(step)
         self.engine = eng
         if not getattr(optimizer, '_vitae_hooked', False):
             optimizer.register_state_dict_pre_hook(lambda opt: opt._vitae_adopter._publish_step(opt))
@@ -132,8 +132,9 @@ class _AdoptedAdamW:
         optimizer.engine = eng
 
     def _publish_step(self, optimizer):
+        step = self.engine.read_opt_step()
         for st in optimizer.state.values():
-            st['step'] = torch.tensor(float(self.engine.opt_step))
+            st['step'] = torch.tensor(float(step))
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -162,8 +162,8 @@ def _fused_epoch(model, data_loader, optimizer, device, epoch, log_writer, args,
             if not math.isfinite(loss_value):
                 print("Loss is {}, stopping training".format(loss_value))
                 sys.exit(1)
-            if stepped and not math.isfinite(vals[5]):
-                eng.opt_step -= 1        # the AdamW kernel skipped this step (GradScaler.step semantics): do not count it
+            # (a step the AdamW kernels skipped for a non-finite gradient norm — GradScaler.step semantics — is not counted:
+            # the count of applied steps lives on the device, hp[VITAE_HP_STEP], and the bias corrections follow it)
             metric_logger.update(loss=loss_value)
             metric_logger.update(lr=lr)
             rows.append((it, lr, [loss_value, recon, edge, percep, contr_loss]))
