@@ -572,6 +572,8 @@ int bt_launch(GArgs p, int a_kc, int b_kc, int id, hipStream_t st) {
     if (p.K - (p.splits - 1) * p.k_per_split < 2 * BK || p.k_per_split < 2 * BK) return VITAE_ERR_UNSUPPORTED_SHAPE;
     p.tiles_m = cdiv(p.M, bm); p.tiles_n = cdiv(p.N, bn);
     if (p.splits > 1 && (!p.ws || id == 0 || (long)p.tiles_m * p.tiles_n > VITAE_GLDS_TICKETS || p.epi == VITAE_EPI_GELU)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    // (128x64 / 64x128 on TWO waves, three workgroups per CU, were tried for the batch-8 encoder shapes where the vendor library uses
+    // 128x64 / 128x96 macro tiles: 13.9 vs 13.4 us for the 64-row family on qkv, 15.7 vs 14.4 on fc1 — not kept.)
     // (256x128 and 128x256 on eight waves were built and measured too: four MFMAs per phase against the same barrier / DMA
     // overhead as eight — 2150 clocks per k-tile for 1024 of MFMA — never the best tile on any shape of the step: not kept)
     if (id == 0) bt_launch_cfg<256, 256, 2, 4>(p, a_kc, b_kc, st);

@@ -533,17 +533,31 @@ __global__ __launch_bounds__(256) void loss_fwd_fused_kernel(const float* __rest
 // reference's sqrt backward) -> three LDS arrays; transposed (flipped) separable stencils over those -> dvol.
 // All C channels of a voxel are adjacent in patchify order, so they are collected in registers and stored as
 // one vector per voxel.
-template <int CH>
+// one LDS-DMA lane-piece: 16 bytes (WIDE) or 4 (the size operand must be a literal)
+template <bool WIDE> __device__ __forceinline__ void lds_dma(const float* src, float* dst);
+template <> __device__ __forceinline__ void lds_dma<true>(const float* src, float* dst) {
+    __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+}
+template <> __device__ __forceinline__ void lds_dma<false>(const float* src, float* dst) {
+    __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)dst, 4, 0, 0);
+}
+
+// ROW16: the pred_vol tile goes HBM -> LDS in 16-byte pieces of x-rows (tile x-extent + a 4-voxel halo on each side so that
+// every piece starts 16-byte aligned: 40 floats = 10 pieces per row, 6 DMA instructions per thread and channel) instead of one
+// float per lane (21 instructions per thread and channel, 256 bytes per wave instruction: the texture addresser, not HBM, bounded
+// the kernel).  Needs Wx % 4 == 0.
+template <int CH, bool ROW16>
 __global__ __launch_bounds__(256, 2) void loss_bwd_fused_kernel(const float* __restrict__ pvol, const float* __restrict__ imgs,
                                                              const float* __restrict__ mask, const float* __restrict__ Ep,
                                                              const float* __restrict__ Et, const float* __restrict__ hp,
                                                              float* __restrict__ dpred, __bf16* __restrict__ dpred16,
                                                              float* __restrict__ nonfinite, float inv_count,
                                                              float inv_p_masksum, int xtiles, VolGeom g) {
-    constexpr int VZ = TZ + 4, VY = TY_ + 4, VX = TX + 4;      // pred_vol region (halo 2)
+    constexpr int VZ = TZ + 4, VY = TY_ + 4, VX = ROW16 ? TX + 8 : TX + 4;      // pred_vol region (halo 2; ROW16: x halo 4)
+    constexpr int XH = ROW16 ? 4 : 2;                          // x halo of the staged region
     constexpr int GZ = TZ + 2, GY = TY_ + 2, GX = TX + 2;      // dG region (halo 1)
     constexpr int NCOL = GY * GX, NPASS = (NCOL + 255) / 256;
-    __shared__ float sv[VZ * VY * VX];
+    __shared__ __attribute__((aligned(16))) float sv[VZ * VY * VX];
     __shared__ float sg[3][GZ * GY * GX];
     const int Lz = g.Lz, Hy = g.Hy, Wx = g.Wx;
     const long V = (long)Lz * Hy * Wx;
@@ -588,25 +602,32 @@ __global__ __launch_bounds__(256, 2) void loss_bwd_fused_kernel(const float* __r
     // channel (the index arithmetic was a third of the kernel's instructions), no registers hold data in flight,
     // and the next channel's tile is fetched underneath the transposed stencils.  Out-of-volume elements are zeroed
     // once and never written again (their lanes are masked out of the DMA).
-    constexpr int NLD = (VZ * VY * VX + 255) / 256;
+    constexpr int NPIECE = ROW16 ? VZ * VY * (VX / 4) : VZ * VY * VX;       // DMA lane-pieces of one channel's region
+    constexpr int NLD = (NPIECE + 255) / 256;
     int off[NLD];
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
         const int idx = threadIdx.x + k * 256;
-        const int xx = idx % VX, r = idx / VX, yy = r % VY, zz = r / VY;
-        const int gx = x0 - 2 + xx, gy = y0 - 2 + yy, gz = z0 - 2 + zz;
-        const bool in = idx < VZ * VY * VX && gx >= 0 && gx < Wx && gy >= 0 && gy < Hy && gz >= 0 && gz < Lz;
-        off[k] = in ? (gz * Hy + gy) * Wx + gx : -1;
-        if (!in && idx < VZ * VY * VX) sv[idx] = 0.f;
+        if constexpr (ROW16) {
+            const int ch = idx % (VX / 4), r = idx / (VX / 4), yy = r % VY, zz = r / VY;
+            const int gx = x0 - XH + 4 * ch, gy = y0 - 2 + yy, gz = z0 - 2 + zz;
+            const bool in = idx < NPIECE && gx >= 0 && gx + 3 < Wx && gy >= 0 && gy < Hy && gz >= 0 && gz < Lz;   // Wx % 4 == 0: all or nothing
+            off[k] = in ? (gz * Hy + gy) * Wx + gx : -1;
+            if (!in && idx < NPIECE) *reinterpret_cast<float4*>(sv + idx * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            const int xx = idx % VX, r = idx / VX, yy = r % VY, zz = r / VY;
+            const int gx = x0 - 2 + xx, gy = y0 - 2 + yy, gz = z0 - 2 + zz;
+            const bool in = idx < NPIECE && gx >= 0 && gx < Wx && gy >= 0 && gy < Hy && gz >= 0 && gz < Lz;
+            off[k] = in ? (gz * Hy + gy) * Wx + gx : -1;
+            if (!in && idx < NPIECE) sv[idx] = 0.f;
+        }
     }
     const int wave_base = (threadIdx.x >> 6) * 64;
     auto fetch = [&](int c) {
         const float* src = pvol + ((long)b * g.C + c) * V;
 #pragma unroll
         for (int k = 0; k < NLD; ++k)
-            if (off[k] >= 0)
-                __builtin_amdgcn_global_load_lds(src + off[k], (__attribute__((address_space(3))) void*)(sv + k * 256 + wave_base),
-                                                 4, 0, 0);
+            if (off[k] >= 0) lds_dma<ROW16>(src + off[k], sv + (k * 256 + wave_base) * (ROW16 ? 4 : 1));
     };
     fetch(0);
     for (int c = 0; c < CH; ++c) {
@@ -617,14 +638,14 @@ __global__ __launch_bounds__(256, 2) void loss_bwd_fused_kernel(const float* __r
         __syncthreads();                                     // ... everyone's; last channel's sg readers are done
         float pvc[TZ];
 #pragma unroll
-        for (int tz = 0; tz < TZ; ++tz) pvc[tz] = sv[((tz + 2) * VY + ty + 2) * VX + tx + 2];
+        for (int tz = 0; tz < TZ; ++tz) pvc[tz] = sv[((tz + 2) * VY + ty + 2) * VX + tx + XH];
         // ---- dG on the halo-1 region, one (y, x) column per thread (and a second one for the first threads)
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             const int col = threadIdx.x + ps * 256;
             if (col < NCOL) {
                 const int cx = col % GX, cy = col / GX;
-                const float* base = sv + cy * VX + cx;        // region (vz, cy .. cy+2, cx .. cx+2)
+                const float* base = sv + cy * VX + cx + (XH - 2);        // region (vz, cy .. cy+2, cx .. cx+2)
                 float A0, B0, C0, A1, B1, C1, A2, B2, C2;
                 sobel_plane(base, VX, A0, B0, C0);
                 sobel_plane(base + VY * VX, VX, A1, B1, C1);
@@ -900,12 +921,14 @@ extern "C" int vitae_loss_bwd_fused(const float* pred, const float* pred_vol, co
     __bf16* d16 = reinterpret_cast<__bf16*>(dpred_bf16);
     const bool vec_ok = ((uintptr_t)dpred % 16 == 0) && ((uintptr_t)dpred_bf16 % 8 == 0) && pred_bstride % 4 == 0;
     if (zt <= 65535 && B <= 65535 && (C == 1 || (C == 4 && vec_ok))) {
-        if (C == 1)
-            hipLaunchKernelGGL(loss_bwd_fused_kernel<1>, dim3(xt * yt, zt, B), dim3(256), 0, st, pred_vol, imgs, mask, edge_pred,
-                               edge_tgt, hp, dpred, d16, nonfinite_flag, inv_count, inv_pm, xt, g);
-        else
-            hipLaunchKernelGGL(loss_bwd_fused_kernel<4>, dim3(xt * yt, zt, B), dim3(256), 0, st, pred_vol, imgs, mask, edge_pred,
-                               edge_tgt, hp, dpred, d16, nonfinite_flag, inv_count, inv_pm, xt, g);
+        static const int row16_on = getenv("VITAE_LOSS_ROW16") ? atoi(getenv("VITAE_LOSS_ROW16")) : 1;
+        const bool row16 = row16_on && Wx % 4 == 0 && ((uintptr_t)pred_vol % 16 == 0);
+        const dim3 grid(xt * yt, zt, B);
+#define VITAE_LBW(CH_, R_) hipLaunchKernelGGL((loss_bwd_fused_kernel<CH_, R_>), grid, dim3(256), 0, st, pred_vol, imgs, mask, edge_pred, \
+                                              edge_tgt, hp, dpred, d16, nonfinite_flag, inv_count, inv_pm, xt, g)
+        if (C == 1) { if (row16) VITAE_LBW(1, true); else VITAE_LBW(1, false); }
+        else { if (row16) VITAE_LBW(4, true); else VITAE_LBW(4, false); }
+#undef VITAE_LBW
         return vitae_launch_status();
     }
     // other channel counts: the three-kernel path (needs the dG scratch)
