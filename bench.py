@@ -64,6 +64,7 @@ def parse(argv=None):
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--batch', type=int, default=4, help='volumes per GPU per step (BASELINE config 2: 4)')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--patch', type=int, default=PATCH, help='patch size (BASELINE configs: 16; the reference\'s config.ini default: 8) — not the headline workload when changed')
     ap.add_argument('--model', default='contr', choices=['contr', 'mae'])
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--grad-comm', default=None, choices=['fp32', 'bf16'],
@@ -129,14 +130,14 @@ def masking_noise(batch, num_patches, seed):
     return [torch.rand(batch, num_patches, generator=g) for _ in range(2)]
 
 
-def build_model(kind, precision, dev, seed=0, patch=PATCH, fused_opt=True):
+def build_model(kind, precision, dev, seed=0, patch=None, fused_opt=True):
     """The product's own constructor + initialize_weights under a fixed seed; returns (model, cpu state dict, engine)."""
     from vit_ae_plus_plus_amd.model import vit_autoenc as VA
     from vit_ae_plus_plus_amd.optim import FusedAdamW
     torch.manual_seed(seed)
     margs = argparse.Namespace(use_imagenet=False, perceptual_weight=0)
     ctor = VA.contr_mae_vit_base_patch16 if kind == 'contr' else VA.mae_vit_base_patch16
-    model = ctor(volume_size=VOL, in_chans=CH, patch_size=patch, args=margs, precision=precision)
+    model = ctor(volume_size=VOL, in_chans=CH, patch_size=patch or PATCH, args=margs, precision=precision)
     sd_cpu = {k: v.detach().clone() for k, v in model.state_dict().items()}
     model = model.to(dev).train()
     eng = model._ensure_engine(dev)
@@ -417,7 +418,9 @@ def pinned_trajectory_parity(args, dev):
 
 
 def main():
+    global PATCH
     args = parse()
+    PATCH = args.patch
     cmd = spawn_command(args, sys.argv[1:], torch.cuda.device_count(), free_port())
     if cmd is not None:
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
@@ -605,7 +608,7 @@ def main():
                'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                'dtype': args.precision, 'data': 'synthetic',
                'config': {'workload': f'ViT-B/16^3 {"contrastive " if contr else ""}MAE full optimisation step '
-                                      f'(fwd+loss+bwd+grad-norm+AdamW), synthetic BraTS-shape 96^3x4ch, batch '
+                                      f'(fwd+loss+bwd+grad-norm+AdamW), synthetic BraTS-shape 96^3x4ch, ' + (f'PATCH {PATCH} (not the headline workload), ' if PATCH != 16 else '') + 'batch '
                                       f'{args.batch}/GPU, mask 0.75 (BASELINE config 2{" / 3" if world > 1 else ""})',
                           'global_batch': world * args.batch,
                           'parallelism': f'dp{world}' + (' (PLUMBING CHECK: all ranks on ONE GPU, gloo transport)' if ONE_GPU else ''),
