@@ -464,15 +464,23 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
         // Partials and tickets move with agent-scope relaxed atomics (sc1: written through to / read from the
         // memory side, coherent across the 8 XCD L2s); a full release/acquire fence pair instead would write back
         // and invalidate the whole L2 per workgroup (measured 3x slower than no split at all).
+        // Round 3: the partials move 16 bytes per lane (write-through buffer stores / sc1 buffer loads instead of 4-byte agent
+        // atomics), and the last arriver keeps the groups of FOUR splits in flight together: one round trip to the memory side
+        // per four splits instead of one per split (the fix-up cost the last arriver ~7000 clocks, tools/gemm_phase_probe.py).
         const int tile = tm * p.tiles_n + tn;
         float* part = p.ws + VITAE_GLDS_TICKETS + ((long)tile * p.splits) * (BM * BN);
         int* ticket = reinterpret_cast<int*>(p.ws) + tile;
+        constexpr int GRP = NF * 4;                                   // 16-byte groups per lane and split
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(part, 0, p.splits * (BM * BN * 4), 0x00020000);
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const int toff = (int)threadIdx.x * 16;
 #pragma unroll
         for (int f = 0; f < NF; ++f)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                __hip_atomic_store(&part[(long)zid * (BM * BN) + (f * 16 + r) * NT + threadIdx.x], a[f][r], __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 v = {a[f][4 * g4], a[f][4 * g4 + 1], a[f][4 * g4 + 2], a[f][4 * g4 + 3]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (zid * GRP + f * 4 + g4) * (NT * 16) + toff, 0, 16);
+            }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this thread's partials are out
         __syncthreads();
         int* flag = reinterpret_cast<int*>(smem);
@@ -484,13 +492,28 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
         for (int f = 0; f < NF; ++f)
 #pragma unroll
             for (int r = 0; r < 16; ++r) a[f][r] = 0.f;
-        for (int sp = 0; sp < p.splits; ++sp)
+        constexpr int SB = NF == 1 ? 4 : 2;                           // splits in flight together
+#pragma unroll 1
+        for (int sp0 = 0; sp0 < p.splits; sp0 += SB) {
+            f32x4 v[SB][GRP];
 #pragma unroll
-            for (int f = 0; f < NF; ++f)
+            for (int u = 0; u < SB; ++u) {
+                const int sp = min(sp0 + u, p.splits - 1);             // (clamped: a repeated load, never added)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    a[f][r] += __hip_atomic_load(&part[(long)sp * (BM * BN) + (f * 16 + r) * NT + threadIdx.x], __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT);
+                for (int i = 0; i < GRP; ++i)
+                    v[u][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (sp * GRP + i) * (NT * 16) + toff, 0, 16));
+            }
+#pragma unroll
+            for (int u = 0; u < SB; ++u)
+                if (sp0 + u < p.splits) {
+#pragma unroll
+                    for (int f = 0; f < NF; ++f)
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) a[f][4 * g4 + e] += v[u][f * 4 + g4][e];
+                }
+        }
         if (threadIdx.x == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     }
 
