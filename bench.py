@@ -46,9 +46,6 @@ KNAMES = {'glds_pair': 'gemm_glds_pair_kernel<64,64,64,64> (csrc/gemm_glds.hip: 
           'glds_wide': 'gemm_glds_kernel<64,128,..> (csrc/gemm_glds.hip)',
           'glds_pair_wide': 'gemm_glds_pair_kernel<..,64,128> (csrc/gemm_glds.hip)',
           'glds_dgrad': 'gemm_glds_kernel<64,64,true,false> (csrc/gemm_glds.hip: dgrad of one Linear)',
-          'glds_wgrad_group': 'gemm_glds_group_kernel (csrc/gemm_glds.hip: the four weight gradients of a block in one launch)',
-          'glds_slab': 'gemm_glds_kernel<64,64,true,true> in slab mode (csrc/gemm_glds.hip: split-K summed by the consuming LayerNorm)',
-          'glds_pair_slab': 'gemm_glds_pair_kernel<64,64,64,64> with the dgrad in slab mode (csrc/gemm_glds.hip)',
           'bt256': 'gemm_bt_kernel<256,256,2,4,..> (csrc/gemm_bt.hip: 8 staggered waves)',
           'bt128': 'gemm_bt_kernel<128,128,2,2,..> (csrc/gemm_bt.hip: 4 waves, two workgroups per CU, in-launch split-K)',
           'bt_bwd': 'backward of one Linear as two launches (dgrad, wgrad), at least one on a csrc/gemm_bt.hip tile',

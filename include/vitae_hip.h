@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITAE_ABI_VERSION 29
+#define VITAE_ABI_VERSION 30
 
 /* matrix-core arithmetic of the dense contractions */
 #define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
@@ -112,25 +112,6 @@ int vitae_gemm_glds(int a_kcontig, int b_kcontig, const void* A16, long lda, con
                     long ldc, void* C16, long ldc16, int M, int N, int K, const float* bias, const float* residual,
                     long ldr, int epi, float* aux, long ldaux, int accumulate, int split_k, float* splitk_ws,
                     float* out_colsum_accum, void* stream);
-/* The same GEMM, additionally leaving the LayerNorm statistics of its result rows for the op that follows (model/vit.py:141,143:
- * the residual stream goes into norm1 / norm2), in 64-column partials: out_rowstats[s][m] = (sum, sum of squares) of
- * C(m, 64 s .. 64 s + 63), s < ceil(N / 64), [ceil(N / 64)][M][2] floats, 8-byte aligned (plain stores: nothing to zero).  Row-major epilogue only (N % 4 == 0, 16-byte
- * aligned operands, 64x64 / 64x128 tiles), else VITAE_ERR_UNSUPPORTED_SHAPE. */
-int vitae_gemm_glds_stats(int a_kcontig, int b_kcontig, const void* A16, long lda, const void* B16, long ldb, float* C,
-                          long ldc, void* C16, long ldc16, int M, int N, int K, const float* bias, const float* residual,
-                          long ldr, int epi, float* aux, long ldaux, int accumulate, int split_k, float* splitk_ws,
-                          float* out_colsum_accum, float* out_rowstats, void* stream);
-/* LayerNorm folded into the Linear that consumes it (nn.LayerNorm + nn.Linear of model/vit.py:141,143 in ONE launch):
- * C / C16 [M, N] = epi( LN(X)[M, K] @ W16[N, K]^T + bias ),  LN(X)(m, k) = (X(m, k) - mean_m) rstd_m gamma_k + beta_k, with
- * mean / rstd from stats[stat_parts][M][2] = partial (sum, sum of squares) of X's rows (vitae_gemm_glds_stats with
- * stat_parts = K / 64, or any producer of X).  X is read
- * as fp32 through registers and normalised on its way into LDS; W16 arrives by LDS-DMA.  y16_out (row stride ldy; must have
- * ceil(M / 64) * 64 rows), mean_out, rstd_out — all or none: the bf16 LayerNorm output and row statistics the backward needs,
- * stored by the workgroups of column tile 0 (the pad rows of y16_out are written with zeros).  K in {512, 768, 1024}; epi as vitae_gemm_glds. */
-int vitae_gemm_glds_lnfold(const float* X, long ldx, const float* stats, int stat_parts, const float* gamma, const float* beta, float eps,
-                           const void* W16, long ldw, float* C, long ldc, void* C16, long ldc16, int M, int N, int K,
-                           const float* bias, int epi, float* aux, long ldaux, void* y16_out, long ldy, float* mean_out,
-                           float* rstd_out, void* stream);
 int vitae_gemm_glds_pick_split_k(int M, int N, int K);
 /* Big-tile kernels (csrc/gemm_bt.hip; 0: 256x256 on 8 waves, 3: 128x128 on 4 waves, in-launch split-K) behind vitae_gemm_glds and
  * vitae_linear_bwd_pair_glds (whose halves then go out as two launches).  mode -1 (default): picked per problem by the cost
@@ -149,18 +130,6 @@ int vitae_gemm_glds_set_debug(void* buf);
 int vitae_gemm_glds_set_wgrad_sqnorm(double* slot);
 /* norm_out[0] = sqrt(acc[VITAE_ACC_GRADSQ]) (the finalisation vitae_grad_sqnorm appends, on its own) */
 int vitae_grad_norm_finalize(const double* acc, float* norm_out, void* stream);
-/* Split-K whose partial sums leave the launch as separate matrices ("slabs", z-th at slabs + z * slab_stride floats, each
- * [M, N] fp32) and are summed by the LayerNorm that consumes the result anyway (vitae_layernorm_{fwd,bwd}_slabs) — the
- * launch-boundary reduce: no tickets, no partial round trip inside the launch, no bias / residual / epilogue here.
- * vitae_gemm_glds_slab_count(K, split_k) = the number of slabs produced (k-ranges are multiples of 64). */
-int vitae_gemm_glds_slab_count(int K, int split_k);
-int vitae_gemm_glds_slabs(int a_kcontig, int b_kcontig, const void* A16, long lda, const void* B16, long ldb, float* slabs,
-                          long slab_stride, int M, int N, int K, int split_k, void* stream);
-/* vitae_linear_bwd_pair_glds with the input gradient in slab form (dx_slabs[z][M, K], z over N-ranges of the reduction):
- * for Linears whose input gradient goes straight into a LayerNorm backward (fc1, qkv). */
-int vitae_linear_bwd_pair_glds_slabs(const void* dy16, const void* w16, const void* x16, float* dx_slabs, long slab_stride,
-                                     float* dw, void* dw16, int M, int Mpad, int N, int K, float* dy_colsum_accum,
-                                     int dw_accumulate, int split_k, void* stream);
 /* Backward of one nn.Linear on bf16 operands in one launch: dx / dx16 [M,K] = epi(dy16 W16), optional
  * dx_colsum_accum[k] += sum_m dx(m,k); dW[N,K] (+)= dy16^T x16 reduced over Mpad (>= M, multiple of 64) token
  * rows — rows M..Mpad-1 of dy16 and x16 must be zero. */
@@ -201,39 +170,6 @@ int vitae_layernorm_fwd(const float* x, const float* w, const float* b, float* y
 int vitae_layernorm_bwd(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
                         float* dx, float* dw, float* db, void* dx_bf16, float* dx_colsum_accum, int M, int D,
                         int dx_accumulate, void* stream);
-
-/* The same two on an input that still is `nslabs` partial sums (slab s at slabs + s * slab_stride, each [M, D]; the
- * fused MLP kernels below leave their result that way): forward x_out = residual + bias + sum_s slab_s (bias may be NULL),
- * y_bf16 = LayerNorm(x_out); backward dy = sum_s slab_s.  D in {512, 768, 1024}. */
-int vitae_layernorm_fwd_slabs(const float* slabs, int nslabs, long slab_stride, const float* residual, const float* bias,
-                              const float* w, const float* b, float* x_out, float* y /* optional fp32 copy of the LayerNorm
-                              output */, void* y_bf16, float* mean, float* rstd, int M, int D, float eps, void* stream);
-int vitae_layernorm_bwd_slabs(const float* slabs, int nslabs, long slab_stride, const float* x, const float* w,
-                              const float* mean, const float* rstd, float* dx, float* dw, float* db, void* dx_bf16,
-                              float* dx_colsum_accum, int M, int D, int dx_accumulate, void* stream);
-
-/* ---- the MLP of a transformer block in one launch (Mlp3D.forward, model/vit.py:90-96, inside Block.forward :143) --------
- * forward : h = y16 W1^T + b1 (saved bf16 in hpre16), act16 = gelu(h) (saved: operand of fc2's weight gradient),
- *           slabs[s] = act16[:, s-th 128-slice] W2[:, slice]^T — H/128 partial sums of the fc2 product, [Mpad, d] fp32 each
- *           (sum them with vitae_layernorm_fwd_slabs, which also adds fc2's bias and the residual);
- * backward: dh16 = (dxo16 W2) * gelu'(hpre16) (saved: operand of fc1's weight gradient), slabs[s] = dh16[:, slice] W1[slice, :]
- *           — partial sums of the gradient w.r.t. the LayerNorm output (sum them with vitae_layernorm_bwd_slabs).
- * All matrices bf16, k-contiguous as nn.Linear stores them; token rows padded to Mpad (multiple of 64), pad rows of the
- * inputs zero, pad rows of act16 / dh16 / hpre16 written as zeros.  d in {512, 768, 1024}, H % 128 == 0. */
-int vitae_mlp_fused_supported(int d, int H);
-int vitae_mlp_fused_slabs(int H);
-/* profiling hook (tools/mlp_fused_probe.py): with a device buffer of 8 long long per workgroup set, the following launches
- * record shader-clock stamps at their phase boundaries; NULL switches it off */
-int vitae_mlp_fused_set_debug(void* buf);
-int vitae_mlp_fused_fwd(const void* y16, const void* w1_16, const float* b1, const void* w2_16, void* hpre16, void* act16,
-                        float* slabs, int M, int Mpad, int d, int H, void* stream);
-int vitae_mlp_fused_bwd(const void* dxo16, const void* w1_16, const void* w2_16, const void* hpre16, void* dh16,
-                        float* slabs, int M, int Mpad, int d, int H, void* stream);
-/* Weight gradients of up to four Linears in ONE launch, off the critical path of the backward: for i < n,
- * dw[i][N[i], K[i]] (+)= dy16[i][Mpad, N[i]]^T x16[i][Mpad, K[i]]; optional bf16 copy dw16[i] (NULL array or NULL entries);
- * optional dy_colsum[i][N[i]] += column sums of dy16[i] (the bias gradient).  The pointer arrays and N / K live on the HOST. */
-int vitae_wgrad_group_glds(int n, const void* const* dy16, const void* const* x16, float* const* dw, void* const* dw16,
-                           float* const* dy_colsum, const int* N, const int* K, int Mpad, int dw_accumulate, void* stream);
 
 /* ---- attention core  softmax(q k^T / sqrt(hd)) v  (model/vit.py:117-121) -------------------------
  * qkv [B,N,3,H,hd] (output of the qkv Linear, model/vit.py:114), o [B,N,H*hd], lse/delta [B,H,N]. */

@@ -226,17 +226,6 @@ def test_gemm_glds_forward_forms(lib, C, M, N, K):
     assert rel_err(aux, ref) < 2e-3 and rel_err(y16.float(), F.gelu(ref)) < 1e-2
 
 
-def test_gemm_glds_experimental_tiles():
-    """The 128x128 tiles (4-wave and 8-wave) are off by default; run the forward-form checks with each forced on in a
-    child process (the knobs are read once per process)."""
-    import subprocess, sys
-    for knob in ('VITAE_GLDS_T128', 'VITAE_GLDS_T128W8'):
-        env = dict(os.environ, **{knob: '1'})
-        r = subprocess.run([sys.executable, '-m', 'pytest', __file__, '-q', '-m', 'gpu', '-k', 'glds_forward_forms or linear_bwd_pair_glds',
-                            '-p', 'no:cacheprovider'], env=env, capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, (knob, r.stdout[-2000:], r.stderr[-2000:])
-
-
 def test_gemm_bf16_asymmetric(lib):
     a = torch.eye(64)
     b = torch.arange(64 * 64, dtype=torch.float32).reshape(64, 64) / 128.0
@@ -645,205 +634,9 @@ def test_adamw_and_gradnorm_from_bf16_gradients(lib, C):
     assert abs(float(outs[0][4]) - float(g32[:n].norm())) < 1e-5 * float(g32[:n].norm())
 
 
-# --------------------------------------------------------------------------- fused MLP, slab LayerNorm, grouped wgrad
+# --------------------------------------------------------------------------- bf16-input attention, bf16 pre-activation
 def _bf(t):
     return t.to(torch.bfloat16)
-
-
-@pytest.mark.parametrize('M,d,H', [(440, 768, 3072), (868, 512, 2048), (70, 512, 256), (129, 1024, 512)])
-def test_mlp_fused_fwd_bwd(lib, M, d, H):
-    """vitae_mlp_fused_{fwd,bwd} (Mlp3D, model/vit.py:90-96) against fp32 PyTorch on the same bf16-rounded operands;
-    the slabs are summed by vitae_layernorm_{fwd,bwd}_slabs in the step, by torch here."""
-    assert lib.vitae_mlp_fused_supported(d, H)
-    S = lib.vitae_mlp_fused_slabs(H)
-    Mp = (M + 63) // 64 * 64
-    y = _bf(gen(M, d, seed=1)).float()
-    w1, b1 = _bf(gen(H, d, seed=2, scale=d ** -0.5)).float(), gen(H, seed=3, scale=0.5)
-    w2 = _bf(gen(d, H, seed=4, scale=H ** -0.5)).float()
-    y16 = torch.zeros(Mp, d, dtype=torch.bfloat16, device='cuda'); y16[:M] = _bf(y).cuda()
-    w1d, w2d, b1d = dev(_bf(w1)), dev(_bf(w2)), dev(b1)
-    hpre16 = torch.full((Mp, H), 7.0, dtype=torch.bfloat16, device='cuda')
-    act16 = torch.full((Mp, H), 7.0, dtype=torch.bfloat16, device='cuda')
-    slabs = torch.full((S, Mp, d), float('nan'), device='cuda')
-    lib.vitae_mlp_fused_fwd(y16.data_ptr(), w1d.data_ptr(), b1d.data_ptr(), w2d.data_ptr(), hpre16.data_ptr(), act16.data_ptr(),
-                            slabs.data_ptr(), M, Mp, d, H, st())
-    h = y @ w1.t() + b1
-    act = F.gelu(h)
-    out = _bf(act).float() @ w2.t()
-    assert rel_err(hpre16[:M].float(), h) < 1e-2
-    assert rel_err(act16[:M].float(), act) < 1e-2
-    assert float(hpre16[M:].float().abs().max() if Mp > M else 0.0) == 0.0 and float(act16[M:].float().abs().max() if Mp > M else 0.0) == 0.0
-    got = slabs.sum(0)
-    assert rel_err(got[:M], out) < 1e-2
-    assert float(got[M:].abs().max() if Mp > M else 0.0) == 0.0
-    # backward: dh = (dxo W2) * gelu'(h), dy = dh W1
-    dxo = _bf(gen(M, d, seed=5)).float()
-    dxo16 = torch.zeros(Mp, d, dtype=torch.bfloat16, device='cuda'); dxo16[:M] = _bf(dxo).cuda()
-    dh16 = torch.full((Mp, H), 7.0, dtype=torch.bfloat16, device='cuda')
-    slabs.fill_(float('nan'))
-    lib.vitae_mlp_fused_bwd(dxo16.data_ptr(), w1d.data_ptr(), w2d.data_ptr(), hpre16.data_ptr(), dh16.data_ptr(), slabs.data_ptr(),
-                            M, Mp, d, H, st())
-    hq = hpre16[:M].float().cpu().requires_grad_(True)
-    F.gelu(hq).backward(dxo @ w2)
-    dh = hq.grad
-    assert rel_err(dh16[:M].float(), dh) < 1e-2
-    dy = _bf(dh).float() @ w1
-    got = slabs.sum(0)
-    assert rel_err(got[:M], dy) < 1e-2
-    assert float(dh16[M:].float().abs().max() if Mp > M else 0.0) == 0.0
-
-
-@pytest.mark.parametrize('M,D,S', [(440, 768, 24), (868, 512, 16), (5, 1024, 3), (37, 768, 1)])
-def test_layernorm_slabs(lib, M, D, S):
-    """LayerNorm forward / backward on an input that still is S partial sums (the launch-boundary reduce of the fused MLP)."""
-    Mp = (M + 63) // 64 * 64
-    slabs = gen(S, Mp, D, seed=1, scale=0.3)
-    res, bias, w, b = gen(M, D, seed=2), gen(D, seed=3), 1 + 0.1 * gen(D, seed=4), gen(D, seed=5)
-    sd, rd, bd, wd, bbd = dev(slabs), dev(res), dev(bias), dev(w), dev(b)
-    x_out, yf = torch.empty(M, D, device='cuda'), torch.empty(M, D, device='cuda')
-    y16 = torch.empty(M, D, dtype=torch.bfloat16, device='cuda')
-    mean, rstd = torch.empty(M, device='cuda'), torch.empty(M, device='cuda')
-    lib.vitae_layernorm_fwd_slabs(sd.data_ptr(), S, Mp * D, rd.data_ptr(), bd.data_ptr(), wd.data_ptr(), bbd.data_ptr(), x_out.data_ptr(),
-                                  yf.data_ptr(), y16.data_ptr(), mean.data_ptr(), rstd.data_ptr(), M, D, 1e-6, st())
-    x = res + bias + slabs[:, :M].sum(0)
-    ref = F.layer_norm(x, (D,), w, b, 1e-6)
-    assert rel_err(x_out, x) < 1e-5 and rel_err(yf, ref) < 2e-5 and rel_err(y16.float(), ref) < 1e-2
-    assert rel_err(mean, x.mean(1)) < 1e-4 and rel_err(rstd, (x.var(1, unbiased=False) + 1e-6).rsqrt()) < 1e-4
-    # backward with dy = sum of slabs, accumulating into dx
-    dx0 = gen(M, D, seed=6)
-    dxd = dev(dx0)
-    dw, db, dcs = torch.zeros(D, device='cuda'), torch.zeros(D, device='cuda'), torch.zeros(D, device='cuda')
-    dx16 = torch.empty(M, D, dtype=torch.bfloat16, device='cuda')
-    lib.vitae_layernorm_bwd_slabs(sd.data_ptr(), S, Mp * D, x_out.data_ptr(), wd.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                  dxd.data_ptr(), dw.data_ptr(), db.data_ptr(), dx16.data_ptr(), dcs.data_ptr(), M, D, 1, st())
-    xx = x.clone().requires_grad_(True)
-    ww, bb = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
-    F.layer_norm(xx, (D,), ww, bb, 1e-6).backward(slabs[:, :M].sum(0))
-    want = dx0 + xx.grad
-    assert rel_err(dxd, want) < 5e-5 and rel_err(dx16.float(), want) < 1e-2
-    assert rel_err(dw, ww.grad) < 1e-4 and rel_err(db, bb.grad) < 1e-4 and rel_err(dcs, want.sum(0)) < 1e-4
-
-
-def test_wgrad_group(lib):
-    """Four weight gradients in one launch (the deferred wgrads of one transformer block), with bias gradients and accumulate."""
-    M, Mp, d, H = 440, 448, 768, 3072
-    probs = [(d, H, False), (H, d, True), (d, d, False), (3 * d, d, True)]
-    keep, want = [], []
-    for i, (N, K, has_b) in enumerate(probs):
-        dy, x = _bf(gen(M, N, seed=10 + i)).float(), _bf(gen(M, K, seed=20 + i)).float()
-        dy16 = torch.zeros(Mp, N, dtype=torch.bfloat16, device='cuda'); dy16[:M] = _bf(dy).cuda()
-        x16 = torch.zeros(Mp, K, dtype=torch.bfloat16, device='cuda'); x16[:M] = _bf(x).cuda()
-        dw = torch.full((N, K), float('nan'), device='cuda')
-        dw16 = torch.empty(N, K, dtype=torch.bfloat16, device='cuda') if i == 0 else None
-        db = torch.zeros(N, device='cuda') if has_b else None
-        keep.append((dy16, x16, dw, dw16, db))
-        want.append((dy.t() @ x, dy.sum(0)))
-    arr = lambda vals: np.array(list(vals), dtype=np.uint64)
-    a_dy, a_x, a_dw = arr(k[0].data_ptr() for k in keep), arr(k[1].data_ptr() for k in keep), arr(k[2].data_ptr() for k in keep)
-    a_w16 = arr((0 if k[3] is None else k[3].data_ptr()) for k in keep)
-    a_db = arr((0 if k[4] is None else k[4].data_ptr()) for k in keep)
-    Ns, Ks = np.array([p[0] for p in probs], dtype=np.int32), np.array([p[1] for p in probs], dtype=np.int32)
-    for acc in (0, 1):
-        lib.vitae_wgrad_group_glds(4, a_dy.ctypes.data, a_x.ctypes.data, a_dw.ctypes.data, a_w16.ctypes.data, a_db.ctypes.data,
-                                   Ns.ctypes.data, Ks.ctypes.data, Mp, acc, st())
-        for (dy16, x16, dw, dw16, db), (rw, rb) in zip(keep, want):
-            assert rel_err(dw, (1 + acc) * rw) < 1e-2
-            if db is not None:
-                assert rel_err(db, (1 + acc) * rb) < 1e-2
-            if dw16 is not None:
-                assert rel_err(dw16.float(), (1 + acc) * rw) < 2e-2
-    # fewer than four problems
-    keep[0][2].fill_(float('nan'))
-    lib.vitae_wgrad_group_glds(1, a_dy.ctypes.data, a_x.ctypes.data, a_dw.ctypes.data, None, None, Ns.ctypes.data, Ks.ctypes.data, Mp, 0, st())
-    assert rel_err(keep[0][2], want[0][0]) < 1e-2
-
-
-@pytest.mark.parametrize('M,N,K,split', [(440, 768, 768, 3), (440, 768, 3072, 5), (868, 512, 2048, 4), (70, 512, 512, 1), (130, 1024, 4096, 16)])
-def test_gemm_slab_mode(lib, M, N, K, split):
-    """Split-K whose k-ranges leave the launch as separate matrices (summed by the consuming LayerNorm in the step, by torch here):
-    forward form and the paired backward form with the input gradient in slabs."""
-    Mp = (M + 63) // 64 * 64
-    x, w = _bf(gen(M, K, seed=1)).float(), _bf(gen(N, K, seed=2, scale=K ** -0.5)).float()
-    x16 = torch.zeros(Mp, K, dtype=torch.bfloat16, device='cuda'); x16[:M] = _bf(x).cuda()
-    w16 = dev(_bf(w))
-    n = lib.vitae_gemm_glds_slab_count(K, split)
-    assert 1 <= n <= split
-    slabs = torch.full((n, Mp, N), float('nan'), device='cuda')
-    lib.vitae_gemm_glds_slabs(1, 1, x16.data_ptr(), K, w16.data_ptr(), K, slabs.data_ptr(), Mp * N, M, N, K, split, st())
-    assert rel_err(slabs[:, :M].sum(0), x @ w.t()) < 1e-2
-    # backward pair: dx slabs over the N-ranges of the reduction, dW, bias gradient
-    dy = _bf(gen(M, N, seed=3)).float()
-    dy16 = torch.zeros(Mp, N, dtype=torch.bfloat16, device='cuda'); dy16[:M] = _bf(dy).cuda()
-    nb = lib.vitae_gemm_glds_slab_count(N, split)
-    dxs = torch.full((nb, Mp, K), float('nan'), device='cuda')
-    dw = torch.full((N, K), float('nan'), device='cuda')
-    db = torch.zeros(N, device='cuda')
-    lib.vitae_linear_bwd_pair_glds_slabs(dy16.data_ptr(), w16.data_ptr(), x16.data_ptr(), dxs.data_ptr(), Mp * K, dw.data_ptr(), None,
-                                         M, Mp, N, K, db.data_ptr(), 0, split, st())
-    assert rel_err(dxs[:, :M].sum(0), dy @ w) < 1e-2
-    assert rel_err(dw, dy.t() @ x) < 1e-2 and rel_err(db, dy.sum(0)) < 1e-2
-
-
-@pytest.mark.parametrize('M,N,K,split', [(440, 768, 768, 1), (440, 768, 3072, 5), (868, 512, 2048, 4), (55, 1024, 1024, 1), (130, 768, 768, 1)])
-def test_gemm_rowstats(lib, M, N, K, split):
-    """The producer half of the folded LayerNorm: a residual GEMM that leaves (sum, sum of squares) of its result rows."""
-    x, w = _bf(gen(M, K, seed=1)).float(), _bf(gen(N, K, seed=2, scale=K ** -0.5)).float()
-    bias, res = gen(N, seed=3), gen(M, N, seed=4)
-    y = torch.full((M, N), float('nan'), device='cuda')
-    stats = torch.full((N // 64, M, 2), float('nan'), device='cuda')
-    ws = torch.zeros(max(1, lib.vitae_gemm_glds_ws_floats(M, N, split)), device='cuda')
-    lib.vitae_gemm_glds_stats(1, 1, dev(_bf(x)).data_ptr(), K, dev(_bf(w)).data_ptr(), K, y.data_ptr(), N, None, 0, M, N, K,
-                              dev(bias).data_ptr(), dev(res).data_ptr(), N, 0, None, 0, 0, split, ws.data_ptr(), None, stats.data_ptr(), st())
-    want = x @ w.t() + bias + res
-    assert rel_err(y, want) < 1e-2
-    got = stats.cpu().double()
-    yc = y.cpu().double().reshape(M, N // 64, 64).permute(1, 0, 2)
-    assert torch.allclose(got[..., 0], yc.sum(2), rtol=1e-4, atol=1e-3)
-    assert torch.allclose(got[..., 1], (yc * yc).sum(2), rtol=1e-4, atol=1e-3)
-
-
-@pytest.mark.parametrize('M,N,K,epi', [(440, 2304, 768, 0), (440, 3072, 768, 1), (868, 1536, 512, 0), (868, 2048, 512, 1), (129, 1024, 1024, 0),
-                                       (55, 192, 768, 0)])
-def test_gemm_lnfold(lib, C, M, N, K, epi):
-    """nn.LayerNorm + nn.Linear (model/vit.py:141,143) in one launch: X is normalised on its way into LDS.  Reference: fp32
-    LayerNorm, rounded to bf16 (what the standalone kernel hands the GEMM), times the bf16 weights in fp32."""
-    Mp = (M + 63) // 64 * 64
-    x = gen(M, K, seed=1) * 2.0 + 0.3 * gen(M, 1, seed=5)            # rows with different means
-    gamma, beta = 1.0 + 0.1 * gen(K, seed=6), 0.1 * gen(K, seed=7)
-    w, bias = _bf(gen(N, K, seed=2, scale=K ** -0.5)).float(), gen(N, seed=3)
-    eps = 1e-6
-    xs = x.reshape(M, K // 64, 64).permute(1, 0, 2)
-    stats = torch.stack([xs.sum(2), (xs * xs).sum(2)], 2).contiguous()          # [K / 64, M, 2]
-    y = torch.full((M, N), float('nan'), device='cuda')
-    y16o = torch.full((M, N), float('nan'), device='cuda', dtype=torch.bfloat16)
-    aux = torch.full((M, N), float('nan'), device='cuda') if epi else None
-    ln16 = torch.zeros(Mp, K, device='cuda', dtype=torch.bfloat16)
-    mean, rstd = torch.full((M,), float('nan'), device='cuda'), torch.full((M,), float('nan'), device='cuda')
-    lib.vitae_gemm_glds_lnfold(dev(x).data_ptr(), K, dev(stats).data_ptr(), K // 64, dev(gamma).data_ptr(), dev(beta).data_ptr(), eps,
-                               dev(_bf(w)).data_ptr(), K, y.data_ptr(), N, y16o.data_ptr(), N, M, N, K, dev(bias).data_ptr(),
-                               C['VITAE_EPI_GELU'] if epi else C['VITAE_EPI_NONE'], None if aux is None else aux.data_ptr(), N,
-                               ln16.data_ptr(), K, mean.data_ptr(), rstd.data_ptr(), st())
-    ln = torch.nn.functional.layer_norm(x, (K,), gamma, beta, eps)
-    pre = _bf(ln).float() @ w.t() + bias
-    want = torch.nn.functional.gelu(pre) if epi else pre
-    assert rel_err(y, want) < 1e-2
-    assert rel_err(y16o.float(), want) < 2e-2
-    if epi:
-        assert rel_err(aux, pre) < 1e-2
-    # what the backward reads: bf16 LayerNorm output (one bf16 ulp where the statistics differ in the last bit), mean, rstd
-    got = ln16[:M].float().cpu()
-    assert (got - _bf(ln).float()).abs().max() <= 2.0 ** -6 * ln.abs().max() and rel_err(got, ln) < 5e-3
-    assert torch.all(ln16[M:] == 0)
-    mu = x.mean(1)
-    assert torch.allclose(mean.cpu(), mu, rtol=1e-5, atol=1e-5)
-    assert torch.allclose(rstd.cpu(), (x.var(1, unbiased=False) + eps).rsqrt(), rtol=1e-4, atol=1e-5)
-    # without the backward outputs: same product
-    y2 = torch.full((M, N), float('nan'), device='cuda')
-    lib.vitae_gemm_glds_lnfold(dev(x).data_ptr(), K, dev(stats).data_ptr(), K // 64, dev(gamma).data_ptr(), dev(beta).data_ptr(), eps,
-                               dev(_bf(w)).data_ptr(), K, y2.data_ptr(), N, None, 0, M, N, K, dev(bias).data_ptr(),
-                               C['VITAE_EPI_GELU'] if epi else C['VITAE_EPI_NONE'], None if aux is None else aux.data_ptr(), N,
-                               None, 0, None, None, st())
-    assert torch.equal(y2, y)
 
 
 @pytest.mark.parametrize('B,N,H,hd', [(8, 55, 12, 64), (4, 217, 16, 32), (2, 129, 16, 64), (1, 17, 4, 32)])

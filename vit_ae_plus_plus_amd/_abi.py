@@ -104,8 +104,8 @@ class _Lib:
 
 
 # int-returning entry points whose result is a value, not a status
-_VALUE_RETURNING = {'vitae_abi_version', 'vitae_sdpa_bwd_fused_fits', 'vitae_mlp_fused_supported', 'vitae_mlp_fused_slabs', 'vitae_ddp_available',
-                    'vitae_ddp_world_size', 'vitae_gemm_glds_slab_count', 'vitae_gemm_glds_bt_choice'}
+_VALUE_RETURNING = {'vitae_abi_version', 'vitae_sdpa_bwd_fused_fits', 'vitae_ddp_available',
+                    'vitae_ddp_world_size', 'vitae_gemm_glds_bt_choice'}
 
 lib = _Lib()
 

@@ -560,11 +560,11 @@ bool bt_tile_dims(int id, int& bm, int& bn) {
     }
 }
 
-// p: a complete problem descriptor (splits == 1, slab_stride == 0, no a_rowsum); tiles_m / tiles_n are set here
+// p: a complete problem descriptor (no a_rowsum); tiles_m / tiles_n are set here
 int bt_launch(GArgs p, int a_kc, int b_kc, int id, hipStream_t st) {
     int bm, bn;
     if (!bt_tile_dims(id, bm, bn)) return VITAE_ERR_INVALID_ARG;
-    if (!p.vec_epi || p.slab_stride != 0 || p.a_rowsum || p.rowstats || (p.K % BK) || p.splits < 1) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    if (!p.vec_epi || p.a_rowsum || (p.K % BK) || p.splits < 1) return VITAE_ERR_UNSUPPORTED_SHAPE;
     if (!a_kc && b_kc) return VITAE_ERR_UNSUPPORTED_SHAPE;
     // every split gets k_per_split (a multiple of 64) except the last; each needs >= 2 k-tiles
     p.k_per_split = cdiv(cdiv(p.K, p.splits), BK) * BK;

@@ -94,9 +94,6 @@ __device__ __forceinline__ void epilogue_rows(const GArgs& p, const float (&a)[N
     else if (p.bias && ncol) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
     f32x4 csum = {0.f, 0.f, 0.f, 0.f};
     float sqs = 0.f;
-    float rsum[PASSES], rsq[PASSES];
-#pragma unroll
-    for (int q = 0; q < PASSES; ++q) rsum[q] = rsq[q] = 0.f;
 #pragma unroll
     for (int pb = 0; pb < PASSES; pb += PB) {
         f32x4 ax[PB], rs[PB], co[PB];
@@ -168,25 +165,8 @@ __device__ __forceinline__ void epilogue_rows(const GArgs& p, const float (&a)[N
 #pragma unroll
             for (int e = 0; e < 4; ++e) csum[e] += x[e];
             if (p.sqacc) sqs += (x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3]);
-            if (p.rowstats) { rsum[pb + q] = (x[0] + x[1]) + (x[2] + x[3]); rsq[pb + q] = (x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3]); }
         }
         asm volatile("" ::: "memory");   // keep the next batch's loads behind these stores (register pressure)
-    }
-    if (p.rowstats) {
-        // 64 columns of a row are held by 16 consecutive lanes (4 columns each): butterfly over them, then ONE 8-byte store per
-        // row and 64-column slot — rowstats[slot][m] = (sum, sum of squares); the consumer adds the N / 64 slots of its rows
-        // (no atomics: they cost the launch ~2 us of memory-side round trips at its very end; no zeroing either)
-#pragma unroll
-        for (int q = 0; q < PASSES; ++q) {
-            float a0 = rsum[q], a1 = rsq[q];
-#pragma unroll
-            for (int d = 1; d < 16; d <<= 1) { a0 += __shfl_xor(a0, d, 64); a1 += __shfl_xor(a1, d, 64); }
-            const int m = m0 + r0 + q * RPP;
-            if ((cg & 15) == 0 && m < p.M && ncol) {
-                typedef float f32x2 __attribute__((ext_vector_type(2)));
-                *reinterpret_cast<f32x2*>(p.rowstats + ((long)(n >> 6) * p.M + m) * 2) = f32x2{a0, a1};
-            }
-        }
     }
     if (p.sqacc) {
         // the gradient norm's share of this tile (every stored element exactly once): one double atomic per workgroup, instead
@@ -202,23 +182,13 @@ __device__ __forceinline__ void epilogue_rows(const GArgs& p, const float (&a)[N
     }
 }
 
-// Workgroup tile BM x BN (64x64, 64x128 or 128x128), four waves in a 2 x 2 arrangement: each wave owns
-// (BM/2) x (BN/2) = FM x FN accumulator fragments of 32x32.  128x128 doubles the flop per LDS byte and per L2 byte
-// (64 flop/B from L2 instead of 32) and is picked when a GEMM has enough such tiles to fill the chip.
+// Workgroup tile BM x BN (64x64 or 64x128), four waves in a 2 x 2 arrangement: each wave owns (BM/2) x (BN/2) = FM x FN
+// accumulator fragments of 32x32.  (The 128x128 and 256x256 tiles are a kernel family of their own: gemm_bt.hip.)
 #ifndef VITAE_GLDS_NS_WIDE
 #define VITAE_GLDS_NS_WIDE 2
 #endif
-#ifndef VITAE_GLDS_NS_W8
-#define VITAE_GLDS_NS_W8 4
-#endif
-#ifndef VITAE_GLDS_NS_T128
-#define VITAE_GLDS_NS_T128 2
-#endif
 #ifndef VITAE_GLDS_NACC_BIG
 #define VITAE_GLDS_NACC_BIG 1
-#endif
-#ifndef VITAE_GLDS_INTERLEAVE
-#define VITAE_GLDS_INTERLEAVE 0  // (measured round 2: 4.91 vs 4.87 ms/step with it — the GEMMs mostly share a CU) DMA pieces of the stage being refilled are issued one by one between the MFMAs of a k-step
 #endif
 #ifndef VITAE_GLDS_NS_PAIR
 #define VITAE_GLDS_NS_PAIR 0     // > 0: stages of the 64x64 tiles inside the paired (dgrad + wgrad) launch.  Measured in the step
@@ -227,10 +197,8 @@ __device__ __forceinline__ void epilogue_rows(const GArgs& p, const float (&a)[N
 #endif
 template <int BM, int BN, int NW = 4, bool PAIR = false> struct GCfg {
     // stages: 3 for 64x64 (48 KB, three workgroups per CU); the wider 4-wave tiles take 2 (48 KB for 64x128 -> three
-    // workgroups per CU instead of two: decoder_pred fwd 49.8 -> 45.6 us) — occupancy beats prefetch depth there;
-    // the 8-wave 128x128 workgroup is alone on its CU and takes 4 (128 KB, three 32 KB tiles in flight)
-    static constexpr int NST = NW == 8 ? VITAE_GLDS_NS_W8 : (BM * BN > 64 * 128) ? VITAE_GLDS_NS_T128 : (BM * BN > 64 * 64) ? VITAE_GLDS_NS_WIDE
-                               : (PAIR && VITAE_GLDS_NS_PAIR > 0) ? VITAE_GLDS_NS_PAIR : NS;
+    // workgroups per CU instead of two: decoder_pred fwd 49.8 -> 45.6 us) — occupancy beats prefetch depth there
+    static constexpr int NST = (BM * BN > 64 * 64) ? VITAE_GLDS_NS_WIDE : (PAIR && VITAE_GLDS_NS_PAIR > 0) ? VITAE_GLDS_NS_PAIR : NS;
     static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES, SMEM = NST * STAGE;
 };
 
@@ -286,14 +254,6 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
         unsigned char* st = smem + (t % NST) * STAGE;
         dma_tile<BM, A_KC, NW>(p.A, p.lda, p.M, m0, kbeg + t * BK, st, wave, lane);
         dma_tile<BN, B_KC, NW>(p.B, p.ldb, p.N, n0, kbeg + t * BK, st + A_BYTES, wave, lane);
-    };
-    // one DMA instruction (1 KB) of the stage of tile t: pieces 0..NA-1 belong to A, the rest to B
-    constexpr int NA = pieces<BM, A_KC, NW>(), NB = pieces<BN, B_KC, NW>();
-    static_assert(NA + NB == G, "DMA pieces per wave and stage");
-    auto piece = [&](int t, int i) {
-        unsigned char* st = smem + (t % NST) * STAGE;
-        if (i < NA) dma_piece<BM, A_KC, NW>(p.A, p.lda, p.M, m0, kbeg + t * BK, st, wave, lane, i);
-        else dma_piece<BN, B_KC, NW>(p.B, p.ldb, p.N, n0, kbeg + t * BK, st + A_BYTES, wave, lane, i - NA);
     };
     EpiPre epre;
     epilogue_prefetch<BM, BN, NW>(p, m0, n0, epre);     // older than every DMA: the counted waits below never see these loads
@@ -372,9 +332,7 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
         if (t == 0) stamp(2);
         if (t == 4) stamp(9);
         const bool more = t + NST - 1 < nk;    // the stage tile t-1 used is refilled with tile t + NST - 1 ...
-#if !VITAE_GLDS_INTERLEAVE
         if (more) issue(t + NST - 1);
-#endif
         if (t == 4) stamp(10);
         const unsigned char* at = smem + (t % NST) * STAGE;
         const unsigned char* bt = at + A_BYTES;
@@ -400,33 +358,16 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
         }
         if (t == 4 && p.dbg) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp(11); }
         __builtin_amdgcn_sched_barrier(0);
-        // ... one DMA piece after each MFMA: a piece occupies the wave while the texture addresser takes its 64 lanes
-        // (16-100 clocks), the matrix pipe runs beside it.  With ONE workgroup on a CU (every GEMM of the step with fewer
-        // than ~256 tiles) nobody else overlaps the two: issued as a block in front of the fragment reads, the pieces
-        // of a stage cost as much wave time as its MFMAs (measured on the fused MLP kernel).
+        // (DMA pieces issued one by one between these MFMAs instead of as a block above: measured 4.91 vs 4.87 ms per step
+        // here, where the GEMMs mostly share a CU — removed; the big tiles of gemm_bt.hip, alone on their CU, do issue that way)
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk)
 #pragma unroll
             for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
-                for (int fn = 0; fn < FN; ++fn) {
+                for (int fn = 0; fn < FN; ++fn)
                     acc[kk % NACC][fm * FN + fn] =
                         __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][fm], fb[kk][fn], acc[kk % NACC][fm * FN + fn], 0, 0, 0);
-#if VITAE_GLDS_INTERLEAVE
-                    constexpr int NMF = (BK / 16) * FM * FN;
-                    const int i = (kk * FM + fm) * FN + fn;
-                    // spread the G pieces over the NMF MFMAs (NMF >= G for every tile shape)
-                    if (i < G || (NMF < G && i == NMF - 1)) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (more) {
-                            piece(t + NST - 1, i);
-                            if (NMF < G && i == NMF - 1)
-                                for (int r = NMF; r < G; ++r) piece(t + NST - 1, r);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-#endif
-                }
         if (t == 3) stamp(12);
         if (t == 4) stamp(13);
         if constexpr (RS) {
@@ -457,7 +398,7 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
 #pragma unroll
         for (int r = 0; r < 16; ++r) a[f][r] = NACC == 2 ? acc[0][f][r] + acc[NACC - 1][f][r] : acc[0][f][r];
 
-    if (p.splits > 1 && p.slab_stride == 0) {
+    if (p.splits > 1) {
         // Split-K fix-up without a second launch: every split parks its partial tile (fragment order, coalesced),
         // takes a ticket, and the LAST one to arrive sums all partials in split order (bitwise reproducible whatever
         // the arrival order) and runs the epilogue.  Fences: release before the ticket, acquire after it.
@@ -518,11 +459,9 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
     }
 
     stamp(5);
-    GArgs q = p;
-    if (p.slab_stride != 0) q.C = p.C + (long)zid * p.slab_stride;      // slab mode: this split's own result matrix
     if constexpr (BM * BN <= 64 * 128 && NW == 4) {
         if (p.vec_epi) {
-            epilogue_rows<BM, BN, NW, NF>(q, a, m0, n0, wm, wn, lane, smem, epre);
+            epilogue_rows<BM, BN, NW, NF>(p, a, m0, n0, wm, wn, lane, smem, epre);
             stamp(6);
             if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(7); }
             return;
@@ -534,7 +473,7 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
         const int n = n0 + wn * (BN / 2) + fn * 32 + l31;
         float csum = 0.f;
 #pragma unroll
-        for (int fm = 0; fm < FM; ++fm) csum += epilogue_frag(q, a[fm * FN + fn], m0 + wm * (BM / WAVES_M) + fm * 32, n, hi, sqsum);
+        for (int fm = 0; fm < FM; ++fm) csum += epilogue_frag(p, a[fm * FN + fn], m0 + wm * (BM / WAVES_M) + fm * 32, n, hi, sqsum);
         if (p.out_colsum) {
             csum += __shfl_xor(csum, 32, 64);
             if (hi == 0 && n < p.N) atomicAdd(p.out_colsum + n, csum);
@@ -561,265 +500,6 @@ __global__ __launch_bounds__(256) void gemm_glds_pipe_kernel(const GArgs p) {
     gemm_glds_body<64, 64, true, true, 4, false, false, VITAE_GLDS_PIPE_STAGES>(p, blockIdx.x, blockIdx.z, smem);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// LayerNorm folded into the GEMM that consumes it (model/vit.py:141, 143: qkv(norm1(x)), fc1(norm2(x))):
-//   C[M, N] = epi( LN(X)[M, K] @ W16[N, K]^T + bias ),   LN(X)(m, k) = (X(m, k) - mean_m) * rstd_m * gamma_k + beta_k
-// X is the fp32 residual stream; its row statistics (sum, sum of squares) were left by the epilogue of the GEMM that produced
-// it (vitae_gemm_glds_stats).  The A operand therefore never exists in HBM as a GEMM operand: every workgroup loads its
-// 64 x 64 slice of X through registers (16 floats per thread and k-step, two k-steps ahead), normalises, rounds to bf16 and
-// writes the slice into the LDS stage in the very image the LDS-DMA path produces (chunk slot = chunk ^ swz(row)), so the
-// fragment reads and the MFMA loop are the pipelined loop of gemm_glds_pipe_kernel; W still arrives by LDS-DMA.  The
-// workgroups of column tile 0 also store what they normalised (Y16: the wgrad operand of the backward) and the row's mean / rstd
-// (LayerNorm backward) — so the standalone LayerNorm launch (4.9 us x 38 per step) disappears and nothing is computed twice
-// that is stored.  One 64 x 64 tile per workgroup, 4 stages, no split-K (K = 512 .. 1024 here).
-// Register-path global loads of a loop that also keeps LDS-DMA in flight, as INLINE ASM: hipcc treats every global_load_lds as
-// a FLAT access that may hit LDS ("pending flat": results may return out of order), so its own wait for any compiler-visible VMEM
-// load issued in such a loop is s_waitcnt vmcnt(0) — which drains the whole DMA prefetch each time the loaded registers are
-// used (seen in the ISA of the first versions of lnfold_loop).  The compiler cannot see these loads, so the CALLER orders them:
-// a counted wait_vmcnt_n() and vm_tie() on every destination before its first use.
-template <int OFF> __device__ __forceinline__ void gload16(f32x4& r, const float* p) {
-    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(r) : "v"(p), "n"(OFF) : "memory");
-}
-__device__ __forceinline__ void vm_tie(f32x4& r) { asm volatile("" : "+v"(r)); }
-__device__ __forceinline__ void wait_vmcnt_n(int n) {     // n is a compile-time constant after unrolling
-    switch (n) {
-#define VITAE_W(i) case i: wait_vmcnt<i>(); break;
-        VITAE_W(0) VITAE_W(1) VITAE_W(2) VITAE_W(3) VITAE_W(4) VITAE_W(5) VITAE_W(6) VITAE_W(7) VITAE_W(8) VITAE_W(9) VITAE_W(10)
-        VITAE_W(11) VITAE_W(12) VITAE_W(13) VITAE_W(14) VITAE_W(15) VITAE_W(16) VITAE_W(17) VITAE_W(18) VITAE_W(19) VITAE_W(20)
-        VITAE_W(21) VITAE_W(22) VITAE_W(23) VITAE_W(24) VITAE_W(25) VITAE_W(26) VITAE_W(27) VITAE_W(28) VITAE_W(29) VITAE_W(30)
-        VITAE_W(31) VITAE_W(32) VITAE_W(33) VITAE_W(34) VITAE_W(35) VITAE_W(36) VITAE_W(37) VITAE_W(38) VITAE_W(39) VITAE_W(40)
-#undef VITAE_W
-        default: wait_vmcnt<0>(); break;
-    }
-}
-
-// VMEM issue order of lnfold_loop (per wave), for the counted waits.  Prologue: W0, W1 (GB each), X0, X1 (GA each), Y0, Y1 (YS
-// each: the four Y16 stores of a writer), X2, W2, X3.  Step s: W(s + 3), Y(s + 2), X(s + 4) — each only while that tile exists.
-template <bool WRITER, int NK> struct LnfSeq {
-    static constexpr int GA = 4, GB = 2, YS = WRITER ? 4 : 0;
-    static constexpr int ys(int s) { return s + 2 < NK ? YS : 0; }
-    static constexpr int al(int s) { return s + 4 < NK ? GA : 0; }
-    static constexpr int bd(int s) { return s + 3 < NK ? GB : 0; }
-    static constexpr int step_ops(int s) { return bd(s) + ys(s) + al(s); }
-    // operations younger than X(t + 2) (the LAST thing step t - 2 issued) when step t, having issued W(t + 3), writes it to LDS
-    static constexpr int after_x(int t) { return t == 0 ? GB + GA + bd(0) : step_ops(t - 1) + bd(t); }
-    // operations younger than W(t + 1) (the FIRST thing step t - 2 issued) once step t has issued W(t + 3)
-    static constexpr int after_w(int t) {
-        return t == 0 ? (4 * GA + 2 * YS + GB) + bd(0)          // X0 X1 Y0 Y1 X2 W2 X3 | W3
-             : t == 1 ? GA + step_ops(0) + bd(1)               // X3 | step 0 | W4
-             : ys(t - 2) + al(t - 2) + step_ops(t - 1) + bd(t);
-    }
-};
-
-struct LArgs {
-    const float* X; long ldx;
-    const float* stats; int nparts;      // stats[s][M][2], s < nparts: partial (sum, sum of squares) of the rows of X
-    const float* gamma; const float* beta;
-    float eps;
-    __bf16* Y16; long ldy;
-    float* mean; float* rstd;
-};
-
-constexpr int LNF_KMAX = 1024;
-
-template <bool WRITER, int NK>
-__device__ __forceinline__ void lnfold_loop(const GArgs& p, const LArgs& l, unsigned char* smem, f32x16 (&acc)[2][1], const int m0,
-                                            const int n0, const int wave, const int lane, const int wm, const int wn) {
-    constexpr int NST = 4, STAGE = GCfg<64, 64, 4>::STAGE, A_BYTES = GCfg<64, 64, 4>::A_BYTES, GB = 2, GA = 4;
-    const float* gb = reinterpret_cast<const float*>(smem + NST * STAGE);
-    // X slice (64 rows x 64 k, fp32) -> registers: lane l of wave w takes the 16-byte segment seg = l & 7 of a 128-byte half
-    // row, rows w * 16 + (l >> 3) and + 8: every load instruction covers 8 rows x one whole 128-byte line (a first version
-    // with 64 contiguous bytes per THREAD touched every line from four instructions and cost +0.4 us per k-step in the
-    // texture addresser).  Load j: row (j >> 1), half (j & 1).
-    const int seg = lane & 7, rw0 = wave * 16 + (lane >> 3);
-    float mu[2], rs[2];                      // filled in the prologue, behind the first operand loads
-    const int mrow[2] = {m0 + rw0, m0 + rw0 + 8};
-    const float* xsrc[2] = {l.X + (long)min(mrow[0], p.M - 1) * l.ldx + 4 * seg, l.X + (long)min(mrow[1], p.M - 1) * l.ldx + 4 * seg};
-    // LDS image of the k-contiguous tile: [row][8 chunks of 16 B], chunk slot = chunk ^ swz(row); this thread's 4 bf16 of
-    // (row i, half h) are the (seg & 1) half of chunk 4 h + (seg >> 1)
-    unsigned a_off[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = rw0 + 8 * (j >> 1), c = 4 * (j & 1) + (seg >> 1);
-        a_off[j] = r * 128 + ((c ^ ((r >> 1) & 7)) << 4) + (seg & 1) * 8;
-    }
-    auto aload = [&](int t, f32x4 (&ra)[GA]) {
-        const float* s0 = xsrc[0] + t * BK;
-        const float* s1 = xsrc[1] + t * BK;
-        gload16<0>(ra[0], s0); gload16<128>(ra[1], s0); gload16<0>(ra[2], s1); gload16<128>(ra[3], s1);
-    };
-    auto aready = [&](int younger, f32x4 (&ra)[GA]) {          // the loads into ra are complete once <= `younger` VMEM ops are out
-        wait_vmcnt_n(younger);
-#pragma unroll
-        for (int j = 0; j < GA; ++j) vm_tie(ra[j]);
-    };
-    auto awrite = [&](int t, const f32x4 (&ra)[GA]) {
-        const float* g = gb + t * BK + 4 * seg;
-        const f32x4 gg[2] = {*reinterpret_cast<const f32x4*>(g), *reinterpret_cast<const f32x4*>(g + 32)};
-        const f32x4 bb[2] = {*reinterpret_cast<const f32x4*>(g + p.K), *reinterpret_cast<const f32x4*>(g + p.K + 32)};
-        unsigned char* st = smem + (t % NST) * STAGE;
-#pragma unroll
-        for (int j = 0; j < GA; ++j) {
-            const int i = j >> 1, h = j & 1;
-            bf16x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (__bf16)((ra[j][e] - mu[i]) * rs[i] * gg[h][e] + bb[h][e]);
-            *reinterpret_cast<bf16x4*>(st + a_off[j]) = o;
-            if (WRITER) {
-                // UNCONDITIONAL (the wait counts of LnfSeq assume these stores from every wave: a wave whose rows all lie
-                // beyond M must not branch around them): rows >= M of the 64-row padded Y16 receive zeros, which is what the
-                // padding holds anyway (the wgrad reduces over the padded rows)
-                if (mrow[i] >= p.M) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (__bf16)0.f;
-                }
-                *reinterpret_cast<bf16x4*>(l.Y16 + (long)mrow[i] * l.ldy + t * BK + 32 * h + 4 * seg) = o;
-            }
-        }
-    };
-    auto bdma = [&](int t) {
-        dma_tile<64, true, 4>(p.B, p.ldb, p.N, n0, t * BK, smem + (t % NST) * STAGE + A_BYTES, wave, lane);
-    };
-    bf16x8 fa[2][BK / 16][1], fb[2][BK / 16][1];
-    auto rd = [&](int t, bf16x8 (&xa)[BK / 16][1], bf16x8 (&xb)[BK / 16][1]) {
-        const unsigned char* at = smem + (t % NST) * STAGE;
-#pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-            xa[kk][0] = frag<64, true>(at, wm * 32, kk, lane);
-            xb[kk][0] = frag<64, true>(at + A_BYTES, wn * 32, kk, lane);
-        }
-    };
-    auto mm = [&](bf16x8 (&xa)[BK / 16][1], bf16x8 (&xb)[BK / 16][1]) {
-#pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk)
-            acc[kk & 1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[kk][0], xb[kk][0], acc[kk & 1][0], 0, 0, 0);
-    };
-    // ---- prologue: W tiles 0, 1 by DMA, X slices 0, 1 through registers into their stages, then the steady-state pattern
-    static_assert(NK >= 4, "k-steps");
-    f32x4 ra[2][GA];
-    using Seq = LnfSeq<WRITER, NK>;
-    static_assert(Seq::GA == GA && Seq::GB == GB, "issue bookkeeping");
-    auto stamp = [&](int i) {
-        if (p.dbg && threadIdx.x == 0) p.dbg[(long)blockIdx.x * 16 + i] = __builtin_amdgcn_s_memtime();
-    };
-    stamp(0);
-    bdma(0);
-    bdma(1);
-    aload(0, ra[0]);
-    aload(1, ra[1]);
-    stamp(1);
-    // behind the first operand loads (one memory latency for everything the k-loop needs): gamma | beta -> LDS, and the row
-    // statistics -> mean, rstd of this thread's two rows
-    {
-        float* gbw = reinterpret_cast<float*>(smem + NST * STAGE);
-        const int i4 = threadIdx.x * 4;                            // K <= 1024: one 16-byte piece of each per thread
-        f32x4 gv = {0.f, 0.f, 0.f, 0.f}, bv = gv;
-        if (i4 < p.K) { gv = *reinterpret_cast<const f32x4*>(l.gamma + i4); bv = *reinterpret_cast<const f32x4*>(l.beta + i4); }
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        f32x2 part[2][NK];                   // X has K = 64 NK columns: NK partial slots per row
-        const float invk = 1.f / (float)p.K;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int mc = min(mrow[i], p.M - 1);
-#pragma unroll
-            for (int sl = 0; sl < NK; ++sl) part[i][sl] = *reinterpret_cast<const f32x2*>(l.stats + ((long)sl * p.M + mc) * 2);
-        }
-        if (i4 < p.K) { *reinterpret_cast<f32x4*>(gbw + i4) = gv; *reinterpret_cast<f32x4*>(gbw + p.K + i4) = bv; }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-            for (int sl = 0; sl < NK; ++sl) { s0 += part[i][sl][0]; s1 += part[i][sl][1]; }
-            mu[i] = s0 * invk;
-            rs[i] = rsqrtf(fmaxf(s1 * invk - mu[i] * mu[i], 0.f) + l.eps);
-            if (WRITER && seg == 0 && mrow[i] < p.M && l.mean) { l.mean[mrow[i]] = mu[i]; l.rstd[mrow[i]] = rs[i]; }
-        }
-        __syncthreads();                     // gamma | beta visible to everyone (drains the VMEM queue: every load above landed)
-    }
-    stamp(2);
-    aready(GA, ra[0]);                     // younger than X0: X1
-    awrite(0, ra[0]);
-    aready(Seq::YS, ra[1]);                // younger than X1: the Y16 stores of slice 0
-    awrite(1, ra[1]);
-    aload(2, ra[0]);
-    bdma(2);
-    aload(3, ra[1]);
-    // (W tiles 0 and 1 are older than X1: landed)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    rd(0, fa[0], fb[0]);
-    stamp(3);
-    // Step t: DMA W tile t + 3; W tile t + 1 landed -> barrier -> its fragments; the MFMAs of tile t; and BEHIND them (the matrix
-    // pipe works on its own while the wave issues VALU) X slice t + 2 is normalised into its stage from the registers loaded
-    // two steps ago, which are then refilled with slice t + 4.  The X loads are invisible to the compiler (gload16): the
-    // wait counts are constants of the step (LnfSeq).  Steps 0, 1 (prologue-dependent counts) and the last four (the pipeline
-    // drains) are peeled; the steady state is a ROLLED loop of two steps (the two register sets alternate) — fully unrolled,
-    // the kernel is ~1000 instructions per variant, and a launch that short pays for its instruction fetches.
-#define LNF_STEP(T, P, AW, AL, BD, NEXT, WAITW, WAITX)                                                                 \
-    {                                                                                                                  \
-        if (BD) bdma((T) + 3);                                                                                         \
-        if (NEXT) wait_vmcnt<(WAITW)>();                                                                               \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                             \
-        __builtin_amdgcn_s_barrier();                                                                                  \
-        if (NEXT) rd((T) + 1, fa[(P) ^ 1], fb[(P) ^ 1]);                                                               \
-        __builtin_amdgcn_sched_barrier(0);                                                                             \
-        mm(fa[P], fb[P]);                                                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                                             \
-        if (AW) {                                                                                                      \
-            wait_vmcnt<(WAITX)>();                                                                                     \
-            for (int j_ = 0; j_ < GA; ++j_) vm_tie(ra[P][j_]);                                                         \
-            awrite((T) + 2, ra[P]);                                                                                    \
-        }                                                                                                              \
-        if (AL) aload((T) + 4, ra[P]);                                                                                 \
-    }
-    static_assert(NK >= 8 && NK % 2 == 0, "k-steps");
-    LNF_STEP(0, 0, true, true, true, true, Seq::after_w(0), Seq::after_x(0))
-    LNF_STEP(1, 1, true, true, true, true, Seq::after_w(1), Seq::after_x(1))
-    stamp(4);
-#pragma unroll 1
-    for (int t = 2; t < NK - 4; t += 2) {
-        LNF_STEP(t, 0, true, true, true, true, Seq::after_w(2), Seq::after_x(2))
-        LNF_STEP(t + 1, 1, true, true, true, true, Seq::after_w(2), Seq::after_x(2))
-    }
-    static_assert(Seq::after_w(2) == Seq::after_w(NK - 5) && Seq::after_x(3) == Seq::after_x(NK - 5), "steady state");
-    stamp(5);
-    LNF_STEP(NK - 4, 0, true, false, true, true, Seq::after_w(NK - 4), Seq::after_x(NK - 4))
-    LNF_STEP(NK - 3, 1, true, false, false, true, Seq::after_w(NK - 3), Seq::after_x(NK - 3))
-    LNF_STEP(NK - 2, 0, false, false, false, true, Seq::after_w(NK - 2), 0)
-    LNF_STEP(NK - 1, 1, false, false, false, false, 0, 0)
-    stamp(6);
-#undef LNF_STEP
-}
-
-template <int NK>
-__global__ __launch_bounds__(256) void gemm_glds_lnfold_kernel(const GArgs p, const LArgs l) {
-    constexpr int NST = 4, STAGE = GCfg<64, 64, 4>::STAGE;
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE + 2 * LNF_KMAX * 4];
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, local = bid >> 3;
-    const int tn = p.xcd_m ? local % p.tiles_n : xcd + 8 * (local / p.tiles_m);
-    const int tm = p.xcd_m ? xcd + 8 * (local / p.tiles_n) : local % p.tiles_m;
-    if (tn >= p.tiles_n || tm >= p.tiles_m) return;
-    const int m0 = tm * 64, n0 = tn * 64;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    EpiPre epre;
-    epilogue_prefetch<64, 64, 4>(p, m0, n0, epre);
-    f32x16 acc[2][1];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[h][0][i] = 0.f;
-    if (tn == 0 && l.Y16) lnfold_loop<true, NK>(p, l, smem, acc, m0, n0, wave, lane, wm, wn);
-    else lnfold_loop<false, NK>(p, l, smem, acc, m0, n0, wave, lane, wm, wn);
-    float a[1][16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) a[0][r] = acc[0][0][r] + acc[1][0][r];
-    epilogue_rows<64, 64, 4, 1>(p, a, m0, n0, wm, wn, lane, smem, epre);
-    if (p.dbg && threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p.dbg[(long)blockIdx.x * 16 + 7] = __builtin_amdgcn_s_memtime(); }
-}
-
 // dgrad (dy @ W: A k-contiguous, B = bf16 weights read row-contiguous) and wgrad (dy^T @ x: both operands
 // row-contiguous) of one Linear in one launch — they share dy, and together they double the resident
 // workgroups per CU.
@@ -830,21 +510,6 @@ __global__ __launch_bounds__(256) void gemm_glds_pair_kernel(const GArgs p1, con
     // nb1 = workgroups of one dgrad split; the dgrad's long reduction (N of the Linear) is cut into p1.splits
     if ((int)blockIdx.x < nb1 * p1.splits) gemm_glds_body<BM1, BN1, true, false, 4, false, true>(p1, blockIdx.x % nb1, blockIdx.x / nb1, smem);
     else gemm_glds_body<BM2, BN2, false, false, 4, RS, true>(p2, blockIdx.x - nb1 * p1.splits, 0, smem);
-}
-
-// Up to four independent wgrad problems dW_i[N_i, K_i] (+)= dy_i^T x_i (64x64 tiles, both operands row-contiguous, reduced over
-// the padded token count) in ONE launch: the weight gradients of a transformer block are off the critical path of the backward
-// (nothing reads them before the optimiser), so the engine defers them to a side stream and issues them as one fat launch per
-// block instead of pairing each with its dgrad.  Block ranges start at multiples of 8, so the XCD mapping of every problem holds.
-struct GGroup { GArgs p[4]; int start[5]; };
-
-__global__ __launch_bounds__(256) void gemm_glds_group_kernel(const GGroup g) {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[GCfg<64, 64, 4>::SMEM];
-    const int b = blockIdx.x;
-    if (b < g.start[1]) gemm_glds_body<64, 64, false, false, 4, true>(g.p[0], b, 0, smem);
-    else if (b < g.start[2]) gemm_glds_body<64, 64, false, false, 4, true>(g.p[1], b - g.start[1], 0, smem);
-    else if (b < g.start[3]) gemm_glds_body<64, 64, false, false, 4, true>(g.p[2], b - g.start[2], 0, smem);
-    else gemm_glds_body<64, 64, false, false, 4, true>(g.p[3], b - g.start[3], 0, smem);
 }
 
 template <int BM, int BN, int NW = 4>
@@ -889,18 +554,10 @@ inline int xcd_by_rows(int M, int N) {
     return M > N;
 }
 
-// 0: 64x64, 1: 64x128, 2: 128x128 — the largest tile that still yields enough workgroups for 256 CUs.
-// 128x128 is OFF by default (VITAE_GLDS_T128 = minimum tile count to use it): with 128 accumulator + 150 other
-// registers and 96 KB of LDS only one 4-wave workgroup fits a CU, and the DMA / LDS / MFMA chain of a single workgroup
-// does not overlap with anything — measured slower than 64x128 at two workgroups per CU on every large GEMM of the
-// step (decoder_pred fwd 54.7 -> 72.5 us, its wgrad 85.7 -> 148 us).  The 8-wave 128x128 workgroup (id 3,
-// VITAE_GLDS_T128W8; four stages, 128 KB of LDS) comes closer but still loses to 64x128 (fwd 53.8 vs 49.4 us, the
-// row-contiguous wgrad 103 vs 71 us): both stay OFF and are exercised by the tests through the environment knobs.
+// 0: 64x64, 1: 64x128 — the wider tile once it still yields enough workgroups for 256 CUs.  (A 128x128 tile inside THIS
+// kernel — 4 waves / 96 KB or 8 waves / 128 KB of LDS, one workgroup per CU — lost to 64x128 on every large GEMM of the step,
+// decoder_pred fwd 54.7 -> 72.5 / 53.8 us: removed in round 3; the big tiles that do win have their own schedule, gemm_bt.hip.)
 inline Tile pick_tile(int M, int N) {
-    static const int t128 = getenv("VITAE_GLDS_T128") ? atoi(getenv("VITAE_GLDS_T128")) : 0;
-    static const int t128w8 = getenv("VITAE_GLDS_T128W8") ? atoi(getenv("VITAE_GLDS_T128W8")) : 0;
-    if (N >= 128 && M >= 128 && t128w8 > 0 && (long)cdiv(M, 128) * cdiv(N, 128) >= t128w8) return {128, 128, 3};   // 8 waves
-    if (N >= 128 && M >= 128 && t128 > 0 && (long)cdiv(M, 128) * cdiv(N, 128) >= t128) return {128, 128, 2};
     static const int wide_min = getenv("VITAE_GLDS_WIDE_MIN_TILES") ? atoi(getenv("VITAE_GLDS_WIDE_MIN_TILES")) : 400;
     if (N >= 128 && (long)cdiv(M, 64) * cdiv(N, 128) >= wide_min) return {64, 128, 1};
     return {64, 64, 0};
@@ -974,8 +631,7 @@ template <int BM1, int BN1>
 void launch_pair(int id2, dim3 grid, hipStream_t st, const GArgs& p1, const GArgs& p2, int nb1) {
     dim3 block(256);
     if (id2 == 0) hipLaunchKernelGGL((gemm_glds_pair_kernel<BM1, BN1, 64, 64>), grid, block, 0, st, p1, p2, nb1);
-    else if (id2 == 1) hipLaunchKernelGGL((gemm_glds_pair_kernel<BM1, BN1, 64, 128>), grid, block, 0, st, p1, p2, nb1);
-    else hipLaunchKernelGGL((gemm_glds_pair_kernel<BM1, BN1, 128, 128>), grid, block, 0, st, p1, p2, nb1);
+    else hipLaunchKernelGGL((gemm_glds_pair_kernel<BM1, BN1, 64, 128>), grid, block, 0, st, p1, p2, nb1);
 }
 
 }  // namespace
@@ -1012,7 +668,7 @@ extern "C" int vitae_gemm_glds_set_ws_capacity(long floats) {
 static int gemm_glds_launch(int a_kcontig, int b_kcontig, const void* A16, long lda, const void* B16, long ldb,
                             float* C, long ldc, void* C16, long ldc16, int M, int N, int K, const float* bias,
                             const float* residual, long ldr, int epi, float* aux, long ldaux, int accumulate,
-                            int split_k, float* splitk_ws, float* out_colsum_accum, float* out_rowstats, void* stream,
+                            int split_k, float* splitk_ws, float* out_colsum_accum, void* stream,
                             const BtPlan* forced = nullptr) {
     if (!A16 || !B16 || (!C && !C16) || M <= 0 || N <= 0 || K <= 0) return VITAE_ERR_INVALID_ARG;
     const int aux16 = (epi & VITAE_EPI_AUX_BF16) != 0;
@@ -1038,21 +694,19 @@ static int gemm_glds_launch(int a_kcontig, int b_kcontig, const void* A16, long 
     p.k_per_split = kps; p.splits = split_k;
     p.bias = bias; p.residual = residual; p.ldr = ldr; p.aux = aux; p.ldaux = ldaux;
     p.epi = epi; p.aux16 = aux16; p.accumulate = accumulate; p.ws = splitk_ws; p.out_colsum = out_colsum_accum; p.a_rowsum = nullptr;
-    p.dbg = g_gemm_dbg; p.slab_stride = 0;
+    p.dbg = g_gemm_dbg;
     const Tile t = pick_tile(M, N);
     p.tiles_m = cdiv(M, t.bm); p.tiles_n = cdiv(N, t.bn);
     p.xcd_m = xcd_by_rows(M, N);
     p.vec_epi = vec_epilogue_ok(p);
-    p.rowstats = out_rowstats;
     if (!a_kcontig && !b_kcontig) p.sqacc = g_wgrad_sqacc;      // the weight-gradient form (dy^T @ x)
-    if (!out_rowstats && p.vec_epi) {
+    if (p.vec_epi) {
         const BtPlan bp = forced ? *forced : bt_plan(M, N, K, a_kcontig, b_kcontig, epi != VITAE_EPI_GELU);
         if (bp.tile >= 0 && bp.split == split_k) {
             p.splits = split_k;
             return bt_launch(p, a_kcontig, b_kcontig, bp.tile, (hipStream_t)stream);
         }
     }
-    if (out_rowstats && (!p.vec_epi || t.id > 1)) return VITAE_ERR_UNSUPPORTED_SHAPE;   // taken in the row-major epilogue only
     if (split_k > 1 && (long)p.tiles_m * p.tiles_n > VITAE_GLDS_TICKETS) return VITAE_ERR_UNSUPPORTED_SHAPE;
     dim3 grid(glds_blocks(p), 1, split_k);
     hipStream_t st = (hipStream_t)stream;
@@ -1061,9 +715,7 @@ static int gemm_glds_launch(int a_kcontig, int b_kcontig, const void* A16, long 
         hipLaunchKernelGGL(gemm_glds_pipe_kernel, grid, dim3(256), 0, st, p);
         return vitae_launch_status();
     }
-    if (t.id == 3) launch<128, 128, 8>(p, a_kcontig != 0, b_kcontig != 0, grid, st);
-    else if (t.id == 2) launch<128, 128>(p, a_kcontig != 0, b_kcontig != 0, grid, st);
-    else if (t.id == 1) launch<64, 128>(p, a_kcontig != 0, b_kcontig != 0, grid, st);
+    if (t.id == 1) launch<64, 128>(p, a_kcontig != 0, b_kcontig != 0, grid, st);
     else launch<64, 64>(p, a_kcontig != 0, b_kcontig != 0, grid, st);
     return vitae_launch_status();
 }
@@ -1073,61 +725,7 @@ extern "C" int vitae_gemm_glds(int a_kcontig, int b_kcontig, const void* A16, lo
                                const float* residual, long ldr, int epi, float* aux, long ldaux, int accumulate,
                                int split_k, float* splitk_ws, float* out_colsum_accum, void* stream) {
     return gemm_glds_launch(a_kcontig, b_kcontig, A16, lda, B16, ldb, C, ldc, C16, ldc16, M, N, K, bias, residual, ldr, epi, aux, ldaux,
-                            accumulate, split_k, splitk_ws, out_colsum_accum, nullptr, stream);
-}
-
-// The same GEMM, additionally leaving the LayerNorm statistics of its result rows in 64-column partials:
-// out_rowstats[s][m] = (sum, sum of squares) of C(m, 64 s .. 64 s + 63), s < ceil(N / 64) (plain stores: every slot of every row is
-// written, nothing to zero).  Consumed by vitae_gemm_glds_lnfold, which normalises the rows while it loads them.
-extern "C" int vitae_gemm_glds_stats(int a_kcontig, int b_kcontig, const void* A16, long lda, const void* B16, long ldb,
-                                     float* C, long ldc, void* C16, long ldc16, int M, int N, int K, const float* bias,
-                                     const float* residual, long ldr, int epi, float* aux, long ldaux, int accumulate,
-                                     int split_k, float* splitk_ws, float* out_colsum_accum, float* out_rowstats, void* stream) {
-    if (!out_rowstats) return VITAE_ERR_INVALID_ARG;
-    return gemm_glds_launch(a_kcontig, b_kcontig, A16, lda, B16, ldb, C, ldc, C16, ldc16, M, N, K, bias, residual, ldr, epi, aux, ldaux,
-                            accumulate, split_k, splitk_ws, out_colsum_accum, out_rowstats, stream);
-}
-
-// C / C16 [M, N] = epi( LayerNorm(X)[M, K] @ W16[N, K]^T + bias ) with the LayerNorm applied while X is loaded (see
-// gemm_glds_lnfold_kernel).  stats[stat_parts][M][2] = partial (sum, sum of squares) of X's rows (vitae_gemm_glds_stats leaves
-// them, stat_parts = K / 64).  y16_out /
-// mean_out / rstd_out (all or none): the bf16 LayerNorm output (row stride ldy, ceil(M / 64) * 64 rows: the pad rows are
-// written with zeros) and the row statistics for the backward.
-extern "C" int vitae_gemm_glds_lnfold(const float* X, long ldx, const float* stats, int stat_parts, const float* gamma, const float* beta, float eps,
-                                      const void* W16, long ldw, float* C, long ldc, void* C16, long ldc16, int M, int N, int K,
-                                      const float* bias, int epi, float* aux, long ldaux, void* y16_out, long ldy, float* mean_out,
-                                      float* rstd_out, void* stream) {
-    if (!X || !stats || stat_parts <= 0 || !gamma || !beta || !W16 || (!C && !C16) || M <= 0 || N <= 0 || K <= 0) return VITAE_ERR_INVALID_ARG;
-    const int aux16 = (epi & VITAE_EPI_AUX_BF16) != 0;
-    epi &= ~VITAE_EPI_AUX_BF16;
-    if ((uintptr_t)stats & 7) return VITAE_ERR_UNSUPPORTED_SHAPE;
-    if (epi != VITAE_EPI_NONE && epi != VITAE_EPI_RELU && !aux) return VITAE_ERR_INVALID_ARG;
-    if ((y16_out != nullptr) != (mean_out != nullptr) || (mean_out != nullptr) != (rstd_out != nullptr)) return VITAE_ERR_INVALID_ARG;
-    if ((K != 512 && K != 768 && K != 1024) || (ldx & 3) || (ldw & 7) || (ldy & 7)) return VITAE_ERR_UNSUPPORTED_SHAPE;   // unrolled k-loops
-    if (((uintptr_t)X & 15) || ((uintptr_t)W16 & 15) || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15) || ((uintptr_t)y16_out & 15))
-        return VITAE_ERR_UNSUPPORTED_SHAPE;
-    if ((long)M * (ldc > N ? ldc : N) >= (1L << 31) || (long)M * ldaux >= (1L << 31) || (long)M * ldc16 >= (1L << 31))
-        return VITAE_ERR_UNSUPPORTED_SHAPE;
-    GArgs p;
-    p.A = nullptr; p.lda = 0;
-    p.B = reinterpret_cast<const __bf16*>(W16); p.ldb = ldw;
-    p.C = C; p.ldc = ldc; p.C16 = reinterpret_cast<__bf16*>(C16); p.ldc16 = ldc16;
-    p.M = M; p.N = N; p.K = K; p.k_per_split = K; p.splits = 1;
-    p.bias = bias; p.residual = nullptr; p.ldr = 0; p.aux = aux; p.ldaux = ldaux;
-    p.epi = epi; p.aux16 = aux16; p.accumulate = 0; p.ws = nullptr; p.out_colsum = nullptr; p.a_rowsum = nullptr;
-    p.dbg = g_gemm_dbg; p.slab_stride = 0;
-    p.tiles_m = cdiv(M, 64); p.tiles_n = cdiv(N, 64);
-    p.xcd_m = xcd_by_rows(M, N);
-    p.vec_epi = vec_epilogue_ok(p);
-    if (!p.vec_epi) return VITAE_ERR_UNSUPPORTED_SHAPE;
-    LArgs l;
-    l.X = X; l.ldx = ldx; l.stats = stats; l.nparts = stat_parts; l.gamma = gamma; l.beta = beta; l.eps = eps;
-    l.Y16 = reinterpret_cast<__bf16*>(y16_out); l.ldy = ldy; l.mean = mean_out; l.rstd = rstd_out;
-    const dim3 grid(glds_blocks(p));
-    if (K == 512) hipLaunchKernelGGL(gemm_glds_lnfold_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, p, l);
-    else if (K == 768) hipLaunchKernelGGL(gemm_glds_lnfold_kernel<12>, grid, dim3(256), 0, (hipStream_t)stream, p, l);
-    else hipLaunchKernelGGL(gemm_glds_lnfold_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, p, l);
-    return vitae_launch_status();
+                            accumulate, split_k, splitk_ws, out_colsum_accum, stream);
 }
 
 // Backward of one Linear on bf16 operands in ONE launch: dx[M,K] = epi(dy16[M,N] @ W16[N,K]) (fp32 dx and/or
@@ -1142,8 +740,7 @@ extern "C" int vitae_linear_bwd_pair_pick_split_k(int M, int Mpad, int N, int K)
     int s = (ks1 + (ks2 > target ? ks2 : target) / 2) / (ks2 > target ? ks2 : target);
     if (s > 8) s = 8;
     while (s > 1 && ks1 / s < 4) --s;
-    Tile t1 = pick_tile(M, K);
-    if (t1.id == 3) t1 = Tile{64, 128, 1};
+    const Tile t1 = pick_tile(M, K);
     if ((long)cdiv(M, t1.bm) * cdiv(K, t1.bn) > VITAE_GLDS_TICKETS) s = 1;
     return s < 1 ? 1 : s;
 }
@@ -1177,10 +774,10 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
                 return sp;
             };
             int rc = gemm_glds_launch(1, 0, dy16, N, w16, K, dx, K, dx16, K, M, K, N, nullptr, nullptr, 0, epi | (aux16 ? VITAE_EPI_AUX_BF16 : 0),
-                                      aux, K, dx_accumulate, fit(pd, M, K, N), splitk_ws, dx_colsum_accum, nullptr, stream, &pd);
+                                      aux, K, dx_accumulate, fit(pd, M, K, N), splitk_ws, dx_colsum_accum, stream, &pd);
             if (rc != VITAE_OK) return rc;
             rc = gemm_glds_launch(0, 0, dy16, N, x16, K, dw, K, dw16, K, N, K, Mpad, nullptr, nullptr, 0, VITAE_EPI_NONE, nullptr, 0,
-                                  dw_accumulate, fit(pw, N, K, Mpad), splitk_ws, nullptr, nullptr, stream, &pw);
+                                  dw_accumulate, fit(pw, N, K, Mpad), splitk_ws, nullptr, stream, &pw);
             if (rc != VITAE_OK) return rc;
             if (dy_colsum_accum)
                 hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(N, 256), cdiv(M, 32)), dim3(256), 0, (hipStream_t)stream,
@@ -1197,9 +794,8 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
     split_k = cdiv(N, kps);
     p1.M = M; p1.N = K; p1.K = N; p1.k_per_split = kps; p1.splits = split_k;
     p1.bias = nullptr; p1.residual = nullptr; p1.ldr = 0; p1.aux = aux; p1.ldaux = K; p1.epi = epi; p1.aux16 = aux16; p1.accumulate = dx_accumulate != 0;
-    p1.ws = splitk_ws; p1.out_colsum = dx_colsum_accum; p1.a_rowsum = nullptr; p1.dbg = nullptr; p2.dbg = nullptr; p1.slab_stride = 0; p2.slab_stride = 0;
-    Tile t1 = pick_tile(M, K);
-    if (t1.id == 3) t1 = Tile{64, 128, 1};      // the paired launch is 4-wave only
+    p1.ws = splitk_ws; p1.out_colsum = dx_colsum_accum; p1.a_rowsum = nullptr; p1.dbg = nullptr; p2.dbg = nullptr;
+    const Tile t1 = pick_tile(M, K);
     p1.tiles_m = cdiv(M, t1.bm); p1.tiles_n = cdiv(K, t1.bn);
     p1.xcd_m = xcd_by_rows(M, K);
     p1.vec_epi = vec_epilogue_ok(p1);
@@ -1210,8 +806,7 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
     p2.bias = nullptr; p2.residual = nullptr; p2.ldr = 0; p2.aux = nullptr; p2.ldaux = 0; p2.epi = VITAE_EPI_NONE;
     p2.accumulate = dw_accumulate; p2.ws = nullptr; p2.out_colsum = nullptr; p2.a_rowsum = dy_colsum_accum;
     p2.sqacc = g_wgrad_sqacc;
-    Tile t2 = pick_tile(N, K);
-    if (t2.id == 3) t2 = Tile{64, 128, 1};
+    const Tile t2 = pick_tile(N, K);
     p2.tiles_m = cdiv(N, t2.bm); p2.tiles_n = cdiv(K, t2.bn);
     p2.xcd_m = xcd_by_rows(N, K);
     p2.vec_epi = vec_epilogue_ok(p2);
@@ -1224,48 +819,11 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
         return vitae_launch_status();
     }
     p2.a_rowsum = nullptr;
-    if (t1.id == 2) launch_pair<128, 128>(t2.id, grid, st, p1, p2, nb1);
-    else if (t1.id == 1) launch_pair<64, 128>(t2.id, grid, st, p1, p2, nb1);
+    if (t1.id == 1) launch_pair<64, 128>(t2.id, grid, st, p1, p2, nb1);
     else launch_pair<64, 64>(t2.id, grid, st, p1, p2, nb1);
     if (dy_colsum_accum)
         hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(N, 256), cdiv(M, 32)), dim3(256), 0, st,
                            reinterpret_cast<const __bf16*>(dy16), dy_colsum_accum, M, N, 32);
-    return vitae_launch_status();
-}
-
-// Weight gradients of up to four Linears in one launch (see gemm_glds_group_kernel): for each i,
-// dw[i][N[i], K[i]] (+)= dy16[i][Mpad, N[i]]^T @ x16[i][Mpad, K[i]], optional bf16 copy dw16[i], optional
-// dy_colsum[i][N[i]] += column sums of dy16[i] (the bias gradient).  Rows M..Mpad-1 of every operand must be zero.
-extern "C" int vitae_wgrad_group_glds(int n, const void* const* dy16, const void* const* x16, float* const* dw, void* const* dw16,
-                                      float* const* dy_colsum, const int* N, const int* K, int Mpad, int dw_accumulate,
-                                      void* stream) {
-    if (n < 1 || n > 4 || !dy16 || !x16 || !dw || !N || !K || Mpad <= 0) return VITAE_ERR_INVALID_ARG;
-    if (Mpad % BK) return VITAE_ERR_UNSUPPORTED_SHAPE;
-    GGroup g;
-    int total = 0;
-    for (int i = 0; i < 4; ++i) {
-        g.start[i] = total;
-        if (i >= n) { g.p[i] = g.p[0]; continue; }
-        if (!dy16[i] || !x16[i] || !dw[i] || N[i] <= 0 || K[i] <= 0) return VITAE_ERR_INVALID_ARG;
-        if ((N[i] & 7) || (K[i] & 7) || (long)N[i] * K[i] >= (1L << 31)) return VITAE_ERR_UNSUPPORTED_SHAPE;
-        if (((uintptr_t)dy16[i] & 15) || ((uintptr_t)x16[i] & 15)) return VITAE_ERR_UNSUPPORTED_SHAPE;
-        GArgs& p = g.p[i];
-        p.A = reinterpret_cast<const __bf16*>(dy16[i]); p.lda = N[i];
-        p.B = reinterpret_cast<const __bf16*>(x16[i]); p.ldb = K[i];
-        p.C = dw[i]; p.ldc = K[i];
-        p.C16 = reinterpret_cast<__bf16*>(dw16 ? dw16[i] : nullptr); p.ldc16 = K[i];
-        p.M = N[i]; p.N = K[i]; p.K = Mpad; p.k_per_split = Mpad; p.splits = 1;
-        p.bias = nullptr; p.residual = nullptr; p.ldr = 0; p.aux = nullptr; p.ldaux = 0; p.epi = VITAE_EPI_NONE;
-        p.accumulate = dw_accumulate; p.ws = nullptr; p.out_colsum = nullptr;
-        p.a_rowsum = dy_colsum ? dy_colsum[i] : nullptr; p.dbg = nullptr; p.slab_stride = 0;
-        p.tiles_m = cdiv(N[i], 64); p.tiles_n = cdiv(K[i], 64);
-        p.xcd_m = xcd_by_rows(N[i], K[i]);
-        p.vec_epi = vec_epilogue_ok(p);
-        total += glds_blocks(p);
-    }
-    g.start[4] = total;
-    for (int i = n; i < 4; ++i) g.start[i] = total;      // unused slots: empty ranges
-    hipLaunchKernelGGL(gemm_glds_group_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, g);
     return vitae_launch_status();
 }
 
@@ -1278,76 +836,3 @@ extern "C" int vitae_gemm_glds_set_debug(void* buf) { g_gemm_dbg = reinterpret_c
 // acc[VITAE_ACC_GRADSQ]).  Process-global launch-time state of the (single) thread that issues the step; captured graphs keep
 // the value it had at capture.  Not for split-K wgrads (the paired launch never splits its wgrad half).
 extern "C" int vitae_gemm_glds_set_wgrad_sqnorm(double* slot) { g_wgrad_sqacc = slot; return VITAE_OK; }
-
-// ---- split-K whose partial sums leave the launch as separate matrices ("slabs"), summed by the consumer ----------------
-// number of slabs vitae_gemm_glds_slabs / vitae_linear_bwd_pair_glds_slabs produce for a reduction length and a requested split
-extern "C" int vitae_gemm_glds_slab_count(int K, int split_k) {
-    if (K <= 0 || (K % BK)) return 0;
-    if (split_k < 1) split_k = 1;
-    const int kps = cdiv(cdiv(K, split_k), BK) * BK;
-    return cdiv(K, kps);
-}
-
-// slabs[z][M, N] (z-th at slabs + z * slab_stride floats) = A(:, k-range z) @ B(:, k-range z)^T: no bias, no residual, no
-// epilogue — the LayerNorm that consumes the sum adds those (vitae_layernorm_fwd_slabs) — and no in-launch reduction.
-extern "C" int vitae_gemm_glds_slabs(int a_kcontig, int b_kcontig, const void* A16, long lda, const void* B16, long ldb, float* slabs,
-                                     long slab_stride, int M, int N, int K, int split_k, void* stream) {
-    if (!A16 || !B16 || !slabs || M <= 0 || N <= 0 || K <= 0 || split_k < 1) return VITAE_ERR_INVALID_ARG;
-    if ((K % BK) || slab_stride < (long)M * N || (slab_stride & 3)) return VITAE_ERR_UNSUPPORTED_SHAPE;
-    if ((long)M * N >= (1L << 31)) return VITAE_ERR_UNSUPPORTED_SHAPE;
-    const int a_vec = a_kcontig ? K : M, b_vec = b_kcontig ? K : N;
-    if ((a_vec & 7) || (lda & 7) || (b_vec & 7) || (ldb & 7)) return VITAE_ERR_UNSUPPORTED_SHAPE;
-    if (((uintptr_t)A16 & 15) || ((uintptr_t)B16 & 15) || ((uintptr_t)slabs & 15)) return VITAE_ERR_UNSUPPORTED_SHAPE;
-    GArgs p;
-    p.A = reinterpret_cast<const __bf16*>(A16); p.lda = lda;
-    p.B = reinterpret_cast<const __bf16*>(B16); p.ldb = ldb;
-    p.C = slabs; p.ldc = N; p.C16 = nullptr; p.ldc16 = 0;
-    p.M = M; p.N = N; p.K = K;
-    const int kps = cdiv(cdiv(K, split_k), BK) * BK;
-    p.k_per_split = kps; p.splits = cdiv(K, kps);
-    p.bias = nullptr; p.residual = nullptr; p.ldr = 0; p.aux = nullptr; p.ldaux = 0; p.epi = VITAE_EPI_NONE; p.accumulate = 0;
-    p.ws = nullptr; p.out_colsum = nullptr; p.a_rowsum = nullptr; p.dbg = g_gemm_dbg; p.slab_stride = slab_stride;
-    p.tiles_m = cdiv(M, 64); p.tiles_n = cdiv(N, 64);
-    p.xcd_m = xcd_by_rows(M, N);
-    p.vec_epi = vec_epilogue_ok(p);
-    dim3 grid(glds_blocks(p), 1, p.splits);
-    launch<64, 64>(p, a_kcontig != 0, b_kcontig != 0, grid, (hipStream_t)stream);
-    return vitae_launch_status();
-}
-
-// Backward of one nn.Linear whose input gradient feeds a LayerNorm backward: dx leaves as split-K slabs
-// (dx_slabs[z][M, K] = dy16(:, n-range z) @ W16(n-range z, :)), dW[N, K] (+)= dy16^T x16 and the bias gradient as in
-// vitae_linear_bwd_pair_glds.  One launch, no in-launch reduction.
-extern "C" int vitae_linear_bwd_pair_glds_slabs(const void* dy16, const void* w16, const void* x16, float* dx_slabs, long slab_stride,
-                                                float* dw, void* dw16, int M, int Mpad, int N, int K, float* dy_colsum_accum,
-                                                int dw_accumulate, int split_k, void* stream) {
-    if (!dy16 || !w16 || !x16 || !dx_slabs || !dw || M <= 0 || N <= 0 || K <= 0 || split_k < 1) return VITAE_ERR_INVALID_ARG;
-    if ((N % BK) || (Mpad % BK) || (K & 7) || Mpad < M || slab_stride < (long)M * K || (slab_stride & 3)) return VITAE_ERR_UNSUPPORTED_SHAPE;
-    if ((long)(M > N ? M : N) * K >= (1L << 31)) return VITAE_ERR_UNSUPPORTED_SHAPE;
-    if (((uintptr_t)dy16 & 15) || ((uintptr_t)w16 & 15) || ((uintptr_t)x16 & 15) || ((uintptr_t)dx_slabs & 15)) return VITAE_ERR_UNSUPPORTED_SHAPE;
-    GArgs p1, p2;
-    p1.A = reinterpret_cast<const __bf16*>(dy16); p1.lda = N;
-    p1.B = reinterpret_cast<const __bf16*>(w16); p1.ldb = K;
-    p1.C = dx_slabs; p1.ldc = K; p1.C16 = nullptr; p1.ldc16 = 0;
-    const int kps = cdiv(cdiv(N, split_k), BK) * BK;
-    p1.M = M; p1.N = K; p1.K = N; p1.k_per_split = kps; p1.splits = cdiv(N, kps);
-    p1.bias = nullptr; p1.residual = nullptr; p1.ldr = 0; p1.aux = nullptr; p1.ldaux = 0; p1.epi = VITAE_EPI_NONE; p1.accumulate = 0;
-    p1.ws = nullptr; p1.out_colsum = nullptr; p1.a_rowsum = nullptr; p1.dbg = nullptr; p1.slab_stride = slab_stride;
-    p1.tiles_m = cdiv(M, 64); p1.tiles_n = cdiv(K, 64);
-    p1.xcd_m = xcd_by_rows(M, K);
-    p1.vec_epi = vec_epilogue_ok(p1);
-    p2.A = reinterpret_cast<const __bf16*>(dy16); p2.lda = N;
-    p2.B = reinterpret_cast<const __bf16*>(x16); p2.ldb = K;
-    p2.C = dw; p2.ldc = K; p2.C16 = reinterpret_cast<__bf16*>(dw16); p2.ldc16 = K;
-    p2.M = N; p2.N = K; p2.K = Mpad; p2.k_per_split = Mpad; p2.splits = 1;
-    p2.bias = nullptr; p2.residual = nullptr; p2.ldr = 0; p2.aux = nullptr; p2.ldaux = 0; p2.epi = VITAE_EPI_NONE;
-    p2.accumulate = dw_accumulate; p2.ws = nullptr; p2.out_colsum = nullptr; p2.a_rowsum = dy_colsum_accum; p2.dbg = nullptr;
-    p2.slab_stride = 0;
-    p2.tiles_m = cdiv(N, 64); p2.tiles_n = cdiv(K, 64);
-    p2.xcd_m = xcd_by_rows(N, K);
-    p2.vec_epi = vec_epilogue_ok(p2);
-    const int nb1 = glds_blocks(p1), nb2 = glds_blocks(p2);
-    dim3 grid(nb1 * p1.splits + nb2);
-    hipLaunchKernelGGL((gemm_glds_pair_kernel<64, 64, 64, 64, true>), grid, dim3(256), 0, (hipStream_t)stream, p1, p2, nb1);
-    return vitae_launch_status();
-}

@@ -318,155 +318,6 @@ __global__ __launch_bounds__(256) void layernorm_bwd_rows_vec_kernel(const float
     }
 }
 
-// ------------------------------------------------------------------ LayerNorm on a result that still is S partial sums
-// The fused MLP kernels (mlp_fused.hip) leave their result as S slabs (one per slice of the hidden dimension).  The
-// LayerNorm that consumes the result anyway sums them while it reads — the launch-boundary reduce: no atomics, no
-// extra launch.
-// Forward: x_out[row] = residual[row] + bias + sum_s slabs[s][row];  y16 = LN(x_out).  One row per block; the four waves
-// split the slabs (6 x 3 independent 16-byte loads per lane in flight at S = 24, D = 768) and meet in LDS.
-template <int NV>
-__global__ __launch_bounds__(256) void layernorm_fwd_slabs_kernel(const float* __restrict__ slabs, int nslabs, long stride,
-                                                                  const float* __restrict__ res, const float* __restrict__ bias,
-                                                                  const float* __restrict__ w, const float* __restrict__ b,
-                                                                  float* __restrict__ x_out, float* __restrict__ y,
-                                                                  __bf16* __restrict__ y16,
-                                                                  float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                                  float eps) {
-    constexpr int D = 256 * NV;
-    __shared__ f32x4 part[3][64 * NV];
-    const int row = blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    f32x4 v[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int s = wave; s < nslabs; s += 4) {
-        const f32x4* sp = reinterpret_cast<const f32x4*>(slabs + s * stride + (long)row * D);
-#pragma unroll
-        for (int i = 0; i < NV; ++i) v[i] += sp[lane + 64 * i];
-    }
-    if (wave) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) part[wave - 1][lane + 64 * i] = v[i];
-    }
-    __syncthreads();
-    if (wave) return;
-    const f32x4* r4 = reinterpret_cast<const f32x4*>(res + (long)row * D);
-    const f32x4* bi4 = reinterpret_cast<const f32x4*>(bias);
-    const f32x4* w4 = reinterpret_cast<const f32x4*>(w);
-    const f32x4* b4 = reinterpret_cast<const f32x4*>(b);
-    f32x4 wv[NV], bv[NV];
-    float sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = lane + 64 * i;
-        v[i] += (part[0][c] + part[1][c]) + (part[2][c] + r4[c]);
-        if (bias) v[i] += bi4[c];
-        wv[i] = w4[c]; bv[i] = b4[c];
-        sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-    }
-    const float mean = wave_sum(sum) / D;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { const float dlt = v[i][e] - mean; q += dlt * dlt; }
-    const float rstd = rsqrtf(wave_sum(q) / D + eps);
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        reinterpret_cast<f32x4*>(x_out + (long)row * D)[lane + 64 * i] = v[i];
-        f32x4 o;
-        bf16x4 o16;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { o[e] = (v[i][e] - mean) * rstd * wv[i][e] + bv[i][e]; o16[e] = (__bf16)o[e]; }
-        if (y) reinterpret_cast<f32x4*>(y + (long)row * D)[lane + 64 * i] = o;
-        reinterpret_cast<bf16x4*>(y16 + (long)row * D)[lane + 64 * i] = o16;
-    }
-    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
-}
-
-// Backward: dy[row] = sum_s slabs[s][row], then as layernorm_bwd_rows_vec_kernel with one row per wave.
-template <int NV>
-__global__ __launch_bounds__(256) void layernorm_bwd_slabs_kernel(const float* __restrict__ slabs, int nslabs, long stride,
-                                                                  const float* __restrict__ x, const float* __restrict__ w,
-                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                                  float* __restrict__ dx, float* __restrict__ dw,
-                                                                  float* __restrict__ db, __bf16* __restrict__ dx16,
-                                                                  float* __restrict__ dx_colsum, int M, int dx_accumulate) {
-    constexpr int D = 256 * NV;
-    extern __shared__ float red[];   // [3][4][D]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row = blockIdx.x * 4 + wave;
-    const bool valid = row < M;
-    const int rr = valid ? row : M - 1;
-    f32x4 dv[NV], xv[NV], ov[NV], wv[NV];
-    const f32x4* w4 = reinterpret_cast<const f32x4*>(w);
-    const f32x4* x4 = reinterpret_cast<const f32x4*>(x + (long)rr * D);
-    const f32x4* o4 = reinterpret_cast<const f32x4*>(dx + (long)rr * D);
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        wv[i] = w4[lane + 64 * i];
-        xv[i] = x4[lane + 64 * i];
-        if (dx_accumulate) ov[i] = o4[lane + 64 * i];
-        else ov[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        dv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    const float mu = mean[rr], rs = rstd[rr];
-#pragma unroll 8
-    for (int s = 0; s < nslabs; ++s) {
-        const f32x4* sp = reinterpret_cast<const f32x4*>(slabs + s * stride + (long)rr * D);
-#pragma unroll
-        for (int i = 0; i < NV; ++i) dv[i] += sp[lane + 64 * i];
-    }
-    f32x4 pw[NV], pb[NV], pc[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) { pw[i] = f32x4{0.f, 0.f, 0.f, 0.f}; pb[i] = pw[i]; pc[i] = pw[i]; }
-    if (valid) {
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int i = 0; i < NV; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float xh = (xv[i][e] - mu) * rs;
-                const float dd = dv[i][e];
-                const float g = dd * wv[i][e];
-                pw[i][e] = dd * xh; pb[i][e] = dd;
-                s1 += g; s2 += g * xh;
-                xv[i][e] = xh; dv[i][e] = g;
-            }
-        s1 = wave_sum(s1) / D; s2 = wave_sum(s2) / D;
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            f32x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                o[e] = rs * (dv[i][e] - s1 - xv[i][e] * s2) + ov[i][e];
-                pc[i][e] = o[e];
-            }
-            reinterpret_cast<f32x4*>(dx + (long)row * D)[lane + 64 * i] = o;
-            if (dx16) {
-                bf16x4 o16;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o16[e] = (__bf16)o[e];
-                reinterpret_cast<bf16x4*>(dx16 + (long)row * D)[lane + 64 * i] = o16;
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = 4 * (lane + 64 * i);
-        *reinterpret_cast<f32x4*>(&red[(0 * 4 + wave) * D + c]) = pw[i];
-        *reinterpret_cast<f32x4*>(&red[(1 * 4 + wave) * D + c]) = pb[i];
-        *reinterpret_cast<f32x4*>(&red[(2 * 4 + wave) * D + c]) = pc[i];
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < D; c += 256) {
-        atomicAdd(dw + c, red[0 * D + c] + red[1 * D + c] + red[2 * D + c] + red[3 * D + c]);
-        atomicAdd(db + c, red[4 * D + c] + red[5 * D + c] + red[6 * D + c] + red[7 * D + c]);
-        if (dx_colsum) atomicAdd(dx_colsum + c, red[8 * D + c] + red[9 * D + c] + red[10 * D + c] + red[11 * D + c]);
-    }
-}
-
 // ------------------------------------------------------------------ column sum (bias gradients)
 // out[n] += sum_m dy[m, n].  Threads own columns (coalesced rows), blocks own row slabs.
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dy, long ld, float* __restrict__ out,
@@ -614,39 +465,6 @@ extern "C" int vitae_layernorm_bwd(const float* dy, const float* x, const float*
     if (blocks > 256) blocks = 256;   // one row per wave up to 1024 rows (row work dominates; capping at 48 blocks doubled the time)
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, w, mean, rstd,
                        dx, dw, db, reinterpret_cast<__bf16*>(dx_bf16), dx_colsum_accum, M, D, dx_accumulate);
-    return vitae_launch_status();
-}
-
-extern "C" int vitae_layernorm_fwd_slabs(const float* slabs, int nslabs, long slab_stride, const float* residual,
-                                         const float* bias, const float* w, const float* b, float* x_out, float* y, void* y_bf16,
-                                         float* mean, float* rstd, int M, int D, float eps, void* stream) {
-    if (!slabs || nslabs < 1 || !residual || !w || !b || !x_out || !y_bf16 || !mean || !rstd || M <= 0) return VITAE_ERR_INVALID_ARG;
-    if (D != 512 && D != 768 && D != 1024) return VITAE_ERR_UNSUPPORTED_SHAPE;
-    if ((((uintptr_t)slabs | (uintptr_t)residual | (uintptr_t)bias | (uintptr_t)w | (uintptr_t)b | (uintptr_t)x_out | (uintptr_t)y) & 15) ||
-        ((uintptr_t)y_bf16 & 7) || (slab_stride & 3))
-        return VITAE_ERR_UNSUPPORTED_SHAPE;
-    __bf16* y16 = reinterpret_cast<__bf16*>(y_bf16);
-    hipStream_t st = (hipStream_t)stream;
-    if (D == 768) hipLaunchKernelGGL(layernorm_fwd_slabs_kernel<3>, dim3(M), dim3(256), 0, st, slabs, nslabs, slab_stride, residual, bias, w, b, x_out, y, y16, mean, rstd, eps);
-    else if (D == 512) hipLaunchKernelGGL(layernorm_fwd_slabs_kernel<2>, dim3(M), dim3(256), 0, st, slabs, nslabs, slab_stride, residual, bias, w, b, x_out, y, y16, mean, rstd, eps);
-    else hipLaunchKernelGGL(layernorm_fwd_slabs_kernel<4>, dim3(M), dim3(256), 0, st, slabs, nslabs, slab_stride, residual, bias, w, b, x_out, y, y16, mean, rstd, eps);
-    return vitae_launch_status();
-}
-
-extern "C" int vitae_layernorm_bwd_slabs(const float* slabs, int nslabs, long slab_stride, const float* x, const float* w,
-                                         const float* mean, const float* rstd, float* dx, float* dw, float* db, void* dx_bf16,
-                                         float* dx_colsum_accum, int M, int D, int dx_accumulate, void* stream) {
-    if (!slabs || nslabs < 1 || !x || !w || !mean || !rstd || !dx || !dw || !db || M <= 0) return VITAE_ERR_INVALID_ARG;
-    if (D != 512 && D != 768 && D != 1024) return VITAE_ERR_UNSUPPORTED_SHAPE;
-    if ((((uintptr_t)slabs | (uintptr_t)x | (uintptr_t)w | (uintptr_t)dx) & 15) || ((uintptr_t)dx_bf16 & 7) || (slab_stride & 3))
-        return VITAE_ERR_UNSUPPORTED_SHAPE;
-    __bf16* dx16v = reinterpret_cast<__bf16*>(dx_bf16);
-    const size_t lds = (size_t)12 * D * sizeof(float);
-    hipStream_t st = (hipStream_t)stream;
-    const dim3 grid(cdiv(M, 4));
-    if (D == 768) hipLaunchKernelGGL(layernorm_bwd_slabs_kernel<3>, grid, dim3(256), lds, st, slabs, nslabs, slab_stride, x, w, mean, rstd, dx, dw, db, dx16v, dx_colsum_accum, M, dx_accumulate);
-    else if (D == 512) hipLaunchKernelGGL(layernorm_bwd_slabs_kernel<2>, grid, dim3(256), lds, st, slabs, nslabs, slab_stride, x, w, mean, rstd, dx, dw, db, dx16v, dx_colsum_accum, M, dx_accumulate);
-    else hipLaunchKernelGGL(layernorm_bwd_slabs_kernel<4>, grid, dim3(256), lds, st, slabs, nslabs, slab_stride, x, w, mean, rstd, dx, dw, db, dx16v, dx_colsum_accum, M, dx_accumulate);
     return vitae_launch_status();
 }
 

@@ -125,44 +125,20 @@ class HipMAEEngine:
         dims = (D, Dd, self.Hm, self.Hmd, cfg.patch_dim)
         self.act16 = (self.prec == PREC['bf16'] and all(v % 64 == 0 for v in dims)
                       and self.hd in (32, 64) and self.hdd in (32, 64))
-        # fused MLP launches (csrc/mlp_fused.hip) + weight gradients deferred to one grouped launch per block on a side
-        # stream: fewer and shorter kernels on the dependent chain; both stacks must be eligible
-        # (measured round 2, B = 4: the fused chain is NOT faster than the paired launches — 5.2-5.35 vs 4.86 ms/step — so it is
-        # opt-in: VITAE_FUSE_MLP=1; DESIGN.md §3c has the numbers and the reason: the per-CU texture-addresser rate)
-        self.fuse_mlp = (self.act16 and os.environ.get('VITAE_FUSE_MLP', '0') != '0'
-                         and bool(lib.vitae_mlp_fused_supported(D, self.Hm)) and bool(lib.vitae_mlp_fused_supported(Dd, self.Hmd)))
         self.wgrad_side = os.environ.get('VITAE_WGRAD_SIDE', '1') != '0'
         self.target_fork = os.environ.get('VITAE_TARGET_FORK', 'start')
-        # split-K reduced at the launch boundary: the GEMMs whose result goes straight into a LayerNorm (proj and fc2 forward,
-        # the input gradients of fc1 and qkv backward) leave their k-splits as separate fp32 slabs and the LayerNorm sums them
-        # while it reads — no tickets / partial round trip inside the GEMM launch
-        self.slab_k = (self.act16 and not self.fuse_mlp and os.environ.get('VITAE_SLAB_SPLITK', '0') != '0'
-                       and D in (512, 768, 1024) and Dd in (512, 768, 1024))
-        # OPT-IN (VITAE_SLAB_SPLITK=1): measured round 2 at batch 4 / 8 / 32: 4.78 vs 4.81, 6.43 vs 6.30, 16.2 vs 16.0 ms/step.
-        # (per encoder block: forward 66 -> 61.6 us — proj 9.4 -> 7.6, fc2 16.4 -> 12.1, the two LayerNorms +0.5
-        # and +1.1; backward +3 us — the paired launches are not shortened by dropping the dgrad half's in-launch reduction, their
-        # wgrad half and the 900-workgroup grid set their duration, while the slab-summing LayerNorm backward costs 1.5 us
-        # more: so the backward keeps the in-launch reduction unless VITAE_SLAB_SPLITK_BWD=1)
-        self.slab_k_bwd = self.slab_k and os.environ.get('VITAE_SLAB_SPLITK_BWD', '0') != '0'
         # OPT-IN (measured: no gain — 4.81-4.84 vs 4.82-4.84 ms at batch 4, 15.96 vs 15.94 at batch 32): the saved fc1
         # pre-activation (read once, by the GELU' of the fc2 input gradient) in bf16: half the bytes of the fc1 epilogue's largest
         # store and of the fc2 backward's largest epilogue read
-        self.hpre16 = self.act16 and not self.fuse_mlp and os.environ.get('VITAE_HPRE_BF16', '0') == '1'
+        self.hpre16 = self.act16 and os.environ.get('VITAE_HPRE_BF16', '0') == '1'
         self._aux16 = CONSTS['VITAE_EPI_AUX_BF16'] if self.hpre16 else 0
         # the gradient norm's matrix share is accumulated by the weight-gradient epilogues themselves (vitae_gemm_glds_set_wgrad_sqnorm)
         # instead of a pass over each bucket (45 us per bucket, the last one exposed behind the backward); single process only — a
         # data-parallel norm is the norm of the REDUCED gradients
-        self.epi_norm = self.act16 and not self.fuse_mlp and not self.slab_k and os.environ.get('VITAE_EPI_GRADNORM', '1') != '0'
+        self.epi_norm = self.act16 and os.environ.get('VITAE_EPI_GRADNORM', '1') != '0'
         # q | k | v leave the qkv GEMM in bf16 only and the attention kernels read that (no fp32 qkv in HBM: the GEMM epilogue is
         # bound by its output bytes, and the kernels no longer convert while staging); needs the one-launch attention backward
-        self.qkv16 = self.act16 and not self.fuse_mlp and not self.slab_k and os.environ.get('VITAE_QKV_BF16', '1') != '0'
-        # OPT-IN (measured: 4.83-4.88 vs 4.81-4.87 ms at batch 4, slower at batch 8 / 32 — DESIGN.md section 3c): LayerNorm folded
-        # into the GEMM that consumes it (csrc/gemm_glds.hip: vitae_gemm_glds_stats leaves the row statistics of the residual
-        # stream, vitae_gemm_glds_lnfold normalises while it loads): no standalone norm1 / norm2 launch except in front of the
-        # first block of a stack
-        self.fold_ln = (self.act16 and not self.fuse_mlp and not self.slab_k and os.environ.get('VITAE_FOLD_LN', '0') == '1')
-        self._slabk_target = int(os.environ.get('VITAE_SLABK_TARGET', '384'))
-        self._slabk_min_kt = int(os.environ.get('VITAE_SLABK_MIN_KT', '4'))
+        self.qkv16 = self.act16 and os.environ.get('VITAE_QKV_BF16', '1') != '0'
         self.buffers = buffers   # pos_embed, decoder_pos_embed, BN running stats (device tensors)
         f32 = dict(dtype=torch.float32, device=device)
         # ring of pinned staging buffers: the host may run a few steps ahead of the stream, so the
@@ -368,9 +344,8 @@ class HipMAEEngine:
                 b[q + 'y1'], b[q + 'mean1'], b[q + 'rstd1'] = f(M, d), f(M), f(M)
                 b[q + 'qkv'], b[q + 'o'] = f(M, 3 * d), f(M, d)
                 b[q + 'xmid'], b[q + 'y2'], b[q + 'mean2'], b[q + 'rstd2'] = f(M, d), f(M, d), f(M), f(M)
-                if not self.fuse_mlp:     # the fused MLP keeps its pre-activation / activation in bf16 only
-                    b[q + 'hpre'] = torch.empty(M, h, dtype=torch.bfloat16, device=dev) if self.hpre16 else f(M, h)
-                    b[q + 'act'] = f(M, h)
+                b[q + 'hpre'] = torch.empty(M, h, dtype=torch.bfloat16, device=dev) if self.hpre16 else f(M, h)
+                b[q + 'act'] = f(M, h)
             b[pre + 'dx'], b[pre + 'dy'], b[pre + 'do'] = f(M, d), f(M, d), f(M, d)
             b[pre + 'dh'], b[pre + 'dqkv'] = f(M, h), f(M, 3 * d)
 
@@ -388,23 +363,6 @@ class HipMAEEngine:
                     if self.qkv16:
                         b[q + 'qkv_16'] = z16(Mp, 3 * d)
                 b[pre + 'dx_16'], b[pre + 'dh_16'], b[pre + 'dqkv_16'] = z16(Mp, d), z16(Mp, h), z16(Mp, 3 * d)
-                if self.fuse_mlp:
-                    # per block: the four dy operands of its (deferred) weight gradients + the saved fc1 pre-activation
-                    for i in range(depth):
-                        q = f'{pre}{i}.'
-                        b[q + 'gout_16'], b[q + 'gmid_16'] = z16(Mp, d), z16(Mp, d)
-                        b[q + 'dh_16'], b[q + 'dqkv_16'], b[q + 'hpre_16'] = z16(Mp, h), z16(Mp, 3 * d), z16(Mp, h)
-                    b[pre + 'slabs'] = torch.empty(lib.vitae_mlp_fused_slabs(h), Mp, d, dtype=torch.float32, device=dev)
-                if self.slab_k:
-                    smax = max(self._slab_split(Me if pre == 'enc' else Md, d, k) for k in (d, h, 3 * d))
-                    b[pre + 'kslab'] = torch.empty(smax, Mp, d, dtype=torch.float32, device=dev)
-            if self.fold_ln:
-                # (sum, sum of squares) of the residual-stream rows in front of every folded LayerNorm;
-                # st1 of block i is filled by the fc2 GEMM of block i - 1, st2 by the block's own proj GEMM
-                for pre, depth, M, d in (('enc', cfg.depth, Me, D), ('dec', cfg.decoder_depth, Md, Dd)):
-                    for i in range(depth):
-                        for nm in ('st1', 'st2'):
-                            b[f'{pre}{i}.{nm}'] = f((d + 63) // 64, M, 2)      # 64-column partials, all written every step
             b['dn_16'] = z16(self.Mpd, Dd)
             b['dpred_16'] = z16(self.Mpd, P)
             b['patches_16'], b['dtok_16'] = z16(self.Mpt, P), z16(self.Mpt, D)
@@ -604,9 +562,8 @@ class HipMAEEngine:
                                 M, D, dx_accumulate, self.stream)
 
     # ------------------------------------------------------------------ bf16-activation GEMM helpers (LDS-DMA kernel)
-    def _g16_fwd(self, x16, w, bias, M, N, K, y=None, y16=None, epi=EPI_NONE, aux=None, res=None, rowstats=None):
-        """y / y16 = epi(x16 @ W16^T + b) (+ res) on the LDS-DMA GEMM (bf16 operands in HBM).  ``rowstats``:
-        [N / 64, M, 2] array that receives (sum, sum of squares) of the result rows per 64-column slot — the statistics of the LayerNorm that follows."""
+    def _g16_fwd(self, x16, w, bias, M, N, K, y=None, y16=None, epi=EPI_NONE, aux=None, res=None):
+        """y / y16 = epi(x16 @ W16^T + b) (+ res) on the LDS-DMA GEMM (bf16 operands in HBM)."""
         key = ('g', M, N, K)
         s = self._split_cache.get(key)
         if s is None:
@@ -615,12 +572,8 @@ class HipMAEEngine:
                 s -= 1
             self._split_cache[key] = s
         t = self._timed(2.0 * M * N * K, self._gemm_tag(1, 1, M, N, K, s, 'glds' if N < 8192 else 'glds_wide'))   # wide = the 64x128-tile instantiation
-        if rowstats is not None:
-            lib.vitae_gemm_glds_stats(1, 1, _ptr(x16), K, self._w16(w), K, _ptr(y), N, _ptr(y16), N, M, N, K, _ptr(bias), _ptr(res), N,
-                                      epi, _ptr(aux), N, 0, s, self.ws16.data_ptr(), None, _ptr(rowstats), self.stream)
-        else:
-            lib.vitae_gemm_glds(1, 1, _ptr(x16), K, self._w16(w), K, _ptr(y), N, _ptr(y16), N, M, N, K, _ptr(bias), _ptr(res), N,
-                                epi, _ptr(aux), N, 0, s, self.ws16.data_ptr(), None, self.stream)
+        lib.vitae_gemm_glds(1, 1, _ptr(x16), K, self._w16(w), K, _ptr(y), N, _ptr(y16), N, M, N, K, _ptr(bias), _ptr(res), N,
+                            epi, _ptr(aux), N, 0, s, self.ws16.data_ptr(), None, self.stream)
         if t is not None:
             t.record()
 
@@ -635,16 +588,6 @@ class HipMAEEngine:
             tag = default if (c < 0 or lib.vitae_gemm_glds_pick_split_k(M, N, K) != split) else ('bt256' if c == 0 else 'bt128')
             self._split_cache[key] = tag
         return tag
-
-    def _g16_fwd_ln(self, x, stats, pre_ln, w, bias, M, N, K, y16_ln, mean, rstd, y=None, y16=None, epi=EPI_NONE, aux=None):
-        """y / y16 = epi(LayerNorm(x) @ W16^T + b) in one launch (x fp32 [M, K] with row statistics ``stats``); the bf16 LayerNorm
-        output and mean / rstd (what the backward reads) are stored on the way."""
-        t = self._timed(2.0 * M * N * K, 'glds')
-        lib.vitae_gemm_glds_lnfold(_ptr(x), K, _ptr(stats), stats.shape[0], _ptr(self.p[pre_ln + 'weight']), _ptr(self.p[pre_ln + 'bias']),
-                                   self.cfg.ln_eps, self._w16(w), K, _ptr(y), N, _ptr(y16), N, M, N, K, _ptr(bias), epi, _ptr(aux), N,
-                                   _ptr(y16_ln), K, _ptr(mean), _ptr(rstd), self.stream)
-        if t is not None:
-            t.record()
 
     def _wire_of(self, gview: torch.Tensor):
         """bf16 data-parallel exchange: address of this gradient tensor's slot in the wire buffer (same layout as the
@@ -701,206 +644,14 @@ class HipMAEEngine:
         if t is not None:
             t.record()
 
-    # ------------------------------------------------------------------ fused-MLP block chain (csrc/mlp_fused.hip)
-    def _ln_fwd_slabs(self, s, res, bias, pre, x_out, mean, rstd, M, D, y16, y=None):
-        """x_out = res + bias + sum of the stack's MLP slabs; y16 (and y) = LayerNorm(x_out)."""
-        sl = self.buf[s + 'slabs']
-        lib.vitae_layernorm_fwd_slabs(sl.data_ptr(), sl.shape[0], sl.stride(0), _ptr(res), _ptr(bias), _ptr(self.p[pre + 'weight']),
-                                      _ptr(self.p[pre + 'bias']), _ptr(x_out), _ptr(y), _ptr(y16), _ptr(mean), _ptr(rstd), M, D,
-                                      self.cfg.ln_eps, self.stream)
-
-    def _g16_dgrad(self, dy16, w, M, N, K, dx=None, dx16=None, epi=EPI_NONE, aux=None, dx_colsum=None, accumulate=0):
-        """dx / dx16 [M, K] = epi(dy16[M, N] @ W16[N, K]) on the LDS-DMA GEMM (dgrad only: the weight gradient is deferred)."""
-        key = ('d', M, N, K)
-        sp = self._split_cache.get(key)
-        if sp is None:
-            sp = lib.vitae_gemm_glds_pick_split_k(M, K, N)
-            while sp > 1 and lib.vitae_gemm_glds_ws_floats(M, K, sp) > self.ws16.numel():
-                sp -= 1
-            self._split_cache[key] = sp
-        t = self._timed(2.0 * M * N * K, 'glds_dgrad')
-        lib.vitae_gemm_glds(1, 0, _ptr(dy16), N, self._w16(w), K, _ptr(dx), K, _ptr(dx16), K, M, K, N, None, None, 0, epi, _ptr(aux), K,
-                            int(accumulate), sp, self.ws16.data_ptr(), _ptr(dx_colsum), self.stream)
-        if t is not None:
-            t.record()
-
-    def _wgrad_group(self, items, Mp):
-        """Weight gradients of up to four Linears as ONE launch; items = [(dy16, x16, dw, dbias | None, N, K)].  They are off
-        the critical path (nothing reads dW before the optimiser), so the launch goes to the wgrad side stream and is joined
-        at the end of the backward phase (``_wg_join``)."""
-        n = len(items)
-        arr = lambda vals: np.array(list(vals) + [0] * (4 - n), dtype=np.uint64)
-        dy = arr(t[0].data_ptr() for t in items)
-        x = arr(t[1].data_ptr() for t in items)
-        dw = arr(t[2].data_ptr() for t in items)
-        w16 = arr((self._wire_of(t[2]) or 0) for t in items)
-        db = arr((0 if t[3] is None else t[3].data_ptr()) for t in items)
-        N = np.array([t[4] for t in items] + [0] * (4 - n), dtype=np.int32)
-        K = np.array([t[5] for t in items] + [0] * (4 - n), dtype=np.int32)
-        side = self.wgrad_side and self.gemm_timer is None
-        if side:
-            self.wside.wait_stream(torch.cuda.current_stream(self.device))
-            stream = self.wside.cuda_stream
-        else:
-            stream = self.stream
-        t = self._timed(sum(2.0 * Mp * it[4] * it[5] for it in items), 'glds_wgrad_group')
-        lib.vitae_wgrad_group_glds(n, dy.ctypes.data, x.ctypes.data, dw.ctypes.data, w16.ctypes.data, db.ctypes.data,
-                                   N.ctypes.data, K.ctypes.data, Mp, int(self._accum), stream)
-        if t is not None:
-            t.record()
-        if side:
-            self._wg_pending.add('group')
-
-    def _block_fwd_fused(self, pre, q, s, prev, x_in, Bs, N, d, heads, hd, hid, Mp):
-        """model/vit.py:139-144 as 6 launches.  ``prev`` = (state-dict prefix, workspace prefix) of the block below, whose MLP
-        result still sits in the stack's slabs: this block's first LayerNorm sums them into ``x_in`` (the launch-boundary
-        reduce); None for the first block of a stack (``x_in`` is final)."""
-        b, p, M = self.buf, self.p, Bs * N
-        if prev is None:
-            self._ln_fwd(x_in, pre + 'norm1.', None, b[q + 'mean1'], b[q + 'rstd1'], M, d, y16=b[q + 'y1_16'])
-        else:
-            self._ln_fwd_slabs(s, b[prev[1] + 'xmid'], p[prev[0] + 'mlp.fc2.bias'], pre + 'norm1.', x_in, b[q + 'mean1'],
-                               b[q + 'rstd1'], M, d, b[q + 'y1_16'])
-        self._g16_fwd(b[q + 'y1_16'], p[pre + 'attn.qkv.weight'], p[pre + 'attn.qkv.bias'], M, 3 * d, d, y=b[q + 'qkv'])
-        lib.vitae_sdpa_mfma_fwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(b[q + 'o_16']), _ptr(b[q + 'lse']), Bs, N, heads, hd,
-                                self.stream)
-        self._g16_fwd(b[q + 'o_16'], p[pre + 'attn.proj.weight'], p[pre + 'attn.proj.bias'], M, d, d, y=b[q + 'xmid'], res=x_in)
-        self._ln_fwd(b[q + 'xmid'], pre + 'norm2.', None, b[q + 'mean2'], b[q + 'rstd2'], M, d, y16=b[q + 'y2_16'])
-        lib.vitae_mlp_fused_fwd(_ptr(b[q + 'y2_16']), self._w16(p[pre + 'mlp.fc1.weight']), _ptr(p[pre + 'mlp.fc1.bias']),
-                                self._w16(p[pre + 'mlp.fc2.weight']), _ptr(b[q + 'hpre_16']), _ptr(b[q + 'act_16']),
-                                _ptr(b[s + 'slabs']), M, Mp, d, hid, self.stream)
-
-    def _block_bwd_fused(self, pre, q, s, x_in, Bs, N, d, heads, hd, hid, Mp, prev_q, prev_fc2_bias):
-        """Backward of one block, 7 launches on the chain + one grouped weight-gradient launch beside it.  On entry
-        buf[s+'dx'] (fp32) and buf[q+'gout_16'] hold the gradient of the block's output; the gradient of its input leaves in
-        buf[s+'dx'] and, in bf16, in the block below's ``gout_16`` (``prev_q``)."""
-        b, p, g, M = self.buf, self.p, self.g, Bs * N
-        dx, dy, do, dqkv = b[s + 'dx'], b[s + 'dy'], b[s + 'do'], b[s + 'dqkv']
-        sl = b[s + 'slabs']
-        lib.vitae_mlp_fused_bwd(_ptr(b[q + 'gout_16']), self._w16(p[pre + 'mlp.fc1.weight']), self._w16(p[pre + 'mlp.fc2.weight']),
-                                _ptr(b[q + 'hpre_16']), _ptr(b[q + 'dh_16']), _ptr(sl), M, Mp, d, hid, self.stream)
-        lib.vitae_layernorm_bwd_slabs(sl.data_ptr(), sl.shape[0], sl.stride(0), _ptr(b[q + 'xmid']), _ptr(p[pre + 'norm2.weight']),
-                                      _ptr(b[q + 'mean2']), _ptr(b[q + 'rstd2']), _ptr(dx), _ptr(g[pre + 'norm2.weight']),
-                                      _ptr(g[pre + 'norm2.bias']), _ptr(b[q + 'gmid_16']), _ptr(g[pre + 'attn.proj.bias']), M, d, 1,
-                                      self.stream)
-        self._g16_dgrad(b[q + 'gmid_16'], p[pre + 'attn.proj.weight'], M, d, d, dx=do)
-        lib.vitae_sdpa_mfma_bwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(do), _ptr(b[q + 'lse']), _ptr(self._dqkv32(dqkv, N, hd)), _ptr(b[q + 'dqkv_16']),
-                                None, _ptr(b['delta']), Bs, N, heads, hd, self.stream)
-        self._wgrad_group([
-            (b[q + 'gout_16'], b[q + 'act_16'], g[pre + 'mlp.fc2.weight'], None, d, hid),
-            (b[q + 'dh_16'], b[q + 'y2_16'], g[pre + 'mlp.fc1.weight'], g[pre + 'mlp.fc1.bias'], hid, d),
-            (b[q + 'gmid_16'], b[q + 'o_16'], g[pre + 'attn.proj.weight'], None, d, d),
-            (b[q + 'dqkv_16'], b[q + 'y1_16'], g[pre + 'attn.qkv.weight'], g[pre + 'attn.qkv.bias'], 3 * d, d)], Mp)
-        self._g16_dgrad(b[q + 'dqkv_16'], p[pre + 'attn.qkv.weight'], M, 3 * d, d, dx=dy)
-        self._ln_bwd(dy, x_in, pre + 'norm1.', b[q + 'mean1'], b[q + 'rstd1'], dx, M, d, 1,
-                     dx16=b[prev_q + 'gout_16'] if prev_q is not None else None, dx_colsum=prev_fc2_bias)
-
-    # ------------------------------------------------------------------ split-K slabs summed by the consuming LayerNorm
-    def _slab_split(self, M, N, K):
-        """k-splits of a slab-mode GEMM with an [M, N] result reduced over K: enough workgroups to fill the chip, at least
-        ``_slabk_min_kt`` 64-deep k-tiles each (the per-split fix-up is gone, so shorter splits than the in-launch reduction
-        allows pay off)."""
-        tiles = ((M + 63) // 64) * ((N + 63) // 64)
-        want = max(1, -(-self._slabk_target // tiles))
-        by_k = max(1, (K // 64) // self._slabk_min_kt)
-        return int(lib.vitae_gemm_glds_slab_count(K, min(want, by_k, 16)))
-
-    def _g16_fwd_slabs(self, x16, w, s, M, N, K):
-        """slabs of (x16 @ W16^T) in buf[s+'kslab']; -> number of slabs"""
-        sl = self.buf[s + 'kslab']
-        n = self._slab_split(M, N, K)
-        t = self._timed(2.0 * M * N * K, 'glds_slab')
-        lib.vitae_gemm_glds_slabs(1, 1, _ptr(x16), K, self._w16(w), K, sl.data_ptr(), sl.stride(0), M, N, K, n, self.stream)
-        if t is not None:
-            t.record()
-        return n
-
-    def _g16_bwd_slabs(self, dy16, w, x16, dw, s, M, Mpad, N, K, dy_colsum=None):
-        """dW (+)= dy16^T x16 and the slabs of dx = dy16 @ W16 in buf[s+'kslab'] (one paired launch); -> number of slabs"""
-        sl = self.buf[s + 'kslab']
-        n = self._slab_split(M, K, N)
-        t = self._timed(4.0 * M * N * K, 'glds_pair_slab')
-        lib.vitae_linear_bwd_pair_glds_slabs(_ptr(dy16), self._w16(w), _ptr(x16), sl.data_ptr(), sl.stride(0), _ptr(dw), self._wire_of(dw),
-                                             M, Mpad, N, K, _ptr(dy_colsum), int(self._accum), n, self.stream)
-        if t is not None:
-            t.record()
-        return n
-
-    def _ln_fwd_kslab(self, s, n, res, bias, pre, x_out, mean, rstd, M, D, y16, y=None):
-        sl = self.buf[s + 'kslab']
-        lib.vitae_layernorm_fwd_slabs(sl.data_ptr(), n, sl.stride(0), _ptr(res), _ptr(bias), _ptr(self.p[pre + 'weight']),
-                                      _ptr(self.p[pre + 'bias']), _ptr(x_out), _ptr(y), _ptr(y16), _ptr(mean), _ptr(rstd), M, D,
-                                      self.cfg.ln_eps, self.stream)
-
-    def _ln_bwd_kslab(self, s, n, x, pre, mean, rstd, dx, M, D, dx16, dx_colsum):
-        sl, g = self.buf[s + 'kslab'], self.g
-        lib.vitae_layernorm_bwd_slabs(sl.data_ptr(), n, sl.stride(0), _ptr(x), _ptr(self.p[pre + 'weight']), _ptr(mean), _ptr(rstd),
-                                      _ptr(dx), _ptr(g[pre + 'weight']), _ptr(g[pre + 'bias']), _ptr(dx16), _ptr(dx_colsum), M, D, 1,
-                                      self.stream)
-
-    def _block_fwd_slabk(self, pre, q, s, prev, x_in, Bs, N, d, heads, hd, hid):
-        """model/vit.py:139-144, 7 launches like ``_block_fwd16`` — but proj and fc2 are split-K GEMMs in slab mode and the two
-        LayerNorms sum their slabs (+ bias + residual).  ``prev`` = (state-dict prefix, workspace prefix, slab count) of the
-        block below, whose fc2 result still sits in the stack's slabs; None for the first block.  -> this block's fc2 slab count"""
-        b, p, M = self.buf, self.p, Bs * N
-        self._scope = s
-        if prev is None:
-            self._ln_fwd(x_in, pre + 'norm1.', None, b[q + 'mean1'], b[q + 'rstd1'], M, d, y16=b[q + 'y1_16'])
-        else:
-            self._ln_fwd_kslab(s, prev[2], b[prev[1] + 'xmid'], p[prev[0] + 'mlp.fc2.bias'], pre + 'norm1.', x_in, b[q + 'mean1'],
-                               b[q + 'rstd1'], M, d, b[q + 'y1_16'])
-        self._g16_fwd(b[q + 'y1_16'], p[pre + 'attn.qkv.weight'], p[pre + 'attn.qkv.bias'], M, 3 * d, d, y=b[q + 'qkv'])
-        t = self._timed(4.0 * Bs * heads * N * N * hd, 'attn')
-        lib.vitae_sdpa_mfma_fwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(b[q + 'o_16']), _ptr(b[q + 'lse']), Bs, N, heads, hd,
-                                self.stream)
-        if t is not None:
-            t.record()
-        n = self._g16_fwd_slabs(b[q + 'o_16'], p[pre + 'attn.proj.weight'], s, M, d, d)
-        self._ln_fwd_kslab(s, n, x_in, p[pre + 'attn.proj.bias'], pre + 'norm2.', b[q + 'xmid'], b[q + 'mean2'], b[q + 'rstd2'], M, d,
-                           b[q + 'y2_16'])
-        self._g16_fwd(b[q + 'y2_16'], p[pre + 'mlp.fc1.weight'], p[pre + 'mlp.fc1.bias'], M, hid, d, y16=b[q + 'act_16'],
-                      epi=EPI_GELU | self._aux16, aux=b[q + 'hpre'])
-        n = self._g16_fwd_slabs(b[q + 'act_16'], p[pre + 'mlp.fc2.weight'], s, M, d, hid)
-        self._scope = None
-        return n
-
-    def _block_bwd_slabk(self, pre, q, s, x_in, Bs, N, d, heads, hd, hid, Mp, prev_fc2_bias):
-        """Backward of one block like ``_block_bwd16``; the input gradients of fc1 and qkv leave their paired launches as
-        slabs and are summed by the LayerNorm backward that consumes them."""
-        b, p, g, M = self.buf, self.p, self.g, Bs * N
-        self._scope = s
-        dx, dx16, dh16, do, dqkv, dqkv16 = b[s + 'dx'], b[s + 'dx_16'], b[s + 'dh_16'], b[s + 'do'], b[s + 'dqkv'], b[s + 'dqkv_16']
-        self._g16_bwd(dx16, p[pre + 'mlp.fc2.weight'], b[q + 'act_16'], g[pre + 'mlp.fc2.weight'], M, Mp, d, hid,
-                      dx16=dh16, epi=EPI_DGELU | self._aux16, aux=b[q + 'hpre'], dx_colsum=g[pre + 'mlp.fc1.bias'])
-        n = self._g16_bwd_slabs(dh16, p[pre + 'mlp.fc1.weight'], b[q + 'y2_16'], g[pre + 'mlp.fc1.weight'], s, M, Mp, hid, d)
-        self._ln_bwd_kslab(s, n, b[q + 'xmid'], pre + 'norm2.', b[q + 'mean2'], b[q + 'rstd2'], dx, M, d, dx16, g[pre + 'attn.proj.bias'])
-        self._g16_bwd(dx16, p[pre + 'attn.proj.weight'], b[q + 'o_16'], g[pre + 'attn.proj.weight'], M, Mp, d, d, dx=do)
-        t = self._timed(10.0 * Bs * heads * N * N * hd, 'attn')
-        lib.vitae_sdpa_mfma_bwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(do), _ptr(b[q + 'lse']), _ptr(self._dqkv32(dqkv, N, hd)), _ptr(dqkv16),
-                                None, _ptr(b['delta']), Bs, N, heads, hd, self.stream)
-        if t is not None:
-            t.record()
-        n = self._g16_bwd_slabs(dqkv16, p[pre + 'attn.qkv.weight'], b[q + 'y1_16'], g[pre + 'attn.qkv.weight'], s, M, Mp, 3 * d, d,
-                                dy_colsum=g[pre + 'attn.qkv.bias'])
-        self._ln_bwd_kslab(s, n, x_in, pre + 'norm1.', b[q + 'mean1'], b[q + 'rstd1'], dx, M, d, dx16, prev_fc2_bias)
-        self._scope = None
-
     # ------------------------------------------------------------------ transformer block
     def _block_fwd16(self, pre, q, x_in, x_out, Bs, N, d, heads, hd, hid):
         """model/vit.py:139-144 with bf16 GEMM operands written by their producers."""
         b, p, M = self.buf, self.p, Bs * N
-        fold = self.fold_ln and d in (512, 768, 1024)
-        i = int(q[3:-1])
-        st_in = b[q + 'st1'] if (fold and i > 0) else None                 # statistics of x_in (left by the block below)
-        st_out = b.get(f'{q[:3]}{i + 1}.st1') if fold else None           # ... of x_out for the block above (None: last block)
         q16 = self._qkv16_ok(N, hd)
         qkv32, qkv16 = (None, b[q + 'qkv_16']) if q16 else (b[q + 'qkv'], None)
-        if st_in is not None:
-            self._g16_fwd_ln(x_in, st_in, pre + 'norm1.', p[pre + 'attn.qkv.weight'], p[pre + 'attn.qkv.bias'], M, 3 * d, d,
-                             b[q + 'y1_16'], b[q + 'mean1'], b[q + 'rstd1'], y=qkv32, y16=qkv16)
-        else:
-            self._ln_fwd(x_in, pre + 'norm1.', None, b[q + 'mean1'], b[q + 'rstd1'], M, d, y16=b[q + 'y1_16'])
-            self._g16_fwd(b[q + 'y1_16'], p[pre + 'attn.qkv.weight'], p[pre + 'attn.qkv.bias'], M, 3 * d, d, y=qkv32, y16=qkv16)
+        self._ln_fwd(x_in, pre + 'norm1.', None, b[q + 'mean1'], b[q + 'rstd1'], M, d, y16=b[q + 'y1_16'])
+        self._g16_fwd(b[q + 'y1_16'], p[pre + 'attn.qkv.weight'], p[pre + 'attn.qkv.bias'], M, 3 * d, d, y=qkv32, y16=qkv16)
         t = self._timed(4.0 * Bs * heads * N * N * hd, 'attn')
         if q16:
             lib.vitae_sdpa_mfma_fwd_bf16in(_ptr(qkv16), _ptr(b[q + 'o']), _ptr(b[q + 'o_16']), _ptr(b[q + 'lse']), Bs, N, heads, hd,
@@ -910,18 +661,11 @@ class HipMAEEngine:
                                     self.stream)
         if t is not None:
             t.record()
-        if fold:
-            self._g16_fwd(b[q + 'o_16'], p[pre + 'attn.proj.weight'], p[pre + 'attn.proj.bias'], M, d, d, y=b[q + 'xmid'], res=x_in,
-                          rowstats=b[q + 'st2'])
-            self._g16_fwd_ln(b[q + 'xmid'], b[q + 'st2'], pre + 'norm2.', p[pre + 'mlp.fc1.weight'], p[pre + 'mlp.fc1.bias'], M, hid, d,
-                             b[q + 'y2_16'], b[q + 'mean2'], b[q + 'rstd2'], y16=b[q + 'act_16'], epi=EPI_GELU | self._aux16, aux=b[q + 'hpre'])
-        else:
-            self._g16_fwd(b[q + 'o_16'], p[pre + 'attn.proj.weight'], p[pre + 'attn.proj.bias'], M, d, d, y=b[q + 'xmid'], res=x_in)
-            self._ln_fwd(b[q + 'xmid'], pre + 'norm2.', None, b[q + 'mean2'], b[q + 'rstd2'], M, d, y16=b[q + 'y2_16'])
-            self._g16_fwd(b[q + 'y2_16'], p[pre + 'mlp.fc1.weight'], p[pre + 'mlp.fc1.bias'], M, hid, d, y16=b[q + 'act_16'],
-                          epi=EPI_GELU | self._aux16, aux=b[q + 'hpre'])
-        self._g16_fwd(b[q + 'act_16'], p[pre + 'mlp.fc2.weight'], p[pre + 'mlp.fc2.bias'], M, d, hid, y=x_out, res=b[q + 'xmid'],
-                      rowstats=st_out)
+        self._g16_fwd(b[q + 'o_16'], p[pre + 'attn.proj.weight'], p[pre + 'attn.proj.bias'], M, d, d, y=b[q + 'xmid'], res=x_in)
+        self._ln_fwd(b[q + 'xmid'], pre + 'norm2.', None, b[q + 'mean2'], b[q + 'rstd2'], M, d, y16=b[q + 'y2_16'])
+        self._g16_fwd(b[q + 'y2_16'], p[pre + 'mlp.fc1.weight'], p[pre + 'mlp.fc1.bias'], M, hid, d, y16=b[q + 'act_16'],
+                      epi=EPI_GELU | self._aux16, aux=b[q + 'hpre'])
+        self._g16_fwd(b[q + 'act_16'], p[pre + 'mlp.fc2.weight'], p[pre + 'mlp.fc2.bias'], M, d, hid, y=x_out, res=b[q + 'xmid'])
 
     def _qkv16_ok(self, N, hd) -> bool:
         """bf16-only qkv for this stack: the flag, an MFMA head size, and the whole head fitting the one-launch backward"""
@@ -1093,24 +837,9 @@ class HipMAEEngine:
         ex = b['encx']
         lib.vitae_encoder_assemble_fwd(_ptr(b['tok']), _ptr(p['cls_token']), _ptr(self.buffers['pos_embed']),
                                        _ptr(b['ids_shuffle']), _ptr(ex[0]), Be, L, keep, D, st)
-        if self.slab_k:
-            prev = None
-            for i in range(cfg.depth):
-                n = self._block_fwd_slabk(f'blocks.{i}.', f'enc{i}.', 'enc', prev, ex[i], Be, Ne, D, cfg.num_heads, self.hd, self.Hm)
-                prev = (f'blocks.{i}.', f'enc{i}.', n)
-            self._ln_fwd_kslab('enc', prev[2], b[prev[1] + 'xmid'], p[prev[0] + 'mlp.fc2.bias'], 'norm.', ex[cfg.depth], b['lat_mean'],
-                               b['lat_rstd'], Me, D, b['latent_16'], y=b['latent'])
-        elif self.fuse_mlp:
-            for i in range(cfg.depth):
-                self._block_fwd_fused(f'blocks.{i}.', f'enc{i}.', 'enc', (f'blocks.{i - 1}.', f'enc{i - 1}.') if i else None, ex[i],
-                                      Be, Ne, D, cfg.num_heads, self.hd, self.Hm, self.Mpe)
-            last = cfg.depth - 1
-            self._ln_fwd_slabs('enc', b[f'enc{last}.xmid'], p[f'blocks.{last}.mlp.fc2.bias'], 'norm.', ex[cfg.depth], b['lat_mean'],
-                               b['lat_rstd'], Me, D, b['latent_16'], y=b['latent'])
-        else:
-            for i in range(cfg.depth):
-                self._block_fwd(f'blocks.{i}.', f'enc{i}.', ex[i], ex[i + 1], Be, Ne, D, cfg.num_heads, self.hd, self.Hm)
-            self._ln_fwd(ex[cfg.depth], 'norm.', b['latent'], b['lat_mean'], b['lat_rstd'], Me, D, y16=b.get('latent_16'))
+        for i in range(cfg.depth):
+            self._block_fwd(f'blocks.{i}.', f'enc{i}.', ex[i], ex[i + 1], Be, Ne, D, cfg.num_heads, self.hd, self.Hm)
+        self._ln_fwd(ex[cfg.depth], 'norm.', b['latent'], b['lat_mean'], b['lat_rstd'], Me, D, y16=b.get('latent_16'))
         if cfg.contrastive and self.overlap_predictor:
             # the predictor branch only needs the latent: it runs on its own stream beside the decoder and the loss chain
             self.pside.wait_stream(torch.cuda.current_stream(self.device))
@@ -1127,29 +856,11 @@ class HipMAEEngine:
         dx_ = b['decx']
         lib.vitae_decoder_assemble_fwd(_ptr(b['e']), _ptr(p['mask_token']), _ptr(self.buffers['decoder_pos_embed']),
                                        _ptr(b['ids_restore']), _ptr(dx_[0]), B, L, keep, Dd, st)
-        if self.slab_k:
-            prev = None
-            for i in range(cfg.decoder_depth):
-                n = self._block_fwd_slabk(f'decoder_blocks.{i}.', f'dec{i}.', 'dec', prev, dx_[i], B, Nd, Dd, cfg.decoder_num_heads,
-                                          self.hdd, self.Hmd)
-                prev = (f'decoder_blocks.{i}.', f'dec{i}.', n)
-            self._ln_fwd_kslab('dec', prev[2], b[prev[1] + 'xmid'], p[prev[0] + 'mlp.fc2.bias'], 'decoder_norm.',
-                               dx_[cfg.decoder_depth], b['dn_mean'], b['dn_rstd'], Md, Dd, b['dn_16'])
-        elif self.fuse_mlp:
-            for i in range(cfg.decoder_depth):
-                self._block_fwd_fused(f'decoder_blocks.{i}.', f'dec{i}.', 'dec',
-                                      (f'decoder_blocks.{i - 1}.', f'dec{i - 1}.') if i else None, dx_[i], B, Nd, Dd,
-                                      cfg.decoder_num_heads, self.hdd, self.Hmd, self.Mpd)
-            last = cfg.decoder_depth - 1
-            self._ln_fwd_slabs('dec', b[f'dec{last}.xmid'], p[f'decoder_blocks.{last}.mlp.fc2.bias'], 'decoder_norm.',
-                               dx_[cfg.decoder_depth], b['dn_mean'], b['dn_rstd'], Md, Dd, b['dn_16'])
-        else:
-            for i in range(cfg.decoder_depth):
-                self._block_fwd(f'decoder_blocks.{i}.', f'dec{i}.', dx_[i], dx_[i + 1], B, Nd, Dd, cfg.decoder_num_heads,
-                                self.hdd, self.Hmd)
+        for i in range(cfg.decoder_depth):
+            self._block_fwd(f'decoder_blocks.{i}.', f'dec{i}.', dx_[i], dx_[i + 1], B, Nd, Dd, cfg.decoder_num_heads,
+                            self.hdd, self.Hmd)
         if a16:
-            if not (self.fuse_mlp or self.slab_k):
-                self._ln_fwd(dx_[cfg.decoder_depth], 'decoder_norm.', None, b['dn_mean'], b['dn_rstd'], Md, Dd, y16=b['dn_16'])
+            self._ln_fwd(dx_[cfg.decoder_depth], 'decoder_norm.', None, b['dn_mean'], b['dn_rstd'], Md, Dd, y16=b['dn_16'])
             self._g16_fwd(b['dn_16'], p['decoder_pred.weight'], p['decoder_pred.bias'], Md, P, Dd, y=b['predfull'])
         else:
             self._ln_fwd(dx_[cfg.decoder_depth], 'decoder_norm.', b['dn'], b['dn_mean'], b['dn_rstd'], Md, Dd)
@@ -1265,19 +976,11 @@ class HipMAEEngine:
                 self._g16_bwd(b['dpred_16'], p['decoder_pred.weight'], b['dn_16'], g['decoder_pred.weight'], Md, self.Mpd, P, Dd,
                               dx=b['ddn'])
                 self._ln_bwd(b['ddn'], dx_[nd], 'decoder_norm.', b['dn_mean'], b['dn_rstd'], b['decdx'], Md, Dd, 0,
-                             dx16=b[f'dec{nd - 1}.gout_16'] if self.fuse_mlp else b['decdx_16'],
+                             dx16=b['decdx_16'],
                              dx_colsum=g[f'decoder_blocks.{nd - 1}.mlp.fc2.bias'])
             for i in blocks:
-                if self.slab_k_bwd:
-                    self._block_bwd_slabk(f'decoder_blocks.{i}.', f'dec{i}.', 'dec', dx_[i], B, Nd, Dd, cfg.decoder_num_heads,
-                                          self.hdd, self.Hmd, self.Mpd, g[f'decoder_blocks.{i - 1}.mlp.fc2.bias'] if i > 0 else None)
-                elif self.fuse_mlp:
-                    self._block_bwd_fused(f'decoder_blocks.{i}.', f'dec{i}.', 'dec', dx_[i], B, Nd, Dd, cfg.decoder_num_heads,
-                                          self.hdd, self.Hmd, self.Mpd, f'dec{i - 1}.' if i > 0 else None,
-                                          g[f'decoder_blocks.{i - 1}.mlp.fc2.bias'] if i > 0 else None)
-                else:
-                    self._block_bwd16(f'decoder_blocks.{i}.', f'dec{i}.', 'dec', dx_[i], B, Nd, Dd, cfg.decoder_num_heads, self.hdd,
-                                      self.Hmd, self.Mpd, g[f'decoder_blocks.{i - 1}.mlp.fc2.bias'] if i > 0 else None)
+                self._block_bwd16(f'decoder_blocks.{i}.', f'dec{i}.', 'dec', dx_[i], B, Nd, Dd, cfg.decoder_num_heads, self.hdd,
+                                  self.Hmd, self.Mpd, g[f'decoder_blocks.{i - 1}.mlp.fc2.bias'] if i > 0 else None)
         else:
             if top:
                 self._lin_bwd(b['dpredfull'], p['decoder_pred.weight'], b['dn'], b['ddn'], g['decoder_pred.weight'],
@@ -1330,7 +1033,7 @@ class HipMAEEngine:
             dec_embed_bwd(0)
         if a16:
             self._ln_bwd(b['dlatent'], b['encx'][cfg.depth], 'norm.', b['lat_mean'], b['lat_rstd'], b['encdx'], Me, D, 0,
-                         dx16=b[f'enc{cfg.depth - 1}.gout_16'] if self.fuse_mlp else b['encdx_16'],
+                         dx16=b['encdx_16'],
                          dx_colsum=g[f'blocks.{cfg.depth - 1}.mlp.fc2.bias'])
         else:
             self._ln_bwd(b['dlatent'], b['encx'][cfg.depth], 'norm.', b['lat_mean'], b['lat_rstd'], b['encdx'], Me, D, 0)
@@ -1356,14 +1059,7 @@ class HipMAEEngine:
         self.stream = torch.cuda.current_stream(self.device).cuda_stream
         ex = self.buf['encx']
         for i in range(hi, lo - 1, -1):
-            if self.slab_k_bwd:
-                self._block_bwd_slabk(f'blocks.{i}.', f'enc{i}.', 'enc', ex[i], self.Be, self.Ne, cfg.embed_dim, cfg.num_heads,
-                                      self.hd, self.Hm, self.Mpe, self.g[f'blocks.{i - 1}.mlp.fc2.bias'] if i > 0 else None)
-            elif self.fuse_mlp:
-                self._block_bwd_fused(f'blocks.{i}.', f'enc{i}.', 'enc', ex[i], self.Be, self.Ne, cfg.embed_dim, cfg.num_heads,
-                                      self.hd, self.Hm, self.Mpe, f'enc{i - 1}.' if i > 0 else None,
-                                      self.g[f'blocks.{i - 1}.mlp.fc2.bias'] if i > 0 else None)
-            elif self.act16:
+            if self.act16:
                 self._block_bwd16(f'blocks.{i}.', f'enc{i}.', 'enc', ex[i], self.Be, self.Ne, cfg.embed_dim, cfg.num_heads,
                                   self.hd, self.Hm, self.Mpe, self.g[f'blocks.{i - 1}.mlp.fc2.bias'] if i > 0 else None)
             else:
