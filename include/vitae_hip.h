@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITAE_ABI_VERSION 30
+#define VITAE_ABI_VERSION 31
 
 /* matrix-core arithmetic of the dense contractions */
 #define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
@@ -315,6 +315,15 @@ int vitae_loss_bwd_fused(const float* pred, const float* pred_vol, const float* 
                          void* dpred_bf16, float* nonfinite_flag /* optional: set to NaN when a non-finite gradient is written
                          (C in {1,4} only) */, long pred_bstride, float mask_sum, int B, int C, int Lz, int Hy, int Wx, int p,
                          void* stream);
+/* Both of the above in ONE pass over the prediction (csrc/loss_fused.hip; C = 4): acc[VITAE_ACC_RECON] / acc[VITAE_ACC_EDGE] as
+ * vitae_loss_fwd_fused, dpred / dpred_bf16 / nonfinite_flag as vitae_loss_bwd_fused; the unpatchified prediction and its edge map
+ * are not produced.  Both MSE terms are linear in their upstream gradient (hp[VITAE_HP_G_RECON], hp[VITAE_HP_G_EDGE]), so the
+ * gradient needs no result of the forward.  vitae_loss_fwd_bwd_supported: 1 when the geometry is served (else
+ * VITAE_ERR_UNSUPPORTED_SHAPE and the caller keeps the two calls above). */
+int vitae_loss_fwd_bwd_supported(int C, int Lz, int Hy, int Wx, int p);
+int vitae_loss_fwd_bwd(const float* pred, long pred_bstride, const float* imgs, const float* mask, const float* edge_tgt,
+                       const float* hp, float* dpred, void* dpred_bf16, float* nonfinite_flag, double* acc, float mask_sum,
+                       int B, int C, int Lz, int Hy, int Wx, int p, void* stream);
 /* out4 = [loss, raw_edge_mse, recon, percep=0] (model/vit_autoenc.py:231-232) */
 int vitae_loss_finalize(const double* acc, const float* hp, float* out4, float mask_sum, long edge_count, void* stream);
 

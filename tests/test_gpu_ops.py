@@ -434,7 +434,7 @@ def test_gather_patches_and_assemble(lib, C_, vol, p):
 
 # --------------------------------------------------------------------------- loss chain
 @pytest.mark.parametrize('C_,vol,p', [(4, (32, 32, 32), 16), (2, (16, 16, 16), 4), (1, (24, 16, 8), 8), (4, (48, 24, 40), 8),
-                                      (1, (16, 48, 80), 16)])
+                                      (1, (16, 48, 80), 16), (4, (16, 32, 96), 16), (4, (8, 40, 136), 8)])
 def test_loss_chain(lib, C, C_, vol, p):
     from vit_ae_plus_plus_amd.engine import gaussian_taps_host
     B = 2
@@ -498,6 +498,20 @@ def test_loss_chain(lib, C, C_, vol, p):
     assert float(dfu[:, 0].abs().max()) == 0.0
     assert rel_err(dfu, pr.grad) < 3e-5
     assert torch.equal(dfu16, dfu.to(torch.bfloat16))
+    # forward sums and gradient in ONE pass (csrc/loss_fused.hip; 4 channels): the fused training step's loss chain
+    if lib.vitae_loss_fwd_bwd_supported(C_, *vol, p):
+        acc3 = torch.zeros(C['VITAE_ACC_COUNT'], dtype=torch.float64, device='cuda')
+        d1 = torch.zeros(B, L + 1, P, device='cuda')
+        d116 = torch.zeros(B, L + 1, P, dtype=torch.bfloat16, device='cuda')
+        flag = torch.zeros(1, device='cuda')
+        lib.vitae_loss_fwd_bwd(pp, pbs, im.data_ptr(), mk.data_ptr(), et.data_ptr(), hp.data_ptr(), d1.data_ptr() + P * 4,
+                               d116.data_ptr() + P * 2, flag.data_ptr(), acc3.data_ptr(), msum, B, C_, *vol, p, st())
+        assert torch.allclose(acc3[:2].cpu(), acc[:2].cpu(), rtol=1e-5), (acc3[:2], acc[:2])
+        assert float(d1[:, 0].abs().max()) == 0.0 and float(flag) == 0.0
+        assert rel_err(d1, pr.grad) < 3e-5, rel_err(d1, pr.grad)
+        assert torch.equal(d116, d1.to(torch.bfloat16))
+    else:
+        assert C_ != 4
 
 
 def test_sobel_kat_and_nan_semantics(lib):

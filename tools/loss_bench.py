@@ -6,7 +6,7 @@ from vit_ae_plus_plus_amd import _abi
 from vit_ae_plus_plus_amd.engine import gaussian_taps_host
 
 lib, C = _abi.lib, _abi.CONSTS
-B, Cc, vol, p = 4, 4, (96, 96, 96), 16
+B, Cc, vol, p = int(os.environ.get('LB_BATCH', '4')), 4, (96, 96, 96), int(os.environ.get('LB_PATCH', '16'))
 V = vol[0] * vol[1] * vol[2]
 L, P = (vol[0] // p) ** 3, p ** 3 * Cc
 g = torch.Generator(device='cuda').manual_seed(0)
@@ -31,6 +31,8 @@ ops = {
     'loss_fwd_fused': lambda: lib.vitae_loss_fwd_fused(pp, pbs, imgs.data_ptr(), mask.data_ptr(), et.data_ptr(), pv.data_ptr(), ep.data_ptr(), acc.data_ptr(), B, Cc, *vol, p, st),
     'loss_bwd_fused': lambda: lib.vitae_loss_bwd_fused(pp, pv.data_ptr(), imgs.data_ptr(), mask.data_ptr(), ep.data_ptr(), et.data_ptr(), hp.data_ptr(), None,
                                                       dpred.data_ptr() + P * 4, d16.data_ptr() + P * 2, None, pbs, msum, B, Cc, *vol, p, st),
+    'loss_fwd_bwd (one pass)': lambda: lib.vitae_loss_fwd_bwd(pp, pbs, imgs.data_ptr(), mask.data_ptr(), et.data_ptr(), hp.data_ptr(),
+                                                              dpred.data_ptr() + P * 4, d16.data_ptr() + P * 2, None, acc.data_ptr(), msum, B, Cc, *vol, p, st),
 }
 for name, fn in ops.items():
     for _ in range(3):
@@ -41,4 +43,4 @@ for name, fn in ops.items():
     for _ in range(20):
         fn()
     b.record(); torch.cuda.synchronize()
-    print(f'{name:18s} {a.elapsed_time(b) / 20 * 1e3:8.1f} us')
+    print(f'{name:24s} {a.elapsed_time(b) / 20 * 1e3:8.1f} us')

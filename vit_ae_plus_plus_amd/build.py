@@ -17,7 +17,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, 'csrc')
 OBJ = os.path.join(CSRC, '_obj')
 LIB = os.path.join(PKG, 'libvitae_hip.so')
-SOURCES = ['gemm.hip', 'gemm_bf16.hip', 'gemm_glds.hip', 'gemm_bt.hip', 'norm.hip', 'attention.hip', 'attention_mfma.hip', 'tokens.hip', 'loss.hip',
+SOURCES = ['gemm.hip', 'gemm_bf16.hip', 'gemm_glds.hip', 'gemm_bt.hip', 'norm.hip', 'attention.hip', 'attention_mfma.hip', 'tokens.hip', 'loss.hip', 'loss_fused.hip',
            'optim.hip', 'input.hip', 'ddp.hip', 'percep.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast',
          '-I', os.path.join(ROOT, 'include'), '-I', CSRC] + os.environ.get('VITAE_HIPCC_FLAGS', '').split()

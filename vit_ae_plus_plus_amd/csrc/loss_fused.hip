@@ -1,0 +1,287 @@
+// The whole loss chain on the prediction — forward sums AND the gradient — in ONE pass over it (C = 4 channels):
+//   masked-voxel reconstruction MSE        model/vit_autoenc.py:226-227   (+ its gradient)
+//   3D Sobel magnitude, channel sum         model/model_utils/sobel_filter.py:37-45, model/vit_autoenc.py:221-223
+//   edge-map MSE against the target's map   model/vit_autoenc.py:224-225   (+ its gradient through the Sobel magnitude)
+//   dpred = mask 2 g_recon (pred - img) / (P mask.sum()) + d(edge mse)/d pred              (fp32 and bf16)
+// Both MSEs are linear in their upstream gradient, so the backward needs no scalar from the forward and the two meet in one
+// kernel: the unpatchified prediction (57 MB at batch 4) and its edge map never exist in HBM, and one launch replaces
+// loss_fwd_fused_kernel + loss_bwd_fused_kernel (csrc/loss.hip: 80 + 149 us on the step's main chain).
+//
+// Why this shape on MI355X.  The two-kernel version was LDS-bandwidth bound: every thread fetched the 3x3 neighbourhoods of its
+// stencils from LDS (196 B of LDS traffic per output value; profiles/round3_loss_pmc.txt).  Here the three directions of the 3x3x3
+// stencils are served by three different mechanisms, none of which re-reads a neighbourhood:
+//   x: the 64 lanes of a wave are 64 consecutive x — neighbours come from DPP wave shifts (v_add_f32_dpp ... wave_shr:1), no memory;
+//   y: a thread MARCHES along y and keeps the two previous rows of every partial result in registers;
+//   z: the NW waves of a workgroup are NW consecutive z-planes; the forward stencil loads the three planes it needs straight from
+//      global memory (16 bytes = the four channels of a voxel, patchify order), the transposed stencil of the backward exchanges two
+//      16-byte values per thread and row through LDS (double-buffered, one barrier per row).
+// The four channels of a voxel are processed together (the edge map sums the channels' magnitudes: model_utils/sobel_filter.py:45),
+// so E_pred, its error against the target's map and the per-channel gradient field are all formed in registers.
+// Halo: lanes 0, 1, 62, 63 and the first / last wave compute halo values only (outputs: at most 60 x by NW - 2 planes per workgroup).
+#include <cstdlib>
+#include <type_traits>
+#include "common.hpp"
+#include "vitae_hip.h"
+
+namespace {
+
+#ifndef VITAE_LOSS_MINW
+#define VITAE_LOSS_MINW 2        // waves per SIMD the register budget is cut for (2: 172 VGPRs, no spills; 4: 128 with 64 spilled)
+#endif
+constexpr int NW = 8;                  // waves = z-planes per workgroup (NW - 2 of them produce outputs)
+constexpr int NT = 64 * NW;
+constexpr int XO_MAX = 60;             // output columns of a 64-lane row
+
+struct FGeom {
+    int Lz, Hy, Wx, p, g1, g2, L;
+    long P, pred_bstride, V;
+    int xo, xtiles, tys;               // outputs per x-tile, number of x-tiles, output rows per y-segment
+    float inv_count, inv_pm;           // 1 / (B V), 1 / (P mask.sum())
+};
+
+// lane i <- lane i - 1 (x - 1) / lane i + 1 (x + 1); lanes without a source read 0 (halo lanes: their results are never used)
+__device__ __forceinline__ float lft(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float rgt(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+__device__ __forceinline__ f32x4 lft(f32x4 v) { return f32x4{lft(v[0]), lft(v[1]), lft(v[2]), lft(v[3])}; }
+__device__ __forceinline__ f32x4 rgt(f32x4 v) { return f32x4{rgt(v[0]), rgt(v[1]), rgt(v[2]), rgt(v[3])}; }
+__device__ __forceinline__ f32x4 smooth_x(f32x4 v) { return lft(v) + 2.f * v + rgt(v); }        // [1 2 1] along x
+
+struct State {
+    f32x4 in[3];                      // prediction at (x, row, z - 1 | z | z + 1) of the NEXT step (loaded one step ahead)
+    float et;                         // target edge map at the row whose gradient field is formed in that step
+    f32x4 img;                        // image values / mask flag of the row that leaves in that step
+    float mk;
+    f32x4 P0[2], P1[2], P2[2];        // forward partials (z and x applied) of the two previous rows
+    f32x4 F0[2], F1[2], F2[2];        // gradient field of the two previous rows
+    f32x4 ctr[2];                     // the prediction itself at (x, row, z) of the two previous rows (reconstruction term)
+};
+
+// (row / p, row % p) of a clamped row index that advances by one per step, without a division per step (uniform: SGPRs)
+struct RowIdx {
+    int q, r;
+    __device__ __forceinline__ void init(int row, int p, int Hy) { const int c = min(max(row, 0), Hy - 1); q = c / p; r = c % p; }
+    // the (unclamped) row becomes `row`: the clamped one moves only inside (0, Hy)
+    __device__ __forceinline__ void advance(int row, int p, int Hy) {
+        if (row > 0 && row < Hy) { if (++r == p) { r = 0; ++q; } }
+    }
+};
+
+__global__ __launch_bounds__(NT, VITAE_LOSS_MINW) void loss_fwd_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ imgs,
+                                                            const float* __restrict__ mask, const float* __restrict__ Et,
+                                                            const float* __restrict__ hp, float* __restrict__ dpred,
+                                                            __bf16* __restrict__ dpred16, float* __restrict__ nonfinite,
+                                                            double* __restrict__ acc, const FGeom g) {
+    __shared__ f32x4 sU[2][NW][64];
+    __shared__ f32x4 sW[2][NW][64];
+    __shared__ float red[2][NW];
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int Lz = g.Lz, Hy = g.Hy, Wx = g.Wx, p = g.p;
+    const int xt = blockIdx.x % g.xtiles, yseg = blockIdx.x / g.xtiles, b = blockIdx.z;
+    const int x0 = xt * g.xo, ys = yseg * g.tys, z0 = blockIdx.y * (NW - 2);
+    const int x = x0 - 2 + lane, z = z0 - 1 + w;
+    const int rows = min(g.tys, Hy - ys);                 // output rows of this segment
+    const float ce = 2.f * hp[VITAE_HP_G_EDGE] * g.inv_count, cr = 2.f * hp[VITAE_HP_G_RECON] * g.inv_pm;
+
+    // x / z parts of every address (constant along the march).  The prediction is read through a buffer resource over this
+    // batch element's slab: a lane / plane outside the volume gets an out-of-range offset and the load returns zeros (the zero
+    // padding of the convolutions) — no select behind the load.
+    const bool okx = x >= 0 && x < Wx;
+    const int xc = min(max(x, 0), Wx - 1);
+    const int lx = xc / p, ex = (xc % p) * 4;
+    const float* pb = pred + (long)b * g.pred_bstride;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pb), 0, (int)((long)g.L * g.P * 4), 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    unsigned zoffb[3];                                      // byte offset of (plane zq, patch column lx, in-patch x) inside the slab
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int zq = z - 1 + j;
+        const bool ok = okx && zq >= 0 && zq < Lz;
+        const int zc = min(max(zq, 0), Lz - 1);
+        zoffb[j] = ok ? 4u * (unsigned)((int)(((long)(zc / p) * g.g1 * g.g2 + lx) * g.P) + (zc % p) * p * p * 4 + ex) : OOB;
+    }
+    const bool okzc = z >= 0 && z < Lz;
+    const int zc1 = min(max(z, 0), Lz - 1);
+    const float* etp = Et + ((long)b * g.V) + (long)zc1 * Hy * Wx + xc;        // edge maps: row r at etp[r * Wx]
+    const float* imp = imgs + ((long)b * 4 * g.V) + (long)zc1 * Hy * Wx + xc;  // images: channel c, row r at imp[c * V + r * Wx]
+    const float* mkp = mask + (long)b * g.L + (zc1 / p) * g.g1 * g.g2 + lx;    // mask: row r at mkp[(r / p) * g2]
+    const bool outw = w >= 1 && w <= NW - 2;                                   // (wave-uniform) this plane produces outputs
+    const bool owner_xz = lane >= 2 && lane < 2 + g.xo && okx && outw && okzc; // this thread's column produces outputs
+    const long dbase = (long)b * g.pred_bstride + ((long)(zc1 / p) * g.g1 * g.g2 + lx) * g.P + (zc1 % p) * p * p * 4 + ex;
+    const int rstride = g.g2 * (int)g.P, rin = p * 4;      // element offset of row r inside the slab: (r / p) * rstride + (r % p) * rin
+
+    State s;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        s.P0[q] = s.P1[q] = s.P2[q] = s.F0[q] = s.F1[q] = s.F2[q] = s.ctr[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    s.img = f32x4{0.f, 0.f, 0.f, 0.f};
+    s.et = s.mk = 0.f;
+    float sq = 0.f, rc = 0.f, chk = 0.f;
+
+    // rows of the NEXT step's loads: input row yy, field row yy - 1, leaving row yy - 2 (clamped into the volume)
+    RowIdx ri, rf, ro;
+    int yyn = ys - 2;                                       // input row of the next issue()
+    ri.init(yyn, p, Hy); rf.init(yyn - 1, p, Hy); ro.init(yyn - 2, p, Hy);
+
+    auto issue = [&]() {
+        if (yyn >= 0 && yyn < Hy) {                         // (uniform) rows outside the volume are zero padding
+            const unsigned roffb = 4u * (unsigned)(ri.q * rstride + ri.r * rin);
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                s.in[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, zoffb[j] + roffb, 0, 0));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) s.in[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        s.et = etp[(rf.q * p + rf.r) * Wx];
+        if (outw) {                                         // (uniform) halo planes produce no output
+            const int orow = (ro.q * p + ro.r) * Wx;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s.img[c] = imp[(long)c * g.V + orow];
+            s.mk = mkp[ro.q * g.g2];
+        }
+        ++yyn;
+        ri.advance(yyn, p, Hy); rf.advance(yyn - 1, p, Hy); ro.advance(yyn - 2, p, Hy);
+    };
+
+    RowIdx rs_out;                                          // the row that leaves in the CURRENT step (for the store address)
+    rs_out.init(ys - 4, p, Hy);
+
+    auto step = [&](int t, auto PARC) {
+        constexpr int cur = decltype(PARC)::value, oth = cur ^ 1;
+        const int yy = ys - 2 + t;
+        // ---- forward partials of input row yy: z, then x
+        const f32x4 c0 = s.in[1];
+        const f32x4 sz = s.in[0] + 2.f * c0 + s.in[2], dz = s.in[2] - s.in[0];
+        const f32x4 im = s.img;
+        const float mk = s.mk, etv = s.et;
+        if (t + 1 < rows + 4) issue();                      // the next row's loads fly under this step
+        const f32x4 szl = lft(sz), szr = rgt(sz);
+        const f32x4 n0 = szl - szr;                         // d(x) s(z)
+        const f32x4 n1 = szl + 2.f * sz + szr;              // s(x) s(z)
+        const f32x4 n2 = smooth_x(dz);                      // s(x) d(z)
+        // ---- Sobel components at row yy - 1 (rows: slot cur = yy - 2, slot oth = yy - 1, n* = yy)
+        const f32x4 g0 = s.P0[cur] + 2.f * s.P0[oth] + n0;  // d(x) s(y) s(z)
+        const f32x4 g1 = n1 - s.P1[cur];                    // s(x) d(y) s(z): row y + 1 minus row y - 1
+        const f32x4 g2 = s.P2[cur] + 2.f * s.P2[oth] + n2;  // s(x) s(y) d(z)
+        const f32x4 m2 = g0 * g0 + g1 * g1 + g2 * g2;
+        const float ep = (__builtin_amdgcn_sqrtf(m2[0]) + __builtin_amdgcn_sqrtf(m2[1])) +
+                         (__builtin_amdgcn_sqrtf(m2[2]) + __builtin_amdgcn_sqrtf(m2[3]));
+        const int yf = yy - 1;
+        const bool fin = okx && okzc && yf >= 0 && yf < Hy; // the field is exactly 0 outside the volume
+        const float err = ep - etv;
+        sq += (owner_xz && fin && yf >= ys && yf < ys + rows) ? err * err : 0.f;
+        const float de = ce * err;
+        f32x4 f0, f1, f2;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float f = fin ? de * __builtin_amdgcn_rsqf(m2[c]) : 0.f;      // |g| = 0 -> inf -> NaN, like the reference's sqrt backward
+            f0[c] = f * g0[c]; f1[c] = f * g1[c]; f2[c] = f * g2[c];
+        }
+        // ---- transposed stencils at row yy - 2: y (registers), x (DPP); z goes through LDS below
+        const f32x4 h0 = s.F0[cur] + 2.f * s.F0[oth] + f0;  // s(y) F0
+        const f32x4 h1 = s.F1[cur] - f1;                    // row y - 1 minus row y + 1 of F1
+        const f32x4 h2 = s.F2[cur] + 2.f * s.F2[oth] + f2;  // s(y) F2
+        const f32x4 u = (rgt(h0) - lft(h0)) + smooth_x(h1); // e(x) s(y) F0 + s(x) d(y) F1
+        const f32x4 wv = smooth_x(h2);                      // s(x) s(y) F2
+        const f32x4 pc = s.ctr[cur];                        // prediction at (x, yy - 2, z)
+        // rotate: slot cur now holds row yy
+        s.P0[cur] = n0; s.P1[cur] = n1; s.P2[cur] = n2;
+        s.F0[cur] = f0; s.F1[cur] = f1; s.F2[cur] = f2;
+        s.ctr[cur] = c0;
+        const int oq = rs_out.q, orr = rs_out.r;
+        rs_out.advance(yy - 1, p, Hy);
+        if (t < 4) return;                                  // rows ys - 4 .. ys - 1: nothing leaves yet (uniform)
+        sU[cur][w][lane] = u;
+        sW[cur][w][lane] = wv;
+        __syncthreads();
+        if (outw) {
+            const f32x4 um = sU[cur][w - 1][lane], up = sU[cur][w + 1][lane];
+            const f32x4 wm = sW[cur][w - 1][lane], wp = sW[cur][w + 1][lane];
+            f32x4 val = (um + 2.f * u + up) + (wm - wp);    // s(z) [..] + (plane z - 1 minus plane z + 1) of s(x) s(y) F2
+            const f32x4 d = pc - im;
+            const float mflag = mk != 0.f ? 1.f : 0.f;
+            val = (cr * mflag) * d + val;
+            if (owner_xz) {
+                rc += mflag * ((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]));
+                chk += (val[0] + val[1]) + (val[2] + val[3]);          // non-finite as soon as one stored value is
+                const long doff = dbase + (long)(oq * rstride + orr * rin);
+                *reinterpret_cast<f32x4*>(dpred + doff) = val;
+                if (dpred16) {
+                    typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+                    *reinterpret_cast<bf4*>(dpred16 + doff) = bf4{(__bf16)val[0], (__bf16)val[1], (__bf16)val[2], (__bf16)val[3]};
+                }
+            }
+        }
+    };
+
+    const int nsteps = rows + 4;
+    issue();
+    int t = 0;
+    for (; t + 1 < nsteps; t += 2) {
+        step(t, std::integral_constant<int, 0>{});
+        step(t + 1, std::integral_constant<int, 1>{});
+    }
+    if (t < nsteps) step(t, std::integral_constant<int, 0>{});
+
+    const bool bad = !(fabsf(chk) <= 3.4028234e38f);         // NaN or inf
+    sq = wave_sum(sq);
+    rc = wave_sum(rc);
+    __syncthreads();
+    if (lane == 0) { red[0][w] = sq; red[1][w] = rc; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.f, r = 0.f;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) { a += red[0][i]; r += red[1][i]; }
+        atomicAdd(acc + VITAE_ACC_EDGE, (double)a);
+        atomicAdd(acc + VITAE_ACC_RECON, (double)(r / (float)g.P));
+    }
+    if (bad && nonfinite) *nonfinite = __builtin_nanf("");   // benign race: every writer stores the same value
+}
+
+}  // namespace
+
+// 1 when vitae_loss_fwd_bwd serves this geometry (else the caller keeps vitae_loss_fwd_fused + vitae_loss_bwd_fused)
+extern "C" int vitae_loss_fwd_bwd_supported(int C, int Lz, int Hy, int Wx, int p) {
+    if (C != 4 || p <= 0 || Lz % p || Hy % p || Wx % p) return 0;
+    const long per_batch = ((long)(Lz / p) * (Hy / p) * (Wx / p) + 1) * p * p * p * 4;   // incl. the cls row of the decoder output
+    return per_batch < (1L << 31) && cdiv(Lz, NW - 2) <= 65535;
+}
+
+extern "C" int vitae_loss_fwd_bwd(const float* pred, long pred_bstride, const float* imgs, const float* mask, const float* edge_tgt,
+                                  const float* hp, float* dpred, void* dpred_bf16, float* nonfinite_flag, double* acc,
+                                  float mask_sum, int B, int C, int Lz, int Hy, int Wx, int p, void* stream) {
+    if (!pred || !imgs || !mask || !edge_tgt || !hp || !dpred || !acc || B <= 0 || B > 65535 || p <= 0 || mask_sum <= 0.f ||
+        Lz % p || Hy % p || Wx % p)
+        return VITAE_ERR_INVALID_ARG;
+    if (!vitae_loss_fwd_bwd_supported(C, Lz, Hy, Wx, p) || pred_bstride >= (1L << 31) || (pred_bstride & 3) ||
+        ((uintptr_t)pred & 15) || ((uintptr_t)dpred & 15) || ((uintptr_t)dpred_bf16 & 7))
+        return VITAE_ERR_UNSUPPORTED_SHAPE;
+    FGeom g;
+    g.Lz = Lz; g.Hy = Hy; g.Wx = Wx; g.p = p; g.g1 = Hy / p; g.g2 = Wx / p; g.L = (Lz / p) * g.g1 * g.g2;
+    g.P = (long)p * p * p * 4; g.pred_bstride = pred_bstride; g.V = (long)Lz * Hy * Wx;
+    g.xtiles = cdiv(Wx, XO_MAX); g.xo = cdiv(Wx, g.xtiles);
+    const int zt = cdiv(Lz, NW - 2);
+    // y-segments: one workgroup per CU is enough (measured: 124 us with 256 workgroups, 145 with 1024 at batch 4 — every segment
+    // re-does 4 rows of the march); rows per segment a multiple of 4 and at least 8
+    static const int target = getenv("VITAE_LOSS_WGS") ? atoi(getenv("VITAE_LOSS_WGS")) : 256;
+    int nseg = cdiv(target, g.xtiles * zt * B);
+    if (nseg < 1) nseg = 1;
+    int tys = cdiv(cdiv(Hy, nseg), 4) * 4;
+    if (tys < 8) tys = 8;
+    if (tys > Hy) tys = Hy;
+    g.tys = tys;
+    nseg = cdiv(Hy, tys);
+    g.inv_count = 1.0f / (float)((long)B * g.V);
+    g.inv_pm = 1.0f / ((float)g.P * mask_sum);
+    hipLaunchKernelGGL(loss_fwd_bwd_kernel, dim3(g.xtiles * nseg, zt, B), dim3(NT), 0, (hipStream_t)stream, pred, imgs, mask, edge_tgt,
+                       hp, dpred, reinterpret_cast<__bf16*>(dpred_bf16), nonfinite_flag, acc, g);
+    return vitae_launch_status();
+}

@@ -761,9 +761,12 @@ class HipMAEEngine:
 
     # ------------------------------------------------------------------ forward
     def forward(self, view1: torch.Tensor, view2: Optional[torch.Tensor], noise: torch.Tensor, mask_ratio: float,
-                training: bool = True, defer_predictor_join: bool = False, defer_finalize: bool = False):
+                training: bool = True, defer_predictor_join: bool = False, defer_finalize: bool = False,
+                loss_with_grad: bool = False):
         """Everything up to the four loss scalars and (contrastive) p1/p2.  ``noise`` is [Be, L]
-        (view-1 rows first), the torch.rand of vit_autoenc.py:139."""
+        (view-1 rows first), the torch.rand of vit_autoenc.py:139.  ``loss_with_grad`` (the fused step, whose backward follows
+        at once and whose gradient multipliers are already in ``hp``): the loss chain leaves the gradient w.r.t. the
+        prediction in the same pass (csrc/loss_fused.hip) and ``backward_dec`` skips its own loss kernel."""
         cfg = self.cfg
         B = view1.shape[0]
         self._alloc(B, mask_ratio)
@@ -868,8 +871,14 @@ class HipMAEEngine:
         # --- loss chain on pred = predfull[:, 1:, :]
         pred_ptr, pbs = b['predfull'].data_ptr() + P * 4, Nd * P
         torch.cuda.current_stream(self.device).wait_stream(self.side)   # edge map of the blurred target is ready
-        lib.vitae_loss_fwd_fused(pred_ptr, pbs, _ptr(view1), _ptr(b['mask']), _ptr(b['edge_t']), _ptr(b['pred_vol']),
-                                 _ptr(b['edge_p']), _ptr(self.acc), B, C, Lz, Hy, Wx, ps, st)
+        self._loss_grad_done = bool(loss_with_grad and self.loss_one_pass and lib.vitae_loss_fwd_bwd_supported(C, Lz, Hy, Wx, ps))
+        if self._loss_grad_done:
+            lib.vitae_loss_fwd_bwd(pred_ptr, pbs, _ptr(view1), _ptr(b['mask']), _ptr(b['edge_t']), _ptr(self.hp),
+                                   b['dpredfull'].data_ptr() + P * 4, (b['dpred_16'].data_ptr() + P * 2) if a16 else None, None,
+                                   _ptr(self.acc), self.mask_sum, B, C, Lz, Hy, Wx, ps, st)
+        else:
+            lib.vitae_loss_fwd_fused(pred_ptr, pbs, _ptr(view1), _ptr(b['mask']), _ptr(b['edge_t']), _ptr(b['pred_vol']),
+                                     _ptr(b['edge_p']), _ptr(self.acc), B, C, Lz, Hy, Wx, ps, st)
         if not defer_finalize:
             self.loss_finalize()
         if cfg.contrastive and not self._pred_pending:
@@ -965,7 +974,9 @@ class HipMAEEngine:
         dx_ = b['decx']
         nd = cfg.decoder_depth
         blocks = [i for i in reversed(range(nd)) if (i >= cut and top) or (i < cut and bottom)]
-        if top:
+        if top and self._loss_grad_done:
+            self._loss_grad_done = False        # forward(loss_with_grad=True) left dpred / dpred_16 already
+        elif top:
             lib.vitae_loss_bwd_fused(pred_ptr, _ptr(b['pred_vol']), _ptr(view1), _ptr(b['mask']), _ptr(b['edge_p']), _ptr(b['edge_t']),
                                      _ptr(self.hp), _ptr(b.get('dG')), dpred_ptr, (b['dpred_16'].data_ptr() + P * 2) if a16 else None,
                                      None, pbs, self.mask_sum, B, C, Lz, Hy, Wx, ps, st)
@@ -1212,6 +1223,9 @@ class HipMAEEngine:
     # encoder backward is cut into this many phases (= gradient buckets = optimiser-in-backward units)
     # (3: since AdamW got faster a third, smaller last bucket shortens the exposed tail: 5.15 -> 5.00 ms on one box, even on another)
     enc_chunks = int(os.environ.get('VITAE_ENC_CHUNKS', '3'))
+    # loss forward sums + gradient in one pass over the prediction inside the fused step (csrc/loss_fused.hip; 4-channel volumes)
+    loss_one_pass = os.environ.get('VITAE_LOSS_ONE_PASS', '1') != '0'
+    _loss_grad_done = False
     # optional explicit ascending block boundaries, e.g. "0,2,7,12" (uneven chunks: a smaller last, exposed bucket)
     enc_cuts = [int(v) for v in os.environ['VITAE_ENC_CUTS'].split(',')] if os.environ.get('VITAE_ENC_CUTS') else None
 
@@ -1267,7 +1281,8 @@ class HipMAEEngine:
             # the zeroing of the token / vector gradient segment and the loss finalisation are not on the dependent chain:
             # the first goes in front of the forward, the second behind the decoder backward (12 us between the loss kernels)
             self.step_prologue(noise, accumulate)
-            self.forward(view1, view2, noise, mask_ratio, training=True, defer_predictor_join=True, defer_finalize=True)
+            self.forward(view1, view2, noise, mask_ratio, training=True, defer_predictor_join=True, defer_finalize=True,
+                         loss_with_grad=True)
             if cfg.contrastive:
                 self.contrastive_loss_fwd()
                 self.contrastive_loss_bwd()
