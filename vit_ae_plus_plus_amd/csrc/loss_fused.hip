@@ -25,10 +25,16 @@
 
 namespace {
 
-#ifndef VITAE_LOSS_MINW
-#define VITAE_LOSS_MINW 2        // waves per SIMD the register budget is cut for (2: 172 VGPRs, no spills; 4: 128 with 64 spilled)
+#ifndef VITAE_LOSS_NW
+#define VITAE_LOSS_NW 8
 #endif
-constexpr int NW = 8;                  // waves = z-planes per workgroup (NW - 2 of them produce outputs)
+#ifndef VITAE_LOSS_MINW
+#define VITAE_LOSS_MINW 2        // waves per SIMD the register budget is cut for (2: 174 VGPRs, no spills; 4: 128 with 64 spilled)
+#endif
+constexpr int NW = VITAE_LOSS_NW;      // waves = z-planes per workgroup (NW - 2 of them produce outputs)
+#ifndef VITAE_LOSS_ABLATE
+#define VITAE_LOSS_ABLATE 0          // timing ablations (wrong results): 1 no barrier / LDS exchange, 2 no global loads, 3 no stores
+#endif
 constexpr int NT = 64 * NW;
 constexpr int XO_MAX = 60;             // output columns of a 64-lane row
 
@@ -51,10 +57,12 @@ __device__ __forceinline__ f32x4 rgt(f32x4 v) { return f32x4{rgt(v[0]), rgt(v[1]
 __device__ __forceinline__ f32x4 smooth_x(f32x4 v) { return lft(v) + 2.f * v + rgt(v); }        // [1 2 1] along x
 
 struct State {
-    f32x4 in[3];                      // prediction at (x, row, z - 1 | z | z + 1) of the NEXT step (loaded one step ahead)
-    float et;                         // target edge map at the row whose gradient field is formed in that step
-    f32x4 img;                        // image values / mask flag of the row that leaves in that step
-    float mk;
+    // loaded TWO steps ahead (slot = parity of the step that consumes them; one step of ~200 VALU instructions on two waves per
+    // SIMD does not cover an HBM round trip: 77 -> ... us)
+    f32x4 in[2][3];                   // prediction at (x, row, z - 1 | z | z + 1)
+    float et[2];                      // target edge map at the row whose gradient field is formed in that step
+    f32x4 img[2];                     // image values / mask flag of the row that leaves in that step
+    float mk[2];
     f32x4 P0[2], P1[2], P2[2];        // forward partials (z and x applied) of the two previous rows
     f32x4 F0[2], F1[2], F2[2];        // gradient field of the two previous rows
     f32x4 ctr[2];                     // the prediction itself at (x, row, z) of the two previous rows (reconstruction term)
@@ -96,7 +104,7 @@ __global__ __launch_bounds__(NT, VITAE_LOSS_MINW) void loss_fwd_bwd_kernel(const
     const int lx = xc / p, ex = (xc % p) * 4;
     const float* pb = pred + (long)b * g.pred_bstride;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pb), 0, (int)((long)g.L * g.P * 4), 0x00020000);
-    constexpr unsigned OOB = 0x80000000u;
+    constexpr unsigned OOB = 0x80000000u, OOB_ROW = 0x40000000u;   // (slab < 1 GB: vitae_loss_fwd_bwd_supported; the two never wrap)
     unsigned zoffb[3];                                      // byte offset of (plane zq, patch column lx, in-patch x) inside the slab
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -120,8 +128,8 @@ __global__ __launch_bounds__(NT, VITAE_LOSS_MINW) void loss_fwd_bwd_kernel(const
     for (int q = 0; q < 2; ++q) {
         s.P0[q] = s.P1[q] = s.P2[q] = s.F0[q] = s.F1[q] = s.F2[q] = s.ctr[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    s.img = f32x4{0.f, 0.f, 0.f, 0.f};
-    s.et = s.mk = 0.f;
+    s.img[0] = s.img[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    s.et[0] = s.et[1] = s.mk[0] = s.mk[1] = 0.f;
     float sq = 0.f, rc = 0.f, chk = 0.f;
 
     // rows of the NEXT step's loads: input row yy, field row yy - 1, leaving row yy - 2 (clamped into the volume)
@@ -129,23 +137,26 @@ __global__ __launch_bounds__(NT, VITAE_LOSS_MINW) void loss_fwd_bwd_kernel(const
     int yyn = ys - 2;                                       // input row of the next issue()
     ri.init(yyn, p, Hy); rf.init(yyn - 1, p, Hy); ro.init(yyn - 2, p, Hy);
 
-    auto issue = [&]() {
-        if (yyn >= 0 && yyn < Hy) {                         // (uniform) rows outside the volume are zero padding
-            const unsigned roffb = 4u * (unsigned)(ri.q * rstride + ri.r * rin);
+    // Every load of the march is UNCONDITIONAL (rows outside the volume: an out-of-range buffer offset returns the zero
+    // padding; halo planes and steps past the end read clamped, valid addresses they do not use): with a load under a branch
+    // inside the loop hipcc's s_waitcnt for the loads of two steps ago came out as vmcnt(1..5) — it waited for the loads just
+    // issued as well, and the two-step prefetch was one in name only.
+    auto issue = [&](auto SLOT) {
+        constexpr int sl = decltype(SLOT)::value;
+#if VITAE_LOSS_ABLATE != 2
+        const unsigned roffb = (yyn >= 0 && yyn < Hy) ? 4u * (unsigned)(ri.q * rstride + ri.r * rin) : OOB_ROW;
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
-                s.in[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, zoffb[j] + roffb, 0, 0));
-        } else {
+        for (int j = 0; j < 3; ++j)
+            s.in[sl][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, zoffb[j] + roffb, 0, 0));
+        s.et[sl] = etp[(rf.q * p + rf.r) * Wx];
+        const int orow = (ro.q * p + ro.r) * Wx;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) s.in[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        s.et = etp[(rf.q * p + rf.r) * Wx];
-        if (outw) {                                         // (uniform) halo planes produce no output
-            const int orow = (ro.q * p + ro.r) * Wx;
+        for (int c = 0; c < 4; ++c) s.img[sl][c] = imp[(long)c * g.V + orow];
+        s.mk[sl] = mkp[ro.q * g.g2];
+#else
 #pragma unroll
-            for (int c = 0; c < 4; ++c) s.img[c] = imp[(long)c * g.V + orow];
-            s.mk = mkp[ro.q * g.g2];
-        }
+        for (int j = 0; j < 3; ++j) s.in[sl][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
         ++yyn;
         ri.advance(yyn, p, Hy); rf.advance(yyn - 1, p, Hy); ro.advance(yyn - 2, p, Hy);
     };
@@ -153,15 +164,16 @@ __global__ __launch_bounds__(NT, VITAE_LOSS_MINW) void loss_fwd_bwd_kernel(const
     RowIdx rs_out;                                          // the row that leaves in the CURRENT step (for the store address)
     rs_out.init(ys - 4, p, Hy);
 
-    auto step = [&](int t, auto PARC) {
+    auto step = [&](int t, auto PARC, auto OUTC) {
+        constexpr bool OUT = decltype(OUTC)::value;             // false: the first four rows of the march (nothing leaves yet)
         constexpr int cur = decltype(PARC)::value, oth = cur ^ 1;
         const int yy = ys - 2 + t;
         // ---- forward partials of input row yy: z, then x
-        const f32x4 c0 = s.in[1];
-        const f32x4 sz = s.in[0] + 2.f * c0 + s.in[2], dz = s.in[2] - s.in[0];
-        const f32x4 im = s.img;
-        const float mk = s.mk, etv = s.et;
-        if (t + 1 < rows + 4) issue();                      // the next row's loads fly under this step
+        const f32x4 c0 = s.in[cur][1];
+        const f32x4 sz = s.in[cur][0] + 2.f * c0 + s.in[cur][2], dz = s.in[cur][2] - s.in[cur][0];
+        const f32x4 im = s.img[cur];
+        const float mk = s.mk[cur], etv = s.et[cur];
+        issue(PARC);                                        // slot cur is free: the loads of step t + 2 fly under two steps
         const f32x4 szl = lft(sz), szr = rgt(sz);
         const f32x4 n0 = szl - szr;                         // d(x) s(z)
         const f32x4 n1 = szl + 2.f * sz + szr;              // s(x) s(z)
@@ -197,18 +209,24 @@ __global__ __launch_bounds__(NT, VITAE_LOSS_MINW) void loss_fwd_bwd_kernel(const
         s.ctr[cur] = c0;
         const int oq = rs_out.q, orr = rs_out.r;
         rs_out.advance(yy - 1, p, Hy);
-        if (t < 4) return;                                  // rows ys - 4 .. ys - 1: nothing leaves yet (uniform)
+        if constexpr (!OUT) return;
+#if VITAE_LOSS_ABLATE != 1
         sU[cur][w][lane] = u;
         sW[cur][w][lane] = wv;
         __syncthreads();
+#endif
         if (outw) {
+#if VITAE_LOSS_ABLATE == 1
+            const f32x4 um = u, up = wv, wm = u, wp = wv;
+#else
             const f32x4 um = sU[cur][w - 1][lane], up = sU[cur][w + 1][lane];
             const f32x4 wm = sW[cur][w - 1][lane], wp = sW[cur][w + 1][lane];
+#endif
             f32x4 val = (um + 2.f * u + up) + (wm - wp);    // s(z) [..] + (plane z - 1 minus plane z + 1) of s(x) s(y) F2
             const f32x4 d = pc - im;
             const float mflag = mk != 0.f ? 1.f : 0.f;
             val = (cr * mflag) * d + val;
-            if (owner_xz) {
+            if (owner_xz && (VITAE_LOSS_ABLATE != 3 || val[0] == 1234.5f)) {
                 rc += mflag * ((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]));
                 chk += (val[0] + val[1]) + (val[2] + val[3]);          // non-finite as soon as one stored value is
                 const long doff = dbase + (long)(oq * rstride + orr * rin);
@@ -222,13 +240,20 @@ __global__ __launch_bounds__(NT, VITAE_LOSS_MINW) void loss_fwd_bwd_kernel(const
     };
 
     const int nsteps = rows + 4;
-    issue();
-    int t = 0;
+    issue(std::integral_constant<int, 0>{});
+    issue(std::integral_constant<int, 1>{});
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    step(0, I0{}, std::false_type{});
+    step(1, I1{}, std::false_type{});
+    step(2, I0{}, std::false_type{});
+    step(3, I1{}, std::false_type{});
+    int t = 4;
     for (; t + 1 < nsteps; t += 2) {
-        step(t, std::integral_constant<int, 0>{});
-        step(t + 1, std::integral_constant<int, 1>{});
+        step(t, I0{}, std::true_type{});
+        step(t + 1, I1{}, std::true_type{});
     }
-    if (t < nsteps) step(t, std::integral_constant<int, 0>{});
+    if (t < nsteps) step(t, I0{}, std::true_type{});
 
     const bool bad = !(fabsf(chk) <= 3.4028234e38f);         // NaN or inf
     sq = wave_sum(sq);
@@ -252,7 +277,7 @@ __global__ __launch_bounds__(NT, VITAE_LOSS_MINW) void loss_fwd_bwd_kernel(const
 extern "C" int vitae_loss_fwd_bwd_supported(int C, int Lz, int Hy, int Wx, int p) {
     if (C != 4 || p <= 0 || Lz % p || Hy % p || Wx % p) return 0;
     const long per_batch = ((long)(Lz / p) * (Hy / p) * (Wx / p) + 1) * p * p * p * 4;   // incl. the cls row of the decoder output
-    return per_batch < (1L << 31) && cdiv(Lz, NW - 2) <= 65535;
+    return per_batch < (1L << 28) && cdiv(Lz, NW - 2) <= 65535;   // (slab bytes < 2^30: the out-of-range offsets of the kernel never wrap)
 }
 
 extern "C" int vitae_loss_fwd_bwd(const float* pred, long pred_bstride, const float* imgs, const float* mask, const float* edge_tgt,
