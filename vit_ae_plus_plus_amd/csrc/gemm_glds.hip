@@ -589,11 +589,14 @@ inline int old_split_rule(int M, int N, int K) {
     return s < 1 ? 1 : (int)s;
 }
 
-inline double est_64row(int M, int N, int K, bool allow_split) {
+inline double est_64row(int M, int N, int K, bool allow_split, bool wgrad_form) {
     const Tile t = pick_tile(M, N);
     const int s = allow_split ? old_split_rule(M, N, K) : 1;
     const double nk = (double)K / BK / s, wgs = (double)cdiv(M, t.bm) * cdiv(N, t.bn) * s;
-    const double c = t.id == 1 ? 2800 + 930 * nk : 5100 + 400 * nk;
+    // both operands row-contiguous (the weight-gradient form): every fragment comes through the transposing LDS read, two
+    // instructions per 16-byte fragment — 650 instead of 400 clocks per k-tile and resident workgroup (tools/wgrad_split_sweep.py:
+    // enc fc1 wgrad at batch 32, 576 tiles x 55 k-tiles, 39.8 us)
+    const double c = t.id == 1 ? 2800 + 930 * nk : 5100 + (wgrad_form ? 650 : 400) * nk;
     const double lat = 8000 + (t.id == 1 ? 1000 : 760) * nk + (s > 1 ? 7000 : 0);
     const double thr = wgs * c / 256;
     return thr > lat ? thr : lat;
@@ -623,7 +626,7 @@ inline BtPlan bt_plan(int M, int N, int K, int a_kc, int b_kc, bool allow_split,
         }
     }
     if (best.tile < 0 || g_bt_mode >= 0) return best;
-    if (best.clocks >= 0.92 * est_64row(M, N, K, allow_split)) return BtPlan{-1, 1, 0.0};
+    if (best.clocks >= 0.92 * est_64row(M, N, K, allow_split, !a_kc && !b_kc)) return BtPlan{-1, 1, 0.0};
     return best;
 }
 
