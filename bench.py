@@ -513,24 +513,16 @@ def main():
     # N > 1 (the driver's one scaling run): BOTH exchange routes in the same invocation — host-issued collectives between
     # per-phase graphs (default) and RCCL inside the step graph (vitae_ddp_*); the faster is the reported value, the other sits in
     # config.also_exchange.  (The plumbing mode shares one GPU over gloo: RCCL refuses two ranks on a device, so no native leg.)
+    # The host-issued route goes first and the line is ASSEMBLED from it (instrumentation included) before the native route is
+    # tried under a watchdog (below): RCCL through the C ABI has only ever met a world of one rank on this pool, and a second
+    # route that hangs or throws on some rank must never cost the line.
+    t_leg0 = time.perf_counter()
     legs = [timed_leg(False)]
+    t_leg0 = time.perf_counter() - t_leg0
     also_exchange = None
-    if ddp_on:
-        if ONE_GPU:
-            also_exchange = {'skipped': 'native RCCL leg needs one GPU per rank (plumbing mode: all ranks on one GPU over gloo)'}
-        else:
-            try:
-                legs.append(timed_leg(True))
-            except Exception as e:       # the second route must never cost the line
-                also_exchange = {'error': repr(e)[:300]}
-    best = min(range(len(legs)), key=lambda i: legs[i][0])
-    elapsed, first_gpu, last, exchange = legs[best]
-    if len(legs) > 1:
-        also_exchange = legs[1 - best][3]
-    if ddp_on and best != len(legs) - 1:
-        # instrumentation below runs on the route that was timed last: put the winner back
-        model.enable_data_parallel(dev, force=force_ddp, comm_dtype=comm_dtype, native=(best == 1))
-        eng.set_loss_weights(0.01, 0.001 if contr else 0.0, 1, world)
+    if ddp_on and ONE_GPU:
+        also_exchange = {'skipped': 'native RCCL leg needs one GPU per rank (plumbing mode: all ranks on one GPU over gloo)'}
+    elapsed, first_gpu, last, exchange = legs[0]
     ms = elapsed / args.steps * 1e3
     value = world * args.batch * args.steps / elapsed
 
@@ -619,16 +611,51 @@ def main():
         out['config'].update(extra)
         if parity:
             out['parity'] = parity
-    if world > 1 or force_ddp:
-        dist.destroy_process_group()
-    if rank == 0:
-        # RCCL writes its version banner through C stdio: drain that first so the JSON line is the LAST line
-        import ctypes
+    def emit():
+        if rank == 0:
+            # RCCL writes its version banner through C stdio: drain that first so the JSON line is the LAST line
+            import ctypes
+            try:
+                ctypes.CDLL(None).fflush(None)
+            except Exception:
+                pass
+            print(json.dumps(out), flush=True)
+
+    clean = True
+    if ddp_on and not ONE_GPU:
+        import threading
+        limit = 3.0 * t_leg0 + 90.0
+
+        def bail():        # every rank runs the same timer: rank 0 prints the host-issued line, everybody leaves
+            if rank == 0:
+                out['config']['also_exchange'] = {'error': f'native route (vitae_ddp_*) did not finish within {limit:.0f} s; abandoned'}
+            emit()
+            os._exit(0)
+
+        dog = threading.Timer(limit, bail)
+        dog.daemon = True
+        dog.start()
         try:
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
-        print(json.dumps(out), flush=True)
+            leg = timed_leg(True)
+            dog.cancel()
+            if rank == 0:
+                if leg[0] < elapsed:      # the faster route is the reported one, the other goes to also_exchange
+                    out['config']['also_exchange'], out['config']['exchange'] = out['config']['exchange'], leg[3]
+                    out['value'] = round(world * args.batch * args.steps / leg[0], 2)
+                    out['ms_per_step'] = round(leg[0] / args.steps * 1e3, 3)
+                    out['config']['final_losses'] = [round(x, 6) for x in leg[2][:6]]
+                else:
+                    out['config']['also_exchange'] = leg[3]
+        except Exception as e:
+            dog.cancel()
+            clean = False
+            if rank == 0:
+                out['config']['also_exchange'] = {'error': repr(e)[:300]}
+    if (world > 1 or force_ddp) and clean:
+        dist.destroy_process_group()
+    emit()
+    if not clean:
+        os._exit(0)        # a rank that threw inside the native route may have left its peers in a collective
 
 
 if __name__ == '__main__':
