@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITAE_ABI_VERSION 31
+#define VITAE_ABI_VERSION 32
 
 /* matrix-core arithmetic of the dense contractions */
 #define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
@@ -315,6 +315,12 @@ int vitae_loss_bwd_fused(const float* pred, const float* pred_vol, const float* 
                          void* dpred_bf16, float* nonfinite_flag /* optional: set to NaN when a non-finite gradient is written
                          (C in {1,4} only) */, long pred_bstride, float mask_sum, int B, int C, int Lz, int Hy, int Wx, int p,
                          void* stream);
+/* The target's edge map in one launch (csrc/loss_fused.hip; C = 4, 11 taps): edge_tgt = sum_c |Sobel(gauss(imgs[:, c]))| =
+ * vitae_gauss_blur_fwd followed by vitae_sobel_edge_fwd without the blurred intermediates (model/vit_autoenc.py:221-223).
+ * vitae_target_edge_supported: 1 when the geometry is served, else VITAE_ERR_UNSUPPORTED_SHAPE. */
+int vitae_target_edge_supported(int C, int ntaps, int Lz, int Hy, int Wx);
+int vitae_target_edge(const float* imgs, float* edge_tgt, const float* taps_host, int ntaps, int B, int C, int Lz, int Hy, int Wx,
+                      void* stream);
 /* Both of the above in ONE pass over the prediction (csrc/loss_fused.hip; C = 4): acc[VITAE_ACC_RECON] / acc[VITAE_ACC_EDGE] as
  * vitae_loss_fwd_fused, dpred / dpred_bf16 / nonfinite_flag as vitae_loss_bwd_fused; the unpatchified prediction and its edge map
  * are not produced.  Both MSE terms are linear in their upstream gradient (hp[VITAE_HP_G_RECON], hp[VITAE_HP_G_EDGE]), so the

@@ -468,6 +468,13 @@ def test_loss_chain(lib, C, C_, vol, p):
     lib.vitae_sobel_edge_fwd(bl.data_ptr(), et.data_ptr(), None, None, B, C_, *vol, st())
     lib.vitae_sobel_edge_fwd(pv.data_ptr(), ep.data_ptr(), et.data_ptr(), acc.data_ptr(), B, C_, *vol, st())
     assert rel_err(et, trace['edge_target']) < 1e-5 and rel_err(ep, trace['edge_pred']) < 1e-5
+    # blur + Sobel of the target in ONE launch (csrc/loss_fused.hip; 4 channels): what the training step's target branch runs
+    if lib.vitae_target_edge_supported(C_, len(taps), *vol):
+        et1 = torch.full((B, *vol), float('nan'), device='cuda')
+        lib.vitae_target_edge(im.data_ptr(), et1.data_ptr(), taps.ctypes.data, len(taps), B, C_, *vol, st())
+        assert rel_err(et1, trace['edge_target']) < 1e-5, rel_err(et1, trace['edge_target'])
+    else:
+        assert C_ != 4
     out = torch.zeros(4, device='cuda')
     msum = float(mask.sum())
     lib.vitae_loss_finalize(acc.data_ptr(), hp.data_ptr(), out.data_ptr(), msum, B * V, st())

@@ -31,6 +31,7 @@ ops = {
     'loss_fwd_fused': lambda: lib.vitae_loss_fwd_fused(pp, pbs, imgs.data_ptr(), mask.data_ptr(), et.data_ptr(), pv.data_ptr(), ep.data_ptr(), acc.data_ptr(), B, Cc, *vol, p, st),
     'loss_bwd_fused': lambda: lib.vitae_loss_bwd_fused(pp, pv.data_ptr(), imgs.data_ptr(), mask.data_ptr(), ep.data_ptr(), et.data_ptr(), hp.data_ptr(), None,
                                                       dpred.data_ptr() + P * 4, d16.data_ptr() + P * 2, None, pbs, msum, B, Cc, *vol, p, st),
+    'target_edge (one pass)': lambda: lib.vitae_target_edge(imgs.data_ptr(), et.data_ptr(), taps.ctypes.data, len(taps), B, Cc, *vol, st),
     'loss_fwd_bwd (one pass)': lambda: lib.vitae_loss_fwd_bwd(pp, pbs, imgs.data_ptr(), mask.data_ptr(), et.data_ptr(), hp.data_ptr(),
                                                               dpred.data_ptr() + P * 4, d16.data_ptr() + P * 2, None, acc.data_ptr(), msum, B, Cc, *vol, p, st),
 }

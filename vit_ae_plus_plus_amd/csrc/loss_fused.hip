@@ -271,6 +271,146 @@ __global__ __launch_bounds__(NT, VITAE_LOSS_MINW) void loss_fwd_bwd_kernel(const
     if (bad && nonfinite) *nonfinite = __builtin_nanf("");   // benign race: every writer stores the same value
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The target's edge map in ONE pass over the input: E_tgt = sum_c |Sobel(gauss11(img_c))| (model/model_utils/gaussian_filter.py:16-26,
+// sobel_filter.py:37-45, model/vit_autoenc.py:221-223) — replaces blur_xy + blur_z + sobel_mag_tiled (csrc/loss.hip: 57 MB read and
+// written twice for the blurred intermediates; 89 + 44 + 59 us on the target branch at batch 4).  Same organisation as the
+// kernel above: lanes = x (the 11-tap blur along x is a chain of five DPP wave shifts to either side), the thread marches along y
+// (the blur along y as eleven running sums — each new row feeds all of them, the oldest leaves complete; the Sobel rows in a
+// two-deep ring), waves = z-planes (the blur along z reads its eleven planes straight from global memory, one dword per channel
+// and plane: neighbouring waves ask for ten of the same eleven lines, so they come from the L1; the Sobel's z-stencil exchanges the
+// blurred value through LDS).  Zero padding twice, as the reference's two convolutions do it: the INPUT is zero outside the volume
+// (out-of-range buffer offsets), and the BLURRED volume is zero outside it as well (forced before the Sobel).
+constexpr int TAPS = 11, RADB = 5;
+constexpr int XO_T = 64 - 2 * (RADB + 1);      // 52 output columns of a 64-lane row
+
+struct TGeom {
+    int Lz, Hy, Wx;
+    long V;
+    int xo, xtiles, tys;
+    float k[TAPS];
+};
+
+__global__ __launch_bounds__(NT, 2) void target_edge_kernel(const float* __restrict__ imgs, float* __restrict__ Et, const TGeom g) {
+    __shared__ f32x4 sB[2][NW][64];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int Lz = g.Lz, Hy = g.Hy, Wx = g.Wx;
+    const int xt = blockIdx.x % g.xtiles, yseg = blockIdx.x / g.xtiles, b = blockIdx.z;
+    const int x0 = xt * g.xo, ys = yseg * g.tys, z0 = blockIdx.y * (NW - 2);
+    const int x = x0 - (RADB + 1) + lane, z = z0 - 1 + w;
+    const int rows = min(g.tys, Hy - ys);
+    const bool okx = x >= 0 && x < Wx, okzc = z >= 0 && z < Lz;
+    const int xc = min(max(x, 0), Wx - 1);
+    const bool outw = w >= 1 && w <= NW - 2;
+    const bool owner_xz = lane >= RADB + 1 && lane < RADB + 1 + g.xo && okx && outw && okzc;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(imgs + (long)b * 4 * g.V), 0, (int)(g.V * 16), 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    unsigned offz[TAPS];                                    // byte offset of (plane z + dz, x) inside a channel; out of range outside the volume
+#pragma unroll
+    for (int j = 0; j < TAPS; ++j) {
+        const int zq = z - RADB + j;
+        offz[j] = (okx && zq >= 0 && zq < Lz) ? 4u * (unsigned)((long)zq * Hy * Wx + xc) : OOB;
+    }
+    float* etp = Et + (long)b * g.V + (long)min(max(z, 0), Lz - 1) * Hy * Wx + xc;
+    float kk[TAPS];
+#pragma unroll
+    for (int j = 0; j < TAPS; ++j) kk[j] = g.k[j];
+
+    f32x4 in[TAPS];                                        // the eleven planes of the NEXT step's input row (four channels each)
+    f32x4 A[TAPS];                                         // running sums of the blur along y: A[j] belongs to row (current row - 5 + j)
+    f32x4 P0[2], P1[2], P2[2];                             // Sobel partials (z and x applied) of the two previous blurred rows
+#pragma unroll
+    for (int j = 0; j < TAPS; ++j) A[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    P0[0] = P0[1] = P1[0] = P1[1] = P2[0] = P2[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int yyn = ys - (RADB + 1);                              // input row of the next issue()
+    auto issue = [&]() {                                    // (unconditional: see the kernel above)
+        const int yc = min(max(yyn, 0), Hy - 1);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const unsigned soff = 4u * (unsigned)((long)c * g.V + (long)yc * Wx);
+#pragma unroll
+            for (int j = 0; j < TAPS; ++j)
+                in[j][c] = VITAE_LOSS_ABLATE == 2 ? 1.f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, offz[j], soff, 0));
+        }
+        ++yyn;
+    };
+
+    auto step = [&](int t, auto PARC, auto SOBC, auto OUTC) {
+        constexpr int cur = decltype(PARC)::value, oth = cur ^ 1;
+        constexpr bool SOB = decltype(SOBC)::value, OUT = decltype(OUTC)::value;
+        const int yy = ys - (RADB + 1) + t;                  // input row of this step
+        // ---- blur along z (the row is zero outside the volume)
+        const float rowok = (yy >= 0 && yy < Hy) ? 1.f : 0.f;
+        f32x4 bz = kk[0] * in[0];
+#pragma unroll
+        for (int j = 1; j < TAPS; ++j) bz += kk[j] * in[j];
+        bz *= rowok;
+        issue();                                            // the next row's loads fly under this step
+        // ---- blur along x: five wave shifts to either side
+        f32x4 bx = kk[RADB] * bz, l = bz, r = bz;
+#pragma unroll
+        for (int d = 1; d <= RADB; ++d) {
+            l = lft(l); r = rgt(r);                         // l = bz(x - d), r = bz(x + d)
+            bx += kk[RADB - d] * l + kk[RADB + d] * r;
+        }
+        // ---- blur along y: the new row feeds the eleven running sums; A[0] (row yy - 5) is complete
+#pragma unroll
+        for (int j = 0; j < TAPS - 1; ++j) A[j] = A[j + 1] + kk[TAPS - 1 - j] * bx;
+        A[TAPS - 1] = kk[0] * bx;
+        if constexpr (!SOB) return;                         // the first ten rows of the march: no blurred row yet
+        const int yb = yy - RADB;                           // the blurred row
+        const bool bok = okx && okzc && yb >= 0 && yb < Hy; // the blurred volume is zero outside the volume, too
+        f32x4 bl = A[0];
+        if (!bok) bl = f32x4{0.f, 0.f, 0.f, 0.f};
+#if VITAE_LOSS_ABLATE != 1
+        sB[cur][w][lane] = bl;
+        __syncthreads();
+#endif
+        if (outw) {
+#if VITAE_LOSS_ABLATE == 1
+            const f32x4 bm = bl, bp = bl * 2.f;
+#else
+            const f32x4 bm = sB[cur][w - 1][lane], bp = sB[cur][w + 1][lane];
+#endif
+            const f32x4 sz = bm + 2.f * bl + bp, dz = bp - bm;
+            const f32x4 szl = lft(sz), szr = rgt(sz);
+            const f32x4 n0 = szl - szr, n1 = szl + 2.f * sz + szr, n2 = smooth_x(dz);
+            if constexpr (OUT) {
+                const f32x4 g0 = P0[cur] + 2.f * P0[oth] + n0;
+                const f32x4 g1 = n1 - P1[cur];
+                const f32x4 g2 = P2[cur] + 2.f * P2[oth] + n2;
+                const f32x4 m2 = g0 * g0 + g1 * g1 + g2 * g2;
+                const float e = (__builtin_amdgcn_sqrtf(m2[0]) + __builtin_amdgcn_sqrtf(m2[1])) +
+                                (__builtin_amdgcn_sqrtf(m2[2]) + __builtin_amdgcn_sqrtf(m2[3]));
+                const int yo = yb - 1;                      // the row whose edge value is complete
+                if (owner_xz && yo < Hy) etp[(long)yo * Wx] = e;
+            }
+            P0[cur] = n0; P1[cur] = n1; P2[cur] = n2;
+        }
+    };
+
+    // rows: input ys - 6 + t; blurred ys - 11 + t (t >= 10: ys - 1); edge ys - 12 + t (t >= 12: ys)
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using F = std::false_type;
+    using T = std::true_type;
+    issue();
+#pragma unroll 1
+    for (int t = 0; t < 10; t += 2) { step(t, I0{}, F{}, F{}); step(t + 1, I1{}, F{}, F{}); }
+    step(10, I0{}, T{}, F{});
+    step(11, I1{}, T{}, F{});
+    const int nsteps = rows + 12;
+    int t = 12;
+#pragma unroll 1
+    for (; t + 1 < nsteps; t += 2) {
+        step(t, I0{}, T{}, T{});
+        step(t + 1, I1{}, T{}, T{});
+    }
+    if (t < nsteps) step(t, I0{}, T{}, T{});
+}
+
 }  // namespace
 
 // 1 when vitae_loss_fwd_bwd serves this geometry (else the caller keeps vitae_loss_fwd_fused + vitae_loss_bwd_fused)
@@ -308,5 +448,31 @@ extern "C" int vitae_loss_fwd_bwd(const float* pred, long pred_bstride, const fl
     g.inv_pm = 1.0f / ((float)g.P * mask_sum);
     hipLaunchKernelGGL(loss_fwd_bwd_kernel, dim3(g.xtiles * nseg, zt, B), dim3(NT), 0, (hipStream_t)stream, pred, imgs, mask, edge_tgt,
                        hp, dpred, reinterpret_cast<__bf16*>(dpred_bf16), nonfinite_flag, acc, g);
+    return vitae_launch_status();
+}
+
+// edge_tgt[B, Lz, Hy, Wx] = sum_c |Sobel(gauss(imgs[:, c]))| in one launch (4 channels, 11 taps); 1 / 0 = served / not
+extern "C" int vitae_target_edge_supported(int C, int ntaps, int Lz, int Hy, int Wx) {
+    return C == 4 && ntaps == TAPS && (long)Lz * Hy * Wx * 16 < (1L << 31) && cdiv(Lz, NW - 2) <= 65535;
+}
+
+extern "C" int vitae_target_edge(const float* imgs, float* edge_tgt, const float* taps_host, int ntaps, int B, int C, int Lz, int Hy,
+                                 int Wx, void* stream) {
+    if (!imgs || !edge_tgt || !taps_host || B <= 0 || B > 65535 || Lz <= 0 || Hy <= 0 || Wx <= 0) return VITAE_ERR_INVALID_ARG;
+    if (!vitae_target_edge_supported(C, ntaps, Lz, Hy, Wx)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    TGeom g;
+    g.Lz = Lz; g.Hy = Hy; g.Wx = Wx; g.V = (long)Lz * Hy * Wx;
+    for (int i = 0; i < TAPS; ++i) g.k[i] = taps_host[i];
+    g.xtiles = cdiv(Wx, XO_T); g.xo = cdiv(Wx, g.xtiles);
+    const int zt = cdiv(Lz, NW - 2);
+    static const int target = getenv("VITAE_TARGET_WGS") ? atoi(getenv("VITAE_TARGET_WGS")) : 256;
+    int nseg = cdiv(target, g.xtiles * zt * B);
+    if (nseg < 1) nseg = 1;
+    int tys = cdiv(cdiv(Hy, nseg), 4) * 4;                 // (every segment re-does 12 rows of the march)
+    if (tys < 16) tys = 16;
+    if (tys > Hy) tys = Hy;
+    g.tys = tys;
+    nseg = cdiv(Hy, tys);
+    hipLaunchKernelGGL(target_edge_kernel, dim3(g.xtiles * nseg, zt, B), dim3(NT), 0, (hipStream_t)stream, imgs, edge_tgt, g);
     return vitae_launch_status();
 }

@@ -801,9 +801,13 @@ class HipMAEEngine:
                 self.side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.side):
                 ss = self.side.cuda_stream
-                lib.vitae_gauss_blur_fwd(_ptr(view1), _ptr(b['blur_tmp']), _ptr(b['blurred']), self._taps_c, len(self.taps),
-                                         B * C, Lz, Hy, Wx, ss)
-                lib.vitae_sobel_edge_fwd(_ptr(b['blurred']), _ptr(b['edge_t']), None, None, B, C, Lz, Hy, Wx, ss)
+                if self.target_one_pass and lib.vitae_target_edge_supported(C, len(self.taps), Lz, Hy, Wx):
+                    # blur + Sobel of the input in one launch: no blurred intermediates in HBM (csrc/loss_fused.hip)
+                    lib.vitae_target_edge(_ptr(view1), _ptr(b['edge_t']), self._taps_c, len(self.taps), B, C, Lz, Hy, Wx, ss)
+                else:
+                    lib.vitae_gauss_blur_fwd(_ptr(view1), _ptr(b['blur_tmp']), _ptr(b['blurred']), self._taps_c, len(self.taps),
+                                             B * C, Lz, Hy, Wx, ss)
+                    lib.vitae_sobel_edge_fwd(_ptr(b['blurred']), _ptr(b['edge_t']), None, None, B, C, Lz, Hy, Wx, ss)
 
         # where the branch forks off the main chain: 'start' (beside masking / gather / patch embedding), 'embed' (after the
         # patch-embedding GEMM, beside the first encoder blocks), 'decoder' (beside the first decoder blocks)
@@ -1226,6 +1230,7 @@ class HipMAEEngine:
     # loss forward sums + gradient in one pass over the prediction inside the fused step (csrc/loss_fused.hip; 4-channel volumes)
     loss_one_pass = os.environ.get('VITAE_LOSS_ONE_PASS', '1') != '0'
     _loss_grad_done = False
+    target_one_pass = os.environ.get('VITAE_TARGET_ONE_PASS', '1') != '0'
     # optional explicit ascending block boundaries, e.g. "0,2,7,12" (uneven chunks: a smaller last, exposed bucket)
     enc_cuts = [int(v) for v in os.environ['VITAE_ENC_CUTS'].split(',')] if os.environ.get('VITAE_ENC_CUTS') else None
 
