@@ -18,7 +18,7 @@ def timeit(fn, n=20):
         a.record(s); g.replay(); g.replay(); b.record(s); s.synchronize()
     return a.elapsed_time(b) / (2 * n) * 1e3
 
-for M, D in ((440, 768), (868, 512)):
+for M, D in ((440, 768), (868, 512), (880, 768), (1736, 512), (3520, 768), (6944, 512), (3464, 768), (6916, 512)):
     x, dy = torch.randn(M, D, device='cuda'), torch.randn(M, D, device='cuda')
     w, b = torch.randn(D, device='cuda'), torch.randn(D, device='cuda')
     y, y16 = torch.empty(M, D, device='cuda'), torch.empty(M, D, dtype=torch.bfloat16, device='cuda')

@@ -245,12 +245,21 @@ __global__ __launch_bounds__(256) void layernorm_bwd_rows_vec_kernel(const float
     constexpr int D = 256 * NV;
     extern __shared__ float red[];   // [3][4][D]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row0 = (blockIdx.x * 4 + wave) * RPW;
-    f32x4 dv[RPW][NV], xv[RPW][NV], ov[RPW][NV], wv[NV];
-    float mu[RPW], rs[RPW];
+    f32x4 wv[NV];
     const f32x4* w4 = reinterpret_cast<const f32x4*>(w);
 #pragma unroll
     for (int i = 0; i < NV; ++i) wv[i] = w4[lane + 64 * i];
+    f32x4 pw[NV], pb[NV], pc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { pw[i] = f32x4{0.f, 0.f, 0.f, 0.f}; pb[i] = pw[i]; pc[i] = pw[i]; }
+    // a workgroup takes every gridDim.x-th group of 4 * RPW rows: its d(gamma) / d(beta) / column-sum partials meet in LDS and
+    // leave as 3 D atomics ONCE per workgroup — with one group per workgroup a batch-32 launch (M = 6944: 868 workgroups)
+    // spent two thirds of its time on 1.3 M device-scope atomics (29.7 us against 10 us of HBM time)
+    const int ngroups = (M + 4 * RPW - 1) / (4 * RPW);
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int row0 = (grp * 4 + wave) * RPW;
+    f32x4 dv[RPW][NV], xv[RPW][NV], ov[RPW][NV];
+    float mu[RPW], rs[RPW];
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         const int row = min(row0 + r, M - 1);
@@ -266,9 +275,6 @@ __global__ __launch_bounds__(256) void layernorm_bwd_rows_vec_kernel(const float
             else ov[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
-    f32x4 pw[NV], pb[NV], pc[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) { pw[i] = f32x4{0.f, 0.f, 0.f, 0.f}; pb[i] = pw[i]; pc[i] = pw[i]; }
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         const int row = row0 + r;
@@ -302,6 +308,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_rows_vec_kernel(const float
                 reinterpret_cast<bf16x4*>(dx16 + (long)row * D)[lane + 64 * i] = o16;
             }
         }
+    }
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -450,9 +457,11 @@ extern "C" int vitae_layernorm_bwd(const float* dy, const float* x, const float*
     if (aligned && (D == 768 || D == 512 || D == 256)) {
         const size_t lds = (size_t)12 * D * sizeof(float);
         hipStream_t st = (hipStream_t)stream;
-        if (D == 768) hipLaunchKernelGGL((layernorm_bwd_rows_vec_kernel<2, 3>), dim3(cdiv(M, 8)), dim3(256), lds, st, dy, x, w, mean, rstd, dx, dw, db, dx16v, dx_colsum_accum, M, dx_accumulate);
-        else if (D == 512) hipLaunchKernelGGL((layernorm_bwd_rows_vec_kernel<2, 2>), dim3(cdiv(M, 8)), dim3(256), lds, st, dy, x, w, mean, rstd, dx, dw, db, dx16v, dx_colsum_accum, M, dx_accumulate);
-        else hipLaunchKernelGGL((layernorm_bwd_rows_vec_kernel<2, 1>), dim3(cdiv(M, 8)), dim3(256), lds, st, dy, x, w, mean, rstd, dx, dw, db, dx16v, dx_colsum_accum, M, dx_accumulate);
+        static const int cap = getenv("VITAE_LN_BWD_BLOCKS") ? atoi(getenv("VITAE_LN_BWD_BLOCKS")) : 128;   // (sweep: 64 / 128 / 192 / 256 / 512 / all -> 18.3 / 13.0 / 13.3 / 13.1 / 18.1 / 18.6 us at M = 3520, D = 768; 8.2 / 7.5 / 8.8 / 9.8 / 9.5 / 9.5 at M = 1736, D = 512)
+        const int nb = min(cdiv(M, 8), cap < 1 ? 1 : cap);
+        if (D == 768) hipLaunchKernelGGL((layernorm_bwd_rows_vec_kernel<2, 3>), dim3(nb), dim3(256), lds, st, dy, x, w, mean, rstd, dx, dw, db, dx16v, dx_colsum_accum, M, dx_accumulate);
+        else if (D == 512) hipLaunchKernelGGL((layernorm_bwd_rows_vec_kernel<2, 2>), dim3(nb), dim3(256), lds, st, dy, x, w, mean, rstd, dx, dw, db, dx16v, dx_colsum_accum, M, dx_accumulate);
+        else hipLaunchKernelGGL((layernorm_bwd_rows_vec_kernel<2, 1>), dim3(nb), dim3(256), lds, st, dy, x, w, mean, rstd, dx, dw, db, dx16v, dx_colsum_accum, M, dx_accumulate);
         return vitae_launch_status();
     }
     if (D <= 768) {
