@@ -549,6 +549,38 @@ def test_sobel_kat_and_nan_semantics(lib):
     assert bool(torch.isnan(flag).all())        # the early non-finite flag the in-backward optimiser keys its skip on
 
 
+def test_one_pass_loss_nan_semantics_and_flag(lib, C):
+    """csrc/loss_fused.hip on a constant 4-channel prediction: |grad| = 0 in the interior -> the reference's sqrt backward gives
+    0/0 = NaN there; the one-pass kernel must produce NaN at exactly the same voxels and raise the non-finite flag."""
+    vol, p, B = (16, 16, 32), 8, 1
+    L, P = (vol[0] // p) * (vol[1] // p) * (vol[2] // p), p ** 3 * 4
+    cfg = R.RefConfig(volume_size=vol, patch_size=p, in_chans=4, embed_dim=48, depth=1, num_heads=3, decoder_embed_dim=32,
+                      decoder_depth=1, decoder_num_heads=2)
+    hp = torch.zeros(C['VITAE_HP_COUNT'], device='cuda')
+    hp[C['VITAE_HP_G_RECON']], hp[C['VITAE_HP_G_EDGE']] = 1.0, 1.0
+    pred = torch.ones(B, L, P, device='cuda')
+    imgs = gen(B, 4, *vol, seed=5)
+    mk = torch.ones(B, L, device='cuda')
+    et = torch.zeros(B, *vol, device='cuda')
+    d = torch.zeros(B, L, P, device='cuda')
+    flag = torch.zeros(1, device='cuda')
+    acc = torch.zeros(C['VITAE_ACC_COUNT'], dtype=torch.float64, device='cuda')
+    assert lib.vitae_loss_fwd_bwd_supported(4, *vol, p)
+    lib.vitae_loss_fwd_bwd(pred.data_ptr(), L * P, dev(imgs).data_ptr(), mk.data_ptr(), et.data_ptr(), hp.data_ptr(), d.data_ptr(), None,
+                           flag.data_ptr(), acc.data_ptr(), float(L), B, 4, *vol, p, st())
+    xr = torch.ones(B, 4, *vol, requires_grad=True)
+    (R.sobel_magnitude(xr) ** 2).mean().backward()
+    got = R.unpatchify(d.cpu(), p, cfg.grid)
+    assert torch.equal(torch.isnan(got), torch.isnan(xr.grad)) and bool(torch.isnan(xr.grad).any())
+    assert bool(torch.isnan(flag).all())
+    # and a generic prediction leaves the flag alone
+    flag.zero_()
+    pred2 = dev(gen(B, L, P, seed=6))
+    lib.vitae_loss_fwd_bwd(pred2.data_ptr(), L * P, dev(imgs).data_ptr(), mk.data_ptr(), et.data_ptr(), hp.data_ptr(), d.data_ptr(), None,
+                           flag.data_ptr(), acc.data_ptr(), float(L), B, 4, *vol, p, st())
+    assert float(flag) == 0.0 and bool(torch.isfinite(d).all())
+
+
 # --------------------------------------------------------------------------- predictor pieces
 def test_bn1d_relu(lib):
     Rr, D = 220, 768
