@@ -19,7 +19,7 @@ def timeit(fn, n=20):
         a.record(s); g.replay(); g.replay(); b.record(s); s.synchronize()
     return a.elapsed_time(b) / (2 * n) * 1e3
 
-for B, N, H, hd in ((8, 55, 12, 64), (4, 217, 16, 32)):
+for B, N, H, hd in ((8, 55, 12, 64), (4, 217, 16, 32), (8, 433, 12, 64), (4, 1729, 16, 32), (64, 55, 12, 64), (32, 217, 16, 32)):
     D = H * hd
     qkv, do = torch.randn(B, N, 3 * D, device='cuda'), torch.randn(B, N, D, device='cuda')
     o, lse = torch.empty(B, N, D, device='cuda'), torch.empty(B, H, N, device='cuda')

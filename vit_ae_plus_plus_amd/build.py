@@ -23,6 +23,13 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=f
          '-I', os.path.join(ROOT, 'include'), '-I', CSRC] + os.environ.get('VITAE_HIPCC_FLAGS', '').split()
 
 
+# Per-source flags.  attention_mfma.hip: MFMA accumulators in VGPRs — its softmax touches every accumulator register of every tile,
+# and with the accumulators in AGPRs (hipcc's default at this register count) each touch was a v_accvgpr_read / _write: 80 of the
+# 170 VALU instructions per 32 x 32 tile of the forward (ISA), 6-12 % of the kernels' time (tools/attn_bench.py).  The GEMM files
+# measured neutral to slightly slower with it (their accumulators are only read once, in the epilogue) and keep the default.
+EXTRA_FLAGS = {'attention_mfma.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
+
+
 def _hipcc() -> str:
     for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
@@ -46,8 +53,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         src = os.path.join(CSRC, s)
         obj = os.path.join(OBJ, s.replace('.hip', '.o'))
         objs.append(obj)
-        if force or not _newer(obj, [src] + headers):
-            jobs.append([hipcc, *FLAGS, '-c', src, '-o', obj])
+        if force or not _newer(obj, [src] + headers + [os.path.abspath(__file__)]):
+            jobs.append([hipcc, *FLAGS, *EXTRA_FLAGS.get(s, []), '-c', src, '-o', obj])
 
     def run(cmd):
         if verbose:

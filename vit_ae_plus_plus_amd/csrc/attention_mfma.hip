@@ -81,6 +81,57 @@ __device__ __forceinline__ void stage_bf16(__bf16* dst, const float* __restrict_
     }
 }
 
+// The same two in two halves: issue() puts a chunk's global loads in flight (into registers), commit() converts and writes the
+// LDS tile.  The streaming kernels issue chunk c + 1 right after the barrier that publishes chunk c and commit it behind the
+// tiles of chunk c: the global latency of a chunk (1-2 us, every workgroup of a launch staging at the same moments) no longer
+// sits between two barriers with all four waves waiting.
+template <int HD, typename QT> struct ChunkStager;
+template <int HD> struct ChunkStager<HD, float> {
+    static constexpr int LD = HD + 8, V = HD / 4, NL = CH * V / 256;
+    f32x4 r[NL];
+    __device__ __forceinline__ void issue(const float* __restrict__ src, long ld, int r0, int N) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int idx = threadIdx.x + 256 * i, row = idx / V, c4 = idx % V;
+            r[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (r0 + row < N) r[i] = *reinterpret_cast<const f32x4*>(src + (long)(r0 + row) * ld + c4 * 4);
+        }
+    }
+    __device__ __forceinline__ void commit(__bf16* dst, float mul) const {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int idx = threadIdx.x + 256 * i, row = idx / V, c4 = idx % V;
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (__bf16)(r[i][e] * mul);
+            *reinterpret_cast<bf16x4*>(dst + row * LD + c4 * 4) = o;
+        }
+    }
+};
+template <int HD> struct ChunkStager<HD, __bf16> {
+    static constexpr int LD = HD + 8, V = HD / 8, NL = CH * V / 256;
+    bf16x8 r[NL];
+    __device__ __forceinline__ void issue(const __bf16* __restrict__ src, long ld, int r0, int N) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int idx = threadIdx.x + 256 * i, row = idx / V, c8 = idx % V;
+            r[i] = load_frag(src + (long)(r0 + row) * ld + c8 * 8, r0 + row < N, 1.f);
+        }
+    }
+    __device__ __forceinline__ void commit(__bf16* dst, float mul) const {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int idx = threadIdx.x + 256 * i, row = idx / V, c8 = idx % V;
+            bf16x8 v = r[i];
+            if (mul != 1.f) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (__bf16)((float)v[e] * mul);
+            }
+            *reinterpret_cast<bf16x8*>(dst + row * LD + c8 * 8) = v;
+        }
+    }
+};
+
 // A operand (32 x 16 slice of T^T) for reduction slots (s2, hi, e) <-> rows rowbase + crow(8 s2 + e, hi),
 // output rows i <-> columns colbase + (lane & 31) of the row-major LDS tile T (row stride LD).
 template <int LD>
@@ -159,11 +210,18 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const QT* __restrict
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) oacc[nt] = zero16();
     float m = -1e30f, lsum = 0.f;
+    ChunkStager<HD, QT> sk, sv;
+    sk.issue(base + D, ld, 0, N);
+    sv.issue(base + 2 * D, ld, 0, N);
     for (int c0 = 0; c0 < N; c0 += CH) {
         __syncthreads();
-        stage_bf16<HD>(Ks, base + D, ld, c0, N, 1.f);
-        stage_bf16<HD>(Vs, base + 2 * D, ld, c0, N, 1.f);
+        sk.commit(Ks, 1.f);
+        sv.commit(Vs, 1.f);
         __syncthreads();
+        if (c0 + CH < N) {                                  // the next chunk's loads fly under this chunk's tiles
+            sk.issue(base + D, ld, c0 + CH, N);
+            sv.issue(base + 2 * D, ld, c0 + CH, N);
+        }
         if (!wave_live) continue;
         const int kend = min(CH, N - c0);
         for (int kt = 0; kt * 32 < kend; ++kt) {
@@ -263,11 +321,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const float* __re
     f32x16 acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = zero16();
+    ChunkStager<HD, float> sk, sv;
+    sk.issue(base + D, ld, 0, N);
+    sv.issue(base + 2 * D, ld, 0, N);
     for (int c0 = 0; c0 < N; c0 += CH) {
         __syncthreads();
-        stage_bf16<HD>(Ks, base + D, ld, c0, N, 1.f);
-        stage_bf16<HD>(Vs, base + 2 * D, ld, c0, N, 1.f);
+        sk.commit(Ks, 1.f);
+        sv.commit(Vs, 1.f);
         __syncthreads();
+        if (c0 + CH < N) {
+            sk.issue(base + D, ld, c0 + CH, N);
+            sv.issue(base + 2 * D, ld, c0 + CH, N);
+        }
         if (!wave_live) continue;
         const int kend = min(CH, N - c0);
         for (int kt = 0; kt * 32 < kend; ++kt) {
@@ -353,16 +418,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const float* __r
     const float* gbase = d_o + (long)b * N * D + h * HD;
     const float* lrow = lse + ((long)b * H + h) * N;
     const float* drow = delta + ((long)b * H + h) * N;
+    ChunkStager<HD, float> sq, sg;
+    float nl = 1e30f, nd = 0.f;                            // lse / delta of this thread's query of the NEXT chunk (threads < CH)
+    auto issue_chunk = [&](int c) {
+        sq.issue(base, ld, c, N);
+        sg.issue(gbase, D, c, N);
+        if (threadIdx.x < CH) {
+            const int q = c + threadIdx.x;
+            nl = q < N ? lrow[q] * LOG2E : 1e30f;           // invalid query -> P = exp2(-huge) = 0
+            nd = q < N ? drow[q] : 0.f;
+        }
+    };
+    issue_chunk(0);
     for (int c0 = 0; c0 < N; c0 += CH) {
         __syncthreads();
-        stage_bf16<HD>(Qs, base, ld, c0, N, scale * LOG2E);
-        stage_bf16<HD>(Gs, gbase, D, c0, N, 1.f);
-        if (threadIdx.x < CH) {
-            const int q = c0 + threadIdx.x;
-            Ls[threadIdx.x] = q < N ? lrow[q] * LOG2E : 1e30f;   // invalid query -> P = exp2(-huge) = 0
-            Ds[threadIdx.x] = q < N ? drow[q] : 0.f;
-        }
+        sq.commit(Qs, scale * LOG2E);
+        sg.commit(Gs, 1.f);
+        if (threadIdx.x < CH) { Ls[threadIdx.x] = nl; Ds[threadIdx.x] = nd; }
         __syncthreads();
+        if (c0 + CH < N) issue_chunk(c0 + CH);
         if (!wave_live) continue;
         const int qend = min(CH, N - c0);
         for (int qt = 0; qt * 32 < qend; ++qt) {
