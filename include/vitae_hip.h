@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITAE_ABI_VERSION 32
+#define VITAE_ABI_VERSION 33
 
 /* matrix-core arithmetic of the dense contractions */
 #define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
@@ -182,18 +182,19 @@ int vitae_sdpa_bwd(const float* qkv, const float* o, const float* d_o, const flo
 int vitae_sdpa_mfma_fwd(const float* qkv, float* o, void* o_bf16, float* lse, int B, int N, int H, int head_dim,
                         void* stream);
 int vitae_sdpa_mfma_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv /* may be NULL when
-                        dqkv_bf16 is given and the head fits the one-launch backward (N <= 512 at hd 32, 256 at hd 64) */,
+                        dqkv_bf16 is given */,
                         void* dqkv_bf16, float* dqkv_colsum_accum /* [3*H*hd] += column sums of dqkv, or NULL */,
                         float* delta_ws, int B, int N, int H, int head_dim, void* stream);
 /* The same two ops with q | k | v read from the bf16 copy the qkv GEMM writes ([B*N, 3*H*hd] bf16: no fp32 qkv in HBM):
  * operands are what the fp32-input kernels round to while staging, except that q takes the softmax scale after its
- * rounding.  The backward is the one-launch form only: vitae_sdpa_bwd_fused_fits(N, hd) says whether a head fits LDS
- * (1) — otherwise keep an fp32 qkv and use vitae_sdpa_mfma_bwd. */
+ * rounding.  vitae_sdpa_bwd_fused_fits(N, hd): 1 when a head fits LDS and the backward is ONE launch; otherwise two streaming
+ * kernels (dQ + delta, then dK / dV) run and delta_ws [B * H * N] floats is required (may be NULL when it fits). */
 int vitae_sdpa_mfma_fwd_bf16in(const void* qkv_bf16, float* o, void* o_bf16, float* lse, int B, int N, int H, int head_dim,
                                void* stream);
 int vitae_sdpa_bwd_fused_fits(int N, int head_dim);
 int vitae_sdpa_mfma_bwd_bf16in(const void* qkv_bf16, const float* o, const float* d_o, const float* lse, float* dqkv,
-                               void* dqkv_bf16, float* dqkv_colsum_accum, int B, int N, int H, int head_dim, void* stream);
+                               void* dqkv_bf16, float* dqkv_colsum_accum, float* delta_ws, int B, int N, int H, int head_dim,
+                               void* stream);
 
 /* ---- masking and sequence assembly ---------------------------------------------------------------
  * random_masking (model/vit_autoenc.py:141-153) from a caller-supplied noise[B,L] (the torch.rand of

@@ -283,8 +283,8 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const QT* __restrict
 }
 
 // ------------------------------------------------------------------------------- backward: dQ (+ delta)
-template <int HD>
-__global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
+template <int HD, typename QT = float>
+__global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const QT* __restrict__ qkv, const float* __restrict__ o,
                                                                const float* __restrict__ d_o, const float* __restrict__ lse,
                                                                float* __restrict__ dqkv, __bf16* __restrict__ dqkv16,
                                                                float* __restrict__ dbias, float* __restrict__ delta, int N,
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const float* __re
     const int l31 = lane & 31, hi = lane >> 5;
     const int D = H * HD;
     const long ld = 3L * D;
-    const float* base = qkv + (long)b * N * ld + h * HD;
+    const QT* base = qkv + (long)b * N * ld + h * HD;
     const int q0 = (blockIdx.x * 4 + wave) * 32, qrow = q0 + l31;
     const bool qvalid = qrow < N, wave_live = q0 < N;
     bf16x8 qf[NKK], gf[NKK];
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const float* __re
     f32x16 acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = zero16();
-    ChunkStager<HD, float> sk, sv;
+    ChunkStager<HD, QT> sk, sv;
     sk.issue(base + D, ld, 0, N);
     sv.issue(base + 2 * D, ld, 0, N);
     for (int c0 = 0; c0 < N; c0 += CH) {
@@ -371,13 +371,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const float* __re
         colsum_to<16 * NT>(cs, wave_live && qvalid, dbias + h * HD, reinterpret_cast<float*>(Ks), hi, l31, wave);
     }
     if (!wave_live || !qvalid) return;
-    float* out = dqkv + ((long)b * N + qrow) * ld + h * HD;
+    const long ooff = ((long)b * N + qrow) * ld + h * HD;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             f32x4 v = {acc[nt][4 * g] * scale, acc[nt][4 * g + 1] * scale, acc[nt][4 * g + 2] * scale, acc[nt][4 * g + 3] * scale};
-            *reinterpret_cast<f32x4*>(out + 32 * nt + 8 * g + 4 * hi) = v;
+            if (dqkv) *reinterpret_cast<f32x4*>(dqkv + ooff + 32 * nt + 8 * g + 4 * hi) = v;
             if (dqkv16) {
                 bf16x4 v16;
 #pragma unroll
@@ -389,8 +389,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------- backward: dK, dV
-template <int HD>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ d_o,
+template <int HD, typename QT = float>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const QT* __restrict__ qkv, const float* __restrict__ d_o,
                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
                                                                 float* __restrict__ dqkv, __bf16* __restrict__ dqkv16,
                                                                 float* __restrict__ dbias, int N, int H, float scale) {
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const float* __r
     const int l31 = lane & 31, hi = lane >> 5;
     const int D = H * HD;
     const long ld = 3L * D;
-    const float* base = qkv + (long)b * N * ld + h * HD;
+    const QT* base = qkv + (long)b * N * ld + h * HD;
     const int k0 = (blockIdx.x * 4 + wave) * 32, krow = k0 + l31;
     const bool kvalid = krow < N, wave_live = k0 < N;
     bf16x8 kf[NKK], vf[NKK];
@@ -418,7 +418,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const float* __r
     const float* gbase = d_o + (long)b * N * D + h * HD;
     const float* lrow = lse + ((long)b * H + h) * N;
     const float* drow = delta + ((long)b * H + h) * N;
-    ChunkStager<HD, float> sq, sg;
+    ChunkStager<HD, QT> sq;
+    ChunkStager<HD, float> sg;
     float nl = 1e30f, nd = 0.f;                            // lse / delta of this thread's query of the NEXT chunk (threads < CH)
     auto issue_chunk = [&](int c) {
         sq.issue(base, ld, c, N);
@@ -484,7 +485,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const float* __r
         colsum_to<16 * NT>(cv, wave_live && kvalid, dbias + 2 * D + h * HD, reinterpret_cast<float*>(Gs), hi, l31, wave);
     }
     if (!wave_live || !kvalid) return;
-    float* out = dqkv + ((long)b * N + krow) * ld + h * HD;
+    const long ooff = ((long)b * N + krow) * ld + h * HD;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -492,8 +493,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const float* __r
             const int d = 32 * nt + 8 * g + 4 * hi;
             f32x4 vk = {dk[nt][4 * g] * LN2, dk[nt][4 * g + 1] * LN2, dk[nt][4 * g + 2] * LN2, dk[nt][4 * g + 3] * LN2};
             f32x4 vv = {dv[nt][4 * g], dv[nt][4 * g + 1], dv[nt][4 * g + 2], dv[nt][4 * g + 3]};
-            *reinterpret_cast<f32x4*>(out + D + d) = vk;       // Qs carried scale*log2e: dK = sum dS * scale * Q
-            *reinterpret_cast<f32x4*>(out + 2 * D + d) = vv;
+            if (dqkv) {
+                *reinterpret_cast<f32x4*>(dqkv + ooff + D + d) = vk;       // Qs carried scale*log2e: dK = sum dS * scale * Q
+                *reinterpret_cast<f32x4*>(dqkv + ooff + 2 * D + d) = vv;
+            }
             if (dqkv16) {
                 bf16x4 k16, v16;
 #pragma unroll
@@ -795,14 +798,37 @@ extern "C" int vitae_sdpa_bwd_fused_fits(int N, int head_dim) {
     return fused_on && (head_dim == 32 || head_dim == 64) && lds <= 150 * 1024;
 }
 
+// dq + dkv kernels (any N): the head streams through LDS in 128-row chunks; delta_ws [B * H * N] floats
+template <typename QT>
+static int sdpa_bwd_two_kernels(const QT* qkv, const float* o, const float* d_o, const float* lse, float* dqkv, __bf16* g16,
+                                float* dqkv_colsum_accum, float* delta_ws, int B, int N, int H, int head_dim, float scale,
+                                hipStream_t st) {
+    dim3 grid(cdiv(N, 128), H, B);
+    if (head_dim == 32) {
+        hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<32, QT>), grid, dim3(256), 0, st, qkv, o, d_o, lse, dqkv, g16, dqkv_colsum_accum, delta_ws, N, H, scale);
+        hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<32, QT>), grid, dim3(256), 0, st, qkv, d_o, lse, delta_ws, dqkv, g16, dqkv_colsum_accum, N, H, scale);
+    } else if (head_dim == 64) {
+        hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<64, QT>), grid, dim3(256), 0, st, qkv, o, d_o, lse, dqkv, g16, dqkv_colsum_accum, delta_ws, N, H, scale);
+        hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<64, QT>), grid, dim3(256), 0, st, qkv, d_o, lse, delta_ws, dqkv, g16, dqkv_colsum_accum, N, H, scale);
+    } else {
+        return VITAE_ERR_UNSUPPORTED_SHAPE;
+    }
+    return vitae_launch_status();
+}
+
 extern "C" int vitae_sdpa_mfma_bwd_bf16in(const void* qkv_bf16, const float* o, const float* d_o, const float* lse, float* dqkv,
-                                          void* dqkv_bf16, float* dqkv_colsum_accum, int B, int N, int H, int head_dim,
-                                          void* stream) {
+                                          void* dqkv_bf16, float* dqkv_colsum_accum, float* delta_ws, int B, int N, int H,
+                                          int head_dim, void* stream) {
     if (!qkv_bf16 || !o || !d_o || !lse || (!dqkv && !dqkv_bf16) || B <= 0 || N <= 0 || H <= 0) return VITAE_ERR_INVALID_ARG;
     if ((((long)H * head_dim) & 7) || ((uintptr_t)qkv_bf16 & 15) || ((uintptr_t)o & 15) || ((uintptr_t)d_o & 15) ||
-        ((uintptr_t)dqkv & 15) || !vitae_sdpa_bwd_fused_fits(N, head_dim))
+        ((uintptr_t)dqkv & 15) || (head_dim != 32 && head_dim != 64))
         return VITAE_ERR_UNSUPPORTED_SHAPE;
     const float scale = 1.0f / sqrtf((float)head_dim);
+    if (!vitae_sdpa_bwd_fused_fits(N, head_dim)) {         // the head does not fit LDS: the two streaming kernels
+        if (!delta_ws) return VITAE_ERR_INVALID_ARG;
+        return sdpa_bwd_two_kernels<__bf16>(reinterpret_cast<const __bf16*>(qkv_bf16), o, d_o, lse, dqkv, reinterpret_cast<__bf16*>(dqkv_bf16),
+                                            dqkv_colsum_accum, delta_ws, B, N, H, head_dim, scale, (hipStream_t)stream);
+    }
     const int NP = cdiv(N, 32) * 32;
     const size_t lds = (size_t)4 * NP * (head_dim + 8) * 2 + (size_t)2 * NP * 4 + (size_t)3 * head_dim * 4;
     const int items = 2 * (NP / 32);
@@ -864,15 +890,5 @@ extern "C" int vitae_sdpa_mfma_bwd(const float* qkv, const float* o, const float
         }
         return vitae_launch_status();
     }
-    if (!dqkv) return VITAE_ERR_UNSUPPORTED_SHAPE;      // the two-kernel fallback writes the fp32 gradient
-    if (head_dim == 32) {
-        hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<32>), grid, dim3(256), 0, st, qkv, o, d_o, lse, dqkv, g16, dqkv_colsum_accum, delta_ws, N, H, scale);
-        hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<32>), grid, dim3(256), 0, st, qkv, d_o, lse, delta_ws, dqkv, g16, dqkv_colsum_accum, N, H, scale);
-    } else if (head_dim == 64) {
-        hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<64>), grid, dim3(256), 0, st, qkv, o, d_o, lse, dqkv, g16, dqkv_colsum_accum, delta_ws, N, H, scale);
-        hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<64>), grid, dim3(256), 0, st, qkv, d_o, lse, delta_ws, dqkv, g16, dqkv_colsum_accum, N, H, scale);
-    } else {
-        return VITAE_ERR_UNSUPPORTED_SHAPE;
-    }
-    return vitae_launch_status();
+    return sdpa_bwd_two_kernels<float>(qkv, o, d_o, lse, dqkv, g16, dqkv_colsum_accum, delta_ws, B, N, H, head_dim, scale, st);
 }

@@ -668,8 +668,11 @@ class HipMAEEngine:
         self._g16_fwd(b[q + 'act_16'], p[pre + 'mlp.fc2.weight'], p[pre + 'mlp.fc2.bias'], M, d, hid, y=x_out, res=b[q + 'xmid'])
 
     def _qkv16_ok(self, N, hd) -> bool:
-        """bf16-only qkv for this stack: the flag, an MFMA head size, and the whole head fitting the one-launch backward"""
-        return bool(self.qkv16 and hd in (32, 64) and lib.vitae_sdpa_bwd_fused_fits(N, hd))
+        """bf16-only qkv for this stack: the flag and an MFMA head size (round 3: any sequence length — the two streaming backward
+        kernels read the bf16 copy as well; VITAE_QKV_BF16_LONG=0 keeps fp32 q | k | v when the head does not fit LDS)"""
+        if not (self.qkv16 and hd in (32, 64)):
+            return False
+        return bool(lib.vitae_sdpa_bwd_fused_fits(N, hd) or os.environ.get('VITAE_QKV_BF16_LONG', '1') != '0')
 
     def _dqkv32(self, dqkv, N, hd):
         """fp32 dqkv is write-only on the bf16-operand path (the qkv weight / input gradients read the bf16 copy): skip it
@@ -695,6 +698,7 @@ class HipMAEEngine:
         t = self._timed(10.0 * Bs * heads * N * N * hd, 'attn')
         if self._qkv16_ok(N, hd):
             lib.vitae_sdpa_mfma_bwd_bf16in(_ptr(b[q + 'qkv_16']), _ptr(b[q + 'o']), _ptr(do), _ptr(b[q + 'lse']), None, _ptr(dqkv16), None,
+                                           _ptr(b['delta']),
                                            Bs, N, heads, hd, self.stream)
         else:
             lib.vitae_sdpa_mfma_bwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(do), _ptr(b[q + 'lse']), _ptr(self._dqkv32(dqkv, N, hd)),
