@@ -337,20 +337,21 @@ class HipMAEEngine:
         b['tok'] = f(Be * keep, D)
         b['dtok'] = f(Be * keep, D)
 
-        def stack(pre, depth, M, d, h):
+        def stack(pre, depth, M, d, h, N, hd):
+            q32 = not (self.act16 and self._qkv16_ok(N, hd))   # fp32 q | k | v and their gradient exist only when the bf16 copy is not the operand
             b[pre + 'x'] = [f(M, d) for _ in range(depth + 1)]
             for i in range(depth):
                 q = f'{pre}{i}.'
                 b[q + 'y1'], b[q + 'mean1'], b[q + 'rstd1'] = f(M, d), f(M), f(M)
-                b[q + 'qkv'], b[q + 'o'] = f(M, 3 * d), f(M, d)
+                b[q + 'qkv'], b[q + 'o'] = (f(M, 3 * d) if q32 else None), f(M, d)
                 b[q + 'xmid'], b[q + 'y2'], b[q + 'mean2'], b[q + 'rstd2'] = f(M, d), f(M, d), f(M), f(M)
                 b[q + 'hpre'] = torch.empty(M, h, dtype=torch.bfloat16, device=dev) if self.hpre16 else f(M, h)
                 b[q + 'act'] = f(M, h)
             b[pre + 'dx'], b[pre + 'dy'], b[pre + 'do'] = f(M, d), f(M, d), f(M, d)
-            b[pre + 'dh'], b[pre + 'dqkv'] = f(M, h), f(M, 3 * d)
+            b[pre + 'dh'], b[pre + 'dqkv'] = f(M, h), (f(M, 3 * d) if q32 else None)
 
-        stack('enc', cfg.depth, Me, D, self.Hm)
-        stack('dec', cfg.decoder_depth, Md, Dd, self.Hmd)
+        stack('enc', cfg.depth, Me, D, self.Hm, self.Ne, self.hd)
+        stack('dec', cfg.decoder_depth, Md, Dd, self.Hmd, self.Nd, self.hdd)
         if self.act16:
             # bf16 GEMM operands, token rows padded to 64 with zeros (wgrad reduces over the padded count)
             z16 = lambda *s: torch.zeros(*s, dtype=torch.bfloat16, device=dev)
