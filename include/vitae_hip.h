@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITAE_ABI_VERSION 33
+#define VITAE_ABI_VERSION 34
 
 /* matrix-core arithmetic of the dense contractions */
 #define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
@@ -141,6 +141,15 @@ int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, const void* x1
                                tiles, a separate bf16 column-sum launch otherwise) */,
                                int dx_accumulate /* dx += instead of = (fp32 dx only) */, int dw_accumulate, int split_k,
                                float* splitk_ws, void* stream);
+/* (dw == NULL: the input gradient only — the weight gradient is deferred to vitae_wgrad_group_bt.)
+ * Weight gradients of up to four Linears with the same token count in ONE launch of 128x128 tiles: for i < n,
+ * dw[i][N[i], K[i]] (+)= dy16[i][Mpad, N[i]]^T x16[i][Mpad, K[i]] (rows M..Mpad-1 of every operand zero), optional bf16 copies
+ * dw16[i] (NULL array or entries), optional dy_colsum[i][N[i]] += column sums of dy16[i] (bias gradients).  The pointer arrays
+ * and N / K live on the HOST.  Together the problems of a transformer block have enough tiles that the reduction needs no
+ * split (or two) where each alone wanted 3-8; splitk_ws as for vitae_gemm_glds (capacity: vitae_gemm_glds_set_ws_capacity). */
+int vitae_wgrad_group_bt(int n, const void* const* dy16, const void* const* x16, float* const* dw, void* const* dw16,
+                         float* const* dy_colsum, const int* N, const int* K, int M, int Mpad, int dw_accumulate,
+                         float* splitk_ws, void* stream);
 /* split of the dgrad reduction for the call above (1 = none); workspace as for vitae_gemm_glds with (M, K) */
 int vitae_linear_bwd_pair_pick_split_k(int M, int Mpad, int N, int K);
 /* dst_bf16[i] = bf16(src[i]) (round to nearest even) */

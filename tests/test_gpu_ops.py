@@ -906,6 +906,39 @@ def test_linear_bwd_pair_on_big_tiles(lib, C, bt_mode, tile, M, N, K):
         assert rel_err(a, b) < 1e-5           # the two routes differ in fp32 summation order only
 
 
+@pytest.mark.parametrize('M,dims', [(3520, [(2304, 768), (768, 768), (3072, 768), (768, 3072)]), (1000, [(1536, 512), (512, 512)]),
+                                    (6944, [(512, 2048)]), (260, [(264, 136), (128, 520), (520, 128)])])
+def test_wgrad_group_bt(lib, M, dims):
+    """vitae_wgrad_group_bt: the weight gradients (and bias gradients) of up to four Linears of a block in one launch of 128x128
+    tiles, against fp32 products of the same bf16 operands; accumulation and the bf16 copy."""
+    import numpy as np
+    Mp = (M + 63) // 64 * 64
+    n = len(dims)
+    dys = [torch.zeros(Mp, N, dtype=torch.bfloat16, device='cuda') for N, K in dims]
+    xs = [torch.zeros(Mp, K, dtype=torch.bfloat16, device='cuda') for N, K in dims]
+    for i, (N, K) in enumerate(dims):
+        dys[i][:M] = dev(_bf(gen(M, N, seed=10 + i)))
+        xs[i][:M] = dev(_bf(gen(M, K, seed=20 + i)))
+    dws = [torch.full((N, K), float('nan'), device='cuda') for N, K in dims]
+    d16 = [torch.empty(N, K, dtype=torch.bfloat16, device='cuda') for N, K in dims]
+    dbs = [torch.zeros(N, device='cuda') for N, K in dims]
+    ws = torch.zeros(1 << 24, device='cuda')
+    lib.vitae_gemm_glds_set_ws_capacity(ws.numel())
+    arr = lambda ts: np.array([t.data_ptr() for t in ts], dtype=np.uint64)
+    a_dy, a_x, a_dw, a_16, a_db = arr(dys), arr(xs), arr(dws), arr(d16), arr(dbs)
+    Ns, Ks = np.array([d[0] for d in dims], dtype=np.int32), np.array([d[1] for d in dims], dtype=np.int32)
+    refs = [dys[i][:M].float().t() @ xs[i][:M].float() for i in range(n)]
+    for accumulate in (0, 1):
+        lib.vitae_wgrad_group_bt(n, a_dy.ctypes.data, a_x.ctypes.data, a_dw.ctypes.data, a_16.ctypes.data, a_db.ctypes.data if not accumulate else None,
+                                 Ns.ctypes.data, Ks.ctypes.data, M, Mp, accumulate, ws.data_ptr(), st())
+        for i in range(n):
+            want = refs[i] * (2 if accumulate else 1)
+            assert rel_err(dws[i], want) < 2e-5, (i, accumulate, rel_err(dws[i], want))
+            assert torch.equal(d16[i], dws[i].to(torch.bfloat16))
+            assert rel_err(dbs[i], dys[i][:M].float().sum(0)) < 1e-5
+    assert float(ws[:4096].abs().max()) == 0.0          # the tickets are back to zero
+
+
 def test_gemm_bt_planner_is_consistent(lib, bt_mode):
     """vitae_gemm_glds_pick_split_k returns the split of the plan the launcher will follow; forcing a tile changes the plan;
     -2 switches the family off."""

@@ -220,7 +220,7 @@ __device__ __forceinline__ void bt_park_quadrant(const f32x16 (&acc)[NACC][FM * 
 }
 
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC>
-__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bt_kernel(const GArgs p) {
+__device__ __forceinline__ void gemm_bt_body(const GArgs& p, const int bid, const int zid, unsigned char* smem) {
     using Cf = BtCfg<BM, BN, WM, WN>;
     constexpr int NW = Cf::NW, HM = Cf::HM, HN = Cf::HN, FM = Cf::FM, FN = Cf::FN, NF = FM * FN;
     constexpr int A_HALF = Cf::A_HALF, B_HALF = Cf::B_HALF, BUF = Cf::BUF;
@@ -228,14 +228,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bt_kernel(const GArgs p)
     constexpr int PA = pieces<HM, A_KC, NW>(), PB = pieces<HN, B_KC, NW>();
     constexpr int NACC = NF == 1 ? 2 : 1;          // one fragment per quadrant: even / odd k-slices on separate accumulators
     constexpr bool ASM_READS = !A_KC || !B_KC;     // transposing reads are inline asm: ordered by hand
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[Cf::SMEM];      // the ONLY LDS object
-
     // XCD-aware AND balanced tile map (block b runs on XCD b % 8): the T = tiles_m * tiles_n tiles are cut into eight contiguous
     // chunks of the linear order (sizes differ by at most one), XCD x takes chunk x.  The linear order walks the SHORTER operand's
     // tiles fastest, so a chunk covers whole column tiles (all row tiles under them) — or whole row tiles when A is the larger
     // operand (xcd_m): an XCD's L2 holds 1/8 of one operand and streams the other.  (The 64-row kernels give XCD x the column
     // tiles x, x + 8, ...: with 18 column tiles two XCDs get three columns and six get two — a 1.5x longer tail.)
-    const int bid = blockIdx.x;
     const int T = p.tiles_m * p.tiles_n;
     const int xq = T >> 3, xr = T & 7, xcd = bid & 7;
     const int lin = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
@@ -243,7 +240,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bt_kernel(const GArgs p)
     const int tn = p.xcd_m ? lin % p.tiles_n : lin / p.tiles_m;
     const int tm = p.xcd_m ? lin / p.tiles_n : lin % p.tiles_m;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int zid = blockIdx.z;
     const int kbeg = zid * p.k_per_split;
     const int nk = (min(p.K, kbeg + p.k_per_split) - kbeg) / BK;         // >= 2 (launcher)
     const int lane = threadIdx.x & 63;
@@ -252,7 +248,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bt_kernel(const GArgs p)
     const bool late = STAGGER && wave >= 4;         // group 1: one barrier behind
     // tools/bt_phase_probe.py: shader-clock stamps of wave 0 / wave 4 (one per stagger group), 32 per (workgroup, group)
     auto stamp = [&](int i) {
-        if (p.dbg && lane == 0 && (wave & 3) == 0) p.dbg[(((long)zid * gridDim.x + bid) * 2 + (wave >> 2)) * 32 + i] = __builtin_amdgcn_s_memtime();
+        if (p.dbg && lane == 0 && (wave & 3) == 0) p.dbg[(((long)zid * (8 * ((T + 7) >> 3)) + bid) * 2 + (wave >> 2)) * 32 + i] = __builtin_amdgcn_s_memtime();
     };
     stamp(0);
 
@@ -445,7 +441,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bt_kernel(const GArgs p)
         // fence), drains, takes a ticket; the LAST arriver of a tile re-reads all partials with sc1 loads in split order
         // (bitwise reproducible whatever the arrival order) and runs the epilogue.  cdna_hip_programming.md §6 Guideline 16 R1.
         constexpr int NT = 64 * NW, GROUPS = 4 * NF * 4;                  // 16-byte groups per lane: quadrants x fragments x 4
-        const int tile = tm * p.tiles_n + tn;
+        const int tile = p.tile0 + tm * p.tiles_n + tn;
         float* part = p.ws + VITAE_GLDS_TICKETS + (long)tile * p.splits * (NT * GROUPS * 4);
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(part, 0, p.splits * (NT * GROUPS * 16), 0x00020000);
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -544,6 +540,25 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bt_kernel(const GArgs p)
     if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(25); }
 }
 
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bt_kernel(const GArgs p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[BtCfg<BM, BN, WM, WN>::SMEM];      // the ONLY LDS object
+    gemm_bt_body<BM, BN, WM, WN, A_KC, B_KC>(p, blockIdx.x, blockIdx.z, smem);
+}
+
+// Up to four weight-gradient problems dW_i[N_i, K_i] (+)= dy_i^T x_i of one transformer block (same reduction length: the padded
+// token count) as ONE launch of 128x128 tiles: together they have enough tiles that the reduction needs no split (batch 32
+// encoder: 432 tiles) or a split of two (decoder: 192) where each of them alone wanted 3-8 — and the in-launch split-K fix-up was
+// half of those launches (tools/wgrad_split_sweep.py).  Block ranges start at multiples of 8: every problem keeps its XCD map.
+struct BtGroup { GArgs p[4]; int start[5]; };
+
+__global__ __launch_bounds__(256, 2) void gemm_bt_wgrad_group_kernel(const BtGroup g) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[BtCfg<128, 128, 2, 2>::SMEM];
+    const int b = blockIdx.x;
+    const int i = (b >= g.start[1]) + (b >= g.start[2]) + (b >= g.start[3]);
+    gemm_bt_body<128, 128, 2, 2, false, false>(g.p[i], b - g.start[i], blockIdx.z, smem);
+}
+
 template <int BM, int BN, int WM, int WN>
 static void bt_launch_cfg(const GArgs& p, bool a_kc, bool b_kc, hipStream_t st) {
     const dim3 grid(8 * cdiv((long)p.tiles_m * p.tiles_n, 8), 1, p.splits), block(64 * WM * WN);
@@ -578,6 +593,35 @@ int bt_launch(GArgs p, int a_kc, int b_kc, int id, hipStream_t st) {
     // overhead as eight — 2150 clocks per k-tile for 1024 of MFMA — never the best tile on any shape of the step: not kept)
     if (id == 0) bt_launch_cfg<256, 256, 2, 4>(p, a_kc, b_kc, st);
     else bt_launch_cfg<128, 128, 2, 2>(p, a_kc, b_kc, st);
+    return vitae_launch_status();
+}
+
+// n <= 4 complete weight-gradient descriptors (A = dy16 [K, M] row-contiguous, B = x16 [K, N], same K, vec_epi set); `splits`
+// k-ranges for all of them; ws: tickets + partial tiles for the sum of their tiles
+int bt_wgrad_group_launch(GArgs* ps, int n, int splits, hipStream_t st) {
+    if (n < 1 || n > 4) return VITAE_ERR_INVALID_ARG;
+    BtGroup g;
+    int total = 0, tiles = 0;
+    const int K = ps[0].K;
+    int kps = cdiv(cdiv(K, splits), BK) * BK;
+    splits = cdiv(K, kps);
+    if (K - (splits - 1) * kps < 2 * BK || kps < 2 * BK) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    for (int i = 0; i < 4; ++i) {
+        g.start[i] = total;
+        if (i >= n) { g.p[i] = g.p[0]; continue; }
+        GArgs& p = ps[i];
+        if (!p.vec_epi || p.a_rowsum || p.K != K || (K % BK)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+        p.k_per_split = kps; p.splits = splits;
+        p.tiles_m = cdiv(p.M, 128); p.tiles_n = cdiv(p.N, 128);
+        p.tile0 = tiles;
+        tiles += p.tiles_m * p.tiles_n;
+        total += 8 * cdiv(p.tiles_m * p.tiles_n, 8);
+        g.p[i] = p;
+    }
+    g.start[4] = total;
+    for (int i = n; i < 4; ++i) g.start[i] = total;
+    if (splits > 1 && (!ps[0].ws || tiles > VITAE_GLDS_TICKETS)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    hipLaunchKernelGGL(gemm_bt_wgrad_group_kernel, dim3(total, 1, splits), dim3(256), 0, st, g);
     return vitae_launch_status();
 }
 

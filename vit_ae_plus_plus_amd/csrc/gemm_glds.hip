@@ -788,7 +788,7 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
                                           float* dw, void* dw16, int M, int Mpad, int N, int K, int epi, float* aux,
                                           float* dx_colsum_accum, float* dy_colsum_accum, int dx_accumulate, int dw_accumulate,
                                           int split_k, float* splitk_ws, void* stream) {
-    if (!dy16 || !w16 || !x16 || (!dx && !dx16) || !dw || M <= 0 || N <= 0 || K <= 0) return VITAE_ERR_INVALID_ARG;
+    if (!dy16 || !w16 || (!x16 && dw) || (!dx && !dx16) || M <= 0 || N <= 0 || K <= 0) return VITAE_ERR_INVALID_ARG;
     const int aux16 = (epi & VITAE_EPI_AUX_BF16) != 0;
     epi &= ~VITAE_EPI_AUX_BF16;
     if (epi != VITAE_EPI_NONE && !aux) return VITAE_ERR_INVALID_ARG;
@@ -796,6 +796,16 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
     if ((N % BK) || (Mpad % BK) || (K & 7) || Mpad < M) return VITAE_ERR_UNSUPPORTED_SHAPE;
     if ((long)(M > N ? M : N) * K >= (1L << 31)) return VITAE_ERR_UNSUPPORTED_SHAPE;   // 32-bit epilogue offsets
     if (((uintptr_t)dy16 & 15) || ((uintptr_t)w16 & 15) || ((uintptr_t)x16 & 15)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    if (!dw) {
+        // dW deferred (vitae_wgrad_group_bt collects a block's weight gradients into one launch): the input gradient alone, through
+        // the planner of vitae_gemm_glds
+        const long cap = !splitk_ws ? 0 : g_ws_capacity > 0 ? g_ws_capacity : vitae_gemm_glds_ws_floats(M, K, split_k);
+        const BtPlan pd = bt_plan(M, K, N, 1, 0, true, cap);
+        int sp = pd.tile >= 0 ? pd.split : old_split_rule(M, K, N);
+        while (pd.tile < 0 && sp > 1 && vitae_gemm_glds_ws_floats(M, K, sp) > cap) --sp;
+        return gemm_glds_launch(1, 0, dy16, N, w16, K, dx, K, dx16, K, M, K, N, nullptr, nullptr, 0, epi | (aux16 ? VITAE_EPI_AUX_BF16 : 0),
+                                aux, K, dx_accumulate, sp, splitk_ws, dx_colsum_accum, stream, &pd);
+    }
     if (g_bt_mode != -2) {
         // When the big tiles serve either half, the halves go out as two launches of their own (each fills the chip; the
         // paired launch exists to double the resident workgroups of two SMALL problems): dx = epi(dy16 @ W16) and
@@ -861,6 +871,52 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
     else launch_pair<64, 64>(t2.id, grid, st, p1, p2, nb1);
     if (dy_colsum_accum)
         launch_colsum_bf16(dy16, dy_colsum_accum, M, N, st);
+    return vitae_launch_status();
+}
+
+// Weight gradients of up to four Linears with the same token count in ONE launch of 128x128 tiles (csrc/gemm_bt.hip): for i < n,
+// dw[i][N[i], K[i]] (+)= dy16[i][Mpad, N[i]]^T x16[i][Mpad, K[i]]; optional bf16 copies dw16[i]; optional bias gradients
+// dy_colsum[i][N[i]] += column sums of the first M rows of dy16[i] (one small launch each).  Pointer arrays and N / K on the HOST.
+// The split of the reduction is chosen for the SUM of the tiles (about two resident workgroups per CU).
+extern "C" int vitae_wgrad_group_bt(int n, const void* const* dy16, const void* const* x16, float* const* dw, void* const* dw16,
+                                    float* const* dy_colsum, const int* N, const int* K, int M, int Mpad, int dw_accumulate,
+                                    float* splitk_ws, void* stream) {
+    if (n < 1 || n > 4 || !dy16 || !x16 || !dw || !N || !K || M <= 0 || Mpad < M) return VITAE_ERR_INVALID_ARG;
+    if ((Mpad % BK) || Mpad < 4 * BK) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    GArgs ps[4];
+    long tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!dy16[i] || !x16[i] || !dw[i] || N[i] <= 0 || K[i] <= 0) return VITAE_ERR_INVALID_ARG;
+        if ((N[i] & 7) || (K[i] & 7) || (long)N[i] * K[i] >= (1L << 31)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+        if (((uintptr_t)dy16[i] & 15) || ((uintptr_t)x16[i] & 15)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+        GArgs& p = ps[i];
+        p.A = reinterpret_cast<const __bf16*>(dy16[i]); p.lda = N[i];
+        p.B = reinterpret_cast<const __bf16*>(x16[i]); p.ldb = K[i];
+        p.C = dw[i]; p.ldc = K[i];
+        p.C16 = reinterpret_cast<__bf16*>(dw16 ? dw16[i] : nullptr); p.ldc16 = K[i];
+        p.M = N[i]; p.N = K[i]; p.K = Mpad; p.k_per_split = Mpad; p.splits = 1;
+        p.bias = nullptr; p.residual = nullptr; p.ldr = 0; p.aux = nullptr; p.ldaux = 0; p.epi = VITAE_EPI_NONE;
+        p.accumulate = dw_accumulate; p.ws = splitk_ws; p.out_colsum = nullptr; p.a_rowsum = nullptr; p.dbg = nullptr;
+        p.sqacc = g_wgrad_sqacc;
+        p.xcd_m = xcd_by_rows(N[i], K[i]);
+        p.tiles_m = cdiv(N[i], 128); p.tiles_n = cdiv(K[i], 128);
+        p.vec_epi = vec_epilogue_ok(p);
+        if (!p.vec_epi) return VITAE_ERR_UNSUPPORTED_SHAPE;
+        tiles += (long)p.tiles_m * p.tiles_n;
+    }
+    // split: fill ~512 resident slots, at least 8 k-tiles per split, workspace permitting
+    static const int slots = getenv("VITAE_WGRAD_GROUP_SLOTS") ? atoi(getenv("VITAE_WGRAD_GROUP_SLOTS")) : 384;   // (sweep 256 / 384 / 512 / 768 at batch 32: encoder block 76 / 74 / 74 / 90 us, decoder block 106 / 74 / 93 / 82 us)
+    int split = (int)((slots + tiles / 2) / tiles);
+    if (split < 1) split = 1;
+    if (split > 8) split = 8;
+    while (split > 1 && Mpad / BK / split < 8) --split;
+    const long cap = !splitk_ws ? 0 : g_ws_capacity;
+    while (split > 1 && (tiles > VITAE_GLDS_TICKETS || VITAE_GLDS_TICKETS + tiles * split * 128 * 128 > cap)) --split;
+    const int rc = bt_wgrad_group_launch(ps, n, split, (hipStream_t)stream);
+    if (rc != VITAE_OK) return rc;
+    if (dy_colsum)
+        for (int i = 0; i < n; ++i)
+            if (dy_colsum[i]) launch_colsum_bf16(dy16[i], dy_colsum[i], M, N[i], (hipStream_t)stream);
     return vitae_launch_status();
 }
 

@@ -26,6 +26,7 @@ struct GArgs {
                          // base pointers allow it): the tile goes through LDS and leaves row-major, 16 bytes per lane
     int tiles_m, tiles_n;
     double* sqacc = nullptr;     // optional: *sqacc += sum of squares of the stored result (the gradient norm's share of a wgrad)
+    int tile0 = 0;               // index of this problem's first tile among the tickets / partial tiles of a grouped launch
     int aux16 = 0;               // aux holds bf16 (VITAE_EPI_AUX_BF16): the saved GELU pre-activation at half the bytes
     long long* dbg;      // optional (tools/gemm_phase_probe.py): 8 s_memtime stamps per workgroup
     int xcd_m;           // 0: an XCD owns column tiles tn = xcd (mod 8) and walks every row tile (its L2 holds 1/8 of B and all
@@ -105,5 +106,6 @@ __device__ __forceinline__ float epilogue_frag(const GArgs& p, const float (&v)[
 // descriptor of ONE unsplit problem; tiles_m / tiles_n are set by the launcher.
 bool bt_tile_dims(int id, int& bm, int& bn);
 int bt_launch(GArgs p, int a_kc, int b_kc, int id, hipStream_t st);
+int bt_wgrad_group_launch(GArgs* ps, int n, int splits, hipStream_t st);
 
 }  // namespace vglds

@@ -364,6 +364,8 @@ class HipMAEEngine:
                     if self.qkv16:
                         b[q + 'qkv_16'] = z16(Mp, 3 * d)
                 b[pre + 'dx_16'], b[pre + 'dh_16'], b[pre + 'dqkv_16'] = z16(Mp, d), z16(Mp, h), z16(Mp, 3 * d)
+                if Mp * d >= self.wgrad_group_min:
+                    b[pre + 'dx_16b'] = z16(Mp, d)
             b['dn_16'] = z16(self.Mpd, Dd)
             b['dpred_16'] = z16(self.Mpd, P)
             b['patches_16'], b['dtok_16'] = z16(self.Mpt, P), z16(self.Mpt, D)
@@ -625,7 +627,8 @@ class HipMAEEngine:
 
     def _g16_bwd(self, dy16, w, x16, dw, M, Mpad, N, K, dx=None, dx16=None, epi=EPI_NONE, aux=None, dx_colsum=None,
                  dy_colsum=None, dx_accumulate=0):
-        """dx / dx16 = epi(dy16 @ W16), dW (+)= dy16^T @ x16 in one paired launch."""
+        """dx / dx16 = epi(dy16 @ W16), dW (+)= dy16^T @ x16 in one paired launch.  ``dw`` None: the input gradient only (the
+        weight gradient is collected by ``_wgrad_group``)."""
         key = ('p', M, N, K)
         s = self._split_cache.get(key)
         if s is None:
@@ -636,12 +639,33 @@ class HipMAEEngine:
         tag = 'glds_pair' if N < 8192 else 'glds_pair_wide'
         if self.gemm_timer is not None and (lib.vitae_gemm_glds_bt_choice(1, 0, M, K, N) >= 0 or lib.vitae_gemm_glds_bt_choice(0, 0, N, K, Mpad) >= 0):
             tag = 'bt_bwd'      # the halves leave as two launches, at least one of them on a big tile
-        t = self._timed(4.0 * M * N * K, tag)
-        lib.vitae_linear_bwd_pair_glds(_ptr(dy16), self._w16(w), _ptr(x16), _ptr(dx), _ptr(dx16), _ptr(dw), self._wire_of(dw), M, Mpad,
+        if dw is None:
+            tag = self._gemm_tag(1, 0, M, K, N, lib.vitae_gemm_glds_pick_split_k(M, K, N), 'glds')
+        t = self._timed((4.0 if dw is not None else 2.0) * M * N * K, tag)
+        lib.vitae_linear_bwd_pair_glds(_ptr(dy16), self._w16(w), _ptr(x16), _ptr(dx), _ptr(dx16), _ptr(dw),
+                                       None if dw is None else self._wire_of(dw), M, Mpad,
                                        N, K,
                                        epi, _ptr(aux), _ptr(dx_colsum), _ptr(dy_colsum), int(dx_accumulate), int(self._accum), s,
                                        self.ws16.data_ptr(),
                                        self.stream)
+        if t is not None:
+            t.record()
+
+    def _wgrad_group(self, items, M, Mpad, bias=None):
+        """The weight gradients of one block's Linears in ONE launch (csrc/gemm_bt.hip: gemm_bt_wgrad_group_kernel).
+        ``items``: [(dy16, x16, dw, N, K)]; ``bias``: {index: bias-gradient tensor} for column sums of dy taken beside it."""
+        n = len(items)
+        arr = lambda v: np.array(v, dtype=np.uint64)
+        a_dy, a_x = arr([it[0].data_ptr() for it in items]), arr([it[1].data_ptr() for it in items])
+        a_dw = arr([it[2].data_ptr() for it in items])
+        wires = [self._wire_of(it[2]) for it in items]
+        a_16 = arr([w or 0 for w in wires]) if any(wires) else None
+        a_db = arr([(bias[i].data_ptr() if bias and i in bias else 0) for i in range(n)]) if bias else None
+        Ns, Ks = np.array([it[3] for it in items], dtype=np.int32), np.array([it[4] for it in items], dtype=np.int32)
+        t = self._timed(sum(2.0 * Mpad * it[3] * it[4] for it in items), 'bt_group')
+        lib.vitae_wgrad_group_bt(n, a_dy.ctypes.data, a_x.ctypes.data, a_dw.ctypes.data, None if a_16 is None else a_16.ctypes.data,
+                                 None if a_db is None else a_db.ctypes.data, Ns.ctypes.data, Ks.ctypes.data, M, Mpad, int(self._accum),
+                                 self.ws16.data_ptr(), self.stream)
         if t is not None:
             t.record()
 
@@ -690,12 +714,18 @@ class HipMAEEngine:
         self._scope = s
         dx, dx16, dh16, dy, do, dqkv, dqkv16 = (b[s + 'dx'], b[s + 'dx_16'], b[s + 'dh_16'], b[s + 'dy'], b[s + 'do'],
                                                   b[s + 'dqkv'], b[s + 'dqkv_16'])
-        self._g16_bwd(dx16, p[pre + 'mlp.fc2.weight'], b[q + 'act_16'], g[pre + 'mlp.fc2.weight'], M, Mp, d, hid,
+        # Many token rows (batch >= ~16, patch 8): the four weight gradients of the block leave as ONE launch at its end
+        # (``_wgrad_group``) and the Linears' backward launches compute the input gradients only.  Each dy operand then has to
+        # survive until that launch: the gradient w.r.t. the block's middle (norm2's output) goes to a second bf16 buffer.
+        grp = Mp * d >= self.wgrad_group_min
+        dw = (lambda name: None) if grp else (lambda name: g[name])
+        dmid16 = b[s + 'dx_16b'] if grp else dx16
+        self._g16_bwd(dx16, p[pre + 'mlp.fc2.weight'], b[q + 'act_16'], dw(pre + 'mlp.fc2.weight'), M, Mp, d, hid,
                       dx16=dh16, epi=EPI_DGELU | self._aux16, aux=b[q + 'hpre'], dx_colsum=g[pre + 'mlp.fc1.bias'])
-        self._g16_bwd(dh16, p[pre + 'mlp.fc1.weight'], b[q + 'y2_16'], g[pre + 'mlp.fc1.weight'], M, Mp, hid, d, dx=dy)
-        self._ln_bwd(dy, b[q + 'xmid'], pre + 'norm2.', b[q + 'mean2'], b[q + 'rstd2'], dx, M, d, 1, dx16=dx16,
+        self._g16_bwd(dh16, p[pre + 'mlp.fc1.weight'], b[q + 'y2_16'], dw(pre + 'mlp.fc1.weight'), M, Mp, hid, d, dx=dy)
+        self._ln_bwd(dy, b[q + 'xmid'], pre + 'norm2.', b[q + 'mean2'], b[q + 'rstd2'], dx, M, d, 1, dx16=dmid16,
                      dx_colsum=g[pre + 'attn.proj.bias'])
-        self._g16_bwd(dx16, p[pre + 'attn.proj.weight'], b[q + 'o_16'], g[pre + 'attn.proj.weight'], M, Mp, d, d, dx=do)
+        self._g16_bwd(dmid16, p[pre + 'attn.proj.weight'], b[q + 'o_16'], dw(pre + 'attn.proj.weight'), M, Mp, d, d, dx=do)
         t = self._timed(10.0 * Bs * heads * N * N * hd, 'attn')
         if self._qkv16_ok(N, hd):
             lib.vitae_sdpa_mfma_bwd_bf16in(_ptr(b[q + 'qkv_16']), _ptr(b[q + 'o']), _ptr(do), _ptr(b[q + 'lse']), None, _ptr(dqkv16), None,
@@ -707,8 +737,14 @@ class HipMAEEngine:
         if t is not None:
             t.record()
         # the qkv bias gradient colsum(dqkv) rides on the wgrad workgroups (one extra MFMA against a ones operand)
-        self._g16_bwd(dqkv16, p[pre + 'attn.qkv.weight'], b[q + 'y1_16'], g[pre + 'attn.qkv.weight'], M, Mp, 3 * d, d, dx=dy,
-                      dy_colsum=g[pre + 'attn.qkv.bias'])
+        self._g16_bwd(dqkv16, p[pre + 'attn.qkv.weight'], b[q + 'y1_16'], dw(pre + 'attn.qkv.weight'), M, Mp, 3 * d, d, dx=dy,
+                      dy_colsum=None if grp else g[pre + 'attn.qkv.bias'])
+        if grp:       # (before norm1's backward overwrites dx16, the fc2 weight gradient's dy operand)
+            self._wgrad_group([(dx16, b[q + 'act_16'], g[pre + 'mlp.fc2.weight'], d, hid),
+                               (dh16, b[q + 'y2_16'], g[pre + 'mlp.fc1.weight'], hid, d),
+                               (dmid16, b[q + 'o_16'], g[pre + 'attn.proj.weight'], d, d),
+                               (dqkv16, b[q + 'y1_16'], g[pre + 'attn.qkv.weight'], 3 * d, d)], M, Mp,
+                              bias={3: g[pre + 'attn.qkv.bias']})
         self._ln_bwd(dy, x_in, pre + 'norm1.', b[q + 'mean1'], b[q + 'rstd1'], dx, M, d, 1, dx16=dx16,
                      dx_colsum=prev_fc2_bias)
         self._scope = None
@@ -1235,6 +1271,10 @@ class HipMAEEngine:
     # loss forward sums + gradient in one pass over the prediction inside the fused step (csrc/loss_fused.hip; 4-channel volumes)
     loss_one_pass = os.environ.get('VITAE_LOSS_ONE_PASS', '1') != '0'
     _loss_grad_done = False
+    # (padded token rows x model width) from which a block's four weight gradients leave as ONE grouped launch.  Measured
+    # (volumes/s, grouped vs paired): batch 32 2766 vs 2480, batch 16 1906 vs 1802 (encoder 1792 x 768 grouped: 1906 vs 1843 without),
+    # patch 8 328 vs 294; batch 8 1336 vs 1361-1372 when its decoder (1792 x 512) is grouped, 1314-1343 when everything is
+    wgrad_group_min = int(float(os.environ.get('VITAE_WGRAD_GROUP_MIN', '1.2e6')))
     target_one_pass = os.environ.get('VITAE_TARGET_ONE_PASS', '1') != '0'
     # optional explicit ascending block boundaries, e.g. "0,2,7,12" (uneven chunks: a smaller last, exposed bucket)
     enc_cuts = [int(v) for v in os.environ['VITAE_ENC_CUTS'].split(',')] if os.environ.get('VITAE_ENC_CUTS') else None
