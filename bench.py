@@ -37,7 +37,7 @@ if ROOT not in sys.path:
 # can be run on a one-GPU box.  The printed line says so in config.parallelism.
 ONE_GPU = os.environ.get('VITAE_BENCH_ONE_GPU') == '1'
 VOL, CH, PATCH = 96, 4, 16
-PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3, 'fp32x3': 2500.0 / 3}   # dense MFMA peaks, MI355X_MICROARCH.md (fp32x3: three bf16 MFMAs per product)
 ALGO_GFLOP_PER_VOL = {'contr': 136.3, 'mae': 90.8}   # BASELINE.md §4 (fwd+bwd, reference formulation)
 ENC_ATTN_MLP_GFLOP_PER_VOL = 9.45 * 3                # encoder blocks fwd+bwd, one view per volume
 P8_GFLOP_PER_VOL = 941.4                             # the reference's shipped shape (patch 8), contrastive ViT-B, fwd+bwd
@@ -61,7 +61,7 @@ def parse(argv=None):
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--batch', type=int, default=4, help='volumes per GPU per step (BASELINE config 2: 4)')
-    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32', 'fp32x3'])
     ap.add_argument('--patch', type=int, default=PATCH, help='patch size (BASELINE configs: 16; the reference\'s config.ini default: 8) — not the headline workload when changed')
     ap.add_argument('--model', default='contr', choices=['contr', 'mae'])
     ap.add_argument('--no-graph', action='store_true')
@@ -566,6 +566,14 @@ def main():
                                                        'the headline model in fp32 mode (exact-fp32 MFMA: the parity mode)')
         except Exception as e:
             extra['also_fp32'] = {'error': repr(e)[:200]}
+        try:   # the reference's arithmetic is fp32 — the fast mode that still holds its losses to 1e-4
+            extra['also_fp32x3'] = secondary_model_point(args, dev, args.model, 'fp32x3', batches,
+                                                         'the headline model in fp32x3 mode (fp32 operands split into bf16 hi + lo while '
+                                                         'staged, hi.hi + hi.lo + lo.hi on the bf16 MFMA, fp32 accumulate; fp32 attention, '
+                                                         'norms, losses, optimiser): fp32-grade parity — tests/test_gpu_model.py holds it to the '
+                                                         'fp32 mode\'s bounds against the reference pins')
+        except Exception as e:
+            extra['also_fp32x3'] = {'error': repr(e)[:200]}
     if single:
         try:
             extra['also_epoch_loop'] = epoch_loop_point(args, dev, ms)

@@ -24,11 +24,13 @@
 extern "C" {
 #endif
 
-#define VITAE_ABI_VERSION 34
+#define VITAE_ABI_VERSION 35
 
 /* matrix-core arithmetic of the dense contractions */
 #define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
 #define VITAE_PREC_BF16 1 /* v_mfma_f32_32x32x16_bf16: bf16 operands, fp32 accumulate */
+#define VITAE_PREC_BF16X3 2 /* fp32 operands split into bf16 hi + lo while staged, hi.hi + hi.lo + lo.hi on the bf16 MFMA, fp32
+                             * accumulate: products exact to 2^-16 — the fast mode that holds the reference's fp32 losses to 1e-4 */
 
 /* GEMM epilogues */
 #define VITAE_EPI_NONE 0
@@ -96,6 +98,11 @@ int vitae_gemm_bf16(int a_kcontig, int b_kcontig, const float* A, long lda, cons
                     int epi, float* aux, long ldaux, int accumulate, int split_k, float* splitk_ws,
                     float* a_colsum_accum, void* stream);
 int vitae_gemm_bf16_pick_split_k(int M, int N, int K);
+/* Split-operand variant (what vitae_gemm and vitae_linear_{fwd,bwd_input,bwd_weight} run at prec = VITAE_PREC_BF16X3): the
+ * contract of vitae_gemm, both operands fp32. */
+int vitae_gemm_bf16x3(int a_kcontig, int b_kcontig, const float* A, long lda, const float* B, long ldb, float* C, long ldc,
+                      int M, int N, int K, const float* bias, const float* residual, long ldr, int epi, float* aux,
+                      long ldaux, int accumulate, int split_k, float* splitk_ws, void* stream);
 /* Backward of one nn.Linear in a single launch (dgrad + wgrad + bias grad), bf16 MFMA:
  * dx[M,K] (+)= epi(dy[M,N] W[N,K]) (W from its bf16 shadow), dW[N,K] (+)= dy^T x, db[N] += colsum(dy). */
 int vitae_linear_bwd_pair_bf16(const float* dy, const void* w_bf16, const float* x, float* dx, float* dw,

@@ -61,7 +61,7 @@ def gen(*shape, seed=0, scale=1.0):
 
 
 # --------------------------------------------------------------------------- GEMM
-@pytest.mark.parametrize('prec,tol', [(0, 2e-5), (1, 2e-2)])
+@pytest.mark.parametrize('prec,tol', [(0, 2e-5), (1, 2e-2), (2, 2e-5)])   # 2 = VITAE_PREC_BF16X3: split operands, fp32-grade
 @pytest.mark.parametrize('M,N,K', [(440, 2304, 768), (37, 48, 128), (868, 512, 2048), (64, 64, 32), (130, 72, 4096)])
 def test_linear_fwd_bwd(lib, C, prec, tol, M, N, K):
     x, w, b = gen(M, K, seed=1), gen(N, K, seed=2, scale=K ** -0.5), gen(N, seed=3)
@@ -224,6 +224,30 @@ def test_gemm_glds_forward_forms(lib, C, M, N, K):
     lib.vitae_gemm_glds(1, 1, x16.data_ptr(), K, w16.data_ptr(), K, None, 0, y16.data_ptr(), N, M, N, K, bd.data_ptr(), None, 0,
                         C['VITAE_EPI_GELU'], aux.data_ptr(), N, 0, 1, None, None, st())
     assert rel_err(aux, ref) < 2e-3 and rel_err(y16.float(), F.gelu(ref)) < 1e-2
+
+
+@pytest.mark.parametrize('M,N,K', [(440, 768, 3072), (3472, 2048, 512), (868, 16384, 512), (100, 72, 132)])
+def test_gemm_bf16x3_error_against_float64(lib, C, M, N, K):
+    """The split-operand mode (hi.hi + hi.lo + lo.hi on the bf16 MFMA) against the float64 product: its error sits with the
+    exact-fp32 MFMA's (a few 1e-6 of the output scale), three orders under the one-term bf16 product — in all four operand layouts
+    (the wide 64 x 128 tile at the large shapes)."""
+    assert C['VITAE_PREC_BF16X3'] == 2
+    a, b = gen(M, K, seed=11), gen(N, K, seed=12)
+    ref = a.double() @ b.double().t()
+    ws = torch.empty(1 << 22, device='cuda')
+    errs = {}
+    for prec in (0, 1, 2):
+        c = torch.empty(M, N, device='cuda')
+        lib.vitae_gemm(prec, 1, 1, dev(a).data_ptr(), K, dev(b).data_ptr(), K, c.data_ptr(), N, M, N, K, None, None, 0, 0, None, 0,
+                       0, 1, ws.data_ptr(), st())
+        errs[prec] = rel_err(c, ref)
+    assert errs[2] < 1e-5 and errs[2] < errs[1] / 100 and errs[0] < 4e-6, errs   # observed 4.5e-6 / 2.7e-3 / 2.1e-6 at K = 3072
+    at, bt = a.t().contiguous(), b.t().contiguous()
+    for akc, bkc in ((1, 0), (0, 1), (0, 0)):
+        c = torch.empty(M, N, device='cuda')
+        lib.vitae_gemm(2, akc, bkc, dev(a if akc else at).data_ptr(), K if akc else M, dev(b if bkc else bt).data_ptr(),
+                       K if bkc else N, c.data_ptr(), N, M, N, K, None, None, 0, 0, None, 0, 0, 1, ws.data_ptr(), st())
+        assert rel_err(c, ref) < 1e-5, (akc, bkc)
 
 
 def test_gemm_bf16_asymmetric(lib):

@@ -220,6 +220,9 @@ extern "C" int vitae_gemm(int prec, int a_kcontig, int b_kcontig,
                           int epi, float* aux, long ldaux, int accumulate,
                           int split_k, float* splitk_ws, void* stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return VITAE_ERR_INVALID_ARG;
+    if (prec == VITAE_PREC_BF16X3)   // split-operand bf16 MFMA (csrc/gemm_bf16.hip)
+        return vitae_gemm_bf16x3(a_kcontig, b_kcontig, A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, epi, aux, ldaux,
+                                 accumulate, split_k, splitk_ws, stream);
     if (prec != 0 && prec != 1) return VITAE_ERR_INVALID_ARG;
     if (epi != VITAE_EPI_NONE && !aux) return VITAE_ERR_INVALID_ARG;
     // 16-byte vector loads run along the contiguous dimension of each operand.

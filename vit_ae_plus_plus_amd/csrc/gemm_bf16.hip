@@ -69,11 +69,16 @@ __host__ __device__ constexpr int ld_pad(int n) { return n == 128 ? n + 16 : n +
 
 // ---------------------------------------------------------------- operand staging
 // One operand tile = ROWS rows x BK k.  Per thread NPIECE 16-byte global pieces.
-template <int ROWS, int BK, int NT, bool KC, bool BF16> struct Stage {
+// X3 (fp32 operands only): the LDS image is TWO bf16 tiles, hi = bf16(x) and lo = bf16(x - hi), ONE elements apart — the
+// split-operand form of the fp32-accurate mode (VITAE_PREC_BF16X3): x = hi + lo to 2^-17, and the k-loop computes
+// hi.hi + hi.lo + lo.hi with fp32 accumulation.
+template <int ROWS, int BK, int NT, bool KC, bool BF16, bool X3 = false> struct Stage {
+    static_assert(!(X3 && BF16), "the split form splits fp32 operands");
     static constexpr int EPP = BF16 ? 8 : 4;                       // elements per 16-byte piece
     static constexpr int NPIECE = ROWS * BK / EPP / NT;
     static constexpr int LD = KC ? BK + 8 : ld_pad(ROWS);          // LDS row stride in bf16 elements (conflict-free)
-    static constexpr int BYTES = (KC ? ROWS : BK) * LD * 2;
+    static constexpr int ONE = (KC ? ROWS : BK) * LD;              // elements of one bf16 tile image
+    static constexpr int BYTES = ONE * 2 * (X3 ? 2 : 1);
     u32x4 r[NPIECE];
     unsigned ok;   // bit j: piece j is inside the operand (others are zero-filled at store time)
 
@@ -136,6 +141,12 @@ template <int ROWS, int BK, int NT, bool KC, bool BF16> struct Stage {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (__bf16)in.f[e];
                 *reinterpret_cast<bf16x4*>(dst) = o;
+                if constexpr (X3) {
+                    bf16x4 l;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) l[e] = (__bf16)(in.f[e] - (float)o[e]);
+                    *reinterpret_cast<bf16x4*>(dst + ONE) = l;
+                }
             }
         }
     }
@@ -161,17 +172,17 @@ __device__ __forceinline__ bf16x8 frag(const __bf16* T, int row0, int kk, int la
 // Tile configurations (BM x BN x BK, threads): 64x64x256/256 (default), 64x128x128/256 (large GEMMs),
 // 32x64x256/128 (small GEMMs: twice the workgroups, 2-3 resident per CU so one's MFMA loop overlaps
 // another's load wait).  Waves form a (BM/32) x (rest) grid; wave tile 32 x (32*FN).
-template <int BM, int BN, int BK, int NT, bool A_KC, bool B_KC, bool B_BF16> struct TileCfg {
-    using SA = Stage<BM, BK, NT, A_KC, false>;
-    using SB = Stage<BN, BK, NT, B_KC, B_BF16>;
+template <int BM, int BN, int BK, int NT, bool A_KC, bool B_KC, bool B_BF16, bool X3 = false> struct TileCfg {
+    using SA = Stage<BM, BK, NT, A_KC, false, X3>;
+    using SB = Stage<BN, BK, NT, B_KC, B_BF16, X3>;
     static constexpr int SMEM = SA::BYTES + SB::BYTES;
     static constexpr int KS = NT > 256 ? NT / 256 : 1;            // wave groups splitting each phase's k range
     static constexpr int WM = BM / 32, WN = (NT / 64 / KS) / WM, FN = BN / WN / 32;
 };
 
-template <int BM, int BN, int BK, int NT, bool A_KC, bool B_KC, bool B_BF16>
+template <int BM, int BN, int BK, int NT, bool A_KC, bool B_KC, bool B_BF16, bool X3 = false>
 __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, const int zid, unsigned char* smem) {
-    using CFG = TileCfg<BM, BN, BK, NT, A_KC, B_KC, B_BF16>;
+    using CFG = TileCfg<BM, BN, BK, NT, A_KC, B_KC, B_BF16, X3>;
     using SA = typename CFG::SA;
     using SB = typename CFG::SB;
     constexpr int FN = CFG::FN, WN = CFG::WN, KS = CFG::KS;
@@ -221,9 +232,16 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, cons
         for (int kq = 0; kq < BK / 16 / KS; ++kq) {
             const int kk = kh * (BK / 16 / KS) + kq;
             const bf16x8 fa = frag<A_KC, SA::LD>(at, wm * 32, kk, lane);
+            bf16x8 fal;
+            if constexpr (X3) fal = frag<A_KC, SA::LD>(at + SA::ONE, wm * 32, kk, lane);
 #pragma unroll
             for (int f = 0; f < FN; ++f) {
                 const bf16x8 fb = frag<B_KC, SB::LD>(bt, wn * (32 * FN) + f * 32, kk, lane);
+                if constexpr (X3) {   // the two cross terms first: they are 2^-8 of the main term
+                    const bf16x8 fbl = frag<B_KC, SB::LD>(bt + SB::ONE, wn * (32 * FN) + f * 32, kk, lane);
+                    acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fbl, acc[f], 0, 0, 0);
+                    acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal, fb, acc[f], 0, 0, 0);
+                }
                 acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[f], 0, 0, 0);
             }
         }
@@ -262,10 +280,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, cons
     }
 }
 
-template <int BM, int BN, int BK, int NT, bool A_KC, bool B_KC, bool B_BF16>
+template <int BM, int BN, int BK, int NT, bool A_KC, bool B_KC, bool B_BF16, bool X3 = false>
 __global__ __launch_bounds__(NT) void gemm_bf16_kernel(const GemmArgs p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[TileCfg<BM, BN, BK, NT, A_KC, B_KC, B_BF16>::SMEM];
-    gemm_body<BM, BN, BK, NT, A_KC, B_KC, B_BF16>(p, blockIdx.x, blockIdx.z, smem);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[TileCfg<BM, BN, BK, NT, A_KC, B_KC, B_BF16, X3>::SMEM];
+    gemm_body<BM, BN, BK, NT, A_KC, B_KC, B_BF16, X3>(p, blockIdx.x, blockIdx.z, smem);
 }
 
 // One launch, two independent GEMMs that consume the same dy: the dgrad (dy @ W, bf16 weight shadow read
@@ -289,13 +307,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const GemmArgs 
     }
 }
 
-template <int BM, int BN, int BK, int NT, bool B_BF16>
+template <int BM, int BN, int BK, int NT, bool B_BF16, bool X3 = false>
 void launch(const GemmArgs& p, bool a_kc, bool b_kc, dim3 grid, hipStream_t st) {
     dim3 block(NT);
-    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, BK, NT, true, true, B_BF16>), grid, block, 0, st, p);
-    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, BK, NT, true, false, B_BF16>), grid, block, 0, st, p);
-    else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, BK, NT, false, true, B_BF16>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, BK, NT, false, false, B_BF16>), grid, block, 0, st, p);
+    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, BK, NT, true, true, B_BF16, X3>), grid, block, 0, st, p);
+    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, BK, NT, true, false, B_BF16, X3>), grid, block, 0, st, p);
+    else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, BK, NT, false, true, B_BF16, X3>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, BK, NT, false, false, B_BF16, X3>), grid, block, 0, st, p);
 }
 
 }  // namespace
@@ -363,6 +381,50 @@ extern "C" int vitae_gemm_bf16(int a_kcontig, int b_kcontig, const float* A, lon
     else if (c == 3) { if (b_is_bf16) launch<64, 64, 256, 512, true>(p, akc, bkc, grid, st); else launch<64, 64, 256, 512, false>(p, akc, bkc, grid, st); }
     else if (c == 1) { if (b_is_bf16) launch<64, 64, 256, 256, true>(p, akc, bkc, grid, st); else launch<64, 64, 256, 256, false>(p, akc, bkc, grid, st); }
     else { if (b_is_bf16) launch<32, 64, 256, 128, true>(p, akc, bkc, grid, st); else launch<32, 64, 256, 128, false>(p, akc, bkc, grid, st); }
+    if (split_k > 1) {
+        const long total = (long)M * N;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_bf16_kernel, dim3(blocks), dim3(256), 0, st, p);
+    }
+    return vitae_launch_status();
+}
+
+// fp32-accurate mode (VITAE_PREC_BF16X3; vitae_gemm / vitae_linear_* with prec = 2 land here): both operands fp32 in HBM, split
+// into bf16 hi + lo while they are staged, three MFMAs per fragment pair (hi.hi + hi.lo + lo.hi; the dropped lo.lo term is
+// 2^-16 of a product).  The reference computes this path in fp32 (autocast off, utils/train_one_epoch.py:50): this mode keeps
+// its losses within the 1e-4 bound at 8/3 of the exact-fp32 MFMA rate (v_mfma_f32_32x32x2_f32: 157 TFLOP/s).
+// Tiles: 64 x 64 x 128 (two tile images per operand: 70 KB, two workgroups per CU) or 64 x 128 x 64 for GEMMs with many tiles.
+extern "C" int vitae_gemm_bf16x3(int a_kcontig, int b_kcontig, const float* A, long lda, const float* B, long ldb,
+                                 float* C, long ldc, int M, int N, int K, const float* bias, const float* residual, long ldr,
+                                 int epi, float* aux, long ldaux, int accumulate, int split_k, float* splitk_ws, void* stream) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return VITAE_ERR_INVALID_ARG;
+    if (epi != VITAE_EPI_NONE && !aux) return VITAE_ERR_INVALID_ARG;
+    const int a_vec = a_kcontig ? K : M, b_vec = b_kcontig ? K : N;
+    if ((a_vec & 3) || (lda & 3) || (b_vec & 3) || (ldb & 3)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    if (split_k < 1) split_k = 1;
+    if (epi == VITAE_EPI_GELU) split_k = 1;
+    static const int big = env_int("VITAE_X3_BN128_MIN_TILES", 512), wide_bk = env_int("VITAE_X3_BN128_BK", 64);
+    const bool wide = N >= 128 && (long)cdiv(M, 64) * cdiv(N, 128) >= big;
+    const int bn = wide ? 128 : 64, bk = wide ? wide_bk : 128;   // (64 x 64 x 256 — 135 KB, one workgroup per CU — measured no faster)
+    GemmArgs p;
+    p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc;
+    p.M = M; p.N = N; p.K = K;
+    int kps = cdiv(cdiv(K, split_k), bk) * bk;
+    split_k = cdiv(K, kps);
+    if (split_k > 1 && !splitk_ws) return VITAE_ERR_INVALID_ARG;
+    p.k_per_split = kps; p.splits = split_k;
+    p.bias = bias; p.residual = residual; p.ldr = ldr; p.aux = aux; p.ldaux = ldaux;
+    p.epi = epi; p.accumulate = accumulate; p.ws = splitk_ws; p.colsum = nullptr;
+    p.tiles_m = cdiv(M, 64); p.tiles_n = cdiv(N, bn);
+    p.n_per_xcd = cdiv(p.tiles_n, 8);
+    dim3 grid(8 * p.n_per_xcd * p.tiles_m, 1, split_k);
+    hipStream_t st = (hipStream_t)stream;
+    const bool akc = a_kcontig != 0, bkc = b_kcontig != 0;
+    if (!wide) launch<64, 64, 128, 256, false, true>(p, akc, bkc, grid, st);
+    else if (bk == 64) launch<64, 128, 64, 256, false, true>(p, akc, bkc, grid, st);
+    else launch<64, 128, 128, 256, false, true>(p, akc, bkc, grid, st);
     if (split_k > 1) {
         const long total = (long)M * N;
         int blocks = (int)((total + 255) / 256);

@@ -19,7 +19,7 @@ import torch
 
 from ._abi import CONSTS as _C, VitaeError, lib
 
-PREC = {'fp32': _C['VITAE_PREC_F32'], 'bf16': _C['VITAE_PREC_BF16']}
+PREC = {'fp32': _C['VITAE_PREC_F32'], 'bf16': _C['VITAE_PREC_BF16'], 'fp32x3': _C['VITAE_PREC_BF16X3']}
 EPI_NONE, EPI_GELU = _C['VITAE_EPI_NONE'], _C['VITAE_EPI_GELU']
 
 

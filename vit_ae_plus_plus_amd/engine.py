@@ -34,7 +34,7 @@ _C = CONSTS
 EPI_NONE, EPI_GELU, EPI_DGELU, EPI_RELU = (_C['VITAE_EPI_NONE'], _C['VITAE_EPI_GELU'], _C['VITAE_EPI_DGELU'],
                                            _C['VITAE_EPI_RELU_MASK'])
 HP = {k[len('VITAE_HP_'):]: v for k, v in _C.items() if k.startswith('VITAE_HP_')}
-PREC = {'fp32': _C['VITAE_PREC_F32'], 'bf16': _C['VITAE_PREC_BF16']}
+PREC = {'fp32': _C['VITAE_PREC_F32'], 'bf16': _C['VITAE_PREC_BF16'], 'fp32x3': _C['VITAE_PREC_BF16X3']}
 
 
 def _triple(v):
@@ -429,7 +429,7 @@ class HipMAEEngine:
         key = (M, N, K)
         s = self._split_cache.get(key)
         if s is None:
-            s = (lib.vitae_gemm_bf16_pick_split_k if self.prec == PREC['bf16'] else lib.vitae_gemm_pick_split_k)(M, N, K)
+            s = (lib.vitae_gemm_pick_split_k if self.prec == PREC['fp32'] else lib.vitae_gemm_bf16_pick_split_k)(M, N, K)
             while s > 1 and s * M * N > self.ws.numel():
                 s -= 1
             self._split_cache[key] = s

@@ -543,7 +543,10 @@ class MaskedAutoencoderViT(nn.Module):
         return self._engine
 
     def set_precision(self, precision: str):
-        """'fp32' (exact-fp32 MFMA, the reference's precision) or 'bf16' (bf16 MFMA, fp32 accumulate)."""
+        """'fp32' (exact-fp32 MFMA, the reference's precision), 'fp32x3' (fp32 operands split into bf16 hi + lo inside the GEMMs,
+        three bf16 MFMAs per product: fp32-grade results at several times the rate) or 'bf16' (bf16 MFMA, fp32 accumulate)."""
+        if precision not in ('fp32', 'fp32x3', 'bf16'):
+            raise ValueError(f"precision must be 'fp32', 'fp32x3' or 'bf16', not {precision!r}")
         self._precision = precision
         self._engine = None
 
