@@ -23,9 +23,10 @@
 
 namespace {
 
-constexpr int BM = 64, BN = 64, BK = 32;
+constexpr int BM = 64, BN = 64, BK = 32;   // (BK = 64 — 32 MFMAs per barrier, 70 KB of LDS — measured SLOWER in the step: fp32 mode 11.2 -> 12.1 ms)
+constexpr int NPC = BK / 16;               // 16-byte pieces per thread and operand tile
 constexpr int SM32 = 68;   // fp32 LDS row stride (floats), k-major tile [BK][SM32]
-constexpr int SK16 = 40;   // bf16 LDS row stride (elements), row-major tile [64][SK16]
+constexpr int SK16 = BK + 8;   // bf16 LDS row stride (elements), row-major tile [64][SK16]
 
 struct GemmArgs {
     const float* A; long lda;
@@ -59,13 +60,13 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, float v, int m
 
 template <bool KC>
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, long ld, int rows, int r0,
-                                          int k0, int kend, f32x4 (&v)[2]) {
+                                          int k0, int kend, f32x4 (&v)[NPC]) {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NPC; ++j) {
         const int i = tid + 256 * j;
         int row, k;
-        if (KC) { row = i >> 3; k = (i & 7) * 4; } else { k = i >> 4; row = (i & 15) * 4; }
+        if (KC) { row = i / (BK / 4); k = (i % (BK / 4)) * 4; } else { k = i >> 4; row = (i & 15) * 4; }
         const int gr = r0 + row, gk = k0 + k;
         f32x4 x = {0.f, 0.f, 0.f, 0.f};
         if (gr < rows && gk < kend) {
@@ -77,13 +78,13 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, long ld, 
 }
 
 template <int PREC, bool KC>
-__device__ __forceinline__ void store_tile(void* lds, const f32x4 (&v)[2]) {
+__device__ __forceinline__ void store_tile(void* lds, const f32x4 (&v)[NPC]) {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NPC; ++j) {
         const int i = tid + 256 * j;
         int row, k;
-        if (KC) { row = i >> 3; k = (i & 7) * 4; } else { k = i >> 4; row = (i & 15) * 4; }
+        if (KC) { row = i / (BK / 4); k = (i % (BK / 4)) * 4; } else { k = i >> 4; row = (i & 15) * 4; }
         if (PREC == 0) {
             float* s = reinterpret_cast<float*>(lds);
             if (KC) {
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
-    f32x4 ra[2], rb[2];
+    f32x4 ra[NPC], rb[NPC];
     if (nk > 0) {
         load_tile<A_KC>(p.A, p.lda, p.M, m0, kbeg, kend, ra);
         load_tile<B_KC>(p.B, p.ldb, p.N, n0, kbeg, kend, rb);
