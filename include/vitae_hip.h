@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITAE_ABI_VERSION 35
+#define VITAE_ABI_VERSION 36
 
 /* matrix-core arithmetic of the dense contractions */
 #define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
@@ -103,6 +103,7 @@ int vitae_gemm_bf16_pick_split_k(int M, int N, int K);
 int vitae_gemm_bf16x3(int a_kcontig, int b_kcontig, const float* A, long lda, const float* B, long ldb, float* C, long ldc,
                       int M, int N, int K, const float* bias, const float* residual, long ldr, int epi, float* aux,
                       long ldaux, int accumulate, int split_k, float* splitk_ws, void* stream);
+int vitae_gemm_bf16x3_pick_split_k(int M, int N, int K);
 /* Backward of one nn.Linear in a single launch (dgrad + wgrad + bias grad), bf16 MFMA:
  * dx[M,K] (+)= epi(dy[M,N] W[N,K]) (W from its bf16 shadow), dW[N,K] (+)= dy^T x, db[N] += colsum(dy). */
 int vitae_linear_bwd_pair_bf16(const float* dy, const void* w_bf16, const float* x, float* dx, float* dw,

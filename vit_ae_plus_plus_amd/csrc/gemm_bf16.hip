@@ -390,6 +390,19 @@ extern "C" int vitae_gemm_bf16(int a_kcontig, int b_kcontig, const float* A, lon
     return vitae_launch_status();
 }
 
+// Split of the reduction for the split-operand kernels below: their k-loop is bound by the latency of each 128-deep phase's fp32
+// loads (one phase in flight per workgroup), so a GEMM with fewer workgroups than CUs is cut until it has them (swept in the step:
+// 256 workgroups / 256-deep splits 8.79 ms; 512: 9.27; 768: 9.48; never: 10.38; the bf16 rule of this file: 9.13).
+extern "C" int vitae_gemm_bf16x3_pick_split_k(int M, int N, int K) {
+    static const int want = env_int("VITAE_X3_SPLIT_WGS", 256), min_k = env_int("VITAE_X3_SPLIT_MIN_K", 256);
+    const long tiles = (long)cdiv(M, 64) * cdiv(N, 64);
+    if (tiles >= want || K < 2 * min_k) return 1;
+    long s = (want + tiles - 1) / tiles;
+    if (s > K / min_k) s = K / min_k;
+    if (s > 16) s = 16;
+    return s < 1 ? 1 : (int)s;
+}
+
 // fp32-accurate mode (VITAE_PREC_BF16X3; vitae_gemm / vitae_linear_* with prec = 2 land here): both operands fp32 in HBM, split
 // into bf16 hi + lo while they are staged, three MFMAs per fragment pair (hi.hi + hi.lo + lo.hi; the dropped lo.lo term is
 // 2^-16 of a product).  The reference computes this path in fp32 (autocast off, utils/train_one_epoch.py:50): this mode keeps

@@ -429,7 +429,8 @@ class HipMAEEngine:
         key = (M, N, K)
         s = self._split_cache.get(key)
         if s is None:
-            s = (lib.vitae_gemm_pick_split_k if self.prec == PREC['fp32'] else lib.vitae_gemm_bf16_pick_split_k)(M, N, K)
+            s = (lib.vitae_gemm_pick_split_k if self.prec == PREC['fp32'] else lib.vitae_gemm_bf16x3_pick_split_k if self.prec == PREC['fp32x3']
+                 else lib.vitae_gemm_bf16_pick_split_k)(M, N, K)
             while s > 1 and s * M * N > self.ws.numel():
                 s -= 1
             self._split_cache[key] = s
