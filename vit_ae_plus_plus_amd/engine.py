@@ -177,6 +177,7 @@ class HipMAEEngine:
         self.wside = torch.cuda.Stream(device=device)  # weight-gradient GEMMs run beside the dgrad chain
         self.pside = torch.cuda.Stream(device=device)  # predictor branch (fwd, cosine loss, bwd) beside the decoder
         self.ws_side = torch.empty(1 << 22, **f32)     # its own split-K scratch
+        self.ws_wside = torch.empty(1 << 23, **f32)    # ... and the wgrad side stream's (fp32 / fp32x3 schedules: split weight gradients)
         self.overlap_predictor = os.environ.get('VITAE_PREDICTOR_SIDE', '1') != '0'
         self.oside = torch.cuda.Stream(device=device)  # per-bucket grad-norm + AdamW beside the rest of the backward
         self.overlap_optimizer = os.environ.get('VITAE_OPT_IN_BACKWARD', '1') != '0'
@@ -489,7 +490,12 @@ class HipMAEEngine:
         backward phase.  ``tag`` names the dy buffer so that ``_wg_fence(tag)`` can be placed in front of the
         kernel that next overwrites it."""
         s = self._split(N, K, M)
-        side = tag is not None and self.overlap_wgrad and s == 1 and self.gemm_timer is None
+        side = tag is not None and self.overlap_wgrad and self.gemm_timer is None
+        ws = self.ws
+        if side and s > 1:      # a split reduction beside the chain needs scratch of its own (the chain's GEMMs use self.ws)
+            ws = self.ws_wside
+            while s > 1 and s * N * K > ws.numel():
+                s -= 1
         if side:
             main = torch.cuda.current_stream(self.device)
             self.wside.wait_stream(main)
@@ -499,10 +505,10 @@ class HipMAEEngine:
         t = self._timed(2.0 * M * N * K)
         if self.prec == PREC['bf16']:
             lib.vitae_gemm_bf16(0, 0, _ptr(dy), N, _ptr(x), K, 0, _ptr(dw), K, N, K, M, None, None, 0, EPI_NONE, None, 0,
-                                int(self._accum), s, self.ws.data_ptr(), None, stream)
+                                int(self._accum), s, ws.data_ptr(), None, stream)
         else:
             lib.vitae_linear_bwd_weight(self.prec, _ptr(dy), _ptr(x), _ptr(dw), M, N, K, int(self._accum), s,
-                                        self.ws.data_ptr(), stream)
+                                        ws.data_ptr(), stream)
         if t is not None:
             t.record()
         if db is not None:
