@@ -240,6 +240,12 @@ int launch_bwd(const float* qkv, const float* o, const float* d_o, const float* 
 //     the lower and crow(r, 1) on the upper half wave), so the A operand is a plain row read of the staged tile.
 constexpr int FM_TILE = 32;
 
+// exp on the transcendental unit (v_exp_f32 of x * log2 e; relative error <= 2e-6 over the arguments a softmax produces): ocml's expf is
+// ~25 VALU instructions per value, and 16 of them per lane and 32-key tile cost as much as the tile's 32 MFMAs (N = 1729 forward
+// 358 -> 299 us).  Measured and NOT kept: workgroups of two waves for short sequences (N = 217: 18.9 vs 18.8 us) and the whole other
+// axis resident in LDS without per-tile barriers (17.5 vs 18.9 us) — at N = 217 a workgroup is bound by its own 7 x (32 MFMAs + softmax).
+__device__ __forceinline__ float fm_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+
 __device__ __forceinline__ int fm_crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
 // 32 rows x HD floats (global row stride ld, rows >= nrows are zero) -> registers -> LDS [32][HD + 4]
@@ -354,7 +360,7 @@ __global__ __launch_bounds__(256) void attn_fwd_f32mfma_kernel(const float* __re
         }
         cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
         const float mn = fmaxf(m, cmax);
-        const float corr = expf(m - mn);
+        const float corr = fm_exp(m - mn);
         m = mn;
         l *= corr;
 #pragma unroll
@@ -363,7 +369,7 @@ __global__ __launch_bounds__(256) void attn_fwd_f32mfma_kernel(const float* __re
             for (int r = 0; r < 16; ++r) oacc[t][r] *= corr;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s[r] = expf(s[r] - mn);
+            s[r] = fm_exp(s[r] - mn);
             l += s[r];
         }
         fm_accumulate<HD>(oacc, Vs, s, l31, hi);
@@ -422,7 +428,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_f32mfma_kernel(const float* _
         const f32x16 dp = fm_dot_rows<HD>(Vs, gf, l31, hi);   // dp[r] = dO_i . v_(c0 + crow(r, hi))
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float p = c0 + fm_crow(r, hi) < N ? expf(s[r] - L) : 0.f;
+            const float p = c0 + fm_crow(r, hi) < N ? fm_exp(s[r] - L) : 0.f;
             s[r] = p * (dp[r] - dl);
         }
         fm_accumulate<HD>(dq, Ks, s, l31, hi);
@@ -490,7 +496,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_f32mfma_kernel(const float* 
             const f32x4 d4 = *reinterpret_cast<const f32x4*>(Ds + 8 * g + 4 * hi);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float p = expf(s[4 * g + e] - l4[e]);
+                const float p = fm_exp(s[4 * g + e] - l4[e]);
                 s[4 * g + e] = p;
                 dp[4 * g + e] = p * (dp[4 * g + e] - d4[e]);
             }
