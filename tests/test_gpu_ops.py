@@ -250,6 +250,18 @@ def test_gemm_bf16x3_error_against_float64(lib, C, M, N, K):
         assert rel_err(c, ref) < 1e-5, (akc, bkc)
 
 
+@pytest.mark.parametrize('M,N,ld', [(440, 2304, 2304), (868, 16384, 16384), (6944, 512, 512), (33, 48, 64), (130, 70, 70), (5, 4, 4)])
+def test_colsum_accum(lib, M, N, ld):
+    """Bias gradients of the fp32 schedules (out[n] += sum_m dy[m, n]): the 16-byte form and the scalar fallback (N % 4 != 0), a row
+    stride wider than the row, accumulation into what is already there."""
+    dy = gen(M, ld, seed=21)
+    base = gen(N, seed=22)
+    out = dev(base)
+    lib.vitae_colsum_accum(dev(dy).data_ptr(), ld, out.data_ptr(), M, N, st())
+    want = base.double() + dy[:, :N].double().sum(0)
+    assert float((out.double().cpu() - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))
+
+
 def test_gemm_bf16_asymmetric(lib):
     a = torch.eye(64)
     b = torch.arange(64 * 64, dtype=torch.float32).reshape(64, 64) / 128.0
