@@ -110,7 +110,7 @@ def test_hip_features_micro(gold, gp):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('precision,tol', [('fp32', 1e-4), ('bf16', 3e-2)])
+@pytest.mark.parametrize('precision,tol', [('fp32', 1e-4), ('fp32x3', 1e-4), ('bf16', 3e-2)])   # fp32x3: split-operand GEMMs, the fp32 bound
 def test_hip_features_vitb(gold, precision, tol):
     """ViT-B/16 on 96^3 x 4ch (N = 217 tokens): fp32 mode inside the 1e-4 of the north star, bf16 (the reference runs
     this call under autocast) to bf16 round-off."""

@@ -183,7 +183,8 @@ class VisionTransformer3D(nn.Module):
     token/head, ``representation_size`` pre-logits, non-zero dropout / stochastic depth, and back-propagation
     (fine-tuning) — the constructor or the call says so instead of computing something else.
 
-    ``precision``: 'fp32' (exact-fp32 MFMA, matches the CPU reference to ~1e-6) or 'bf16' (bf16 MFMA operands with
+    ``precision``: 'fp32' (exact-fp32 MFMA, matches the CPU reference to ~1e-6), 'fp32x3' (fp32 operands split into bf16 hi + lo
+    inside the GEMMs: the same results to a few 1e-6) or 'bf16' (bf16 MFMA operands with
     fp32 accumulation — the counterpart of the ``torch.cuda.amp.autocast()`` the reference wraps around
     forward_features, utils/feature_extraction.py:35-36)."""
 
