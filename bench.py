@@ -229,11 +229,13 @@ def roofline_block(args, recs, overhead_ms, ms_step, world):
     d_ms, d_fl, d_n, d_raw = fam[dom]
     ach = d_fl / (d_ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS[args.precision]
-    traffic, tnote = None, None   # PMC counters cannot be read in-process: last committed rocprofv3 --pmc result
+    traffic, tnote, rp_us = None, None, None   # PMC counters cannot be read in-process: last committed rocprofv3 --pmc result
     for name in ('round3_gemm_traffic.json', 'round2_gemm_traffic.json', 'round1_gemm_traffic.json'):
         tfile = os.path.join(ROOT, 'profiles', name)
         if args.precision == 'bf16' and args.batch == 4 and os.path.exists(tfile):
-            traffic = json.load(open(tfile)).get('bytes_per_launch', {}).get(dom)
+            tj = json.load(open(tfile))
+            traffic = tj.get('bytes_per_launch', {}).get(dom)
+            rp_us = tj.get('rocprof_avg_launch_us', {}).get(dom)    # the committed rocprofv3 mean of the same kernel (graph replays)
             tnote = f'HBM-side bytes per launch of that kernel (2*FETCH_SIZE + WRITE_SIZE, profiles/{name})'
             if traffic is not None:
                 break
@@ -244,6 +246,10 @@ def roofline_block(args, recs, overhead_ms, ms_step, world):
             'frac': round(ach / peak, 4), 'traffic': traffic, 'traffic_unit': tnote,
             'launches_per_step': d_n / n, 'gflop_per_launch': round(d_fl / d_n / 1e9, 3), 'avg_launch_us': round(d_ms * 1e3 / d_n, 2),
             'avg_launch_us_events_raw': round(d_raw * 1e3 / d_n, 2), 'event_pair_overhead_us': round(overhead_ms * 1e3, 2),
+            # the same kernel's mean in the committed rocprofv3 profile and the fraction it gives (graph replays: launches beside an
+            # AdamW bucket run slower than in the instrumented eager steps above)
+            'avg_launch_us_rocprof_committed': rp_us,
+            'frac_at_rocprof_duration': round(d_fl / d_n / (rp_us * 1e-6) / 1e12 / peak, 4) if rp_us else None,
             'gemm_family': {'launches_per_step': sum(d[2] for d in fam.values()) / n, 'gflop_per_step': round(exe_gflop, 2),
                             'ms_per_step': round(tot_ms / n, 3), 'tflops': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
                             'by_kernel_ms_per_step': {k: round(v[0] / n, 3) for k, v in fam.items()}},
