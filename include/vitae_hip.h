@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITAE_ABI_VERSION 36
+#define VITAE_ABI_VERSION 37
 
 /* matrix-core arithmetic of the dense contractions */
 #define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
@@ -125,11 +125,10 @@ int vitae_gemm_glds_pick_split_k(int M, int N, int K);
  * vitae_linear_bwd_pair_glds (whose halves then go out as two launches).  mode -1 (default): picked per problem by the cost
  * model together with the split (vitae_gemm_glds_pick_split_k returns the split of the plan: pass it on unchanged); -2: never;
  * 0 / 3: that tile for every eligible problem (tests, tools).  vitae_gemm_glds_bt_choice = the tile a problem would get (-1 = none).
- * vitae_gemm_glds_set_ws_capacity: floats the split-K workspace handed to these calls holds (default 2^23) — plans that need more
- * are not made. */
+ * vitae_linear_bwd_pair_glds / vitae_wgrad_group_bt plan their own splits: they are told what the workspace holds per call
+ * (splitk_ws_floats) and never make a plan that needs more. */
 int vitae_gemm_glds_set_bt_tile(int mode);
 int vitae_gemm_glds_bt_choice(int a_kcontig, int b_kcontig, int M, int N, int K);
-int vitae_gemm_glds_set_ws_capacity(long floats);
 /* profiling hook (tools/gemm_phase_probe.py): 8 long long per workgroup; NULL = off */
 int vitae_gemm_glds_set_debug(void* buf);
 /* Gradient norm without a pass over the gradients: while `slot` is set (NULL clears), every weight-gradient launch
@@ -148,16 +147,19 @@ int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, const void* x1
                                gradient of this Linear (one extra MFMA against ones in the wgrad workgroups when both halves use 64x64
                                tiles, a separate bf16 column-sum launch otherwise) */,
                                int dx_accumulate /* dx += instead of = (fp32 dx only) */, int dw_accumulate, int split_k,
-                               float* splitk_ws, void* stream);
+                               float* splitk_ws, long splitk_ws_floats /* floats splitk_ws holds (first VITAE_GLDS_TICKETS zero):
+                               the planner of either half never exceeds it; >= vitae_gemm_glds_ws_floats(M, K, split_k) */,
+                               void* stream);
 /* (dw == NULL: the input gradient only — the weight gradient is deferred to vitae_wgrad_group_bt.)
  * Weight gradients of up to four Linears with the same token count in ONE launch of 128x128 tiles: for i < n,
  * dw[i][N[i], K[i]] (+)= dy16[i][Mpad, N[i]]^T x16[i][Mpad, K[i]] (rows M..Mpad-1 of every operand zero), optional bf16 copies
  * dw16[i] (NULL array or entries), optional dy_colsum[i][N[i]] += column sums of dy16[i] (bias gradients).  The pointer arrays
  * and N / K live on the HOST.  Together the problems of a transformer block have enough tiles that the reduction needs no
- * split (or two) where each alone wanted 3-8; splitk_ws as for vitae_gemm_glds (capacity: vitae_gemm_glds_set_ws_capacity). */
+ * split (or two) where each alone wanted 3-8; splitk_ws as for vitae_gemm_glds, holding splitk_ws_floats floats (the split is
+ * shrunk to fit). */
 int vitae_wgrad_group_bt(int n, const void* const* dy16, const void* const* x16, float* const* dw, void* const* dw16,
                          float* const* dy_colsum, const int* N, const int* K, int M, int Mpad, int dw_accumulate,
-                         float* splitk_ws, void* stream);
+                         float* splitk_ws, long splitk_ws_floats, void* stream);
 /* split of the dgrad reduction for the call above (1 = none); workspace as for vitae_gemm_glds with (M, K) */
 int vitae_linear_bwd_pair_pick_split_k(int M, int Mpad, int N, int K);
 /* dst_bf16[i] = bf16(src[i]) (round to nearest even) */

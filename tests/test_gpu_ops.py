@@ -184,7 +184,7 @@ def test_linear_bwd_pair_glds(lib, C, M, N, K):
     split = lib.vitae_linear_bwd_pair_pick_split_k(M, Mp, N, K)
     ws = torch.zeros(max(1, lib.vitae_gemm_glds_ws_floats(M, K, max(split, 3))), device='cuda')
     lib.vitae_linear_bwd_pair_glds(dy16.data_ptr(), w16.data_ptr(), x16.data_ptr(), dx.data_ptr(), dx16.data_ptr(), dw.data_ptr(), dw16.data_ptr(),
-                                   M, Mp, N, K, C['VITAE_EPI_DGELU'], hd_.data_ptr(), cs.data_ptr(), dycs.data_ptr(), 0, 0, split, ws.data_ptr(), st())
+                                   M, Mp, N, K, C['VITAE_EPI_DGELU'], hd_.data_ptr(), cs.data_ptr(), dycs.data_ptr(), 0, 0, split, ws.data_ptr(), ws.numel(), st())
     dyr, wr, xr = dy16[:M].float().cpu(), w16.float().cpu(), x16[:M].float().cpu()
     hh = h.clone().requires_grad_(True)
     F.gelu(hh).backward(dyr @ wr)
@@ -195,15 +195,15 @@ def test_linear_bwd_pair_glds(lib, C, M, N, K):
     assert int(ws[:C['VITAE_GLDS_TICKETS']].abs().sum()) == 0      # tickets handed back
     # forced 3-way split of the dgrad reduction: same numbers as the unsplit launch up to fp32 summation order
     lib.vitae_linear_bwd_pair_glds(dy16.data_ptr(), w16.data_ptr(), x16.data_ptr(), dx.data_ptr(), None, dw.data_ptr(), None,
-                                   M, Mp, N, K, 0, None, None, None, 0, 1, 3 if N >= 192 else 1, ws.data_ptr(), st())
+                                   M, Mp, N, K, 0, None, None, None, 0, 1, 3 if N >= 192 else 1, ws.data_ptr(), ws.numel(), st())
     assert rel_err(dx, dyr @ wr) < 2e-3 and rel_err(dw, 2 * (dyr.t() @ xr)) < 2e-3
     d1 = dx.clone()
     lib.vitae_linear_bwd_pair_glds(dy16.data_ptr(), w16.data_ptr(), x16.data_ptr(), dx.data_ptr(), None, dw.data_ptr(), None,
-                                   M, Mp, N, K, 0, None, None, None, 0, 0, 3 if N >= 192 else 1, ws.data_ptr(), st())
+                                   M, Mp, N, K, 0, None, None, None, 0, 0, 3 if N >= 192 else 1, ws.data_ptr(), ws.numel(), st())
     assert torch.equal(dx, d1)                                      # split order is fixed -> bitwise reproducible
     # dx_accumulate: dx += dy16 @ W16 (decoder_embed adds into the predictor's latent gradient)
     lib.vitae_linear_bwd_pair_glds(dy16.data_ptr(), w16.data_ptr(), x16.data_ptr(), dx.data_ptr(), None, dw.data_ptr(), None,
-                                   M, Mp, N, K, 0, None, None, None, 1, 0, split, ws.data_ptr(), st())
+                                   M, Mp, N, K, 0, None, None, None, 1, 0, split, ws.data_ptr(), ws.numel(), st())
     assert rel_err(dx, 2 * (dyr @ wr)) < 2e-3 and rel_err(dw, dyr.t() @ xr) < 2e-3
 
 
@@ -793,7 +793,7 @@ def test_gemm_bf16_saved_preactivation(lib, C, M, N, K):
     ws = torch.zeros(max(1, lib.vitae_gemm_glds_ws_floats(M, N, max(sp, 1))), device='cuda')
     lib.vitae_linear_bwd_pair_glds(dy16.data_ptr(), dev(_bf(w2)).data_ptr(), y16.data_ptr(), None, dh16.data_ptr(), dw.data_ptr(), None,
                                    M, Mp, D2, N, C['VITAE_EPI_DGELU'] | C['VITAE_EPI_AUX_BF16'], aux16.data_ptr(), None, None, 0, 0, sp,
-                                   ws.data_ptr(), st())
+                                   ws.data_ptr(), ws.numel(), st())
     p = aux16.float().cpu().requires_grad_(True)
     F.gelu(p).backward(dy @ w2)
     assert rel_err(dh16[:M].float(), p.grad) < 2e-2
@@ -806,7 +806,6 @@ def test_gemm_bf16_saved_preactivation(lib, C, M, N, K):
 def bt_mode(lib):
     yield lib.vitae_gemm_glds_set_bt_tile
     lib.vitae_gemm_glds_set_bt_tile(-1)
-    lib.vitae_gemm_glds_set_ws_capacity(0)
 
 
 def _bt_operands(form, M, N, K, seed=0):
@@ -919,7 +918,6 @@ def test_linear_bwd_pair_on_big_tiles(lib, C, bt_mode, tile, M, N, K):
     dy16 = torch.zeros(Mp, N, dtype=torch.bfloat16, device='cuda'); dy16[:M] = dy.cuda().to(torch.bfloat16)
     w16, hd_ = w.cuda().to(torch.bfloat16), dev(h)
     ws = torch.zeros(1 << 24, device='cuda')
-    lib.vitae_gemm_glds_set_ws_capacity(ws.numel())
     outs = {}
     for mode in (-2, tile):
         bt_mode(mode)
@@ -928,7 +926,7 @@ def test_linear_bwd_pair_on_big_tiles(lib, C, bt_mode, tile, M, N, K):
         cs, dycs = torch.zeros(K, device='cuda'), torch.zeros(N, device='cuda')
         split = lib.vitae_linear_bwd_pair_pick_split_k(M, Mp, N, K)
         lib.vitae_linear_bwd_pair_glds(dy16.data_ptr(), w16.data_ptr(), x16.data_ptr(), dx.data_ptr(), dx16.data_ptr(), dw.data_ptr(), dw16.data_ptr(),
-                                       M, Mp, N, K, C['VITAE_EPI_DGELU'], hd_.data_ptr(), cs.data_ptr(), dycs.data_ptr(), 0, 0, split, ws.data_ptr(), st())
+                                       M, Mp, N, K, C['VITAE_EPI_DGELU'], hd_.data_ptr(), cs.data_ptr(), dycs.data_ptr(), 0, 0, split, ws.data_ptr(), ws.numel(), st())
         assert torch.equal(dx16, dx.to(torch.bfloat16)) and torch.equal(dw16, dw.to(torch.bfloat16))
         assert int(ws[:C['VITAE_GLDS_TICKETS']].abs().sum()) == 0
         outs[mode] = (dx, dw, cs, dycs)
@@ -959,14 +957,13 @@ def test_wgrad_group_bt(lib, M, dims):
     d16 = [torch.empty(N, K, dtype=torch.bfloat16, device='cuda') for N, K in dims]
     dbs = [torch.zeros(N, device='cuda') for N, K in dims]
     ws = torch.zeros(1 << 24, device='cuda')
-    lib.vitae_gemm_glds_set_ws_capacity(ws.numel())
     arr = lambda ts: np.array([t.data_ptr() for t in ts], dtype=np.uint64)
     a_dy, a_x, a_dw, a_16, a_db = arr(dys), arr(xs), arr(dws), arr(d16), arr(dbs)
     Ns, Ks = np.array([d[0] for d in dims], dtype=np.int32), np.array([d[1] for d in dims], dtype=np.int32)
     refs = [dys[i][:M].float().t() @ xs[i][:M].float() for i in range(n)]
     for accumulate in (0, 1):
         lib.vitae_wgrad_group_bt(n, a_dy.ctypes.data, a_x.ctypes.data, a_dw.ctypes.data, a_16.ctypes.data, a_db.ctypes.data if not accumulate else None,
-                                 Ns.ctypes.data, Ks.ctypes.data, M, Mp, accumulate, ws.data_ptr(), st())
+                                 Ns.ctypes.data, Ks.ctypes.data, M, Mp, accumulate, ws.data_ptr(), ws.numel(), st())
         for i in range(n):
             want = refs[i] * (2 if accumulate else 1)
             assert rel_err(dws[i], want) < 2e-5, (i, accumulate, rel_err(dws[i], want))

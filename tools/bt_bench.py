@@ -43,7 +43,6 @@ def one(form, M, N, K, tile, iters=20, check=True, epi=False):
     got = lib.vitae_gemm_glds_bt_choice(akc, bkc, M, N, K)
     split = lib.vitae_gemm_glds_pick_split_k(M, N, K)
     ws = torch.zeros(1 << 24, device=dev)
-    lib.vitae_gemm_glds_set_ws_capacity(ws.numel())
     cnt = [0]
 
     def go():

@@ -114,7 +114,7 @@ def run_pair(name, M, N, K, iters=50):
         cnt[0] += 1
         w = Ws[cnt[0] % len(Ws)]
         lib.vitae_linear_bwd_pair_glds(dy16.data_ptr(), w.data_ptr(), x16.data_ptr(), dx.data_ptr(), None, dw.data_ptr(), None, M, Mp, N, K,
-                                       0, None, None, None, 0, 0, split, ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                                       0, None, None, None, 0, 0, split, ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
     for _ in range(5): go()
     torch.cuda.synchronize()
     e1 = float((dx - dy16[:M].float() @ w0.float()).abs().max() / (dx.abs().max() + 1e-20))

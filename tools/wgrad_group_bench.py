@@ -7,7 +7,6 @@ from vit_ae_plus_plus_amd._abi import lib
 from bt_bench import graph_time
 dev = 'cuda'
 ws = torch.zeros(1 << 24, device=dev)
-lib.vitae_gemm_glds_set_ws_capacity(ws.numel())
 for name, M, dims in (('B32 enc', 3520, [(2304, 768), (768, 768), (3072, 768), (768, 3072)]),
                       ('B32 dec', 6944, [(1536, 512), (512, 512), (2048, 512), (512, 2048)]),
                       ('B8 enc', 880, [(2304, 768), (768, 768), (3072, 768), (768, 3072)]),
@@ -21,7 +20,7 @@ for name, M, dims in (('B32 enc', 3520, [(2304, 768), (768, 768), (3072, 768), (
     Ns, Ks = np.array([d[0] for d in dims], dtype=np.int32), np.array([d[1] for d in dims], dtype=np.int32)
     stf = lambda: torch.cuda.current_stream().cuda_stream
     grp = lambda: lib.vitae_wgrad_group_bt(4, a_dy.ctypes.data, a_x.ctypes.data, a_dw.ctypes.data, None, None, Ns.ctypes.data, Ks.ctypes.data, M, Mp, 0,
-                                           ws.data_ptr(), stf())
+                                           ws.data_ptr(), ws.numel(), stf())
     def sep():
         for i, (N, K) in enumerate(dims):
             sp = lib.vitae_gemm_glds_pick_split_k(N, K, Mp)

@@ -11,7 +11,6 @@ SHAPES = [('B32 dec qkv', 1536, 512, 6976), ('B32 dec proj', 512, 512, 6976), ('
           ('B32 enc qkv', 2304, 768, 3520), ('B32 enc proj', 768, 768, 3520), ('B32 enc fc1', 3072, 768, 3520), ('B32 enc fc2', 768, 3072, 3520),
           ('p8 dec qkv', 1536, 512, 6976), ('p8 enc qkv', 2304, 768, 3520), ('B8 enc fc1', 3072, 768, 896), ('B8 dec fc1', 2048, 512, 1792)]
 ws = torch.zeros(1 << 24, device=dev)
-lib.vitae_gemm_glds_set_ws_capacity(ws.numel())
 for name, M, N, K in SHAPES:
     A = torch.randn(K, M, device=dev).bfloat16()
     B = torch.randn(K, N, device=dev).bfloat16()

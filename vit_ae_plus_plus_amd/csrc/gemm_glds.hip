@@ -608,7 +608,6 @@ inline Tile pick_tile(int M, int N) {
 //   latency of one workgroup 8000 + 760 nk (+ 7000 for the in-launch split-K fix-up).
 // g_bt_mode: -1 the model decides, -2 never, 0 / 3: that tile wherever it is eligible (vitae_gemm_glds_set_bt_tile; VITAE_BT_TILE).
 int g_bt_mode = getenv("VITAE_BT_TILE") ? atoi(getenv("VITAE_BT_TILE")) : -1;
-long g_ws_capacity = 0;              // floats the caller's split-K workspace holds (vitae_gemm_glds_set_ws_capacity); 0: not told
 
 struct BtPlan { int tile, split; double clocks; };
 
@@ -698,12 +697,6 @@ extern "C" long vitae_gemm_glds_ws_floats(int M, int N, int split_k) {
     return VITAE_GLDS_TICKETS + (small > big ? small : big) * split_k;
 }
 
-extern "C" int vitae_gemm_glds_set_ws_capacity(long floats) {
-    if (floats < 0) return VITAE_ERR_INVALID_ARG;
-    g_ws_capacity = floats;
-    return VITAE_OK;
-}
-
 static int gemm_glds_launch(int a_kcontig, int b_kcontig, const void* A16, long lda, const void* B16, long ldb,
                             float* C, long ldc, void* C16, long ldc16, int M, int N, int K, const float* bias,
                             const float* residual, long ldr, int epi, float* aux, long ldaux, int accumulate,
@@ -787,7 +780,7 @@ extern "C" int vitae_linear_bwd_pair_pick_split_k(int M, int Mpad, int N, int K)
 extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, const void* x16, float* dx, void* dx16,
                                           float* dw, void* dw16, int M, int Mpad, int N, int K, int epi, float* aux,
                                           float* dx_colsum_accum, float* dy_colsum_accum, int dx_accumulate, int dw_accumulate,
-                                          int split_k, float* splitk_ws, void* stream) {
+                                          int split_k, float* splitk_ws, long splitk_ws_floats, void* stream) {
     if (!dy16 || !w16 || (!x16 && dw) || (!dx && !dx16) || M <= 0 || N <= 0 || K <= 0) return VITAE_ERR_INVALID_ARG;
     const int aux16 = (epi & VITAE_EPI_AUX_BF16) != 0;
     epi &= ~VITAE_EPI_AUX_BF16;
@@ -795,11 +788,13 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
     if (dx_accumulate && !dx) return VITAE_ERR_INVALID_ARG;
     if ((N % BK) || (Mpad % BK) || (K & 7) || Mpad < M) return VITAE_ERR_UNSUPPORTED_SHAPE;
     if ((long)(M > N ? M : N) * K >= (1L << 31)) return VITAE_ERR_UNSUPPORTED_SHAPE;   // 32-bit epilogue offsets
+    // what the split-K plans of either half may use: exactly what the caller says the workspace holds
+    const long cap = splitk_ws && splitk_ws_floats > 0 ? splitk_ws_floats : 0;
+    if (split_k > 1 && vitae_gemm_glds_ws_floats(M, K, split_k) > cap) return VITAE_ERR_INVALID_ARG;
     if (((uintptr_t)dy16 & 15) || ((uintptr_t)w16 & 15) || ((uintptr_t)x16 & 15)) return VITAE_ERR_UNSUPPORTED_SHAPE;
     if (!dw) {
         // dW deferred (vitae_wgrad_group_bt collects a block's weight gradients into one launch): the input gradient alone, through
         // the planner of vitae_gemm_glds
-        const long cap = !splitk_ws ? 0 : g_ws_capacity > 0 ? g_ws_capacity : vitae_gemm_glds_ws_floats(M, K, split_k);
         const BtPlan pd = bt_plan(M, K, N, 1, 0, true, cap);
         int sp = pd.tile >= 0 ? pd.split : old_split_rule(M, K, N);
         while (pd.tile < 0 && sp > 1 && vitae_gemm_glds_ws_floats(M, K, sp) > cap) --sp;
@@ -810,9 +805,6 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
         // When the big tiles serve either half, the halves go out as two launches of their own (each fills the chip; the
         // paired launch exists to double the resident workgroups of two SMALL problems): dx = epi(dy16 @ W16) and
         // dW (+)= dy16^T @ x16 through the planner of vitae_gemm_glds, bias gradient by the column-sum kernel.
-        // workspace the halves may use: what the caller said it holds, else what this entry point documents (as for
-        // vitae_gemm_glds with (M, K) and the split it was handed)
-        const long cap = !splitk_ws ? 0 : g_ws_capacity > 0 ? g_ws_capacity : vitae_gemm_glds_ws_floats(M, K, split_k);
         const BtPlan pd = bt_plan(M, K, N, 1, 0, true, cap), pw = bt_plan(N, K, Mpad, 0, 0, true, cap);
         if (pd.tile >= 0 || pw.tile >= 0) {
             // each half: the plan's split when the plan is a big tile, else the 64-row family's own rule, shrunk to the workspace
@@ -880,7 +872,7 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
 // The split of the reduction is chosen for the SUM of the tiles (about two resident workgroups per CU).
 extern "C" int vitae_wgrad_group_bt(int n, const void* const* dy16, const void* const* x16, float* const* dw, void* const* dw16,
                                     float* const* dy_colsum, const int* N, const int* K, int M, int Mpad, int dw_accumulate,
-                                    float* splitk_ws, void* stream) {
+                                    float* splitk_ws, long splitk_ws_floats, void* stream) {
     if (n < 1 || n > 4 || !dy16 || !x16 || !dw || !N || !K || M <= 0 || Mpad < M) return VITAE_ERR_INVALID_ARG;
     if ((Mpad % BK) || Mpad < 4 * BK) return VITAE_ERR_UNSUPPORTED_SHAPE;
     GArgs ps[4];
@@ -910,7 +902,7 @@ extern "C" int vitae_wgrad_group_bt(int n, const void* const* dy16, const void* 
     if (split < 1) split = 1;
     if (split > 8) split = 8;
     while (split > 1 && Mpad / BK / split < 8) --split;
-    const long cap = !splitk_ws ? 0 : g_ws_capacity;
+    const long cap = splitk_ws && splitk_ws_floats > 0 ? splitk_ws_floats : 0;
     while (split > 1 && (tiles > VITAE_GLDS_TICKETS || VITAE_GLDS_TICKETS + tiles * split * 128 * 128 > cap)) --split;
     const int rc = bt_wgrad_group_launch(ps, n, split, (hipStream_t)stream);
     if (rc != VITAE_OK) return rc;

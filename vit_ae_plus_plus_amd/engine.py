@@ -161,7 +161,6 @@ class HipMAEEngine:
         self._taps_c = self.taps.ctypes.data
         self.ws = torch.empty(1 << 24, **f32)   # split-K scratch (64 MiB)
         self.ws16 = torch.zeros(1 << 24, **f32)  # LDS-DMA GEMMs: tile tickets (kept zero by the kernels) + partial tiles
-        lib.vitae_gemm_glds_set_ws_capacity(self.ws16.numel())   # (process-global: every engine allocates the same size)
         self.B = None
         self.buf: Dict[str, torch.Tensor] = {}
         # one workspace per (batch, kept patches), kept alive while captured graphs may hold its addresses; evicting one
@@ -656,7 +655,7 @@ class HipMAEEngine:
                                        None if dw is None else self._wire_of(dw), M, Mpad,
                                        N, K,
                                        epi, _ptr(aux), _ptr(dx_colsum), _ptr(dy_colsum), int(dx_accumulate), int(self._accum), s,
-                                       self.ws16.data_ptr(),
+                                       self.ws16.data_ptr(), self.ws16.numel(),
                                        self.stream)
         if t is not None:
             t.record()
@@ -675,7 +674,7 @@ class HipMAEEngine:
         t = self._timed(sum(2.0 * Mpad * it[3] * it[4] for it in items), 'bt_group')
         lib.vitae_wgrad_group_bt(n, a_dy.ctypes.data, a_x.ctypes.data, a_dw.ctypes.data, None if a_16 is None else a_16.ctypes.data,
                                  None if a_db is None else a_db.ctypes.data, Ns.ctypes.data, Ks.ctypes.data, M, Mpad, int(self._accum),
-                                 self.ws16.data_ptr(), self.stream)
+                                 self.ws16.data_ptr(), self.ws16.numel(), self.stream)
         if t is not None:
             t.record()
 
