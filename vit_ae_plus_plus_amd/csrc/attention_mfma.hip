@@ -85,9 +85,9 @@ __device__ __forceinline__ void stage_bf16(__bf16* dst, const float* __restrict_
 // LDS tile.  The streaming kernels issue chunk c + 1 right after the barrier that publishes chunk c and commit it behind the
 // tiles of chunk c: the global latency of a chunk (1-2 us, every workgroup of a launch staging at the same moments) no longer
 // sits between two barriers with all four waves waiting.
-template <int HD, typename QT> struct ChunkStager;
-template <int HD> struct ChunkStager<HD, float> {
-    static constexpr int LD = HD + 8, V = HD / 4, NL = CH * V / 256;
+template <int HD, typename QT, int CHR = CH> struct ChunkStager;
+template <int HD, int CHR> struct ChunkStager<HD, float, CHR> {
+    static constexpr int LD = HD + 8, V = HD / 4, NL = CHR * V / 256;
     f32x4 r[NL];
     __device__ __forceinline__ void issue(const float* __restrict__ src, long ld, int r0, int N) {
 #pragma unroll
@@ -108,8 +108,8 @@ template <int HD> struct ChunkStager<HD, float> {
         }
     }
 };
-template <int HD> struct ChunkStager<HD, __bf16> {
-    static constexpr int LD = HD + 8, V = HD / 8, NL = CH * V / 256;
+template <int HD, int CHR> struct ChunkStager<HD, __bf16, CHR> {
+    static constexpr int LD = HD + 8, V = HD / 8, NL = CHR * V / 256;
     bf16x8 r[NL];
     __device__ __forceinline__ void issue(const __bf16* __restrict__ src, long ld, int r0, int N) {
 #pragma unroll
@@ -188,324 +188,497 @@ __device__ __forceinline__ void colsum_to(float (&v)[NV], bool valid, float* __r
     }
 }
 
+// ------------------------------------------------------------------------------- streaming kernels (any N), round 4
+// What changed against the round-3 kernels (68 us forward / 97 + 85 us backward at N = 1729, hd = 32, ~90 VALU instructions per
+// 32 x 32 tile against 4-8 MFMAs, two workgroup barriers per four tiles).  Counters (profiles/round4_attention.txt) say these
+// kernels are bound by instruction ISSUE of their SIMD — a wave-64 VALU instruction holds it ~4 clocks, an MFMA ~21-32, and the
+// sum over the resident waves reaches ~80 % of the SIMD's time whatever the occupancy — so the work is counted in instructions:
+//   * the softmax reference point rides in the MFMA's C operand: S' = K Q^T + (-m) costs nothing (the C input of
+//     v_mfma is a register block of its own — 16 VGPRs holding -m broadcast — so no per-tile initialisation either), and the
+//     backward's S - lse and dP - delta come out of the matrix pipe the same way: exp2(S') with NO subtraction per element;
+//   * the running maximum is only a reference point: it moves when a tile's maximum exceeds it by more than 2^SM_THR (deferred
+//     rescale, cdna_hip_programming.md T13; the first tile always sets it) — no per-tile exp2(m - m'), no per-tile O *= corr;
+//   * a wave owns RB blocks of 32 rows (queries in forward / dQ, keys in dK/dV): every LDS fragment read serves RB MFMAs;
+//   * K/V (Q/dO) chunks are double-buffered in LDS: ONE workgroup barrier per 128-row chunk, the chunk after next already in
+//     flight in registers;
+//   * the half-wave exchange of the tile maximum is a v_permlane32_swap (VALU), not a ds_bpermute.
+constexpr float SM_THR = 8.f;
+
+__device__ __forceinline__ f32x16 bcast16(float x) {
+    f32x16 v;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = x;
+    return v;
+}
+
+// max over the two lanes that hold the same query (lane, lane ^ 32)
+__device__ __forceinline__ float half_pair_max(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
+    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
+
+__device__ __forceinline__ float max16(const f32x16& s) {
+    float a = fmaxf(fmaxf(s[0], s[1]), s[2]), b = fmaxf(fmaxf(s[3], s[4]), s[5]);
+    float c = fmaxf(fmaxf(s[6], s[7]), s[8]), d = fmaxf(fmaxf(s[9], s[10]), s[11]);
+    a = fmaxf(fmaxf(a, s[12]), s[13]); b = fmaxf(fmaxf(b, s[14]), s[15]);
+    return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+
 // ------------------------------------------------------------------------------- forward
-template <int HD, typename QT = float>
+// One STEP of a wave = QB query blocks x KT key tiles (32 x 32 each): all QB * KT score products are issued back to back as
+// independent accumulate chains (a dependent v_mfma pair costs its 64-clock result latency, an independent one 32 clocks of issue),
+// one maximum / rescale decision and one pass of exp2 cover the whole step, and the P V products alternate between accumulators.
+template <int HD, int QB, int KT, int CHK, typename QT = float>
 __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const QT* __restrict__ qkv, float* __restrict__ o,
                                                             __bf16* __restrict__ o16,
                                                             float* __restrict__ lse, int N, int H, float scale) {
     constexpr int LD = HD + 8, NKK = HD / 16, NT = HD / 32;
-    __shared__ __attribute__((aligned(16))) __bf16 Ks[CH * LD];
-    __shared__ __attribute__((aligned(16))) __bf16 Vs[CH * LD];
+    constexpr int NACC = (QB * NT >= 2) ? 1 : 2;            // independent P V accumulate chains per step: at least two
+    static_assert(CHK % (32 * KT) == 0, "a chunk is a whole number of steps");
+    __shared__ __attribute__((aligned(16))) __bf16 Ks[2][CHK * LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Vs[2][CHK * LD];
     const int b = blockIdx.z, h = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int D = H * HD;
     const long ld = 3L * D;
     const QT* base = qkv + (long)b * N * ld + h * HD;
-    const int q0 = (blockIdx.x * 4 + wave) * 32, qrow = q0 + l31;
-    const bool qvalid = qrow < N, wave_live = q0 < N;
-    bf16x8 qf[NKK];
+    const int q0 = (blockIdx.x * 4 + wave) * (32 * QB);
+    const bool wave_live = q0 < N;
+    bf16x8 qf[QB][NKK];
 #pragma unroll
-    for (int kk = 0; kk < NKK; ++kk) qf[kk] = load_frag(base + (long)qrow * ld + 16 * kk + 8 * hi, qvalid, scale * LOG2E);
-    f32x16 oacc[NT];
+    for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) oacc[nt] = zero16();
-    float m = -1e30f, lsum = 0.f;
-    ChunkStager<HD, QT> sk, sv;
-    sk.issue(base + D, ld, 0, N);
-    sv.issue(base + 2 * D, ld, 0, N);
-    for (int c0 = 0; c0 < N; c0 += CH) {
-        __syncthreads();
-        sk.commit(Ks, 1.f);
-        sv.commit(Vs, 1.f);
-        __syncthreads();
-        if (c0 + CH < N) {                                  // the next chunk's loads fly under this chunk's tiles
-            sk.issue(base + D, ld, c0 + CH, N);
-            sv.issue(base + 2 * D, ld, c0 + CH, N);
+        for (int kk = 0; kk < NKK; ++kk) {
+            const int qrow = q0 + 32 * qb + l31;
+            qf[qb][kk] = load_frag(base + (long)qrow * ld + 16 * kk + 8 * hi, qrow < N, scale * LOG2E);
         }
-        if (!wave_live) continue;
-        const int kend = min(CH, N - c0);
-        for (int kt = 0; kt * 32 < kend; ++kt) {
-            f32x16 s = zero16();
+    f32x16 oacc[QB][NT][NACC], negm[QB];
+    float m[QB], lsum[QB];
 #pragma unroll
-            for (int kk = 0; kk < NKK; ++kk) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(&Ks[(kt * 32 + l31) * LD + 16 * kk + 8 * hi]);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[kk], s, 0, 0, 0);
-            }
-            if (c0 + kt * 32 + 32 > N) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) if (c0 + kt * 32 + crow(r, hi) >= N) s[r] = -1e30f;
-            }
-            float tmax = s[0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float mn = fmaxf(m, tmax);
-            const float corr = __builtin_amdgcn_exp2f(m - mn);
-            m = mn;
-            float psum = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - mn); psum += s[r]; }
-            lsum = lsum * corr + psum;
-            bf16x8 pf[2];
-            pack16(s, pf);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[nt][r] *= corr;
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const bf16x8 a = tr_frag<LD>(Vs, kt * 32, s2, 32 * nt, lane);
-                    oacc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pf[s2], oacc[nt], 0, 0, 0);
-                }
-            }
-        }
-    }
-    if (!wave_live) return;
-    const float ltot = lsum + __shfl_xor(lsum, 32, 64);
-    if (qvalid) {
-        const float inv = 1.f / ltot;
-        float* orow = o + ((long)b * N + qrow) * D + h * HD;
+    for (int qb = 0; qb < QB; ++qb) {
+        negm[qb] = zero16(); m[qb] = 0.f; lsum[qb] = 0.f;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 v = {oacc[nt][4 * g] * inv, oacc[nt][4 * g + 1] * inv, oacc[nt][4 * g + 2] * inv, oacc[nt][4 * g + 3] * inv};
-                *reinterpret_cast<f32x4*>(orow + 32 * nt + 8 * g + 4 * hi) = v;
-                if (o16) {
-                    bf16x4 v16;
+            for (int a = 0; a < NACC; ++a) oacc[qb][nt][a] = zero16();
+    }
+    ChunkStager<HD, QT, CHK> sk, sv;
+    const int nch = (N + CHK - 1) / CHK;
+    sk.issue(base + D, ld, 0, N);
+    sv.issue(base + 2 * D, ld, 0, N);
+    sk.commit(Ks[0], 1.f);
+    sv.commit(Vs[0], 1.f);
+    if (nch > 1) { sk.issue(base + D, ld, CHK, N); sv.issue(base + 2 * D, ld, CHK, N); }
+    __syncthreads();
+    for (int c = 0; c < nch; ++c) {
+        const int cur = c & 1, c0 = c * CHK;
+        if (c + 1 < nch) {                                   // chunk c + 1 -> the buffer chunk c - 1 was read from (free since the last barrier)
+            sk.commit(Ks[cur ^ 1], 1.f);
+            sv.commit(Vs[cur ^ 1], 1.f);
+            if (c + 2 < nch) { sk.issue(base + D, ld, c0 + 2 * CHK, N); sv.issue(base + 2 * D, ld, c0 + 2 * CHK, N); }
+        }
+        if (wave_live) {
+            const __bf16* Kc = Ks[cur];
+            const __bf16* Vc = Vs[cur];
+            const int kend = min(CHK, N - c0);
+            for (int k0 = 0; k0 < kend; k0 += 32 * KT) {
+                bf16x8 kfr[KT][NKK];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v16[e] = (__bf16)v[e];
-                    *reinterpret_cast<bf16x4*>(o16 + ((long)b * N + qrow) * D + h * HD + 32 * nt + 8 * g + 4 * hi) = v16;
+                for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                    for (int kk = 0; kk < NKK; ++kk) kfr[kt][kk] = *reinterpret_cast<const bf16x8*>(&Kc[(k0 + kt * 32 + l31) * LD + 16 * kk + 8 * hi]);
+                f32x16 s[QB][KT];
+#pragma unroll
+                for (int kk = 0; kk < NKK; ++kk)
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                        for (int qb = 0; qb < QB; ++qb)
+                            s[qb][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kt][kk], qf[qb][kk], kk == 0 ? negm[qb] : s[qb][kt], 0, 0, 0);
+                if (c0 + k0 + 32 * KT > N) {                 // keys past the sequence (their K rows are zero in LDS)
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) if (c0 + k0 + kt * 32 + crow(r, hi) >= N) s[qb][kt][r] = -1e30f;
                 }
+                const bool first = c == 0 && k0 == 0;
+                float tm[QB];
+                bool need = first;
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) {
+                    float t = max16(s[qb][0]);
+#pragma unroll
+                    for (int kt = 1; kt < KT; ++kt) t = fmaxf(t, max16(s[qb][kt]));
+                    tm[qb] = half_pair_max(t);
+                    need |= tm[qb] > SM_THR;
+                }
+                if (__any(need)) {
+                    // move the reference point: the first step sets it to the step's maximum, later ones only ever raise it
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) {
+                        const float delta = first ? tm[qb] : fmaxf(tm[qb], 0.f);
+                        const float corr = __builtin_amdgcn_exp2f(-delta);
+                        m[qb] += delta;
+                        lsum[qb] *= corr;
+                        negm[qb] = bcast16(-m[qb]);
+#pragma unroll
+                        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) s[qb][kt][r] -= delta;
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                            for (int a = 0; a < NACC; ++a)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) oacc[qb][nt][a][r] *= corr;
+                    }
+                }
+                bf16x8 pf[QB][KT][2];
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) {
+                    float ps = 0.f;
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            s[qb][kt][r] = __builtin_amdgcn_exp2f(s[qb][kt][r]);
+                            ps += s[qb][kt][r];
+                        }
+                        pack16(s[qb][kt], pf[qb][kt]);
+                    }
+                    lsum[qb] += ps;
+                }
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            const bf16x8 a = tr_frag<LD>(Vc, k0 + kt * 32, s2, 32 * nt, lane);
+#pragma unroll
+                            for (int qb = 0; qb < QB; ++qb)
+                                oacc[qb][nt][(2 * kt + s2) % NACC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pf[qb][kt][s2], oacc[qb][nt][(2 * kt + s2) % NACC], 0, 0, 0);
+                        }
             }
-        if (hi == 0) lse[((long)b * H + h) * N + qrow] = (m + __builtin_amdgcn_logf(ltot)) * LN2;
+        }
+        __syncthreads();                                     // chunk c + 1 is visible, chunk c's buffer is free
+    }
+    if (!wave_live) return;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int qrow = q0 + 32 * qb + l31;
+        const float ltot = lsum[qb] + __shfl_xor(lsum[qb], 32, 64);
+        if (qrow < N) {
+            const float inv = 1.f / ltot;
+            float* orow = o + ((long)b * N + qrow) * D + h * HD;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (NACC == 2 ? oacc[qb][nt][0][4 * g + e] + oacc[qb][nt][NACC - 1][4 * g + e] : oacc[qb][nt][0][4 * g + e]) * inv;
+                    *reinterpret_cast<f32x4*>(orow + 32 * nt + 8 * g + 4 * hi) = v;
+                    if (o16) {
+                        bf16x4 v16;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v16[e] = (__bf16)v[e];
+                        *reinterpret_cast<bf16x4*>(o16 + ((long)b * N + qrow) * D + h * HD + 32 * nt + 8 * g + 4 * hi) = v16;
+                    }
+                }
+            if (hi == 0) lse[((long)b * H + h) * N + qrow] = (m[qb] + __builtin_amdgcn_logf(ltot)) * LN2;
+        }
     }
 }
 
 // ------------------------------------------------------------------------------- backward: dQ (+ delta)
-template <int HD, typename QT = float>
+template <int HD, int QB, typename QT = float>
 __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const QT* __restrict__ qkv, const float* __restrict__ o,
                                                                const float* __restrict__ d_o, const float* __restrict__ lse,
                                                                float* __restrict__ dqkv, __bf16* __restrict__ dqkv16,
                                                                float* __restrict__ dbias, float* __restrict__ delta, int N,
                                                                int H, float scale) {
     constexpr int LD = HD + 8, NKK = HD / 16, NT = HD / 32;
-    __shared__ __attribute__((aligned(16))) __bf16 Ks[CH * LD];
-    __shared__ __attribute__((aligned(16))) __bf16 Vs[CH * LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Ks[2][CH * LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Vs[2][CH * LD];
     const int b = blockIdx.z, h = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int D = H * HD;
     const long ld = 3L * D;
     const QT* base = qkv + (long)b * N * ld + h * HD;
-    const int q0 = (blockIdx.x * 4 + wave) * 32, qrow = q0 + l31;
-    const bool qvalid = qrow < N, wave_live = q0 < N;
-    bf16x8 qf[NKK], gf[NKK];
-    float dl = 0.f;
-    const float* grow = d_o + ((long)b * N + qrow) * D + h * HD;
-    const float* orow = o + ((long)b * N + qrow) * D + h * HD;
+    const int q0 = (blockIdx.x * 4 + wave) * (32 * QB);
+    const bool wave_live = q0 < N;
+    bf16x8 qf[QB][NKK], gf[QB][NKK];
+    f32x16 negL[QB], negD[QB], acc[QB][NT];
+    float dlv[QB];
 #pragma unroll
-    for (int kk = 0; kk < NKK; ++kk) {
-        const int c = 16 * kk + 8 * hi;
-        qf[kk] = load_frag(base + (long)qrow * ld + c, qvalid, scale * LOG2E);
-        f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, o0 = g0, o1 = g0;
-        if (qvalid) {
-            g0 = *reinterpret_cast<const f32x4*>(grow + c); g1 = *reinterpret_cast<const f32x4*>(grow + c + 4);
-            o0 = *reinterpret_cast<const f32x4*>(orow + c); o1 = *reinterpret_cast<const f32x4*>(orow + c + 4);
+    for (int qb = 0; qb < QB; ++qb) {
+        const int qrow = q0 + 32 * qb + l31;
+        const bool qvalid = qrow < N;
+        const float* grow = d_o + ((long)b * N + qrow) * D + h * HD;
+        const float* orow = o + ((long)b * N + qrow) * D + h * HD;
+        float dl = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+            const int cc = 16 * kk + 8 * hi;
+            qf[qb][kk] = load_frag(base + (long)qrow * ld + cc, qvalid, scale * LOG2E);
+            f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, o0 = g0, o1 = g0;
+            if (qvalid) {
+                g0 = *reinterpret_cast<const f32x4*>(grow + cc); g1 = *reinterpret_cast<const f32x4*>(grow + cc + 4);
+                o0 = *reinterpret_cast<const f32x4*>(orow + cc); o1 = *reinterpret_cast<const f32x4*>(orow + cc + 4);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dl += g0[e] * o0[e] + g1[e] * o1[e];
+            gf[qb][kk] = cvt8(g0, g1, 1.f);
         }
+        dl += __shfl_xor(dl, 32, 64);
+        dlv[qb] = dl;
+        const float Lq = qvalid ? lse[((long)b * H + h) * N + qrow] * LOG2E : 0.f;
+        negL[qb] = bcast16(-Lq);
+        negD[qb] = bcast16(-dl);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dl += g0[e] * o0[e] + g1[e] * o1[e];
-        gf[kk] = cvt8(g0, g1, 1.f);
+        for (int nt = 0; nt < NT; ++nt) acc[qb][nt] = zero16();
     }
-    dl += __shfl_xor(dl, 32, 64);
-    const float Lq = qvalid ? lse[((long)b * H + h) * N + qrow] * LOG2E : 0.f;
-    f32x16 acc[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[nt] = zero16();
     ChunkStager<HD, QT> sk, sv;
+    const int nch = (N + CH - 1) / CH;
     sk.issue(base + D, ld, 0, N);
     sv.issue(base + 2 * D, ld, 0, N);
-    for (int c0 = 0; c0 < N; c0 += CH) {
-        __syncthreads();
-        sk.commit(Ks, 1.f);
-        sv.commit(Vs, 1.f);
-        __syncthreads();
-        if (c0 + CH < N) {
-            sk.issue(base + D, ld, c0 + CH, N);
-            sv.issue(base + 2 * D, ld, c0 + CH, N);
+    sk.commit(Ks[0], 1.f);
+    sv.commit(Vs[0], 1.f);
+    if (nch > 1) { sk.issue(base + D, ld, CH, N); sv.issue(base + 2 * D, ld, CH, N); }
+    __syncthreads();
+    for (int c = 0; c < nch; ++c) {
+        const int cur = c & 1, c0 = c * CH;
+        if (c + 1 < nch) {
+            sk.commit(Ks[cur ^ 1], 1.f);
+            sv.commit(Vs[cur ^ 1], 1.f);
+            if (c + 2 < nch) { sk.issue(base + D, ld, c0 + 2 * CH, N); sv.issue(base + 2 * D, ld, c0 + 2 * CH, N); }
         }
-        if (!wave_live) continue;
-        const int kend = min(CH, N - c0);
-        for (int kt = 0; kt * 32 < kend; ++kt) {
-            f32x16 s = zero16(), dp = zero16();
+        if (wave_live) {
+            const __bf16* Kc = Ks[cur];
+            const __bf16* Vc = Vs[cur];
+            const int kend = min(CH, N - c0);
+            for (int kt = 0; kt * 32 < kend; ++kt) {
+                bf16x8 kfr[NKK], vfr[NKK];
 #pragma unroll
-            for (int kk = 0; kk < NKK; ++kk) {
-                const bf16x8 ak = *reinterpret_cast<const bf16x8*>(&Ks[(kt * 32 + l31) * LD + 16 * kk + 8 * hi]);
-                const bf16x8 av = *reinterpret_cast<const bf16x8*>(&Vs[(kt * 32 + l31) * LD + 16 * kk + 8 * hi]);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ak, qf[kk], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, gf[kk], dp, 0, 0, 0);
-            }
-            const bool tail = c0 + kt * 32 + 32 > N;
+                for (int kk = 0; kk < NKK; ++kk) {
+                    kfr[kk] = *reinterpret_cast<const bf16x8*>(&Kc[(kt * 32 + l31) * LD + 16 * kk + 8 * hi]);
+                    vfr[kk] = *reinterpret_cast<const bf16x8*>(&Vc[(kt * 32 + l31) * LD + 16 * kk + 8 * hi]);
+                }
+                const bool tail = c0 + kt * 32 + 32 > N;
+                bf16x8 dsf[QB][2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float p = __builtin_amdgcn_exp2f(s[r] - Lq);
-                if (tail && c0 + kt * 32 + crow(r, hi) >= N) p = 0.f;
-                s[r] = p * (dp[r] - dl);
+                for (int qb = 0; qb < QB; ++qb) {
+                    // S' = K Q^T - lse and dP' = V dO^T - delta straight out of the matrix pipe
+                    f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[0], qf[qb][0], negL[qb], 0, 0, 0);
+                    f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[0], gf[qb][0], negD[qb], 0, 0, 0);
+#pragma unroll
+                    for (int kk = 1; kk < NKK; ++kk) {
+                        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kk], qf[qb][kk], s, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[kk], gf[qb][kk], dp, 0, 0, 0);
+                    }
+                    if (tail) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) if (c0 + kt * 32 + crow(r, hi) >= N) s[r] = -1e30f;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]) * dp[r];
+                    pack16(s, dsf[qb]);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const bf16x8 a = tr_frag<LD>(Kc, kt * 32, s2, 32 * nt, lane);
+#pragma unroll
+                        for (int qb = 0; qb < QB; ++qb) acc[qb][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, dsf[qb][s2], acc[qb][nt], 0, 0, 0);
+                    }
             }
-            bf16x8 dsf[2];
-            pack16(s, dsf);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int qrow = q0 + 32 * qb + l31;
+        const bool qvalid = qrow < N;
+        if (dbias) {
+            float cs[16 * NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const bf16x8 a = tr_frag<LD>(Ks, kt * 32, s2, 32 * nt, lane);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, dsf[s2], acc[nt], 0, 0, 0);
-                }
+                for (int r = 0; r < 16; ++r) cs[16 * nt + r] = acc[qb][nt][r] * scale;
+            colsum_to<16 * NT>(cs, wave_live && qvalid, dbias + h * HD, reinterpret_cast<float*>(&Ks[0][0]), hi, l31, wave);
         }
-    }
-    if (dbias) {
-        float cs[16 * NT];
+        if (!wave_live || !qvalid) continue;
+        const long ooff = ((long)b * N + qrow) * ld + h * HD;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) cs[16 * nt + r] = acc[nt][r] * scale;
-        colsum_to<16 * NT>(cs, wave_live && qvalid, dbias + h * HD, reinterpret_cast<float*>(Ks), hi, l31, wave);
-    }
-    if (!wave_live || !qvalid) return;
-    const long ooff = ((long)b * N + qrow) * ld + h * HD;
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = {acc[qb][nt][4 * g] * scale, acc[qb][nt][4 * g + 1] * scale, acc[qb][nt][4 * g + 2] * scale, acc[qb][nt][4 * g + 3] * scale};
+                if (dqkv) *reinterpret_cast<f32x4*>(dqkv + ooff + 32 * nt + 8 * g + 4 * hi) = v;
+                if (dqkv16) {
+                    bf16x4 v16;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 v = {acc[nt][4 * g] * scale, acc[nt][4 * g + 1] * scale, acc[nt][4 * g + 2] * scale, acc[nt][4 * g + 3] * scale};
-            if (dqkv) *reinterpret_cast<f32x4*>(dqkv + ooff + 32 * nt + 8 * g + 4 * hi) = v;
-            if (dqkv16) {
-                bf16x4 v16;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v16[e] = (__bf16)v[e];
-                *reinterpret_cast<bf16x4*>(dqkv16 + ((long)b * N + qrow) * ld + h * HD + 32 * nt + 8 * g + 4 * hi) = v16;
+                    for (int e = 0; e < 4; ++e) v16[e] = (__bf16)v[e];
+                    *reinterpret_cast<bf16x4*>(dqkv16 + ooff + 32 * nt + 8 * g + 4 * hi) = v16;
+                }
             }
-        }
-    if (hi == 0) delta[((long)b * H + h) * N + qrow] = dl;
+        if (hi == 0) delta[((long)b * H + h) * N + qrow] = dlv[qb];
+    }
 }
 
 // ------------------------------------------------------------------------------- backward: dK, dV
-template <int HD, typename QT = float>
+template <int HD, int KB, typename QT = float>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const QT* __restrict__ qkv, const float* __restrict__ d_o,
                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
                                                                 float* __restrict__ dqkv, __bf16* __restrict__ dqkv16,
                                                                 float* __restrict__ dbias, int N, int H, float scale) {
     constexpr int LD = HD + 8, NKK = HD / 16, NT = HD / 32;
-    __shared__ __attribute__((aligned(16))) __bf16 Qs[CH * LD];
-    __shared__ __attribute__((aligned(16))) __bf16 Gs[CH * LD];
-    __shared__ __attribute__((aligned(16))) float Ls[CH];
-    __shared__ __attribute__((aligned(16))) float Ds[CH];
+    __shared__ __attribute__((aligned(16))) __bf16 Qs[2][CH * LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Gs[2][CH * LD];
+    __shared__ __attribute__((aligned(16))) float Ls[2][CH];      // -lse * log2(e) of the chunk's queries (the C operand of S)
+    __shared__ __attribute__((aligned(16))) float Ds[2][CH];      // -delta (the C operand of dP)
     const int b = blockIdx.z, h = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int D = H * HD;
     const long ld = 3L * D;
     const QT* base = qkv + (long)b * N * ld + h * HD;
-    const int k0 = (blockIdx.x * 4 + wave) * 32, krow = k0 + l31;
-    const bool kvalid = krow < N, wave_live = k0 < N;
-    bf16x8 kf[NKK], vf[NKK];
+    const int k0 = (blockIdx.x * 4 + wave) * (32 * KB);
+    const bool wave_live = k0 < N;
+    bf16x8 kf[KB][NKK], vf[KB][NKK];
+    f32x16 dk[KB][NT], dv[KB][NT];
 #pragma unroll
-    for (int kk = 0; kk < NKK; ++kk) {
-        kf[kk] = load_frag(base + (long)krow * ld + D + 16 * kk + 8 * hi, kvalid, 1.f);
-        vf[kk] = load_frag(base + (long)krow * ld + 2 * D + 16 * kk + 8 * hi, kvalid, 1.f);
+    for (int kb = 0; kb < KB; ++kb) {
+        const int krow = k0 + 32 * kb + l31;
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+            kf[kb][kk] = load_frag(base + (long)krow * ld + D + 16 * kk + 8 * hi, krow < N, 1.f);
+            vf[kb][kk] = load_frag(base + (long)krow * ld + 2 * D + 16 * kk + 8 * hi, krow < N, 1.f);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { dk[kb][nt] = zero16(); dv[kb][nt] = zero16(); }
     }
-    f32x16 dk[NT], dv[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) { dk[nt] = zero16(); dv[nt] = zero16(); }
     const float* gbase = d_o + (long)b * N * D + h * HD;
     const float* lrow = lse + ((long)b * H + h) * N;
     const float* drow = delta + ((long)b * H + h) * N;
     ChunkStager<HD, QT> sq;
     ChunkStager<HD, float> sg;
-    float nl = 1e30f, nd = 0.f;                            // lse / delta of this thread's query of the NEXT chunk (threads < CH)
-    auto issue_chunk = [&](int c) {
-        sq.issue(base, ld, c, N);
-        sg.issue(gbase, D, c, N);
+    float nl = -1e30f, nd = 0.f;                           // -lse / -delta of this thread's query of the staged chunk (threads < CH)
+    auto issue_chunk = [&](int c0) {
+        sq.issue(base, ld, c0, N);
+        sg.issue(gbase, D, c0, N);
         if (threadIdx.x < CH) {
-            const int q = c + threadIdx.x;
-            nl = q < N ? lrow[q] * LOG2E : 1e30f;           // invalid query -> P = exp2(-huge) = 0
-            nd = q < N ? drow[q] : 0.f;
+            const int q = c0 + threadIdx.x;
+            nl = q < N ? -lrow[q] * LOG2E : -1e30f;          // invalid query -> P = exp2(-huge) = 0
+            nd = q < N ? -drow[q] : 0.f;
         }
     };
+    auto commit_chunk = [&](int buf) {
+        sq.commit(Qs[buf], scale * LOG2E);
+        sg.commit(Gs[buf], 1.f);
+        if (threadIdx.x < CH) { Ls[buf][threadIdx.x] = nl; Ds[buf][threadIdx.x] = nd; }
+    };
+    const int nch = (N + CH - 1) / CH;
     issue_chunk(0);
-    for (int c0 = 0; c0 < N; c0 += CH) {
-        __syncthreads();
-        sq.commit(Qs, scale * LOG2E);
-        sg.commit(Gs, 1.f);
-        if (threadIdx.x < CH) { Ls[threadIdx.x] = nl; Ds[threadIdx.x] = nd; }
-        __syncthreads();
-        if (c0 + CH < N) issue_chunk(c0 + CH);
-        if (!wave_live) continue;
-        const int qend = min(CH, N - c0);
-        for (int qt = 0; qt * 32 < qend; ++qt) {
-            f32x16 s = zero16(), dp = zero16();
+    commit_chunk(0);
+    if (nch > 1) issue_chunk(CH);
+    __syncthreads();
+    for (int c = 0; c < nch; ++c) {
+        const int cur = c & 1, c0 = c * CH;
+        if (c + 1 < nch) {
+            commit_chunk(cur ^ 1);
+            if (c + 2 < nch) issue_chunk(c0 + 2 * CH);
+        }
+        if (wave_live) {
+            const __bf16* Qc = Qs[cur];
+            const __bf16* Gc = Gs[cur];
+            const float* Lc = Ls[cur];
+            const float* Dc = Ds[cur];
+            const int qend = min(CH, N - c0);
+            for (int qt = 0; qt * 32 < qend; ++qt) {
+                bf16x8 aq[NKK], ag[NKK];
 #pragma unroll
-            for (int kk = 0; kk < NKK; ++kk) {
-                const bf16x8 aq = *reinterpret_cast<const bf16x8*>(&Qs[(qt * 32 + l31) * LD + 16 * kk + 8 * hi]);
-                const bf16x8 ag = *reinterpret_cast<const bf16x8*>(&Gs[(qt * 32 + l31) * LD + 16 * kk + 8 * hi]);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, kf[kk], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ag, vf[kk], dp, 0, 0, 0);
-            }
-            f32x16 p;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 L4 = *reinterpret_cast<const f32x4*>(&Ls[qt * 32 + 8 * g + 4 * hi]);
-                const f32x4 D4 = *reinterpret_cast<const f32x4*>(&Ds[qt * 32 + 8 * g + 4 * hi]);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float pe = __builtin_amdgcn_exp2f(s[4 * g + e] - L4[e]);
-                    p[4 * g + e] = pe;
-                    s[4 * g + e] = pe * (dp[4 * g + e] - D4[e]);
+                for (int kk = 0; kk < NKK; ++kk) {
+                    aq[kk] = *reinterpret_cast<const bf16x8*>(&Qc[(qt * 32 + l31) * LD + 16 * kk + 8 * hi]);
+                    ag[kk] = *reinterpret_cast<const bf16x8*>(&Gc[(qt * 32 + l31) * LD + 16 * kk + 8 * hi]);
                 }
+                f32x16 cL, cD;                               // rows crow(r, hi) of the tile: four 16-byte groups each
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 L4 = *reinterpret_cast<const f32x4*>(&Lc[qt * 32 + 8 * g + 4 * hi]);
+                    const f32x4 D4 = *reinterpret_cast<const f32x4*>(&Dc[qt * 32 + 8 * g + 4 * hi]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { cL[4 * g + e] = L4[e]; cD[4 * g + e] = D4[e]; }
+                }
+                bf16x8 pf[KB][2], dsf[KB][2];
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) {
+                    f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[0], kf[kb][0], cL, 0, 0, 0);
+                    f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ag[0], vf[kb][0], cD, 0, 0, 0);
+#pragma unroll
+                    for (int kk = 1; kk < NKK; ++kk) {
+                        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[kk], kf[kb][kk], s, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ag[kk], vf[kb][kk], dp, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r]); dp[r] *= s[r]; }
+                    pack16(s, pf[kb]);
+                    pack16(dp, dsf[kb]);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const bf16x8 agt = tr_frag<LD>(Gc, qt * 32, s2, 32 * nt, lane);
+                        const bf16x8 aqt = tr_frag<LD>(Qc, qt * 32, s2, 32 * nt, lane);
+#pragma unroll
+                        for (int kb = 0; kb < KB; ++kb) {
+                            dv[kb][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(agt, pf[kb][s2], dv[kb][nt], 0, 0, 0);
+                            dk[kb][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aqt, dsf[kb][s2], dk[kb][nt], 0, 0, 0);
+                        }
+                    }
             }
-            bf16x8 pf[2], dsf[2];
-            pack16(p, pf);
-            pack16(s, dsf);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        const int krow = k0 + 32 * kb + l31;
+        const bool kvalid = krow < N;
+        if (dbias) {
+            float ck[16 * NT], cv[16 * NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const bf16x8 ag = tr_frag<LD>(Gs, qt * 32, s2, 32 * nt, lane);
-                    dv[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ag, pf[s2], dv[nt], 0, 0, 0);
-                    const bf16x8 aq = tr_frag<LD>(Qs, qt * 32, s2, 32 * nt, lane);
-                    dk[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, dsf[s2], dk[nt], 0, 0, 0);
-                }
+                for (int r = 0; r < 16; ++r) { ck[16 * nt + r] = dk[kb][nt][r] * LN2; cv[16 * nt + r] = dv[kb][nt][r]; }
+            colsum_to<16 * NT>(ck, wave_live && kvalid, dbias + D + h * HD, reinterpret_cast<float*>(&Qs[0][0]), hi, l31, wave);
+            colsum_to<16 * NT>(cv, wave_live && kvalid, dbias + 2 * D + h * HD, reinterpret_cast<float*>(&Gs[0][0]), hi, l31, wave);
         }
-    }
-    if (dbias) {
-        float ck[16 * NT], cv[16 * NT];
+        if (!wave_live || !kvalid) continue;
+        const long ooff = ((long)b * N + krow) * ld + h * HD;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { ck[16 * nt + r] = dk[nt][r] * LN2; cv[16 * nt + r] = dv[nt][r]; }
-        colsum_to<16 * NT>(ck, wave_live && kvalid, dbias + D + h * HD, reinterpret_cast<float*>(Qs), hi, l31, wave);
-        colsum_to<16 * NT>(cv, wave_live && kvalid, dbias + 2 * D + h * HD, reinterpret_cast<float*>(Gs), hi, l31, wave);
+            for (int g = 0; g < 4; ++g) {
+                const int d = 32 * nt + 8 * g + 4 * hi;
+                f32x4 vk = {dk[kb][nt][4 * g] * LN2, dk[kb][nt][4 * g + 1] * LN2, dk[kb][nt][4 * g + 2] * LN2, dk[kb][nt][4 * g + 3] * LN2};
+                f32x4 vv = {dv[kb][nt][4 * g], dv[kb][nt][4 * g + 1], dv[kb][nt][4 * g + 2], dv[kb][nt][4 * g + 3]};
+                if (dqkv) {
+                    *reinterpret_cast<f32x4*>(dqkv + ooff + D + d) = vk;       // Qs carried scale*log2e: dK = sum dS * scale * Q
+                    *reinterpret_cast<f32x4*>(dqkv + ooff + 2 * D + d) = vv;
+                }
+                if (dqkv16) {
+                    bf16x4 k16, v16;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { k16[e] = (__bf16)vk[e]; v16[e] = (__bf16)vv[e]; }
+                    *reinterpret_cast<bf16x4*>(dqkv16 + ooff + D + d) = k16;
+                    *reinterpret_cast<bf16x4*>(dqkv16 + ooff + 2 * D + d) = v16;
+                }
+            }
     }
-    if (!wave_live || !kvalid) return;
-    const long ooff = ((long)b * N + krow) * ld + h * HD;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int d = 32 * nt + 8 * g + 4 * hi;
-            f32x4 vk = {dk[nt][4 * g] * LN2, dk[nt][4 * g + 1] * LN2, dk[nt][4 * g + 2] * LN2, dk[nt][4 * g + 3] * LN2};
-            f32x4 vv = {dv[nt][4 * g], dv[nt][4 * g + 1], dv[nt][4 * g + 2], dv[nt][4 * g + 3]};
-            if (dqkv) {
-                *reinterpret_cast<f32x4*>(dqkv + ooff + D + d) = vk;       // Qs carried scale*log2e: dK = sum dS * scale * Q
-                *reinterpret_cast<f32x4*>(dqkv + ooff + 2 * D + d) = vv;
-            }
-            if (dqkv16) {
-                bf16x4 k16, v16;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { k16[e] = (__bf16)vk[e]; v16[e] = (__bf16)vv[e]; }
-                __bf16* o16 = dqkv16 + ((long)b * N + krow) * ld + h * HD;
-                *reinterpret_cast<bf16x4*>(o16 + D + d) = k16;
-                *reinterpret_cast<bf16x4*>(o16 + 2 * D + d) = v16;
-            }
-        }
 }
 
 // ------------------------------------------------------------------------------- backward, one launch
@@ -579,10 +752,10 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(const QT* __restric
         float dl = g[0] * ov[0] + g[1] * ov[1] + g[2] * ov[2] + g[3] * ov[3];
 #pragma unroll
         for (int of = 1; of < V4; of <<= 1) dl += __shfl_xor(dl, of, 64);
-        if ((idx % V4) == 0) Ds[row] = dl;         // rows >= N: 0
+        if ((idx % V4) == 0) Ds[row] = -dl;        // rows >= N: 0.  NEGATED: the C operand of the dP products
     }
     for (int row = threadIdx.x; row < NP; row += 256)
-        Ls[row] = row < N ? lse[((long)b * H + h) * N + row] * LOG2E : 1e30f;      // invalid query: P = exp2(s - huge) = 0
+        Ls[row] = row < N ? -lse[((long)b * H + h) * N + row] * LOG2E : -1e30f;    // (negated) invalid query: P = exp2(s - huge) = 0
     if (threadIdx.x < 3 * HD) Cs[threadIdx.x] = 0.f;
     __syncthreads();
 
@@ -598,26 +771,26 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(const QT* __restric
                 qf[kk] = *reinterpret_cast<const bf16x8*>(&Qs[qrow * LD + 16 * kk + 8 * hi]);
                 gf[kk] = *reinterpret_cast<const bf16x8*>(&Gs[qrow * LD + 16 * kk + 8 * hi]);
             }
-            const float Lq = Ls[qrow], dl = Ds[qrow];
+            // S - lse and dP - delta come out of the matrix pipe: -lse / -delta of the lane's query are the C operands
+            const f32x16 negL = bcast16(Ls[qrow]), negD = bcast16(Ds[qrow]);
             f32x16 acc[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[nt] = zero16();
             for (int kt = 0; kt < T; ++kt) {
-                f32x16 sc = zero16(), dp = zero16();
+                f32x16 sc, dp;
 #pragma unroll
                 for (int kk = 0; kk < NKK; ++kk) {
                     const bf16x8 ak = *reinterpret_cast<const bf16x8*>(&Ks[(kt * 32 + l31) * LD + 16 * kk + 8 * hi]);
                     const bf16x8 av = *reinterpret_cast<const bf16x8*>(&Vs[(kt * 32 + l31) * LD + 16 * kk + 8 * hi]);
-                    sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ak, qf[kk], sc, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, gf[kk], dp, 0, 0, 0);
+                    sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ak, qf[kk], kk == 0 ? negL : sc, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, gf[kk], kk == 0 ? negD : dp, 0, 0, 0);
                 }
-                const bool tail = kt * 32 + 32 > N;
+                if (kt * 32 + 32 > N) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float p = __builtin_amdgcn_exp2f(sc[r] - Lq);
-                    if (tail && kt * 32 + crow(r, hi) >= N) p = 0.f;
-                    sc[r] = p * (dp[r] - dl);
+                    for (int r = 0; r < 16; ++r) if (kt * 32 + crow(r, hi) >= N) sc[r] = -1e30f;
                 }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[r] = __builtin_amdgcn_exp2f(sc[r]) * dp[r];
                 bf16x8 dsf[2];
                 pack16(sc, dsf);
 #pragma unroll
@@ -674,29 +847,27 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(const QT* __restric
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) { dk[nt] = zero16(); dv[nt] = zero16(); }
             for (int qt = 0; qt < T; ++qt) {
-                f32x16 sc = zero16(), dp = zero16();
-#pragma unroll
-                for (int kk = 0; kk < NKK; ++kk) {
-                    const bf16x8 aq = *reinterpret_cast<const bf16x8*>(&Qs[(qt * 32 + l31) * LD + 16 * kk + 8 * hi]);
-                    const bf16x8 ag = *reinterpret_cast<const bf16x8*>(&Gs[(qt * 32 + l31) * LD + 16 * kk + 8 * hi]);
-                    sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, kf[kk], sc, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ag, vf[kk], dp, 0, 0, 0);
-                }
-                f32x16 p;
+                f32x16 cL, cD;                               // -lse / -delta of the tile's query rows crow(r, hi): the C operands
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 L4 = *reinterpret_cast<const f32x4*>(&Ls[qt * 32 + 8 * g + 4 * hi]);
                     const f32x4 D4 = *reinterpret_cast<const f32x4*>(&Ds[qt * 32 + 8 * g + 4 * hi]);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float pe = __builtin_amdgcn_exp2f(sc[4 * g + e] - L4[e]);
-                        p[4 * g + e] = pe;
-                        sc[4 * g + e] = pe * (dp[4 * g + e] - D4[e]);
-                    }
+                    for (int e = 0; e < 4; ++e) { cL[4 * g + e] = L4[e]; cD[4 * g + e] = D4[e]; }
                 }
+                f32x16 sc, dp;
+#pragma unroll
+                for (int kk = 0; kk < NKK; ++kk) {
+                    const bf16x8 aq = *reinterpret_cast<const bf16x8*>(&Qs[(qt * 32 + l31) * LD + 16 * kk + 8 * hi]);
+                    const bf16x8 ag = *reinterpret_cast<const bf16x8*>(&Gs[(qt * 32 + l31) * LD + 16 * kk + 8 * hi]);
+                    sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, kf[kk], kk == 0 ? cL : sc, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ag, vf[kk], kk == 0 ? cD : dp, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { sc[r] = __builtin_amdgcn_exp2f(sc[r]); dp[r] *= sc[r]; }
                 bf16x8 pf[2], dsf[2];
-                pack16(p, pf);
-                pack16(sc, dsf);
+                pack16(sc, pf);
+                pack16(dp, dsf);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -764,17 +935,45 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(const QT* __restric
 
 // Returns VITAE_ERR_UNSUPPORTED_SHAPE for head dims without an MFMA instantiation (caller falls back
 // to the fp32 VALU kernels of attention.hip — same results to bf16 round-off).
+// rows (32-row blocks) per wave of the streaming kernels: two blocks halve the LDS fragment reads per MFMA and the workgroup count; one
+// block keeps short sequences spread over more waves.  VITAE_ATTN_RB = 1 / 2 forces it (tools/attn_bench.py).
+static int attn_row_blocks(int N, int head_dim, int which /* 0 fwd, 1 dq, 2 dkv */) {
+    static const int forced = getenv("VITAE_ATTN_RB") ? atoi(getenv("VITAE_ATTN_RB")) : 0;
+    if (forced == 1 || forced == 2) return (forced == 2 && head_dim == 64 && which == 2) ? 1 : forced;
+    (void)N;
+    return 1;   // two blocks per wave (253-256 VGPRs: one wave per SIMD and half the workgroups) measured 177 against 164 us at N = 1729
+}
+
 template <typename QT>
 static int sdpa_mfma_fwd_launch(const QT* qkv, float* o, void* o_bf16, float* lse, int B, int N, int H, int head_dim, void* stream) {
     if (!qkv || !o || !lse || B <= 0 || N <= 0 || H <= 0) return VITAE_ERR_INVALID_ARG;
     if ((((long)H * head_dim) & 7) || ((uintptr_t)qkv & 15) || ((uintptr_t)o & 15)) return VITAE_ERR_UNSUPPORTED_SHAPE;
     const float scale = 1.0f / sqrtf((float)head_dim);
-    dim3 grid(cdiv(N, 128), H, B);
+    // forward variants (VITAE_ATTN_FWD forces one): 0: 1 query block x 1 key tile per step (short sequences); 1: 1 x 2; 2: 2 x 2
+    // (256-key chunks — 1 x 4 and 2 x 2 — measured no faster at N = 1729: 64.0 / 58.7 against 56.9 us; they halve the resident workgroups)
+    static const int forced = getenv("VITAE_ATTN_FWD") ? atoi(getenv("VITAE_ATTN_FWD")) : -1;
+    const int var = forced >= 0 ? forced : (N >= 512 ? (head_dim == 32 ? 2 : 1) : 0);
+    const int qb = var == 2 ? 2 : 1;
+    dim3 grid(cdiv(N, 128 * qb), H, B);
     hipStream_t st = (hipStream_t)stream;
     __bf16* o16 = reinterpret_cast<__bf16*>(o_bf16);
-    if (head_dim == 32) hipLaunchKernelGGL((attn_fwd_mfma_kernel<32, QT>), grid, dim3(256), 0, st, qkv, o, o16, lse, N, H, scale);
-    else if (head_dim == 64) hipLaunchKernelGGL((attn_fwd_mfma_kernel<64, QT>), grid, dim3(256), 0, st, qkv, o, o16, lse, N, H, scale);
-    else return VITAE_ERR_UNSUPPORTED_SHAPE;
+#define VITAE_FWD(HD_, QB_, KT_, CHK_) hipLaunchKernelGGL((attn_fwd_mfma_kernel<HD_, QB_, KT_, CHK_, QT>), grid, dim3(256), 0, st, qkv, o, o16, lse, N, H, scale)
+    if (head_dim == 32) {
+        switch (var) {
+            case 1: VITAE_FWD(32, 1, 2, 128); break;
+            case 2: VITAE_FWD(32, 2, 2, 128); break;
+            default: VITAE_FWD(32, 1, 1, 128); break;
+        }
+    } else if (head_dim == 64) {
+        switch (var) {
+            case 1: VITAE_FWD(64, 1, 2, 128); break;
+            case 2: VITAE_FWD(64, 2, 1, 128); break;
+            default: VITAE_FWD(64, 1, 1, 128); break;
+        }
+    } else {
+        return VITAE_ERR_UNSUPPORTED_SHAPE;
+    }
+#undef VITAE_FWD
     return vitae_launch_status();
 }
 
@@ -803,16 +1002,25 @@ template <typename QT>
 static int sdpa_bwd_two_kernels(const QT* qkv, const float* o, const float* d_o, const float* lse, float* dqkv, __bf16* g16,
                                 float* dqkv_colsum_accum, float* delta_ws, int B, int N, int H, int head_dim, float scale,
                                 hipStream_t st) {
-    dim3 grid(cdiv(N, 128), H, B);
+    const int rq = attn_row_blocks(N, head_dim, 1), rk = attn_row_blocks(N, head_dim, 2);
+    dim3 gq(cdiv(N, 128 * rq), H, B), gk(cdiv(N, 128 * rk), H, B);
+#define VITAE_ATTN_BWD(HD_, RQ_, RK_)                                                                                                       \
+    do {                                                                                                                                   \
+        hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<HD_, RQ_, QT>), gq, dim3(256), 0, st, qkv, o, d_o, lse, dqkv, g16, dqkv_colsum_accum, delta_ws, N, H, scale); \
+        hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<HD_, RK_, QT>), gk, dim3(256), 0, st, qkv, d_o, lse, delta_ws, dqkv, g16, dqkv_colsum_accum, N, H, scale);   \
+    } while (0)
     if (head_dim == 32) {
-        hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<32, QT>), grid, dim3(256), 0, st, qkv, o, d_o, lse, dqkv, g16, dqkv_colsum_accum, delta_ws, N, H, scale);
-        hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<32, QT>), grid, dim3(256), 0, st, qkv, d_o, lse, delta_ws, dqkv, g16, dqkv_colsum_accum, N, H, scale);
+        if (rq == 2 && rk == 2) VITAE_ATTN_BWD(32, 2, 2);
+        else if (rq == 2) VITAE_ATTN_BWD(32, 2, 1);
+        else if (rk == 2) VITAE_ATTN_BWD(32, 1, 2);
+        else VITAE_ATTN_BWD(32, 1, 1);
     } else if (head_dim == 64) {
-        hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<64, QT>), grid, dim3(256), 0, st, qkv, o, d_o, lse, dqkv, g16, dqkv_colsum_accum, delta_ws, N, H, scale);
-        hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<64, QT>), grid, dim3(256), 0, st, qkv, d_o, lse, delta_ws, dqkv, g16, dqkv_colsum_accum, N, H, scale);
+        if (rq == 2) VITAE_ATTN_BWD(64, 2, 1);
+        else VITAE_ATTN_BWD(64, 1, 1);
     } else {
         return VITAE_ERR_UNSUPPORTED_SHAPE;
     }
+#undef VITAE_ATTN_BWD
     return vitae_launch_status();
 }
 
