@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITAE_ABI_VERSION 37
+#define VITAE_ABI_VERSION 38
 
 /* matrix-core arithmetic of the dense contractions */
 #define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
@@ -189,6 +189,15 @@ int vitae_layernorm_fwd(const float* x, const float* w, const float* b, float* y
 int vitae_layernorm_bwd(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
                         float* dx, float* dw, float* db, void* dx_bf16, float* dx_colsum_accum, int M, int D,
                         int dx_accumulate, void* stream);
+/* The same without atomics (round 4): a launch of vitae_layernorm_bwd_part_records(M) workgroups, each leaving its column partials
+ * [d gamma | d beta | colsum(dx)] as one 3 D-float record in part[records][3][D]; vitae_ln_grad_reduce adds the records of n
+ * LayerNorm instances (HOST arrays of pointers / counts; dx_colsum entries may be NULL) into dw / db / dx_colsum in ONE launch,
+ * in a fixed order (bitwise reproducible).  D in {256, 512, 768, 1024}, 16-byte aligned operands. */
+int vitae_layernorm_bwd_part_records(int M);
+int vitae_layernorm_bwd_part(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
+                             float* dx, float* part, void* dx_bf16, int M, int D, int dx_accumulate, void* stream);
+int vitae_ln_grad_reduce(int n, const float* const* part, float* const* dw, float* const* db, float* const* dx_colsum,
+                         const int* records, const int* D, void* stream);
 
 /* ---- attention core  softmax(q k^T / sqrt(hd)) v  (model/vit.py:117-121) -------------------------
  * qkv [B,N,3,H,hd] (output of the qkv Linear, model/vit.py:114), o [B,N,H*hd], lse/delta [B,H,N]. */

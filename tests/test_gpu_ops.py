@@ -325,6 +325,46 @@ def test_layernorm(lib, M, D):
         assert rel_err(dw, wr.grad) < 2e-5 and rel_err(db, br.grad) < 2e-5
 
 
+@pytest.mark.parametrize('M,D', [(440, 768), (868, 512), (3464, 768), (6916, 512), (9, 256), (4100, 1024)])
+def test_layernorm_bwd_partial_records(lib, M, D):
+    """The atomic-free LayerNorm backward: dx / dx16 as the atomic kernel, parameter gradients and colsum(dx) through partial
+    records + vitae_ln_grad_reduce (two instances in one reduce launch, one of them without a column sum); += into the targets;
+    bitwise reproducible."""
+    x, w, dy = gen(M, D, seed=1, scale=2.0) + 0.3, gen(D, seed=2) + 1.0, gen(M, D, seed=4)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), torch.zeros(D, requires_grad=True)
+    F.layer_norm(xr, (D,), wr, br, 1e-6).backward(dy)
+    xd, wd, dyd = dev(x), dev(w), dev(dy)
+    mean = xd.mean(1).contiguous()
+    rstd = (xd.var(1, unbiased=False) + 1e-6).rsqrt().contiguous()
+    G = lib.vitae_layernorm_bwd_part_records(M)
+    assert 1 <= G <= max(1, (M + 7) // 8)
+    base = gen(M, D, seed=5)
+    outs = []
+    for rep in range(2):
+        dx, dx2 = dev(base), torch.empty(M, D, device='cuda')
+        dx16 = torch.empty(M, D, dtype=torch.bfloat16, device='cuda')
+        parts = [torch.full((G * 3 * D,), float('nan'), device='cuda') for _ in range(2)]
+        lib.vitae_layernorm_bwd_part(dyd.data_ptr(), xd.data_ptr(), wd.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
+                                     parts[0].data_ptr(), dx16.data_ptr(), M, D, 1, st())
+        lib.vitae_layernorm_bwd_part(dyd.data_ptr(), xd.data_ptr(), wd.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx2.data_ptr(),
+                                     parts[1].data_ptr(), None, M, D, 0, st())
+        dw, db, cs = (torch.ones(2, D, device='cuda') for _ in range(3))      # the reduce ADDS to what is there
+        u64 = lambda v: np.array(v, dtype=np.uint64)
+        a_p, a_w, a_b = u64([t.data_ptr() for t in parts]), u64([dw[0].data_ptr(), dw[1].data_ptr()]), u64([db[0].data_ptr(), db[1].data_ptr()])
+        a_c = u64([cs[0].data_ptr(), 0])
+        a_g, a_d = np.array([G, G], dtype=np.int32), np.array([D, D], dtype=np.int32)
+        lib.vitae_ln_grad_reduce(2, a_p.ctypes.data, a_w.ctypes.data, a_b.ctypes.data, a_c.ctypes.data, a_g.ctypes.data, a_d.ctypes.data, st())
+        torch.cuda.synchronize()
+        outs.append((dx.clone(), dx2.clone(), dw.clone(), db.clone(), cs.clone()))
+        assert rel_err(dx, xr.grad + base) < 2e-5 and rel_err(dx2, xr.grad) < 2e-5
+        assert torch.equal(dx16, dx.to(torch.bfloat16))
+        for i in range(2):
+            assert rel_err(dw[i] - 1, wr.grad) < 2e-5 and rel_err(db[i] - 1, br.grad) < 2e-5
+        assert rel_err(cs[0] - 1, dx.sum(0)) < 2e-5 and torch.equal(cs[1], torch.ones(D, device='cuda'))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 # --------------------------------------------------------------------------- attention
 @pytest.mark.parametrize('B,N,H,hd', [(8, 55, 12, 64), (4, 217, 16, 32), (2, 17, 3, 16), (1, 130, 2, 64), (2, 70, 2, 128),
                                       (1, 433, 2, 64), (1, 1729, 2, 32)])       # patch-8 sequence lengths

@@ -1,4 +1,6 @@
-"""LayerNorm / colsum kernel timings at the bench shapes (graph replay of 20 launches)."""
+"""LayerNorm kernel timings at the bench shapes (graph replay of 20 launches): forward, the atomic backward, the partial-record
+backward (VITAE_LN_PART_BLOCKS caps its workgroups) and the reduce launch for 10 such LayerNorms; GB/s on the algorithmic bytes."""
+import numpy as np
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -27,7 +29,15 @@ for M, D in ((440, 768), (868, 512), (880, 768), (1736, 512), (3520, 768), (6944
     dw, db, cs = torch.zeros(D, device='cuda'), torch.zeros(D, device='cuda'), torch.zeros(D, device='cuda')
     big = torch.randn(M, 3 * D, device='cuda'); csb = torch.zeros(3 * D, device='cuda')
     P = lambda t: t.data_ptr()
-    print(M, D,
+    G = lib.vitae_layernorm_bwd_part_records(M)
+    parts = [torch.empty(G * 3 * D, device='cuda') for _ in range(10)]
+    u64 = lambda v: np.array(v, dtype=np.uint64)
+    a_p, a_w, a_b, a_c = u64([P(t) for t in parts]), u64([P(dw)] * 10), u64([P(db)] * 10), u64([P(cs)] * 10)
+    a_g, a_d = np.array([G] * 10, dtype=np.int32), np.array([D] * 10, dtype=np.int32)
+    tp = timeit(lambda st: lib.vitae_layernorm_bwd_part(P(dy), P(x), P(w), P(mean), P(rstd), P(dx), P(parts[0]), P(dx16), M, D, 1, st))
+    tr = timeit(lambda st: lib.vitae_ln_grad_reduce(10, a_p.ctypes.data, a_w.ctypes.data, a_b.ctypes.data, a_c.ctypes.data, a_g.ctypes.data, a_d.ctypes.data, st))
+    bwd_bytes = M * D * (4 * 4 + 2)
+    print(M, D, 'records', G, 'bwd-part %.1f (%.0f GB/s)' % (tp, bwd_bytes / tp / 1e3), 'reduce x10 %.1f' % tr,
           'fwd %.1f' % timeit(lambda st: lib.vitae_layernorm_fwd(P(x), P(w), P(b), None, P(y16), P(mean), P(rstd), M, D, 1e-6, st)),
           'bwd %.1f' % timeit(lambda st: lib.vitae_layernorm_bwd(P(dy), P(x), P(w), P(mean), P(rstd), P(dx), P(dw), P(db), P(dx16), P(cs), M, D, 1, st)),
           'colsum[M,3D] %.1f' % timeit(lambda st: lib.vitae_colsum_accum(P(big), 3 * D, P(csb), M, 3 * D, st)),

@@ -105,7 +105,7 @@ class _Lib:
 
 # int-returning entry points whose result is a value, not a status
 _VALUE_RETURNING = {'vitae_abi_version', 'vitae_sdpa_bwd_fused_fits', 'vitae_loss_fwd_bwd_supported', 'vitae_target_edge_supported', 'vitae_ddp_available',
-                    'vitae_ddp_world_size', 'vitae_gemm_glds_bt_choice'}
+                    'vitae_ddp_world_size', 'vitae_gemm_glds_bt_choice', 'vitae_layernorm_bwd_part_records'}
 
 lib = _Lib()
 

@@ -161,6 +161,8 @@ class HipMAEEngine:
         self._taps_c = self.taps.ctypes.data
         self.ws = torch.empty(1 << 24, **f32)   # split-K scratch (64 MiB)
         self.ws16 = torch.zeros(1 << 24, **f32)  # LDS-DMA GEMMs: tile tickets (kept zero by the kernels) + partial tiles
+        self.ln_part_on = os.environ.get('VITAE_LN_PART', '1') != '0'   # LayerNorm backward through partial records (no atomics)
+        self._ln_pending = []
         self.B = None
         self.buf: Dict[str, torch.Tensor] = {}
         # one workspace per (batch, kept patches), kept alive while captured graphs may hold its addresses; evicting one
@@ -374,6 +376,14 @@ class HipMAEEngine:
             # (view 2) sit opposite them contribute nothing.
             self.Mpl = pad(B * Ne)
             b['latent_16'], b['de_16'] = z16(max(self.Mpe, self.Mpl), D), z16(self.Mpl, Dd)
+        if self.ln_part_on:
+            # LayerNorm backward: one record of column partials [d gamma | d beta | colsum(dx)] per workgroup and LayerNorm instance
+            for pre_, depth, M_, d_ in (('blocks.', cfg.depth, Me, D), ('decoder_blocks.', cfg.decoder_depth, Md, Dd)):
+                G = lib.vitae_layernorm_bwd_part_records(M_)
+                for i in range(depth):
+                    b[f'lnpart.{pre_}{i}.norm1.'], b[f'lnpart.{pre_}{i}.norm2.'] = f(G * 3 * d_), f(G * 3 * d_)
+            b['lnpart.norm.'] = f(lib.vitae_layernorm_bwd_part_records(Me) * 3 * D)
+            b['lnpart.decoder_norm.'] = f(lib.vitae_layernorm_bwd_part_records(Md) * 3 * Dd)
         for i in range(cfg.depth):
             b[f'enc{i}.lse'] = f(Be * cfg.num_heads * Ne)
         for i in range(cfg.decoder_depth):
@@ -569,9 +579,34 @@ class HipMAEEngine:
                                 _ptr(mean), _ptr(rstd), M, D, self.cfg.ln_eps, self.stream)
 
     def _ln_bwd(self, dy, x, pre, mean, rstd, dx, M, D, dx_accumulate, dx16=None, dx_colsum=None):
+        """LayerNorm backward.  Default (round 4): no atomics — the launch leaves its d(gamma) / d(beta) / colsum(dx) partials as
+        records in ``ln_part`` and ``_ln_flush`` (once per backward phase) adds the records of every LayerNorm of the phase into the
+        gradient arena with one launch; nothing reads those gradients before the optimiser's tail."""
+        if self.ln_part_on and D in (256, 512, 768, 1024) and self.buf:
+            G = lib.vitae_layernorm_bwd_part_records(M)
+            part = self.buf.get('lnpart.' + pre)
+            if part is None or part.numel() < G * 3 * D:      # (a LayerNorm the workspace does not know: allocated on first use)
+                part = self.buf['lnpart.' + pre] = torch.empty(G * 3 * D, dtype=torch.float32, device=self.device)
+            lib.vitae_layernorm_bwd_part(_ptr(dy), _ptr(x), _ptr(self.p[pre + 'weight']), _ptr(mean), _ptr(rstd), _ptr(dx),
+                                         _ptr(part), _ptr(dx16), M, D, dx_accumulate, self.stream)
+            self._ln_pending.append((part.data_ptr(), self.g[pre + 'weight'].data_ptr(), self.g[pre + 'bias'].data_ptr(),
+                                     dx_colsum.data_ptr() if dx_colsum is not None else 0, G, D))
+            return
         lib.vitae_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(self.p[pre + 'weight']), _ptr(mean), _ptr(rstd), _ptr(dx),
                                 _ptr(self.g[pre + 'weight']), _ptr(self.g[pre + 'bias']), _ptr(dx16), _ptr(dx_colsum),
                                 M, D, dx_accumulate, self.stream)
+
+    def _ln_flush(self):
+        """Add the pending LayerNorm partial records into the gradient arena (end of a backward phase)."""
+        pend = self._ln_pending
+        if not pend:
+            return
+        u64 = lambda k: np.array([t[k] for t in pend], dtype=np.uint64)
+        i32 = lambda k: np.array([t[k] for t in pend], dtype=np.int32)
+        a_p, a_w, a_b, a_c, a_g, a_d = u64(0), u64(1), u64(2), u64(3), i32(4), i32(5)
+        lib.vitae_ln_grad_reduce(len(pend), a_p.ctypes.data, a_w.ctypes.data, a_b.ctypes.data, a_c.ctypes.data, a_g.ctypes.data,
+                                 a_d.ctypes.data, self.stream)
+        self._ln_pending = []
 
     # ------------------------------------------------------------------ bf16-activation GEMM helpers (LDS-DMA kernel)
     def _g16_fwd(self, x16, w, bias, M, N, K, y=None, y16=None, epi=EPI_NONE, aux=None, res=None):
@@ -1061,6 +1096,7 @@ class HipMAEEngine:
                 # the next phase
                 self._lin_bwd_x(b['dph'], p['predictor.0.weight'], b['dlatent'], 2 * self.R, D, D)
                 self._pred_joined = True
+            self._ln_flush()
             self._wg_join()
             return
         lib.vitae_decoder_assemble_bwd(_ptr(b['decdx']), _ptr(b['ids_shuffle']), _ptr(b['de']), _ptr(b.get('de_16')),
@@ -1102,6 +1138,7 @@ class HipMAEEngine:
                          dx_colsum=g[f'blocks.{cfg.depth - 1}.mlp.fc2.bias'])
         else:
             self._ln_bwd(b['dlatent'], b['encx'][cfg.depth], 'norm.', b['lat_mean'], b['lat_rstd'], b['encdx'], Me, D, 0)
+        self._ln_flush()
         self._wg_join()
 
     def _predictor_bwd(self):
@@ -1130,6 +1167,7 @@ class HipMAEEngine:
             else:
                 self._block_bwd(f'blocks.{i}.', f'enc{i}.', 'enc', ex[i], self.Be, self.Ne, cfg.embed_dim, cfg.num_heads,
                                 self.hd, self.Hm)
+        self._ln_flush()
         self._wg_join()
 
     def backward_tail(self):
