@@ -353,7 +353,7 @@ int vitae_target_edge(const float* imgs, float* edge_tgt, const float* taps_host
 /* Both of the above in ONE pass over the prediction (csrc/loss_fused.hip; C = 4): acc[VITAE_ACC_RECON] / acc[VITAE_ACC_EDGE] as
  * vitae_loss_fwd_fused, dpred / dpred_bf16 / nonfinite_flag as vitae_loss_bwd_fused; the unpatchified prediction and its edge map
  * are not produced.  Both MSE terms are linear in their upstream gradient (hp[VITAE_HP_G_RECON], hp[VITAE_HP_G_EDGE]), so the
- * gradient needs no result of the forward.  vitae_loss_fwd_bwd_supported: 1 when the geometry is served (else
+ * gradient needs no result of the forward.  dpred may be NULL when dpred_bf16 is given (the bf16 copy only).  vitae_loss_fwd_bwd_supported: 1 when the geometry is served (else
  * VITAE_ERR_UNSUPPORTED_SHAPE and the caller keeps the two calls above). */
 int vitae_loss_fwd_bwd_supported(int C, int Lz, int Hy, int Wx, int p);
 int vitae_loss_fwd_bwd(const float* pred, long pred_bstride, const float* imgs, const float* mask, const float* edge_tgt,

@@ -593,6 +593,12 @@ def test_loss_chain(lib, C, C_, vol, p):
         assert float(d1[:, 0].abs().max()) == 0.0 and float(flag) == 0.0
         assert rel_err(d1, pr.grad) < 3e-5, rel_err(d1, pr.grad)
         assert torch.equal(d116, d1.to(torch.bfloat16))
+        # bf16 gradient only (what the bf16 step asks for): the same bits, the same sums, no fp32 store
+        d216 = torch.zeros(B, L + 1, P, dtype=torch.bfloat16, device='cuda')
+        acc4 = torch.zeros(C['VITAE_ACC_COUNT'], dtype=torch.float64, device='cuda')
+        lib.vitae_loss_fwd_bwd(pp, pbs, im.data_ptr(), mk.data_ptr(), et.data_ptr(), hp.data_ptr(), None,
+                               d216.data_ptr() + P * 2, flag.data_ptr(), acc4.data_ptr(), msum, B, C_, *vol, p, st())
+        assert torch.equal(d216, d116) and torch.equal(acc4[:2], acc3[:2]) and float(flag) == 0.0
     else:
         assert C_ != 4
 

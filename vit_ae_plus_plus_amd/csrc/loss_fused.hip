@@ -78,6 +78,8 @@ struct RowIdx {
     }
 };
 
+// F32OUT: the fp32 gradient is stored too (false: the bf16 copy only — all the bf16 step consumes; 57 of its 213 MB at batch 4)
+template <bool F32OUT>
 __global__ __launch_bounds__(NT, VITAE_LOSS_MINW) void loss_fwd_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ imgs,
                                                             const float* __restrict__ mask, const float* __restrict__ Et,
                                                             const float* __restrict__ hp, float* __restrict__ dpred,
@@ -230,8 +232,8 @@ __global__ __launch_bounds__(NT, VITAE_LOSS_MINW) void loss_fwd_bwd_kernel(const
                 rc += mflag * ((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]));
                 chk += (val[0] + val[1]) + (val[2] + val[3]);          // non-finite as soon as one stored value is
                 const long doff = dbase + (long)(oq * rstride + orr * rin);
-                *reinterpret_cast<f32x4*>(dpred + doff) = val;
-                if (dpred16) {
+                if (F32OUT) *reinterpret_cast<f32x4*>(dpred + doff) = val;
+                if (!F32OUT || dpred16) {
                     typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
                     *reinterpret_cast<bf4*>(dpred16 + doff) = bf4{(__bf16)val[0], (__bf16)val[1], (__bf16)val[2], (__bf16)val[3]};
                 }
@@ -423,7 +425,7 @@ extern "C" int vitae_loss_fwd_bwd_supported(int C, int Lz, int Hy, int Wx, int p
 extern "C" int vitae_loss_fwd_bwd(const float* pred, long pred_bstride, const float* imgs, const float* mask, const float* edge_tgt,
                                   const float* hp, float* dpred, void* dpred_bf16, float* nonfinite_flag, double* acc,
                                   float mask_sum, int B, int C, int Lz, int Hy, int Wx, int p, void* stream) {
-    if (!pred || !imgs || !mask || !edge_tgt || !hp || !dpred || !acc || B <= 0 || B > 65535 || p <= 0 || mask_sum <= 0.f ||
+    if (!pred || !imgs || !mask || !edge_tgt || !hp || (!dpred && !dpred_bf16) || !acc || B <= 0 || B > 65535 || p <= 0 || mask_sum <= 0.f ||
         Lz % p || Hy % p || Wx % p)
         return VITAE_ERR_INVALID_ARG;
     if (!vitae_loss_fwd_bwd_supported(C, Lz, Hy, Wx, p) || pred_bstride >= (1L << 31) || (pred_bstride & 3) ||
@@ -446,8 +448,12 @@ extern "C" int vitae_loss_fwd_bwd(const float* pred, long pred_bstride, const fl
     nseg = cdiv(Hy, tys);
     g.inv_count = 1.0f / (float)((long)B * g.V);
     g.inv_pm = 1.0f / ((float)g.P * mask_sum);
-    hipLaunchKernelGGL(loss_fwd_bwd_kernel, dim3(g.xtiles * nseg, zt, B), dim3(NT), 0, (hipStream_t)stream, pred, imgs, mask, edge_tgt,
-                       hp, dpred, reinterpret_cast<__bf16*>(dpred_bf16), nonfinite_flag, acc, g);
+    if (dpred)
+        hipLaunchKernelGGL(loss_fwd_bwd_kernel<true>, dim3(g.xtiles * nseg, zt, B), dim3(NT), 0, (hipStream_t)stream, pred, imgs, mask, edge_tgt,
+                           hp, dpred, reinterpret_cast<__bf16*>(dpred_bf16), nonfinite_flag, acc, g);
+    else
+        hipLaunchKernelGGL(loss_fwd_bwd_kernel<false>, dim3(g.xtiles * nseg, zt, B), dim3(NT), 0, (hipStream_t)stream, pred, imgs, mask, edge_tgt,
+                           hp, dpred, reinterpret_cast<__bf16*>(dpred_bf16), nonfinite_flag, acc, g);
     return vitae_launch_status();
 }
 

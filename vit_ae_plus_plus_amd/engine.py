@@ -962,8 +962,10 @@ class HipMAEEngine:
         torch.cuda.current_stream(self.device).wait_stream(self.side)   # edge map of the blurred target is ready
         self._loss_grad_done = bool(loss_with_grad and self.loss_one_pass and lib.vitae_loss_fwd_bwd_supported(C, Lz, Hy, Wx, ps))
         if self._loss_grad_done:
+            # (bf16 step: the gradient leaves in bf16 only — decoder_pred's dgrad / wgrad read that copy, its bias gradient is the
+            # column sum of the same copy)
             lib.vitae_loss_fwd_bwd(pred_ptr, pbs, _ptr(view1), _ptr(b['mask']), _ptr(b['edge_t']), _ptr(self.hp),
-                                   b['dpredfull'].data_ptr() + P * 4, (b['dpred_16'].data_ptr() + P * 2) if a16 else None, None,
+                                   None if a16 else b['dpredfull'].data_ptr() + P * 4, (b['dpred_16'].data_ptr() + P * 2) if a16 else None, None,
                                    _ptr(self.acc), self.mask_sum, B, C, Lz, Hy, Wx, ps, st)
         else:
             lib.vitae_loss_fwd_fused(pred_ptr, pbs, _ptr(view1), _ptr(b['mask']), _ptr(b['edge_t']), _ptr(b['pred_vol']),
@@ -1071,10 +1073,10 @@ class HipMAEEngine:
                                      None, pbs, self.mask_sum, B, C, Lz, Hy, Wx, ps, st)
         if a16:
             if top:
-                # decoder_pred (bias grad from the fp32 dpred), decoder_norm -> dx, dx_16, fc2 bias grad of the last block
-                self._colsum_beside(b['dpredfull'], P, g['decoder_pred.bias'], Md, P, 'dpredfull')
+                # decoder_pred (bias grad = column sum of the bf16 dpred, cls rows zero), decoder_norm -> dx, dx_16, fc2 bias grad of
+                # the last block
                 self._g16_bwd(b['dpred_16'], p['decoder_pred.weight'], b['dn_16'], g['decoder_pred.weight'], Md, self.Mpd, P, Dd,
-                              dx=b['ddn'])
+                              dx=b['ddn'], dy_colsum=g['decoder_pred.bias'])
                 self._ln_bwd(b['ddn'], dx_[nd], 'decoder_norm.', b['dn_mean'], b['dn_rstd'], b['decdx'], Md, Dd, 0,
                              dx16=b['decdx_16'],
                              dx_colsum=g[f'decoder_blocks.{nd - 1}.mlp.fc2.bias'])
