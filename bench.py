@@ -505,6 +505,44 @@ def main():
             el = float(tmax)
         red = model._reducer
         desc = None
+        diag = None
+        if red is not None and red.active:
+            # VERDICT r3 item 7 — make the one hardware run say WHY: per-bucket all-reduce time on the communication stream
+            # (host-issued route: events around every collective), and the same step with the exchange switched off on the same
+            # ranks (replicas drift apart: measurement only, nothing after this leg uses them without a fresh broadcast)
+            diag = {}
+            try:
+                if not native:
+                    red.timing = []
+                    for i in range(10):
+                        step(i)
+                    torch.cuda.synchronize()
+                    rep = red.timing_report()
+                    red.timing = None
+                    diag['allreduce_ms_per_bucket'] = [round(rep.get(b, 0.0), 3) for b in range(len(red.ranges))]
+                    diag['allreduce_ms_per_step'] = round(sum(rep.values()), 3)
+                red.paused = True
+                for i in range(2 * len(batches) + 2):          # graphs of the exchange-free route: staged on first, direct on second sight
+                    step(i)
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                t1 = time.perf_counter()
+                for i in range(10):
+                    step(i)
+                torch.cuda.synchronize()
+                off = (time.perf_counter() - t1) / 10
+                if world > 1:
+                    tt = torch.tensor([off], dtype=torch.float64, device=dev)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    off = float(tt)
+                diag['ms_per_step_exchange_off'] = round(off * 1e3, 3)
+                diag['exposed_exchange_ms_per_step'] = round((el / args.steps - off) * 1e3, 3)
+            except Exception as e:   # diagnostics must never cost the line
+                diag['error'] = repr(e)[:200]
+            finally:
+                red.paused = False
+                red.timing = None
         if red is not None:
             from vit_ae_plus_plus_amd._abi import lib as _lib
             sizes = [sum(e - b for b, e in parts) for parts in red.ranges]
@@ -512,6 +550,8 @@ def main():
                              else 'host-issued: torch.distributed (RCCL process group) between per-phase graphs, on a stream of its own',
                     'wire_dtype': grad_comm, 'buckets': len(red.ranges), 'bucket_mbytes': [round(n * (2 if grad_comm == 'bf16' else 4) / 2**20, 1) for n in sizes],
                     'ms_per_step': round(el / args.steps * 1e3, 3), 'value': round(world * args.batch * args.steps / el, 2)}
+            if diag:
+                desc['diagnostics'] = diag
             if native:
                 desc['vitae_ddp_world_size'] = int(_lib.vitae_ddp_world_size())
                 assert desc['vitae_ddp_world_size'] == world, (desc['vitae_ddp_world_size'], world)
@@ -602,9 +642,15 @@ def main():
                   'note': 'first step (the prediction is ~0 there: the losses barely depend on the model); the trained-model figures '
                           'are in pinned_trajectory. North-star tolerance: reconstruction loss within 1e-4 relative.'}
         try:
-            parity['pinned_trajectory'] = pinned_trajectory_parity(args, dev)
+            parity['pinned_trajectory'] = pt = pinned_trajectory_parity(args, dev)
+            # the terms the headline dtype does NOT hold to 1e-4 once the model has moved, at the top level
+            parity['worst_total_loss_rel_err'] = pt.get('worst_total_loss_rel_err')
+            parity['worst_raw_edge_rel_err'] = pt.get('worst_raw_edge_rel_err')
+            parity['worst_contr_rel_err'] = pt.get('worst_contr_rel_err')
         except Exception as e:
             parity['pinned_trajectory'] = {'error': repr(e)[:200]}
+        parity['parity_note'] = ('cubic volumes (configs 1, 2, 4 and patch 8): pinned to the reference itself (tests/golden); '
+                                 'non-cubic (config 5, 192x192x32): oracle only (the reference cannot construct it)')
 
     if rank == 0:
         out = {'metric': 'pretrain volumes/sec (96^3x4ch, mask 0.75) at 1/2/4/8 MI355X + recon-loss parity',

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITAE_ABI_VERSION 38
+#define VITAE_ABI_VERSION 39
 
 /* matrix-core arithmetic of the dense contractions */
 #define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
@@ -45,8 +45,8 @@ extern "C" {
 #define VITAE_HP_BETA1 1
 #define VITAE_HP_BETA2 2
 #define VITAE_HP_EPS 3
-#define VITAE_HP_BC1 4       /* 1 - beta1^t */
-#define VITAE_HP_BC2 5       /* 1 - beta2^t */
+#define VITAE_HP_BC1 4       /* 1 - beta1^t; <= 0: computed on the device from hp[VITAE_HP_STEP] (< 0: the slot holds -(1 - beta1)) */
+#define VITAE_HP_BC2 5       /* 1 - beta2^t; same convention */
 #define VITAE_HP_GRAD_MUL 6  /* multiplier applied to grads inside AdamW (1/loss_scale; 1 here) */
 #define VITAE_HP_G_RECON 7   /* d total / d recon_loss  */
 #define VITAE_HP_G_EDGE 8    /* d total / d raw_edge_mse (= edge_map_weight * upstream) */
@@ -365,14 +365,17 @@ int vitae_loss_finalize(const double* acc, const float* hp, float* out4, float m
 /* ---- contrastive head ----------------------------------------------------------------------------
  * BatchNorm1d (training) + ReLU of the predictor (model/vit_autoenc.py:263-268); running stats updated
  * in place (momentum 0.1, unbiased variance). */
-int vitae_bn1d_relu_fwd(const float* x, const float* w, const float* b, float* y, float* save_mean, float* save_rstd,
+int vitae_bn1d_relu_fwd(const float* x, const float* w, const float* b, float* y, void* y_bf16 /* optional bf16 copy of y: the next
+                        Linear's GEMM operand */, float* save_mean, float* save_rstd,
                         float* running_mean, float* running_var, long long* num_batches_tracked, int R, int D,
                         float eps, float momentum, void* stream);
 /* the same in eval mode (model.eval()): y = relu((x - running_mean) / sqrt(running_var + eps) * w + b) */
 int vitae_bn1d_relu_eval(const float* x, const float* w, const float* b, const float* running_mean,
                          const float* running_var, float* y, int R, int D, float eps, void* stream);
 int vitae_bn1d_relu_bwd(const float* dy, const float* x, const float* y, const float* w, const float* save_mean,
-                        const float* save_rstd, float* dx, float* dw_accum, float* db_accum, int R, int D, void* stream);
+                        const float* save_rstd, float* dx, void* dx_bf16 /* optional bf16 copy of dx */, float* dw_accum, float* db_accum,
+                        int R, int D, void* stream);
+/* (D % 4 == 0 and 16-byte aligned operands: the kernels move float4 column groups) */
 /* contr = contr_w * (-(mean cos(p1,z2) + mean cos(p2,z1))/2)  (utils/train_one_epoch.py:113-114) */
 int vitae_cosine_loss_fwd(const float* p1, const float* z2, const float* p2, const float* z1, double* acc,
                           const float* hp, float* out1, int R, int D, void* stream);

@@ -55,3 +55,9 @@ def test_bench_times_both_exchange_routes_on_a_world_of_one():
     assert nat['vitae_ddp_world_size'] == 1 and d['config']['rccl_ranks'] == 1
     assert a['ms_per_step'] <= b['ms_per_step'] and abs(d['ms_per_step'] - a['ms_per_step']) < 1e-3
     assert a['wire_dtype'] == 'bf16' and len(a['bucket_mbytes']) == a['buckets']
+    # the diagnostics of the one hardware run: per-bucket all-reduce time (host-issued route), the step with the exchange off
+    host = a if a['route'].startswith('host-issued') else b
+    dg = host['diagnostics']
+    assert 'error' not in dg, dg
+    assert len(dg['allreduce_ms_per_bucket']) == host['buckets'] and dg['ms_per_step_exchange_off'] > 0
+    assert 'exposed_exchange_ms_per_step' in dg and 'ms_per_step_exchange_off' in nat['diagnostics']

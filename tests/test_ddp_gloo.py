@@ -132,6 +132,89 @@ def test_bucketed_allreduce_world2_gloo():
     assert all(r[1] == 'ok' for r in res), res
 
 
+def _worker4(rank, world, port, q):
+    """World of four, the data-parallel DEFAULTS: four exchange buckets with block cuts 0,1,4,8,12 (the last bucket only block 0 +
+    the patch embedding), bf16 wire, a two-part decoder (VITAE_DEC_CHUNKS=2: decoder_pred + top blocks + predictor exchanged
+    while the bottom blocks are still in their backward)."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import types
+        from oracle import mae_ref as R
+        from vit_ae_plus_plus_amd import ddp
+        from vit_ae_plus_plus_amd.engine import HipMAEEngine
+        cfg = R.RefConfig(volume_size=(16, 16, 16), patch_size=4, in_chans=1, embed_dim=24, depth=12, num_heads=2,
+                          decoder_embed_dim=24, decoder_depth=4, decoder_num_heads=2, contrastive=True)
+        sd = R.init_state_dict(cfg, seed=0)
+
+        class FakeEngine:
+            pass
+        eng = FakeEngine()
+        eng.cfg = cfg
+        names = [k for k in sd if R.is_trainable(k)]
+        mats = [k for k in names if not (sd[k].ndim <= 1 or k.endswith('.bias')) and k not in ('cls_token', 'mask_token')]
+        toks = [k for k in names if k in ('cls_token', 'mask_token')]
+        vecs = [k for k in names if sd[k].ndim <= 1 or k.endswith('.bias')]
+        eng.layout, off = {}, 0
+        for k in mats + toks + vecs:
+            if toks and k == toks[0]:
+                eng.tok_off = off
+            if k == vecs[0]:
+                eng.vec_off = off
+            eng.layout[k] = (off, tuple(sd[k].shape))
+            off += (sd[k].numel() + 3) // 4 * 4
+        eng.n_total = off
+        for name in ('enc_chunk_bounds', 'set_backward_chunks', 'set_decoder_chunks'):
+            setattr(eng, name, types.MethodType(getattr(HipMAEEngine, name), eng))
+        eng.enc_chunks, eng.enc_cuts, eng.dec_chunks = 3, None, 1
+        os.environ['VITAE_DEC_CHUNKS'] = '2'
+        from vit_ae_plus_plus_amd.model.vit_autoenc import MaskedAutoencoderViT
+        MaskedAutoencoderViT._set_exchange_buckets(eng, None)           # the data-parallel default cuts
+        assert eng.enc_chunks == 4 and eng.enc_cuts == [0, 1, 4, 8, 12] and eng.dec_chunks == 2
+        eng.dec_cut = cfg.decoder_depth // 2
+        ranges = ddp.engine_bucket_ranges(eng)
+        assert len(ranges) == 2 + 4 + 1                                  # two decoder buckets, four encoder buckets, tokens + vectors
+        covered = sorted(ranges)
+        assert covered[0][0] == 0 and covered[-1][1] == off and all(a[1] == b[0] for a, b in zip(covered, covered[1:])), covered
+        bounds = eng.enc_chunk_bounds()
+        assert len(bounds) == 4 and bounds[-1] == (0, 0), bounds          # the LAST encoder bucket: block 0 (+ the patch embedding)
+        g = torch.Generator().manual_seed(100 + rank)
+        local = torch.randn(off, generator=g) / world
+        flat = local.clone()
+        red = ddp.GradBucketReducer(flat, ranges, comm_dtype=torch.bfloat16)
+        assert red.world_size == world
+        for b in range(len(ranges)):
+            red.launch(b)
+            red.wait_bucket(b, copy_back=True)
+        red.wait()
+        gathered = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        want = sum(gathered)
+        assert float((flat - want).norm() / want.norm()) < 1e-2
+        both = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(both, flat)
+        assert all(torch.equal(both[0], t) for t in both[1:])            # every replica holds the same reduced arena
+        q.put((rank, 'ok'))
+    except Exception:   # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_default_buckets_bf16_wire_world4_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker4, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == 'ok' for r in res), res
+
+
 def test_single_process_reducer_is_a_noop():
     from vit_ae_plus_plus_amd import ddp
     flat = torch.arange(10.0)

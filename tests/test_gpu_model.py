@@ -762,7 +762,10 @@ def test_native_rccl_exchange_inside_the_step_graph(comm, use_graph):
         if ddp_on and use_graph:
             assert all(len(g) == 1 for g in runner.graphs.values())      # ONE graph per step, collectives inside
         outs.append(({k: v.detach().clone() for k, v in model.state_dict().items()}, eng.losses.cpu().tolist()))
-    lib.vitae_ddp_destroy()
+        if ddp_on:
+            del runner
+            model.disable_data_parallel()      # graphs first, then the communicator they were captured with
+            assert lib.vitae_ddp_world_size() == 0
     (a, la), (b, lb) = outs
     close(lb[0], la[0], 2e-3 if comm else 1e-5, 1e-7)
     close(lb[5], la[5], 2e-2 if comm else 1e-4, 1e-7)          # grad norm
@@ -772,4 +775,39 @@ def test_native_rccl_exchange_inside_the_step_graph(comm, use_graph):
         err = float((a[k].double() - b[k].double()).norm() / upd)
         assert err < (0.1 if comm else 2e-3), (k, err)
 
+
+def test_native_exchange_refuses_more_fork_points_than_its_event_ring():
+    """csrc/ddp.hip keeps 64 fork / join events; a captured step that needs more must be refused loudly (VITAE_ERR_UNSUPPORTED_SHAPE),
+    not served by silently recycling an event that an earlier node of the same capture still depends on.  Eager launches may wrap."""
+    import ctypes
+    from vit_ae_plus_plus_amd._abi import lib, VitaeError
+    assert lib.vitae_ddp_available()
+    uid = ctypes.create_string_buffer(128)
+    lib.vitae_ddp_unique_id(uid)
+    lib.vitae_ddp_init(uid, 1, 0)
+    try:
+        buf = torch.ones(1024, device='cuda')
+        main, comm = torch.cuda.Stream(), torch.cuda.Stream()
+        for _ in range(70):                                   # eager: the ring wraps, every call is served
+            lib.vitae_ddp_allreduce_bucket(buf.data_ptr(), buf.numel(), 0, main.cuda_stream, comm.cuda_stream)
+        lib.vitae_ddp_wait(main.cuda_stream, comm.cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(buf, torch.ones_like(buf))         # SUM over one rank
+        g = torch.cuda.CUDAGraph()
+        served, refused = 0, None
+        with torch.cuda.graph(g, stream=main, capture_error_mode='thread_local'):
+            for i in range(80):
+                try:
+                    lib.vitae_ddp_allreduce_bucket(buf.data_ptr(), buf.numel(), 0, main.cuda_stream, comm.cuda_stream)
+                    served += 1
+                except VitaeError as e:
+                    refused = str(e)
+                    break
+            main.wait_stream(comm)                            # join the side stream so that the capture can end
+        assert served == 64 and refused is not None and 'VITAE_ERR_UNSUPPORTED_SHAPE' in refused, (served, refused)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(buf, torch.ones_like(buf))
+    finally:
+        lib.vitae_ddp_destroy()
 

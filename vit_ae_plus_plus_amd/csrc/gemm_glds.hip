@@ -646,11 +646,13 @@ inline BtPlan bt_plan(int M, int N, int K, int a_kc, int b_kc, bool allow_split,
         if (g_bt_mode >= 0 && id != g_bt_mode) continue;
         int bm, bn;
         bt_tile_dims(id, bm, bn);
-        if (M < bm / 2 || N < bn / 2) continue;
+        // (a FORCED tile — tests, tools — is held to what the kernel itself needs: two k-tiles per split, any M / N)
+        const bool forced = g_bt_mode >= 0;
+        if (!forced && (M < bm / 2 || N < bn / 2)) continue;
         const long tiles = (long)cdiv(M, bm) * cdiv(N, bn);
         for (int s = 1; s <= (id == 3 && allow_split ? 8 : 1); ++s) {
             const int kps = cdiv(cdiv(K, s), BK) * BK;
-            if (cdiv(K, kps) != s || kps < 4 * BK || K - (s - 1) * kps < 2 * BK) continue;
+            if (cdiv(K, kps) != s || kps < (forced ? 2 : 4) * BK || K - (s - 1) * kps < 2 * BK) continue;
             if (s > 1 && (tiles > VITAE_GLDS_TICKETS || (cap >= 0 && VITAE_GLDS_TICKETS + tiles * s * bm * bn > cap))) continue;
             const double wgs = (double)tiles * s, slots = id == 0 ? 256 : 512;
             const double rounds = (double)cdiv((long)wgs, (long)slots);

@@ -5,6 +5,7 @@
 // statistics by wave shuffles; parameter gradients are wave-partial sums + one atomicAdd per
 // column per block into the (pre-zeroed) gradient arena.
 #include <cstdlib>
+#include <initializer_list>
 #include "common.hpp"
 #include "vitae_hip.h"
 
@@ -476,51 +477,87 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ d
 }
 
 // ------------------------------------------------------------------ BatchNorm1d (+ReLU), training mode
-// Block = BN_COLS feature columns x BN_GRPS row groups (256 threads): rows are strided over the groups,
-// column partials are combined through LDS.  R rows (R = B * Ne = 220 at config 2).  Two passes
-// (mean, then centred variance) like ATen's CPU batch_norm.  Saves mean / rstd, updates the running
-// stats with momentum and the unbiased variance (nn.BatchNorm1d semantics).
-constexpr int BN_COLS = 16, BN_GRPS = 16;   // 16 feature columns x 16 row groups per 256-thread block: 48 blocks at D = 768
+// R rows (R = B * Ne tokens of one view: 220 at config 2, 1760 at batch 32) x D features.  Round 4: a workgroup owns 64 feature
+// columns (16 lanes x float4: 256-byte row pieces) and its 16 row groups walk the rows with four loads in flight; the statistics
+// meet in LDS.  Two passes (mean, then centred variance) like ATen's CPU batch_norm; saves mean / rstd, updates the running stats
+// with momentum and the unbiased variance (nn.BatchNorm1d semantics).  Optional bf16 copy of the output (the next Linear's GEMM
+// operand).  The round-3 kernels read 64-byte row pieces with one load in flight on 48 workgroups: 124 / 235 us at [1760, 768].
+constexpr int BN_CG = 16, BN_RG = 16, BN_COLS = 4 * BN_CG;     // 16 column groups of 4 x 16 row groups = 256 threads, 64 columns
 
-__device__ __forceinline__ float bn_col_reduce(float v, float (*red)[BN_COLS], int col, int grp) {
+__device__ __forceinline__ f32x4 bn_col_reduce4(f32x4 v, f32x4 (*red)[BN_CG], int cg, int rg) {
     __syncthreads();
-    red[grp][col] = v;
+    red[rg][cg] = v;
     __syncthreads();
-    float s = 0.f;
+    f32x4 s = red[0][cg];
 #pragma unroll
-    for (int g = 0; g < BN_GRPS; ++g) s += red[g][col];
+    for (int g = 1; g < BN_RG; ++g) s += red[g][cg];
     return s;
 }
 
 __global__ __launch_bounds__(256) void bn1d_relu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                            const float* __restrict__ b, float* __restrict__ y,
+                                                            const float* __restrict__ b, float* __restrict__ y, __bf16* __restrict__ y16,
                                                             float* __restrict__ save_mean, float* __restrict__ save_rstd,
                                                             float* __restrict__ run_mean, float* __restrict__ run_var,
                                                             long long* __restrict__ num_batches_tracked,
                                                             int R, int D, float eps, float momentum) {
-    __shared__ float red[BN_GRPS][BN_COLS];
+    __shared__ f32x4 red[BN_RG][BN_CG];
     if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
-    const int col = threadIdx.x % BN_COLS, grp = threadIdx.x / BN_COLS;
-    const int c = blockIdx.x * BN_COLS + col;
-    const bool ok = c < D;
-    float s = 0.f;
-    if (ok) for (int r = grp; r < R; r += BN_GRPS) s += x[(long)r * D + c];
-    const float mean = bn_col_reduce(s, red, col, grp) / R;
-    float q = 0.f;
-    if (ok) for (int r = grp; r < R; r += BN_GRPS) { const float d = x[(long)r * D + c] - mean; q += d * d; }
-    q = bn_col_reduce(q, red, col, grp);
-    if (!ok) return;
-    const float rstd = rsqrtf(q / R + eps);
-    const float g = w[c], be = b[c];
-    for (int r = grp; r < R; r += BN_GRPS) {
-        const float v = (x[(long)r * D + c] - mean) * rstd * g + be;
-        y[(long)r * D + c] = v > 0.f ? v : 0.f;
+    const int cg = threadIdx.x % BN_CG, rg = threadIdx.x / BN_CG;
+    const int c = blockIdx.x * BN_COLS + 4 * cg;
+    const bool ok = c < D;                                  // D % 4 == 0 (launcher)
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 s = z;
+    if (ok) {
+        int r = rg;
+        for (; r + 3 * BN_RG < R; r += 4 * BN_RG) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(x + (long)(r + u * BN_RG) * D + c);
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+        for (; r < R; r += BN_RG) s += *reinterpret_cast<const f32x4*>(x + (long)r * D + c);
     }
-    if (grp == 0) {
-        save_mean[c] = mean; save_rstd[c] = rstd;
+    const f32x4 mean = bn_col_reduce4(s, red, cg, rg) / (float)R;
+    f32x4 q = z;
+    if (ok) {
+        int r = rg;
+        for (; r + 3 * BN_RG < R; r += 4 * BN_RG) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(x + (long)(r + u * BN_RG) * D + c);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const f32x4 d = v[u] - mean; q += d * d; }
+        }
+        for (; r < R; r += BN_RG) { const f32x4 d = *reinterpret_cast<const f32x4*>(x + (long)r * D + c) - mean; q += d * d; }
+    }
+    q = bn_col_reduce4(q, red, cg, rg);
+    if (!ok) return;
+    f32x4 rstd;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) rstd[e] = rsqrtf(q[e] / R + eps);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(w + c), be = *reinterpret_cast<const f32x4*>(b + c);
+    const f32x4 sc = rstd * g;
+    for (int r = rg; r < R; r += BN_RG) {
+        f32x4 v = (*reinterpret_cast<const f32x4*>(x + (long)r * D + c) - mean) * sc + be;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        *reinterpret_cast<f32x4*>(y + (long)r * D + c) = v;
+        if (y16) {
+            bf16x4 h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[e] = (__bf16)v[e];
+            *reinterpret_cast<bf16x4*>(y16 + (long)r * D + c) = h;
+        }
+    }
+    if (rg == 0) {
+        *reinterpret_cast<f32x4*>(save_mean + c) = mean;
+        *reinterpret_cast<f32x4*>(save_rstd + c) = rstd;
         if (run_mean) {
-            run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
-            run_var[c] = (1.f - momentum) * run_var[c] + momentum * (q / (R > 1 ? R - 1 : 1));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                run_mean[c + e] = (1.f - momentum) * run_mean[c + e] + momentum * mean[e];
+                run_var[c + e] = (1.f - momentum) * run_var[c + e] + momentum * (q[e] / (R > 1 ? R - 1 : 1));
+            }
         }
     }
 }
@@ -537,32 +574,71 @@ __global__ __launch_bounds__(256) void bn1d_relu_eval_kernel(const float* __rest
     y[i] = v > 0.f ? v : 0.f;
 }
 
-// dy arrives for the ReLU output y; ReLU mask = (y > 0).  dx = w*rstd*(g - mean(g) - xhat*mean(g*xhat)).
+// dy arrives for the ReLU output y; ReLU mask = (y > 0).  dx = w*rstd*(g - mean(g) - xhat*mean(g*xhat)).  Optional bf16 copy of dx.
 __global__ __launch_bounds__(256) void bn1d_relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ y, const float* __restrict__ w,
                                                             const float* __restrict__ save_mean,
-                                                            const float* __restrict__ save_rstd, float* __restrict__ dx,
+                                                            const float* __restrict__ save_rstd, float* __restrict__ dx, __bf16* __restrict__ dx16,
                                                             float* __restrict__ dw, float* __restrict__ db, int R, int D) {
-    __shared__ float red[BN_GRPS][BN_COLS];
-    const int col = threadIdx.x % BN_COLS, grp = threadIdx.x / BN_COLS;
-    const int c = blockIdx.x * BN_COLS + col;
+    __shared__ f32x4 red[BN_RG][BN_CG];
+    const int cg = threadIdx.x % BN_CG, rg = threadIdx.x / BN_CG;
+    const int c = blockIdx.x * BN_COLS + 4 * cg;
     const bool ok = c < D;
-    const float mean = ok ? save_mean[c] : 0.f, rstd = ok ? save_rstd[c] : 0.f, g = ok ? w[c] : 0.f;
-    float s1 = 0.f, s2 = 0.f;
-    if (ok) for (int r = grp; r < R; r += BN_GRPS) {
-        const long i = (long)r * D + c;
-        const float d = y[i] > 0.f ? dy[i] : 0.f;
-        s1 += d; s2 += d * (x[i] - mean) * rstd;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 mean = ok ? *reinterpret_cast<const f32x4*>(save_mean + c) : z, rstd = ok ? *reinterpret_cast<const f32x4*>(save_rstd + c) : z;
+    const f32x4 g = ok ? *reinterpret_cast<const f32x4*>(w + c) : z;
+    f32x4 s1 = z, s2 = z;
+    if (ok) {
+        int r = rg;
+        for (; r + BN_RG < R; r += 2 * BN_RG) {
+            f32x4 yv[2], dv[2], xv[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const long i = (long)(r + u * BN_RG) * D + c;
+                yv[u] = *reinterpret_cast<const f32x4*>(y + i); dv[u] = *reinterpret_cast<const f32x4*>(dy + i); xv[u] = *reinterpret_cast<const f32x4*>(x + i);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = yv[u][e] > 0.f ? dv[u][e] : 0.f;
+                    s1[e] += d; s2[e] += d * (xv[u][e] - mean[e]) * rstd[e];
+                }
+        }
+        for (; r < R; r += BN_RG) {
+            const long i = (long)r * D + c;
+            const f32x4 yv = *reinterpret_cast<const f32x4*>(y + i), dv = *reinterpret_cast<const f32x4*>(dy + i), xv = *reinterpret_cast<const f32x4*>(x + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = yv[e] > 0.f ? dv[e] : 0.f;
+                s1[e] += d; s2[e] += d * (xv[e] - mean[e]) * rstd[e];
+            }
+        }
     }
-    s1 = bn_col_reduce(s1, red, col, grp);
-    s2 = bn_col_reduce(s2, red, col, grp);
+    s1 = bn_col_reduce4(s1, red, cg, rg);
+    s2 = bn_col_reduce4(s2, red, cg, rg);
     if (!ok) return;
-    if (grp == 0) { atomicAdd(dw + c, s2); atomicAdd(db + c, s1); }
-    const float m1 = s1 / R, m2 = s2 / R;
-    for (int r = grp; r < R; r += BN_GRPS) {
+    if (rg == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { atomicAdd(dw + c + e, s2[e]); atomicAdd(db + c + e, s1[e]); }
+    }
+    const f32x4 m1 = s1 / (float)R, m2 = s2 / (float)R;
+    for (int r = rg; r < R; r += BN_RG) {
         const long i = (long)r * D + c;
-        const float d = y[i] > 0.f ? dy[i] : 0.f;
-        dx[i] = g * rstd * (d - m1 - (x[i] - mean) * rstd * m2);
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(y + i), dv = *reinterpret_cast<const f32x4*>(dy + i), xv = *reinterpret_cast<const f32x4*>(x + i);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = yv[e] > 0.f ? dv[e] : 0.f;
+            o[e] = g[e] * rstd[e] * (d - m1[e] - (xv[e] - mean[e]) * rstd[e] * m2[e]);
+        }
+        *reinterpret_cast<f32x4*>(dx + i) = o;
+        if (dx16) {
+            bf16x4 h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[e] = (__bf16)o[e];
+            *reinterpret_cast<bf16x4*>(dx16 + i) = h;
+        }
     }
 }
 
@@ -664,13 +740,20 @@ extern "C" int vitae_colsum_accum(const float* dy, long ld, float* out, int M, i
     return vitae_launch_status();
 }
 
-extern "C" int vitae_bn1d_relu_fwd(const float* x, const float* w, const float* b, float* y, float* save_mean,
+static bool bn_vec_ok(int D, std::initializer_list<const void*> ptrs) {
+    if (D & 3) return false;
+    for (const void* q : ptrs) if ((uintptr_t)q & 15) return false;
+    return true;
+}
+
+extern "C" int vitae_bn1d_relu_fwd(const float* x, const float* w, const float* b, float* y, void* y_bf16, float* save_mean,
                                    float* save_rstd, float* running_mean, float* running_var,
                                    long long* num_batches_tracked, int R, int D, float eps, float momentum,
                                    void* stream) {
     if (!x || !w || !b || !y || !save_mean || !save_rstd || R <= 0 || D <= 0) return VITAE_ERR_INVALID_ARG;
+    if (!bn_vec_ok(D, {x, w, b, y, save_mean, save_rstd}) || ((uintptr_t)y_bf16 & 7)) return VITAE_ERR_UNSUPPORTED_SHAPE;
     hipLaunchKernelGGL(bn1d_relu_fwd_kernel, dim3(cdiv(D, BN_COLS)), dim3(256), 0, (hipStream_t)stream, x, w, b, y,
-                       save_mean, save_rstd, running_mean, running_var, num_batches_tracked, R, D, eps, momentum);
+                       reinterpret_cast<__bf16*>(y_bf16), save_mean, save_rstd, running_mean, running_var, num_batches_tracked, R, D, eps, momentum);
     return vitae_launch_status();
 }
 
@@ -684,11 +767,12 @@ extern "C" int vitae_bn1d_relu_eval(const float* x, const float* w, const float*
 }
 
 extern "C" int vitae_bn1d_relu_bwd(const float* dy, const float* x, const float* y, const float* w,
-                                   const float* save_mean, const float* save_rstd, float* dx, float* dw,
+                                   const float* save_mean, const float* save_rstd, float* dx, void* dx_bf16, float* dw,
                                    float* db, int R, int D, void* stream) {
     if (!dy || !x || !y || !w || !save_mean || !save_rstd || !dx || !dw || !db || R <= 0 || D <= 0)
         return VITAE_ERR_INVALID_ARG;
+    if (!bn_vec_ok(D, {dy, x, y, w, save_mean, save_rstd, dx}) || ((uintptr_t)dx_bf16 & 7)) return VITAE_ERR_UNSUPPORTED_SHAPE;
     hipLaunchKernelGGL(bn1d_relu_bwd_kernel, dim3(cdiv(D, BN_COLS)), dim3(256), 0, (hipStream_t)stream, dy, x, y, w,
-                       save_mean, save_rstd, dx, dw, db, R, D);
+                       save_mean, save_rstd, dx, reinterpret_cast<__bf16*>(dx_bf16), dw, db, R, D);
     return vitae_launch_status();
 }

@@ -42,6 +42,14 @@ __global__ void grad_norm_finalize_kernel(const double* __restrict__ acc, float*
     if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = (float)sqrt(acc[VITAE_ACC_GRADSQ]);
 }
 
+// 1 - beta^t on the device.  A NEGATIVE slot carries -(1 - beta) from the host's double (relative error 6e-8; fp32(0.999) itself is
+// 1.3e-8 off, which is 1.3e-5 of 1 - 0.999^t for small t): 1 - beta^t = -expm1(t log1p(-(1 - beta))).  Slot == 0: from fp32 beta.
+__device__ __forceinline__ void device_bias_corrections(float b1, float b2, float t, float& bc1, float& bc2) {
+    const float omb1 = bc1 < 0.f ? -bc1 : 1.f - b1, omb2 = bc2 < 0.f ? -bc2 : 1.f - b2;
+    bc1 = -expm1f(t * log1pf(-omb1));
+    bc2 = -expm1f(t * log1pf(-omb2));
+}
+
 // torch.optim.AdamW (single-tensor form): p *= 1 - lr*wd; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
 // p -= (lr / bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
 template <bool NT, typename G, int U = 8>
@@ -52,10 +60,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     if (gnorm) { const float gn = gnorm[0]; if (!(gn == gn) || fabsf(gn) == INFINITY) return; }
     const float lr = hp[VITAE_HP_LR], b1 = hp[VITAE_HP_BETA1], b2 = hp[VITAE_HP_BETA2], eps = hp[VITAE_HP_EPS];
     float bc1 = hp[VITAE_HP_BC1], bc2 = hp[VITAE_HP_BC2];
-    if (bc1 == 0.f) {            // the host left the bias corrections to the device: t = applied steps + 1 (vitae_hip.h VITAE_HP_STEP)
+    if (bc1 <= 0.f) {            // the host left the bias corrections to the device: t = applied steps + 1 (vitae_hip.h VITAE_HP_STEP)
         const float t = hp[VITAE_HP_STEP] + 1.f;
-        bc1 = 1.f - powf(b1, t);
-        bc2 = 1.f - powf(b2, t);
+        device_bias_corrections(b1, b2, t, bc1, bc2);
     }
     const float sq_bc2 = sqrtf(bc2);
     const float gs = hp[VITAE_HP_GRAD_MUL];
@@ -162,10 +169,9 @@ __global__ __launch_bounds__(256) void opt_tail_adamw_kernel(float* __restrict__
     if (finite) {
         const float lr = hp[VITAE_HP_LR], b1 = hp[VITAE_HP_BETA1], b2 = hp[VITAE_HP_BETA2], eps = hp[VITAE_HP_EPS];
         float bc1 = hp[VITAE_HP_BC1], bc2 = hp[VITAE_HP_BC2];
-        if (bc1 == 0.f) {
+        if (bc1 <= 0.f) {
             const float t = hp[VITAE_HP_STEP] + 1.f;
-            bc1 = 1.f - powf(b1, t);
-            bc2 = 1.f - powf(b2, t);
+            device_bias_corrections(b1, b2, t, bc1, bc2);
         }
         const float sq_bc2 = sqrtf(bc2), gs = hp[VITAE_HP_GRAD_MUL], step = lr / bc1;
         const long n = n_decay + n_plain;                  // both segment lengths are multiples of 4 (arena alignment)

@@ -159,6 +159,10 @@ class GradBucketReducer:
         # queue the all-reduce kernel occupies, is ours to choose: ``pick_streams``); None = asynchronous Work objects
         # (CPU / gloo, where there is no stream)
         self.comm_stream = torch.cuda.Stream(device=flat.device) if flat.is_cuda else None
+        # diagnostics (bench.py --gpus N): ``timing`` = a list collects (bucket, start event, end event) around every all-reduce on
+        # the communication stream; ``paused`` switches the exchange off (replicas drift apart: measurement only)
+        self.timing: Optional[list] = None
+        self.paused = False
 
     @property
     def world_size(self) -> int:
@@ -166,7 +170,16 @@ class GradBucketReducer:
 
     @property
     def active(self) -> bool:
+        if self.paused:
+            return False
         return self.world_size > 1 or (self.force and dist.is_available() and dist.is_initialized())
+
+    def timing_report(self):
+        """-> {bucket: mean milliseconds of its all-reduce on the communication stream} from the events collected so far."""
+        out = {}
+        for b, e0, e1 in self.timing or []:
+            out.setdefault(b, []).append(e0.elapsed_time(e1))
+        return {b: sum(v) / len(v) for b, v in sorted(out.items())}
 
     def launch(self, bucket: int):
         """Issue the all-reduce of bucket ``bucket`` (non-blocking; ordered after work already enqueued
@@ -185,18 +198,24 @@ class GradBucketReducer:
                             a, b = max(cs, s), min(ce, e)
                             if b > a:
                                 self.wire[a:b].copy_(self.flat[a:b])
-                    work = self._all_reduce(self.wire[s:e])
+                    work = self._all_reduce(self.wire[s:e], bucket)
                 else:
-                    work = self._all_reduce(self.flat[s:e])
+                    work = self._all_reduce(self.flat[s:e], bucket)
                 self.pending.append((work, s, e, bucket))
 
-    def _all_reduce(self, t: torch.Tensor):
+    def _all_reduce(self, t: torch.Tensor, bucket: int = -1):
         if self.comm_stream is None:
             return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         cs = self.comm_stream
         cs.wait_stream(torch.cuda.current_stream(t.device))      # ordered after the kernels that produced the bucket
         with torch.cuda.stream(cs):
+            if self.timing is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            if self.timing is not None:
+                e1.record()
+                self.timing.append((bucket, e0, e1))
             if self._model is not None:
                 self._model.occupy(t.numel() * t.element_size())
             ev = torch.cuda.Event()
@@ -284,7 +303,7 @@ class RcclBucketReducer(GradBucketReducer):
 
     @property
     def active(self) -> bool:
-        return self._world > 1 or self.force
+        return (self._world > 1 or self.force) and not self.paused
 
     def launch(self, bucket: int):
         if not self.active:

@@ -150,10 +150,21 @@ class HipMAEEngine:
         # the steps it has launched (step_seq_host): no host-to-device copy sits between two graph replays.  Everything else
         # that reads hp (generic autograd route, stand-alone forward) gets it by ``flush_hparams`` (an ordinary copy).
         self.hp_ring = torch.zeros(16, _C['VITAE_HP_COUNT'], dtype=torch.float32).pin_memory()
+        # staging ring of ``flush_hparams`` (launches outside the fused step, where step_seq_host does not advance): every flush
+        # takes the NEXT slot, so a copy still in flight is never rewritten by the following set_hparams / flush
+        self.hp_stage = torch.zeros(16, _C['VITAE_HP_COUNT'], dtype=torch.float32).pin_memory()
+        self._hp_stage_i = 0
         self.step_seq_host = 0
         self.step_seq = torch.zeros(1, dtype=torch.int64, device=device)
         self._hp_dirty = True
-        self.noise_seed = int(torch.initial_seed()) & ((1 << 63) - 1)
+        # Masking noise of the fused step (vit_autoenc.py:139's torch.rand): Philox4x32-10 keyed by (noise_seed, step_seq) inside the
+        # step's first launch — a DIFFERENT random stream from torch's generator (documented deviation; injected noise reproduces
+        # the reference bit for bit).  The seed follows torch's: ``_noise_seed_now`` re-derives it from torch.initial_seed() and the
+        # data-parallel rank whenever the user has reseeded (a manual_seed after the first step takes effect at the next capture /
+        # eager launch; ranks that did not seed with seed + rank still draw different masks).
+        self._seed_src = None
+        self.noise_seed = 0
+        self._noise_seed_now()
         self.hp = torch.zeros(_C['VITAE_HP_COUNT'], **f32)
         self.acc = torch.zeros(_C['VITAE_ACC_COUNT'], dtype=torch.float64, device=device)
         self.losses = torch.zeros(8, **f32)   # [loss, raw_edge, recon, percep, contr, grad_norm, -, -]
@@ -161,7 +172,13 @@ class HipMAEEngine:
         self._taps_c = self.taps.ctypes.data
         self.ws = torch.empty(1 << 24, **f32)   # split-K scratch (64 MiB)
         self.ws16 = torch.zeros(1 << 24, **f32)  # LDS-DMA GEMMs: tile tickets (kept zero by the kernels) + partial tiles
-        self.ln_part_on = os.environ.get('VITAE_LN_PART', '1') != '0'   # LayerNorm backward through partial records (no atomics)
+        self.attn_bias_colsum = os.environ.get('VITAE_ATTN_BIAS_COLSUM', '1') != '0'
+        # predictor Linears on bf16 operands (LDS-DMA GEMMs) instead of the fp32-activation kernel (round 4: 6 launches of 70-110 us on
+        # the predictor branch at batch 32, beside a chain that has no spare CUs there)
+        self.pred16 = self.act16 and (cfg.embed_dim % 64 == 0) and os.environ.get('VITAE_PREDICTOR_BF16', '1') != '0'
+        self.ws16_side = torch.zeros(1 << 22, **f32) if self.pred16 else None
+        self.ln_part_on = os.environ.get('VITAE_LN_PART', '1') != '0'
+        self.ln_part_min = int(float(os.environ.get('VITAE_LN_PART_MIN', '1.2e6')))   # LayerNorm backward through partial records (no atomics)
         self._ln_pending = []
         self.B = None
         self.buf: Dict[str, torch.Tensor] = {}
@@ -260,9 +277,25 @@ class HipMAEEngine:
         """For launches outside the fused step: the host slots of the device block by an ordinary (stream-ordered) copy."""
         if self._hp_dirty:
             n = _C['VITAE_HP_HOST_COUNT']
-            stage = self.hp_ring[self.step_seq_host % self.hp_ring.shape[0]]
+            self._hp_stage_i = (self._hp_stage_i + 1) % self.hp_stage.shape[0]
+            stage = self.hp_stage[self._hp_stage_i]
+            stage.copy_(torch.tensor(self.hp_vals, dtype=torch.float32))
             self.hp[:n].copy_(stage[:n], non_blocking=True)
             self._hp_dirty = False
+
+    def _noise_seed_now(self) -> int:
+        src = int(torch.initial_seed())
+        if src != self._seed_src:
+            rank = 0
+            try:
+                import torch.distributed as dist
+                if dist.is_available() and dist.is_initialized():
+                    rank = dist.get_rank()
+            except Exception:
+                rank = 0
+            self._seed_src = src
+            self.noise_seed = (src * 0x9E3779B97F4A7C15 + rank * 0xD1B54A32D192ED03 + 0x2545F4914F6CDD1D) & ((1 << 63) - 1)
+        return self.noise_seed
 
     def step_prologue(self, noise: torch.Tensor, accumulate: bool):
         """First launch of a fused step (captured with it): hp <- ring, masking noise, acc <- 0, token / vector gradients <- 0."""
@@ -270,7 +303,7 @@ class HipMAEEngine:
         st = torch.cuda.current_stream(self.device).cuda_stream
         n = self.n_total - self.tok_off
         lib.vitae_step_prologue(self.hp.data_ptr(), self.hp_ring.data_ptr(), self.hp_ring.shape[0], self.step_seq.data_ptr(),
-                                noise.data_ptr(), noise.numel(), self.noise_seed, self.acc.data_ptr(),
+                                noise.data_ptr(), noise.numel(), self._noise_seed_now(), self.acc.data_ptr(),
                                 None if accumulate else self.grads.data_ptr() + self.tok_off * 4, 0 if accumulate else n * 4, st)
         self._hp_dirty = False
         self._head_done = True
@@ -376,7 +409,10 @@ class HipMAEEngine:
             # (view 2) sit opposite them contribute nothing.
             self.Mpl = pad(B * Ne)
             b['latent_16'], b['de_16'] = z16(max(self.Mpe, self.Mpl), D), z16(self.Mpl, Dd)
-        if self.ln_part_on:
+            if cfg.contrastive and self.pred16:
+                # predictor on the LDS-DMA GEMMs: bf16 copies of its activations / their gradients (2 R = Me rows, zero pad rows)
+                b['pr_16'], b['dp_16'], b['dph_16'] = z16(self.Mpe, D), z16(self.Mpe, D), z16(self.Mpe, D)
+        if self.ln_part_on and max(Me * D, Md * Dd) >= self.ln_part_min:
             # LayerNorm backward: one record of column partials [d gamma | d beta | colsum(dx)] per workgroup and LayerNorm instance
             for pre_, depth, M_, d_ in (('blocks.', cfg.depth, Me, D), ('decoder_blocks.', cfg.decoder_depth, Md, Dd)):
                 G = lib.vitae_layernorm_bwd_part_records(M_)
@@ -417,15 +453,17 @@ class HipMAEEngine:
 
         def __enter__(self):
             e = self.eng
-            self.saved = (e.stream, e.ws)
+            self.saved = (e.stream, e.ws, e.ws16)
             self.ctx = torch.cuda.stream(e.pside)
             self.ctx.__enter__()
             e.stream, e.ws = e.pside.cuda_stream, e.ws_side
+            if e.ws16_side is not None:
+                e.ws16 = e.ws16_side        # split-K tickets / partials of the branch's LDS-DMA GEMMs: never shared with the chain's
             return e
 
         def __exit__(self, *a):
             e = self.eng
-            e.stream, e.ws = self.saved
+            e.stream, e.ws, e.ws16 = self.saved
             return self.ctx.__exit__(*a)
 
     def _predictor_join(self):
@@ -582,7 +620,9 @@ class HipMAEEngine:
         """LayerNorm backward.  Default (round 4): no atomics — the launch leaves its d(gamma) / d(beta) / colsum(dx) partials as
         records in ``ln_part`` and ``_ln_flush`` (once per backward phase) adds the records of every LayerNorm of the phase into the
         gradient arena with one launch; nothing reads those gradients before the optimiser's tail."""
-        if self.ln_part_on and D in (256, 512, 768, 1024) and self.buf:
+        # (few rows: the atomic kernel — its 3 D atomics per workgroup are cheaper than the reduce launches: batch 4 measured 10.8 us +
+        # 4 x 13 us of reduces per step against 10.2 us)
+        if self.ln_part_on and D in (256, 512, 768, 1024) and self.buf and M * D >= self.ln_part_min:
             G = lib.vitae_layernorm_bwd_part_records(M)
             part = self.buf.get('lnpart.' + pre)
             if part is None or part.numel() < G * 3 * D:      # (a LayerNorm the workspace does not know: allocated on first use)
@@ -611,7 +651,7 @@ class HipMAEEngine:
     # ------------------------------------------------------------------ bf16-activation GEMM helpers (LDS-DMA kernel)
     def _g16_fwd(self, x16, w, bias, M, N, K, y=None, y16=None, epi=EPI_NONE, aux=None, res=None):
         """y / y16 = epi(x16 @ W16^T + b) (+ res) on the LDS-DMA GEMM (bf16 operands in HBM)."""
-        key = ('g', M, N, K)
+        key = ('g', M, N, K, self.ws16.numel())
         s = self._split_cache.get(key)
         if s is None:
             s = 1 if (epi & 15) == EPI_GELU else lib.vitae_gemm_glds_pick_split_k(M, N, K)
@@ -673,7 +713,7 @@ class HipMAEEngine:
                  dy_colsum=None, dx_accumulate=0):
         """dx / dx16 = epi(dy16 @ W16), dW (+)= dy16^T @ x16 in one paired launch.  ``dw`` None: the input gradient only (the
         weight gradient is collected by ``_wgrad_group``)."""
-        key = ('p', M, N, K)
+        key = ('p', M, N, K, self.ws16.numel())
         s = self._split_cache.get(key)
         if s is None:
             s = lib.vitae_linear_bwd_pair_pick_split_k(M, Mpad, N, K)
@@ -771,9 +811,13 @@ class HipMAEEngine:
                      dx_colsum=g[pre + 'attn.proj.bias'])
         self._g16_bwd(dmid16, p[pre + 'attn.proj.weight'], b[q + 'o_16'], dw(pre + 'attn.proj.weight'), M, Mp, d, d, dx=do)
         t = self._timed(10.0 * Bs * heads * N * N * hd, 'attn')
+        # grouped weight gradients: the qkv bias gradient colsum(dqkv) is collected by the attention backward itself (wave
+        # shuffles + one atomic per column and workgroup) — as a separate bf16 column-sum launch it was 9-10 us on the main chain of
+        # each of the 20 blocks at batch 32 / patch 8
+        qkv_db = g[pre + 'attn.qkv.bias'] if (grp and self.attn_bias_colsum) else None
         if self._qkv16_ok(N, hd):
-            lib.vitae_sdpa_mfma_bwd_bf16in(_ptr(b[q + 'qkv_16']), _ptr(b[q + 'o']), _ptr(do), _ptr(b[q + 'lse']), None, _ptr(dqkv16), None,
-                                           _ptr(b['delta']),
+            lib.vitae_sdpa_mfma_bwd_bf16in(_ptr(b[q + 'qkv_16']), _ptr(b[q + 'o']), _ptr(do), _ptr(b[q + 'lse']), None, _ptr(dqkv16),
+                                           _ptr(qkv_db), _ptr(b['delta']),
                                            Bs, N, heads, hd, self.stream)
         else:
             lib.vitae_sdpa_mfma_bwd(_ptr(b[q + 'qkv']), _ptr(b[q + 'o']), _ptr(do), _ptr(b[q + 'lse']), _ptr(self._dqkv32(dqkv, N, hd)),
@@ -788,7 +832,7 @@ class HipMAEEngine:
                                (dh16, b[q + 'y2_16'], g[pre + 'mlp.fc1.weight'], hid, d),
                                (dmid16, b[q + 'o_16'], g[pre + 'attn.proj.weight'], d, d),
                                (dqkv16, b[q + 'y1_16'], g[pre + 'attn.qkv.weight'], 3 * d, d)], M, Mp,
-                              bias={3: g[pre + 'attn.qkv.bias']})
+                              bias=None if (qkv_db is not None and self._qkv16_ok(N, hd)) else {3: g[pre + 'attn.qkv.bias']})
         self._ln_bwd(dy, x_in, pre + 'norm1.', b[q + 'mean1'], b[q + 'rstd1'], dx, M, d, 1, dx16=dx16,
                      dx_colsum=prev_fc2_bias)
         self._scope = None
@@ -986,7 +1030,11 @@ class HipMAEEngine:
         """predictor on both views (vit_autoenc.py:280-284); launches on ``self.stream``."""
         cfg, b, p = self.cfg, self.buf, self.p
         R, D = self.R, cfg.embed_dim
-        self._lin_fwd(b['latent'], p['predictor.0.weight'], None, b['ph'], 2 * R, D, D)
+        p16 = self.pred16 and training
+        if p16:
+            self._g16_fwd(b['latent_16'], p['predictor.0.weight'], None, 2 * R, D, D, y=b['ph'])
+        else:
+            self._lin_fwd(b['latent'], p['predictor.0.weight'], None, b['ph'], 2 * R, D, D)
         for v in range(2):
             o = v * R * D * 4
             if not training:     # model.eval(): nn.BatchNorm1d normalises with its running statistics (vit_autoenc.py:263-268)
@@ -996,13 +1044,17 @@ class HipMAEEngine:
                                          self.stream)
                 continue
             lib.vitae_bn1d_relu_fwd(b['ph'].data_ptr() + o, _ptr(p['predictor.1.weight']), _ptr(p['predictor.1.bias']),
-                                    b['pr'].data_ptr() + o, b['bn_mean'].data_ptr() + v * D * 4,
+                                    b['pr'].data_ptr() + o, (b['pr_16'].data_ptr() + o // 2) if p16 else None,
+                                    b['bn_mean'].data_ptr() + v * D * 4,
                                     b['bn_rstd'].data_ptr() + v * D * 4,
                                     _ptr(self.buffers['predictor.1.running_mean']) if training else None,
                                     _ptr(self.buffers['predictor.1.running_var']) if training else None,
                                     _ptr(self.buffers['predictor.1.num_batches_tracked']) if training else None,
                                     R, D, 1e-5, 0.1, self.stream)
-        self._lin_fwd(b['pr'], p['predictor.3.weight'], p['predictor.3.bias'], b['pout'], 2 * R, D, D)
+        if p16:
+            self._g16_fwd(b['pr_16'], p['predictor.3.weight'], p['predictor.3.bias'], 2 * R, D, D, y=b['pout'])
+        else:
+            self._lin_fwd(b['pr'], p['predictor.3.weight'], p['predictor.3.bias'], b['pout'], 2 * R, D, D)
 
     def contrastive_loss_fwd(self):
         """utils/train_one_epoch.py:113-114 on (p1, z2), (p2, z1); result -> losses[4]."""
@@ -1096,7 +1148,7 @@ class HipMAEEngine:
                 self._predictor_join()          # dph and the predictor's parameter gradients are final
                 # ... and dph goes through predictor.0 HERE: this phase's bucket holds that weight, and its AdamW runs beside
                 # the next phase
-                self._lin_bwd_x(b['dph'], p['predictor.0.weight'], b['dlatent'], 2 * self.R, D, D)
+                self._pred0_dgrad()
                 self._pred_joined = True
             self._ln_flush()
             self._wg_join()
@@ -1124,7 +1176,7 @@ class HipMAEEngine:
                     self._predictor_join()      # dph and the predictor's parameter gradients are final
                 else:
                     self._predictor_bwd()
-                self._lin_bwd_x(b['dph'], p['predictor.0.weight'], b['dlatent'], 2 * R, D, D)
+                self._pred0_dgrad()
             dec_embed_bwd(1)
         else:
             if cfg.contrastive:   # predictor unused this step: its matrices get exact zeros
@@ -1143,19 +1195,39 @@ class HipMAEEngine:
         self._ln_flush()
         self._wg_join()
 
+    def _pred0_dgrad(self):
+        """dlatent = dph @ W0 (predictor.0 has no bias): the first writer of the latent gradient."""
+        b, p, D = self.buf, self.p, self.cfg.embed_dim
+        if self.pred16:
+            self._g16_bwd(b['dph_16'], p['predictor.0.weight'], None, None, 2 * self.R, self.Mpe, D, D, dx=b['dlatent'])
+        else:
+            self._lin_bwd_x(b['dph'], p['predictor.0.weight'], b['dlatent'], 2 * self.R, D, D)
+
     def _predictor_bwd(self):
         """dp -> predictor.3, BatchNorm+ReLU, predictor.0 weight gradients and dph (launches on ``self.stream``)."""
         cfg, b, p, g = self.cfg, self.buf, self.p, self.g
         R, D = self.R, cfg.embed_dim
-        self._lin_bwd_w(b['dp'], b['pr'], g['predictor.3.weight'], None, 2 * R, D, D)
-        self._lin_bwd_x(b['dp'], p['predictor.3.weight'], b['dpr'], 2 * R, D, D, db=g['predictor.3.bias'])
+        p16 = self.pred16
+        if p16:
+            # dp -> bf16, then predictor.3's dgrad + wgrad + bias gradient as one paired launch on bf16 operands
+            lib.vitae_cast_bf16(_ptr(b['dp']), _ptr(b['dp_16']), 2 * R * D, self.stream)
+            self._g16_bwd(b['dp_16'], p['predictor.3.weight'], b['pr_16'], g['predictor.3.weight'], 2 * R, self.Mpe, D, D, dx=b['dpr'],
+                          dy_colsum=g['predictor.3.bias'])
+        else:
+            self._lin_bwd_w(b['dp'], b['pr'], g['predictor.3.weight'], None, 2 * R, D, D)
+            self._lin_bwd_x(b['dp'], p['predictor.3.weight'], b['dpr'], 2 * R, D, D, db=g['predictor.3.bias'])
         for v in range(2):
             o = v * R * D * 4
             lib.vitae_bn1d_relu_bwd(b['dpr'].data_ptr() + o, b['ph'].data_ptr() + o, b['pr'].data_ptr() + o,
                                     _ptr(p['predictor.1.weight']), b['bn_mean'].data_ptr() + v * D * 4,
                                     b['bn_rstd'].data_ptr() + v * D * 4, b['dph'].data_ptr() + o,
+                                    (b['dph_16'].data_ptr() + o // 2) if p16 else None,
                                     _ptr(g['predictor.1.weight']), _ptr(g['predictor.1.bias']), R, D, self.stream)
-        self._lin_bwd_w(b['dph'], b['latent'], g['predictor.0.weight'], None, 2 * R, D, D)
+        if p16:      # dW0 = dph16^T @ latent16 (both row-contiguous bf16, reduced over the padded row count)
+            lib.vitae_gemm_glds(0, 0, _ptr(b['dph_16']), D, _ptr(b['latent_16']), D, _ptr(g['predictor.0.weight']), D, None, D,
+                                D, D, self.Mpe, None, None, 0, EPI_NONE, None, 0, int(self._accum), 1, None, None, self.stream)
+        else:
+            self._lin_bwd_w(b['dph'], b['latent'], g['predictor.0.weight'], None, 2 * R, D, D)
 
     def backward_enc(self, hi: int, lo: int):
         """encoder blocks hi, hi-1, ..., lo."""
@@ -1203,8 +1275,9 @@ class HipMAEEngine:
         """Host side of one AdamW step: advances the step count, refreshes lr / bias corrections."""
         self.opt_step += 1          # the host's belief; the device count (hp[VITAE_HP_STEP], read_opt_step) is the truth
         b1, b2 = self.betas
-        # bc1 = bc2 = 0: the AdamW kernels derive 1 - beta^t from the device-side count of APPLIED steps
-        self.set_hparams(lr=lr, beta1=b1, beta2=b2, eps=self.eps, bc1=0.0, bc2=0.0)
+        # bc1, bc2 < 0: the AdamW kernels derive 1 - beta^t from the device-side count of APPLIED steps and from -(1 - beta), which
+        # the host forms in double (csrc/optim.hip: device_bias_corrections)
+        self.set_hparams(lr=lr, beta1=b1, beta2=b2, eps=self.eps, bc1=-(1.0 - float(b1)), bc2=-(1.0 - float(b2)))
 
     def grad_norm_and_step(self):
         """utils/misc.py:265-267: global grad L2 norm -> losses[5]; AdamW over the arena

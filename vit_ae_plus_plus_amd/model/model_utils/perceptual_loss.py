@@ -57,7 +57,8 @@ class vgg_perceptual_loss(nn.Module):
     def _note_loaded(module, incompatible):
         import re
         mine = [k for k in incompatible.missing_keys if re.search(r'(^|\.)slice\d\.\d+\.(weight|bias)$', k)]
-        module._weights_loaded = not mine
+        if not mine:                      # only ever SET: a later parent load_state_dict(strict=False) without the VGG keys must
+            module._weights_loaded = True     # not turn loaded weights back into "random" 
         module._packed = None
 
     def convs(self):
@@ -82,7 +83,6 @@ class vgg_perceptual_loss(nn.Module):
         self._packed = (key, out)
         return out
 
-    @torch.no_grad()
     def _warn_if_random(self):
         if not self._weights_loaded and not self._warned:
             import warnings
@@ -94,9 +94,11 @@ class vgg_perceptual_loss(nn.Module):
                           'non-zero perceptual_weight also takes the model off the fused (captured) step: the generic route runs.',
                           RuntimeWarning, stacklevel=3)
 
+    @torch.no_grad()
     def forward(self, X1, X2):
+        """mean over channels of mean over the four slices of MSE(features(X1 slices), features(X2 slices)); X: [B, C, Z, H, W].
+        Evaluated under torch.no_grad() like the reference's logging term (model/vit_autoenc.py:229-230)."""
         self._warn_if_random()
-        """mean over channels of mean over the four slices of MSE(features(X1 slices), features(X2 slices)); X: [B, C, Z, H, W]"""
         if not X1.is_cuda:
             raise VitaeError('vgg_perceptual_loss: MI355X only (no CPU fallback; the CPU restatement is oracle/percep_ref.py)')
         X1, X2 = X1.contiguous().float(), X2.contiguous().float()

@@ -532,6 +532,11 @@ class MaskedAutoencoderViT(nn.Module):
         if red is not None:
             self._runners.clear()
             if getattr(red, 'native', False):
+                # the step graphs hold RCCL nodes of this communicator: they must be GONE (not merely unreferenced) before it is —
+                # a graph destroyed later, next to a capture that uses the next communicator, crashed hipGraphLaunch (seen with
+                # two graph-route data-parallel models in one process)
+                import gc
+                gc.collect()
                 torch.cuda.synchronize()
                 red.close()
         self._reducer = None
