@@ -434,34 +434,46 @@ __global__ __launch_bounds__(256) void layernorm_bwd_part_kernel(const float* __
 }
 
 // out_k[c] += sum over the G records of instance i of part_i[g][k][c], k = 0 (d gamma), 1 (d beta), 2 (column sum of dx; optional),
-// for up to LN_RED_MAX LayerNorm instances in one launch: grid (instances, column blocks of 1024 floats of the 3 D), every thread
-// one float4 column group, eight records in flight.  Summation order is fixed: bitwise reproducible.
+// for up to LN_RED_MAX LayerNorm instances in one launch: grid (instances, blocks of 16 float4 column groups of the 3 D).
+// Summation order is fixed: bitwise reproducible.
 constexpr int LN_RED_MAX = 48;
 struct LnRedDesc { const float* part; float* dw; float* db; float* cs; int G, D; };
 struct LnRedArgs { LnRedDesc d[LN_RED_MAX]; };
 
 __global__ __launch_bounds__(256) void ln_grad_reduce_kernel(const LnRedArgs a) {
+    // a workgroup = 16 float4 column groups (256-byte row pieces) x 16 record lanes: lane j of a column group sums records j, j + 16, ...
+    // (all of its loads in flight together for G <= 128), the 16 partial sums meet in LDS in a fixed order
+    __shared__ f32x4 red[16][16];
     const LnRedDesc& t = a.d[blockIdx.x];
     const int D = t.D, n4 = 3 * D / 4;
-    const int c4 = blockIdx.y * 256 + threadIdx.x;
-    if (c4 >= n4) return;
-    const int k = c4 / (D / 4), c = 4 * (c4 % (D / 4));
+    const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c4 = blockIdx.y * 16 + cg;
+    const bool ok = c4 < n4;
+    const int k = ok ? c4 / (D / 4) : 0, c = ok ? 4 * (c4 % (D / 4)) : 0;
     float* out = k == 0 ? t.dw : k == 1 ? t.db : t.cs;
-    if (!out) return;
     const float* src = t.part + k * D + c;
     const long stride = 3L * D;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    int g = 0;
-    for (; g + 8 <= t.G; g += 8) {
-        f32x4 v[8];
+    if (ok && out) {
+        int g = rl;
+        for (; g + 7 * 16 < t.G; g += 8 * 16) {
+            f32x4 v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (g + u) * stride);
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (long)(g + 16 * u) * stride);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc += v[u];
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; g < t.G; g += 16) acc += *reinterpret_cast<const f32x4*>(src + (long)g * stride);
     }
-    for (; g < t.G; ++g) acc += *reinterpret_cast<const f32x4*>(src + g * stride);
-    f32x4* o4 = reinterpret_cast<f32x4*>(out + c);
-    *o4 = *o4 + acc;
+    red[rl][cg] = acc;
+    __syncthreads();
+    if (rl == 0 && ok && out) {
+        f32x4 s = red[0][cg];
+#pragma unroll
+        for (int j = 1; j < 16; ++j) s += red[j][cg];
+        f32x4* o4 = reinterpret_cast<f32x4*>(out + c);
+        *o4 = *o4 + s;
+    }
 }
 
 // ------------------------------------------------------------------ column sum (bias gradients)
@@ -727,7 +739,7 @@ extern "C" int vitae_ln_grad_reduce(int n, const float* const* part, float* cons
             a.d[i] = LnRedDesc{part[i0 + i], dw[i0 + i], db[i0 + i], dx_colsum ? dx_colsum[i0 + i] : nullptr, records[i0 + i], D[i0 + i]};
             if (D[i0 + i] > dmax) dmax = D[i0 + i];
         }
-        hipLaunchKernelGGL(ln_grad_reduce_kernel, dim3(m, cdiv(3 * dmax / 4, 256)), dim3(256), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(ln_grad_reduce_kernel, dim3(m, cdiv(3 * dmax / 4, 16)), dim3(256), 0, (hipStream_t)stream, a);
     }
     return vitae_launch_status();
 }
