@@ -50,7 +50,10 @@ template <int BM, int BN, int WM, int WN> struct BtCfg {
 //   0 plain (bias), 1 + residual, 2 + old C (accumulate), 3 GELU (aux <- pre-activation), 4 GELU' (aux read), 5 ReLU mask (aux
 //   read), 6 ReLU, 7 anything else (every option behind run-time checks: correct, slow).
 // All global loads of the wave's part (one 16-byte load per row pass) are issued BEFORE the first store.
-template <int FM, int FN, int KIND, bool FULL>
+// AUX16 (kinds 3 / 4 / 5 / 7): the aux array holds bf16.  A template parameter, not a run-time test: with `if (p.aux16)` around the
+// aux loads hipcc put every one of them behind a branch and an `s_waitcnt vmcnt(0)` — eight serialised memory round trips per
+// quadrant in the GELU' epilogue (round 4, ISA of gemm_bt_kernel<256, 256, 2, 4, true, false>).
+template <int FM, int FN, int KIND, bool FULL, bool AUX16>
 __device__ __forceinline__ void bt_wave_rows(const GArgs& p, int mb, int nb, const float* Tw, int lane, float& sqs, f32x4& csum, const f32x4 bias4) {
     constexpr int S = 32 * FN, LPR = 8 * FN, RPI = 64 / LPR, PASSES = 32 * FM / RPI, PB = PASSES >= 4 ? 4 : PASSES;
     const int cg = lane % LPR, rr = lane / LPR;
@@ -66,19 +69,16 @@ __device__ __forceinline__ void bt_wave_rows(const GArgs& p, int mb, int nb, con
     // one array per operand kind; an instantiation other than 7 uses at most one of them (and loads all its passes up front;
     // kind 7 loads batch by batch: three arrays of all passes would spill next to 128 live accumulators)
     constexpr int LDN = KIND == 7 ? PB : PASSES;
-    f32x4 ax[LDN], rs[LDN], co[LDN];
+    f32x4 ax[AUX16 ? 1 : LDN], rs[LDN], co[LDN];
+    bf16x4 ax16[AUX16 ? LDN : 1];                  // raw: converted where it is used, so that the loads of a batch fly together
     auto load_ops = [&](int q0) {
 #pragma unroll
         for (int q = 0; q < LDN; ++q) {
             const int mr = mb + rr + (q0 + q) * RPI;
             const int mc = FULL ? mr : min(mr, p.M - 1);
             if (need_aux) {
-                if (p.aux16) {
-                    const bf16x4 h = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(p.aux) + mc * ldaux + nc);
-                    ax[q] = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
-                } else {
-                    ax[q] = *reinterpret_cast<const f32x4*>(p.aux + mc * ldaux + nc);
-                }
+                if constexpr (AUX16) ax16[q] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(p.aux) + mc * ldaux + nc);
+                else ax[q] = *reinterpret_cast<const f32x4*>(p.aux + mc * ldaux + nc);
             }
             if (has_res) rs[q] = *reinterpret_cast<const f32x4*>(p.residual + mc * ldr + nc);
             if (acc_c) co[q] = *reinterpret_cast<const f32x4*>(p.C + mc * ldc + nc);
@@ -110,9 +110,18 @@ __device__ __forceinline__ void bt_wave_rows(const GArgs& p, int mb, int nb, con
             f32x4 v = x[pb * XB + q];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += bias4[e];
+            f32x4 axv = {0.f, 0.f, 0.f, 0.f};
+            if (need_aux) {
+                if constexpr (AUX16) {
+                    const bf16x4 h = ax16[pb * LB + q];
+                    axv = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+                } else {
+                    axv = ax[pb * LB + q];
+                }
+            }
             if (epi == VITAE_EPI_GELU) {
                 if (ok) {
-                    if (p.aux16) {
+                    if constexpr (AUX16) {
                         bf16x4 h;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) h[e] = (__bf16)v[e];
@@ -125,10 +134,10 @@ __device__ __forceinline__ void bt_wave_rows(const GArgs& p, int mb, int nb, con
                 for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
             } else if (epi == VITAE_EPI_DGELU) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= gelu_fast_grad(ax[pb * LB + q][e]);
+                for (int e = 0; e < 4; ++e) v[e] *= gelu_fast_grad(axv[e]);
             } else if (epi == VITAE_EPI_RELU_MASK) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = ax[pb * LB + q][e] > 0.f ? v[e] : 0.f;
+                for (int e = 0; e < 4; ++e) v[e] = axv[e] > 0.f ? v[e] : 0.f;
             } else if (epi == VITAE_EPI_RELU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -178,16 +187,30 @@ __device__ __forceinline__ void bt_wave_epilogue(const GArgs& p, int kind, int m
     constexpr int LPR = 8 * FN;
     f32x4 csum = {0.f, 0.f, 0.f, 0.f};
     const bool full = mb + 32 * FM <= p.M && nb + 32 * FN <= p.N;
-#define VITAE_BT_ROWS(E)                                                              \
-    case E:                                                                           \
-        if (full) bt_wave_rows<FM, FN, E, true>(p, mb, nb, Tw, lane, sqs, csum, bias4); \
-        else bt_wave_rows<FM, FN, E, false>(p, mb, nb, Tw, lane, sqs, csum, bias4);     \
+#define VITAE_BT_ROWS(E)                                                                       \
+    case E:                                                                                    \
+        if (full) bt_wave_rows<FM, FN, E, true, false>(p, mb, nb, Tw, lane, sqs, csum, bias4);  \
+        else bt_wave_rows<FM, FN, E, false, false>(p, mb, nb, Tw, lane, sqs, csum, bias4);      \
+        break;
+#define VITAE_BT_ROWS_AUX(E)                                                                   \
+    case E:                                                                                    \
+        if (p.aux16) {                                                                         \
+            if (full) bt_wave_rows<FM, FN, E, true, true>(p, mb, nb, Tw, lane, sqs, csum, bias4);  \
+            else bt_wave_rows<FM, FN, E, false, true>(p, mb, nb, Tw, lane, sqs, csum, bias4);      \
+        } else {                                                                               \
+            if (full) bt_wave_rows<FM, FN, E, true, false>(p, mb, nb, Tw, lane, sqs, csum, bias4); \
+            else bt_wave_rows<FM, FN, E, false, false>(p, mb, nb, Tw, lane, sqs, csum, bias4);     \
+        }                                                                                      \
         break;
     switch (kind) {
-        VITAE_BT_ROWS(0) VITAE_BT_ROWS(1) VITAE_BT_ROWS(2) VITAE_BT_ROWS(3) VITAE_BT_ROWS(4) VITAE_BT_ROWS(5) VITAE_BT_ROWS(6)
-        default: bt_wave_rows<FM, FN, 7, false>(p, mb, nb, Tw, lane, sqs, csum, bias4); break;
+        VITAE_BT_ROWS(0) VITAE_BT_ROWS(1) VITAE_BT_ROWS(2) VITAE_BT_ROWS_AUX(3) VITAE_BT_ROWS_AUX(4) VITAE_BT_ROWS_AUX(5) VITAE_BT_ROWS(6)
+        default:
+            if (p.aux16) bt_wave_rows<FM, FN, 7, false, true>(p, mb, nb, Tw, lane, sqs, csum, bias4);
+            else bt_wave_rows<FM, FN, 7, false, false>(p, mb, nb, Tw, lane, sqs, csum, bias4);
+            break;
     }
 #undef VITAE_BT_ROWS
+#undef VITAE_BT_ROWS_AUX
     if (p.out_colsum) {
         // lanes with equal (lane % LPR) hold the same four columns: fold the row groups, then one atomic per column
 #pragma unroll

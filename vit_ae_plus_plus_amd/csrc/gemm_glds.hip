@@ -97,16 +97,13 @@ __device__ __forceinline__ void epilogue_rows(const GArgs& p, const float (&a)[N
 #pragma unroll
     for (int pb = 0; pb < PASSES; pb += PB) {
         f32x4 ax[PB], rs[PB], co[PB];
+        bf16x4 ax16[PB];       // a bf16 aux stays raw until it is used: converting right behind the load made hipcc wait for every load in turn
 #pragma unroll
         for (int q = 0; q < PB; ++q) {
             const int mc = min(m0 + r0 + (pb + q) * RPP, p.M - 1);
             if (need_aux) {
-                if (p.aux16) {
-                    const bf16x4 h = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(p.aux) + mc * ldaux + nc);
-                    ax[q] = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
-                } else {
-                    ax[q] = *reinterpret_cast<const f32x4*>(p.aux + mc * ldaux + nc);
-                }
+                if (p.aux16) ax16[q] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(p.aux) + mc * ldaux + nc);
+                else ax[q] = *reinterpret_cast<const f32x4*>(p.aux + mc * ldaux + nc);
             }
             if (p.residual) {
                 if (pre.have) rs[q] = pre.res[(pb + q) & 3];
@@ -133,9 +130,11 @@ __device__ __forceinline__ void epilogue_rows(const GArgs& p, const float (&a)[N
 #pragma unroll
                 for (int e = 0; e < 4; ++e) x[e] = gelu_fast(x[e]);
             } else if (p.epi == VITAE_EPI_DGELU) {
+                if (p.aux16) ax[q] = f32x4{(float)ax16[q][0], (float)ax16[q][1], (float)ax16[q][2], (float)ax16[q][3]};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) x[e] *= gelu_fast_grad(ax[q][e]);
             } else if (p.epi == VITAE_EPI_RELU_MASK) {
+                if (p.aux16) ax[q] = f32x4{(float)ax16[q][0], (float)ax16[q][1], (float)ax16[q][2], (float)ax16[q][3]};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) x[e] = ax[q][e] > 0.f ? x[e] : 0.f;
             } else if (p.epi == VITAE_EPI_RELU) {

@@ -130,8 +130,12 @@ class HipMAEEngine:
         # OPT-IN (measured: no gain — 4.81-4.84 vs 4.82-4.84 ms at batch 4, 15.96 vs 15.94 at batch 32): the saved fc1
         # pre-activation (read once, by the GELU' of the fc2 input gradient) in bf16: half the bytes of the fc1 epilogue's largest
         # store and of the fc2 backward's largest epilogue read
-        self.hpre16 = self.act16 and os.environ.get('VITAE_HPRE_BF16', '0') == '1'
-        self._aux16 = CONSTS['VITAE_EPI_AUX_BF16'] if self.hpre16 else 0
+        # saved fc1 pre-activation in bf16 (VITAE_EPI_AUX_BF16): decided per workspace in ``_alloc`` — a gain where the fc1 / fc2-dgrad
+        # GEMMs run on the 64-row tiles (batch 4: 4.50 -> 4.43 ms), neutral at batch 8, a LOSS on the big tiles (batch 32 / patch 8:
+        # +1.3 %; alternating runs, round 4).  VITAE_HPRE_BF16 = 1 / 0 forces it on / off.
+        self._hpre16_env = os.environ.get('VITAE_HPRE_BF16', 'auto')
+        self.hpre16 = False
+        self._aux16 = 0
         # the gradient norm's matrix share is accumulated by the weight-gradient epilogues themselves (vitae_gemm_glds_set_wgrad_sqnorm)
         # instead of a pass over each bucket (45 us per bucket, the last one exposed behind the backward); single process only — a
         # data-parallel norm is the norm of the REDUCED gradients
@@ -332,7 +336,7 @@ class HipMAEEngine:
         self.hp[_C['VITAE_HP_STEP']] = float(step)
 
     # ------------------------------------------------------------------ workspace
-    _WS_ATTRS = ('B', 'keep', 'Be', 'Ne', 'Nd', 'Me', 'Md', 'Mpe', 'Mpd', 'Mpt', 'Mpl', 'R', 'mask_sum', 'edge_count', 'buf')
+    _WS_ATTRS = ('B', 'keep', 'Be', 'Ne', 'Nd', 'Me', 'Md', 'Mpe', 'Mpd', 'Mpt', 'Mpl', 'R', 'mask_sum', 'edge_count', 'buf', 'hpre16', '_aux16')
     _WS_MAX = int(os.environ.get('VITAE_WORKSPACES', '4'))
 
     def _alloc(self, B: int, mask_ratio: float):
@@ -359,6 +363,8 @@ class HipMAEEngine:
         Ne, Nd, Be = keep + 1, L + 1, self.Be
         Me, Md = Be * Ne, B * Nd
         self.Ne, self.Nd, self.Me, self.Md = Ne, Nd, Me, Md
+        self.hpre16 = self.act16 and (self._hpre16_env == '1' or (self._hpre16_env == 'auto' and Me * self.Hm < 2.0e6))
+        self._aux16 = CONSTS['VITAE_EPI_AUX_BF16'] if self.hpre16 else 0
         dev = self.device
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         b = self.buf = {}
