@@ -230,7 +230,7 @@ def roofline_block(args, recs, overhead_ms, ms_step, world):
     ach = d_fl / (d_ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS[args.precision]
     traffic, tnote, rp_us = None, None, None   # PMC counters cannot be read in-process: last committed rocprofv3 --pmc result
-    for name in ('round3_gemm_traffic.json', 'round2_gemm_traffic.json', 'round1_gemm_traffic.json'):
+    for name in ('round4_gemm_traffic.json', 'round3_gemm_traffic.json', 'round2_gemm_traffic.json', 'round1_gemm_traffic.json'):
         tfile = os.path.join(ROOT, 'profiles', name)
         if args.precision == 'bf16' and args.batch == 4 and os.path.exists(tfile):
             tj = json.load(open(tfile))
