@@ -952,7 +952,9 @@ static int sdpa_mfma_fwd_launch(const QT* qkv, float* o, void* o_bf16, float* ls
     // forward variants (VITAE_ATTN_FWD forces one): 0: 1 query block x 1 key tile per step (short sequences); 1: 1 x 2; 2: 2 x 2
     // (256-key chunks — 1 x 4 and 2 x 2 — measured no faster at N = 1729: 64.0 / 58.7 against 56.9 us; they halve the resident workgroups)
     static const int forced = getenv("VITAE_ATTN_FWD") ? atoi(getenv("VITAE_ATTN_FWD")) : -1;
-    const int var = forced >= 0 ? forced : (N >= 512 ? (head_dim == 32 ? 2 : 1) : 0);
+    // (two query blocks per wave also for short sequences once there are enough heads to fill the chip with half the workgroups:
+    // batch 32 decoder, N = 217: 22.6 -> 18.6 us; batch 4: 6.7 -> 8.9 us)
+    const int var = forced >= 0 ? forced : (N >= 512 ? (head_dim == 32 ? 2 : 1) : (head_dim == 32 && N > 128 && (long)H * B >= 512) ? 2 : 0);
     const int qb = var == 2 ? 2 : 1;
     dim3 grid(cdiv(N, 128 * qb), H, B);
     hipStream_t st = (hipStream_t)stream;
@@ -986,6 +988,18 @@ extern "C" int vitae_sdpa_mfma_fwd(const float* qkv, float* o, void* o_bf16, flo
 extern "C" int vitae_sdpa_mfma_fwd_bf16in(const void* qkv_bf16, float* o, void* o_bf16, float* lse, int B, int N, int H,
                                           int head_dim, void* stream) {
     return sdpa_mfma_fwd_launch<__bf16>(reinterpret_cast<const __bf16*>(qkv_bf16), o, o_bf16, lse, B, N, H, head_dim, stream);
+}
+
+// Workgroups per (batch, head) of the one-launch backward: every workgroup stages the WHOLE head (Q, K, V, dO), so with many heads
+// one workgroup per head is best — it walks all the head's items, four at a time (batch 32 decoder, 512 heads x 14 items: 42.2 us
+// with two workgroups per head, 31.3 with one); with few heads the items are spread over up to items / 4 workgroups to fill the chip.
+static int fused_bwd_groups(int items, int H, int B) {
+    static const int gforce = getenv("VITAE_ATTN_BWD_G") ? atoi(getenv("VITAE_ATTN_BWD_G")) : 0;
+    if (gforce > 0) return gforce;
+    const long heads = (long)H * B;
+    int g = cdiv(items, 4), fill = cdiv(512, heads);
+    if (g > fill) g = fill;
+    return g < 1 ? 1 : g;
 }
 
 // one-launch backward from bf16 q | k | v; VITAE_ERR_UNSUPPORTED_SHAPE when the head does not fit LDS (the caller then keeps an
@@ -1040,8 +1054,7 @@ extern "C" int vitae_sdpa_mfma_bwd_bf16in(const void* qkv_bf16, const float* o, 
     const int NP = cdiv(N, 32) * 32;
     const size_t lds = (size_t)4 * NP * (head_dim + 8) * 2 + (size_t)2 * NP * 4 + (size_t)3 * head_dim * 4;
     const int items = 2 * (NP / 32);
-    int G = cdiv(items, 4);
-    if ((long)G * H * B > 1024) G = cdiv(items, 8);
+    const int G = fused_bwd_groups(items, H, B);
     dim3 fgrid(G, H, B);
     hipStream_t st = (hipStream_t)stream;
     const __bf16* q16 = reinterpret_cast<const __bf16*>(qkv_bf16);
@@ -1080,8 +1093,7 @@ extern "C" int vitae_sdpa_mfma_bwd(const float* qkv, const float* o, const float
     const size_t lds = (size_t)4 * NP * (head_dim + 8) * 2 + (size_t)2 * NP * 4 + (size_t)3 * head_dim * 4;
     if (fused_on && (head_dim == 32 || head_dim == 64) && lds <= 150 * 1024) {
         const int items = 2 * (NP / 32);
-        int G = cdiv(items, 4);                                 // one item per wave ...
-        if ((long)G * H * B > 1024) G = cdiv(items, 8);          // ... two when that many workgroups would queue up
+        const int G = fused_bwd_groups(items, H, B);
         dim3 fgrid(G, H, B);
         if (head_dim == 32) {
             static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<32>),
