@@ -591,7 +591,9 @@ inline int xcd_by_rows(int M, int N) {
 
 // 0: 64x64, 1: 64x128 — the wider tile once it still yields enough workgroups for 256 CUs.  (A 128x128 tile inside THIS
 // kernel — 4 waves / 96 KB or 8 waves / 128 KB of LDS, one workgroup per CU — lost to 64x128 on every large GEMM of the step,
-// decoder_pred fwd 54.7 -> 72.5 / 53.8 us: removed in round 3; the big tiles that do win have their own schedule, gemm_bt.hip.)
+// decoder_pred fwd 54.7 -> 72.5 / 53.8 us: removed in round 3; the big tiles that do win have their own schedule, gemm_bt.hip.
+// Round 4, the few-column shapes again with 8 waves / 3 stages and no split: 3520 x 768 x 3072 38.6 us (planner's choice 39.1 in
+// the same cold-operand loop), x 768: 18.1 (14.2), 6944 x 512 x 2048: 32.8 (34.5) — ~1580 clocks per 128 x 128 x 64 k-tile.)
 inline Tile pick_tile(int M, int N) {
     static const int wide_min = getenv("VITAE_GLDS_WIDE_MIN_TILES") ? atoi(getenv("VITAE_GLDS_WIDE_MIN_TILES")) : 400;
     if (N >= 128 && (long)cdiv(M, 64) * cdiv(N, 128) >= wide_min) return {64, 128, 1};
@@ -649,7 +651,9 @@ inline BtPlan bt_plan(int M, int N, int K, int a_kc, int b_kc, bool allow_split,
         const bool forced = g_bt_mode >= 0;
         if (!forced && (M < bm / 2 || N < bn / 2)) continue;
         const long tiles = (long)cdiv(M, bm) * cdiv(N, bn);
+        static const int fsplit = getenv("VITAE_BT_SPLIT") ? atoi(getenv("VITAE_BT_SPLIT")) : 0;   // tools: with a forced tile, this split only
         for (int s = 1; s <= (id == 3 && allow_split ? 8 : 1); ++s) {
+            if (forced && fsplit > 0 && s != fsplit) continue;
             const int kps = cdiv(cdiv(K, s), BK) * BK;
             if (cdiv(K, kps) != s || kps < (forced ? 2 : 4) * BK || K - (s - 1) * kps < 2 * BK) continue;
             if (s > 1 && (tiles > VITAE_GLDS_TICKETS || (cap >= 0 && VITAE_GLDS_TICKETS + tiles * s * bm * bn > cap))) continue;
