@@ -866,7 +866,7 @@ def _bt_operands(form, M, N, K, seed=0):
     return akc, bkc, A, B, Af @ Bf.t()
 
 
-@pytest.mark.parametrize('tile', [0, 3])
+@pytest.mark.parametrize('tile', [0, 3, 4])
 @pytest.mark.parametrize('form', ['fwd', 'dgrad', 'wgrad'])
 @pytest.mark.parametrize('M,N,K', [(868, 16384, 512), (440, 776, 192), (1000, 520, 128), (300, 264, 640), (130, 128, 1024)])
 def test_gemm_bt_forms_and_epilogues(lib, C, bt_mode, tile, form, M, N, K):
@@ -924,16 +924,17 @@ def test_gemm_bt_forms_and_epilogues(lib, C, bt_mode, tile, form, M, N, K):
     assert rel_err(y, F.relu(prod + b)) < 2e-3
 
 
+@pytest.mark.parametrize('tile', [3, 4])
 @pytest.mark.parametrize('form', ['fwd', 'dgrad', 'wgrad'])
 @pytest.mark.parametrize('M,N,K,split', [(880, 768, 3072, 6), (440, 520, 1024, 2), (3456, 768, 4096, 3), (300, 264, 640, 2)])
-def test_gemm_bt_split_k(lib, C, bt_mode, form, M, N, K, split):
-    """In-launch split-K of the 128x128 tile: partials through write-through stores, last arriver sums in split order —
+def test_gemm_bt_split_k(lib, C, bt_mode, tile, form, M, N, K, split):
+    """In-launch split-K of the 128x128 tiles (3: every wave loads and multiplies, 4: wave-specialised): partials through write-through stores, last arriver sums in split order —
     equal to the unsplit launch up to fp32 summation order, bitwise reproducible, tickets handed back, epilogue applied once."""
     if form == 'wgrad':
         M = M // 8 * 8
     akc, bkc, A, B, prod = _bt_operands(form, M, N, K, seed=7)
     lda, ldb = (K if akc else M), (K if bkc else N)
-    bt_mode(3)
+    bt_mode(tile)
     res, bd = dev(gen(M, N, seed=4)), dev(gen(N, seed=3))
     ws = torch.zeros(lib.vitae_gemm_glds_ws_floats(M, N, split), device='cuda')
     outs = []
@@ -955,7 +956,7 @@ def test_gemm_bt_split_k(lib, C, bt_mode, form, M, N, K, split):
         assert abs(float(sq) - 2 * float(outs[0].double().pow(2).sum())) < 1e-4 * float(sq)      # one share per launch, every element once
 
 
-@pytest.mark.parametrize('tile', [0, 3])
+@pytest.mark.parametrize('tile', [0, 3, 4])
 @pytest.mark.parametrize('M,N,K', [(868, 16384, 512), (3464, 768, 768), (880, 3072, 768)])
 def test_linear_bwd_pair_on_big_tiles(lib, C, bt_mode, tile, M, N, K):
     """vitae_linear_bwd_pair_glds when the planner serves a half with a big tile: the halves leave as two launches — same

@@ -242,6 +242,129 @@ __device__ __forceinline__ void bt_park_quadrant(const f32x16 (&acc)[NACC][FM * 
             }
 }
 
+// What follows the k-loop of a big-tile workgroup: the in-launch split-K fix-up (tiles below 256 x 256) and the wave-private
+// epilogue, quadrant by quadrant.  `wave` / threadIdx.x index the NW = WM * WN waves that hold accumulators (the wave-specialised
+// kernel's producer waves have left by now: a barrier only counts the waves still alive).
+template <int BM, int BN, int WM, int WN, int NACC, class Stamp>
+__device__ __forceinline__ void bt_tail(const GArgs& p, f32x16 (&acc)[2][2][NACC][BtCfg<BM, BN, WM, WN>::FM * BtCfg<BM, BN, WM, WN>::FN],
+                                        unsigned char* smem, const int m0, const int n0, const int tm, const int tn, const int zid,
+                                        const int wave, const int lane, Stamp stamp) {
+    using Cf = BtCfg<BM, BN, WM, WN>;
+    constexpr int NW = Cf::NW, HM = Cf::HM, HN = Cf::HN, FM = Cf::FM, FN = Cf::FN, NF = FM * FN;
+    const int wm = wave / WN, wn = wave % WN;
+    // epilogue: every wave on its own, quadrant by quadrant through its own 32 FM x 32 FN floats of LDS (the stages are free once
+    // everybody has left the k-loop).  The loop over quadrants is ROLLED; only the register -> LDS part depends on which
+    // accumulators are meant.
+    constexpr int TW = 32 * FM * 32 * FN;          // floats per wave
+    static_assert(NW * TW * 4 <= Cf::SMEM, "wave-private staging fits the operand stages");
+    float* Tw = reinterpret_cast<float*>(smem) + wave * TW;
+    float sqs = 0.f;
+    const int kind = bt_epilogue_kind(p);
+    if constexpr (BM * BN < 256 * 256) if (p.splits > 1) {     // (the 256x256 tile: 256 KB of partials per split and workgroup - not offered)
+        // Split-K inside the launch: every split parks its partial tile in the workspace (fragment order: 16 bytes per lane,
+        // lane-contiguous, WRITE-THROUGH stores — sc1 — so the data is on the memory side of the eight L2s without a release
+        // fence), drains, takes a ticket; the LAST arriver of a tile re-reads all partials with sc1 loads in split order
+        // (bitwise reproducible whatever the arrival order) and runs the epilogue.  cdna_hip_programming.md §6 Guideline 16 R1.
+        constexpr int NT = 64 * NW, GROUPS = 4 * NF * 4;                  // 16-byte groups per lane: quadrants x fragments x 4
+        const int tile = p.tile0 + tm * p.tiles_n + tn;
+        float* part = p.ws + VITAE_GLDS_TICKETS + (long)tile * p.splits * (NT * GROUPS * 4);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(part, 0, p.splits * (NT * GROUPS * 16), 0x00020000);
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const int toff = (int)threadIdx.x * 16;
+        if constexpr (NACC == 2) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int f = 0; f < NF; ++f)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) acc[a][b][0][f][i] += acc[a][b][NACC - 1][f][i];
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int f = 0; f < NF; ++f)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[a][b][0][f][4 * g + e];
+                        const int grp = ((a * 2 + b) * NF + f) * 4 + g;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (zid * GROUPS + grp) * (NT * 16) + toff, 0, 16);
+                    }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its own stores
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(smem);
+        if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(reinterpret_cast<int*>(p.ws) + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*flag != p.splits - 1) return;
+        __syncthreads();                                          // everyone has read the flag before the staging area is reused
+        // all GROUPS loads of one split in flight together (a first version with one quadrant's four at a time cost the last
+        // arriver 4 x splits dependent round trips to the memory side, ~1 us each)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int f = 0; f < NF; ++f)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        acc[a][b][0][f][i] = 0.f;
+                        if (NACC == 2) acc[a][b][NACC - 1][f][i] = 0.f;
+                    }
+#pragma unroll 1
+        for (int sp = 0; sp < p.splits; ++sp) {
+            f32x4 v[GROUPS];
+#pragma unroll
+            for (int i = 0; i < GROUPS; ++i)
+                v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (sp * GROUPS + i) * (NT * 16) + toff, 0, 16));
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int f = 0; f < NF; ++f)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[a][b][0][f][4 * g + e] += v[((a * 2 + b) * NF + f) * 4 + g][e];
+        }
+        if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<int*>(p.ws) + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+    // the bias of the wave's two column ranges, fetched under the barrier (issued inside the quadrant loop it cost every
+    // quadrant one exposed memory latency)
+    f32x4 biasq[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int n = n0 + b * HN + wn * 32 * FN + 4 * (lane % (8 * FN));
+        biasq[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias && n < p.N) biasq[b] = *reinterpret_cast<const f32x4*>(p.bias + n);
+    }
+    __syncthreads();                               // every wave is done with the operand stages
+    stamp(17);
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+        switch (q) {
+            case 0: bt_park_quadrant<FM, FN, NACC>(acc[0][0], lane, Tw); break;
+            case 1: bt_park_quadrant<FM, FN, NACC>(acc[0][1], lane, Tw); break;
+            case 2: bt_park_quadrant<FM, FN, NACC>(acc[1][0], lane, Tw); break;
+            default: bt_park_quadrant<FM, FN, NACC>(acc[1][1], lane, Tw); break;
+        }
+        __builtin_amdgcn_wave_barrier();           // compiler-only: the lanes' writes stay in front of the other lanes' reads
+        bt_wave_epilogue<FM, FN>(p, kind, m0 + (q >> 1) * HM + wm * 32 * FM, n0 + (q & 1) * HN + wn * 32 * FN, Tw, lane, sqs, (q & 1) ? biasq[1] : biasq[0]);
+        __builtin_amdgcn_wave_barrier();
+        stamp(18 + q);
+    }
+    if (p.sqacc) {
+        sqs = wave_sum(sqs);
+        if (lane == 0) atomicAdd(p.sqacc, (double)sqs);
+    }
+    if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(25); }
+}
+
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC>
 __device__ __forceinline__ void gemm_bt_body(const GArgs& p, const int bid, const int zid, unsigned char* smem) {
     using Cf = BtCfg<BM, BN, WM, WN>;
@@ -450,123 +573,175 @@ __device__ __forceinline__ void gemm_bt_body(const GArgs& p, const int bid, cons
     stamp(16);
     if (STAGGER && !late) load_done();              // group 0 meets group 1's last barrier
 
-    // epilogue: every wave on its own, quadrant by quadrant through its own 32 FM x 32 FN floats of LDS (the stages are free once
-    // everybody has left the k-loop).  The loop over quadrants is ROLLED; only the register -> LDS part depends on which
-    // accumulators are meant.
-    constexpr int TW = 32 * FM * 32 * FN;          // floats per wave
-    static_assert(NW * TW * 4 <= Cf::SMEM, "wave-private staging fits the operand stages");
-    float* Tw = reinterpret_cast<float*>(smem) + wave * TW;
-    float sqs = 0.f;
-    const int kind = bt_epilogue_kind(p);
-    if constexpr (BM * BN < 256 * 256) if (p.splits > 1) {     // (the 256x256 tile: 256 KB of partials per split and workgroup - not offered)
-        // Split-K inside the launch: every split parks its partial tile in the workspace (fragment order: 16 bytes per lane,
-        // lane-contiguous, WRITE-THROUGH stores — sc1 — so the data is on the memory side of the eight L2s without a release
-        // fence), drains, takes a ticket; the LAST arriver of a tile re-reads all partials with sc1 loads in split order
-        // (bitwise reproducible whatever the arrival order) and runs the epilogue.  cdna_hip_programming.md §6 Guideline 16 R1.
-        constexpr int NT = 64 * NW, GROUPS = 4 * NF * 4;                  // 16-byte groups per lane: quadrants x fragments x 4
-        const int tile = p.tile0 + tm * p.tiles_n + tn;
-        float* part = p.ws + VITAE_GLDS_TICKETS + (long)tile * p.splits * (NT * GROUPS * 4);
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(part, 0, p.splits * (NT * GROUPS * 16), 0x00020000);
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        const int toff = (int)threadIdx.x * 16;
-        if constexpr (NACC == 2) {
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-#pragma unroll
-                    for (int f = 0; f < NF; ++f)
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) acc[a][b][0][f][i] += acc[a][b][NACC - 1][f][i];
-        }
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int f = 0; f < NF; ++f)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        f32x4 v;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = acc[a][b][0][f][4 * g + e];
-                        const int grp = ((a * 2 + b) * NF + f) * 4 + g;
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (zid * GROUPS + grp) * (NT * 16) + toff, 0, 16);
-                    }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its own stores
-        __syncthreads();
-        int* flag = reinterpret_cast<int*>(smem);
-        if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(reinterpret_cast<int*>(p.ws) + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if (*flag != p.splits - 1) return;
-        __syncthreads();                                          // everyone has read the flag before the staging area is reused
-        // all GROUPS loads of one split in flight together (a first version with one quadrant's four at a time cost the last
-        // arriver 4 x splits dependent round trips to the memory side, ~1 us each)
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int f = 0; f < NF; ++f)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        acc[a][b][0][f][i] = 0.f;
-                        if (NACC == 2) acc[a][b][NACC - 1][f][i] = 0.f;
-                    }
-#pragma unroll 1
-        for (int sp = 0; sp < p.splits; ++sp) {
-            f32x4 v[GROUPS];
-#pragma unroll
-            for (int i = 0; i < GROUPS; ++i)
-                v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (sp * GROUPS + i) * (NT * 16) + toff, 0, 16));
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-#pragma unroll
-                    for (int f = 0; f < NF; ++f)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) acc[a][b][0][f][4 * g + e] += v[((a * 2 + b) * NF + f) * 4 + g][e];
-        }
-        if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<int*>(p.ws) + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-    }
-    // the bias of the wave's two column ranges, fetched under the barrier (issued inside the quadrant loop it cost every
-    // quadrant one exposed memory latency)
-    f32x4 biasq[2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int n = n0 + b * HN + wn * 32 * FN + 4 * (lane % (8 * FN));
-        biasq[b] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (p.bias && n < p.N) biasq[b] = *reinterpret_cast<const f32x4*>(p.bias + n);
-    }
-    __syncthreads();                               // every wave is done with the operand stages
-    stamp(17);
-#pragma unroll 1
-    for (int q = 0; q < 4; ++q) {
-        switch (q) {
-            case 0: bt_park_quadrant<FM, FN, NACC>(acc[0][0], lane, Tw); break;
-            case 1: bt_park_quadrant<FM, FN, NACC>(acc[0][1], lane, Tw); break;
-            case 2: bt_park_quadrant<FM, FN, NACC>(acc[1][0], lane, Tw); break;
-            default: bt_park_quadrant<FM, FN, NACC>(acc[1][1], lane, Tw); break;
-        }
-        __builtin_amdgcn_wave_barrier();           // compiler-only: the lanes' writes stay in front of the other lanes' reads
-        bt_wave_epilogue<FM, FN>(p, kind, m0 + (q >> 1) * HM + wm * 32 * FM, n0 + (q & 1) * HN + wn * 32 * FN, Tw, lane, sqs, (q & 1) ? biasq[1] : biasq[0]);
-        __builtin_amdgcn_wave_barrier();
-        stamp(18 + q);
-    }
-    if (p.sqacc) {
-        sqs = wave_sum(sqs);
-        if (lane == 0) atomicAdd(p.sqacc, (double)sqs);
-    }
-    if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(25); }
+    bt_tail<BM, BN, WM, WN, NACC>(p, acc, smem, m0, n0, tm, tn, zid, wave, lane, stamp);
 }
 
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bt_kernel(const GArgs p) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[BtCfg<BM, BN, WM, WN>::SMEM];      // the ONLY LDS object
     gemm_bt_body<BM, BN, WM, WN, A_KC, B_KC>(p, blockIdx.x, blockIdx.z, smem);
+}
+
+// ---- wave-specialised 128 x 128 tile (tile id 4, round 4) --------------------------------------------------------------------
+// Why: on the 128 x 128 tile above every wave issues its own LDS-DMA pieces between its MFMAs.  A piece occupies the issuing wave
+// for 60-180 clocks (the CU's texture addresser takes ~45 B/clk, and the wave sits at the instruction until its 1 KB is accepted):
+// eight pieces per wave and k-tile are 500-1400 clocks during which that wave issues no MFMA — a lone workgroup runs ~1465 clocks
+// per 64-deep k-tile for 512 clocks of MFMA, and two workgroups per CU are no faster (LABNOTES round-4 notes).  Here the roles are
+// split: waves 0-3 (one per SIMD) only read fragments and issue MFMAs, waves 4-7 (their SIMD partners) only issue DMA.  A blocked
+// DMA instruction stalls nobody but its own wave; the matrix pipe of the SIMD keeps running on the consumer wave.
+//   * S stages of one whole k-tile (A 128 x 64 | B 128 x 64 = 32 KB); producers run S - 1 tiles ahead;
+//   * ONE workgroup barrier per k-tile.  B_t (t = 0 .. nk - 1) promises: tile t has landed (every producer waited for its own
+//     pieces of it with a counted vmcnt before arriving) and every fragment read of tile t - 1 has retired (every consumer waited
+//     lgkmcnt(0) before arriving), so the producers restage tile t - 1's slot with tile t + S - 1 right after it;
+//   * a consumer crosses B_{t+1} in the MIDDLE of k-tile t (after the MFMAs of k-slices 0-1, with the fragments of slices 2-3
+//     already in registers) and reads slices 0-1 of tile t + 1 under the MFMAs of slices 2-3: no fragment-read latency is exposed
+//     at a tile boundary;
+//   * producers leave after the last barrier; the consumers run the family's tail (in-launch split-K fix-up, wave-private epilogue).
+#ifndef VITAE_WS_STAGES
+#define VITAE_WS_STAGES 4
+#endif
+#ifndef VITAE_WS_ABLATE
+#define VITAE_WS_ABLATE 0         // timing experiments (results are garbage): 1 no MFMA, 2 half of the DMA pieces, 4 no fragment reads,
+                                  // 8 ONE producer wave issues every piece (correct results), 16 consumer wave 0 (the producer's SIMD partner) skips its MFMAs
+#endif
+template <bool A_KC, bool B_KC, int S>
+__device__ __forceinline__ void gemm_ws_body(const GArgs& p, const int bid, const int zid, unsigned char* smem) {
+    constexpr int BM = 128, BN = 128, NWC = 4, NWP = (VITAE_WS_ABLATE & 8) ? 1 : 4;
+    constexpr int A_T = BM * BK * 2, B_T = BN * BK * 2, STG = A_T + B_T;
+    constexpr int PA = pieces<BM, A_KC, NWP>(), PB = pieces<BN, B_KC, NWP>(), PT = PA + ((VITAE_WS_ABLATE & 2) ? 0 : PB);
+    static_assert(S >= 3 && S <= 5 && S * STG <= 160 * 1024 && (S - 2) * PT <= 63, "stages fit LDS, three tiles of pieces fit the vmcnt field");
+    const int T = p.tiles_m * p.tiles_n;
+    const int xq = T >> 3, xr = T & 7, xcd = bid & 7;
+    const int lin = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    if ((bid >> 3) >= xq + (xcd < xr ? 1 : 0)) return;
+    const int tn = p.xcd_m ? lin % p.tiles_n : lin / p.tiles_m;
+    const int tm = p.xcd_m ? lin / p.tiles_n : lin % p.tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = zid * p.k_per_split;
+    const int nk = (min(p.K, kbeg + p.k_per_split) - kbeg) / BK;         // >= 2 (launcher)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    auto barrier = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto stamp = [&](int i) {
+        if (p.dbg && lane == 0 && (wave & 3) == 0) p.dbg[(((long)zid * (8 * ((T + 7) >> 3)) + bid) * 2 + (wave >> 2)) * 32 + i] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
+
+    if (wave >= NWC) {
+        // ---------------- producers: DMA only ----------------
+        const int pw = wave - NWC;
+        auto issue_tile = [&](int t, int stage) {
+            unsigned char* dst = smem + stage * STG;
+            const int k0 = kbeg + t * BK;
+#pragma unroll
+            for (int j = 0; j < PA; ++j) dma_piece<BM, A_KC, NWP>(p.A, p.lda, p.M, m0, k0, dst, pw, lane, j);
+#pragma unroll
+            for (int j = 0; j < ((VITAE_WS_ABLATE & 2) ? 0 : PB); ++j) dma_piece<BN, B_KC, NWP>(p.B, p.ldb, p.N, n0, k0, dst + A_T, pw, lane, j);
+        };
+        auto wait_tiles = [&](int fly) {       // all but the youngest `fly` tiles of this wave's pieces have landed
+            if (S >= 5 && fly >= 3) wait_vmcnt<(S >= 5 ? 3 : 1) * PT>();
+            else if (S >= 4 && fly >= 2) wait_vmcnt<(S >= 4 ? 2 : 1) * PT>();
+            else if (fly >= 1) wait_vmcnt<PT>();
+            else wait_vmcnt<0>();
+        };
+        const int npre = min(S - 1, nk);
+        const bool active = pw < NWP;
+        for (int t = 0; t < npre; ++t) if (active) issue_tile(t, t);
+        wait_tiles(npre - 1);
+        barrier();                                                       // B_0
+        int stage = npre % S;                                            // slot of tile t + S - 1 (= tile t - 1's)
+#pragma unroll 1
+        for (int t = 0; t + 1 < nk; ++t) {
+            if (t + S - 1 < nk) {
+                if (active) issue_tile(t + S - 1, stage);
+                stage = stage + 1 == S ? 0 : stage + 1;
+            }
+            wait_tiles(min(t + S - 1, nk - 1) - (t + 1));                // B_{t+1}: tile t + 1 has landed
+            barrier();
+        }
+        return;
+    }
+
+    // ---------------- consumers: fragment reads + MFMA ----------------
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 acc[2][2][1][1];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][0][0][i] = 0.f;
+    bf16x8 fa[BK / 16][2], fb[BK / 16][2];
+    if (VITAE_WS_ABLATE & 4) {
+#pragma unroll
+        for (int k = 0; k < BK / 16; ++k)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { fa[k][h][e] = (__bf16)(float)lane; fb[k][h][e] = (__bf16)1.f; }
+    }
+    constexpr int RK = (A_KC ? 2 : 4) + (B_KC ? 2 : 4);                 // LDS instructions of one k-slice's fragments
+    constexpr int W2 = 2 * RK > 15 ? 15 : 2 * RK;
+    auto rd = [&](const unsigned char* TA, auto kk_c) {
+        constexpr int kk = decltype(kk_c)::value;
+        const unsigned char* TB = TA + A_T;
+        if (VITAE_WS_ABLATE & 4) return;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) fa[kk][h] = frag_asm<BM, A_KC>(TA, h * 64 + wm * 32, kk, lane);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) fb[kk][h] = frag_asm<BN, B_KC>(TB, h * 64 + wn * 32, kk, lane);
+    };
+    auto mm = [&](auto kk_c) {
+        constexpr int kk = decltype(kk_c)::value;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { frag_tie(fa[kk][h]); frag_tie(fb[kk][h]); }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                if (!(VITAE_WS_ABLATE & 1) && !((VITAE_WS_ABLATE & 16) && wave == 0)) acc[a][b][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][a], fb[kk][b], acc[a][b][0][0], 0, 0, 0);
+    };
+    using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
+    barrier();                                                           // B_0: tile 0 is in LDS
+    rd(smem, K0{}); rd(smem, K1{});
+    int stage = 0;
+#pragma unroll 1
+    for (int t = 0; t < nk; ++t) {
+        const unsigned char* TA = smem + stage * STG;
+        __builtin_amdgcn_sched_barrier(0);
+        rd(TA, K2{}); rd(TA, K3{});
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(W2) : "memory");     // slices 0-1 (read one barrier ago) are in registers
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        mm(K0{}); mm(K1{});
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // every read of tile t has retired: its slot may be restaged
+        if (t + 1 < nk) {
+            barrier();                                                   // B_{t+1}
+            stage = stage + 1 == S ? 0 : stage + 1;
+            const unsigned char* TN = smem + stage * STG;
+            rd(TN, K0{}); rd(TN, K1{});
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_setprio(1);
+        mm(K2{}); mm(K3{});
+        __builtin_amdgcn_s_setprio(0);
+    }
+    stamp(16);
+    bt_tail<BM, BN, 2, 2, 1>(p, acc, smem, m0, n0, tm, tn, zid, wave, lane, stamp);
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(512, 2) void gemm_ws_kernel(const GArgs p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[VITAE_WS_STAGES * 32768];      // the ONLY LDS object
+    gemm_ws_body<A_KC, B_KC, VITAE_WS_STAGES>(p, blockIdx.x, blockIdx.z, smem);
 }
 
 // Up to four weight-gradient problems dW_i[N_i, K_i] (+)= dy_i^T x_i of one transformer block (same reduction length: the padded
@@ -594,6 +769,7 @@ bool bt_tile_dims(int id, int& bm, int& bn) {
     switch (id) {
         case 0: bm = 256; bn = 256; return true;
         case 3: bm = 128; bn = 128; return true;
+        case 4: bm = 128; bn = 128; return true;       // wave-specialised (4 MFMA waves + 4 DMA waves, one workgroup per CU)
         default: return false;
     }
 }
@@ -615,7 +791,12 @@ int bt_launch(GArgs p, int a_kc, int b_kc, int id, hipStream_t st) {
     // (256x128 and 128x256 on eight waves were built and measured too: four MFMAs per phase against the same barrier / DMA
     // overhead as eight — 2150 clocks per k-tile for 1024 of MFMA — never the best tile on any shape of the step: not kept)
     if (id == 0) bt_launch_cfg<256, 256, 2, 4>(p, a_kc, b_kc, st);
-    else bt_launch_cfg<128, 128, 2, 2>(p, a_kc, b_kc, st);
+    else if (id == 4) {
+        const dim3 grid(8 * cdiv((long)p.tiles_m * p.tiles_n, 8), 1, p.splits), block(512);
+        if (a_kc && b_kc) hipLaunchKernelGGL((gemm_ws_kernel<true, true>), grid, block, 0, st, p);
+        else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_ws_kernel<true, false>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((gemm_ws_kernel<false, false>), grid, block, 0, st, p);
+    } else bt_launch_cfg<128, 128, 2, 2>(p, a_kc, b_kc, st);
     return vitae_launch_status();
 }
 

@@ -643,8 +643,16 @@ inline BtPlan bt_plan(int M, int N, int K, int a_kc, int b_kc, bool allow_split,
     BtPlan best{-1, 1, 1e30};
     if (g_bt_mode == -2 || K < 2 * BK || (K % BK) || (!a_kc && b_kc) || (N & 3)) return best;
     const int nkt = K / BK;
-    for (int id : {0, 3}) {
+    static const int ws_on = getenv("VITAE_BT_WS") ? atoi(getenv("VITAE_BT_WS")) : 1;      // 0: the wave-specialised tile only when forced
+    static const double ws_kt = getenv("VITAE_BT_WS_KT") ? atof(getenv("VITAE_BT_WS_KT")) : 800.0;
+    static const int ws_min_rows = getenv("VITAE_BT_WS_MIN_ROWS") ? atoi(getenv("VITAE_BT_WS_MIN_ROWS")) : 2048;
+    static const double ws_fix = getenv("VITAE_BT_WS_FIX") ? atof(getenv("VITAE_BT_WS_FIX")) : 14000.0;
+    for (int id : {0, 3, 4}) {
         if (g_bt_mode >= 0 && id != g_bt_mode) continue;
+        if (id == 4 && g_bt_mode < 0 && !ws_on) continue;
+        // (the wave-specialised tile needs many token rows: at batch 8 — 880 / 1736 rows — it un-pairs launches the 64-row family
+        // serves as well and the step loses 7 %)
+        if (id == 4 && g_bt_mode < 0 && (a_kc ? M : K) < ws_min_rows) continue;
         int bm, bn;
         bt_tile_dims(id, bm, bn);
         // (a FORCED tile — tests, tools — is held to what the kernel itself needs: two k-tiles per split, any M / N)
@@ -652,15 +660,17 @@ inline BtPlan bt_plan(int M, int N, int K, int a_kc, int b_kc, bool allow_split,
         if (!forced && (M < bm / 2 || N < bn / 2)) continue;
         const long tiles = (long)cdiv(M, bm) * cdiv(N, bn);
         static const int fsplit = getenv("VITAE_BT_SPLIT") ? atoi(getenv("VITAE_BT_SPLIT")) : 0;   // tools: with a forced tile, this split only
-        for (int s = 1; s <= (id == 3 && allow_split ? 8 : 1); ++s) {
+        for (int s = 1; s <= (id >= 3 && allow_split ? 8 : 1); ++s) {
             if (forced && fsplit > 0 && s != fsplit) continue;
             const int kps = cdiv(cdiv(K, s), BK) * BK;
             if (cdiv(K, kps) != s || kps < (forced ? 2 : 4) * BK || K - (s - 1) * kps < 2 * BK) continue;
             if (s > 1 && (tiles > VITAE_GLDS_TICKETS || (cap >= 0 && VITAE_GLDS_TICKETS + tiles * s * bm * bn > cap))) continue;
-            const double wgs = (double)tiles * s, slots = id == 0 ? 256 : 512;
+            const double wgs = (double)tiles * s, slots = id == 3 ? 512 : 256;
             const double rounds = (double)cdiv((long)wgs, (long)slots);
             const double nk = (double)nkt / s;
-            const double per = id == 0 ? 3000 + 2950 * nk + 14500 : 4500 + 1800 * nk + 7500 + (s > 1 ? 6000 + 2200 * s : 0);
+            const double per = id == 0 ? 3000 + 2950 * nk + 14500
+                             : id == 4 ? ws_fix + ws_kt * nk + (s > 1 ? 6000 + 2200 * s : 0)
+                                       : 4500 + 1800 * nk + 7500 + (s > 1 ? 6000 + 2200 * s : 0);
             const double clk = rounds * per;
             if (clk < best.clocks) best = BtPlan{id, s, clk};
         }
@@ -680,7 +690,7 @@ void launch_pair(int id2, dim3 grid, hipStream_t st, const GArgs& p1, const GArg
 }  // namespace
 
 extern "C" int vitae_gemm_glds_set_bt_tile(int mode) {
-    if (mode < -2 || mode > 3 || mode == 1 || mode == 2) return VITAE_ERR_INVALID_ARG;
+    if (mode < -2 || mode > 4 || mode == 1 || mode == 2) return VITAE_ERR_INVALID_ARG;
     g_bt_mode = mode;
     return VITAE_OK;
 }

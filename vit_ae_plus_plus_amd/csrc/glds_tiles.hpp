@@ -100,6 +100,27 @@ __device__ __forceinline__ bf16x8 frag(const unsigned char* T, int row0, int kk,
     }
 }
 
+// The same fragment with EVERY LDS read as inline asm (the k-contiguous ds_read_b128 too): hipcc then tracks none of a loop's
+// reads and inserts no waits of its own — in a loop whose header merges a preheader with scalar loads still pending, its lgkmcnt
+// bookkeeping falls back to lgkmcnt(0) in front of the first use, which drains the reads issued for the NEXT k-slices (seen in the
+// ISA of the wave-specialised kernel).  The caller counts: frag_asm_reads<KC>() LDS instructions per fragment, in issue order.
+__device__ __forceinline__ bf16x8 lds_read_b128_asm(unsigned addr) {
+    bf16x8 r;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr));
+    return r;
+}
+template <bool KC> constexpr int frag_asm_reads() { return KC ? 1 : 2; }
+template <int ROWS, bool KC>
+__device__ __forceinline__ bf16x8 frag_asm(const unsigned char* T, int row0, int kk, int lane) {
+    if constexpr (KC) {
+        typedef __attribute__((address_space(3))) const unsigned char lds_u8;
+        const int r = row0 + (lane & 31), c = 2 * kk + (lane >> 5);
+        return lds_read_b128_asm((unsigned)(uintptr_t)(lds_u8*)T + r * 128 + ((c ^ swz<true, 8>(r)) << 4));
+    } else {
+        return frag<ROWS, false>(T, row0, kk, lane);
+    }
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
