@@ -598,7 +598,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bt_kernel(const GArgs p)
 //     at a tile boundary;
 //   * producers leave after the last barrier; the consumers run the family's tail (in-launch split-K fix-up, wave-private epilogue).
 #ifndef VITAE_WS_STAGES
-#define VITAE_WS_STAGES 4
+#define VITAE_WS_STAGES 3         // (3 / 4 / 5 stages measured alike: the loop is bound by the L2 -> LDS feed, not by its latency)
+#endif
+#ifndef VITAE_WS_TAIL8
+#define VITAE_WS_TAIL8 1          // unsplit launches: the producer waves take half of the epilogue (quadrants A-hi x B-lo / B-hi of their SIMD partner)
 #endif
 #ifndef VITAE_WS_ABLATE
 #define VITAE_WS_ABLATE 0         // timing experiments (results are garbage): 1 no MFMA, 2 half of the DMA pieces, 4 no fragment reads,
@@ -609,7 +612,7 @@ __device__ __forceinline__ void gemm_ws_body(const GArgs& p, const int bid, cons
     constexpr int BM = 128, BN = 128, NWC = 4, NWP = (VITAE_WS_ABLATE & 8) ? 1 : 4;
     constexpr int A_T = BM * BK * 2, B_T = BN * BK * 2, STG = A_T + B_T;
     constexpr int PA = pieces<BM, A_KC, NWP>(), PB = pieces<BN, B_KC, NWP>(), PT = PA + ((VITAE_WS_ABLATE & 2) ? 0 : PB);
-    static_assert(S >= 3 && S <= 5 && S * STG <= 160 * 1024 && (S - 2) * PT <= 63, "stages fit LDS, three tiles of pieces fit the vmcnt field");
+    static_assert(S >= 3 && S <= 5 && S * STG + (VITAE_WS_TAIL8 ? 12 * 4096 : 0) <= 160 * 1024 && (S - 2) * PT <= 63, "stages fit LDS, three tiles of pieces fit the vmcnt field");
     const int T = p.tiles_m * p.tiles_n;
     const int xq = T >> 3, xr = T & 7, xcd = bid & 7;
     const int lin = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
@@ -662,6 +665,26 @@ __device__ __forceinline__ void gemm_ws_body(const GArgs& p, const int bid, cons
             }
             wait_tiles(min(t + S - 1, nk - 1) - (t + 1));                // B_{t+1}: tile t + 1 has landed
             barrier();
+        }
+        if (!VITAE_WS_TAIL8 || p.splits > 1) return;                     // (split launches: the consumers' fix-up has barriers of its own)
+        // the epilogue of the partner's two A-hi quadrants, parked by it in this wave's two LDS regions behind the stages
+        const int wmp = pw >> 1, wnp = pw & 1;
+        f32x4 bq[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int n = n0 + b * 64 + wnp * 32 + 4 * (lane % 8);
+            bq[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.bias && n < p.N) bq[b] = *reinterpret_cast<const f32x4*>(p.bias + n);
+        }
+        const int kind = bt_epilogue_kind(p);
+        const float* Pq = reinterpret_cast<const float*>(smem + S * STG) + pw * 2048;
+        float sqs = 0.f;
+        barrier();                                                       // T: the partner's quadrants are in LDS
+#pragma unroll 1
+        for (int b = 0; b < 2; ++b) bt_wave_epilogue<1, 1>(p, kind, m0 + 64 + wmp * 32, n0 + b * 64 + wnp * 32, Pq + b * 1024, lane, sqs, b ? bq[1] : bq[0]);
+        if (p.sqacc) {
+            sqs = wave_sum(sqs);
+            if (lane == 0) atomicAdd(p.sqacc, (double)sqs);
         }
         return;
     }
@@ -735,12 +758,45 @@ __device__ __forceinline__ void gemm_ws_body(const GArgs& p, const int bid, cons
         __builtin_amdgcn_s_setprio(0);
     }
     stamp(16);
+    if (VITAE_WS_TAIL8 && p.splits == 1) {
+        // unsplit launch: quadrants (A-hi, B-lo) and (A-hi, B-hi) go to the SIMD partner (a producer wave, idle by now) through
+        // its two 4 KB regions behind the stages; this wave keeps (A-lo, B-lo) and (A-lo, B-hi).  Nothing here touches the stages,
+        // which slower waves may still be reading.
+        float* Pq = reinterpret_cast<float*>(smem + S * STG) + wave * 2048;
+        float* Tw = reinterpret_cast<float*>(smem + S * STG) + 4 * 2048 + wave * 1024;
+        f32x4 bq[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int n = n0 + b * 64 + wn * 32 + 4 * (lane % 8);
+            bq[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.bias && n < p.N) bq[b] = *reinterpret_cast<const f32x4*>(p.bias + n);
+        }
+        const int kind = bt_epilogue_kind(p);
+        bt_park_quadrant<1, 1, 1>(acc[1][0], lane, Pq);
+        bt_park_quadrant<1, 1, 1>(acc[1][1], lane, Pq + 1024);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the parked values are in LDS before the partner is released
+        barrier();                                                       // T
+        float sqs = 0.f;
+#pragma unroll 1
+        for (int b = 0; b < 2; ++b) {
+            if (b == 0) bt_park_quadrant<1, 1, 1>(acc[0][0], lane, Tw);
+            else bt_park_quadrant<1, 1, 1>(acc[0][1], lane, Tw);
+            __builtin_amdgcn_wave_barrier();
+            bt_wave_epilogue<1, 1>(p, kind, m0 + wm * 32, n0 + b * 64 + wn * 32, Tw, lane, sqs, b ? bq[1] : bq[0]);
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (p.sqacc) {
+            sqs = wave_sum(sqs);
+            if (lane == 0) atomicAdd(p.sqacc, (double)sqs);
+        }
+        return;
+    }
     bt_tail<BM, BN, 2, 2, 1>(p, acc, smem, m0, n0, tm, tn, zid, wave, lane, stamp);
 }
 
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(const GArgs p) {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[VITAE_WS_STAGES * 32768];      // the ONLY LDS object
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[VITAE_WS_STAGES * 32768 + (VITAE_WS_TAIL8 ? 12 * 4096 : 0)];      // the ONLY LDS object
     gemm_ws_body<A_KC, B_KC, VITAE_WS_STAGES>(p, blockIdx.x, blockIdx.z, smem);
 }
 

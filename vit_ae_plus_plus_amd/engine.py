@@ -181,6 +181,10 @@ class HipMAEEngine:
         # the predictor branch at batch 32, beside a chain that has no spare CUs there)
         self.pred16 = self.act16 and (cfg.embed_dim % 64 == 0) and os.environ.get('VITAE_PREDICTOR_BF16', '1') != '0'
         self.ws16_side = torch.zeros(1 << 22, **f32) if self.pred16 else None
+        # grouped weight gradients of a block (many token rows) on the wgrad side stream: they fill the CUs the dependent chain's
+        # 168-220-tile launches leave idle; two alternating sets of dy operands, a set is rewritten two blocks later
+        self.wgrad_group_side = os.environ.get('VITAE_WGRAD_GROUP_SIDE', '1') == '1'
+        self.ws16_wside = torch.zeros(1 << 24, **f32) if (self.act16 and self.wgrad_group_side) else None
         self.ln_part_on = os.environ.get('VITAE_LN_PART', '1') != '0'
         self.ln_part_min = int(float(os.environ.get('VITAE_LN_PART_MIN', '1.2e6')))   # LayerNorm backward through partial records (no atomics)
         self._ln_pending = []
@@ -407,6 +411,9 @@ class HipMAEEngine:
                 b[pre + 'dx_16'], b[pre + 'dh_16'], b[pre + 'dqkv_16'] = z16(Mp, d), z16(Mp, h), z16(Mp, 3 * d)
                 if Mp * d >= self.wgrad_group_min:
                     b[pre + 'dx_16b'] = z16(Mp, d)
+                    if self.wgrad_group_side:
+                        for nm, w in (('dx_16', d), ('dx_16b', d), ('dh_16', h), ('dqkv_16', 3 * d)):
+                            b[pre + nm + '_alt'] = z16(Mp, w)
             b['dn_16'] = z16(self.Mpd, Dd)
             b['dpred_16'] = z16(self.Mpd, P)
             b['patches_16'], b['dtok_16'] = z16(self.Mpt, P), z16(self.Mpt, D)
@@ -796,20 +803,30 @@ class HipMAEEngine:
         lds = 4 * NP * (hd + 8) * 2 + 2 * NP * 4 + 3 * hd * 4
         return None if (lds <= 150 * 1024 and os.environ.get('VITAE_ATTN_BWD_FUSED', '1') != '0') else dqkv
 
-    def _block_bwd16(self, pre, q, s, x_in, Bs, N, d, heads, hd, hid, Mp, prev_fc2_bias):
+    def _dyset(self, i, Mp, d) -> str:
+        """Suffix of the buffer set that holds block i's output-gradient operands (side-stream grouped weight gradients: two
+        alternating sets, so that block i's weight-gradient launch may still read its set while block i - 1 runs)."""
+        return '_alt' if (self.wgrad_group_side and (i & 1) and Mp * d >= self.wgrad_group_min) else ''
+
+    def _block_bwd16(self, pre, q, s, x_in, Bs, N, d, heads, hd, hid, Mp, prev_fc2_bias, idx=0):
         """Backward of one block on bf16 operands.  On entry buf[s+'dx'] (fp32) and buf[s+'dx_16'] hold the
         output gradient and the fc2 bias gradient has already been produced by whoever wrote dx.
         ``prev_fc2_bias``: gradient slot of the fc2 bias of the block this one feeds INTO dx for (block i-1)."""
         b, p, g, M = self.buf, self.p, self.g, Bs * N
         self._scope = s
-        dx, dx16, dh16, dy, do, dqkv, dqkv16 = (b[s + 'dx'], b[s + 'dx_16'], b[s + 'dh_16'], b[s + 'dy'], b[s + 'do'],
-                                                  b[s + 'dqkv'], b[s + 'dqkv_16'])
+        sfx, sfx_out = self._dyset(idx, Mp, d), self._dyset(idx - 1, Mp, d)
+        dx, dx16, dh16, dy, do, dqkv, dqkv16 = (b[s + 'dx'], b[s + 'dx_16' + sfx], b[s + 'dh_16' + sfx], b[s + 'dy'], b[s + 'do'],
+                                                  b[s + 'dqkv'], b[s + 'dqkv_16' + sfx])
+        dx16_out = b[s + 'dx_16' + sfx_out]          # norm1's bf16 result: the output gradient of block idx - 1
         # Many token rows (batch >= ~16, patch 8): the four weight gradients of the block leave as ONE launch at its end
         # (``_wgrad_group``) and the Linears' backward launches compute the input gradients only.  Each dy operand then has to
         # survive until that launch: the gradient w.r.t. the block's middle (norm2's output) goes to a second bf16 buffer.
         grp = Mp * d >= self.wgrad_group_min
+        side = grp and self.wgrad_group_side and self.gemm_timer is None
         dw = (lambda name: None) if grp else (lambda name: g[name])
-        dmid16 = b[s + 'dx_16b'] if grp else dx16
+        dmid16 = b[s + 'dx_16b' + sfx] if grp else dx16
+        if side:
+            self._wg_fence(f'{s}grp{idx & 1}')      # the weight gradients of block idx + 2 read this set
         self._g16_bwd(dx16, p[pre + 'mlp.fc2.weight'], b[q + 'act_16'], dw(pre + 'mlp.fc2.weight'), M, Mp, d, hid,
                       dx16=dh16, epi=EPI_DGELU | self._aux16, aux=b[q + 'hpre'], dx_colsum=g[pre + 'mlp.fc1.bias'])
         self._g16_bwd(dh16, p[pre + 'mlp.fc1.weight'], b[q + 'y2_16'], dw(pre + 'mlp.fc1.weight'), M, Mp, hid, d, dx=dy)
@@ -834,12 +851,31 @@ class HipMAEEngine:
         self._g16_bwd(dqkv16, p[pre + 'attn.qkv.weight'], b[q + 'y1_16'], dw(pre + 'attn.qkv.weight'), M, Mp, 3 * d, d, dx=dy,
                       dy_colsum=None if grp else g[pre + 'attn.qkv.bias'])
         if grp:       # (before norm1's backward overwrites dx16, the fc2 weight gradient's dy operand)
-            self._wgrad_group([(dx16, b[q + 'act_16'], g[pre + 'mlp.fc2.weight'], d, hid),
-                               (dh16, b[q + 'y2_16'], g[pre + 'mlp.fc1.weight'], hid, d),
-                               (dmid16, b[q + 'o_16'], g[pre + 'attn.proj.weight'], d, d),
-                               (dqkv16, b[q + 'y1_16'], g[pre + 'attn.qkv.weight'], 3 * d, d)], M, Mp,
-                              bias=None if (qkv_db is not None and self._qkv16_ok(N, hd)) else {3: g[pre + 'attn.qkv.bias']})
-        self._ln_bwd(dy, x_in, pre + 'norm1.', b[q + 'mean1'], b[q + 'rstd1'], dx, M, d, 1, dx16=dx16,
+            items = [(dx16, b[q + 'act_16'], g[pre + 'mlp.fc2.weight'], d, hid),
+                     (dh16, b[q + 'y2_16'], g[pre + 'mlp.fc1.weight'], hid, d),
+                     (dmid16, b[q + 'o_16'], g[pre + 'attn.proj.weight'], d, d),
+                     (dqkv16, b[q + 'y1_16'], g[pre + 'attn.qkv.weight'], 3 * d, d)]
+            bias = None if (qkv_db is not None and self._qkv16_ok(N, hd)) else {3: g[pre + 'attn.qkv.bias']}
+            if side:
+                # beside the chain: its launches leave a third of the CUs idle, and nothing reads these gradients before the phase ends
+                tag = f'{s}grp{idx & 1}'
+                self.wside.wait_stream(torch.cuda.current_stream(self.device))
+                saved = (self.stream, self.ws16)
+                self.stream, self.ws16 = self.wside.cuda_stream, self.ws16_wside
+                try:
+                    with torch.cuda.stream(self.wside):
+                        self._wgrad_group(items, M, Mp, bias=bias)
+                finally:
+                    self.stream, self.ws16 = saved
+                ev = self._wg_events.get(tag)
+                if ev is None:
+                    ev = self._wg_events[tag] = torch.cuda.Event()
+                ev.record(self.wside)
+                self._wg_pending.add(tag)
+                self._wg_fence(f'{s}grp{(idx + 1) & 1}')    # norm1 writes the OTHER set's dx16, which block idx + 1's launch reads
+            else:
+                self._wgrad_group(items, M, Mp, bias=bias)
+        self._ln_bwd(dy, x_in, pre + 'norm1.', b[q + 'mean1'], b[q + 'rstd1'], dx, M, d, 1, dx16=dx16_out,
                      dx_colsum=prev_fc2_bias)
         self._scope = None
 
@@ -1136,11 +1172,11 @@ class HipMAEEngine:
                 self._g16_bwd(b['dpred_16'], p['decoder_pred.weight'], b['dn_16'], g['decoder_pred.weight'], Md, self.Mpd, P, Dd,
                               dx=b['ddn'], dy_colsum=g['decoder_pred.bias'])
                 self._ln_bwd(b['ddn'], dx_[nd], 'decoder_norm.', b['dn_mean'], b['dn_rstd'], b['decdx'], Md, Dd, 0,
-                             dx16=b['decdx_16'],
+                             dx16=b['decdx_16' + self._dyset(nd - 1, self.Mpd, Dd)],
                              dx_colsum=g[f'decoder_blocks.{nd - 1}.mlp.fc2.bias'])
             for i in blocks:
                 self._block_bwd16(f'decoder_blocks.{i}.', f'dec{i}.', 'dec', dx_[i], B, Nd, Dd, cfg.decoder_num_heads, self.hdd,
-                                  self.Hmd, self.Mpd, g[f'decoder_blocks.{i - 1}.mlp.fc2.bias'] if i > 0 else None)
+                                  self.Hmd, self.Mpd, g[f'decoder_blocks.{i - 1}.mlp.fc2.bias'] if i > 0 else None, idx=i)
         else:
             if top:
                 self._lin_bwd(b['dpredfull'], p['decoder_pred.weight'], b['dn'], b['ddn'], g['decoder_pred.weight'],
@@ -1194,7 +1230,7 @@ class HipMAEEngine:
             dec_embed_bwd(0)
         if a16:
             self._ln_bwd(b['dlatent'], b['encx'][cfg.depth], 'norm.', b['lat_mean'], b['lat_rstd'], b['encdx'], Me, D, 0,
-                         dx16=b['encdx_16'],
+                         dx16=b['encdx_16' + self._dyset(cfg.depth - 1, self.Mpe, D)],
                          dx_colsum=g[f'blocks.{cfg.depth - 1}.mlp.fc2.bias'])
         else:
             self._ln_bwd(b['dlatent'], b['encx'][cfg.depth], 'norm.', b['lat_mean'], b['lat_rstd'], b['encdx'], Me, D, 0)
@@ -1243,7 +1279,7 @@ class HipMAEEngine:
         for i in range(hi, lo - 1, -1):
             if self.act16:
                 self._block_bwd16(f'blocks.{i}.', f'enc{i}.', 'enc', ex[i], self.Be, self.Ne, cfg.embed_dim, cfg.num_heads,
-                                  self.hd, self.Hm, self.Mpe, self.g[f'blocks.{i - 1}.mlp.fc2.bias'] if i > 0 else None)
+                                  self.hd, self.Hm, self.Mpe, self.g[f'blocks.{i - 1}.mlp.fc2.bias'] if i > 0 else None, idx=i)
             else:
                 self._block_bwd(f'blocks.{i}.', f'enc{i}.', 'enc', ex[i], self.Be, self.Ne, cfg.embed_dim, cfg.num_heads,
                                 self.hd, self.Hm)
