@@ -646,6 +646,7 @@ inline BtPlan bt_plan(int M, int N, int K, int a_kc, int b_kc, bool allow_split,
     static const int ws_on = getenv("VITAE_BT_WS") ? atoi(getenv("VITAE_BT_WS")) : 1;      // 0: the wave-specialised tile only when forced
     static const double ws_kt = getenv("VITAE_BT_WS_KT") ? atof(getenv("VITAE_BT_WS_KT")) : 800.0;
     static const int ws_min_rows = getenv("VITAE_BT_WS_MIN_ROWS") ? atoi(getenv("VITAE_BT_WS_MIN_ROWS")) : 2048;
+    static const int ws_min_rows_fwd = getenv("VITAE_BT_WS_MIN_ROWS_FWD") ? atoi(getenv("VITAE_BT_WS_MIN_ROWS_FWD")) : 800;      // forward launches are never un-paired: batch 16 7.62 -> 7.51 ms, batch 8 neutral
     static const int ws_long_k = getenv("VITAE_BT_WS_LONG_K") ? atoi(getenv("VITAE_BT_WS_LONG_K")) : 8192;   // ... or a very long reduction (decoder_pred's input gradient, the patch embedding: 37.9 vs 41.7 / 33.8 vs 38.6 us at batch 4)
     static const double ws_kt_w = getenv("VITAE_BT_WS_KT_W") ? atof(getenv("VITAE_BT_WS_KT_W")) : 1050.0;    // both operands row-contiguous (every fragment through two transposing reads)
     static const double ws_fix = getenv("VITAE_BT_WS_FIX") ? atof(getenv("VITAE_BT_WS_FIX")) : 14000.0;
@@ -654,7 +655,7 @@ inline BtPlan bt_plan(int M, int N, int K, int a_kc, int b_kc, bool allow_split,
         if (id == 4 && g_bt_mode < 0 && !ws_on) continue;
         // (the wave-specialised tile needs many token rows: at batch 8 — 880 / 1736 rows — it un-pairs launches the 64-row family
         // serves as well and the step loses 7 %)
-        if (id == 4 && g_bt_mode < 0 && (a_kc ? M : K) < ws_min_rows && K < ws_long_k) continue;
+        if (id == 4 && g_bt_mode < 0 && (a_kc ? M : K) < ((a_kc && b_kc) ? ws_min_rows_fwd : ws_min_rows) && K < ws_long_k) continue;
         int bm, bn;
         bt_tile_dims(id, bm, bn);
         // (a FORCED tile — tests, tools — is held to what the kernel itself needs: two k-tiles per split, any M / N)
