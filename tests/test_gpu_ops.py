@@ -866,7 +866,7 @@ def _bt_operands(form, M, N, K, seed=0):
     return akc, bkc, A, B, Af @ Bf.t()
 
 
-@pytest.mark.parametrize('tile', [0, 3, 4])
+@pytest.mark.parametrize('tile', [0, 3, 4, 5])
 @pytest.mark.parametrize('form', ['fwd', 'dgrad', 'wgrad'])
 @pytest.mark.parametrize('M,N,K', [(868, 16384, 512), (440, 776, 192), (1000, 520, 128), (300, 264, 640), (130, 128, 1024)])
 def test_gemm_bt_forms_and_epilogues(lib, C, bt_mode, tile, form, M, N, K):
@@ -924,7 +924,7 @@ def test_gemm_bt_forms_and_epilogues(lib, C, bt_mode, tile, form, M, N, K):
     assert rel_err(y, F.relu(prod + b)) < 2e-3
 
 
-@pytest.mark.parametrize('tile', [3, 4])
+@pytest.mark.parametrize('tile', [3, 4, 5])
 @pytest.mark.parametrize('form', ['fwd', 'dgrad', 'wgrad'])
 @pytest.mark.parametrize('M,N,K,split', [(880, 768, 3072, 6), (440, 520, 1024, 2), (3456, 768, 4096, 3), (300, 264, 640, 2)])
 def test_gemm_bt_split_k(lib, C, bt_mode, tile, form, M, N, K, split):
@@ -956,8 +956,8 @@ def test_gemm_bt_split_k(lib, C, bt_mode, tile, form, M, N, K, split):
         assert abs(float(sq) - 2 * float(outs[0].double().pow(2).sum())) < 1e-4 * float(sq)      # one share per launch, every element once
 
 
-@pytest.mark.parametrize('tile', [0, 3, 4])
-@pytest.mark.parametrize('M,N,K', [(868, 16384, 512), (3464, 768, 768), (880, 3072, 768)])
+@pytest.mark.parametrize('tile', [0, 3, 4, 5])
+@pytest.mark.parametrize('M,N,K', [(868, 16384, 512), (3464, 768, 768), (880, 3072, 768), (440, 2304, 768)])
 def test_linear_bwd_pair_on_big_tiles(lib, C, bt_mode, tile, M, N, K):
     """vitae_linear_bwd_pair_glds when the planner serves a half with a big tile: the halves leave as two launches — same
     results as the paired launch (dx with GELU', its bf16 copy and column sums; dW, its bf16 copy; the bias gradient)."""
@@ -1026,7 +1026,7 @@ def test_gemm_bt_planner_is_consistent(lib, bt_mode):
     -2 switches the family off."""
     bt_mode(-1)
     assert lib.vitae_gemm_glds_bt_choice(1, 1, 868, 16384, 512) == 0 and lib.vitae_gemm_glds_pick_split_k(868, 16384, 512) == 1
-    assert lib.vitae_gemm_glds_bt_choice(1, 1, 440, 768, 768) == -1                 # a batch-4 encoder shape stays on the 64-row tiles
+    assert lib.vitae_gemm_glds_bt_choice(1, 1, 440, 768, 768) == 5                  # a batch-4 encoder shape: the wave-specialised 64 x 64 tile
     assert lib.vitae_gemm_glds_bt_choice(1, 1, 3456, 768, 16384) == 3 and lib.vitae_gemm_glds_pick_split_k(3456, 768, 16384) > 1
     bt_mode(-2)
     assert lib.vitae_gemm_glds_bt_choice(1, 1, 868, 16384, 512) == -1

@@ -256,7 +256,7 @@ __device__ __forceinline__ void bt_tail(const GArgs& p, f32x16 (&acc)[2][2][NACC
     // everybody has left the k-loop).  The loop over quadrants is ROLLED; only the register -> LDS part depends on which
     // accumulators are meant.
     constexpr int TW = 32 * FM * 32 * FN;          // floats per wave
-    static_assert(NW * TW * 4 <= Cf::SMEM, "wave-private staging fits the operand stages");
+    static_assert(NW * TW * 4 + 64 <= Cf::SMEM, "wave-private staging (+ the norm share of each wave) fits the operand stages");
     float* Tw = reinterpret_cast<float*>(smem) + wave * TW;
     float sqs = 0.f;
     const int kind = bt_epilogue_kind(p);
@@ -359,8 +359,18 @@ __device__ __forceinline__ void bt_tail(const GArgs& p, f32x16 (&acc)[2][2][NACC
         stamp(18 + q);
     }
     if (p.sqacc) {
+        // ONE double atomic per workgroup: every launch of a step adds to the same address, and the L2 serialises them — with one
+        // per wave a 700-workgroup launch queued 2800 of them (the ws64 pair launches: 27 us instead of 17 inside the step)
         sqs = wave_sum(sqs);
-        if (lane == 0) atomicAdd(p.sqacc, (double)sqs);
+        float* red = reinterpret_cast<float*>(smem) + NW * TW;
+        if (lane == 0) red[wave] = sqs;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) tot += red[w];
+            atomicAdd(p.sqacc, (double)tot);
+        }
     }
     if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(25); }
 }
@@ -612,7 +622,7 @@ __device__ __forceinline__ void gemm_ws_body(const GArgs& p, const int bid, cons
     constexpr int BM = 128, BN = 128, NWC = 4, NWP = (VITAE_WS_ABLATE & 8) ? 1 : 4;
     constexpr int A_T = BM * BK * 2, B_T = BN * BK * 2, STG = A_T + B_T;
     constexpr int PA = pieces<BM, A_KC, NWP>(), PB = pieces<BN, B_KC, NWP>(), PT = PA + ((VITAE_WS_ABLATE & 2) ? 0 : PB);
-    static_assert(S >= 3 && S <= 5 && S * STG + (VITAE_WS_TAIL8 ? 12 * 4096 : 0) <= 160 * 1024 && (S - 2) * PT <= 63, "stages fit LDS, three tiles of pieces fit the vmcnt field");
+    static_assert(S >= 3 && S <= 5 && S * STG + (VITAE_WS_TAIL8 ? 12 * 4096 + 64 : 0) <= 160 * 1024 && (S - 2) * PT <= 63, "stages fit LDS, three tiles of pieces fit the vmcnt field");
     const int T = p.tiles_m * p.tiles_n;
     const int xq = T >> 3, xr = T & 7, xcd = bid & 7;
     const int lin = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
@@ -682,9 +692,11 @@ __device__ __forceinline__ void gemm_ws_body(const GArgs& p, const int bid, cons
         barrier();                                                       // T: the partner's quadrants are in LDS
 #pragma unroll 1
         for (int b = 0; b < 2; ++b) bt_wave_epilogue<1, 1>(p, kind, m0 + 64 + wmp * 32, n0 + b * 64 + wnp * 32, Pq + b * 1024, lane, sqs, b ? bq[1] : bq[0]);
-        if (p.sqacc) {
+        if (p.sqacc) {                                                   // one atomic per workgroup (see bt_tail)
             sqs = wave_sum(sqs);
-            if (lane == 0) atomicAdd(p.sqacc, (double)sqs);
+            float* red = reinterpret_cast<float*>(smem + S * STG + 12 * 4096);
+            if (lane == 0) red[wave] = sqs;
+            barrier();
         }
         return;
     }
@@ -787,7 +799,15 @@ __device__ __forceinline__ void gemm_ws_body(const GArgs& p, const int bid, cons
         }
         if (p.sqacc) {
             sqs = wave_sum(sqs);
-            if (lane == 0) atomicAdd(p.sqacc, (double)sqs);
+            float* red = reinterpret_cast<float*>(smem + S * STG + 12 * 4096);
+            if (lane == 0) red[wave] = sqs;
+            barrier();
+            if (threadIdx.x == 0) {
+                float tot = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) tot += red[w];
+                atomicAdd(p.sqacc, (double)tot);
+            }
         }
         return;
     }
@@ -796,8 +816,236 @@ __device__ __forceinline__ void gemm_ws_body(const GArgs& p, const int bid, cons
 
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(const GArgs p) {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[VITAE_WS_STAGES * 32768 + (VITAE_WS_TAIL8 ? 12 * 4096 : 0)];      // the ONLY LDS object
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[VITAE_WS_STAGES * 32768 + (VITAE_WS_TAIL8 ? 12 * 4096 + 64 : 0)];      // the ONLY LDS object
     gemm_ws_body<A_KC, B_KC, VITAE_WS_STAGES>(p, blockIdx.x, blockIdx.z, smem);
+}
+
+// ---- the same structure on a 64 x 64 tile (tile id 5): the few-row launches of the batch-4 / batch-8 step ----------------------
+// At 440-1736 token rows a launch is 84-700 workgroups of a handful of k-tiles each, and a workgroup's k-step is a dependent
+// chain (DMA issue, fragment reads, MFMAs, wait + barrier: ~610 clocks per 64-deep step in gemm_glds.hip, ~880 in its pipelined
+// form inside the step).  With the roles split the chain is gone: a k-step costs what its 16 KB of operands cost the CU's
+// L2 -> LDS path (~400 clocks).  Measured alone (us, ws64 / 64-row family / hipBLASLt): 440 x 2304 x 768 7.2 / 10.4 / 8.3,
+// 440 x 768 x 768 6.5 / 8.4 / 7.2, 868 x 2048 x 512 7.8 / 9.7 / 9.4, weight-gradient form 2304 x 768 x 448 7.7 / 9.4.
+// Each consumer wave owns ONE 32 x 32 fragment (two accumulators: even / odd k-slices).  80 KB of LDS and 97 VGPRs: two workgroups
+// share a CU.  In-launch split-K as in the family (partials through write-through stores, ticket, last arriver sums in split
+// order); RS: the consumer waves of column tile 0 add the row sums of A (one more MFMA against ones per k-slice) = the bias
+// gradient colsum(dy) of a weight-gradient launch.
+#ifndef VITAE_WS64_STAGES
+#define VITAE_WS64_STAGES 3         // 64 KB with the epilogue regions: TWO workgroups per CU (four stages = 80 KB ran one per CU inside the step)
+#endif
+constexpr int WS64_SMEM = VITAE_WS64_STAGES * 16384 + 4 * 4096 + 64;
+template <bool A_KC, bool B_KC, int S, bool RS>
+__device__ __forceinline__ void gemm_ws64_body(const GArgs& p, const int bid, const int zid, unsigned char* smem) {
+    constexpr int BM = 64, BN = 64, NWC = 4, NWP = 4;
+    constexpr int A_T = BM * BK * 2, B_T = BN * BK * 2, STG = A_T + B_T;
+    constexpr int PA = pieces<BM, A_KC, NWP>(), PB = pieces<BN, B_KC, NWP>(), PT = PA + PB;
+    static_assert(S >= 3 && S <= 5 && (S - 2) * PT <= 63, "stage count");
+    const int T = p.tiles_m * p.tiles_n;
+    const int xq = T >> 3, xr = T & 7, xcd = bid & 7;
+    const int lin = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    if ((bid >> 3) >= xq + (xcd < xr ? 1 : 0)) return;
+    const int tn = p.xcd_m ? lin % p.tiles_n : lin / p.tiles_m;
+    const int tm = p.xcd_m ? lin / p.tiles_n : lin % p.tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = zid * p.k_per_split;
+    const int nk = (min(p.K, kbeg + p.k_per_split) - kbeg) / BK;         // >= 2 (launcher)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    auto barrier = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if (wave >= NWC) {
+        // ---------------- producers ----------------
+        const int pw = wave - NWC;
+        auto issue_tile = [&](int t, int stage) {
+            unsigned char* dst = smem + stage * STG;
+            const int k0 = kbeg + t * BK;
+#pragma unroll
+            for (int j = 0; j < PA; ++j) dma_piece<BM, A_KC, NWP>(p.A, p.lda, p.M, m0, k0, dst, pw, lane, j);
+#pragma unroll
+            for (int j = 0; j < PB; ++j) dma_piece<BN, B_KC, NWP>(p.B, p.ldb, p.N, n0, k0, dst + A_T, pw, lane, j);
+        };
+        auto wait_tiles = [&](int fly) {
+            if (S >= 5 && fly >= 3) wait_vmcnt<(S >= 5 ? 3 : 1) * PT>();
+            else if (S >= 4 && fly >= 2) wait_vmcnt<(S >= 4 ? 2 : 1) * PT>();
+            else if (fly >= 1) wait_vmcnt<PT>();
+            else wait_vmcnt<0>();
+        };
+        const int npre = min(S - 1, nk);
+        for (int t = 0; t < npre; ++t) issue_tile(t, t);
+        wait_tiles(npre - 1);
+        barrier();                                                       // B_0
+        int stage = npre % S;
+#pragma unroll 1
+        for (int t = 0; t + 1 < nk; ++t) {
+            if (t + S - 1 < nk) {
+                issue_tile(t + S - 1, stage);
+                stage = stage + 1 == S ? 0 : stage + 1;
+            }
+            wait_tiles(min(t + S - 1, nk - 1) - (t + 1));
+            barrier();                                                   // B_{t+1}
+        }
+        return;
+    }
+    // ---------------- consumers ----------------
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    f32x16 acc[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[h][i] = 0.f;
+    const bool rowsum = RS && p.a_rowsum != nullptr && tn == 0 && wn == 0;   // wave-uniform; every k-split adds its share
+    f32x16 accx;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accx[i] = 0.f;
+    bf16x8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
+    bf16x8 fa[BK / 16], fb[BK / 16];
+    constexpr int RK = (A_KC ? 1 : 2) + (B_KC ? 1 : 2);
+    auto rd = [&](const unsigned char* TA, auto kk_c) {
+        constexpr int kk = decltype(kk_c)::value;
+        fa[kk] = frag_asm<BM, A_KC>(TA, wm * 32, kk, lane);
+        fb[kk] = frag_asm<BN, B_KC>(TA + A_T, wn * 32, kk, lane);
+    };
+    auto mm = [&](auto kk_c) {
+        constexpr int kk = decltype(kk_c)::value;
+        frag_tie(fa[kk]); frag_tie(fb[kk]);
+        acc[kk & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk], fb[kk], acc[kk & 1], 0, 0, 0);
+        if constexpr (RS) {
+            if (rowsum) accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk], ones, accx, 0, 0, 0);
+        }
+    };
+    using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
+    // the bias of this wave's four-column groups, fetched now (after the loop it would cost an exposed memory latency)
+    const int nq = n0 + wn * 32 + 4 * (lane % 8);
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias && nq < p.N) bias4 = *reinterpret_cast<const f32x4*>(p.bias + nq);
+    barrier();                                                           // B_0
+    rd(smem, K0{}); rd(smem, K1{});
+    int stage = 0;
+#pragma unroll 1
+    for (int t = 0; t < nk; ++t) {
+        const unsigned char* TA = smem + stage * STG;
+        __builtin_amdgcn_sched_barrier(0);
+        rd(TA, K2{}); rd(TA, K3{});
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * RK) : "memory");     // slices 0-1 are in registers
+        __builtin_amdgcn_sched_barrier(0);
+        mm(K0{}); mm(K1{});
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // every read of tile t has retired
+        if (t + 1 < nk) {
+            barrier();                                                   // B_{t+1}
+            stage = stage + 1 == S ? 0 : stage + 1;
+            const unsigned char* TN = smem + stage * STG;
+            rd(TN, K0{}); rd(TN, K1{});
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        mm(K2{}); mm(K3{});
+    }
+    if (RS && rowsum && l31 == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 32 + crow(r, hi);
+            if (m < p.M) atomicAdd(p.a_rowsum + m, accx[r]);
+        }
+    }
+    f32x16 accs[1][1];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accs[0][0][i] = acc[0][i] + acc[1][i];
+    float* Tw = reinterpret_cast<float*>(smem + S * STG) + wave * 1024;   // this wave's own 4 KB behind the stages
+    if (p.splits > 1) {
+        // (the producers have left: these barriers count the four consumer waves only)
+        const int tile = p.tile0 + tm * p.tiles_n + tn;
+        float* part = p.ws + VITAE_GLDS_TICKETS + (long)tile * p.splits * (BM * BN);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(part, 0, p.splits * (BM * BN * 4), 0x00020000);
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const int toff = (int)threadIdx.x * 16;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = {accs[0][0][4 * g], accs[0][0][4 * g + 1], accs[0][0][4 * g + 2], accs[0][0][4 * g + 3]};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (zid * 4 + g) * (256 * 16) + toff, 0, 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(smem + S * STG);
+        if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(reinterpret_cast<int*>(p.ws) + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*flag != p.splits - 1) return;
+        __syncthreads();                                                 // everyone has read the flag before Tw is written
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accs[0][0][i] = 0.f;
+#pragma unroll 1
+        for (int sp0 = 0; sp0 < p.splits; sp0 += 4) {
+            f32x4 v[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int sp = min(sp0 + u, p.splits - 1);               // (clamped: a repeated load, never added)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    v[u][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (sp * 4 + g) * (256 * 16) + toff, 0, 16));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (sp0 + u < p.splits) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) accs[0][0][4 * g + e] += v[u][g][e];
+                }
+        }
+        if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<int*>(p.ws) + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    bt_park_quadrant<1, 1, 1>(accs, lane, Tw);
+    __builtin_amdgcn_wave_barrier();
+    float sqs = 0.f;
+    bt_wave_epilogue<1, 1>(p, bt_epilogue_kind(p), m0 + wm * 32, n0 + wn * 32, Tw, lane, sqs, bias4);
+    if (p.sqacc) {                                                       // one atomic per workgroup (see bt_tail)
+        sqs = wave_sum(sqs);
+        float* red = reinterpret_cast<float*>(smem + S * STG + 4 * 4096);
+        if (lane == 0) red[wave] = sqs;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(p.sqacc, (double)((red[0] + red[1]) + (red[2] + red[3])));
+    }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(512, 2) void gemm_ws64_kernel(const GArgs p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[WS64_SMEM];      // the ONLY LDS object
+    gemm_ws64_body<A_KC, B_KC, VITAE_WS64_STAGES, false>(p, blockIdx.x, blockIdx.z, smem);
+}
+
+// Backward of one Linear as ONE launch of such workgroups: the first nb1 * p1.splits blocks compute the input gradient
+// dx = epi(dy W) (A = dy k-contiguous, B = W row-contiguous; its long reduction cut into p1.splits), the rest the weight gradient
+// dW (+)= dy^T x (both row-contiguous; RS: + colsum(dy)).
+template <bool RS>
+__global__ __launch_bounds__(512, 2) void gemm_ws64_pair_kernel(const GArgs p1, const GArgs p2, const int nb1) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[WS64_SMEM];
+    if ((int)blockIdx.x < nb1 * p1.splits) gemm_ws64_body<true, false, VITAE_WS64_STAGES, false>(p1, blockIdx.x % nb1, blockIdx.x / nb1, smem);
+    else gemm_ws64_body<false, false, VITAE_WS64_STAGES, RS>(p2, blockIdx.x - nb1 * p1.splits, 0, smem);
+}
+
+// p1 / p2: complete descriptors of the two halves (vec_epi set, K % 64 == 0); p1.splits k-ranges of >= 2 k-tiles each
+int ws64_pair_launch(GArgs p1, GArgs p2, hipStream_t st) {
+    if (!p1.vec_epi || !p2.vec_epi || (p1.K % BK) || (p2.K % BK) || p2.K < 2 * BK || p1.a_rowsum) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    if (p1.splits < 1) p1.splits = 1;
+    p1.k_per_split = cdiv(cdiv(p1.K, p1.splits), BK) * BK;
+    p1.splits = cdiv(p1.K, p1.k_per_split);
+    if (p1.K - (p1.splits - 1) * p1.k_per_split < 2 * BK || p1.k_per_split < 2 * BK) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    p1.tiles_m = cdiv(p1.M, 64); p1.tiles_n = cdiv(p1.N, 64); p1.tile0 = 0;
+    p2.tiles_m = cdiv(p2.M, 64); p2.tiles_n = cdiv(p2.N, 64); p2.tile0 = 0;
+    p2.k_per_split = p2.K; p2.splits = 1;
+    if (p1.splits > 1 && (!p1.ws || (long)p1.tiles_m * p1.tiles_n > VITAE_GLDS_TICKETS)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    const int nb1 = 8 * cdiv((long)p1.tiles_m * p1.tiles_n, 8), nb2 = 8 * cdiv((long)p2.tiles_m * p2.tiles_n, 8);
+    const dim3 grid(nb1 * p1.splits + nb2), block(512);
+    if (p2.a_rowsum) hipLaunchKernelGGL((gemm_ws64_pair_kernel<true>), grid, block, 0, st, p1, p2, nb1);
+    else hipLaunchKernelGGL((gemm_ws64_pair_kernel<false>), grid, block, 0, st, p1, p2, nb1);
+    return vitae_launch_status();
 }
 
 // Up to four weight-gradient problems dW_i[N_i, K_i] (+)= dy_i^T x_i of one transformer block (same reduction length: the padded
@@ -826,6 +1074,7 @@ bool bt_tile_dims(int id, int& bm, int& bn) {
         case 0: bm = 256; bn = 256; return true;
         case 3: bm = 128; bn = 128; return true;
         case 4: bm = 128; bn = 128; return true;       // wave-specialised (4 MFMA waves + 4 DMA waves, one workgroup per CU)
+        case 5: bm = 64; bn = 64; return true;         // ... on a 64 x 64 tile (unsplit launches)
         default: return false;
     }
 }
@@ -847,7 +1096,12 @@ int bt_launch(GArgs p, int a_kc, int b_kc, int id, hipStream_t st) {
     // (256x128 and 128x256 on eight waves were built and measured too: four MFMAs per phase against the same barrier / DMA
     // overhead as eight — 2150 clocks per k-tile for 1024 of MFMA — never the best tile on any shape of the step: not kept)
     if (id == 0) bt_launch_cfg<256, 256, 2, 4>(p, a_kc, b_kc, st);
-    else if (id == 4) {
+    else if (id == 5) {
+        const dim3 grid(8 * cdiv((long)p.tiles_m * p.tiles_n, 8), 1, p.splits), block(512);
+        if (a_kc && b_kc) hipLaunchKernelGGL((gemm_ws64_kernel<true, true>), grid, block, 0, st, p);
+        else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_ws64_kernel<true, false>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((gemm_ws64_kernel<false, false>), grid, block, 0, st, p);
+    } else if (id == 4) {
         const dim3 grid(8 * cdiv((long)p.tiles_m * p.tiles_n, 8), 1, p.splits), block(512);
         if (a_kc && b_kc) hipLaunchKernelGGL((gemm_ws_kernel<true, true>), grid, block, 0, st, p);
         else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_ws_kernel<true, false>), grid, block, 0, st, p);

@@ -639,7 +639,7 @@ inline double est_64row(int M, int N, int K, bool allow_split, bool wgrad_form) 
 }
 
 // cap: floats of split-K workspace a plan may need (< 0: no limit — the caller sizes the workspace from the plan's split)
-inline BtPlan bt_plan(int M, int N, int K, int a_kc, int b_kc, bool allow_split, long cap = -1) {
+inline BtPlan bt_plan(int M, int N, int K, int a_kc, int b_kc, bool allow_split, long cap = -1, bool allow_ws64 = true) {
     BtPlan best{-1, 1, 1e30};
     if (g_bt_mode == -2 || K < 2 * BK || (K % BK) || (!a_kc && b_kc) || (N & 3)) return best;
     const int nkt = K / BK;
@@ -650,7 +650,9 @@ inline BtPlan bt_plan(int M, int N, int K, int a_kc, int b_kc, bool allow_split,
     static const int ws_long_k = getenv("VITAE_BT_WS_LONG_K") ? atoi(getenv("VITAE_BT_WS_LONG_K")) : 8192;   // ... or a very long reduction (decoder_pred's input gradient, the patch embedding: 37.9 vs 41.7 / 33.8 vs 38.6 us at batch 4)
     static const double ws_kt_w = getenv("VITAE_BT_WS_KT_W") ? atof(getenv("VITAE_BT_WS_KT_W")) : 1050.0;    // both operands row-contiguous (every fragment through two transposing reads)
     static const double ws_fix = getenv("VITAE_BT_WS_FIX") ? atof(getenv("VITAE_BT_WS_FIX")) : 14000.0;
-    for (int id : {0, 3, 4}) {
+    static const int ws64_on = getenv("VITAE_BT_WS64") ? atoi(getenv("VITAE_BT_WS64")) : 1;
+    for (int id : {0, 3, 4, 5}) {
+        if (id == 5 && g_bt_mode != 5 && (!ws64_on || !allow_ws64)) continue;
         if (g_bt_mode >= 0 && id != g_bt_mode) continue;
         if (id == 4 && g_bt_mode < 0 && !ws_on) continue;
         // (the wave-specialised tile needs many token rows: at batch 8 — 880 / 1736 rows — it un-pairs launches the 64-row family
@@ -674,7 +676,12 @@ inline BtPlan bt_plan(int M, int N, int K, int a_kc, int b_kc, bool allow_split,
             const double per = id == 0 ? 3000 + 2950 * nk + 14500
                              : id == 4 ? ws_fix + ((!a_kc && !b_kc) ? ws_kt_w : ws_kt) * nk + (s > 1 ? 6000 + 2200 * s : 0)
                                        : 4500 + 1800 * nk + 7500 + (s > 1 ? 6000 + 2200 * s : 0);
-            const double clk = rounds * per;
+            double clk = rounds * per;
+            if (id == 5) {
+                // wave-specialised 64 x 64: the latency of one workgroup (two share a CU) or, with many, the CUs' L2 -> LDS feed
+                const double lat = 6500 + 420 * nk + (s > 1 ? 5000 + 1500 * s : 0), thr = wgs * (3000 + 420 * nk) / 256;
+                clk = lat > thr ? lat : thr;
+            }
             if (clk < best.clocks) best = BtPlan{id, s, clk};
         }
     }
@@ -693,7 +700,7 @@ void launch_pair(int id2, dim3 grid, hipStream_t st, const GArgs& p1, const GArg
 }  // namespace
 
 extern "C" int vitae_gemm_glds_set_bt_tile(int mode) {
-    if (mode < -2 || mode > 4 || mode == 1 || mode == 2) return VITAE_ERR_INVALID_ARG;
+    if (mode < -2 || mode > 5 || mode == 1 || mode == 2) return VITAE_ERR_INVALID_ARG;
     g_bt_mode = mode;
     return VITAE_OK;
 }
@@ -819,11 +826,39 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
         return gemm_glds_launch(1, 0, dy16, N, w16, K, dx, K, dx16, K, M, K, N, nullptr, nullptr, 0, epi | (aux16 ? VITAE_EPI_AUX_BF16 : 0),
                                 aux, K, dx_accumulate, sp, splitk_ws, dx_colsum_accum, stream, &pd);
     }
+    if (g_bt_mode == -1 || g_bt_mode == 5) {
+        // Few token rows: both halves as wave-specialised 64 x 64 workgroups of ONE launch (gemm_bt.hip: gemm_ws64_pair_kernel)
+        const BtPlan pd = bt_plan(M, K, N, 1, 0, true, cap), pw = bt_plan(N, K, Mpad, 0, 0, false, cap);
+        if (pd.tile == 5 && pw.tile == 5) {
+            GArgs p1, p2;
+            p1.A = reinterpret_cast<const __bf16*>(dy16); p1.lda = N;
+            p1.B = reinterpret_cast<const __bf16*>(w16); p1.ldb = K;
+            p1.C = dx; p1.ldc = K; p1.C16 = reinterpret_cast<__bf16*>(dx16); p1.ldc16 = K;
+            p1.M = M; p1.N = K; p1.K = N; p1.k_per_split = N; p1.splits = pd.split;
+            p1.bias = nullptr; p1.residual = nullptr; p1.ldr = 0; p1.aux = aux; p1.ldaux = K; p1.epi = epi; p1.aux16 = aux16;
+            p1.accumulate = dx_accumulate != 0; p1.ws = splitk_ws; p1.out_colsum = dx_colsum_accum; p1.a_rowsum = nullptr; p1.dbg = nullptr;
+            p1.xcd_m = xcd_by_rows(M, K); p1.tiles_m = 0; p1.tiles_n = 0;
+            p1.vec_epi = vec_epilogue_ok(p1);
+            p2.A = reinterpret_cast<const __bf16*>(dy16); p2.lda = N;
+            p2.B = reinterpret_cast<const __bf16*>(x16); p2.ldb = K;
+            p2.C = dw; p2.ldc = K; p2.C16 = reinterpret_cast<__bf16*>(dw16); p2.ldc16 = K;
+            p2.M = N; p2.N = K; p2.K = Mpad; p2.k_per_split = Mpad; p2.splits = 1;
+            p2.bias = nullptr; p2.residual = nullptr; p2.ldr = 0; p2.aux = nullptr; p2.ldaux = 0; p2.epi = VITAE_EPI_NONE;
+            p2.accumulate = dw_accumulate; p2.ws = nullptr; p2.out_colsum = nullptr; p2.a_rowsum = dy_colsum_accum; p2.dbg = nullptr;
+            p2.sqacc = g_wgrad_sqacc;
+            p2.xcd_m = xcd_by_rows(N, K); p2.tiles_m = 0; p2.tiles_n = 0;
+            p2.vec_epi = vec_epilogue_ok(p2);
+            if (p1.vec_epi && p2.vec_epi) {
+                const int rc = ws64_pair_launch(p1, p2, (hipStream_t)stream);
+                if (rc != VITAE_ERR_UNSUPPORTED_SHAPE) return rc;
+            }
+        }
+    }
     if (g_bt_mode != -2) {
         // When the big tiles serve either half, the halves go out as two launches of their own (each fills the chip; the
         // paired launch exists to double the resident workgroups of two SMALL problems): dx = epi(dy16 @ W16) and
         // dW (+)= dy16^T @ x16 through the planner of vitae_gemm_glds, bias gradient by the column-sum kernel.
-        const BtPlan pd = bt_plan(M, K, N, 1, 0, true, cap), pw = bt_plan(N, K, Mpad, 0, 0, true, cap);
+        const BtPlan pd = bt_plan(M, K, N, 1, 0, true, cap, false), pw = bt_plan(N, K, Mpad, 0, 0, true, cap, false);
         if (pd.tile >= 0 || pw.tile >= 0) {
             // each half: the plan's split when the plan is a big tile, else the 64-row family's own rule, shrunk to the workspace
             auto fit = [&](const BtPlan& bp, int m, int n, int k) {

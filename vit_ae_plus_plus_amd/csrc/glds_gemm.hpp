@@ -102,10 +102,12 @@ __device__ __forceinline__ float epilogue_frag(const GArgs& p, const float (&v)[
     return csum;
 }
 
-// gemm_bt.hip: the big-tile kernels (id 0: 256x256, 1: 256x128, 2: 128x256 on 8 waves; 3: 128x128 on 4 waves).  `p` is a complete
+// gemm_bt.hip: the big-tile kernels (id 0: 256x256 on 8 waves; 3: 128x128 on 4 waves; wave-specialised: 4: 128x128, 5: 64x64).  `p` is a complete
 // descriptor of ONE unsplit problem; tiles_m / tiles_n are set by the launcher.
 bool bt_tile_dims(int id, int& bm, int& bn);
 int bt_launch(GArgs p, int a_kc, int b_kc, int id, hipStream_t st);
 int bt_wgrad_group_launch(GArgs* ps, int n, int splits, hipStream_t st);
+// gemm_bt.hip: input gradient + weight gradient of one Linear as ONE launch of wave-specialised 64 x 64 workgroups (tile id 5)
+int ws64_pair_launch(GArgs p1, GArgs p2, hipStream_t st);
 
 }  // namespace vglds
