@@ -8,7 +8,7 @@ import torch
 from vit_ae_plus_plus_amd._abi import lib
 
 dev = 'cuda'
-NAMES = {0: '256x256', 1: '256x128', 2: '128x256', 3: '128x128', 4: 'ws128', -2: '64-row', -1: 'auto'}
+NAMES = {0: '256x256', 1: '256x128', 2: '128x256', 3: '128x128', 4: 'ws128', 5: 'ws64', -2: '64-row', -1: 'auto'}
 
 
 def graph_time(go, iters):

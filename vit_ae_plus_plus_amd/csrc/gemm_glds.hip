@@ -679,7 +679,9 @@ inline BtPlan bt_plan(int M, int N, int K, int a_kc, int b_kc, bool allow_split,
             double clk = rounds * per;
             if (id == 5) {
                 // wave-specialised 64 x 64: the latency of one workgroup (two share a CU) or, with many, the CUs' L2 -> LDS feed
-                const double lat = 6500 + 420 * nk + (s > 1 ? 5000 + 1500 * s : 0), thr = wgs * (3000 + 420 * nk) / 256;
+                // (fitted to tools/probes/r4_ws64.py / r4_ws64_split.sh: 440 x 768 x 3072 at splits 1 / 2 / 4 / 6 = 16.0 / 12.5 / 11.5 / 14.4 us)
+                const double over = wgs > 256 ? (wgs - 256) / 256 : 0;
+                const double lat = (6500 + 420 * nk + (s > 1 ? 3000 + 1000 * s : 0)) * (1 + 0.2 * over), thr = wgs * (3000 + 420 * nk) / 256;
                 clk = lat > thr ? lat : thr;
             }
             if (clk < best.clocks) best = BtPlan{id, s, clk};
