@@ -831,12 +831,15 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(const GArgs p) {
 // order); RS: the consumer waves of column tile 0 add the row sums of A (one more MFMA against ones per k-slice) = the bias
 // gradient colsum(dy) of a weight-gradient launch.
 #ifndef VITAE_WS64_STAGES
-#define VITAE_WS64_STAGES 3         // 64 KB with the epilogue regions: TWO workgroups per CU (four stages = 80 KB ran one per CU inside the step)
+#define VITAE_WS64_STAGES 4         // 64 KB (the epilogue aliases the stages): TWO workgroups per CU, three k-tiles in flight each
 #endif
-constexpr int WS64_SMEM = VITAE_WS64_STAGES * 16384 + 4 * 4096 + 64;
+constexpr int WS64_SMEM = VITAE_WS64_STAGES * 16384;
 template <bool A_KC, bool B_KC, int S, bool RS>
 __device__ __forceinline__ void gemm_ws64_body(const GArgs& p, const int bid, const int zid, unsigned char* smem) {
-    constexpr int BM = 64, BN = 64, NWC = 4, NWP = 4;
+#ifndef VITAE_WS64_PRODUCERS
+#define VITAE_WS64_PRODUCERS 4
+#endif
+    constexpr int BM = 64, BN = 64, NWC = 4, NWP = VITAE_WS64_PRODUCERS;
     constexpr int A_T = BM * BK * 2, B_T = BN * BK * 2, STG = A_T + B_T;
     constexpr int PA = pieces<BM, A_KC, NWP>(), PB = pieces<BN, B_KC, NWP>(), PT = PA + PB;
     static_assert(S >= 3 && S <= 5 && (S - 2) * PT <= 63, "stage count");
@@ -958,7 +961,10 @@ __device__ __forceinline__ void gemm_ws64_body(const GArgs& p, const int bid, co
     f32x16 accs[1][1];
 #pragma unroll
     for (int i = 0; i < 16; ++i) accs[0][0][i] = acc[0][i] + acc[1][i];
-    float* Tw = reinterpret_cast<float*>(smem + S * STG) + wave * 1024;   // this wave's own 4 KB behind the stages
+    // the epilogue's LDS (4 KB per wave, the split-K flag, the norm shares) ALIASES the stages: every consumer is past its last
+    // fragment read at this barrier, every DMA has landed, and the producers are gone — so the whole LDS budget is prefetch depth
+    __syncthreads();
+    float* Tw = reinterpret_cast<float*>(smem) + wave * 1024;
     if (p.splits > 1) {
         // (the producers have left: these barriers count the four consumer waves only)
         const int tile = p.tile0 + tm * p.tiles_n + tn;
@@ -973,11 +979,10 @@ __device__ __forceinline__ void gemm_ws64_body(const GArgs& p, const int bid, co
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        int* flag = reinterpret_cast<int*>(smem + S * STG);
+        int* flag = reinterpret_cast<int*>(smem + 4 * 4096);
         if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(reinterpret_cast<int*>(p.ws) + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         if (*flag != p.splits - 1) return;
-        __syncthreads();                                                 // everyone has read the flag before Tw is written
 #pragma unroll
         for (int i = 0; i < 16; ++i) accs[0][0][i] = 0.f;
 #pragma unroll 1
@@ -1007,7 +1012,7 @@ __device__ __forceinline__ void gemm_ws64_body(const GArgs& p, const int bid, co
     bt_wave_epilogue<1, 1>(p, bt_epilogue_kind(p), m0 + wm * 32, n0 + wn * 32, Tw, lane, sqs, bias4);
     if (p.sqacc) {                                                       // one atomic per workgroup (see bt_tail)
         sqs = wave_sum(sqs);
-        float* red = reinterpret_cast<float*>(smem + S * STG + 4 * 4096);
+        float* red = reinterpret_cast<float*>(smem + 4 * 4096 + 64);
         if (lane == 0) red[wave] = sqs;
         __syncthreads();
         if (threadIdx.x == 0) atomicAdd(p.sqacc, (double)((red[0] + red[1]) + (red[2] + red[3])));
@@ -1015,7 +1020,7 @@ __device__ __forceinline__ void gemm_ws64_body(const GArgs& p, const int bid, co
 }
 
 template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(512, 2) void gemm_ws64_kernel(const GArgs p) {
+__global__ __launch_bounds__(64 * (4 + VITAE_WS64_PRODUCERS), 2) void gemm_ws64_kernel(const GArgs p) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[WS64_SMEM];      // the ONLY LDS object
     gemm_ws64_body<A_KC, B_KC, VITAE_WS64_STAGES, false>(p, blockIdx.x, blockIdx.z, smem);
 }
@@ -1024,7 +1029,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ws64_kernel(const GArgs p) {
 // dx = epi(dy W) (A = dy k-contiguous, B = W row-contiguous; its long reduction cut into p1.splits), the rest the weight gradient
 // dW (+)= dy^T x (both row-contiguous; RS: + colsum(dy)).
 template <bool RS>
-__global__ __launch_bounds__(512, 2) void gemm_ws64_pair_kernel(const GArgs p1, const GArgs p2, const int nb1) {
+__global__ __launch_bounds__(64 * (4 + VITAE_WS64_PRODUCERS), 2) void gemm_ws64_pair_kernel(const GArgs p1, const GArgs p2, const int nb1) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[WS64_SMEM];
     if ((int)blockIdx.x < nb1 * p1.splits) gemm_ws64_body<true, false, VITAE_WS64_STAGES, false>(p1, blockIdx.x % nb1, blockIdx.x / nb1, smem);
     else gemm_ws64_body<false, false, VITAE_WS64_STAGES, RS>(p2, blockIdx.x - nb1 * p1.splits, 0, smem);
@@ -1042,7 +1047,7 @@ int ws64_pair_launch(GArgs p1, GArgs p2, hipStream_t st) {
     p2.k_per_split = p2.K; p2.splits = 1;
     if (p1.splits > 1 && (!p1.ws || (long)p1.tiles_m * p1.tiles_n > VITAE_GLDS_TICKETS)) return VITAE_ERR_UNSUPPORTED_SHAPE;
     const int nb1 = 8 * cdiv((long)p1.tiles_m * p1.tiles_n, 8), nb2 = 8 * cdiv((long)p2.tiles_m * p2.tiles_n, 8);
-    const dim3 grid(nb1 * p1.splits + nb2), block(512);
+    const dim3 grid(nb1 * p1.splits + nb2), block(64 * (4 + VITAE_WS64_PRODUCERS));
     if (p2.a_rowsum) hipLaunchKernelGGL((gemm_ws64_pair_kernel<true>), grid, block, 0, st, p1, p2, nb1);
     else hipLaunchKernelGGL((gemm_ws64_pair_kernel<false>), grid, block, 0, st, p1, p2, nb1);
     return vitae_launch_status();
@@ -1097,7 +1102,7 @@ int bt_launch(GArgs p, int a_kc, int b_kc, int id, hipStream_t st) {
     // overhead as eight — 2150 clocks per k-tile for 1024 of MFMA — never the best tile on any shape of the step: not kept)
     if (id == 0) bt_launch_cfg<256, 256, 2, 4>(p, a_kc, b_kc, st);
     else if (id == 5) {
-        const dim3 grid(8 * cdiv((long)p.tiles_m * p.tiles_n, 8), 1, p.splits), block(512);
+        const dim3 grid(8 * cdiv((long)p.tiles_m * p.tiles_n, 8), 1, p.splits), block(64 * (4 + VITAE_WS64_PRODUCERS));
         if (a_kc && b_kc) hipLaunchKernelGGL((gemm_ws64_kernel<true, true>), grid, block, 0, st, p);
         else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_ws64_kernel<true, false>), grid, block, 0, st, p);
         else hipLaunchKernelGGL((gemm_ws64_kernel<false, false>), grid, block, 0, st, p);
