@@ -49,6 +49,9 @@ KNAMES = {'glds_pair': 'gemm_glds_pair_kernel<64,64,64,64> (csrc/gemm_glds.hip: 
           'bt256': 'gemm_bt_kernel<256,256,2,4,..> (csrc/gemm_bt.hip: 8 staggered waves)',
           'bt128': 'gemm_bt_kernel<128,128,2,2,..> (csrc/gemm_bt.hip: 4 waves, two workgroups per CU, in-launch split-K)',
           'bt_bwd': 'backward of one Linear as two launches (dgrad, wgrad), at least one on a csrc/gemm_bt.hip tile',
+          'ws64_pair': 'gemm_ws64_pair_kernel (csrc/gemm_bt.hip: dgrad + wgrad of one Linear as wave-specialised 64x64 workgroups of one launch)',
+          'ws64': 'gemm_ws64_kernel (csrc/gemm_bt.hip: wave-specialised 64x64 tile, 4 MFMA waves + 4 LDS-DMA waves)',
+          'ws128': 'gemm_ws_kernel (csrc/gemm_bt.hip: wave-specialised 128x128 tile)',
           'bt_group': 'gemm_bt_wgrad_group_kernel (csrc/gemm_bt.hip: the four weight gradients of a transformer block in one launch of 128x128 tiles)',
           'attn': 'attn_fwd_mfma_kernel / attn_bwd_fused_kernel (csrc/attention_mfma.hip)'}
 BT_NOTE = ('GEMM launches are served by csrc/gemm_glds.hip (64-row tiles) or csrc/gemm_bt.hip (256x256 / 128x128 tiles, in-launch split-K) '

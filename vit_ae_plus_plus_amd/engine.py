@@ -685,7 +685,7 @@ class HipMAEEngine:
         tag = self._split_cache.get(key)
         if tag is None:
             c = lib.vitae_gemm_glds_bt_choice(akc, bkc, M, N, K)
-            tag = default if (c < 0 or lib.vitae_gemm_glds_pick_split_k(M, N, K) != split) else ('bt256' if c == 0 else 'bt128')
+            tag = default if (c < 0 or lib.vitae_gemm_glds_pick_split_k(M, N, K) != split) else {0: 'bt256', 3: 'bt128', 4: 'ws128', 5: 'ws64'}.get(c, 'bt128')
             self._split_cache[key] = tag
         return tag
 
@@ -734,8 +734,12 @@ class HipMAEEngine:
                 s -= 1
             self._split_cache[key] = s
         tag = 'glds_pair' if N < 8192 else 'glds_pair_wide'
-        if self.gemm_timer is not None and (lib.vitae_gemm_glds_bt_choice(1, 0, M, K, N) >= 0 or lib.vitae_gemm_glds_bt_choice(0, 0, N, K, Mpad) >= 0):
-            tag = 'bt_bwd'      # the halves leave as two launches, at least one of them on a big tile
+        if self.gemm_timer is not None:
+            cd, cw = lib.vitae_gemm_glds_bt_choice(1, 0, M, K, N), lib.vitae_gemm_glds_bt_choice(0, 0, N, K, Mpad)
+            if cd == 5 and cw == 5:
+                tag = 'ws64_pair'   # both halves as wave-specialised 64 x 64 workgroups of one launch
+            elif cd in (0, 3, 4) or cw in (0, 3, 4):
+                tag = 'bt_bwd'      # the halves leave as two launches, at least one of them on a big tile
         if dw is None:
             tag = self._gemm_tag(1, 0, M, K, N, lib.vitae_gemm_glds_pick_split_k(M, K, N), 'glds')
         t = self._timed((4.0 if dw is not None else 2.0) * M * N * K, tag)
