@@ -1442,7 +1442,9 @@ class HipMAEEngine:
     # (padded token rows x model width) from which a block's four weight gradients leave as ONE grouped launch.  Measured
     # (volumes/s, grouped vs paired): batch 32 2766 vs 2480, batch 16 1906 vs 1802 (encoder 1792 x 768 grouped: 1906 vs 1843 without),
     # patch 8 328 vs 294; batch 8 1336 vs 1361-1372 when its decoder (1792 x 512) is grouped, 1314-1343 when everything is
-    wgrad_group_min = int(float(os.environ.get('VITAE_WGRAD_GROUP_MIN', '1.2e6')))
+    # Round 4 (side-stream grouped launch, wave-specialised input-gradient launches beside it): batch 8 5.40 -> 5.28 ms, batch 12 6.84 -> 6.51
+    # with both stacks grouped; batch 4 neutral (4.14 vs 4.17): threshold between them.
+    wgrad_group_min = int(float(os.environ.get('VITAE_WGRAD_GROUP_MIN', '0.6e6')))
     target_one_pass = os.environ.get('VITAE_TARGET_ONE_PASS', '1') != '0'
     # optional explicit ascending block boundaries, e.g. "0,2,7,12" (uneven chunks: a smaller last, exposed bucket)
     enc_cuts = [int(v) for v in os.environ['VITAE_ENC_CUTS'].split(',')] if os.environ.get('VITAE_ENC_CUTS') else None
