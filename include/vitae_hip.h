@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITAE_ABI_VERSION 39
+#define VITAE_ABI_VERSION 40
 
 /* matrix-core arithmetic of the dense contractions */
 #define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
@@ -104,6 +104,16 @@ int vitae_gemm_bf16x3(int a_kcontig, int b_kcontig, const float* A, long lda, co
                       int M, int N, int K, const float* bias, const float* residual, long ldr, int epi, float* aux,
                       long ldaux, int accumulate, int split_k, float* splitk_ws, void* stream);
 int vitae_gemm_bf16x3_pick_split_k(int M, int N, int K);
+/* The same product on wave-specialised workgroups (csrc/gemm_bt.hip: gemm_wsx3_kernel — four MFMA waves, four producer waves that
+ * split the fp32 operand tiles into bf16 hi + lo while they stage them): K any multiple of 4 (zero-filled tail), in-launch
+ * split-K with the workspace contract of vitae_gemm_glds (vitae_gemm_glds_ws_floats(M, N, split_k) floats, the first
+ * VITAE_GLDS_TICKETS words zero before the first use), exact-erf GELU epilogues, optional out_colsum_accum[n] += column sums of
+ * the result and, in the weight-gradient form (a_kcontig = b_kcontig = 0), a_rowsum_accum[m] += sum_k A(m, k) = colsum(dy), the
+ * bias gradient beside dW = dy^T x.  VITAE_ERR_UNSUPPORTED_SHAPE (misaligned operands, N % 4): keep vitae_gemm_bf16x3. */
+int vitae_gemm_wsx3(int a_kcontig, int b_kcontig, const float* A, long lda, const float* B, long ldb, float* C, long ldc,
+                    int M, int N, int K, const float* bias, const float* residual, long ldr, int epi, float* aux, long ldaux,
+                    int accumulate, int split_k, float* splitk_ws, float* out_colsum_accum, float* a_rowsum_accum, void* stream);
+int vitae_gemm_wsx3_pick_split_k(int M, int N, int K);
 /* Backward of one nn.Linear in a single launch (dgrad + wgrad + bias grad), bf16 MFMA:
  * dx[M,K] (+)= epi(dy[M,N] W[N,K]) (W from its bf16 shadow), dW[N,K] (+)= dy^T x, db[N] += colsum(dy). */
 int vitae_linear_bwd_pair_bf16(const float* dy, const void* w_bf16, const float* x, float* dx, float* dw,
@@ -122,9 +132,11 @@ int vitae_gemm_glds(int a_kcontig, int b_kcontig, const void* A16, long lda, con
                     float* out_colsum_accum, void* stream);
 int vitae_gemm_glds_pick_split_k(int M, int N, int K);
 /* Big-tile kernels (csrc/gemm_bt.hip; 0: 256x256 on 8 waves, 3: 128x128 on 4 waves, in-launch split-K) behind vitae_gemm_glds and
- * vitae_linear_bwd_pair_glds (whose halves then go out as two launches).  mode -1 (default): picked per problem by the cost
+ * vitae_linear_bwd_pair_glds (whose halves then go out as two launches), plus the wave-specialised tiles (4: 128x128, 5: 64x64 —
+ * four MFMA waves + four LDS-DMA producer waves per workgroup; with tile 5 both halves of vitae_linear_bwd_pair_glds stay ONE
+ * launch).  mode -1 (default): picked per problem by the cost
  * model together with the split (vitae_gemm_glds_pick_split_k returns the split of the plan: pass it on unchanged); -2: never;
- * 0 / 3: that tile for every eligible problem (tests, tools).  vitae_gemm_glds_bt_choice = the tile a problem would get (-1 = none).
+ * 0 / 3 / 4 / 5: that tile for every eligible problem (tests, tools).  vitae_gemm_glds_bt_choice = the tile a problem would get (-1 = none).
  * vitae_linear_bwd_pair_glds / vitae_wgrad_group_bt plan their own splits: they are told what the workspace holds per call
  * (splitk_ws_floats) and never make a plan that needs more. */
 int vitae_gemm_glds_set_bt_tile(int mode);

@@ -366,12 +366,12 @@ def _one_step_vs_reference_pins(fixture, cfg, B, seeds, precision, loss_tol, gno
     assert np.abs(ps - g['pred_slice']).max() <= pred_tol * np.abs(g['pred_slice']).max()      # max-norm, relative to the prediction's scale
     (loss[0] + contr).backward()
     named = dict(model.named_parameters())
-    worst = 0.0
+    worst, worst_name = 0.0, None
     for k, refn in zip(list(g['grad_names']), g['grad_norms']):
         gotn = float(named[str(k)].grad.double().norm())
-        if refn > 1e-6 * max(1.0, float(ref[0])):
-            worst = max(worst, abs(gotn - refn) / refn)
-    assert worst < gnorm_tol, worst
+        if refn > 1e-6 * max(1.0, float(ref[0])) and abs(gotn - refn) / refn > worst:
+            worst, worst_name = abs(gotn - refn) / refn, str(k)
+    assert worst < gnorm_tol, (worst, worst_name)
     print(f'{fixture} {precision}: worst loss error {errs.max():.2e}, worst gradient-norm error {worst:.2e}')
     return float(errs.max()), worst
 

@@ -250,6 +250,58 @@ def test_gemm_bf16x3_error_against_float64(lib, C, M, N, K):
         assert rel_err(c, ref) < 1e-5, (akc, bkc)
 
 
+@pytest.mark.parametrize('form', ['fwd', 'dgrad', 'wgrad'])
+@pytest.mark.parametrize('M,N,K', [(440, 768, 3072), (868, 2048, 512), (300, 264, 196), (130, 72, 68), (2304, 768, 440)])
+def test_gemm_wsx3(lib, C, form, M, N, K):
+    """vitae_gemm_wsx3 (fp32 operands split into bf16 hi + lo by the producer waves of a wave-specialised workgroup): against the
+    float64 product in every operand form — reduction lengths that are not multiples of 64 (zero-filled tail), ragged tiles,
+    in-launch split-K (bitwise reproducible, tickets handed back), epilogues (bias + residual + column sums, exact-erf GELU with
+    the saved pre-activation, GELU', accumulate) and the row sums of A beside a weight gradient."""
+    akc, bkc = {'fwd': (1, 1), 'dgrad': (1, 0), 'wgrad': (0, 0)}[form]
+    if form == 'wgrad':
+        M = M // 4 * 4            # row-contiguous operands move in 16-byte groups of rows
+    a, b = gen(M, K, seed=31), gen(N, K, seed=32, scale=K ** -0.5)
+    ref = a.double() @ b.double().t()
+    A = dev(a if akc else a.t().contiguous()); B = dev(b if bkc else b.t().contiguous())
+    lda, ldb = (K if akc else M), (K if bkc else N)
+    ws = torch.zeros(lib.vitae_gemm_glds_ws_floats(M, N, 8) + 64, device='cuda')
+
+    def run(c, bias=None, res=None, epi=0, aux=None, acc=0, split=1, cs=None, rs=None):
+        lib.vitae_gemm_wsx3(akc, bkc, A.data_ptr(), lda, B.data_ptr(), ldb, c.data_ptr(), N, M, N, K, None if bias is None else bias.data_ptr(),
+                            None if res is None else res.data_ptr(), N, epi, None if aux is None else aux.data_ptr(), N, acc, split, ws.data_ptr(),
+                            None if cs is None else cs.data_ptr(), None if rs is None else rs.data_ptr(), st())
+    nan = lambda: torch.full((M, N), float('nan'), device='cuda')
+    c = nan(); run(c)
+    assert rel_err(c, ref) < 1e-5                                    # observed 2-5e-6: the fp32 MFMA's own class
+    # split-K inside the launch: same values up to summation order, reproducible, tickets back to zero
+    outs = []
+    split = max(2, min(4, (K + 63) // 64 // 2))
+    for _ in range(2):
+        c2 = nan(); run(c2, split=split); outs.append(c2)
+    assert rel_err(outs[0], ref) < 1e-5 and torch.equal(outs[0], outs[1])
+    assert int(ws[:C['VITAE_GLDS_TICKETS']].abs().sum()) == 0
+    # bias + residual + column sums; accumulate on top
+    bias, res, old = gen(N, seed=33), gen(M, N, seed=34), gen(M, N, seed=35)
+    cs = torch.zeros(N, device='cuda')
+    c = nan(); run(c, bias=dev(bias), res=dev(res), cs=cs)
+    want = ref + bias.double() + res.double()
+    assert rel_err(c, want) < 1e-5 and rel_err(cs, c.sum(0)) < 1e-5
+    c = dev(old); run(c, acc=1)
+    assert rel_err(c, ref + old.double()) < 1e-5
+    # GELU (exact erf) with the saved pre-activation, then GELU' of it
+    pre = nan(); c = nan(); run(c, bias=dev(bias), epi=C['VITAE_EPI_GELU'], aux=pre)
+    assert rel_err(pre, ref + bias.double()) < 1e-5 and rel_err(c, F.gelu((ref + bias.double()).float())) < 1e-5
+    h = gen(M, N, seed=36)
+    hh = h.clone().double().requires_grad_(True)
+    F.gelu(hh).backward(ref)
+    c = nan(); run(c, epi=C['VITAE_EPI_DGELU'], aux=dev(h))
+    assert rel_err(c, hh.grad) < 1e-5
+    if form == 'wgrad':
+        rs = torch.zeros(M, device='cuda')
+        c = nan(); run(c, rs=rs)
+        assert rel_err(rs, a.double().sum(1)) < 1e-5
+
+
 @pytest.mark.parametrize('M,N,ld', [(440, 2304, 2304), (868, 16384, 16384), (6944, 512, 512), (33, 48, 64), (130, 70, 70), (5, 4, 4)])
 def test_colsum_accum(lib, M, N, ld):
     """Bias gradients of the fp32 schedules (out[n] += sum_m dy[m, n]): the 16-byte form and the scalar fallback (N % 4 != 0), a row

@@ -131,10 +131,10 @@ __device__ __forceinline__ void bt_wave_rows(const GArgs& p, int mb, int nb, con
                     }
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
+                for (int e = 0; e < 4; ++e) v[e] = p.exact ? gelu_erf(v[e]) : gelu_fast(v[e]);
             } else if (epi == VITAE_EPI_DGELU) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= gelu_fast_grad(axv[e]);
+                for (int e = 0; e < 4; ++e) v[e] *= p.exact ? gelu_erf_grad(axv[e]) : gelu_fast_grad(axv[e]);
             } else if (epi == VITAE_EPI_RELU_MASK) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = axv[e] > 0.f ? v[e] : 0.f;
@@ -1023,6 +1023,268 @@ template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(64 * (4 + VITAE_WS64_PRODUCERS), 2) void gemm_ws64_kernel(const GArgs p) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[WS64_SMEM];      // the ONLY LDS object
     gemm_ws64_body<A_KC, B_KC, VITAE_WS64_STAGES, false>(p, blockIdx.x, blockIdx.z, smem);
+}
+
+// ---- fp32x3 on the same structure (round 4) ------------------------------------------------------------------------------------
+// The fp32-grade fast mode multiplies fp32 operands as bf16 hi + lo pairs (hi.hi + hi.lo + lo.hi, fp32 accumulate).  Here the
+// PRODUCER waves — idle VALUs — do the split: they load the fp32 operand tiles with ordinary 16-byte loads (two k-tiles ahead,
+// in registers), form hi = bf16(x), lo = bf16(x - hi) and write both images into LDS in exactly the layout the LDS-DMA leaves
+// (same source permutation, same fragment reads).  Nothing upstream changes: every producer of an fp32 activation stays as it is.
+// A stage = [A hi | B hi | A lo | B lo] = 32 KB; the look-ahead lives in registers, so TWO stages suffice (64 KB: two workgroups
+// per CU).  The reduction length is any multiple of 4 (token counts are not padded on the fp32 side): the tail is zero-filled.
+template <int ROWS, bool KC>
+__device__ __forceinline__ void x3_load_piece(const float* __restrict__ P, long ld, int rows, int K, int r0, int k0, int pw, int lane, int j,
+                                              f32x4 (&v)[2]) {
+    constexpr int LINE_CH = KC ? BK / 8 : ROWS / 8, LPI = 64 / LINE_CH, NI = pieces<ROWS, KC, 4>();
+    const int inst = pw * NI + j;
+    const int line = inst * LPI + lane / LINE_CH;
+    const int slot = lane % LINE_CH;
+    const int chunk = slot ^ swz<KC, LINE_CH>(line);
+    if (KC) {
+        const int gr = min(r0 + line, rows - 1);
+        const int k = k0 + chunk * 8;
+        const float* src = P + (long)gr * ld + k;
+        v[0] = k < K ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
+        v[1] = k + 4 < K ? *reinterpret_cast<const f32x4*>(src + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+        // rows are a multiple of 4 only (fp32 activations are not padded): each 4-row group clamped on its own — groups past
+        // the operand read a valid group and are never stored
+        const int g0 = min(r0 + chunk * 8, rows - 4), g1 = min(r0 + chunk * 8 + 4, rows - 4);
+        const int k = k0 + line;
+        const float* src = P + (long)min(k, K - 1) * ld;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src + g0), b = *reinterpret_cast<const f32x4*>(src + g1);
+        v[0] = k < K ? a : f32x4{0.f, 0.f, 0.f, 0.f};
+        v[1] = k < K ? b : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+template <int ROWS, bool KC>
+__device__ __forceinline__ void x3_store_piece(const f32x4 (&v)[2], unsigned char* hi_img, unsigned char* lo_img, int pw, int lane, int j) {
+    constexpr int NI = pieces<ROWS, KC, 4>();
+    const int inst = pw * NI + j;
+    bf16x8 h, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = v[e >> 2][e & 3];
+        h[e] = (__bf16)x;
+        l[e] = (__bf16)(x - (float)h[e]);
+    }
+    *reinterpret_cast<bf16x8*>(hi_img + inst * 1024 + lane * 16) = h;
+    *reinterpret_cast<bf16x8*>(lo_img + inst * 1024 + lane * 16) = l;
+}
+
+template <bool A_KC, bool B_KC, bool RS>
+__device__ __forceinline__ void gemm_wsx3_body(const GArgs& p, const int bid, const int zid, unsigned char* smem) {
+    constexpr int BM = 64, BN = 64, NWC = 4;
+    constexpr int IMG = 64 * BK * 2, STG = 4 * IMG;                      // [A hi | B hi | A lo | B lo]
+    constexpr int PA = pieces<BM, A_KC, 4>(), PB = pieces<BN, B_KC, 4>();
+    const float* Af = reinterpret_cast<const float*>(p.A);
+    const float* Bf = reinterpret_cast<const float*>(p.B);
+    const int T = p.tiles_m * p.tiles_n;
+    const int xq = T >> 3, xr = T & 7, xcd = bid & 7;
+    const int lin = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    if ((bid >> 3) >= xq + (xcd < xr ? 1 : 0)) return;
+    const int tn = p.xcd_m ? lin % p.tiles_n : lin / p.tiles_m;
+    const int tm = p.xcd_m ? lin / p.tiles_n : lin % p.tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = zid * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+    const int nk = (kend - kbeg + BK - 1) / BK;                          // >= 1; the last tile may be partly past kend (zero-filled)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    auto barrier = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if (wave >= NWC) {
+        // ---------------- producers: fp32 loads two tiles ahead, split, LDS writes ----------------
+        const int pw = wave - NWC;
+        f32x4 ra[2][PA][2], rb[2][PB][2];
+        auto load = [&](int t, auto set_c) {
+            constexpr int SET = decltype(set_c)::value;
+            const int k0 = kbeg + t * BK;
+#pragma unroll
+            for (int j = 0; j < PA; ++j) x3_load_piece<BM, A_KC>(Af, p.lda, p.M, kend, m0, k0, pw, lane, j, ra[SET][j]);
+#pragma unroll
+            for (int j = 0; j < PB; ++j) x3_load_piece<BN, B_KC>(Bf, p.ldb, p.N, kend, n0, k0, pw, lane, j, rb[SET][j]);
+        };
+        auto store = [&](int stage, auto set_c) {
+            constexpr int SET = decltype(set_c)::value;
+            unsigned char* st = smem + stage * STG;
+#pragma unroll
+            for (int j = 0; j < PA; ++j) x3_store_piece<BM, A_KC>(ra[SET][j], st, st + 2 * IMG, pw, lane, j);
+#pragma unroll
+            for (int j = 0; j < PB; ++j) x3_store_piece<BN, B_KC>(rb[SET][j], st + IMG, st + 3 * IMG, pw, lane, j);
+        };
+        using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
+        load(0, S0{});
+        if (nk > 1) load(1, S1{});
+        // tile t goes into stage t & 1 after B_{t-1} (every read of tile t - 2 retired before it); B_t publishes it
+#pragma unroll 1
+        for (int t = 0; t < nk; t += 2) {
+            store(0, S0{});
+            if (t + 2 < nk) load(t + 2, S0{});
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            barrier();                                                   // B_t
+            if (t + 1 < nk) {
+                store(1, S1{});
+                if (t + 3 < nk) load(t + 3, S1{});
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                barrier();                                               // B_{t+1}
+            }
+        }
+        return;
+    }
+    // ---------------- consumers: hi / lo fragments, three MFMAs per pair ----------------
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    f32x16 acc[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[h][i] = 0.f;
+    const bool rowsum = RS && p.a_rowsum != nullptr && tn == 0 && wn == 0;
+    f32x16 accx;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accx[i] = 0.f;
+    bf16x8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
+    bf16x8 fah[BK / 16], fal[BK / 16], fbh[BK / 16], fbl[BK / 16];
+    constexpr int RK = 2 * ((A_KC ? 1 : 2) + (B_KC ? 1 : 2));
+    auto rd = [&](const unsigned char* ST, auto kk_c) {
+        constexpr int kk = decltype(kk_c)::value;
+        fah[kk] = frag_asm<BM, A_KC>(ST, wm * 32, kk, lane);
+        fbh[kk] = frag_asm<BN, B_KC>(ST + IMG, wn * 32, kk, lane);
+        fal[kk] = frag_asm<BM, A_KC>(ST + 2 * IMG, wm * 32, kk, lane);
+        fbl[kk] = frag_asm<BN, B_KC>(ST + 3 * IMG, wn * 32, kk, lane);
+    };
+    auto mm = [&](auto kk_c) {
+        constexpr int kk = decltype(kk_c)::value;
+        frag_tie(fah[kk]); frag_tie(fbh[kk]); frag_tie(fal[kk]); frag_tie(fbl[kk]);
+        // the two cross terms first: they are 2^-8 of the main term
+        acc[kk & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[kk], fbh[kk], acc[kk & 1], 0, 0, 0);
+        acc[kk & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[kk], fbl[kk], acc[kk & 1], 0, 0, 0);
+        acc[kk & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[kk], fbh[kk], acc[kk & 1], 0, 0, 0);
+        if constexpr (RS) {
+            if (rowsum) {
+                accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[kk], ones, accx, 0, 0, 0);
+                accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[kk], ones, accx, 0, 0, 0);
+            }
+        }
+    };
+    using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
+    const int nq = n0 + wn * 32 + 4 * (lane % 8);
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias && nq < p.N) bias4 = *reinterpret_cast<const f32x4*>(p.bias + nq);
+    barrier();                                                           // B_0
+    rd(smem, K0{}); rd(smem, K1{});
+#pragma unroll 1
+    for (int t = 0; t < nk; ++t) {
+        const unsigned char* ST = smem + (t & 1) * STG;
+        __builtin_amdgcn_sched_barrier(0);
+        rd(ST, K2{}); rd(ST, K3{});
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * RK > 15 ? 15 : 2 * RK) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mm(K0{}); mm(K1{});
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // every read of tile t has retired
+        if (t + 1 < nk) {
+            barrier();                                                   // B_{t+1}
+            const unsigned char* SN = smem + ((t + 1) & 1) * STG;
+            rd(SN, K0{}); rd(SN, K1{});
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        mm(K2{}); mm(K3{});
+    }
+    if (RS && rowsum && l31 == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 32 + crow(r, hi);
+            if (m < p.M) atomicAdd(p.a_rowsum + m, accx[r]);
+        }
+    }
+    f32x16 accs[1][1];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accs[0][0][i] = acc[0][i] + acc[1][i];
+    __syncthreads();                                                     // (consumers only: the producers have left) stages are free
+    float* Tw = reinterpret_cast<float*>(smem) + wave * 1024;
+    if (p.splits > 1) {
+        const int tile = p.tile0 + tm * p.tiles_n + tn;
+        float* part = p.ws + VITAE_GLDS_TICKETS + (long)tile * p.splits * (BM * BN);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(part, 0, p.splits * (BM * BN * 4), 0x00020000);
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const int toff = (int)threadIdx.x * 16;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = {accs[0][0][4 * g], accs[0][0][4 * g + 1], accs[0][0][4 * g + 2], accs[0][0][4 * g + 3]};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (zid * 4 + g) * (256 * 16) + toff, 0, 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(smem + 4 * 4096);
+        if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(reinterpret_cast<int*>(p.ws) + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*flag != p.splits - 1) return;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accs[0][0][i] = 0.f;
+#pragma unroll 1
+        for (int sp0 = 0; sp0 < p.splits; sp0 += 4) {
+            f32x4 v[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int sp = min(sp0 + u, p.splits - 1);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    v[u][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (sp * 4 + g) * (256 * 16) + toff, 0, 16));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (sp0 + u < p.splits) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) accs[0][0][4 * g + e] += v[u][g][e];
+                }
+        }
+        if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<int*>(p.ws) + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    bt_park_quadrant<1, 1, 1>(accs, lane, Tw);
+    __builtin_amdgcn_wave_barrier();
+    float sqs = 0.f;
+    bt_wave_epilogue<1, 1>(p, bt_epilogue_kind(p), m0 + wm * 32, n0 + wn * 32, Tw, lane, sqs, bias4);
+    if (p.sqacc) {
+        sqs = wave_sum(sqs);
+        float* red = reinterpret_cast<float*>(smem + 4 * 4096 + 64);
+        if (lane == 0) red[wave] = sqs;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(p.sqacc, (double)((red[0] + red[1]) + (red[2] + red[3])));
+    }
+}
+
+template <bool A_KC, bool B_KC, bool RS>
+__global__ __launch_bounds__(512, 2) void gemm_wsx3_kernel(const GArgs p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * 4 * 8192];      // the ONLY LDS object
+    gemm_wsx3_body<A_KC, B_KC, RS>(p, blockIdx.x, blockIdx.z, smem);
+}
+
+// p: a complete descriptor with FLOAT operands behind p.A / p.B (vec_epi set); p.splits k-ranges, multiples of 64 except the last
+int wsx3_launch(GArgs p, int a_kc, int b_kc, hipStream_t st) {
+    if (!p.vec_epi || (p.K & 3) || p.splits < 1 || p.C16) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    if (!a_kc && b_kc) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    p.k_per_split = cdiv(cdiv(p.K, p.splits), BK) * BK;
+    p.splits = cdiv(p.K, p.k_per_split);
+    p.tiles_m = cdiv(p.M, 64); p.tiles_n = cdiv(p.N, 64); p.tile0 = 0;
+    if (p.splits > 1 && (!p.ws || (long)p.tiles_m * p.tiles_n > VITAE_GLDS_TICKETS || p.epi == VITAE_EPI_GELU)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    if (p.a_rowsum && (a_kc || b_kc)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    const dim3 grid(8 * cdiv((long)p.tiles_m * p.tiles_n, 8), 1, p.splits), block(512);
+    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_wsx3_kernel<true, true, false>), grid, block, 0, st, p);
+    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_wsx3_kernel<true, false, false>), grid, block, 0, st, p);
+    else if (p.a_rowsum) hipLaunchKernelGGL((gemm_wsx3_kernel<false, false, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((gemm_wsx3_kernel<false, false, false>), grid, block, 0, st, p);
+    return vitae_launch_status();
 }
 
 // Backward of one Linear as ONE launch of such workgroups: the first nb1 * p1.splits blocks compute the input gradient

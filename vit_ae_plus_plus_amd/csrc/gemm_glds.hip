@@ -787,6 +787,49 @@ extern "C" int vitae_gemm_glds(int a_kcontig, int b_kcontig, const void* A16, lo
                             accumulate, split_k, splitk_ws, out_colsum_accum, stream);
 }
 
+// fp32x3 on the wave-specialised 64 x 64 workgroup (csrc/gemm_bt.hip: gemm_wsx3_kernel): the contract of vitae_gemm with fp32
+// operands multiplied as bf16 hi + lo pairs; the producer waves split them while they stage.  K any multiple of 4; in-launch
+// split-K with the workspace layout of vitae_gemm_glds (vitae_gemm_glds_ws_floats(M, N, split_k) floats, first VITAE_GLDS_TICKETS
+// words zero before the first use).  a_rowsum_accum (weight-gradient form, a_kcontig = b_kcontig = 0): [M] += sum_k A(m, k), the
+// bias gradient colsum(dy) beside dW = dy^T x.  VITAE_ERR_UNSUPPORTED_SHAPE: the caller keeps vitae_gemm_bf16x3.
+extern "C" int vitae_gemm_wsx3_pick_split_k(int M, int N, int K) {
+    const long tiles = (long)cdiv(M, 64) * cdiv(N, 64);
+    const int nk = cdiv(K, BK);
+    long s = 448 / (tiles > 0 ? tiles : 1);
+    if (s > 8) s = 8;
+    while (s > 1 && nk / s < 4) --s;
+    if (tiles > VITAE_GLDS_TICKETS) s = 1;
+    return s < 1 ? 1 : (int)s;
+}
+
+extern "C" int vitae_gemm_wsx3(int a_kcontig, int b_kcontig, const float* A, long lda, const float* B, long ldb, float* C, long ldc,
+                               int M, int N, int K, const float* bias, const float* residual, long ldr, int epi, float* aux,
+                               long ldaux, int accumulate, int split_k, float* splitk_ws, float* out_colsum_accum,
+                               float* a_rowsum_accum, void* stream) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return VITAE_ERR_INVALID_ARG;
+    if (epi != VITAE_EPI_NONE && epi != VITAE_EPI_RELU && !aux) return VITAE_ERR_INVALID_ARG;
+    if (epi & VITAE_EPI_AUX_BF16) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    const int a_vec = a_kcontig ? K : M, b_vec = b_kcontig ? K : N;
+    if ((a_vec & 3) || (lda & 3) || (b_vec & 3) || (ldb & 3) || (K & 3) || M < 8 || N < 8) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    if ((long)M * (ldc > N ? ldc : N) >= (1L << 31) || (long)M * ldaux >= (1L << 31) || (long)M * ldr >= (1L << 31)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    if (split_k < 1 || epi == VITAE_EPI_GELU) split_k = 1;
+    if (split_k > 1 && !splitk_ws) return VITAE_ERR_INVALID_ARG;
+    GArgs p;
+    p.A = reinterpret_cast<const __bf16*>(A); p.lda = lda;      // (floats behind these two: gemm_wsx3_body casts them back)
+    p.B = reinterpret_cast<const __bf16*>(B); p.ldb = ldb;
+    p.C = C; p.ldc = ldc; p.C16 = nullptr; p.ldc16 = 0;
+    p.M = M; p.N = N; p.K = K; p.k_per_split = K; p.splits = split_k;
+    p.bias = bias; p.residual = residual; p.ldr = ldr; p.aux = aux; p.ldaux = ldaux;
+    p.epi = epi; p.aux16 = 0; p.exact = 1; p.accumulate = accumulate; p.ws = splitk_ws; p.out_colsum = out_colsum_accum;
+    p.a_rowsum = a_rowsum_accum; p.dbg = nullptr;
+    p.tiles_m = 0; p.tiles_n = 0;
+    p.xcd_m = xcd_by_rows(M, N);
+    p.vec_epi = vec_epilogue_ok(p);
+    if (!a_kcontig && !b_kcontig) p.sqacc = g_wgrad_sqacc;
+    return wsx3_launch(p, a_kcontig, b_kcontig, (hipStream_t)stream);
+}
+
 // Backward of one Linear on bf16 operands in ONE launch: dx[M,K] = epi(dy16[M,N] @ W16[N,K]) (fp32 dx and/or
 // bf16 dx16; optional colsum of the result = bias gradient of the layer in front), dW[N,K] (+)= dy16^T @ x16.
 // Mpad = token count rounded up to 64: rows M..Mpad-1 of dy16 and x16 must be zero (wgrad reduces over them).

@@ -28,6 +28,7 @@ struct GArgs {
     double* sqacc = nullptr;     // optional: *sqacc += sum of squares of the stored result (the gradient norm's share of a wgrad)
     int tile0 = 0;               // index of this problem's first tile among the tickets / partial tiles of a grouped launch
     int aux16 = 0;               // aux holds bf16 (VITAE_EPI_AUX_BF16): the saved GELU pre-activation at half the bytes
+    int exact = 0;               // GELU / GELU' through erff (the fp32-grade modes) instead of the 1.5e-7 polynomial
     long long* dbg;      // optional (tools/gemm_phase_probe.py): 8 s_memtime stamps per workgroup
     int xcd_m;           // 0: an XCD owns column tiles tn = xcd (mod 8) and walks every row tile (its L2 holds 1/8 of B and all
                          // of A); 1: it owns row tiles tm = xcd (mod 8) instead — picked when A is the larger operand
@@ -109,5 +110,8 @@ int bt_launch(GArgs p, int a_kc, int b_kc, int id, hipStream_t st);
 int bt_wgrad_group_launch(GArgs* ps, int n, int splits, hipStream_t st);
 // gemm_bt.hip: input gradient + weight gradient of one Linear as ONE launch of wave-specialised 64 x 64 workgroups (tile id 5)
 int ws64_pair_launch(GArgs p1, GArgs p2, hipStream_t st);
+// gemm_bt.hip: fp32 operands split into bf16 hi + lo by the producer waves of a wave-specialised 64 x 64 workgroup (fp32x3 mode);
+// p.A / p.B point at FLOATS here, p.K any multiple of 4
+int wsx3_launch(GArgs p, int a_kc, int b_kc, hipStream_t st);
 
 }  // namespace vglds

@@ -174,7 +174,12 @@ class HipMAEEngine:
         self.losses = torch.zeros(8, **f32)   # [loss, raw_edge, recon, percep, contr, grad_norm, -, -]
         self.taps = gaussian_taps_host(2.0)
         self._taps_c = self.taps.ctypes.data
+        # fp32x3: the GEMMs of the fp32 schedule on the wave-specialised kernel whose producer waves split the fp32 operands
+        # (vitae_gemm_wsx3: in-launch split-K — its workspaces start with zeroed tickets — and bias gradients beside the weight gradients)
+        self.x3ws = self.prec == PREC['fp32x3'] and os.environ.get('VITAE_X3_WS', '1') != '0'
         self.ws = torch.empty(1 << 24, **f32)   # split-K scratch (64 MiB)
+        # (tickets + partial tiles of vitae_gemm_wsx3, one per stream; NOT shared with the older kernels, which park plain partials at offset 0)
+        self.ws_x3 = {k: torch.zeros(n, **f32) for k, n in (('main', 1 << 23), ('pside', 1 << 22), ('wside', 1 << 22))} if self.x3ws else None
         self.ws16 = torch.zeros(1 << 24, **f32)  # LDS-DMA GEMMs: tile tickets (kept zero by the kernels) + partial tiles
         self.attn_bias_colsum = os.environ.get('VITAE_ATTN_BIAS_COLSUM', '1') != '0'
         # predictor Linears on bf16 operands (LDS-DMA GEMMs) instead of the fp32-activation kernel (round 4: 6 launches of 70-110 us on
@@ -514,7 +519,36 @@ class HipMAEEngine:
         a.record()
         return b
 
+    def _x3_ok(self, N, K, *ts) -> bool:
+        """vitae_gemm_wsx3 serves this problem: 4-column groups everywhere, 16-byte aligned arrays."""
+        return self.x3ws and N % 4 == 0 and K % 4 == 0 and all(t is None or t.data_ptr() % 16 == 0 for t in ts)
+
+    def _x3_ws(self, side=False):
+        """The wsx3 workspace of the stream the next launch goes to (main chain, predictor branch, wgrad side stream)."""
+        if side:
+            return self.ws_x3['wside']
+        return self.ws_x3['pside' if self.stream == self.pside.cuda_stream else 'main']
+
+    def _x3_split(self, M, N, K, ws):
+        key = ('x3', M, N, K, ws.numel())
+        s = self._split_cache.get(key)
+        if s is None:
+            s = lib.vitae_gemm_wsx3_pick_split_k(M, N, K)
+            while s > 1 and lib.vitae_gemm_glds_ws_floats(M, N, s) > ws.numel():
+                s -= 1
+            self._split_cache[key] = s
+        return s
+
     def _lin_fwd(self, x, w, bias, y, M, N, K, epi=EPI_NONE, aux=None, res=None):
+        if self._x3_ok(N, K, x, w, y, bias, aux, res):
+            ws = self._x3_ws()
+            s = 1 if epi == EPI_GELU else self._x3_split(M, N, K, ws)
+            t = self._timed(2.0 * M * N * K)
+            lib.vitae_gemm_wsx3(1, 1, _ptr(x), K, _ptr(w), K, _ptr(y), N, M, N, K, _ptr(bias), _ptr(res), N, epi, _ptr(aux), N, 0, s,
+                                ws.data_ptr(), None, None, self.stream)
+            if t is not None:
+                t.record()
+            return
         s = 1 if epi == EPI_GELU else self._split(M, N, K)
         t = self._timed(2.0 * M * N * K)
         if self.prec == PREC['bf16']:
@@ -530,6 +564,17 @@ class HipMAEEngine:
     def _lin_bwd_x(self, dy, w, dx, M, N, K, epi=EPI_NONE, aux=None, accumulate=0, db=None):
         """dx = epi(dy @ W); with ``db`` the bias gradient colsum(dy) rides on the same launch (bf16 mode)
         or is a separate column-sum kernel (fp32 mode)."""
+        if self._x3_ok(K, N, dy, w, dx, aux):
+            ws = self._x3_ws()
+            s = self._x3_split(M, K, N, ws)
+            t = self._timed(2.0 * M * N * K)
+            lib.vitae_gemm_wsx3(1, 0, _ptr(dy), N, _ptr(w), K, _ptr(dx), K, M, K, N, None, None, 0, epi, _ptr(aux), K, accumulate, s,
+                                ws.data_ptr(), None, None, self.stream)
+            if db is not None:
+                lib.vitae_colsum_accum(_ptr(dy), N, _ptr(db), M, N, self.stream)
+            if t is not None:
+                t.record()
+            return
         s = self._split(M, K, N)
         t = self._timed(2.0 * M * N * K)
         if self.prec == PREC['bf16']:
@@ -563,7 +608,14 @@ class HipMAEEngine:
         else:
             stream = self.stream
         t = self._timed(2.0 * M * N * K)
-        if self.prec == PREC['bf16']:
+        if self._x3_ok(K, M, dy, x, dw, db) and N % 4 == 0:
+            # dW = dy^T x (reduction over the M token rows: any multiple of 4), the bias gradient colsum(dy) by the same launch
+            ws = self._x3_ws(side)       # (split-K tickets: never shared between streams)
+            s3 = self._x3_split(N, K, M, ws)
+            lib.vitae_gemm_wsx3(0, 0, _ptr(dy), N, _ptr(x), K, _ptr(dw), K, N, K, M, None, None, 0, EPI_NONE, None, 0, int(self._accum), s3,
+                                ws.data_ptr(), None, _ptr(db), stream)
+            db = None
+        elif self.prec == PREC['bf16']:
             lib.vitae_gemm_bf16(0, 0, _ptr(dy), N, _ptr(x), K, 0, _ptr(dw), K, N, K, M, None, None, 0, EPI_NONE, None, 0,
                                 int(self._accum), s, ws.data_ptr(), None, stream)
         else:
@@ -593,7 +645,7 @@ class HipMAEEngine:
             return
         # the bias gradient colsum(dy) goes with the weight gradient (both only read dy; on the wgrad side stream when that overlaps):
         # as a separate launch on the main chain it was 84 x 11 us = 0.9 ms of the fp32-mode step
-        w_db = db if (tag is not None and self.overlap_wgrad) else None
+        w_db = db if ((tag is not None and self.overlap_wgrad) or self.x3ws) else None
         self._lin_bwd_w(dy, x, dw, w_db, M, N, K, tag=tag)
         self._lin_bwd_x(dy, w, dx, M, N, K, epi=epi, aux=aux, accumulate=dx_accumulate, db=None if w_db is not None else db)
 
