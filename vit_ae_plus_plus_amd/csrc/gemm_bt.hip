@@ -1032,6 +1032,19 @@ __global__ __launch_bounds__(64 * (4 + VITAE_WS64_PRODUCERS), 2) void gemm_ws64_
 // (same source permutation, same fragment reads).  Nothing upstream changes: every producer of an fp32 activation stays as it is.
 // A stage = [A hi | B hi | A lo | B lo] = 32 KB; the look-ahead lives in registers, so TWO stages suffice (64 KB: two workgroups
 // per CU).  The reduction length is any multiple of 4 (token counts are not padded on the fp32 side): the tail is zero-filled.
+// The loads are UNCONDITIONAL (clamped addresses) and the zero-fill of the reduction's tail is applied when the values are
+// converted: a load behind a condition — or a select right behind it — makes hipcc wait for every load in flight (vmcnt(0)), which
+// exposed a full memory latency per k-tile (0.78 us per tile instead of 0.35).
+// ... and they are INLINE ASM: hipcc's own vmcnt bookkeeping across the loop's back edge waited for the younger register set too
+// (vmcnt(7) .. vmcnt(0) in front of the older set's conversion), so a tile's loads had half a k-tile of flight time.  The caller
+// counts: 8 loads per wave and tile, `wait_vmcnt<8>` in front of a conversion while the other set is in flight, then x3_tie.
+__device__ __forceinline__ f32x4 x3_ld(const float* ptr) {
+    f32x4 r;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(ptr) : "memory");
+    return r;
+}
+__device__ __forceinline__ void x3_tie(f32x4& v) { asm volatile("" : "+v"(v)); }
+
 template <int ROWS, bool KC>
 __device__ __forceinline__ void x3_load_piece(const float* __restrict__ P, long ld, int rows, int K, int r0, int k0, int pw, int lane, int j,
                                               f32x4 (&v)[2]) {
@@ -1043,33 +1056,47 @@ __device__ __forceinline__ void x3_load_piece(const float* __restrict__ P, long 
     if (KC) {
         const int gr = min(r0 + line, rows - 1);
         const int k = k0 + chunk * 8;
-        const float* src = P + (long)gr * ld + k;
-        v[0] = k < K ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
-        v[1] = k + 4 < K ? *reinterpret_cast<const f32x4*>(src + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* src = P + (long)gr * ld;
+        v[0] = x3_ld(src + min(k, K - 4));
+        v[1] = x3_ld(src + min(k + 4, K - 4));
     } else {
         // rows are a multiple of 4 only (fp32 activations are not padded): each 4-row group clamped on its own — groups past
         // the operand read a valid group and are never stored
         const int g0 = min(r0 + chunk * 8, rows - 4), g1 = min(r0 + chunk * 8 + 4, rows - 4);
-        const int k = k0 + line;
-        const float* src = P + (long)min(k, K - 1) * ld;
-        const f32x4 a = *reinterpret_cast<const f32x4*>(src + g0), b = *reinterpret_cast<const f32x4*>(src + g1);
-        v[0] = k < K ? a : f32x4{0.f, 0.f, 0.f, 0.f};
-        v[1] = k < K ? b : f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* src = P + (long)min(k0 + line, K - 1) * ld;
+        v[0] = x3_ld(src + g0);
+        v[1] = x3_ld(src + g1);
     }
 }
 template <int ROWS, bool KC>
-__device__ __forceinline__ void x3_store_piece(const f32x4 (&v)[2], unsigned char* hi_img, unsigned char* lo_img, int pw, int lane, int j) {
-    constexpr int NI = pieces<ROWS, KC, 4>();
+__device__ __forceinline__ void x3_store_piece(const f32x4 (&v)[2], int K, int k0, bool full, unsigned char* hi_img, unsigned char* lo_img, int pw, int lane, int j) {
+    constexpr int LINE_CH = KC ? BK / 8 : ROWS / 8, LPI = 64 / LINE_CH, NI = pieces<ROWS, KC, 4>();
     const int inst = pw * NI + j;
-    bf16x8 h, l;
+    const int line = inst * LPI + lane / LINE_CH;
+    const int chunk = (lane % LINE_CH) ^ swz<KC, LINE_CH>(line);
+    // which of the two 4-element groups lie inside the reduction (K % 4 == 0)
+    const int k = KC ? k0 + chunk * 8 : k0 + line;
+    const bool in0 = k < K, in1 = KC ? k + 4 < K : k < K;
+    // 24 VALU operations per 8 elements (the naive form compiled to 40, and the producers' conversion was the k-loop's bound):
+    // pairs converted once (v_cvt_pk_bf16_f32), the two hi values of a pair taken back out of the packed word by a shift / a mask
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 h, l;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const float x = v[e >> 2][e & 3];
-        h[e] = (__bf16)x;
-        l[e] = (__bf16)(x - (float)h[e]);
+    for (int q = 0; q < 4; ++q) {
+        float x0 = v[q >> 1][2 * (q & 1)], x1 = v[q >> 1][2 * (q & 1) + 1];
+        if (!full) {
+            const bool in = (q >> 1) ? in1 : in0;
+            x0 = in ? x0 : 0.f; x1 = in ? x1 : 0.f;
+        }
+        const unsigned ph = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0, x1}, bf16x2));
+        const float h0 = __builtin_bit_cast(float, ph << 16), h1 = __builtin_bit_cast(float, ph & 0xffff0000u);
+        h[q] = ph;
+        l[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0 - h0, x1 - h1}, bf16x2));
     }
-    *reinterpret_cast<bf16x8*>(hi_img + inst * 1024 + lane * 16) = h;
-    *reinterpret_cast<bf16x8*>(lo_img + inst * 1024 + lane * 16) = l;
+    *reinterpret_cast<u32x4*>(hi_img + inst * 1024 + lane * 16) = h;
+    *reinterpret_cast<u32x4*>(lo_img + inst * 1024 + lane * 16) = l;
 }
 
 template <bool A_KC, bool B_KC, bool RS>
@@ -1108,13 +1135,20 @@ __device__ __forceinline__ void gemm_wsx3_body(const GArgs& p, const int bid, co
 #pragma unroll
             for (int j = 0; j < PB; ++j) x3_load_piece<BN, B_KC>(Bf, p.ldb, p.N, kend, n0, k0, pw, lane, j, rb[SET][j]);
         };
-        auto store = [&](int stage, auto set_c) {
+        auto store = [&](int t, int stage, auto set_c, bool other_in_flight) {
             constexpr int SET = decltype(set_c)::value;
             unsigned char* st = smem + stage * STG;
+            const int k0 = kbeg + t * BK;
+            if (other_in_flight) wait_vmcnt<PA * 2 + PB * 2>(); else wait_vmcnt<0>();
 #pragma unroll
-            for (int j = 0; j < PA; ++j) x3_store_piece<BM, A_KC>(ra[SET][j], st, st + 2 * IMG, pw, lane, j);
+            for (int j = 0; j < PA; ++j) { x3_tie(ra[SET][j][0]); x3_tie(ra[SET][j][1]); }
 #pragma unroll
-            for (int j = 0; j < PB; ++j) x3_store_piece<BN, B_KC>(rb[SET][j], st + IMG, st + 3 * IMG, pw, lane, j);
+            for (int j = 0; j < PB; ++j) { x3_tie(rb[SET][j][0]); x3_tie(rb[SET][j][1]); }
+            const bool full = k0 + BK <= kend;          // wave-uniform: only the last tile of a ragged reduction masks
+#pragma unroll
+            for (int j = 0; j < PA; ++j) x3_store_piece<BM, A_KC>(ra[SET][j], kend, k0, full, st, st + 2 * IMG, pw, lane, j);
+#pragma unroll
+            for (int j = 0; j < PB; ++j) x3_store_piece<BN, B_KC>(rb[SET][j], kend, k0, full, st + IMG, st + 3 * IMG, pw, lane, j);
         };
         using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
         load(0, S0{});
@@ -1122,12 +1156,12 @@ __device__ __forceinline__ void gemm_wsx3_body(const GArgs& p, const int bid, co
         // tile t goes into stage t & 1 after B_{t-1} (every read of tile t - 2 retired before it); B_t publishes it
 #pragma unroll 1
         for (int t = 0; t < nk; t += 2) {
-            store(0, S0{});
+            store(t, 0, S0{}, t + 1 < nk);
             if (t + 2 < nk) load(t + 2, S0{});
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             barrier();                                                   // B_t
             if (t + 1 < nk) {
-                store(1, S1{});
+                store(t + 1, 1, S1{}, t + 2 < nk);
                 if (t + 3 < nk) load(t + 3, S1{});
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 barrier();                                               // B_{t+1}
@@ -1265,7 +1299,7 @@ __device__ __forceinline__ void gemm_wsx3_body(const GArgs& p, const int bid, co
 }
 
 template <bool A_KC, bool B_KC, bool RS>
-__global__ __launch_bounds__(512, 2) void gemm_wsx3_kernel(const GArgs p) {
+__global__ __launch_bounds__(512, 4) void gemm_wsx3_kernel(const GArgs p) {      // (4 waves per SIMD: <= 128 VGPRs, two workgroups per CU — the row-sum variant took 132)
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * 4 * 8192];      // the ONLY LDS object
     gemm_wsx3_body<A_KC, B_KC, RS>(p, blockIdx.x, blockIdx.z, smem);
 }
