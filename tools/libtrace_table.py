@@ -8,7 +8,7 @@ runs, cur = [], None
 for r in rows:
     n = r['Kernel_Name']
     d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
-    fam = 'ours' if ('gemm_glds' in n or 'gemm_bt' in n) else 'lib' if ('Cijk' in n or 'gemm' in n.lower() or 'Tensile' in n) else None
+    fam = 'ours' if ('gemm_glds' in n or 'gemm_bt' in n or 'gemm_ws' in n) else 'lib' if ('Cijk' in n or 'gemm' in n.lower() or 'Tensile' in n) else None
     if fam is None:
         continue
     if cur and cur[0] == n:
@@ -29,6 +29,10 @@ def short(n):
     m = re.search(r'MT(\d+x\d+x\d+)', n)
     if m:
         return m.group(1)
+    if 'gemm_ws64' in n:
+        return 'ws 64x64'
+    if 'gemm_ws_kernel' in n:
+        return 'ws 128x128'
     m = re.search(r'gemm_bt_kernel<(\d+), (\d+)', n)
     if m:
         return f'bt {m.group(1)}x{m.group(2)}'

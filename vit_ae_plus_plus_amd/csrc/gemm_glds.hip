@@ -657,7 +657,7 @@ inline BtPlan bt_plan(int M, int N, int K, int a_kc, int b_kc, bool allow_split,
         if (id == 4 && g_bt_mode < 0 && !ws_on) continue;
         // (the wave-specialised tile needs many token rows: at batch 8 — 880 / 1736 rows — it un-pairs launches the 64-row family
         // serves as well and the step loses 7 %)
-        if (id == 4 && g_bt_mode < 0 && (a_kc ? M : K) < ((a_kc && b_kc) ? ws_min_rows_fwd : ws_min_rows) && K < ws_long_k) continue;
+        if (id == 4 && g_bt_mode < 0 && (a_kc ? M : K) < ((a_kc && b_kc) ? ws_min_rows_fwd : ws_min_rows) && !(K >= ws_long_k && (a_kc ? M : K) < 600)) continue;
         int bm, bn;
         bt_tile_dims(id, bm, bn);
         // (a FORCED tile — tests, tools — is held to what the kernel itself needs: two k-tiles per split, any M / N)
