@@ -54,8 +54,8 @@ KNAMES = {'glds_pair': 'gemm_glds_pair_kernel<64,64,64,64> (csrc/gemm_glds.hip: 
           'ws128': 'gemm_ws_kernel (csrc/gemm_bt.hip: wave-specialised 128x128 tile)',
           'bt_group': 'gemm_bt_wgrad_group_kernel (csrc/gemm_bt.hip: the four weight gradients of a transformer block in one launch of 128x128 tiles)',
           'attn': 'attn_fwd_mfma_kernel / attn_bwd_fused_kernel (csrc/attention_mfma.hip)'}
-BT_NOTE = ('GEMM launches are served by csrc/gemm_glds.hip (64-row tiles) or csrc/gemm_bt.hip (256x256 / 128x128 tiles, in-launch split-K) '
-           'as the cost model of vitae_gemm_glds picks per problem')
+BT_NOTE = ('GEMM launches are served by csrc/gemm_bt.hip (wave-specialised 64x64 / 128x128 workgroups: 4 MFMA waves + 4 LDS-DMA producer waves; '
+           '256x256 / 128x128 ping-pong tiles; in-launch split-K) or csrc/gemm_glds.hip (64-row tiles) as the cost model of vitae_gemm_glds picks per problem')
 
 
 def parse(argv=None):
