@@ -1032,6 +1032,9 @@ __global__ __launch_bounds__(64 * (4 + VITAE_WS64_PRODUCERS), 2) void gemm_ws64_
 // (same source permutation, same fragment reads).  Nothing upstream changes: every producer of an fp32 activation stays as it is.
 // A stage = [A hi | B hi | A lo | B lo] = 32 KB; the look-ahead lives in registers, so TWO stages suffice (64 KB: two workgroups
 // per CU).  The reduction length is any multiple of 4 (token counts are not padded on the fp32 side): the tail is zero-filled.
+#ifndef VITAE_X3_PRODUCERS
+#define VITAE_X3_PRODUCERS 4      // producer waves of the fp32x3 workgroup (8: half the conversion work per wave, one workgroup per CU)
+#endif
 // The loads are UNCONDITIONAL (clamped addresses) and the zero-fill of the reduction's tail is applied when the values are
 // converted: a load behind a condition — or a select right behind it — makes hipcc wait for every load in flight (vmcnt(0)), which
 // exposed a full memory latency per k-tile (0.78 us per tile instead of 0.35).
@@ -1048,7 +1051,7 @@ __device__ __forceinline__ void x3_tie(f32x4& v) { asm volatile("" : "+v"(v)); }
 template <int ROWS, bool KC>
 __device__ __forceinline__ void x3_load_piece(const float* __restrict__ P, long ld, int rows, int K, int r0, int k0, int pw, int lane, int j,
                                               f32x4 (&v)[2]) {
-    constexpr int LINE_CH = KC ? BK / 8 : ROWS / 8, LPI = 64 / LINE_CH, NI = pieces<ROWS, KC, 4>();
+    constexpr int LINE_CH = KC ? BK / 8 : ROWS / 8, LPI = 64 / LINE_CH, NI = pieces<ROWS, KC, VITAE_X3_PRODUCERS>();
     const int inst = pw * NI + j;
     const int line = inst * LPI + lane / LINE_CH;
     const int slot = lane % LINE_CH;
@@ -1070,7 +1073,7 @@ __device__ __forceinline__ void x3_load_piece(const float* __restrict__ P, long 
 }
 template <int ROWS, bool KC>
 __device__ __forceinline__ void x3_store_piece(const f32x4 (&v)[2], int K, int k0, bool full, unsigned char* hi_img, unsigned char* lo_img, int pw, int lane, int j) {
-    constexpr int LINE_CH = KC ? BK / 8 : ROWS / 8, LPI = 64 / LINE_CH, NI = pieces<ROWS, KC, 4>();
+    constexpr int LINE_CH = KC ? BK / 8 : ROWS / 8, LPI = 64 / LINE_CH, NI = pieces<ROWS, KC, VITAE_X3_PRODUCERS>();
     const int inst = pw * NI + j;
     const int line = inst * LPI + lane / LINE_CH;
     const int chunk = (lane % LINE_CH) ^ swz<KC, LINE_CH>(line);
@@ -1103,7 +1106,7 @@ template <bool A_KC, bool B_KC, bool RS>
 __device__ __forceinline__ void gemm_wsx3_body(const GArgs& p, const int bid, const int zid, unsigned char* smem) {
     constexpr int BM = 64, BN = 64, NWC = 4;
     constexpr int IMG = 64 * BK * 2, STG = 4 * IMG;                      // [A hi | B hi | A lo | B lo]
-    constexpr int PA = pieces<BM, A_KC, 4>(), PB = pieces<BN, B_KC, 4>();
+    constexpr int PA = pieces<BM, A_KC, VITAE_X3_PRODUCERS>(), PB = pieces<BN, B_KC, VITAE_X3_PRODUCERS>();
     const float* Af = reinterpret_cast<const float*>(p.A);
     const float* Bf = reinterpret_cast<const float*>(p.B);
     const int T = p.tiles_m * p.tiles_n;
@@ -1299,10 +1302,13 @@ __device__ __forceinline__ void gemm_wsx3_body(const GArgs& p, const int bid, co
 }
 
 template <bool A_KC, bool B_KC, bool RS>
-__global__ __launch_bounds__(512, 4) void gemm_wsx3_kernel(const GArgs p) {      // (4 waves per SIMD: <= 128 VGPRs, two workgroups per CU — the row-sum variant took 132)
+__global__ __launch_bounds__(64 * (4 + VITAE_X3_PRODUCERS), VITAE_X3_PRODUCERS == 4 ? 4 : 3) void gemm_wsx3_kernel(const GArgs p) {      // (4 producers: 4 waves per SIMD = <= 128 VGPRs, two workgroups per CU — the row-sum variant took 132)
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * 4 * 8192];      // the ONLY LDS object
     gemm_wsx3_body<A_KC, B_KC, RS>(p, blockIdx.x, blockIdx.z, smem);
 }
+
+// resident workgroup slots of the chip for this kernel (the split-K rule fills about that many)
+int wsx3_slots() { return VITAE_X3_PRODUCERS == 4 ? 512 : 256; }
 
 // p: a complete descriptor with FLOAT operands behind p.A / p.B (vec_epi set); p.splits k-ranges, multiples of 64 except the last
 int wsx3_launch(GArgs p, int a_kc, int b_kc, hipStream_t st) {
@@ -1313,7 +1319,7 @@ int wsx3_launch(GArgs p, int a_kc, int b_kc, hipStream_t st) {
     p.tiles_m = cdiv(p.M, 64); p.tiles_n = cdiv(p.N, 64); p.tile0 = 0;
     if (p.splits > 1 && (!p.ws || (long)p.tiles_m * p.tiles_n > VITAE_GLDS_TICKETS || p.epi == VITAE_EPI_GELU)) return VITAE_ERR_UNSUPPORTED_SHAPE;
     if (p.a_rowsum && (a_kc || b_kc)) return VITAE_ERR_UNSUPPORTED_SHAPE;
-    const dim3 grid(8 * cdiv((long)p.tiles_m * p.tiles_n, 8), 1, p.splits), block(512);
+    const dim3 grid(8 * cdiv((long)p.tiles_m * p.tiles_n, 8), 1, p.splits), block(64 * (4 + VITAE_X3_PRODUCERS));
     if (a_kc && b_kc) hipLaunchKernelGGL((gemm_wsx3_kernel<true, true, false>), grid, block, 0, st, p);
     else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_wsx3_kernel<true, false, false>), grid, block, 0, st, p);
     else if (p.a_rowsum) hipLaunchKernelGGL((gemm_wsx3_kernel<false, false, true>), grid, block, 0, st, p);

@@ -795,7 +795,8 @@ extern "C" int vitae_gemm_glds(int a_kcontig, int b_kcontig, const void* A16, lo
 extern "C" int vitae_gemm_wsx3_pick_split_k(int M, int N, int K) {
     const long tiles = (long)cdiv(M, 64) * cdiv(N, 64);
     const int nk = cdiv(K, BK);
-    long s = 448 / (tiles > 0 ? tiles : 1);
+    static const int want = getenv("VITAE_X3WS_SPLIT_WGS") ? atoi(getenv("VITAE_X3WS_SPLIT_WGS")) : wsx3_slots() * 7 / 8;
+    long s = want / (tiles > 0 ? tiles : 1);
     if (s > 8) s = 8;
     while (s > 1 && nk / s < 4) --s;
     if (tiles > VITAE_GLDS_TICKETS) s = 1;

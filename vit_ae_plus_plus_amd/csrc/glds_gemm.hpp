@@ -113,5 +113,6 @@ int ws64_pair_launch(GArgs p1, GArgs p2, hipStream_t st);
 // gemm_bt.hip: fp32 operands split into bf16 hi + lo by the producer waves of a wave-specialised 64 x 64 workgroup (fp32x3 mode);
 // p.A / p.B point at FLOATS here, p.K any multiple of 4
 int wsx3_launch(GArgs p, int a_kc, int b_kc, hipStream_t st);
+int wsx3_slots();
 
 }  // namespace vglds
