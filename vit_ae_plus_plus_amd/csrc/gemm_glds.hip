@@ -632,7 +632,9 @@ inline double est_64row(int M, int N, int K, bool allow_split, bool wgrad_form) 
     // both operands row-contiguous (the weight-gradient form): every fragment comes through the transposing LDS read, two
     // instructions per 16-byte fragment — 650 instead of 400 clocks per k-tile and resident workgroup (tools/wgrad_split_sweep.py:
     // enc fc1 wgrad at batch 32, 576 tiles x 55 k-tiles, 39.8 us)
-    const double c = t.id == 1 ? 2800 + 930 * nk : 5100 + (wgrad_form ? 650 : 400) * nk;
+    // (64 x 128: refitted in round 4 — 1736 x 2048 x 512 takes 14.3 us = 24 k of these clocks, the first fit said 17.9 k and kept the
+    // wave-specialised tiles, 11.9-13.2 us there, out)
+    const double c = t.id == 1 ? 3800 + 1250 * nk : 5100 + (wgrad_form ? 650 : 400) * nk;
     const double lat = 8000 + (t.id == 1 ? 1000 : 760) * nk + (s > 1 ? 7000 : 0);
     const double thr = wgs * c / 256;
     return thr > lat ? thr : lat;
@@ -657,7 +659,7 @@ inline BtPlan bt_plan(int M, int N, int K, int a_kc, int b_kc, bool allow_split,
         if (id == 4 && g_bt_mode < 0 && !ws_on) continue;
         // (the wave-specialised tile needs many token rows: at batch 8 — 880 / 1736 rows — it un-pairs launches the 64-row family
         // serves as well and the step loses 7 %)
-        if (id == 4 && g_bt_mode < 0 && (a_kc ? M : K) < ((a_kc && b_kc) ? ws_min_rows_fwd : ws_min_rows) && !(K >= ws_long_k && (a_kc ? M : K) < 600)) continue;
+        if (id == 4 && g_bt_mode < 0 && (a_kc ? M : K) < ((a_kc && b_kc) ? ws_min_rows_fwd : ws_min_rows) && !(K >= ws_long_k && (a_kc ? M : K) < 1024)) continue;
         int bm, bn;
         bt_tile_dims(id, bm, bn);
         // (a FORCED tile — tests, tools — is held to what the kernel itself needs: two k-tiles per split, any M / N)
