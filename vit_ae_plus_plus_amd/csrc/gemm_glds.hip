@@ -742,6 +742,8 @@ static int gemm_glds_launch(int a_kcontig, int b_kcontig, const void* A16, long 
     const int a_vec = a_kcontig ? K : M, b_vec = b_kcontig ? K : N;
     if ((a_vec & 7) || (lda & 7) || (b_vec & 7) || (ldb & 7)) return VITAE_ERR_UNSUPPORTED_SHAPE;
     if (((uintptr_t)A16 & 15) || ((uintptr_t)B16 & 15)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    // (LDS-DMA pieces carry 32-bit byte offsets from the operand base)
+    if ((long)(a_kcontig ? M : K) * lda >= (1L << 30) || (long)(b_kcontig ? N : K) * ldb >= (1L << 30)) return VITAE_ERR_UNSUPPORTED_SHAPE;
     if (split_k < 1) split_k = 1;
     if (epi == VITAE_EPI_GELU) split_k = 1;
     GArgs p;
@@ -861,6 +863,7 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
     if (dx_accumulate && !dx) return VITAE_ERR_INVALID_ARG;
     if ((N % BK) || (Mpad % BK) || (K & 7) || Mpad < M) return VITAE_ERR_UNSUPPORTED_SHAPE;
     if ((long)(M > N ? M : N) * K >= (1L << 31)) return VITAE_ERR_UNSUPPORTED_SHAPE;   // 32-bit epilogue offsets
+    if ((long)Mpad * N >= (1L << 30) || (long)Mpad * K >= (1L << 30) || (long)N * K >= (1L << 30)) return VITAE_ERR_UNSUPPORTED_SHAPE;   // 32-bit DMA byte offsets
     // what the split-K plans of either half may use: exactly what the caller says the workspace holds
     const long cap = splitk_ws && splitk_ws_floats > 0 ? splitk_ws_floats : 0;
     if (split_k > 1 && vitae_gemm_glds_ws_floats(M, K, split_k) > cap) return VITAE_ERR_INVALID_ARG;
@@ -980,7 +983,7 @@ extern "C" int vitae_wgrad_group_bt(int n, const void* const* dy16, const void* 
     long tiles = 0;
     for (int i = 0; i < n; ++i) {
         if (!dy16[i] || !x16[i] || !dw[i] || N[i] <= 0 || K[i] <= 0) return VITAE_ERR_INVALID_ARG;
-        if ((N[i] & 7) || (K[i] & 7) || (long)N[i] * K[i] >= (1L << 31)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+        if ((N[i] & 7) || (K[i] & 7) || (long)N[i] * K[i] >= (1L << 31) || (long)Mpad * N[i] >= (1L << 30) || (long)Mpad * K[i] >= (1L << 30)) return VITAE_ERR_UNSUPPORTED_SHAPE;
         if (((uintptr_t)dy16[i] & 15) || ((uintptr_t)x16[i] & 15)) return VITAE_ERR_UNSUPPORTED_SHAPE;
         GArgs& p = ps[i];
         p.A = reinterpret_cast<const __bf16*>(dy16[i]); p.lda = N[i];
