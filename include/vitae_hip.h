@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITAE_ABI_VERSION 40
+#define VITAE_ABI_VERSION 41
 
 /* matrix-core arithmetic of the dense contractions */
 #define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
@@ -39,6 +39,10 @@ extern "C" {
 #define VITAE_EPI_RELU_MASK 3 /* out <- aux > 0 ? acc : 0 */
 #define VITAE_EPI_RELU 4      /* out <- max(acc + bias, 0) (vitae_gemm_glds only; no aux) */
 #define VITAE_EPI_AUX_BF16 16 /* OR-ed into epi (vitae_gemm_glds*, vitae_linear_bwd_pair_glds*): aux points at bf16, not fp32 */
+#define VITAE_EPI_AUX_DERIV 32 /* OR-ed into epi (every GEMM entry point): aux holds the DERIVATIVE GELU'(pre-activation) instead of the
+                                * pre-activation — VITAE_EPI_GELU saves GELU'(acc + bias) (one more FMA on the gate it computes anyway),
+                                * VITAE_EPI_DGELU multiplies by aux.  Same value as evaluating GELU' in the backward (fp32 aux: bit for
+                                * bit), without 20 VALU operations per element in the fc2 input-gradient epilogue (ABI 41) */
 
 /* device-resident hyper-parameter block `hp` (float[VITAE_HP_COUNT]) */
 #define VITAE_HP_LR 0

@@ -221,9 +221,49 @@ def test_three_steps_track_oracle_training():
         # compare the 3-step UPDATE per tensor.  Adam's m/(sqrt(v)+eps) turns round-off into +-lr steps
         # wherever the true gradient is ~0 (e.g. the key bias, whose gradient is analytically zero), so
         # elementwise equality is ill-posed there; the update's relative L2 error is the stable measure.
+        if k.endswith('qkv.bias'):
+            # q | k | v thirds on their own: only the KEY bias has an analytically zero gradient (softmax is invariant to a shift of
+            # every logit of a row), so only its third may wander (bounded by Adam's step size below); a bug in the query / value bias path must still fail at 0.05
+            d = v.numel() // 3
+            for name, sl in (('q', slice(0, d)), ('v', slice(2 * d, 3 * d))):
+                upd_ref = (ref_sd[k][sl] - sd[k][sl]).double()
+                err = float((v.cpu().double()[sl] - ref_sd[k].double()[sl]).norm() / (upd_ref.norm() + 1e-12))
+                assert err < 0.05, (k, name, err)
+            # the key third: both trajectories are +-lr round-off walks (observed relative distance 2.2), so the only sound bound is
+            # Adam's own: no element moves further than lr per step
+            moved = float((v.cpu().double()[d:2 * d] - sd[k].double()[d:2 * d]).abs().max())
+            assert moved <= 3 * 1e-3 * 1.01, (k, 'k', moved)
+            continue
         upd_ref = (ref_sd[k] - sd[k]).double()
         err = float((v.cpu().double() - ref_sd[k].double()).norm() / (upd_ref.norm() + 1e-12))
-        assert err < (0.6 if k.endswith('qkv.bias') else 0.05), (k, err)
+        assert err < 0.05, (k, err)
+
+
+@pytest.mark.parametrize('precision', ['bf16', 'fp32'])
+def test_grad_norm_fused_step_counts_every_gradient_once(precision):
+    """with the optimiser inside the backward (bf16: the matrix share of the norm comes from the weight-gradient
+    epilogues) the reported global gradient norm (utils/misc.py:280-292) must equal the norm of the gradient arena — with a
+    large contrastive weight the predictor's matrices carry a large share, so counting them twice shows at the 10 % level."""
+    from vit_ae_plus_plus_amd.optim import FusedAdamW
+    cfg = R.vit_base_cfg(contrastive=True, **VITB)
+    model = build(cfg, R.init_state_dict(cfg, seed=0), precision=precision).train()
+    opt = FusedAdamW(model, lr=0.0, weight_decay=0.0, betas=(0.9, 0.95))
+    model._ensure_engine(torch.device('cuda', 0))
+    eng = opt.engine
+    eng.set_loss_weights(0.01, 100.0, 1)      # (the contrastive term's gradient is small at initialisation: weight it up)
+    B = 2
+    v1, v2 = R.synthetic_views((B, cfg.in_chans, *cfg.volume_size), seed=11)
+    model.set_masking_noise(*R.masking_noise(B, cfg.num_patches, seed=12))
+    runner = model._step_runner(B, 0.75, True, False, True)
+    runner.load(v1.cuda(), v2.cuda())
+    eng.optimizer_hparams(lr=0.0)
+    runner.run()
+    torch.cuda.synchronize()
+    got = float(eng.losses[5])
+    want = float(eng.grads.double().norm())
+    pred = float(torch.cat([eng.g['predictor.0.weight'].flatten(), eng.g['predictor.3.weight'].flatten()]).double().norm())
+    assert pred > 0.05 * want, (pred, want)          # the case is sensitive to the predictor's share
+    assert abs(got - want) <= 2e-4 * want, (got, want, pred)
 
 
 def _ref_adamw(params, lr, wd):

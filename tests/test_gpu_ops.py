@@ -93,6 +93,22 @@ def test_linear_fwd_bwd(lib, C, prec, tol, M, N, K):
     hh = h.clone().requires_grad_(True)
     F.gelu(hh).backward(dy @ w)
     assert rel_err(dx, hh.grad) < tol
+    # VITAE_EPI_AUX_DERIV: the forward saves GELU'(pre-activation), the backward multiplies by it — bit for bit what evaluating
+    # GELU' in the backward gives (same expression on the same fp32 value)
+    DV = C['VITAE_EPI_AUX_DERIV']
+    y2, auxg = torch.empty(M, N, device='cuda'), torch.empty(M, N, device='cuda')
+    lib.vitae_linear_fwd(prec, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y2.data_ptr(), M, N, K, C['VITAE_EPI_GELU'] | DV,
+                         auxg.data_ptr(), None, 1, None, st())
+    pp = pre.clone().requires_grad_(True)
+    F.gelu(pp).sum().backward()
+    assert torch.equal(y2, y) and rel_err(auxg, pp.grad) < max(tol, 1e-5)
+    hg = hh.detach().clone().requires_grad_(True)
+    F.gelu(hg).sum().backward()
+    gd = dev(hg.grad)
+    dx3 = torch.empty(M, K, device='cuda')
+    lib.vitae_linear_bwd_input(prec, dyd.data_ptr(), wd.data_ptr(), dx3.data_ptr(), M, N, K, C['VITAE_EPI_DGELU'] | DV,
+                               gd.data_ptr(), 0, split, ws.data_ptr(), st())
+    assert rel_err(dx3, hh.grad) < tol
     # dgrad accumulate
     base = gen(M, K, seed=7)
     dx2 = dev(base)
@@ -296,6 +312,14 @@ def test_gemm_wsx3(lib, C, form, M, N, K):
     F.gelu(hh).backward(ref)
     c = nan(); run(c, epi=C['VITAE_EPI_DGELU'], aux=dev(h))
     assert rel_err(c, hh.grad) < 1e-5
+    # the same pair through the saved derivative (VITAE_EPI_AUX_DERIV)
+    DV = C['VITAE_EPI_AUX_DERIV']
+    pg = (ref + bias.double()).float().clone().requires_grad_(True)
+    F.gelu(pg).sum().backward()
+    der = nan(); c2 = nan(); run(c2, bias=dev(bias), epi=C['VITAE_EPI_GELU'] | DV, aux=der)
+    assert rel_err(der, pg.grad) < 3e-5 and rel_err(c2, F.gelu((ref + bias.double()).float())) < 1e-5     # (GELU' of a 5e-6-accurate pre-activation: observed 1.4e-5)
+    c = nan(); run(c, epi=C['VITAE_EPI_DGELU'] | DV, aux=dev(h))
+    assert rel_err(c, ref * h.double()) < 1e-5
     if form == 'wgrad':
         rs = torch.zeros(M, device='cuda')
         c = nan(); run(c, rs=rs)
@@ -899,6 +923,20 @@ def test_gemm_bf16_saved_preactivation(lib, C, M, N, K):
     F.gelu(p).backward(dy @ w2)
     assert rel_err(dh16[:M].float(), p.grad) < 2e-2
     assert rel_err(dw, dy.t() @ y16[:M].float().cpu()) < 1e-2
+    # the same pair with the DERIVATIVE saved by the forward (VITAE_EPI_AUX_DERIV): GELU'(fp32 pre-activation) rounded once
+    DV = C['VITAE_EPI_AUX_DERIV']
+    der16 = torch.full((M, N), float('nan'), dtype=torch.bfloat16, device='cuda')
+    y16b = torch.zeros(Mp, N, dtype=torch.bfloat16, device='cuda')
+    lib.vitae_gemm_glds(1, 1, x16.data_ptr(), K, w16.data_ptr(), K, None, 0, y16b.data_ptr(), N, M, N, K, dev(bias).data_ptr(), None, 0,
+                        C['VITAE_EPI_GELU'] | C['VITAE_EPI_AUX_BF16'] | DV, der16.data_ptr(), N, 0, 1, None, None, st())
+    pg = pre.clone().requires_grad_(True)
+    F.gelu(pg).sum().backward()
+    assert torch.equal(y16b, y16) and rel_err(der16.float(), pg.grad) < 1e-2
+    dh16b = torch.zeros(Mp, N, dtype=torch.bfloat16, device='cuda')
+    lib.vitae_linear_bwd_pair_glds(dy16.data_ptr(), dev(_bf(w2)).data_ptr(), y16.data_ptr(), None, dh16b.data_ptr(), dw.data_ptr(), None,
+                                   M, Mp, D2, N, C['VITAE_EPI_DGELU'] | C['VITAE_EPI_AUX_BF16'] | DV, der16.data_ptr(), None, None, 0, 0, sp,
+                                   ws.data_ptr(), ws.numel(), st())
+    assert rel_err(dh16b[:M].float(), (dy @ w2) * pg.grad) < 2e-2
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -974,6 +1012,20 @@ def test_gemm_bt_forms_and_epilogues(lib, C, bt_mode, tile, form, M, N, K):
     assert rel_err(y, torch.where(aux > 0, prod, torch.zeros(()))) < 2e-3
     y = nan(); run(y, None, bd, None, C['VITAE_EPI_RELU'], None, 0)
     assert rel_err(y, F.relu(prod + b)) < 2e-3
+    # VITAE_EPI_AUX_DERIV: GELU saves GELU'(pre-activation) (fp32 / bf16), GELU' multiplies by the saved derivative
+    DV = C['VITAE_EPI_AUX_DERIV']
+    pb = (prod + b).clone().requires_grad_(True)
+    F.gelu(pb).sum().backward()
+    der, y16 = nan(), torch.zeros(M, N, dtype=torch.bfloat16, device='cuda')
+    run(None, y16, bd, None, C['VITAE_EPI_GELU'] | DV, der, 0)
+    assert rel_err(der, pb.grad) < 2e-3 and rel_err(y16.float(), F.gelu(prod + b)) < 1e-2
+    der16 = torch.zeros(M, N, dtype=torch.bfloat16, device='cuda')
+    run(None, y16, bd, None, C['VITAE_EPI_GELU'] | C['VITAE_EPI_AUX_BF16'] | DV, der16, 0)
+    assert rel_err(der16.float(), pb.grad) < 1e-2 and rel_err(y16.float(), F.gelu(prod + b)) < 1e-2
+    y = nan(); run(y, None, None, None, C['VITAE_EPI_DGELU'] | DV, auxd, 0)
+    assert rel_err(y, prod * aux) < 2e-3
+    y = nan(); run(y, None, None, None, C['VITAE_EPI_DGELU'] | C['VITAE_EPI_AUX_BF16'] | DV, aux16, 0)
+    assert rel_err(y, prod * aux16.float().cpu()) < 2e-3
 
 
 @pytest.mark.parametrize('tile', [3, 4, 5])

@@ -21,6 +21,7 @@ ROOT = os.path.dirname(PKG)
 HEADER = os.path.join(ROOT, 'include', 'vitae_hip.h')
 LIB_PATH = os.environ.get('VITAE_HIP_LIB') or os.path.join(PKG, 'libvitae_hip.so')   # the override: kernel experiments (tools/)
 
+_SYNC_LAUNCHES = os.environ.get('VITAE_SYNC_LAUNCHES') == '1'
 _ERRORS = {-1: 'VITAE_ERR_INVALID_ARG', -2: 'VITAE_ERR_UNSUPPORTED_SHAPE', -3: 'VITAE_ERR_LAUNCH'}
 
 
@@ -96,6 +97,8 @@ class _Lib:
             rc = fn(*args)
             if rc != 0:
                 raise VitaeError(f'{name} failed: {_ERRORS.get(rc, rc)}')
+            if _SYNC_LAUNCHES:      # measurement only (tools/in_step_tax.py): every launch alone on an idle chip
+                torch.cuda.synchronize()
             return rc
 
         checked.__name__ = name

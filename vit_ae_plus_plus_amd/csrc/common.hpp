@@ -72,3 +72,51 @@ __device__ __forceinline__ void gelu_gate(float x, float& cdf, float& pdf) {
 }
 __device__ __forceinline__ float gelu_fast(float x) { float c, d; gelu_gate(x, c, d); return x * c; }
 __device__ __forceinline__ float gelu_fast_grad(float x) { float c, d; gelu_gate(x, c, d); return fmaf(x, d, c); }
+
+// The same gate on FOUR values with packed fp32 VALU (v_pk_mul / v_pk_fma / v_pk_add: two lanes' worth of work per issue slot)
+// and bare v_exp_f32 / v_rcp_f32.  Round 5: a GEMM epilogue that applies GELU to a 256 x 256 tile is VALU-bound — 128 values per
+// lane at ~25 issue slots each (ocml's range-reduced expf alone was 9 of them) cost the fc1 launches of a batch-32 step 8.5-9.4 us
+// of their 37 us (tools/epi_ablate.py).  exp(-x^2/2) = 2^(-x^2 log2(e)/2) is at most 1, and below 2^-126 (|x| > 13.2) a flushed zero
+// is the right gate, so no range handling is needed; the 0.5 of the tail is folded into the polynomial's coefficients.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_gate4(const f32x4 x, f32x4& cdf, f32x4& pdf) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const f32x2 v = {x[2 * h], x[2 * h + 1]};
+        const f32x2 av = __builtin_elementwise_max(v, -v);
+        const f32x2 a = (v * v) * -0.72134752044448170368f;                     // -x^2 / 2 * log2(e)
+        f32x2 e, t;
+        const f32x2 den = __builtin_elementwise_fma(av, (f32x2)(0.3275911f * 0.70710678118654752440f), (f32x2)(1.0f));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { e[i] = __builtin_amdgcn_exp2f(a[i]); t[i] = __builtin_amdgcn_rcpf(den[i]); }
+        f32x2 poly = __builtin_elementwise_fma((f32x2)(0.5f * 1.061405429f), t, (f32x2)(0.5f * -1.453152027f));
+        poly = __builtin_elementwise_fma(poly, t, (f32x2)(0.5f * 1.421413741f));
+        poly = __builtin_elementwise_fma(poly, t, (f32x2)(0.5f * -0.284496736f));
+        poly = __builtin_elementwise_fma(poly, t, (f32x2)(0.5f * 0.254829592f));
+        const f32x2 tail = (poly * t) * e;                                       // 1 - Phi(|x|)
+        const f32x2 up = 1.0f - tail;
+        const f32x2 pd = e * 0.39894228040143267794f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { cdf[2 * h + i] = v[i] >= 0.f ? up[i] : tail[i]; pdf[2 * h + i] = pd[i]; }
+    }
+}
+// y = GELU(x), dy = GELU'(x) from one gate (the forward epilogue that saves the derivative for the backward: VITAE_EPI_AUX_DERIV)
+__device__ __forceinline__ void gelu_fast4(const f32x4 x, f32x4& y, f32x4& dy) {
+    f32x4 c, d;
+    gelu_gate4(x, c, d);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const f32x2 v = {x[2 * h], x[2 * h + 1]}, cc = {c[2 * h], c[2 * h + 1]}, dd = {d[2 * h], d[2 * h + 1]};
+        const f32x2 yy = v * cc, gg = __builtin_elementwise_fma(v, dd, cc);
+        y[2 * h] = yy[0]; y[2 * h + 1] = yy[1]; dy[2 * h] = gg[0]; dy[2 * h + 1] = gg[1];
+    }
+}
+__device__ __forceinline__ f32x4 gelu_fast4(const f32x4 x) { f32x4 y, dy; gelu_fast4(x, y, dy); return y; }
+__device__ __forceinline__ f32x4 gelu_fast_grad4(const f32x4 x) { f32x4 y, dy; gelu_fast4(x, y, dy); return dy; }
+// exact-erf pair (fp32-grade modes): gelu_erf(x) = (0.5 x)(1 + erf) == x (0.5 (1 + erf)) bit for bit (scaling by 0.5 is exact)
+__device__ __forceinline__ void gelu_erf_both(float x, float& y, float& dy) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    y = x * cdf;
+    dy = cdf + x * pdf;
+}

@@ -44,12 +44,17 @@ struct GemmArgs {
 
 __device__ __forceinline__ void epilogue_store(const GemmArgs& p, float v, int m, int n) {
     if (p.bias) v += p.bias[n];
-    if (p.epi == VITAE_EPI_GELU) {
-        p.aux[(long)m * p.ldaux + n] = v;
-        v = gelu_erf(v);
-    } else if (p.epi == VITAE_EPI_DGELU) {
-        v *= gelu_erf_grad(p.aux[(long)m * p.ldaux + n]);
-    } else if (p.epi == VITAE_EPI_RELU_MASK) {
+    const int kind = p.epi & 15;
+    const bool auxd = (p.epi & VITAE_EPI_AUX_DERIV) != 0;      // aux holds GELU'(pre-activation) instead of the pre-activation
+    if (kind == VITAE_EPI_GELU) {
+        float y, dy;
+        gelu_erf_both(v, y, dy);
+        p.aux[(long)m * p.ldaux + n] = auxd ? dy : v;
+        v = y;
+    } else if (kind == VITAE_EPI_DGELU) {
+        const float a = p.aux[(long)m * p.ldaux + n];
+        v *= auxd ? a : gelu_erf_grad(a);
+    } else if (kind == VITAE_EPI_RELU_MASK) {
         v = p.aux[(long)m * p.ldaux + n] > 0.f ? v : 0.f;
     }
     if (p.residual) v += p.residual[(long)m * p.ldr + n];
@@ -226,12 +231,13 @@ extern "C" int vitae_gemm(int prec, int a_kcontig, int b_kcontig,
                                  accumulate, split_k, splitk_ws, stream);
     if (prec != 0 && prec != 1) return VITAE_ERR_INVALID_ARG;
     if (epi != VITAE_EPI_NONE && !aux) return VITAE_ERR_INVALID_ARG;
+    if (epi & VITAE_EPI_AUX_BF16) return VITAE_ERR_UNSUPPORTED_SHAPE;      // (fp32 aux only in this family)
     // 16-byte vector loads run along the contiguous dimension of each operand.
     const int a_vec = a_kcontig ? K : M, b_vec = b_kcontig ? K : N;
     if ((a_vec & 3) || (b_vec & 3) || (lda & 3) || (ldb & 3)) return VITAE_ERR_UNSUPPORTED_SHAPE;
     if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return VITAE_ERR_UNSUPPORTED_SHAPE;
     if (split_k < 1) split_k = 1;
-    if (epi == VITAE_EPI_GELU) split_k = 1;   // non-linear epilogue needs the full sum anyway (done in reduce) — keep simple
+    if ((epi & 15) == VITAE_EPI_GELU) split_k = 1;   // non-linear epilogue needs the full sum anyway (done in reduce) — keep simple
     GemmArgs p;
     p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc;
     p.M = M; p.N = N; p.K = K;

@@ -44,12 +44,17 @@ struct GemmArgs {
 
 __device__ __forceinline__ void epilogue_store(const GemmArgs& p, float v, int m, int n) {
     if (p.bias) v += p.bias[n];
-    if (p.epi == VITAE_EPI_GELU) {
-        p.aux[(long)m * p.ldaux + n] = v;
-        v = gelu_erf(v);
-    } else if (p.epi == VITAE_EPI_DGELU) {
-        v *= gelu_erf_grad(p.aux[(long)m * p.ldaux + n]);
-    } else if (p.epi == VITAE_EPI_RELU_MASK) {
+    const int kind = p.epi & 15;
+    const bool auxd = (p.epi & VITAE_EPI_AUX_DERIV) != 0;      // aux holds GELU'(pre-activation) instead of the pre-activation
+    if (kind == VITAE_EPI_GELU) {
+        float y, dy;
+        gelu_erf_both(v, y, dy);
+        p.aux[(long)m * p.ldaux + n] = auxd ? dy : v;
+        v = y;
+    } else if (kind == VITAE_EPI_DGELU) {
+        const float a = p.aux[(long)m * p.ldaux + n];
+        v *= auxd ? a : gelu_erf_grad(a);
+    } else if (kind == VITAE_EPI_RELU_MASK) {
         v = p.aux[(long)m * p.ldaux + n] > 0.f ? v : 0.f;
     }
     if (p.residual) v += p.residual[(long)m * p.ldr + n];
@@ -355,12 +360,13 @@ extern "C" int vitae_gemm_bf16(int a_kcontig, int b_kcontig, const float* A, lon
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return VITAE_ERR_INVALID_ARG;
     if (a_colsum_accum && !a_kcontig) return VITAE_ERR_INVALID_ARG;
     if (epi != VITAE_EPI_NONE && !aux) return VITAE_ERR_INVALID_ARG;
+    if (epi & VITAE_EPI_AUX_BF16) return VITAE_ERR_UNSUPPORTED_SHAPE;      // (fp32 aux only in this family)
     const int b_epp = b_is_bf16 ? 8 : 4;
     const int a_vec = a_kcontig ? K : M, b_vec = b_kcontig ? K : N;
     if ((a_vec & 3) || (lda & 3) || (b_vec % b_epp) || (ldb % b_epp)) return VITAE_ERR_UNSUPPORTED_SHAPE;
     if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return VITAE_ERR_UNSUPPORTED_SHAPE;
     if (split_k < 1) split_k = 1;
-    if (epi == VITAE_EPI_GELU) split_k = 1;
+    if ((epi & 15) == VITAE_EPI_GELU) split_k = 1;
     GemmArgs p;
     p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc;
     p.M = M; p.N = N; p.K = K;
@@ -413,11 +419,12 @@ extern "C" int vitae_gemm_bf16x3(int a_kcontig, int b_kcontig, const float* A, l
                                  int epi, float* aux, long ldaux, int accumulate, int split_k, float* splitk_ws, void* stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return VITAE_ERR_INVALID_ARG;
     if (epi != VITAE_EPI_NONE && !aux) return VITAE_ERR_INVALID_ARG;
+    if (epi & VITAE_EPI_AUX_BF16) return VITAE_ERR_UNSUPPORTED_SHAPE;      // (fp32 aux only in this family)
     const int a_vec = a_kcontig ? K : M, b_vec = b_kcontig ? K : N;
     if ((a_vec & 3) || (lda & 3) || (b_vec & 3) || (ldb & 3)) return VITAE_ERR_UNSUPPORTED_SHAPE;
     if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return VITAE_ERR_UNSUPPORTED_SHAPE;
     if (split_k < 1) split_k = 1;
-    if (epi == VITAE_EPI_GELU) split_k = 1;
+    if ((epi & 15) == VITAE_EPI_GELU) split_k = 1;
     static const int big = env_int("VITAE_X3_BN128_MIN_TILES", 512), wide_bk = env_int("VITAE_X3_BN128_BK", 64);
     const bool wide = N >= 128 && (long)cdiv(M, 64) * cdiv(N, 128) >= big;
     const int bn = wide ? 128 : 64, bk = wide ? wide_bk : 128;   // (64 x 64 x 256 — 135 KB, one workgroup per CU — measured no faster)
@@ -454,6 +461,7 @@ extern "C" int vitae_linear_bwd_pair_bf16(const float* dy, const void* w_bf16, c
                                           int dx_accumulate, int dw_accumulate, void* stream) {
     if (!dy || !w_bf16 || !x || !dx || !dw || M <= 0 || N <= 0 || K <= 0) return VITAE_ERR_INVALID_ARG;
     if (epi != VITAE_EPI_NONE && !aux) return VITAE_ERR_INVALID_ARG;
+    if (epi & VITAE_EPI_AUX_BF16) return VITAE_ERR_UNSUPPORTED_SHAPE;      // (fp32 aux only in this family)
     if ((N & 7) || (K & 7)) return VITAE_ERR_UNSUPPORTED_SHAPE;
     if (((uintptr_t)dy & 15) || ((uintptr_t)w_bf16 & 15) || ((uintptr_t)x & 15)) return VITAE_ERR_UNSUPPORTED_SHAPE;
     GemmArgs p1, p2;

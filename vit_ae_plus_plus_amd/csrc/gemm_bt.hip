@@ -120,21 +120,37 @@ __device__ __forceinline__ void bt_wave_rows(const GArgs& p, int mb, int nb, con
                 }
             }
             if (epi == VITAE_EPI_GELU) {
+                f32x4 y, dy;
+                if (p.exact) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { float ye, de; gelu_erf_both(v[e], ye, de); y[e] = ye; dy[e] = de; }
+                } else {
+                    gelu_fast4(v, y, dy);
+                }
+                const f32x4 sv = p.auxd ? dy : v;                // what the backward gets: GELU'(x) (VITAE_EPI_AUX_DERIV) or x itself
                 if (ok) {
                     if constexpr (AUX16) {
                         bf16x4 h;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) h[e] = (__bf16)v[e];
+                        for (int e = 0; e < 4; ++e) h[e] = (__bf16)sv[e];
                         *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.aux) + m * ldaux + n) = h;
                     } else {
-                        *reinterpret_cast<f32x4*>(p.aux + m * ldaux + n) = v;
+                        *reinterpret_cast<f32x4*>(p.aux + m * ldaux + n) = sv;
+                    }
+                }
+                v = y;
+            } else if (epi == VITAE_EPI_DGELU) {
+                f32x4 g = axv;                                   // (aux already holds the derivative: a multiply)
+                if (!p.auxd) {
+                    if (p.exact) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) g[e] = gelu_erf_grad(axv[e]);
+                    } else {
+                        g = gelu_fast_grad4(axv);
                     }
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = p.exact ? gelu_erf(v[e]) : gelu_fast(v[e]);
-            } else if (epi == VITAE_EPI_DGELU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= p.exact ? gelu_erf_grad(axv[e]) : gelu_fast_grad(axv[e]);
+                for (int e = 0; e < 4; ++e) v[e] *= g[e];
             } else if (epi == VITAE_EPI_RELU_MASK) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = axv[e] > 0.f ? v[e] : 0.f;
@@ -182,10 +198,15 @@ __device__ __forceinline__ int bt_epilogue_kind(const GArgs& p) {
     return p.epi == VITAE_EPI_GELU ? 3 : p.epi == VITAE_EPI_DGELU ? 4 : p.epi == VITAE_EPI_RELU_MASK ? 5 : p.epi == VITAE_EPI_RELU ? 6 : 7;
 }
 
+// csum_acc: when set, the column sums of this part are ADDED to it (lane layout: the four columns nb + 4 (lane % (8 FN)) ..., one
+// partial per row group) and nothing is flushed — the caller folds the parts of a whole workgroup tile and issues ONE atomic per
+// column (bt_tail); otherwise the wave folds its own row groups and adds its sums to p.out_colsum itself.
 template <int FM, int FN>
-__device__ __forceinline__ void bt_wave_epilogue(const GArgs& p, int kind, int mb, int nb, const float* Tw, int lane, float& sqs, const f32x4 bias4) {
+__device__ __forceinline__ void bt_wave_epilogue(const GArgs& p, int kind, int mb, int nb, const float* Tw, int lane, float& sqs, const f32x4 bias4,
+                                                 f32x4* csum_acc = nullptr) {
     constexpr int LPR = 8 * FN;
     f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+    if (csum_acc) csum = *csum_acc;
     const bool full = mb + 32 * FM <= p.M && nb + 32 * FN <= p.N;
 #define VITAE_BT_ROWS(E)                                                                       \
     case E:                                                                                    \
@@ -211,6 +232,7 @@ __device__ __forceinline__ void bt_wave_epilogue(const GArgs& p, int kind, int m
     }
 #undef VITAE_BT_ROWS
 #undef VITAE_BT_ROWS_AUX
+    if (csum_acc) { *csum_acc = csum; return; }
     if (p.out_colsum) {
         // lanes with equal (lane % LPR) hold the same four columns: fold the row groups, then one atomic per column
 #pragma unroll
@@ -259,6 +281,7 @@ __device__ __forceinline__ void bt_tail(const GArgs& p, f32x16 (&acc)[2][2][NACC
     static_assert(NW * TW * 4 + 64 <= Cf::SMEM, "wave-private staging (+ the norm share of each wave) fits the operand stages");
     float* Tw = reinterpret_cast<float*>(smem) + wave * TW;
     float sqs = 0.f;
+    f32x4 csq0 = {0.f, 0.f, 0.f, 0.f}, csq1 = {0.f, 0.f, 0.f, 0.f};      // column sums of the wave's two B-halves (p.out_colsum)
     const int kind = bt_epilogue_kind(p);
     if constexpr (BM * BN < 256 * 256) if (p.splits > 1) {     // (the 256x256 tile: 256 KB of partials per split and workgroup - not offered)
         // Split-K inside the launch: every split parks its partial tile in the workspace (fragment order: 16 bytes per lane,
@@ -354,9 +377,39 @@ __device__ __forceinline__ void bt_tail(const GArgs& p, f32x16 (&acc)[2][2][NACC
             default: bt_park_quadrant<FM, FN, NACC>(acc[1][1], lane, Tw); break;
         }
         __builtin_amdgcn_wave_barrier();           // compiler-only: the lanes' writes stay in front of the other lanes' reads
-        bt_wave_epilogue<FM, FN>(p, kind, m0 + (q >> 1) * HM + wm * 32 * FM, n0 + (q & 1) * HN + wn * 32 * FN, Tw, lane, sqs, (q & 1) ? biasq[1] : biasq[0]);
+        f32x4 cs = (q & 1) ? csq1 : csq0;           // (selected by value: a run-time index would put the pair in scratch)
+        bt_wave_epilogue<FM, FN>(p, kind, m0 + (q >> 1) * HM + wm * 32 * FM, n0 + (q & 1) * HN + wn * 32 * FN, Tw, lane, sqs, (q & 1) ? biasq[1] : biasq[0],
+                                 p.out_colsum ? &cs : nullptr);
+        if (q & 1) csq1 = cs; else csq0 = cs;
         __builtin_amdgcn_wave_barrier();
         stamp(18 + q);
+    }
+    if (p.out_colsum) {
+        // Column sums of the stored tile (the bias gradient of the Linear in front): the wave's two B-halves were accumulated over its
+        // quadrants; fold the row groups (lanes with equal lane % LPR hold the same four columns), then the WM waves that share a
+        // column range through LDS, and add ONE value per column and workgroup.  (Round 5: one atomic per wave, quadrant and column —
+        // 2048 per 256 x 256 tile — cost the fc2 input-gradient launches of a batch-32 step 5-10 us each, tools/epi_ablate.py.)
+        constexpr int LPR = 8 * FN;
+        float* cred = reinterpret_cast<float*>(smem) + NW * TW + 16;          // [2 halves][WM][HN]
+        static_assert((NW * TW + 16 + 2 * WM * HN) * 4 <= Cf::SMEM, "column-sum staging fits behind the wave-private regions");
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            f32x4 c = b ? csq1 : csq0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int d = LPR; d < 64; d <<= 1) c[e] += __shfl_xor(c[e], d, 64);
+            if (lane < LPR) *reinterpret_cast<f32x4*>(cred + (b * WM + wm) * HN + wn * 32 * FN + 4 * lane) = c;
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < 2 * HN; j += 64 * NW) {
+            const int b = j / HN, c = j % HN, n = n0 + b * HN + c;
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) t += cred[(b * WM + w) * HN + c];
+            if (n < p.N) atomicAdd(p.out_colsum + n, t);
+        }
+        __syncthreads();                            // (the norm share below reuses the words in front)
     }
     if (p.sqacc) {
         // ONE double atomic per workgroup: every launch of a step adds to the same address, and the L2 serialises them — with one

@@ -119,20 +119,23 @@ __device__ __forceinline__ void epilogue_rows(const GArgs& p, const float (&a)[N
 #pragma unroll
             for (int e = 0; e < 4; ++e) x[e] += bias4[e];
             if (p.epi == VITAE_EPI_GELU) {
+                f32x4 y, dy;
+                gelu_fast4(x, y, dy);
+                const f32x4 sv = p.auxd ? dy : x;              // what the backward gets: GELU'(x) or x itself
                 if (p.aux16) {
                     bf16x4 h;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) h[e] = (__bf16)x[e];
+                    for (int e = 0; e < 4; ++e) h[e] = (__bf16)sv[e];
                     *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.aux) + m * ldaux + n) = h;
                 } else {
-                    *reinterpret_cast<f32x4*>(p.aux + m * ldaux + n) = x;
+                    *reinterpret_cast<f32x4*>(p.aux + m * ldaux + n) = sv;
                 }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) x[e] = gelu_fast(x[e]);
+                x = y;
             } else if (p.epi == VITAE_EPI_DGELU) {
                 if (p.aux16) ax[q] = f32x4{(float)ax16[q][0], (float)ax16[q][1], (float)ax16[q][2], (float)ax16[q][3]};
+                const f32x4 g = p.auxd ? ax[q] : gelu_fast_grad4(ax[q]);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) x[e] *= gelu_fast_grad(ax[q][e]);
+                for (int e = 0; e < 4; ++e) x[e] *= g[e];
             } else if (p.epi == VITAE_EPI_RELU_MASK) {
                 if (p.aux16) ax[q] = f32x4{(float)ax16[q][0], (float)ax16[q][1], (float)ax16[q][2], (float)ax16[q][3]};
 #pragma unroll
@@ -732,9 +735,10 @@ static int gemm_glds_launch(int a_kcontig, int b_kcontig, const void* A16, long 
                             int split_k, float* splitk_ws, float* out_colsum_accum, void* stream,
                             const BtPlan* forced = nullptr) {
     if (!A16 || !B16 || (!C && !C16) || M <= 0 || N <= 0 || K <= 0) return VITAE_ERR_INVALID_ARG;
-    const int aux16 = (epi & VITAE_EPI_AUX_BF16) != 0;
-    epi &= ~VITAE_EPI_AUX_BF16;
+    const int aux16 = (epi & VITAE_EPI_AUX_BF16) != 0, auxd = (epi & VITAE_EPI_AUX_DERIV) != 0;
+    epi &= ~(VITAE_EPI_AUX_BF16 | VITAE_EPI_AUX_DERIV);
     if (epi != VITAE_EPI_NONE && epi != VITAE_EPI_RELU && !aux) return VITAE_ERR_INVALID_ARG;
+    if (auxd && epi != VITAE_EPI_GELU && epi != VITAE_EPI_DGELU) return VITAE_ERR_INVALID_ARG;
     if (K % BK) return VITAE_ERR_UNSUPPORTED_SHAPE;
     if ((long)M * (ldc > N ? ldc : N) >= (1L << 31) || (long)M * ldaux >= (1L << 31) || (long)M * ldr >= (1L << 31) ||
         (long)M * ldc16 >= (1L << 31))
@@ -756,7 +760,7 @@ static int gemm_glds_launch(int a_kcontig, int b_kcontig, const void* A16, long 
     if (split_k > 1 && !splitk_ws) return VITAE_ERR_INVALID_ARG;
     p.k_per_split = kps; p.splits = split_k;
     p.bias = bias; p.residual = residual; p.ldr = ldr; p.aux = aux; p.ldaux = ldaux;
-    p.epi = epi; p.aux16 = aux16; p.accumulate = accumulate; p.ws = splitk_ws; p.out_colsum = out_colsum_accum; p.a_rowsum = nullptr;
+    p.epi = epi; p.aux16 = aux16; p.auxd = auxd; p.accumulate = accumulate; p.ws = splitk_ws; p.out_colsum = out_colsum_accum; p.a_rowsum = nullptr;
     p.dbg = g_gemm_dbg;
     const Tile t = pick_tile(M, N);
     p.tiles_m = cdiv(M, t.bm); p.tiles_n = cdiv(N, t.bn);
@@ -812,7 +816,10 @@ extern "C" int vitae_gemm_wsx3(int a_kcontig, int b_kcontig, const float* A, lon
                                long ldaux, int accumulate, int split_k, float* splitk_ws, float* out_colsum_accum,
                                float* a_rowsum_accum, void* stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return VITAE_ERR_INVALID_ARG;
+    const int auxd = (epi & VITAE_EPI_AUX_DERIV) != 0;
+    epi &= ~VITAE_EPI_AUX_DERIV;
     if (epi != VITAE_EPI_NONE && epi != VITAE_EPI_RELU && !aux) return VITAE_ERR_INVALID_ARG;
+    if (auxd && epi != VITAE_EPI_GELU && epi != VITAE_EPI_DGELU) return VITAE_ERR_INVALID_ARG;
     if (epi & VITAE_EPI_AUX_BF16) return VITAE_ERR_UNSUPPORTED_SHAPE;
     const int a_vec = a_kcontig ? K : M, b_vec = b_kcontig ? K : N;
     if ((a_vec & 3) || (lda & 3) || (b_vec & 3) || (ldb & 3) || (K & 3) || M < 8 || N < 8) return VITAE_ERR_UNSUPPORTED_SHAPE;
@@ -826,7 +833,7 @@ extern "C" int vitae_gemm_wsx3(int a_kcontig, int b_kcontig, const float* A, lon
     p.C = C; p.ldc = ldc; p.C16 = nullptr; p.ldc16 = 0;
     p.M = M; p.N = N; p.K = K; p.k_per_split = K; p.splits = split_k;
     p.bias = bias; p.residual = residual; p.ldr = ldr; p.aux = aux; p.ldaux = ldaux;
-    p.epi = epi; p.aux16 = 0; p.exact = 1; p.accumulate = accumulate; p.ws = splitk_ws; p.out_colsum = out_colsum_accum;
+    p.epi = epi; p.aux16 = 0; p.auxd = auxd; p.exact = 1; p.accumulate = accumulate; p.ws = splitk_ws; p.out_colsum = out_colsum_accum;
     p.a_rowsum = a_rowsum_accum; p.dbg = nullptr;
     p.tiles_m = 0; p.tiles_n = 0;
     p.xcd_m = xcd_by_rows(M, N);
@@ -857,9 +864,11 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
                                           float* dx_colsum_accum, float* dy_colsum_accum, int dx_accumulate, int dw_accumulate,
                                           int split_k, float* splitk_ws, long splitk_ws_floats, void* stream) {
     if (!dy16 || !w16 || (!x16 && dw) || (!dx && !dx16) || M <= 0 || N <= 0 || K <= 0) return VITAE_ERR_INVALID_ARG;
-    const int aux16 = (epi & VITAE_EPI_AUX_BF16) != 0;
-    epi &= ~VITAE_EPI_AUX_BF16;
+    const int aux16 = (epi & VITAE_EPI_AUX_BF16) != 0, auxd = (epi & VITAE_EPI_AUX_DERIV) != 0;
+    epi &= ~(VITAE_EPI_AUX_BF16 | VITAE_EPI_AUX_DERIV);
     if (epi != VITAE_EPI_NONE && !aux) return VITAE_ERR_INVALID_ARG;
+    if (auxd && epi != VITAE_EPI_DGELU) return VITAE_ERR_INVALID_ARG;
+    const int epi_flags = (aux16 ? VITAE_EPI_AUX_BF16 : 0) | (auxd ? VITAE_EPI_AUX_DERIV : 0);
     if (dx_accumulate && !dx) return VITAE_ERR_INVALID_ARG;
     if ((N % BK) || (Mpad % BK) || (K & 7) || Mpad < M) return VITAE_ERR_UNSUPPORTED_SHAPE;
     if ((long)(M > N ? M : N) * K >= (1L << 31)) return VITAE_ERR_UNSUPPORTED_SHAPE;   // 32-bit epilogue offsets
@@ -874,7 +883,7 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
         const BtPlan pd = bt_plan(M, K, N, 1, 0, true, cap);
         int sp = pd.tile >= 0 ? pd.split : old_split_rule(M, K, N);
         while (pd.tile < 0 && sp > 1 && vitae_gemm_glds_ws_floats(M, K, sp) > cap) --sp;
-        return gemm_glds_launch(1, 0, dy16, N, w16, K, dx, K, dx16, K, M, K, N, nullptr, nullptr, 0, epi | (aux16 ? VITAE_EPI_AUX_BF16 : 0),
+        return gemm_glds_launch(1, 0, dy16, N, w16, K, dx, K, dx16, K, M, K, N, nullptr, nullptr, 0, epi | epi_flags,
                                 aux, K, dx_accumulate, sp, splitk_ws, dx_colsum_accum, stream, &pd);
     }
     if (g_bt_mode == -1 || g_bt_mode == 5) {
@@ -886,7 +895,7 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
             p1.B = reinterpret_cast<const __bf16*>(w16); p1.ldb = K;
             p1.C = dx; p1.ldc = K; p1.C16 = reinterpret_cast<__bf16*>(dx16); p1.ldc16 = K;
             p1.M = M; p1.N = K; p1.K = N; p1.k_per_split = N; p1.splits = pd.split;
-            p1.bias = nullptr; p1.residual = nullptr; p1.ldr = 0; p1.aux = aux; p1.ldaux = K; p1.epi = epi; p1.aux16 = aux16;
+            p1.bias = nullptr; p1.residual = nullptr; p1.ldr = 0; p1.aux = aux; p1.ldaux = K; p1.epi = epi; p1.aux16 = aux16; p1.auxd = auxd;
             p1.accumulate = dx_accumulate != 0; p1.ws = splitk_ws; p1.out_colsum = dx_colsum_accum; p1.a_rowsum = nullptr; p1.dbg = nullptr;
             p1.xcd_m = xcd_by_rows(M, K); p1.tiles_m = 0; p1.tiles_n = 0;
             p1.vec_epi = vec_epilogue_ok(p1);
@@ -918,7 +927,7 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
                 while (sp > 1 && vitae_gemm_glds_ws_floats(m, n, sp) > cap) --sp;
                 return sp;
             };
-            int rc = gemm_glds_launch(1, 0, dy16, N, w16, K, dx, K, dx16, K, M, K, N, nullptr, nullptr, 0, epi | (aux16 ? VITAE_EPI_AUX_BF16 : 0),
+            int rc = gemm_glds_launch(1, 0, dy16, N, w16, K, dx, K, dx16, K, M, K, N, nullptr, nullptr, 0, epi | epi_flags,
                                       aux, K, dx_accumulate, fit(pd, M, K, N), splitk_ws, dx_colsum_accum, stream, &pd);
             if (rc != VITAE_OK) return rc;
             rc = gemm_glds_launch(0, 0, dy16, N, x16, K, dw, K, dw16, K, N, K, Mpad, nullptr, nullptr, 0, VITAE_EPI_NONE, nullptr, 0,
@@ -937,7 +946,7 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
     const int kps = cdiv(cdiv(N, split_k), BK) * BK;
     split_k = cdiv(N, kps);
     p1.M = M; p1.N = K; p1.K = N; p1.k_per_split = kps; p1.splits = split_k;
-    p1.bias = nullptr; p1.residual = nullptr; p1.ldr = 0; p1.aux = aux; p1.ldaux = K; p1.epi = epi; p1.aux16 = aux16; p1.accumulate = dx_accumulate != 0;
+    p1.bias = nullptr; p1.residual = nullptr; p1.ldr = 0; p1.aux = aux; p1.ldaux = K; p1.epi = epi; p1.aux16 = aux16; p1.auxd = auxd; p1.accumulate = dx_accumulate != 0;
     p1.ws = splitk_ws; p1.out_colsum = dx_colsum_accum; p1.a_rowsum = nullptr; p1.dbg = nullptr; p2.dbg = nullptr;
     const Tile t1 = pick_tile(M, K);
     p1.tiles_m = cdiv(M, t1.bm); p1.tiles_n = cdiv(K, t1.bn);

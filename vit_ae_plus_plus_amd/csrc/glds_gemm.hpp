@@ -29,6 +29,7 @@ struct GArgs {
     int tile0 = 0;               // index of this problem's first tile among the tickets / partial tiles of a grouped launch
     int aux16 = 0;               // aux holds bf16 (VITAE_EPI_AUX_BF16): the saved GELU pre-activation at half the bytes
     int exact = 0;               // GELU / GELU' through erff (the fp32-grade modes) instead of the 1.5e-7 polynomial
+    int auxd = 0;                // aux holds GELU'(pre-activation) (VITAE_EPI_AUX_DERIV): GELU saves it, GELU' multiplies by it
     long long* dbg;      // optional (tools/gemm_phase_probe.py): 8 s_memtime stamps per workgroup
     int xcd_m;           // 0: an XCD owns column tiles tn = xcd (mod 8) and walks every row tile (its L2 holds 1/8 of B and all
                          // of A); 1: it owns row tiles tm = xcd (mod 8) instead — picked when A is the larger operand
@@ -79,11 +80,14 @@ __device__ __forceinline__ float epilogue_frag(const GArgs& p, const float (&v)[
             if (!(ncol && m < p.M)) continue;
             float x = v[8 * half + q] + bias;
             if (p.epi == VITAE_EPI_GELU) {
-                if (p.aux16) reinterpret_cast<__bf16*>(p.aux)[m * ldaux + n] = (__bf16)x;
-                else p.aux[m * ldaux + n] = x;
-                x = gelu_fast(x);
+                float c, d;
+                gelu_gate(x, c, d);
+                const float sv = p.auxd ? fmaf(x, d, c) : x;
+                if (p.aux16) reinterpret_cast<__bf16*>(p.aux)[m * ldaux + n] = (__bf16)sv;
+                else p.aux[m * ldaux + n] = sv;
+                x *= c;
             } else if (p.epi == VITAE_EPI_DGELU) {
-                x *= gelu_fast_grad(ax[q]);
+                x *= p.auxd ? ax[q] : gelu_fast_grad(ax[q]);
             } else if (p.epi == VITAE_EPI_RELU_MASK) {
                 x = ax[q] > 0.f ? x : 0.f;
             } else if (p.epi == VITAE_EPI_RELU) {

@@ -136,6 +136,12 @@ class HipMAEEngine:
         self._hpre16_env = os.environ.get('VITAE_HPRE_BF16', 'auto')
         self.hpre16 = False
         self._aux16 = 0
+        # What fc1's epilogue saves for the backward (round 5): GELU'(pre-activation) instead of the pre-activation itself
+        # (VITAE_EPI_AUX_DERIV) — the gate that gives GELU gives GELU' for one more FMA, and the fc2 input-gradient epilogue becomes
+        # a multiply: its ~20 VALU operations per element were 11 of the 46 us of that launch at batch 32 (tools/epi_ablate.py).
+        # fp32 aux: the same value bit for bit; bf16 aux: GELU' of the fp32 pre-activation, rounded once (was GELU' of the rounded one).
+        self._auxd = _C['VITAE_EPI_AUX_DERIV'] if os.environ.get('VITAE_AUX_DERIV', '1') != '0' else 0
+        self.fc1_bias_by_wgrad = os.environ.get('VITAE_FC1_BIAS_BY_WGRAD', '1') != '0'   # (see _block_bwd16)
         # the gradient norm's matrix share is accumulated by the weight-gradient epilogues themselves (vitae_gemm_glds_set_wgrad_sqnorm)
         # instead of a pass over each bucket (45 us per bucket, the last one exposed behind the backward); single process only — a
         # data-parallel norm is the norm of the REDUCED gradients
@@ -373,7 +379,7 @@ class HipMAEEngine:
         Me, Md = Be * Ne, B * Nd
         self.Ne, self.Nd, self.Me, self.Md = Ne, Nd, Me, Md
         self.hpre16 = self.act16 and self._hpre16_env != '0'      # (end of round 4: a gain at every size — batch 32 10.66 -> 10.58 ms, patch 8 10.90 -> 10.84)
-        self._aux16 = CONSTS['VITAE_EPI_AUX_BF16'] if self.hpre16 else 0
+        self._aux16 = (CONSTS['VITAE_EPI_AUX_BF16'] if self.hpre16 else 0) | self._auxd
         dev = self.device
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         b = self.buf = {}
@@ -542,14 +548,14 @@ class HipMAEEngine:
     def _lin_fwd(self, x, w, bias, y, M, N, K, epi=EPI_NONE, aux=None, res=None):
         if self._x3_ok(N, K, x, w, y, bias, aux, res):
             ws = self._x3_ws()
-            s = 1 if epi == EPI_GELU else self._x3_split(M, N, K, ws)
+            s = 1 if (epi & 15) == EPI_GELU else self._x3_split(M, N, K, ws)
             t = self._timed(2.0 * M * N * K)
             lib.vitae_gemm_wsx3(1, 1, _ptr(x), K, _ptr(w), K, _ptr(y), N, M, N, K, _ptr(bias), _ptr(res), N, epi, _ptr(aux), N, 0, s,
                                 ws.data_ptr(), None, None, self.stream)
             if t is not None:
                 t.record()
             return
-        s = 1 if epi == EPI_GELU else self._split(M, N, K)
+        s = 1 if (epi & 15) == EPI_GELU else self._split(M, N, K)
         t = self._timed(2.0 * M * N * K)
         if self.prec == PREC['bf16']:
             w16 = self._w16(w)
@@ -749,12 +755,14 @@ class HipMAEEngine:
             return None
         return w.data_ptr() + (gview.data_ptr() - self.grads.data_ptr()) // 2
 
-    def wire_uncovered_ranges(self):
-        """Element ranges of the arena whose bf16 wire copy is NOT written by a GEMM epilogue (the reducer rounds those)."""
+    def wire_uncovered_ranges(self, extra_covered=()):
+        """Element ranges of the arena whose bf16 wire copy is NOT written by a GEMM epilogue (the reducer rounds those).
+        ``extra_covered``: names to treat as covered as well (``_epi_norm_uncovered``: the predictor's matrices get their squares
+        from the weight-gradient epilogues but no wire copy)."""
         if not self.act16:
             return [(0, self.n_total)]
         cfg = self.cfg
-        covered = ['patch_embed.proj.weight', 'decoder_pred.weight', 'decoder_embed.weight']
+        covered = ['patch_embed.proj.weight', 'decoder_pred.weight', 'decoder_embed.weight'] + list(extra_covered)
         for pre, depth in (('blocks.', cfg.depth), ('decoder_blocks.', cfg.decoder_depth)):
             for i in range(depth):
                 covered += [f'{pre}{i}.{n}.weight' for n in ('attn.qkv', 'attn.proj', 'mlp.fc1', 'mlp.fc2')]
@@ -883,9 +891,16 @@ class HipMAEEngine:
         dmid16 = b[s + 'dx_16b' + sfx] if grp else dx16
         if side:
             self._wg_fence(f'{s}grp{idx & 1}')      # the weight gradients of block idx + 2 read this set
+        # fc1's bias gradient colsum(dh): paired launches (few token rows) take it as row sums of dh16^T in the fc1 weight-gradient
+        # workgroups (one more MFMA against ones in the first column tile, ONE atomic per output) — as column sums of the fc2
+        # input-gradient epilogue it was 128 atomics per 64 x 64 tile: +1.6 / +3.9 us on the 8.7 / 7.4 us launches of the batch-4
+        # step (tools/epi_ablate.py, round 5).  Grouped weight gradients (many rows): the big-tile epilogue folds a workgroup's
+        # column sums in LDS first.
+        db_w = not grp and self.fc1_bias_by_wgrad
         self._g16_bwd(dx16, p[pre + 'mlp.fc2.weight'], b[q + 'act_16'], dw(pre + 'mlp.fc2.weight'), M, Mp, d, hid,
-                      dx16=dh16, epi=EPI_DGELU | self._aux16, aux=b[q + 'hpre'], dx_colsum=g[pre + 'mlp.fc1.bias'])
-        self._g16_bwd(dh16, p[pre + 'mlp.fc1.weight'], b[q + 'y2_16'], dw(pre + 'mlp.fc1.weight'), M, Mp, hid, d, dx=dy)
+                      dx16=dh16, epi=EPI_DGELU | self._aux16, aux=b[q + 'hpre'], dx_colsum=None if db_w else g[pre + 'mlp.fc1.bias'])
+        self._g16_bwd(dh16, p[pre + 'mlp.fc1.weight'], b[q + 'y2_16'], dw(pre + 'mlp.fc1.weight'), M, Mp, hid, d, dx=dy,
+                      dy_colsum=g[pre + 'mlp.fc1.bias'] if db_w else None)
         self._ln_bwd(dy, b[q + 'xmid'], pre + 'norm2.', b[q + 'mean2'], b[q + 'rstd2'], dx, M, d, 1, dx16=dmid16,
                      dx_colsum=g[pre + 'attn.proj.bias'])
         self._g16_bwd(dmid16, p[pre + 'attn.proj.weight'], b[q + 'o_16'], dw(pre + 'attn.proj.weight'), M, Mp, d, d, dx=do)
@@ -954,7 +969,7 @@ class HipMAEEngine:
                       res=x_in)
         self._ln_fwd(b[q + 'xmid'], pre + 'norm2.', b[q + 'y2'], b[q + 'mean2'], b[q + 'rstd2'], M, d)
         self._lin_fwd(b[q + 'y2'], p[pre + 'mlp.fc1.weight'], p[pre + 'mlp.fc1.bias'], b[q + 'act'], M, hid, d,
-                      epi=EPI_GELU, aux=b[q + 'hpre'])
+                      epi=EPI_GELU | self._auxd, aux=b[q + 'hpre'])
         self._lin_fwd(b[q + 'act'], p[pre + 'mlp.fc2.weight'], p[pre + 'mlp.fc2.bias'], x_out, M, d, hid,
                       res=b[q + 'xmid'])
 
@@ -965,7 +980,7 @@ class HipMAEEngine:
         # mlp.fc2 / fc1
         self._wg_fence(s + 'dh')                       # previous block's fc1 wgrad may still read dh
         self._lin_bwd(dx, p[pre + 'mlp.fc2.weight'], b[q + 'act'], dh, g[pre + 'mlp.fc2.weight'], g[pre + 'mlp.fc2.bias'],
-                      M, d, hid, epi=EPI_DGELU, aux=b[q + 'hpre'], tag=s + 'dx')
+                      M, d, hid, epi=EPI_DGELU | self._auxd, aux=b[q + 'hpre'], tag=s + 'dx')
         self._lin_bwd(dh, p[pre + 'mlp.fc1.weight'], b[q + 'y2'], dy, g[pre + 'mlp.fc1.weight'], g[pre + 'mlp.fc1.bias'],
                       M, hid, d, tag=s + 'dh')
         self._wg_fence(s + 'dx')                       # fc2 wgrad reads dx; LN backward updates it in place
@@ -1463,7 +1478,11 @@ class HipMAEEngine:
         """matrix ranges of the arena that no LDS-DMA weight-gradient epilogue writes (cached)"""
         u = getattr(self, '_epi_unc', None)
         if u is None:
-            u = self._epi_unc = [(a, min(e, self.tok_off)) for a, e in self.wire_uncovered_ranges() if a < self.tok_off]
+            # predictor on the LDS-DMA GEMMs (pred16): predictor.3's weight gradient leaves through the paired launch and predictor.0's
+            # through vitae_gemm_glds' dy^T x form — both add their squares to acc[GRADSQ] like every other wgrad epilogue, so reading
+            # them here again would count them twice (ADVICE r4; tests/test_gpu_model.py::test_grad_norm_fused_equals_generic_with_contrastive_weight_one)
+            extra = ('predictor.0.weight', 'predictor.3.weight') if (self.pred16 and self.cfg.contrastive) else ()
+            u = self._epi_unc = [(a, min(e, self.tok_off)) for a, e in self.wire_uncovered_ranges(extra) if a < self.tok_off]
         return u
 
     def _opt_tail(self):
