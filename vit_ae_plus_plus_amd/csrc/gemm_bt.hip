@@ -198,15 +198,13 @@ __device__ __forceinline__ int bt_epilogue_kind(const GArgs& p) {
     return p.epi == VITAE_EPI_GELU ? 3 : p.epi == VITAE_EPI_DGELU ? 4 : p.epi == VITAE_EPI_RELU_MASK ? 5 : p.epi == VITAE_EPI_RELU ? 6 : 7;
 }
 
-// csum_acc: when set, the column sums of this part are ADDED to it (lane layout: the four columns nb + 4 (lane % (8 FN)) ..., one
-// partial per row group) and nothing is flushed — the caller folds the parts of a whole workgroup tile and issues ONE atomic per
-// column (bt_tail); otherwise the wave folds its own row groups and adds its sums to p.out_colsum itself.
+// csum: the column sums of this part are ADDED to it (lane layout: the four columns nb + 4 (lane % (8 FN)) ..., one partial per row
+// group).  defer_colsum: nothing is flushed — the caller folds the parts of a whole workgroup tile and issues ONE atomic per column
+// (bt_tail); otherwise the wave folds its own row groups and adds its sums to p.out_colsum itself (csum should come in as zero).
 template <int FM, int FN>
 __device__ __forceinline__ void bt_wave_epilogue(const GArgs& p, int kind, int mb, int nb, const float* Tw, int lane, float& sqs, const f32x4 bias4,
-                                                 f32x4* csum_acc = nullptr) {
+                                                 f32x4& csum, const bool defer_colsum) {
     constexpr int LPR = 8 * FN;
-    f32x4 csum = {0.f, 0.f, 0.f, 0.f};
-    if (csum_acc) csum = *csum_acc;
     const bool full = mb + 32 * FM <= p.M && nb + 32 * FN <= p.N;
 #define VITAE_BT_ROWS(E)                                                                       \
     case E:                                                                                    \
@@ -232,7 +230,7 @@ __device__ __forceinline__ void bt_wave_epilogue(const GArgs& p, int kind, int m
     }
 #undef VITAE_BT_ROWS
 #undef VITAE_BT_ROWS_AUX
-    if (csum_acc) { *csum_acc = csum; return; }
+    if (defer_colsum) return;                      // (the caller folds csum over its parts: by reference, never through a pointer — that put it in scratch)
     if (p.out_colsum) {
         // lanes with equal (lane % LPR) hold the same four columns: fold the row groups, then one atomic per column
 #pragma unroll
@@ -281,7 +279,6 @@ __device__ __forceinline__ void bt_tail(const GArgs& p, f32x16 (&acc)[2][2][NACC
     static_assert(NW * TW * 4 + 64 <= Cf::SMEM, "wave-private staging (+ the norm share of each wave) fits the operand stages");
     float* Tw = reinterpret_cast<float*>(smem) + wave * TW;
     float sqs = 0.f;
-    f32x4 csq0 = {0.f, 0.f, 0.f, 0.f}, csq1 = {0.f, 0.f, 0.f, 0.f};      // column sums of the wave's two B-halves (p.out_colsum)
     const int kind = bt_epilogue_kind(p);
     if constexpr (BM * BN < 256 * 256) if (p.splits > 1) {     // (the 256x256 tile: 256 KB of partials per split and workgroup - not offered)
         // Split-K inside the launch: every split parks its partial tile in the workspace (fragment order: 16 bytes per lane,
@@ -368,6 +365,8 @@ __device__ __forceinline__ void bt_tail(const GArgs& p, f32x16 (&acc)[2][2][NACC
     }
     __syncthreads();                               // every wave is done with the operand stages
     stamp(17);
+    float* cred = reinterpret_cast<float*>(smem) + NW * TW + 16;              // column-sum partials [2 A-halves x WM][2 B-halves][HN]
+    static_assert((NW * TW + 16 + 4 * WM * HN) * 4 <= Cf::SMEM, "column-sum staging fits behind the wave-private regions");
 #pragma unroll 1
     for (int q = 0; q < 4; ++q) {
         switch (q) {
@@ -377,39 +376,34 @@ __device__ __forceinline__ void bt_tail(const GArgs& p, f32x16 (&acc)[2][2][NACC
             default: bt_park_quadrant<FM, FN, NACC>(acc[1][1], lane, Tw); break;
         }
         __builtin_amdgcn_wave_barrier();           // compiler-only: the lanes' writes stay in front of the other lanes' reads
-        f32x4 cs = (q & 1) ? csq1 : csq0;           // (selected by value: a run-time index would put the pair in scratch)
+        f32x4 cs = {0.f, 0.f, 0.f, 0.f};
         bt_wave_epilogue<FM, FN>(p, kind, m0 + (q >> 1) * HM + wm * 32 * FM, n0 + (q & 1) * HN + wn * 32 * FN, Tw, lane, sqs, (q & 1) ? biasq[1] : biasq[0],
-                                 p.out_colsum ? &cs : nullptr);
-        if (q & 1) csq1 = cs; else csq0 = cs;
+                                 cs, true);
+        if (p.out_colsum) {
+            // this quadrant's column sums, folded over the wave's row groups, parked per (A-half, wave row): nothing is carried in
+            // registers across the quadrants (eight more live VGPRs spilled next to the 128 accumulators of the 256 x 256 tile)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int d = 8 * FN; d < 64; d <<= 1) cs[e] += __shfl_xor(cs[e], d, 64);
+            if (lane < 8 * FN) *reinterpret_cast<f32x4*>(cred + (((q >> 1) * WM + wm) * 2 + (q & 1)) * HN + wn * 32 * FN + 4 * lane) = cs;
+        }
         __builtin_amdgcn_wave_barrier();
         stamp(18 + q);
     }
     if (p.out_colsum) {
-        // Column sums of the stored tile (the bias gradient of the Linear in front): the wave's two B-halves were accumulated over its
-        // quadrants; fold the row groups (lanes with equal lane % LPR hold the same four columns), then the WM waves that share a
-        // column range through LDS, and add ONE value per column and workgroup.  (Round 5: one atomic per wave, quadrant and column —
-        // 2048 per 256 x 256 tile — cost the fc2 input-gradient launches of a batch-32 step 5-10 us each, tools/epi_ablate.py.)
-        constexpr int LPR = 8 * FN;
-        float* cred = reinterpret_cast<float*>(smem) + NW * TW + 16;          // [2 halves][WM][HN]
-        static_assert((NW * TW + 16 + 2 * WM * HN) * 4 <= Cf::SMEM, "column-sum staging fits behind the wave-private regions");
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            f32x4 c = b ? csq1 : csq0;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int d = LPR; d < 64; d <<= 1) c[e] += __shfl_xor(c[e], d, 64);
-            if (lane < LPR) *reinterpret_cast<f32x4*>(cred + (b * WM + wm) * HN + wn * 32 * FN + 4 * lane) = c;
-        }
+        // Column sums of the stored tile (the bias gradient of the Linear in front): the 2 WM parked partials of every column are
+        // added and ONE value per column and workgroup goes to memory.  (Round 5: one atomic per wave, quadrant and column — 2048
+        // per 256 x 256 tile — cost the fc2 input-gradient launches of a batch-32 step 5-10 us each, tools/epi_ablate.py.)
         __syncthreads();
         for (int j = threadIdx.x; j < 2 * HN; j += 64 * NW) {
             const int b = j / HN, c = j % HN, n = n0 + b * HN + c;
             float t = 0.f;
 #pragma unroll
-            for (int w = 0; w < WM; ++w) t += cred[(b * WM + w) * HN + c];
+            for (int w = 0; w < 2 * WM; ++w) t += cred[(w * 2 + b) * HN + c];
             if (n < p.N) atomicAdd(p.out_colsum + n, t);
         }
-        __syncthreads();                            // (the norm share below reuses the words in front)
+        __syncthreads();                            // (the norm share below reuses words in front)
     }
     if (p.sqacc) {
         // ONE double atomic per workgroup: every launch of a step adds to the same address, and the L2 serialises them — with one
@@ -666,6 +660,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bt_kernel(const GArgs p)
 #ifndef VITAE_WS_TAIL8
 #define VITAE_WS_TAIL8 1          // unsplit launches: the producer waves take half of the epilogue (quadrants A-hi x B-lo / B-hi of their SIMD partner)
 #endif
+#ifndef VITAE_WS_INTERLEAVE
+#define VITAE_WS_INTERLEAVE 1     // fragment reads one per MFMA gap (round 5) instead of bursts of eight between the MFMA blocks
+#endif
+#ifndef VITAE_WS_FINE_STAMPS
+#define VITAE_WS_FINE_STAMPS 0    // 1: s_memtime stamps inside ONE k-tile of the consumer (variant library for tools/ws_phase_probe.py fine)
+#endif
 #ifndef VITAE_WS_ABLATE
 #define VITAE_WS_ABLATE 0         // timing experiments (results are garbage): 1 no MFMA, 2 half of the DMA pieces, 4 no fragment reads,
                                   // 8 ONE producer wave issues every piece (correct results), 16 consumer wave 0 (the producer's SIMD partner) skips its MFMAs
@@ -674,7 +674,7 @@ template <bool A_KC, bool B_KC, int S>
 __device__ __forceinline__ void gemm_ws_body(const GArgs& p, const int bid, const int zid, unsigned char* smem) {
     constexpr int BM = 128, BN = 128, NWC = 4, NWP = (VITAE_WS_ABLATE & 8) ? 1 : 4;
     constexpr int A_T = BM * BK * 2, B_T = BN * BK * 2, STG = A_T + B_T;
-    constexpr int PA = pieces<BM, A_KC, NWP>(), PB = pieces<BN, B_KC, NWP>(), PT = PA + ((VITAE_WS_ABLATE & 2) ? 0 : PB);
+    constexpr int PA = pieces<BM, A_KC, NWP>(), PB = pieces<BN, B_KC, NWP>(), PT = ((VITAE_WS_ABLATE & 32) ? 1 : PA) + ((VITAE_WS_ABLATE & 2) ? 0 : PB);
     static_assert(S >= 3 && S <= 5 && S * STG + (VITAE_WS_TAIL8 ? 12 * 4096 + 64 : 0) <= 160 * 1024 && (S - 2) * PT <= 63, "stages fit LDS, three tiles of pieces fit the vmcnt field");
     const int T = p.tiles_m * p.tiles_n;
     const int xq = T >> 3, xr = T & 7, xcd = bid & 7;
@@ -704,7 +704,7 @@ __device__ __forceinline__ void gemm_ws_body(const GArgs& p, const int bid, cons
             unsigned char* dst = smem + stage * STG;
             const int k0 = kbeg + t * BK;
 #pragma unroll
-            for (int j = 0; j < PA; ++j) dma_piece<BM, A_KC, NWP>(p.A, p.lda, p.M, m0, k0, dst, pw, lane, j);
+            for (int j = 0; j < ((VITAE_WS_ABLATE & 32) ? 1 : PA); ++j) dma_piece<BM, A_KC, NWP>(p.A, p.lda, p.M, m0, k0, dst, pw, lane, j);
 #pragma unroll
             for (int j = 0; j < ((VITAE_WS_ABLATE & 2) ? 0 : PB); ++j) dma_piece<BN, B_KC, NWP>(p.B, p.ldb, p.N, n0, k0, dst + A_T, pw, lane, j);
         };
@@ -722,12 +722,16 @@ __device__ __forceinline__ void gemm_ws_body(const GArgs& p, const int bid, cons
         int stage = npre % S;                                            // slot of tile t + S - 1 (= tile t - 1's)
 #pragma unroll 1
         for (int t = 0; t + 1 < nk; ++t) {
+            const bool pr = p.dbg && t >= 3 && t < 9;                    // tools/ws_phase_probe.py: who arrives last at B_4 .. B_9
             if (t + S - 1 < nk) {
                 if (active) issue_tile(t + S - 1, stage);
                 stage = stage + 1 == S ? 0 : stage + 1;
             }
+            if (pr) stamp(2 + 3 * (t - 3));                               // pieces issued
             wait_tiles(min(t + S - 1, nk - 1) - (t + 1));                // B_{t+1}: tile t + 1 has landed
+            if (pr) stamp(3 + 3 * (t - 3));                               // arrival
             barrier();
+            if (pr) stamp(4 + 3 * (t - 3));                               // departure
         }
         if (!VITAE_WS_TAIL8 || p.splits > 1) return;                     // (split launches: the consumers' fix-up has barriers of its own)
         // the epilogue of the partner's two A-hi quadrants, parked by it in this wave's two LDS regions behind the stages
@@ -744,7 +748,7 @@ __device__ __forceinline__ void gemm_ws_body(const GArgs& p, const int bid, cons
         float sqs = 0.f;
         barrier();                                                       // T: the partner's quadrants are in LDS
 #pragma unroll 1
-        for (int b = 0; b < 2; ++b) bt_wave_epilogue<1, 1>(p, kind, m0 + 64 + wmp * 32, n0 + b * 64 + wnp * 32, Pq + b * 1024, lane, sqs, b ? bq[1] : bq[0]);
+        for (int b = 0; b < 2; ++b) { f32x4 cz = {0.f, 0.f, 0.f, 0.f}; bt_wave_epilogue<1, 1>(p, kind, m0 + 64 + wmp * 32, n0 + b * 64 + wnp * 32, Pq + b * 1024, lane, sqs, b ? bq[1] : bq[0], cz, false); }
         if (p.sqacc) {                                                   // one atomic per workgroup (see bt_tail)
             sqs = wave_sum(sqs);
             float* red = reinterpret_cast<float*>(smem + S * STG + 12 * 4096);
@@ -798,31 +802,126 @@ __device__ __forceinline__ void gemm_ws_body(const GArgs& p, const int bid, cons
     barrier();                                                           // B_0: tile 0 is in LDS
     rd(smem, K0{}); rd(smem, K1{});
     int stage = 0;
+#if VITAE_WS_INTERLEAVE
+    // Round 5 (tools/ws_phase_probe.py): the k-loop was bound by the CONSUMER — every barrier found the producers waiting 200-330
+    // clocks, the interval was 1080 clocks for 512 of MFMA.  An in-order wave that issues eight fragment reads in a burst sits at
+    // them for 100-300 clocks (four waves share the LDS port with the DMA's writes) while its matrix pipe drains.  Here the reads of
+    // the two slices ahead are issued ONE FRAGMENT PER MFMA GAP: the four MFMAs of a slice carry the eight fragments of the next
+    // pair of slices (each read issues in the 32-clock shadow of the MFMA in front of it).
+    //   slice 0 MFMAs + reads of slices 2, 3 | slice 1 MFMAs | all reads of tile t retired, B_{t+1} | slice 2 MFMAs + reads of the
+    //   next tile's slices 0, 1 | slice 3 MFMAs
+    const FragOff<BM, A_KC> offa = frag_offsets<BM, A_KC>(wm * 32, lane);
+    const FragOff<BN, B_KC> offb = frag_offsets<BN, B_KC>(wn * 32, lane);
+    typedef __attribute__((address_space(3))) const unsigned char lds_u8;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_u8*)smem;
+    // Eight MFMAs (k-slices S0, S0 + 1) that carry the eight fragments of slices R0, R0 + 1 of the tile at LDS address `rb`:
+    // gap:       0        1      2      3        4      5     6  7
+    // fragments  a0 b0    a0'    b0'    a1 b1    a1'    b1'   -  -      (x' = the half 64 rows further; the last two gaps stay
+    // empty so that the lgkmcnt(0) behind the block finds every read retired)
+    auto half = [&](auto s0_c, const unsigned rb, auto r0_c, bool do_rd) {
+        constexpr int S0 = decltype(s0_c)::value, R0 = decltype(r0_c)::value;
+#pragma unroll
+        for (int k = S0; k < S0 + 2; ++k)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { frag_tie(fa[k][h]); frag_tie(fb[k][h]); }
+        __builtin_amdgcn_sched_barrier(0);
+        unsigned aa = 0, ab = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int kk = S0 + (j >> 2), a = (j >> 1) & 1, b = j & 1;
+            acc[a][b][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][a], fb[kk][b], acc[a][b][0][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (do_rd && j < 6) {
+                if (j == 0) {
+                    aa = frag_base<BM, A_KC, R0>(rb, offa, 0); ab = frag_base<BN, B_KC, R0>(rb + A_T, offb, 0);
+                    fa[R0][0] = frag_rd<BM, A_KC, R0, 0>(aa); fb[R0][0] = frag_rd<BN, B_KC, R0, 0>(ab);
+                }
+                if (j == 1) { if (!A_KC) aa = frag_base<BM, A_KC, R0>(rb, offa, 1); fa[R0][1] = frag_rd<BM, A_KC, R0, A_KC ? 1 : 0>(aa); }
+                if (j == 2) { if (!B_KC) ab = frag_base<BN, B_KC, R0>(rb + A_T, offb, 1); fb[R0][1] = frag_rd<BN, B_KC, R0, B_KC ? 1 : 0>(ab); }
+                if (j == 3) {
+                    aa = frag_base<BM, A_KC, R0 + 1>(rb, offa, 0); ab = frag_base<BN, B_KC, R0 + 1>(rb + A_T, offb, 0);
+                    fa[R0 + 1][0] = frag_rd<BM, A_KC, R0 + 1, 0>(aa); fb[R0 + 1][0] = frag_rd<BN, B_KC, R0 + 1, 0>(ab);
+                }
+                if (j == 4) { if (!A_KC) aa = frag_base<BM, A_KC, R0 + 1>(rb, offa, 1); fa[R0 + 1][1] = frag_rd<BM, A_KC, R0 + 1, A_KC ? 1 : 0>(aa); }
+                if (j == 5) { if (!B_KC) ab = frag_base<BN, B_KC, R0 + 1>(rb + A_T, offb, 1); fb[R0 + 1][1] = frag_rd<BN, B_KC, R0 + 1, B_KC ? 1 : 0>(ab); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+#pragma unroll 1
+    for (int t = 0; t < nk; ++t) {
+        // entry: the fragments of slices 0, 1 of tile t were read under the MFMAs of the previous tile's slices 2, 3
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        half(K0{}, lds0 + stage * STG, K2{}, true);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // every read of tile t has retired (the last one two MFMAs ago)
+        const bool more = t + 1 < nk;
+        if (more) {
+            barrier();                                                   // B_{t+1}
+            stage = stage + 1 == S ? 0 : stage + 1;
+        }
+        __builtin_amdgcn_s_setprio(1);
+        half(K2{}, lds0 + stage * STG, K0{}, more);
+        __builtin_amdgcn_s_setprio(0);
+    }
+#else
 #pragma unroll 1
     for (int t = 0; t < nk; ++t) {
         const unsigned char* TA = smem + stage * STG;
+#if VITAE_WS_FINE_STAMPS
+        const bool fine = p.dbg && t == 12;                              // tools/ws_phase_probe.py fine: the pieces of ONE k-tile (perturbs the pipeline)
+        if (fine) stamp(21);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         rd(TA, K2{}); rd(TA, K3{});
         __builtin_amdgcn_sched_barrier(0);
+#if VITAE_WS_FINE_STAMPS
+        if (fine) stamp(22);
+#endif
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(W2) : "memory");     // slices 0-1 (read one barrier ago) are in registers
         __builtin_amdgcn_sched_barrier(0);
+#if VITAE_WS_FINE_STAMPS
+        if (fine) stamp(23);
+#endif
         __builtin_amdgcn_s_setprio(1);
         mm(K0{}); mm(K1{});
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
+#if VITAE_WS_FINE_STAMPS
+        if (fine) stamp(24);
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // every read of tile t has retired: its slot may be restaged
         if (t + 1 < nk) {
+            const bool pr = p.dbg && t >= 3 && t < 9;
+            if (pr) stamp(2 + 3 * (t - 3));                               // arrival at B_{t+1}
+#if VITAE_WS_FINE_STAMPS
+            if (fine) stamp(25);
+#endif
             barrier();                                                   // B_{t+1}
+            if (pr) stamp(3 + 3 * (t - 3));                               // departure
+#if VITAE_WS_FINE_STAMPS
+            if (fine) stamp(26);
+#endif
             stage = stage + 1 == S ? 0 : stage + 1;
             const unsigned char* TN = smem + stage * STG;
             rd(TN, K0{}); rd(TN, K1{});
             __builtin_amdgcn_sched_barrier(0);
+#if VITAE_WS_FINE_STAMPS
+            if (fine) stamp(27);
+#endif
         }
         __builtin_amdgcn_s_setprio(1);
         mm(K2{}); mm(K3{});
         __builtin_amdgcn_s_setprio(0);
+#if VITAE_WS_FINE_STAMPS
+        if (fine) stamp(28);
+#endif
     }
-    stamp(16);
+#endif
+    stamp(20);
     if (VITAE_WS_TAIL8 && p.splits == 1) {
         // unsplit launch: quadrants (A-hi, B-lo) and (A-hi, B-hi) go to the SIMD partner (a producer wave, idle by now) through
         // its two 4 KB regions behind the stages; this wave keeps (A-lo, B-lo) and (A-lo, B-hi).  Nothing here touches the stages,
@@ -847,7 +946,7 @@ __device__ __forceinline__ void gemm_ws_body(const GArgs& p, const int bid, cons
             if (b == 0) bt_park_quadrant<1, 1, 1>(acc[0][0], lane, Tw);
             else bt_park_quadrant<1, 1, 1>(acc[0][1], lane, Tw);
             __builtin_amdgcn_wave_barrier();
-            bt_wave_epilogue<1, 1>(p, kind, m0 + wm * 32, n0 + b * 64 + wn * 32, Tw, lane, sqs, b ? bq[1] : bq[0]);
+            { f32x4 cz = {0.f, 0.f, 0.f, 0.f}; bt_wave_epilogue<1, 1>(p, kind, m0 + wm * 32, n0 + b * 64 + wn * 32, Tw, lane, sqs, b ? bq[1] : bq[0], cz, false); }
             __builtin_amdgcn_wave_barrier();
         }
         if (p.sqacc) {
@@ -1062,7 +1161,7 @@ __device__ __forceinline__ void gemm_ws64_body(const GArgs& p, const int bid, co
     bt_park_quadrant<1, 1, 1>(accs, lane, Tw);
     __builtin_amdgcn_wave_barrier();
     float sqs = 0.f;
-    bt_wave_epilogue<1, 1>(p, bt_epilogue_kind(p), m0 + wm * 32, n0 + wn * 32, Tw, lane, sqs, bias4);
+    { f32x4 cz = {0.f, 0.f, 0.f, 0.f}; bt_wave_epilogue<1, 1>(p, bt_epilogue_kind(p), m0 + wm * 32, n0 + wn * 32, Tw, lane, sqs, bias4, cz, false); }
     if (p.sqacc) {                                                       // one atomic per workgroup (see bt_tail)
         sqs = wave_sum(sqs);
         float* red = reinterpret_cast<float*>(smem + 4 * 4096 + 64);
@@ -1344,7 +1443,7 @@ __device__ __forceinline__ void gemm_wsx3_body(const GArgs& p, const int bid, co
     bt_park_quadrant<1, 1, 1>(accs, lane, Tw);
     __builtin_amdgcn_wave_barrier();
     float sqs = 0.f;
-    bt_wave_epilogue<1, 1>(p, bt_epilogue_kind(p), m0 + wm * 32, n0 + wn * 32, Tw, lane, sqs, bias4);
+    { f32x4 cz = {0.f, 0.f, 0.f, 0.f}; bt_wave_epilogue<1, 1>(p, bt_epilogue_kind(p), m0 + wm * 32, n0 + wn * 32, Tw, lane, sqs, bias4, cz, false); }
     if (p.sqacc) {
         sqs = wave_sum(sqs);
         float* red = reinterpret_cast<float*>(smem + 4 * 4096 + 64);

@@ -132,6 +132,51 @@ __device__ __forceinline__ bf16x8 frag_asm(const unsigned char* T, int row0, int
     }
 }
 
+// The same fragments addressed as (stage base) + (per-lane offset that does not depend on the stage: computed ONCE) + (immediate):
+// one v_add per pair of reads in the k-loop instead of 1.5-2 address instructions per read — the wave-specialised consumers issue
+// their reads in the shadow of an MFMA, where only ~5 instructions fit (round 5).
+//   KC image ([row][8 chunks], slot = chunk ^ swz(row)): the k-slice enters through the XOR, so one offset per slice (4 VGPRs);
+//     the fragment 64 rows further down is + 8192 bytes (swz has a period of 16 rows): an immediate.
+//   row-contiguous image ([k][ROWS / 8 chunks]): the k-slice is additive (kk * 16 lines, + 4 lines for the second read): immediates;
+//     the fragment 64 columns further flips a lane-dependent bit of the slot: a second offset (2 VGPRs).
+template <int ROWS, bool KC> struct FragOff { unsigned o[KC ? 4 : 2]; };
+template <int ROWS, bool KC>
+__device__ __forceinline__ FragOff<ROWS, KC> frag_offsets(int row0, int lane) {
+    FragOff<ROWS, KC> f;
+    if constexpr (KC) {
+        const int r = row0 + (lane & 31);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) f.o[kk] = r * 128 + (((2 * kk + (lane >> 5)) ^ swz<true, 8>(r)) << 4);
+    } else {
+        constexpr int LB = ROWS * 2;
+        const int gg = lane >> 4, li = lane & 15;
+        const int kl = 8 * (gg >> 1) + (li >> 2);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int col = row0 + 64 * h + 16 * (gg & 1) + 4 * (li & 3);
+            f.o[h] = kl * LB + (((col >> 3) ^ swz<false, ROWS / 8>(kl)) << 4) + (col & 7) * 2;
+        }
+    }
+    return f;
+}
+// fragment (k-slice KK, row half H) of the tile at LDS byte address `base`; KC: base must already include f.o[KK] (frag_base)
+template <int ROWS, bool KC, int KK>
+__device__ __forceinline__ unsigned frag_base(unsigned base, const FragOff<ROWS, KC>& f, int h) { return base + (KC ? f.o[KK] : f.o[h]); }
+template <int ROWS, bool KC, int KK, int H>
+__device__ __forceinline__ bf16x8 frag_rd(unsigned a) {
+    if constexpr (KC) {
+        bf16x8 r;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(a), "n"(H * 8192));
+        return r;
+    } else {
+        constexpr int LB = ROWS * 2;
+        union { s16x4 s[2]; bf16x8 b; } u;
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(u.s[0]) : "v"(a), "n"(KK * 16 * LB));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(u.s[1]) : "v"(a), "n"(KK * 16 * LB + 4 * LB));
+        return u.b;
+    }
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
