@@ -660,6 +660,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bt_kernel(const GArgs p)
 #ifndef VITAE_WS_TAIL8
 #define VITAE_WS_TAIL8 1          // unsplit launches: the producer waves take half of the epilogue (quadrants A-hi x B-lo / B-hi of their SIMD partner)
 #endif
+#ifndef VITAE_WS_TAIL_ALIAS
+#define VITAE_WS_TAIL_ALIAS 0     // 1: the tail's LDS (parked quadrants, wave-private staging) ALIASES the operand stages behind one more barrier, so
+                                  // that 4 or 5 stages fit.  Measured with the interleaved consumer (tools/probes/r5_ws_ab5.sh, us, 3 / 3 aliased / 4 / 5
+                                  // stages): 3520 x 768 x 3072 27.0 / 27.8 / 27.8 / 27.8, its dgrad 28.6 / 28.5 / 28.6 / 28.6, 6944 x 512 x 2048 22.3 /
+                                  // 22.8 / 22.8 / 22.7 — a deeper pipeline buys nothing: the loop sits on the CU's L2 -> LDS feed (32 KB per ~870 clocks =
+                                  // 37 B/clk, what tools/probes/mfma_rate.hip gets for bare MFMAs beside the same DMA stream)
+#endif
 #ifndef VITAE_WS_INTERLEAVE
 #define VITAE_WS_INTERLEAVE 1     // fragment reads one per MFMA gap (round 5) instead of bursts of eight between the MFMA blocks
 #endif
@@ -675,7 +682,8 @@ __device__ __forceinline__ void gemm_ws_body(const GArgs& p, const int bid, cons
     constexpr int BM = 128, BN = 128, NWC = 4, NWP = (VITAE_WS_ABLATE & 8) ? 1 : 4;
     constexpr int A_T = BM * BK * 2, B_T = BN * BK * 2, STG = A_T + B_T;
     constexpr int PA = pieces<BM, A_KC, NWP>(), PB = pieces<BN, B_KC, NWP>(), PT = ((VITAE_WS_ABLATE & 32) ? 1 : PA) + ((VITAE_WS_ABLATE & 2) ? 0 : PB);
-    static_assert(S >= 3 && S <= 5 && S * STG + (VITAE_WS_TAIL8 ? 12 * 4096 + 64 : 0) <= 160 * 1024 && (S - 2) * PT <= 63, "stages fit LDS, three tiles of pieces fit the vmcnt field");
+    constexpr int TAILOFF = VITAE_WS_TAIL_ALIAS ? 0 : S * STG;       // byte offset of the tail's LDS
+    static_assert(S >= 3 && S <= 5 && (VITAE_WS_TAIL_ALIAS ? S * STG : S * STG + (VITAE_WS_TAIL8 ? 12 * 4096 + 64 : 0)) <= 160 * 1024 && (S - 2) * PT <= 63, "stages fit LDS, three tiles of pieces fit the vmcnt field");
     const int T = p.tiles_m * p.tiles_n;
     const int xq = T >> 3, xr = T & 7, xcd = bid & 7;
     const int lin = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
@@ -744,14 +752,15 @@ __device__ __forceinline__ void gemm_ws_body(const GArgs& p, const int bid, cons
             if (p.bias && n < p.N) bq[b] = *reinterpret_cast<const f32x4*>(p.bias + n);
         }
         const int kind = bt_epilogue_kind(p);
-        const float* Pq = reinterpret_cast<const float*>(smem + S * STG) + pw * 2048;
+        const float* Pq = reinterpret_cast<const float*>(smem + TAILOFF) + pw * 2048;
         float sqs = 0.f;
+        if (VITAE_WS_TAIL_ALIAS) barrier();                              // E: every consumer is past its last fragment read (the tail aliases the stages)
         barrier();                                                       // T: the partner's quadrants are in LDS
 #pragma unroll 1
         for (int b = 0; b < 2; ++b) { f32x4 cz = {0.f, 0.f, 0.f, 0.f}; bt_wave_epilogue<1, 1>(p, kind, m0 + 64 + wmp * 32, n0 + b * 64 + wnp * 32, Pq + b * 1024, lane, sqs, b ? bq[1] : bq[0], cz, false); }
         if (p.sqacc) {                                                   // one atomic per workgroup (see bt_tail)
             sqs = wave_sum(sqs);
-            float* red = reinterpret_cast<float*>(smem + S * STG + 12 * 4096);
+            float* red = reinterpret_cast<float*>(smem + TAILOFF + 12 * 4096);
             if (lane == 0) red[wave] = sqs;
             barrier();
         }
@@ -926,8 +935,9 @@ __device__ __forceinline__ void gemm_ws_body(const GArgs& p, const int bid, cons
         // unsplit launch: quadrants (A-hi, B-lo) and (A-hi, B-hi) go to the SIMD partner (a producer wave, idle by now) through
         // its two 4 KB regions behind the stages; this wave keeps (A-lo, B-lo) and (A-lo, B-hi).  Nothing here touches the stages,
         // which slower waves may still be reading.
-        float* Pq = reinterpret_cast<float*>(smem + S * STG) + wave * 2048;
-        float* Tw = reinterpret_cast<float*>(smem + S * STG) + 4 * 2048 + wave * 1024;
+        float* Pq = reinterpret_cast<float*>(smem + TAILOFF) + wave * 2048;
+        float* Tw = reinterpret_cast<float*>(smem + TAILOFF) + 4 * 2048 + wave * 1024;
+        if (VITAE_WS_TAIL_ALIAS) barrier();                              // E (no DMA is in flight: the producers waited for the last tile before B_{nk-1})
         f32x4 bq[2];
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
@@ -951,7 +961,7 @@ __device__ __forceinline__ void gemm_ws_body(const GArgs& p, const int bid, cons
         }
         if (p.sqacc) {
             sqs = wave_sum(sqs);
-            float* red = reinterpret_cast<float*>(smem + S * STG + 12 * 4096);
+            float* red = reinterpret_cast<float*>(smem + TAILOFF + 12 * 4096);
             if (lane == 0) red[wave] = sqs;
             barrier();
             if (threadIdx.x == 0) {
@@ -968,7 +978,7 @@ __device__ __forceinline__ void gemm_ws_body(const GArgs& p, const int bid, cons
 
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(const GArgs p) {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[VITAE_WS_STAGES * 32768 + (VITAE_WS_TAIL8 ? 12 * 4096 + 64 : 0)];      // the ONLY LDS object
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[VITAE_WS_TAIL_ALIAS ? VITAE_WS_STAGES * 32768 : VITAE_WS_STAGES * 32768 + (VITAE_WS_TAIL8 ? 12 * 4096 + 64 : 0)];      // the ONLY LDS object
     gemm_ws_body<A_KC, B_KC, VITAE_WS_STAGES>(p, blockIdx.x, blockIdx.z, smem);
 }
 
