@@ -232,13 +232,14 @@ def roofline_block(args, recs, overhead_ms, ms_step, world):
     d_ms, d_fl, d_n, d_raw = fam[dom]
     ach = d_fl / (d_ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS[args.precision]
-    traffic, tnote, rp_us = None, None, None   # PMC counters cannot be read in-process: last committed rocprofv3 --pmc result
-    for name in ('round4_gemm_traffic.json', 'round3_gemm_traffic.json', 'round2_gemm_traffic.json', 'round1_gemm_traffic.json'):
+    traffic, tnote, rp_us, mfma_busy = None, None, None, None   # PMC counters cannot be read in-process: last committed rocprofv3 --pmc result
+    for name in ('round5_gemm_traffic.json', 'round4_gemm_traffic.json', 'round3_gemm_traffic.json', 'round2_gemm_traffic.json', 'round1_gemm_traffic.json'):
         tfile = os.path.join(ROOT, 'profiles', name)
         if args.precision == 'bf16' and args.batch == 4 and os.path.exists(tfile):
             tj = json.load(open(tfile))
             traffic = tj.get('bytes_per_launch', {}).get(dom)
             rp_us = tj.get('rocprof_avg_launch_us', {}).get(dom)    # the committed rocprofv3 mean of the same kernel (graph replays)
+            mfma_busy = tj.get('mfma_busy_frac', {}).get(dom)       # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x duration x 2.4 GHz), same file
             tnote = f'HBM-side bytes per launch of that kernel (2*FETCH_SIZE + WRITE_SIZE, profiles/{name})'
             if traffic is not None:
                 break
@@ -247,6 +248,7 @@ def roofline_block(args, recs, overhead_ms, ms_step, world):
     sec = ms_step * 1e-3
     return {'bound': 'mfma', 'kernel': KNAMES.get(dom, dom), 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
             'frac': round(ach / peak, 4), 'traffic': traffic, 'traffic_unit': tnote,
+            'mfma_busy_frac': mfma_busy, 'mfma_busy_note': 'matrix-pipe busy cycles of that kernel (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES, committed pass) / (1024 SIMDs x its duration x 2.4 GHz)',
             'launches_per_step': d_n / n, 'gflop_per_launch': round(d_fl / d_n / 1e9, 3), 'avg_launch_us': round(d_ms * 1e3 / d_n, 2),
             'avg_launch_us_events_raw': round(d_raw * 1e3 / d_n, 2), 'event_pair_overhead_us': round(overhead_ms * 1e3, 2),
             # the same kernel's mean in the committed rocprofv3 profile and the fraction it gives (graph replays: launches beside an
@@ -260,6 +262,18 @@ def roofline_block(args, recs, overhead_ms, ms_step, world):
             # the masked patches too: 136.3 vs 106.1 GFLOP per volume for the contrastive model)
             'step_frac_of_peak_executed': round(exe_gflop * 1e9 / sec / 1e12 / peak, 4),
             'step_frac_of_peak_reference_formulation': round(ref_gflop * 1e9 / sec / 1e12 / (peak * world), 4)}
+
+
+def _committed_b8_mfma_busy():
+    """MFMA-busy share of the GEMM + attention kernels of a batch-8 step from the committed counter pass (profiles/round5_pmc_sq_b8.json,
+    tools/probes/refresh_profiles_r5.sh): sum of busy cycles / (1024 SIMDs x sum of durations x 2.4 GHz).  None when the file is absent."""
+    f = os.path.join(ROOT, 'profiles', 'round5_pmc_sq_b8.json')
+    if not os.path.exists(f):
+        return None
+    try:
+        return json.load(open(f)).get('gemm_attn_mfma_busy_frac')
+    except Exception:
+        return None
 
 
 def encoder_attn_mlp_point(args, dev, model, eng, contr, batch=8):
@@ -279,6 +293,7 @@ def encoder_attn_mlp_point(args, dev, model, eng, contr, batch=8):
              'gflop_reference_formulation_one_view': round(batch * ENC_ATTN_MLP_GFLOP_PER_VOL, 1), 'views': views,
              'sum_kernel_ms': round(ms, 3), 'achieved': round(fl / (ms * 1e-3) / 1e12, 1), 'peak': peak, 'unit': 'TFLOP/s',
              'frac': round(fl / (ms * 1e-3) / 1e12 / peak, 4), 'target_frac': 0.40,
+             'mfma_busy_frac': _committed_b8_mfma_busy(),
              'event_pair_overhead_us': round(ov * 1e3, 2)})
 
 

@@ -32,8 +32,12 @@ for name, M, N, K in SHAPES:
         lib.vitae_gemm_glds(1, 1, xs[i % NSET].data_ptr(), K, wsets[i % NSET].data_ptr(), K, y.data_ptr(), N, None, 0, M, N, K, None,
                             None, 0, 0, None, 0, 0, s, ws.data_ptr(), None, st)
 
+    def glds16_call(i):      # like for like with the library: bf16 output only (what the step's qkv / fc1 launches write)
+        lib.vitae_gemm_glds(1, 1, xs[i % NSET].data_ptr(), K, wsets[i % NSET].data_ptr(), K, None, N, y16.data_ptr(), N, M, N, K, None,
+                            None, 0, 0, None, 0, 0, s, ws.data_ptr(), None, st)
+
     out = []
-    for f in (lib_call, glds_call):
+    for f in (lib_call, glds_call, glds16_call):
         for i in range(10):
             f(i)
         torch.cuda.synchronize()
@@ -45,4 +49,4 @@ for name, M, N, K in SHAPES:
         torch.cuda.synchronize()
         out.append(a.elapsed_time(b) / REP * 1e3)
     fl = 2.0 * M * N * K
-    print(f'{name:<18}{M:>6}{N:>6}{K:>6} | {out[0]:>10.1f} {fl / out[0] / 1e6:>7.0f} | {out[1]:>8.1f} {fl / out[1] / 1e6:>7.0f} | {out[1] / out[0]:.2f}')
+    print(f'{name:<18}{M:>6}{N:>6}{K:>6} | {out[0]:>10.1f} {fl / out[0] / 1e6:>7.0f} | {out[1]:>8.1f} {fl / out[1] / 1e6:>7.0f} | {out[1] / out[0]:.2f} | bf16 out {out[2]:>8.1f} {out[2] / out[0]:.2f}')

@@ -127,12 +127,12 @@ class HipMAEEngine:
                       and self.hd in (32, 64) and self.hdd in (32, 64))
         self.wgrad_side = os.environ.get('VITAE_WGRAD_SIDE', '1') != '0'
         self.target_fork = os.environ.get('VITAE_TARGET_FORK', 'start')
-        # OPT-IN (measured: no gain — 4.81-4.84 vs 4.82-4.84 ms at batch 4, 15.96 vs 15.94 at batch 32): the saved fc1
-        # pre-activation (read once, by the GELU' of the fc2 input gradient) in bf16: half the bytes of the fc1 epilogue's largest
-        # store and of the fc2 backward's largest epilogue read
-        # saved fc1 pre-activation in bf16 (VITAE_EPI_AUX_BF16): decided per workspace in ``_alloc`` — a gain where the fc1 / fc2-dgrad
-        # GEMMs run on the 64-row tiles (batch 4: 4.50 -> 4.43 ms), neutral at batch 8, a LOSS on the big tiles (batch 32 / patch 8:
-        # +1.3 %; alternating runs, round 4).  VITAE_HPRE_BF16 = 1 / 0 forces it on / off.
+        # What fc1 saves for the fc2 input gradient is bf16 (VITAE_EPI_AUX_BF16) in bf16 mode, at EVERY size (default on since the end of
+        # round 4: batch 4 4.50 -> 4.43 ms, batch 32 10.66 -> 10.58, patch 8 10.90 -> 10.84 once the big-tile epilogue took the aux type
+        # as a template parameter; VITAE_HPRE_BF16=0 keeps fp32).  Two documented bf16-mode deviations ride on it: the backward's GELU'
+        # comes from a bf16 value (since round 5: GELU'(fp32 pre-activation) rounded once, VITAE_EPI_AUX_DERIV), and decoder_pred's
+        # bias gradient is the column sum of the bf16 loss gradient.  The bf16 test bounds (tests/test_gpu_model.py) were recorded
+        # with both in place.
         self._hpre16_env = os.environ.get('VITAE_HPRE_BF16', 'auto')
         self.hpre16 = False
         self._aux16 = 0
@@ -302,18 +302,25 @@ class HipMAEEngine:
             self.hp[:n].copy_(stage[:n], non_blocking=True)
             self._hp_dirty = False
 
+    def _rank_now(self) -> int:
+        """Data-parallel rank of this process: torch.distributed when it is initialised, else an explicit ``noise_rank`` (set by
+        ``enable_data_parallel`` on the native RCCL route, which may run without a torch process group)."""
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                return int(dist.get_rank())
+        except Exception:
+            pass
+        return int(getattr(self, 'noise_rank', 0))
+
     def _noise_seed_now(self) -> int:
-        src = int(torch.initial_seed())
+        """Philox key of the masking noise: re-derived whenever torch's seed OR the rank changes (a process group initialised after
+        the engine was built must still give every rank its own masks); a graph captured earlier keeps the key it was
+        captured with, so ``enable_data_parallel`` drops the captured graphs."""
+        src = (int(torch.initial_seed()), self._rank_now())
         if src != self._seed_src:
-            rank = 0
-            try:
-                import torch.distributed as dist
-                if dist.is_available() and dist.is_initialized():
-                    rank = dist.get_rank()
-            except Exception:
-                rank = 0
             self._seed_src = src
-            self.noise_seed = (src * 0x9E3779B97F4A7C15 + rank * 0xD1B54A32D192ED03 + 0x2545F4914F6CDD1D) & ((1 << 63) - 1)
+            self.noise_seed = (src[0] * 0x9E3779B97F4A7C15 + src[1] * 0xD1B54A32D192ED03 + 0x2545F4914F6CDD1D) & ((1 << 63) - 1)
         return self.noise_seed
 
     def step_prologue(self, noise: torch.Tensor, accumulate: bool):
@@ -525,9 +532,12 @@ class HipMAEEngine:
         a.record()
         return b
 
-    def _x3_ok(self, N, K, *ts) -> bool:
-        """vitae_gemm_wsx3 serves this problem: 4-column groups everywhere, 16-byte aligned arrays."""
-        return self.x3ws and N % 4 == 0 and K % 4 == 0 and all(t is None or t.data_ptr() % 16 == 0 for t in ts)
+    def _x3_ok(self, N, K, *ts, M=None) -> bool:
+        """vitae_gemm_wsx3 serves this problem (every precondition of its launcher mirrored, so that a tiny batch or token count
+        falls through to vitae_gemm_bf16x3 instead of aborting the step): 4-column groups everywhere, at least 8 rows
+        and columns, 16-byte aligned arrays."""
+        return (self.x3ws and N % 4 == 0 and K % 4 == 0 and N >= 8 and K >= 4 and (M is None or M >= 8)
+                and all(t is None or t.data_ptr() % 16 == 0 for t in ts))
 
     def _x3_ws(self, side=False):
         """The wsx3 workspace of the stream the next launch goes to (main chain, predictor branch, wgrad side stream)."""
@@ -546,7 +556,7 @@ class HipMAEEngine:
         return s
 
     def _lin_fwd(self, x, w, bias, y, M, N, K, epi=EPI_NONE, aux=None, res=None):
-        if self._x3_ok(N, K, x, w, y, bias, aux, res):
+        if self._x3_ok(N, K, x, w, y, bias, aux, res, M=M):
             ws = self._x3_ws()
             s = 1 if (epi & 15) == EPI_GELU else self._x3_split(M, N, K, ws)
             t = self._timed(2.0 * M * N * K)
@@ -570,7 +580,7 @@ class HipMAEEngine:
     def _lin_bwd_x(self, dy, w, dx, M, N, K, epi=EPI_NONE, aux=None, accumulate=0, db=None):
         """dx = epi(dy @ W); with ``db`` the bias gradient colsum(dy) rides on the same launch (bf16 mode)
         or is a separate column-sum kernel (fp32 mode)."""
-        if self._x3_ok(K, N, dy, w, dx, aux):
+        if self._x3_ok(K, N, dy, w, dx, aux, M=M) and K >= 8:
             ws = self._x3_ws()
             s = self._x3_split(M, K, N, ws)
             t = self._timed(2.0 * M * N * K)
@@ -614,7 +624,7 @@ class HipMAEEngine:
         else:
             stream = self.stream
         t = self._timed(2.0 * M * N * K)
-        if self._x3_ok(K, M, dy, x, dw, db) and N % 4 == 0:
+        if self._x3_ok(K, M, dy, x, dw, db, M=N) and N % 4 == 0 and K >= 8:
             # dW = dy^T x (reduction over the M token rows: any multiple of 4), the bias gradient colsum(dy) by the same launch
             ws = self._x3_ws(side)       # (split-K tickets: never shared between streams)
             s3 = self._x3_split(N, K, M, ws)

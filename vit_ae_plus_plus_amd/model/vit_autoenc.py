@@ -488,6 +488,9 @@ class MaskedAutoencoderViT(nn.Module):
         if native is None:
             native = os.environ.get('VITAE_DDP_NATIVE', '0') == '1'
         self.disable_data_parallel()        # a previous reducer's communicator / captured graphs go first
+        if self._engine is not None:
+            self._engine._noise_seed_now()  # the rank may have become known since the engine was built: new masking-noise key,
+            self._runners.clear()           # ... and no graph captured with the old one survives
         if native and (ddp.is_distributed() or force):
             eng = self._ensure_engine(torch.device(device) if device is not None else next(self.parameters()).device)
             ddp.broadcast_parameters(eng, 0, group)
