@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITAE_ABI_VERSION 41
+#define VITAE_ABI_VERSION 42
 
 /* matrix-core arithmetic of the dense contractions */
 #define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
@@ -135,6 +135,14 @@ int vitae_gemm_glds(int a_kcontig, int b_kcontig, const void* A16, long lda, con
                     long ldr, int epi, float* aux, long ldaux, int accumulate, int split_k, float* splitk_ws,
                     float* out_colsum_accum, void* stream);
 int vitae_gemm_glds_pick_split_k(int M, int N, int K);
+/* The forward form of vitae_gemm_glds (both operands k-contiguous) with a TWO-PLANE weight operand: B = B16_hi + B16_lo (hi the bf16
+ * shadow, lo from vitae_cast_bf16_lo; same layout and leading dimension): two MFMAs per k-slice on the wave-specialised 64 x 64
+ * workgroup, the weight's rounding enters at ~2^-17 instead of 2^-9 (activations stay bf16).  nn.Linear forward of the layers whose
+ * weight rounding carries the bf16 schedule's loss error (model/vit.py:85-92 of the decoder blocks: tools/bf16_rounding_ablation.py).
+ * Epilogue, split-K workspace and errors as vitae_gemm_glds. */
+int vitae_gemm_glds_w2(const void* A16, long lda, const void* B16_hi, const void* B16_lo, long ldb, float* C, long ldc, void* C16,
+                       long ldc16, int M, int N, int K, const float* bias, const float* residual, long ldr, int epi, float* aux,
+                       long ldaux, int accumulate, int split_k, float* splitk_ws, float* out_colsum_accum, void* stream);
 /* Big-tile kernels (csrc/gemm_bt.hip; 0: 256x256 on 8 waves, 3: 128x128 on 4 waves, in-launch split-K) behind vitae_gemm_glds and
  * vitae_linear_bwd_pair_glds (whose halves then go out as two launches), plus the wave-specialised tiles (4: 128x128, 5: 64x64 —
  * four MFMA waves + four LDS-DMA producer waves per workgroup; with tile 5 both halves of vitae_linear_bwd_pair_glds stay ONE
@@ -180,6 +188,9 @@ int vitae_wgrad_group_bt(int n, const void* const* dy16, const void* const* x16,
 int vitae_linear_bwd_pair_pick_split_k(int M, int Mpad, int N, int K);
 /* dst_bf16[i] = bf16(src[i]) (round to nearest even) */
 int vitae_cast_bf16(const float* src, void* dst_bf16, long n, void* stream);
+/* lo plane of `count` equally spaced fp32 tensors of `len` elements (tensor t starts at src + t * stride):
+ * lo_bf16[t * len + i] = bf16(x - float(bf16(x))) — what the bf16 shadow of a weight drops; together they carry it to ~2^-17 */
+int vitae_cast_bf16_lo(const float* src, void* lo_bf16, long len, long stride, int count, void* stream);
 
 /* nn.Linear forward  y = x W^T + b  (model/vit.py:85-96 fc1/fc2, :107-114 qkv, :109,122 proj;
  * model/vit_autoenc.py:41 decoder_embed, :53 decoder_pred, :263-268 predictor; and the Conv3d patch

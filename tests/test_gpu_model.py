@@ -666,7 +666,9 @@ def _b4_batch(cfg, it):
 # itself): operands of every dense contraction are rounded to 8 mantissa bits, accumulation / master weights / optimiser
 # state stay fp32.  At the first step the prediction is ~0, so the losses are insensitive to the model (observed 4e-6 /
 # 2e-5); after AdamW steps (lr 1e-4, the bench's) the prediction carries the rounding.  Gradient norms: 5e-3 per parameter.
-B4_LOSS_RTOL_STEP0, B4_LOSS_RTOL_LATER, B4_EDGE_RTOL, B4_CONTR_RTOL, B4_GRAD_RTOL = 1e-4, 5e-4, 2e-3, 2e-2, 5e-3
+B4_LOSS_RTOL_STEP0, B4_LOSS_RTOL_LATER, B4_EDGE_RTOL, B4_CONTR_RTOL, B4_GRAD_RTOL = 1e-4, 1e-4, 6e-4, 2e-2, 5e-3
+# Round 5: with the decoder's fc1 on two-plane weights (engine._init_w2; the rounding of THAT weight carried 1.2e-4 of the 1.5e-4) the
+# total loss holds the north star's 1e-4 on every step (observed <= 4.7e-5; raw edge loss <= 1.5e-4, was 4.5e-4-6.6e-4).
 # (observed on MI355X, round 2: total loss 2e-5 at the first step and <= 1.6e-4 later, reconstruction loss <= 4e-6, raw edge loss
 # <= 6.4e-4, contrastive term (magnitude 1e-5) <= 5.7e-3, gradient norms <= 1.2e-3; the fp32 mode: everything <= 7e-7)
 

@@ -996,14 +996,20 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(const GArgs p) {
 #define VITAE_WS64_STAGES 4         // 64 KB (the epilogue aliases the stages): TWO workgroups per CU, three k-tiles in flight each
 #endif
 constexpr int WS64_SMEM = VITAE_WS64_STAGES * 16384;
-template <bool A_KC, bool B_KC, int S, bool RS>
+// W2 (round 5, forward form only): the B operand (a weight matrix) comes as TWO bf16 planes, hi = bf16(W) and lo = bf16(W - hi)
+// (p.B / p.B2, same layout): a stage is [A | B hi | B lo] and every k-slice takes two MFMAs, x16 Wlo^T + x16 Whi^T — the weight
+// enters at ~2^-17 instead of 2^-9 while the activations stay bf16.  Why: tools/bf16_rounding_ablation.py — the bf16 schedule's
+// loss error against the fp32 reference is carried by the rounding of the WEIGHTS in the forward (1.3e-4 of 1.5e-4 on the total;
+// activations 9e-6, the whole backward 4e-6), and the decoder's fc1 alone is 1.2e-4 of it.
+template <bool A_KC, bool B_KC, int S, bool RS, bool W2 = false>
 __device__ __forceinline__ void gemm_ws64_body(const GArgs& p, const int bid, const int zid, unsigned char* smem) {
 #ifndef VITAE_WS64_PRODUCERS
 #define VITAE_WS64_PRODUCERS 4
 #endif
     constexpr int BM = 64, BN = 64, NWC = 4, NWP = VITAE_WS64_PRODUCERS;
-    constexpr int A_T = BM * BK * 2, B_T = BN * BK * 2, STG = A_T + B_T;
-    constexpr int PA = pieces<BM, A_KC, NWP>(), PB = pieces<BN, B_KC, NWP>(), PT = PA + PB;
+    constexpr int A_T = BM * BK * 2, B_T = BN * BK * 2, STG = A_T + (W2 ? 2 : 1) * B_T;
+    constexpr int PA = pieces<BM, A_KC, NWP>(), PB = pieces<BN, B_KC, NWP>(), PT = PA + (W2 ? 2 : 1) * PB;
+    static_assert(!W2 || (A_KC && B_KC && !RS), "two weight planes: the forward form");
     static_assert(S >= 3 && S <= 5 && (S - 2) * PT <= 63, "stage count");
     const int T = p.tiles_m * p.tiles_n;
     const int xq = T >> 3, xr = T & 7, xcd = bid & 7;
@@ -1031,6 +1037,10 @@ __device__ __forceinline__ void gemm_ws64_body(const GArgs& p, const int bid, co
             for (int j = 0; j < PA; ++j) dma_piece<BM, A_KC, NWP>(p.A, p.lda, p.M, m0, k0, dst, pw, lane, j);
 #pragma unroll
             for (int j = 0; j < PB; ++j) dma_piece<BN, B_KC, NWP>(p.B, p.ldb, p.N, n0, k0, dst + A_T, pw, lane, j);
+            if constexpr (W2) {
+#pragma unroll
+                for (int j = 0; j < PB; ++j) dma_piece<BN, B_KC, NWP>(p.B2, p.ldb, p.N, n0, k0, dst + A_T + B_T, pw, lane, j);
+            }
         };
         auto wait_tiles = [&](int fly) {
             if (S >= 5 && fly >= 3) wait_vmcnt<(S >= 5 ? 3 : 1) * PT>();
@@ -1069,16 +1079,21 @@ __device__ __forceinline__ void gemm_ws64_body(const GArgs& p, const int bid, co
     bf16x8 ones;
 #pragma unroll
     for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
-    bf16x8 fa[BK / 16], fb[BK / 16];
-    constexpr int RK = (A_KC ? 1 : 2) + (B_KC ? 1 : 2);
+    bf16x8 fa[BK / 16], fb[BK / 16], fb2[W2 ? BK / 16 : 1];
+    constexpr int RK = (A_KC ? 1 : 2) + (W2 ? 2 : 1) * (B_KC ? 1 : 2);
     auto rd = [&](const unsigned char* TA, auto kk_c) {
         constexpr int kk = decltype(kk_c)::value;
         fa[kk] = frag_asm<BM, A_KC>(TA, wm * 32, kk, lane);
         fb[kk] = frag_asm<BN, B_KC>(TA + A_T, wn * 32, kk, lane);
+        if constexpr (W2) fb2[kk] = frag_asm<BN, B_KC>(TA + A_T + B_T, wn * 32, kk, lane);
     };
     auto mm = [&](auto kk_c) {
         constexpr int kk = decltype(kk_c)::value;
         frag_tie(fa[kk]); frag_tie(fb[kk]);
+        if constexpr (W2) {                                              // the small term first
+            frag_tie(fb2[kk]);
+            acc[kk & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk], fb2[kk], acc[kk & 1], 0, 0, 0);
+        }
         acc[kk & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk], fb[kk], acc[kk & 1], 0, 0, 0);
         if constexpr (RS) {
             if (rowsum) accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk], ones, accx, 0, 0, 0);
@@ -1185,6 +1200,25 @@ template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(64 * (4 + VITAE_WS64_PRODUCERS), 2) void gemm_ws64_kernel(const GArgs p) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[WS64_SMEM];      // the ONLY LDS object
     gemm_ws64_body<A_KC, B_KC, VITAE_WS64_STAGES, false>(p, blockIdx.x, blockIdx.z, smem);
+}
+
+constexpr int WS64W2_STAGES = 3;            // [A | B hi | B lo] = 24 KB per stage: three stages = 72 KB, two workgroups per CU
+__global__ __launch_bounds__(64 * (4 + VITAE_WS64_PRODUCERS), 2) void gemm_ws64_w2_kernel(const GArgs p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[WS64W2_STAGES * 24576];      // the ONLY LDS object
+    gemm_ws64_body<true, true, WS64W2_STAGES, false, true>(p, blockIdx.x, blockIdx.z, smem);
+}
+
+// p: a complete forward-form descriptor (both operands k-contiguous, vec_epi set, p.B2 = the lo plane, p.splits k-ranges)
+int ws64_w2_launch(GArgs p, hipStream_t st) {
+    if (!p.vec_epi || !p.B2 || p.a_rowsum || (p.K % BK) || p.splits < 1) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    p.k_per_split = cdiv(cdiv(p.K, p.splits), BK) * BK;
+    p.splits = cdiv(p.K, p.k_per_split);
+    if (p.K - (p.splits - 1) * p.k_per_split < 2 * BK || p.k_per_split < 2 * BK) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    p.tiles_m = cdiv(p.M, 64); p.tiles_n = cdiv(p.N, 64); p.tile0 = 0;
+    if (p.splits > 1 && (!p.ws || (long)p.tiles_m * p.tiles_n > VITAE_GLDS_TICKETS || p.epi == VITAE_EPI_GELU)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    const dim3 grid(8 * cdiv((long)p.tiles_m * p.tiles_n, 8), 1, p.splits), block(64 * (4 + VITAE_WS64_PRODUCERS));
+    hipLaunchKernelGGL(gemm_ws64_w2_kernel, grid, block, 0, st, p);
+    return vitae_launch_status();
 }
 
 // ---- fp32x3 on the same structure (round 4) ------------------------------------------------------------------------------------

@@ -795,6 +795,35 @@ extern "C" int vitae_gemm_glds(int a_kcontig, int b_kcontig, const void* A16, lo
                             accumulate, split_k, splitk_ws, out_colsum_accum, stream);
 }
 
+extern "C" int vitae_gemm_glds_w2(const void* A16, long lda, const void* B16_hi, const void* B16_lo, long ldb, float* C, long ldc, void* C16,
+                                  long ldc16, int M, int N, int K, const float* bias, const float* residual, long ldr, int epi, float* aux,
+                                  long ldaux, int accumulate, int split_k, float* splitk_ws, float* out_colsum_accum, void* stream) {
+    if (!A16 || !B16_hi || !B16_lo || (!C && !C16) || M <= 0 || N <= 0 || K <= 0) return VITAE_ERR_INVALID_ARG;
+    const int aux16 = (epi & VITAE_EPI_AUX_BF16) != 0, auxd = (epi & VITAE_EPI_AUX_DERIV) != 0;
+    epi &= ~(VITAE_EPI_AUX_BF16 | VITAE_EPI_AUX_DERIV);
+    if (epi != VITAE_EPI_NONE && epi != VITAE_EPI_RELU && !aux) return VITAE_ERR_INVALID_ARG;
+    if (auxd && epi != VITAE_EPI_GELU && epi != VITAE_EPI_DGELU) return VITAE_ERR_INVALID_ARG;
+    if ((K % BK) || K < 2 * BK || (K & 7) || (lda & 7) || (ldb & 7)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    if ((long)M * (ldc > N ? ldc : N) >= (1L << 31) || (long)M * ldaux >= (1L << 31) || (long)M * ldr >= (1L << 31) || (long)M * ldc16 >= (1L << 31))
+        return VITAE_ERR_UNSUPPORTED_SHAPE;
+    if (((uintptr_t)A16 & 15) || ((uintptr_t)B16_hi & 15) || ((uintptr_t)B16_lo & 15)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    if ((long)M * lda >= (1L << 30) || (long)N * ldb >= (1L << 30)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    if (split_k < 1 || epi == VITAE_EPI_GELU) split_k = 1;
+    if (split_k > 1 && !splitk_ws) return VITAE_ERR_INVALID_ARG;
+    GArgs p;
+    p.A = reinterpret_cast<const __bf16*>(A16); p.lda = lda;
+    p.B = reinterpret_cast<const __bf16*>(B16_hi); p.ldb = ldb; p.B2 = reinterpret_cast<const __bf16*>(B16_lo);
+    p.C = C; p.ldc = ldc; p.C16 = reinterpret_cast<__bf16*>(C16); p.ldc16 = ldc16;
+    p.M = M; p.N = N; p.K = K; p.k_per_split = K; p.splits = split_k;
+    p.bias = bias; p.residual = residual; p.ldr = ldr; p.aux = aux; p.ldaux = ldaux;
+    p.epi = epi; p.aux16 = aux16; p.auxd = auxd; p.accumulate = accumulate; p.ws = splitk_ws; p.out_colsum = out_colsum_accum; p.a_rowsum = nullptr;
+    p.dbg = nullptr; p.tiles_m = 0; p.tiles_n = 0;
+    p.xcd_m = xcd_by_rows(M, N);
+    p.vec_epi = vec_epilogue_ok(p);
+    if (!p.vec_epi) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    return ws64_w2_launch(p, (hipStream_t)stream);
+}
+
 // fp32x3 on the wave-specialised 64 x 64 workgroup (csrc/gemm_bt.hip: gemm_wsx3_kernel): the contract of vitae_gemm with fp32
 // operands multiplied as bf16 hi + lo pairs; the producer waves split them while they stage.  K any multiple of 4; in-launch
 // split-K with the workspace layout of vitae_gemm_glds (vitae_gemm_glds_ws_floats(M, N, split_k) floats, first VITAE_GLDS_TICKETS

@@ -30,6 +30,7 @@ struct GArgs {
     int aux16 = 0;               // aux holds bf16 (VITAE_EPI_AUX_BF16): the saved GELU pre-activation at half the bytes
     int exact = 0;               // GELU / GELU' through erff (the fp32-grade modes) instead of the 1.5e-7 polynomial
     int auxd = 0;                // aux holds GELU'(pre-activation) (VITAE_EPI_AUX_DERIV): GELU saves it, GELU' multiplies by it
+    const __bf16* B2 = nullptr;  // second plane of the B operand (lo = bf16(W - bf16(W)), same layout as B): vitae_gemm_glds_w2
     long long* dbg;      // optional (tools/gemm_phase_probe.py): 8 s_memtime stamps per workgroup
     int xcd_m;           // 0: an XCD owns column tiles tn = xcd (mod 8) and walks every row tile (its L2 holds 1/8 of B and all
                          // of A); 1: it owns row tiles tm = xcd (mod 8) instead — picked when A is the larger operand
@@ -117,6 +118,8 @@ int ws64_pair_launch(GArgs p1, GArgs p2, hipStream_t st);
 // gemm_bt.hip: fp32 operands split into bf16 hi + lo by the producer waves of a wave-specialised 64 x 64 workgroup (fp32x3 mode);
 // p.A / p.B point at FLOATS here, p.K any multiple of 4
 int wsx3_launch(GArgs p, int a_kc, int b_kc, hipStream_t st);
+// gemm_bt.hip: forward form with a two-plane (hi + lo) weight operand on the wave-specialised 64 x 64 workgroup
+int ws64_w2_launch(GArgs p, hipStream_t st);
 int wsx3_slots();
 
 }  // namespace vglds
