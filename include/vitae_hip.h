@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITAE_ABI_VERSION 42
+#define VITAE_ABI_VERSION 43
 
 /* matrix-core arithmetic of the dense contractions */
 #define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
@@ -135,6 +135,9 @@ int vitae_gemm_glds(int a_kcontig, int b_kcontig, const void* A16, long lda, con
                     long ldr, int epi, float* aux, long ldaux, int accumulate, int split_k, float* splitk_ws,
                     float* out_colsum_accum, void* stream);
 int vitae_gemm_glds_pick_split_k(int M, int N, int K);
+/* ... for a given operand form (vitae_gemm_glds_pick_split_k plans the forward form; the weight-gradient form may want another split:
+ * pass the split of the SAME form to vitae_gemm_glds, or the launch falls back to the 64-row tiles) */
+int vitae_gemm_glds_pick_split_k_form(int a_kcontig, int b_kcontig, int M, int N, int K);
 /* The forward form of vitae_gemm_glds (both operands k-contiguous) with a TWO-PLANE weight operand: B = B16_hi + B16_lo (hi the bf16
  * shadow, lo from vitae_cast_bf16_lo; same layout and leading dimension): two MFMAs per k-slice on the wave-specialised 64 x 64
  * workgroup, the weight's rounding enters at ~2^-17 instead of 2^-9 (activations stay bf16).  nn.Linear forward of the layers whose

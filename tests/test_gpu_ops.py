@@ -1179,3 +1179,50 @@ def test_gemm_bt_planner_is_consistent(lib, bt_mode):
     assert lib.vitae_gemm_glds_bt_choice(1, 1, 868, 16384, 512) == 3
     with pytest.raises(Exception):
         lib.vitae_gemm_glds_set_bt_tile(1)
+
+
+@pytest.mark.parametrize('B', [4, 8, 32])
+def test_planner_pick_is_within_ten_percent_of_the_best_tile(lib, bt_mode, B):
+    """the cost model of vitae_gemm_glds (csrc/gemm_glds.hip: bt_plan) against every tile family forced in turn, on the
+    27 (shape, operand form) problems of the step at this batch — a cost-model regression fails a test instead of a profile.  Each
+    candidate is timed as a graph of 20 back-to-back launches (best of 3); the pick may be 10 % (15 % on the 16384-deep reductions) + 0.8 us
+    (timer resolution at the 6-13 us launches of batch 4 / 8) behind the best."""
+    Me, Md = B * 2 * 55, B * 217
+    shapes = [('enc qkv', Me, 2304, 768), ('enc proj', Me, 768, 768), ('enc fc1', Me, 3072, 768), ('enc fc2', Me, 768, 3072),
+              ('dec qkv', Md, 1536, 512), ('dec fc1', Md, 2048, 512), ('dec fc2', Md, 512, 2048), ('dec pred', Md, 16384, 512),
+              ('patch embed', B * 2 * 54, 768, 16384)]
+    ws = torch.zeros(1 << 24, device='cuda')
+
+    def timed(akc, bkc, A, Bm, Cc, M, N, K, tile):
+        bt_mode(tile)
+        split = lib.vitae_gemm_glds_pick_split_k_form(akc, bkc, M, N, K)
+        go = lambda: lib.vitae_gemm_glds(akc, bkc, A.data_ptr(), K if akc else M, Bm.data_ptr(), K if bkc else N, Cc.data_ptr(), N, None, 0, M, N, K,
+                                         None, None, 0, 0, None, 0, 0, split, ws.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+        go(); torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(20):
+                go()
+        g.replay(); torch.cuda.synchronize()
+        best = 1e9
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / 20 * 1e3)
+        return best
+
+    bad = []
+    for name, M0, N0, K0 in shapes:
+        for form, (akc, bkc) in (('fwd', (1, 1)), ('dgrad', (1, 0)), ('wgrad', (0, 0))):
+            M, N, K = (M0, N0, K0) if form == 'fwd' else (M0, K0, N0) if form == 'dgrad' else (N0, K0, (M0 + 63) // 64 * 64)
+            A = torch.randn((M, K) if akc else (K, M), device='cuda').bfloat16()
+            Bm = torch.randn((N, K) if bkc else (K, N), device='cuda').bfloat16()
+            Cc = torch.empty(M, N, device='cuda')
+            t = {tile: timed(akc, bkc, A, Bm, Cc, M, N, K, tile) for tile in (5, 4, 3, 0, -2, -1)}
+            best = min(v for k, v in t.items() if k != -1)
+            if t[-1] > (1.15 if K >= 8192 else 1.10) * best + 0.8:      # (16384-deep reductions stream their operand from HBM: both candidates' models are 2x low there)
+                bad.append((name, form, round(t[-1], 1), round(best, 1), {k: round(v, 1) for k, v in t.items()}))
+    bt_mode(-1)
+    assert not bad, bad

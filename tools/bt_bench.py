@@ -41,7 +41,7 @@ def one(form, M, N, K, tile, iters=20, check=True, epi=False):
     C16 = torch.empty(M, N, device=dev, dtype=torch.bfloat16) if epi else None
     lib.vitae_gemm_glds_set_bt_tile(tile)
     got = lib.vitae_gemm_glds_bt_choice(akc, bkc, M, N, K)
-    split = lib.vitae_gemm_glds_pick_split_k(M, N, K)
+    split = lib.vitae_gemm_glds_pick_split_k_form(akc, bkc, M, N, K)
     ws = torch.zeros(1 << 24, device=dev)
     cnt = [0]
 

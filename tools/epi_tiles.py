@@ -32,7 +32,7 @@ def case(name, form, M, N, K, out32=False, out16=False, bias=False, res=False, e
     for t in tiles:
         lib.vitae_gemm_glds_set_bt_tile(t)
         got = lib.vitae_gemm_glds_bt_choice(akc, bkc, M, N, K)
-        split = 1 if (epi & 15) == GELU else lib.vitae_gemm_glds_pick_split_k(M, N, K)
+        split = 1 if (epi & 15) == GELU else lib.vitae_gemm_glds_pick_split_k_form(akc, bkc, M, N, K)
         cnt = [0]
 
         def go():

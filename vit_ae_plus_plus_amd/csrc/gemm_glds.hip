@@ -653,16 +653,25 @@ inline BtPlan bt_plan(int M, int N, int K, int a_kc, int b_kc, bool allow_split,
     static const int ws_min_rows = getenv("VITAE_BT_WS_MIN_ROWS") ? atoi(getenv("VITAE_BT_WS_MIN_ROWS")) : 2048;
     static const int ws_min_rows_fwd = getenv("VITAE_BT_WS_MIN_ROWS_FWD") ? atoi(getenv("VITAE_BT_WS_MIN_ROWS_FWD")) : 800;      // forward launches are never un-paired: batch 16 7.62 -> 7.51 ms, batch 8 neutral
     static const int ws_long_k = getenv("VITAE_BT_WS_LONG_K") ? atoi(getenv("VITAE_BT_WS_LONG_K")) : 8192;   // ... or a very long reduction (decoder_pred's input gradient, the patch embedding: 37.9 vs 41.7 / 33.8 vs 38.6 us at batch 4)
-    static const double ws_kt_w = getenv("VITAE_BT_WS_KT_W") ? atof(getenv("VITAE_BT_WS_KT_W")) : 1050.0;    // both operands row-contiguous (every fragment through two transposing reads)
+    static const double ws_kt_w = getenv("VITAE_BT_WS_KT_W") ? atof(getenv("VITAE_BT_WS_KT_W")) : 900.0;     // both operands row-contiguous (every fragment through two transposing reads; round 5, reads one per MFMA gap: 1280 -> 890 clocks per k-tile)
     static const double ws_fix = getenv("VITAE_BT_WS_FIX") ? atof(getenv("VITAE_BT_WS_FIX")) : 14000.0;
     static const int ws64_on = getenv("VITAE_BT_WS64") ? atoi(getenv("VITAE_BT_WS64")) : 1;
+    // in-launch split-K fix-up of the 128 x 128 tile (partials out through write-through stores, ticket, the last arriver's reads):
+    // refitted in round 5 — 3072 x 768 x 3520 (weight-gradient form) at split 3 takes 36 us = 86 k clocks, the first fit (6000 + 2200 s)
+    // priced it at 58 k and kept the wave-specialised tile (28 us) out; 9000 + 4000 s also keeps 3456 x 768 x 16384 at split 3 (105 us) in front of the ws tile (118)
+    static const double ws64_kt_w = getenv("VITAE_BT_WS64_KT_W") ? atof(getenv("VITAE_BT_WS64_KT_W")) : 650.0;
+    static const int ws_long_any = getenv("VITAE_BT_WS_LONG_ANY") ? atoi(getenv("VITAE_BT_WS_LONG_ANY")) : 1;
+    static const double bt_fix0 = getenv("VITAE_BT_FIX0") ? atof(getenv("VITAE_BT_FIX0")) : 9000.0;
+    static const double bt_fix1 = getenv("VITAE_BT_FIX1") ? atof(getenv("VITAE_BT_FIX1")) : 4000.0;
     for (int id : {0, 3, 4, 5}) {
         if (id == 5 && g_bt_mode != 5 && (!ws64_on || !allow_ws64)) continue;
         if (g_bt_mode >= 0 && id != g_bt_mode) continue;
         if (id == 4 && g_bt_mode < 0 && !ws_on) continue;
         // (the wave-specialised tile needs many token rows: at batch 8 — 880 / 1736 rows — it un-pairs launches the 64-row family
         // serves as well and the step loses 7 %)
-        if (id == 4 && g_bt_mode < 0 && (a_kc ? M : K) < ((a_kc && b_kc) ? ws_min_rows_fwd : ws_min_rows) && !(K >= ws_long_k && (a_kc ? M : K) < 1024)) continue;
+        // (round 5: a very long reduction qualifies at any row count — decoder_pred's input gradient at batch 8, 1736 x 512 x 16384, ran
+        // 76.8 us on 128 x 128 with split 4 against 51.0 here; such launches are never paired anyway)
+        if (id == 4 && g_bt_mode < 0 && (a_kc ? M : K) < ((a_kc && b_kc) ? ws_min_rows_fwd : ws_min_rows) && !(K >= ws_long_k && (ws_long_any || (a_kc ? M : K) < 1024))) continue;
         int bm, bn;
         bt_tile_dims(id, bm, bn);
         // (a FORCED tile — tests, tools — is held to what the kernel itself needs: two k-tiles per split, any M / N)
@@ -680,20 +689,25 @@ inline BtPlan bt_plan(int M, int N, int K, int a_kc, int b_kc, bool allow_split,
             const double nk = (double)nkt / s;
             const double per = id == 0 ? 3000 + 2950 * nk + 14500
                              : id == 4 ? ws_fix + ((!a_kc && !b_kc) ? ws_kt_w : ws_kt) * nk + (s > 1 ? 6000 + 2200 * s : 0)
-                                       : 4500 + 1800 * nk + 7500 + (s > 1 ? 6000 + 2200 * s : 0);
+                                       : 4500 + 1800 * nk + 7500 + (s > 1 ? bt_fix0 + bt_fix1 * s : 0);
             double clk = rounds * per;
             if (id == 5) {
                 // wave-specialised 64 x 64: the latency of one workgroup (two share a CU) or, with many, the CUs' L2 -> LDS feed
                 // (fitted to tools/probes/r4_ws64.py / r4_ws64_split.sh: 440 x 768 x 3072 at splits 1 / 2 / 4 / 6 = 16.0 / 12.5 / 11.5 / 14.4 us)
-                const double over = wgs > 256 ? (wgs - 256) / 256 : 0;
-                const double lat = (6500 + 420 * nk + (s > 1 ? 3000 + 1000 * s : 0)) * (1 + 0.2 * over), thr = wgs * (3000 + 420 * nk) / 256;
+                // (weight-gradient form: every fragment through two transposing reads — 3072 x 768 x 3520 takes 37.9 us = 91 k clocks on 576
+                // workgroups: 650 per k-tile, as on the 64-row tiles)
+                const double over = wgs > 256 ? (wgs - 256) / 256 : 0, kt64 = (!a_kc && !b_kc && wgs > 512) ? ws64_kt_w : 420;     // (... once every CU holds two such workgroups; 768 x 768 x 3520 at split 3, 432 workgroups, stays at 14.6 us)
+                const double lat = (6500 + kt64 * nk + (s > 1 ? 3000 + 1000 * s : 0)) * (1 + 0.2 * over), thr = wgs * (3000 + kt64 * nk) / 256;
                 clk = lat > thr ? lat : thr;
+                // (16384-deep reductions stream an operand from HBM: 868 x 512 x 16384 at split 3 takes 42 us against this model's 21 —
+                // the 128 x 128 tiles, modelled 2x low as well, take 36-38)
+                if (nkt >= 128) clk *= 1.25;
             }
             if (clk < best.clocks) best = BtPlan{id, s, clk};
         }
     }
     if (best.tile < 0 || g_bt_mode >= 0) return best;
-    if (best.clocks >= 0.92 * est_64row(M, N, K, allow_split, !a_kc && !b_kc)) return BtPlan{-1, 1, 0.0};
+    if (best.clocks >= 0.92 * est_64row(M, N, K, allow_split, !a_kc && !b_kc) * (nkt >= 128 ? 1.25 : 1.0)) return BtPlan{-1, 1, 0.0};     // (the same HBM-stream factor as above)
     return best;
 }
 
@@ -717,6 +731,13 @@ extern "C" int vitae_gemm_glds_bt_choice(int a_kcontig, int b_kcontig, int M, in
 extern "C" int vitae_gemm_glds_pick_split_k(int M, int N, int K) {
     // (the forward / dgrad / wgrad forms share one plan: the model does not depend on the operand storage)
     const BtPlan bp = bt_plan(M, N, K, 1, 1, true);
+    if (bp.tile >= 0) return bp.split;
+    return old_split_rule(M, N, K);
+}
+
+// the same for a given operand form (the plan depends on it: transposing fragment reads cost the weight-gradient form more per k-tile)
+extern "C" int vitae_gemm_glds_pick_split_k_form(int a_kcontig, int b_kcontig, int M, int N, int K) {
+    const BtPlan bp = bt_plan(M, N, K, a_kcontig, b_kcontig, true);
     if (bp.tile >= 0) return bp.split;
     return old_split_rule(M, N, K);
 }
