@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITAE_ABI_VERSION 43
+#define VITAE_ABI_VERSION 44
 
 /* matrix-core arithmetic of the dense contractions */
 #define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
@@ -138,14 +138,17 @@ int vitae_gemm_glds_pick_split_k(int M, int N, int K);
 /* ... for a given operand form (vitae_gemm_glds_pick_split_k plans the forward form; the weight-gradient form may want another split:
  * pass the split of the SAME form to vitae_gemm_glds, or the launch falls back to the 64-row tiles) */
 int vitae_gemm_glds_pick_split_k_form(int a_kcontig, int b_kcontig, int M, int N, int K);
-/* The forward form of vitae_gemm_glds (both operands k-contiguous) with a TWO-PLANE weight operand: B = B16_hi + B16_lo (hi the bf16
- * shadow, lo from vitae_cast_bf16_lo; same layout and leading dimension): two MFMAs per k-slice on the wave-specialised 64 x 64
- * workgroup, the weight's rounding enters at ~2^-17 instead of 2^-9 (activations stay bf16).  nn.Linear forward of the layers whose
- * weight rounding carries the bf16 schedule's loss error (model/vit.py:85-92 of the decoder blocks: tools/bf16_rounding_ablation.py).
- * Epilogue, split-K workspace and errors as vitae_gemm_glds. */
-int vitae_gemm_glds_w2(const void* A16, long lda, const void* B16_hi, const void* B16_lo, long ldb, float* C, long ldc, void* C16,
+/* The forward form of vitae_gemm_glds (both operands k-contiguous) with a TWO-PLANE weight operand: y = x16 (W_hi + W_lo)^T, the
+ * planes side by side in B16_hilo[N][2 K] (vitae_cast_bf16_hilo).  The weight's rounding enters at ~2^-17 instead of 2^-9, the
+ * activations stay bf16: nn.Linear forward of the layers whose weight rounding carries the bf16 schedule's loss error
+ * (model/vit.py:85-92 of the decoder blocks: tools/bf16_rounding_ablation.py).  Few rows: the wave-specialised 64 x 64 workgroup
+ * stages both planes per k-tile and issues two MFMAs per k-slice; many rows: any big tile runs the reduction over 2 K with the A
+ * operand wrapping.  Epilogue, split-K workspace (sized for (M, N, split_k)) and errors as vitae_gemm_glds; split_k from
+ * vitae_gemm_glds_w2_pick_split_k. */
+int vitae_gemm_glds_w2(const void* A16, long lda, const void* B16_hilo, float* C, long ldc, void* C16,
                        long ldc16, int M, int N, int K, const float* bias, const float* residual, long ldr, int epi, float* aux,
                        long ldaux, int accumulate, int split_k, float* splitk_ws, float* out_colsum_accum, void* stream);
+int vitae_gemm_glds_w2_pick_split_k(int M, int N, int K);
 /* Big-tile kernels (csrc/gemm_bt.hip; 0: 256x256 on 8 waves, 3: 128x128 on 4 waves, in-launch split-K) behind vitae_gemm_glds and
  * vitae_linear_bwd_pair_glds (whose halves then go out as two launches), plus the wave-specialised tiles (4: 128x128, 5: 64x64 —
  * four MFMA waves + four LDS-DMA producer waves per workgroup; with tile 5 both halves of vitae_linear_bwd_pair_glds stay ONE
@@ -191,9 +194,10 @@ int vitae_wgrad_group_bt(int n, const void* const* dy16, const void* const* x16,
 int vitae_linear_bwd_pair_pick_split_k(int M, int Mpad, int N, int K);
 /* dst_bf16[i] = bf16(src[i]) (round to nearest even) */
 int vitae_cast_bf16(const float* src, void* dst_bf16, long n, void* stream);
-/* lo plane of `count` equally spaced fp32 tensors of `len` elements (tensor t starts at src + t * stride):
- * lo_bf16[t * len + i] = bf16(x - float(bf16(x))) — what the bf16 shadow of a weight drops; together they carry it to ~2^-17 */
-int vitae_cast_bf16_lo(const float* src, void* lo_bf16, long len, long stride, int count, void* stream);
+/* hi | lo planes of `count` equally spaced fp32 [rows, K] tensors (tensor t starts at src + t * stride), side by side in
+ * out_bf16[count][rows][2 K]: columns [0, K) = bf16(x) (the shadow), [K, 2K) = bf16(x - float(bf16(x))) — what the shadow drops;
+ * together they carry a weight to ~2^-17.  The B operand of vitae_gemm_glds_w2. */
+int vitae_cast_bf16_hilo(const float* src, void* out_bf16, long rows, int K, long stride, int count, void* stream);
 
 /* nn.Linear forward  y = x W^T + b  (model/vit.py:85-96 fc1/fc2, :107-114 qkv, :109,122 proj;
  * model/vit_autoenc.py:41 decoder_embed, :53 decoder_pred, :263-268 predictor; and the Conv3d patch

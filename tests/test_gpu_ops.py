@@ -939,42 +939,44 @@ def test_gemm_bf16_saved_preactivation(lib, C, M, N, K):
     assert rel_err(dh16b[:M].float(), (dy @ w2) * pg.grad) < 2e-2
 
 
-@pytest.mark.parametrize('M,N,K', [(868, 2048, 512), (440, 3072, 768), (70, 520, 128), (1736, 2048, 512)])
+@pytest.mark.parametrize('M,N,K', [(868, 2048, 512), (440, 3072, 768), (70, 520, 128), (1736, 2048, 512), (6944, 2048, 512), (3520, 3072, 768)])
 def test_gemm_two_plane_weight(lib, C, M, N, K):
-    """vitae_gemm_glds_w2 + vitae_cast_bf16_lo: y = x16 (W_hi + W_lo)^T carries the fp32 weight to ~2^-17 (the one-plane launch: 2^-9);
-    GELU epilogue with the saved derivative and a residual form; split-K."""
+    """vitae_gemm_glds_w2 + vitae_cast_bf16_hilo: y = x16 (W_hi + W_lo)^T carries the fp32 weight to ~2^-17 (the one-plane launch: 2^-9) —
+    few rows on the two-plane 64 x 64 workgroup, many rows on a big tile over 2 K with the activations wrapping; GELU epilogue with the
+    saved derivative, residual form, split-K."""
     x = _bf(gen(M, K, seed=1)).float()
-    w = gen(3, N, K, seed=2, scale=K ** -0.5)                       # three equally spaced tensors: the strided lo-plane cast
+    w = gen(3, N, K, seed=2, scale=K ** -0.5)                       # three equally spaced tensors: the strided cast
     bias, res = gen(N, seed=3), gen(M, N, seed=4)
     wd = dev(w)
     x16 = _bf(x).cuda()
     hi = wd.to(torch.bfloat16)
-    lo = torch.full((3, N * K), float('nan'), dtype=torch.bfloat16, device='cuda')
-    lib.vitae_cast_bf16_lo(wd.data_ptr(), lo.data_ptr(), N * K, N * K, 3, st())
-    assert torch.equal(lo.view(3, N, K), (wd - hi.float()).to(torch.bfloat16))
+    hilo = torch.full((3, N, 2 * K), float('nan'), dtype=torch.bfloat16, device='cuda')
+    lib.vitae_cast_bf16_hilo(wd.data_ptr(), hilo.data_ptr(), N, K, N * K, 3, st())
+    assert torch.equal(hilo[:, :, :K], hi) and torch.equal(hilo[:, :, K:], (wd - hi.float()).to(torch.bfloat16))
     t = 1
     ref = x.double() @ w[t].double().t()
     nan = lambda: torch.full((M, N), float('nan'), device='cuda')
     y1 = nan()
     lib.vitae_gemm_glds(1, 1, x16.data_ptr(), K, hi[t].data_ptr(), K, y1.data_ptr(), N, None, 0, M, N, K, None, None, 0, 0, None, 0, 0, 1, None, None, st())
+    ws = torch.zeros(max(1, lib.vitae_gemm_glds_ws_floats(M, N, 8)), device='cuda')
+    sp = lib.vitae_gemm_glds_w2_pick_split_k(M, N, K)
     y2 = nan()
-    lib.vitae_gemm_glds_w2(x16.data_ptr(), K, hi[t].data_ptr(), lo[t].data_ptr(), K, y2.data_ptr(), N, None, 0, M, N, K, None, None, 0, 0, None, 0, 0, 1,
-                           None, None, st())
+    lib.vitae_gemm_glds_w2(x16.data_ptr(), K, hilo[t].data_ptr(), y2.data_ptr(), N, None, 0, M, N, K, None, None, 0, 0, None, 0, 0, sp,
+                           ws.data_ptr(), None, st())
     e1, e2 = rel_err(y1, ref), rel_err(y2, ref)
     assert e2 < 3e-5 and e2 < e1 / 20, (e1, e2)                      # observed ~2e-3 against ~1e-5
     # GELU + saved derivative (bf16), bf16-only result — the decoder fc1 launch of the bf16 step
     DV = C['VITAE_EPI_GELU'] | C['VITAE_EPI_AUX_BF16'] | C['VITAE_EPI_AUX_DERIV']
     y16, der16 = torch.zeros(M, N, dtype=torch.bfloat16, device='cuda'), torch.zeros(M, N, dtype=torch.bfloat16, device='cuda')
-    lib.vitae_gemm_glds_w2(x16.data_ptr(), K, hi[t].data_ptr(), lo[t].data_ptr(), K, None, 0, y16.data_ptr(), N, M, N, K, dev(bias).data_ptr(), None, 0,
+    lib.vitae_gemm_glds_w2(x16.data_ptr(), K, hilo[t].data_ptr(), None, 0, y16.data_ptr(), N, M, N, K, dev(bias).data_ptr(), None, 0,
                            DV, der16.data_ptr(), N, 0, 1, None, None, st())
     pre = (ref + bias.double()).float().requires_grad_(True)
     F.gelu(pre).sum().backward()
     assert rel_err(y16.float(), F.gelu(pre.detach())) < 1e-2 and rel_err(der16.float(), pre.grad) < 1e-2
-    # bias + residual, in-launch split-K
+    # bias + residual on the two-plane workgroup with an in-launch split-K (any split other than the plan's goes there)
     if K >= 256:
-        ws = torch.zeros(lib.vitae_gemm_glds_ws_floats(M, N, 2), device='cuda')
         y3 = nan()
-        lib.vitae_gemm_glds_w2(x16.data_ptr(), K, hi[t].data_ptr(), lo[t].data_ptr(), K, y3.data_ptr(), N, None, 0, M, N, K, dev(bias).data_ptr(),
+        lib.vitae_gemm_glds_w2(x16.data_ptr(), K, hilo[t].data_ptr(), y3.data_ptr(), N, None, 0, M, N, K, dev(bias).data_ptr(),
                                dev(res).data_ptr(), N, 0, None, 0, 0, 2, ws.data_ptr(), None, st())
         assert rel_err(y3, ref + bias.double() + res.double()) < 3e-5
         assert int(ws[:C['VITAE_GLDS_TICKETS']].abs().sum()) == 0

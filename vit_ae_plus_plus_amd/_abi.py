@@ -90,7 +90,7 @@ class _Lib:
     def __getattr__(self, name):
         dll = self.load()
         fn = getattr(dll, name)
-        if PROTOS[name][0] != 'int' or name in _VALUE_RETURNING or (name.endswith('pick_split_k') or name.endswith('pick_split_k_form')):
+        if PROTOS[name][0] != 'int' or name in _VALUE_RETURNING or ('pick_split_k' in name):
             return fn
 
         def checked(*args):

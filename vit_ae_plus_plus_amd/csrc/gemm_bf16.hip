@@ -514,25 +514,27 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
 }  // namespace
 
 namespace {
-// lo plane of `count` equally spaced tensors: lo[t][i] = bf16(x - float(bf16(x))), x = src[t * stride + i]
-__global__ __launch_bounds__(256) void cast_bf16_lo_kernel(const float* __restrict__ src, __bf16* __restrict__ lo, long len, long stride, int count) {
-    const long n4 = len / 4, tot = n4 * count;
+// hi | lo planes of `count` equally spaced [rows, K] tensors, side by side: out[t][r][0:K] = bf16(x), out[t][r][K:2K] = bf16(x - float(bf16(x)))
+__global__ __launch_bounds__(256) void cast_bf16_hilo_kernel(const float* __restrict__ src, __bf16* __restrict__ out, long rows, int K, long stride, int count) {
+    const long k4 = K / 4, per = rows * k4, tot = per * count;
     for (long j = (long)blockIdx.x * 256 + threadIdx.x; j < tot; j += (long)gridDim.x * 256) {
-        const long t = j / n4, i = j % n4;
+        const long t = j / per, i = j % per, r = i / k4, c = i % k4;
         const f32x4 v = reinterpret_cast<const f32x4*>(src + t * stride)[i];
-        bf16x4 o;
+        bf16x4 h, l;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (__bf16)(v[e] - (float)(__bf16)v[e]);
-        reinterpret_cast<bf16x4*>(lo + t * len)[i] = o;
+        for (int e = 0; e < 4; ++e) { h[e] = (__bf16)v[e]; l[e] = (__bf16)(v[e] - (float)h[e]); }
+        __bf16* row = out + (t * rows + r) * (2L * K);
+        reinterpret_cast<bf16x4*>(row)[c] = h;
+        reinterpret_cast<bf16x4*>(row + K)[c] = l;
     }
 }
 }  // namespace
 
-extern "C" int vitae_cast_bf16_lo(const float* src, void* lo_bf16, long len, long stride, int count, void* stream) {
-    if (!src || !lo_bf16 || len <= 0 || count <= 0 || (len & 3) || (stride & 3) || ((uintptr_t)src & 15) || ((uintptr_t)lo_bf16 & 7)) return VITAE_ERR_INVALID_ARG;
-    long blocks = (len / 4 * count + 255) / 256;
+extern "C" int vitae_cast_bf16_hilo(const float* src, void* out_bf16, long rows, int K, long stride, int count, void* stream) {
+    if (!src || !out_bf16 || rows <= 0 || K <= 0 || count <= 0 || (K & 3) || (stride & 3) || ((uintptr_t)src & 15) || ((uintptr_t)out_bf16 & 7)) return VITAE_ERR_INVALID_ARG;
+    long blocks = (rows * (K / 4) * count + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(cast_bf16_lo_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, src, reinterpret_cast<__bf16*>(lo_bf16), len, stride, count);
+    hipLaunchKernelGGL(cast_bf16_hilo_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, src, reinterpret_cast<__bf16*>(out_bf16), rows, K, stride, count);
     return vitae_launch_status();
 }
 

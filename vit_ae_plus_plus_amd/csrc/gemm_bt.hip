@@ -27,6 +27,11 @@
 
 namespace vglds {
 
+// Two-plane weights on every tile (round 5): B = [W hi | W lo] side by side ([N, 2 Ka]) and the reduction runs over 2 Ka with the A
+// operand (k-contiguous, Ka wide) WRAPPING — k-tile t of the second half re-reads the activations of k-tile t - Ka / 64:
+// y = x16 Whi^T + x16 Wlo^T out of one unmodified k-loop.  p.a_kwrap = Ka (a multiple of 64; 0 = no wrap).
+__device__ __forceinline__ int a_wrap(const GArgs& p, int k0) { return (p.a_kwrap && k0 >= p.a_kwrap) ? k0 - p.a_kwrap : k0; }
+
 template <int BM, int BN, int WM, int WN> struct BtCfg {
     static constexpr int NW = WM * WN, NT = 64 * NW;
     static constexpr int HM = BM / 2, HN = BN / 2;                          // rows of a half-tile
@@ -474,7 +479,7 @@ __device__ __forceinline__ void gemm_bt_body(const GArgs& p, const int bid, cons
         constexpr int OFF = POS == 0 ? 0 : POS == 3 ? A_HALF : POS == 1 ? 2 * A_HALF : 2 * A_HALF + B_HALF;
         unsigned char* dst = smem + buf * BUF + OFF;
         const int k0 = kbeg + tile * BK;
-        if constexpr (POS == 0 || POS == 3) dma_piece<HM, A_KC, NW>(p.A, p.lda, p.M, m0 + (POS == 3 ? HM : 0), k0, dst, wave, lane, j);
+        if constexpr (POS == 0 || POS == 3) dma_piece<HM, A_KC, NW>(p.A, p.lda, p.M, m0 + (POS == 3 ? HM : 0), a_wrap(p, k0), dst, wave, lane, j);
         else dma_piece<HN, B_KC, NW>(p.B, p.ldb, p.N, n0 + (POS == 2 ? HN : 0), k0, dst, wave, lane, j);
     };
     auto issue = [&](auto pos_c, int tile, int buf) {
@@ -712,7 +717,7 @@ __device__ __forceinline__ void gemm_ws_body(const GArgs& p, const int bid, cons
             unsigned char* dst = smem + stage * STG;
             const int k0 = kbeg + t * BK;
 #pragma unroll
-            for (int j = 0; j < ((VITAE_WS_ABLATE & 32) ? 1 : PA); ++j) dma_piece<BM, A_KC, NWP>(p.A, p.lda, p.M, m0, k0, dst, pw, lane, j);
+            for (int j = 0; j < ((VITAE_WS_ABLATE & 32) ? 1 : PA); ++j) dma_piece<BM, A_KC, NWP>(p.A, p.lda, p.M, m0, a_wrap(p, k0), dst, pw, lane, j);
 #pragma unroll
             for (int j = 0; j < ((VITAE_WS_ABLATE & 2) ? 0 : PB); ++j) dma_piece<BN, B_KC, NWP>(p.B, p.ldb, p.N, n0, k0, dst + A_T, pw, lane, j);
         };

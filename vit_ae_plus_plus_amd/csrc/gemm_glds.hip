@@ -816,24 +816,38 @@ extern "C" int vitae_gemm_glds(int a_kcontig, int b_kcontig, const void* A16, lo
                             accumulate, split_k, splitk_ws, out_colsum_accum, stream);
 }
 
-extern "C" int vitae_gemm_glds_w2(const void* A16, long lda, const void* B16_hi, const void* B16_lo, long ldb, float* C, long ldc, void* C16,
+// plan of the two-plane launch: the big tiles see an ordinary forward problem with a reduction of 2 K; tile 5 / no big tile: the
+// two-plane workgroup of gemm_bt.hip (ws64_w2_launch) on the K-deep reduction
+static BtPlan w2_plan(int M, int N, int K, bool allow_split) {
+    BtPlan bp = bt_plan(M, N, 2 * K, 1, 1, allow_split);
+    if (bp.tile == 5 || bp.tile < 0) {
+        bp.tile = 5;
+        const BtPlan b1 = bt_plan(M, N, K, 1, 1, allow_split);
+        bp.split = (b1.tile == 5) ? b1.split : 1;
+    }
+    return bp;
+}
+
+extern "C" int vitae_gemm_glds_w2_pick_split_k(int M, int N, int K) { return w2_plan(M, N, K, true).split; }
+
+extern "C" int vitae_gemm_glds_w2(const void* A16, long lda, const void* B16_hilo, float* C, long ldc, void* C16,
                                   long ldc16, int M, int N, int K, const float* bias, const float* residual, long ldr, int epi, float* aux,
                                   long ldaux, int accumulate, int split_k, float* splitk_ws, float* out_colsum_accum, void* stream) {
-    if (!A16 || !B16_hi || !B16_lo || (!C && !C16) || M <= 0 || N <= 0 || K <= 0) return VITAE_ERR_INVALID_ARG;
+    if (!A16 || !B16_hilo || (!C && !C16) || M <= 0 || N <= 0 || K <= 0) return VITAE_ERR_INVALID_ARG;
     const int aux16 = (epi & VITAE_EPI_AUX_BF16) != 0, auxd = (epi & VITAE_EPI_AUX_DERIV) != 0;
     epi &= ~(VITAE_EPI_AUX_BF16 | VITAE_EPI_AUX_DERIV);
     if (epi != VITAE_EPI_NONE && epi != VITAE_EPI_RELU && !aux) return VITAE_ERR_INVALID_ARG;
     if (auxd && epi != VITAE_EPI_GELU && epi != VITAE_EPI_DGELU) return VITAE_ERR_INVALID_ARG;
-    if ((K % BK) || K < 2 * BK || (K & 7) || (lda & 7) || (ldb & 7)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    if ((K % BK) || K < 2 * BK || (lda & 7)) return VITAE_ERR_UNSUPPORTED_SHAPE;
     if ((long)M * (ldc > N ? ldc : N) >= (1L << 31) || (long)M * ldaux >= (1L << 31) || (long)M * ldr >= (1L << 31) || (long)M * ldc16 >= (1L << 31))
         return VITAE_ERR_UNSUPPORTED_SHAPE;
-    if (((uintptr_t)A16 & 15) || ((uintptr_t)B16_hi & 15) || ((uintptr_t)B16_lo & 15)) return VITAE_ERR_UNSUPPORTED_SHAPE;
-    if ((long)M * lda >= (1L << 30) || (long)N * ldb >= (1L << 30)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    if (((uintptr_t)A16 & 15) || ((uintptr_t)B16_hilo & 15)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    if ((long)M * lda >= (1L << 30) || (long)N * 2 * K >= (1L << 30)) return VITAE_ERR_UNSUPPORTED_SHAPE;
     if (split_k < 1 || epi == VITAE_EPI_GELU) split_k = 1;
     if (split_k > 1 && !splitk_ws) return VITAE_ERR_INVALID_ARG;
     GArgs p;
     p.A = reinterpret_cast<const __bf16*>(A16); p.lda = lda;
-    p.B = reinterpret_cast<const __bf16*>(B16_hi); p.ldb = ldb; p.B2 = reinterpret_cast<const __bf16*>(B16_lo);
+    p.B = reinterpret_cast<const __bf16*>(B16_hilo); p.ldb = 2L * K;
     p.C = C; p.ldc = ldc; p.C16 = reinterpret_cast<__bf16*>(C16); p.ldc16 = ldc16;
     p.M = M; p.N = N; p.K = K; p.k_per_split = K; p.splits = split_k;
     p.bias = bias; p.residual = residual; p.ldr = ldr; p.aux = aux; p.ldaux = ldaux;
@@ -842,6 +856,13 @@ extern "C" int vitae_gemm_glds_w2(const void* A16, long lda, const void* B16_hi,
     p.xcd_m = xcd_by_rows(M, N);
     p.vec_epi = vec_epilogue_ok(p);
     if (!p.vec_epi) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    const BtPlan bp = w2_plan(M, N, K, epi != VITAE_EPI_GELU);
+    if (bp.tile != 5 && bp.split == split_k) {
+        // a big tile on the reduction of 2 K: [W hi | W lo] is one k-contiguous operand, the activations wrap
+        p.K = 2 * K; p.a_kwrap = K;
+        return bt_launch(p, 1, 1, bp.tile, (hipStream_t)stream);
+    }
+    p.B2 = p.B + K;                    // the lo plane: same rows, K columns further
     return ws64_w2_launch(p, (hipStream_t)stream);
 }
 

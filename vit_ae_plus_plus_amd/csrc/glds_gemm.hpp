@@ -31,6 +31,7 @@ struct GArgs {
     int exact = 0;               // GELU / GELU' through erff (the fp32-grade modes) instead of the 1.5e-7 polynomial
     int auxd = 0;                // aux holds GELU'(pre-activation) (VITAE_EPI_AUX_DERIV): GELU saves it, GELU' multiplies by it
     const __bf16* B2 = nullptr;  // second plane of the B operand (lo = bf16(W - bf16(W)), same layout as B): vitae_gemm_glds_w2
+    int a_kwrap = 0;             // > 0: the A operand is a_kwrap wide and k wraps (gemm_bt.hip: a_wrap) — two-plane weights side by side in B
     long long* dbg;      // optional (tools/gemm_phase_probe.py): 8 s_memtime stamps per workgroup
     int xcd_m;           // 0: an XCD owns column tiles tn = xcd (mod 8) and walks every row tile (its L2 holds 1/8 of B and all
                          // of A); 1: it owns row tiles tm = xcd (mod 8) instead — picked when A is the larger operand

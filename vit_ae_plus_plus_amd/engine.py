@@ -283,8 +283,8 @@ class HipMAEEngine:
         tools/bf16_rounding_ablation.py (CPU emulation of this schedule on the oracle, pinned B = 4 trajectory of
         tests/golden/vitb_b4.npz) — the loss error of the bf16 schedule is the rounding of the WEIGHTS in the forward (total 1.3e-4 of
         1.5e-4; activations 9e-6, the whole backward 4e-6), the decoder's fc1 alone +1.2e-4 (raw edge +4.9e-4); with its weight at
-        2^-17 the emulation lands at 6e-5 / 2.2e-4.  The lo planes (8 x 1 M bf16) are rewritten behind the AdamW launch that
-        covers them.  VITAE_W2='' switches it off, VITAE_W2='dec.fc1,dec.fc2' names more classes of the decoder blocks."""
+        2^-17 the emulation lands at 6e-5 / 2.2e-4.  The planes ([W hi | W lo] side by side, 8 x 2 M bf16) are rewritten behind the AdamW
+        launch that covers them.  VITAE_W2='' switches it off, VITAE_W2='dec.fc1,dec.fc2' names more classes of the decoder blocks."""
         self._w2 = {}          # weight name -> (lo-plane tensor view)
         self._w2_groups = []   # (first arena offset, tensor length, stride, count, lo tensor [count, len])
         cls = [c for c in os.environ.get('VITAE_W2', 'dec.fc1').split(',') if c]
@@ -302,21 +302,22 @@ class HipMAEEngine:
             kdim = int(self.layout[names[0]][1][1])
             if any(offs[i + 1] - offs[i] != stride for i in range(depth - 1)) or ln % 4 or stride % 4 or kdim % 64 or kdim < 128:
                 continue       # (not equally spaced in this arena, or a reduction of fewer than two k-tiles: the class keeps its one-plane forward)
-            lo = torch.zeros(depth, ln, dtype=torch.bfloat16, device=self.device)
-            self._w2_groups.append((offs[0], ln, stride, depth, lo))
+            rows = int(self.layout[names[0]][1][0])
+            hilo = torch.zeros(depth, rows, 2 * kdim, dtype=torch.bfloat16, device=self.device)     # [W hi | W lo] side by side
+            self._w2_groups.append((offs[0], ln, stride, depth, hilo, rows, kdim))
             for i, n in enumerate(names):
-                self._w2[n] = lo[i]
+                self._w2[n] = hilo[i]
 
     def refresh_w2(self, stream=None, lo=0, hi=None):
         """Rewrite the lo planes of the two-plane weights that lie inside arena range [lo, hi) (default: all of them)."""
         hi = self.n_total if hi is None else hi
         st = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
-        for off0, ln, stride, count, t in self._w2_groups:
+        for off0, ln, stride, count, t, rows, kdim in self._w2_groups:
             inside = [i for i in range(count) if off0 + i * stride >= lo and off0 + i * stride + ln <= hi]
             if not inside:
                 continue
             i0, n = inside[0], len(inside)          # (a bucket covers a contiguous run of blocks)
-            lib.vitae_cast_bf16_lo(self.params.data_ptr() + 4 * (off0 + i0 * stride), t[i0].data_ptr(), ln, stride, n, st)
+            lib.vitae_cast_bf16_hilo(self.params.data_ptr() + 4 * (off0 + i0 * stride), t[i0].data_ptr(), rows, kdim, stride, n, st)
 
     def refresh_shadow(self, force: bool = False):
         if self.params16 is None:
@@ -784,10 +785,17 @@ class HipMAEEngine:
             self._split_cache[key] = s
         w2 = self._w2.get(name) if name is not None else None
         if w2 is not None:
-            # two-plane weight (hi = the shadow, lo = what it dropped): wave-specialised 64 x 64 workgroups, two MFMAs per k-slice
+            # two-plane weight ([W hi | W lo] side by side): the two-plane 64 x 64 workgroup, or a big tile over 2 K with x16 wrapping
+            key2 = ('w2', M, N, K, self.ws16.numel())
+            s2 = self._split_cache.get(key2)
+            if s2 is None:
+                s2 = 1 if (epi & 15) == EPI_GELU else lib.vitae_gemm_glds_w2_pick_split_k(M, N, K)
+                while s2 > 1 and lib.vitae_gemm_glds_ws_floats(M, N, s2) > self.ws16.numel():
+                    s2 -= 1
+                self._split_cache[key2] = s2
             t = self._timed(2.0 * M * N * K, 'ws64')     # (algorithmic FLOPs: the second plane's MFMAs are not counted as work)
-            lib.vitae_gemm_glds_w2(_ptr(x16), K, self._w16(w), _ptr(w2), K, _ptr(y), N, _ptr(y16), N, M, N, K, _ptr(bias), _ptr(res), N,
-                                   epi, _ptr(aux), N, 0, 1, self.ws16.data_ptr(), None, self.stream)
+            lib.vitae_gemm_glds_w2(_ptr(x16), K, _ptr(w2), _ptr(y), N, _ptr(y16), N, M, N, K, _ptr(bias), _ptr(res), N,
+                                   epi, _ptr(aux), N, 0, s2, self.ws16.data_ptr(), None, self.stream)
             if t is not None:
                 t.record()
             return
