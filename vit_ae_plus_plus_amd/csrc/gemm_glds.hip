@@ -696,7 +696,7 @@ inline BtPlan bt_plan(int M, int N, int K, int a_kc, int b_kc, bool allow_split,
                 // (fitted to tools/probes/r4_ws64.py / r4_ws64_split.sh: 440 x 768 x 3072 at splits 1 / 2 / 4 / 6 = 16.0 / 12.5 / 11.5 / 14.4 us)
                 // (weight-gradient form: every fragment through two transposing reads — 3072 x 768 x 3520 takes 37.9 us = 91 k clocks on 576
                 // workgroups: 650 per k-tile, as on the 64-row tiles)
-                const double over = wgs > 256 ? (wgs - 256) / 256 : 0, kt64 = (!a_kc && !b_kc && wgs > 512) ? ws64_kt_w : 420;     // (... once every CU holds two such workgroups; 768 x 768 x 3520 at split 3, 432 workgroups, stays at 14.6 us)
+                const double over = wgs > 256 ? (wgs - 256) / 256 : 0, kt64 = (!a_kc && !b_kc && wgs >= 512) ? ws64_kt_w : 420;     // (... once every CU holds two such workgroups — 2048 x 512 x 6976 at split 2, exactly 512, takes 32.4 us = 650 per k-tile; 768 x 768 x 3520 at split 3, 432 workgroups, stays at 14.6 us)
                 const double lat = (6500 + kt64 * nk + (s > 1 ? 3000 + 1000 * s : 0)) * (1 + 0.2 * over), thr = wgs * (3000 + kt64 * nk) / 256;
                 clk = lat > thr ? lat : thr;
                 // (16384-deep reductions stream an operand from HBM: 868 x 512 x 16384 at split 3 takes 42 us against this model's 21 —
