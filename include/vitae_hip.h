@@ -181,7 +181,8 @@ int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, const void* x1
                                the planner of either half never exceeds it; >= vitae_gemm_glds_ws_floats(M, K, split_k) */,
                                void* stream);
 /* (dw == NULL: the input gradient only — the weight gradient is deferred to vitae_wgrad_group_bt.)
- * Weight gradients of up to four Linears with the same token count in ONE launch of 128x128 tiles: for i < n,
+ * Weight gradients of up to four Linears with the same token count in ONE launch of 128x128 tiles (ping-pong workgroups, two
+ * per CU, or wave-specialised ones, one per CU: the cheaper by the planner's clocks; a forced tile 3 / 4 forces the kind): for i < n,
  * dw[i][N[i], K[i]] (+)= dy16[i][Mpad, N[i]]^T x16[i][Mpad, K[i]] (rows M..Mpad-1 of every operand zero), optional bf16 copies
  * dw16[i] (NULL array or entries), optional dy_colsum[i][N[i]] += column sums of dy16[i] (bias gradients).  The pointer arrays
  * and N / K live on the HOST.  Together the problems of a transformer block have enough tiles that the reduction needs no

@@ -1138,10 +1138,13 @@ def test_linear_bwd_pair_on_big_tiles(lib, C, bt_mode, tile, M, N, K):
 
 @pytest.mark.parametrize('M,dims', [(3520, [(2304, 768), (768, 768), (3072, 768), (768, 3072)]), (1000, [(1536, 512), (512, 512)]),
                                     (6944, [(512, 2048)]), (260, [(264, 136), (128, 520), (520, 128)])])
-def test_wgrad_group_bt(lib, M, dims):
+@pytest.mark.parametrize('kind', [-1, 3, 4])
+def test_wgrad_group_bt(lib, bt_mode, M, dims, kind):
     """vitae_wgrad_group_bt: the weight gradients (and bias gradients) of up to four Linears of a block in one launch of 128x128
-    tiles, against fp32 products of the same bf16 operands; accumulation and the bf16 copy."""
+    tiles — the planner's kind, the ping-pong workgroups (forced tile 3) and the wave-specialised ones (4) — against fp32 products of
+    the same bf16 operands; accumulation and the bf16 copy."""
     import numpy as np
+    bt_mode(kind)
     Mp = (M + 63) // 64 * 64
     n = len(dims)
     dys = [torch.zeros(Mp, N, dtype=torch.bfloat16, device='cuda') for N, K in dims]

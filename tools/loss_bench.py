@@ -34,7 +34,11 @@ ops = {
     'target_edge (one pass)': lambda: lib.vitae_target_edge(imgs.data_ptr(), et.data_ptr(), taps.ctypes.data, len(taps), B, Cc, *vol, st),
     'loss_fwd_bwd (one pass)': lambda: lib.vitae_loss_fwd_bwd(pp, pbs, imgs.data_ptr(), mask.data_ptr(), et.data_ptr(), hp.data_ptr(),
                                                               dpred.data_ptr() + P * 4, d16.data_ptr() + P * 2, None, acc.data_ptr(), msum, B, Cc, *vol, p, st),
+    'loss_fwd_bwd (bf16 gradient only: the step)': lambda: lib.vitae_loss_fwd_bwd(pp, pbs, imgs.data_ptr(), mask.data_ptr(), et.data_ptr(), hp.data_ptr(),
+                                                              None, d16.data_ptr() + P * 2, None, acc.data_ptr(), msum, B, Cc, *vol, p, st),
 }
+if os.environ.get('LB_ONLY'):                     # e.g. LB_ONLY="one pass,gradient only"
+    ops = {k: v for k, v in ops.items() if any(w in k for w in os.environ['LB_ONLY'].split(','))}
 for name, fn in ops.items():
     for _ in range(3):
         fn()
@@ -44,4 +48,4 @@ for name, fn in ops.items():
     for _ in range(20):
         fn()
     b.record(); torch.cuda.synchronize()
-    print(f'{name:24s} {a.elapsed_time(b) / 20 * 1e3:8.1f} us')
+    print(f'{name:44s} {a.elapsed_time(b) / 20 * 1e3:8.1f} us')

@@ -9,6 +9,10 @@ dev = 'cuda'
 ws = torch.zeros(1 << 24, device=dev)
 for name, M, dims in (('B32 enc', 3520, [(2304, 768), (768, 768), (3072, 768), (768, 3072)]),
                       ('B32 dec', 6944, [(1536, 512), (512, 512), (2048, 512), (512, 2048)]),
+                      ('p8 enc', 3464, [(2304, 768), (768, 768), (3072, 768), (768, 3072)]),
+                      ('p8 dec', 6916, [(1536, 512), (512, 512), (2048, 512), (512, 2048)]),
+                      ('B16 enc', 1760, [(2304, 768), (768, 768), (3072, 768), (768, 3072)]),
+                      ('B16 dec', 3472, [(1536, 512), (512, 512), (2048, 512), (512, 2048)]),
                       ('B8 enc', 880, [(2304, 768), (768, 768), (3072, 768), (768, 3072)]),
                       ('B8 dec', 1736, [(1536, 512), (512, 512), (2048, 512), (512, 2048)])):
     Mp = (M + 63) // 64 * 64
@@ -26,5 +30,11 @@ for name, M, dims in (('B32 enc', 3520, [(2304, 768), (768, 768), (3072, 768), (
             sp = lib.vitae_gemm_glds_pick_split_k(N, K, Mp)
             lib.vitae_gemm_glds(0, 0, dys[i].data_ptr(), N, xs[i].data_ptr(), K, dws[i].data_ptr(), K, None, 0, N, K, Mp, None, None, 0, 0, None, 0, 0, sp,
                                 ws.data_ptr(), None, stf())
+    if os.environ.get('WG_ONLY_GROUP'):          # kind / split sweeps: VITAE_WGRAD_GROUP_WS, VITAE_WGRAD_GROUP_SPLIT in the environment
+        if grp() != 0:
+            print(f'{name}: not served'); continue
+        torch.cuda.synchronize()
+        print(f'{name}: grouped {graph_time(grp, 10):6.1f} us', flush=True)
+        continue
     grp(); sep(); torch.cuda.synchronize()
     print(f'{name}: grouped {graph_time(grp, 10):6.1f} us   four launches {graph_time(sep, 10):6.1f} us', flush=True)

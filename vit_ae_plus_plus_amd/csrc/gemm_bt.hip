@@ -1569,6 +1569,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bt_wgrad_group_kernel(const BtGro
     gemm_bt_body<128, 128, 2, 2, false, false>(g.p[i], b - g.start[i], blockIdx.z, smem);
 }
 
+// The same group on the wave-specialised 128 x 128 workgroup (one per CU): a k-tile of the weight-gradient form costs it ~900
+// clocks against ~1300 per tile for the two co-resident ping-pong workgroups above (both operands come through the transposing
+// reads, and there the waves that wait for them are the ones that multiply).
+__global__ __launch_bounds__(512, 2) void gemm_ws_wgrad_group_kernel(const BtGroup g) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[VITAE_WS_TAIL_ALIAS ? VITAE_WS_STAGES * 32768 : VITAE_WS_STAGES * 32768 + (VITAE_WS_TAIL8 ? 12 * 4096 + 64 : 0)];
+    const int b = blockIdx.x;
+    const int i = (b >= g.start[1]) + (b >= g.start[2]) + (b >= g.start[3]);
+    gemm_ws_body<false, false, VITAE_WS_STAGES>(g.p[i], b - g.start[i], blockIdx.z, smem);
+}
+
 template <int BM, int BN, int WM, int WN>
 static void bt_launch_cfg(const GArgs& p, bool a_kc, bool b_kc, hipStream_t st) {
     const dim3 grid(8 * cdiv((long)p.tiles_m * p.tiles_n, 8), 1, p.splits), block(64 * WM * WN);
@@ -1620,7 +1630,7 @@ int bt_launch(GArgs p, int a_kc, int b_kc, int id, hipStream_t st) {
 
 // n <= 4 complete weight-gradient descriptors (A = dy16 [K, M] row-contiguous, B = x16 [K, N], same K, vec_epi set); `splits`
 // k-ranges for all of them; ws: tickets + partial tiles for the sum of their tiles
-int bt_wgrad_group_launch(GArgs* ps, int n, int splits, hipStream_t st) {
+int bt_wgrad_group_launch(GArgs* ps, int n, int splits, hipStream_t st, bool ws_tile) {
     if (n < 1 || n > 4) return VITAE_ERR_INVALID_ARG;
     BtGroup g;
     int total = 0, tiles = 0;
@@ -1643,7 +1653,8 @@ int bt_wgrad_group_launch(GArgs* ps, int n, int splits, hipStream_t st) {
     g.start[4] = total;
     for (int i = n; i < 4; ++i) g.start[i] = total;
     if (splits > 1 && (!ps[0].ws || tiles > VITAE_GLDS_TICKETS)) return VITAE_ERR_UNSUPPORTED_SHAPE;
-    hipLaunchKernelGGL(gemm_bt_wgrad_group_kernel, dim3(total, 1, splits), dim3(256), 0, st, g);
+    if (ws_tile) hipLaunchKernelGGL(gemm_ws_wgrad_group_kernel, dim3(total, 1, splits), dim3(512), 0, st, g);
+    else hipLaunchKernelGGL(gemm_bt_wgrad_group_kernel, dim3(total, 1, splits), dim3(256), 0, st, g);
     return vitae_launch_status();
 }
 

@@ -1050,10 +1050,11 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
     return vitae_launch_status();
 }
 
-// Weight gradients of up to four Linears with the same token count in ONE launch of 128x128 tiles (csrc/gemm_bt.hip): for i < n,
+// Weight gradients of up to four Linears with the same token count in ONE launch of 128x128 tiles (csrc/gemm_bt.hip: ping-pong
+// workgroups, two per CU, or wave-specialised ones, one per CU): for i < n,
 // dw[i][N[i], K[i]] (+)= dy16[i][Mpad, N[i]]^T x16[i][Mpad, K[i]]; optional bf16 copies dw16[i]; optional bias gradients
 // dy_colsum[i][N[i]] += column sums of the first M rows of dy16[i] (one small launch each).  Pointer arrays and N / K on the HOST.
-// The split of the reduction is chosen for the SUM of the tiles (about two resident workgroups per CU).
+// Workgroup kind and split of the reduction are chosen for the SUM of the tiles.
 extern "C" int vitae_wgrad_group_bt(int n, const void* const* dy16, const void* const* x16, float* const* dw, void* const* dw16,
                                     float* const* dy_colsum, const int* N, const int* K, int M, int Mpad, int dw_accumulate,
                                     float* splitk_ws, long splitk_ws_floats, void* stream) {
@@ -1080,15 +1081,38 @@ extern "C" int vitae_wgrad_group_bt(int n, const void* const* dy16, const void* 
         if (!p.vec_epi) return VITAE_ERR_UNSUPPORTED_SHAPE;
         tiles += (long)p.tiles_m * p.tiles_n;
     }
-    // split: fill ~512 resident slots, at least 8 k-tiles per split, workspace permitting
-    static const int slots = getenv("VITAE_WGRAD_GROUP_SLOTS") ? atoi(getenv("VITAE_WGRAD_GROUP_SLOTS")) : 384;   // (sweep 256 / 384 / 512 / 768 at batch 32: encoder block 76 / 74 / 74 / 90 us, decoder block 106 / 74 / 93 / 82 us)
-    int split = (int)((slots + tiles / 2) / tiles);
-    if (split < 1) split = 1;
-    if (split > 8) split = 8;
-    while (split > 1 && Mpad / BK / split < 8) --split;
+    // Two workgroup kinds (csrc/gemm_bt.hip), each with its own split of the reduction; the cheaper by the clocks fitted to
+    // tools/wgrad_group_bench.py wins:
+    //   ping-pong 128 x 128, two per CU: 12000 + 2650 per k-tile (both co-resident workgroups advance one) + the split fix-up
+    //     (batch 32: encoder block, 432 tiles x 55 k-tiles unsplit, 66 us; decoder block, 192 x 109 at split 2, 73 us);
+    //   wave-specialised 128 x 128, one per CU: 14000 + 900 per k-tile + fix-up.
     const long cap = splitk_ws && splitk_ws_floats > 0 ? splitk_ws_floats : 0;
-    while (split > 1 && (tiles > VITAE_GLDS_TICKETS || VITAE_GLDS_TICKETS + tiles * split * 128 * 128 > cap)) --split;
-    const int rc = bt_wgrad_group_launch(ps, n, split, (hipStream_t)stream);
+    const int nkt = Mpad / BK;
+    auto split_ok = [&](int s) {
+        if (s == 1) return true;
+        const int kps = cdiv(cdiv(Mpad, s), BK) * BK;
+        return cdiv(Mpad, kps) == s && kps >= 8 * BK && Mpad - (s - 1) * kps >= 2 * BK && tiles <= VITAE_GLDS_TICKETS &&
+               VITAE_GLDS_TICKETS + tiles * s * 128 * 128 <= cap;
+    };
+    static const int env_ws = getenv("VITAE_WGRAD_GROUP_WS") ? atoi(getenv("VITAE_WGRAD_GROUP_WS")) : -1;          // 0 / 1: that kind only
+    const int force_ws = g_bt_mode == 3 ? 0 : g_bt_mode == 4 ? 1 : env_ws;                                       // (a forced tile 3 / 4 — tests, tools — forces the kind)
+    static const int force_split = getenv("VITAE_WGRAD_GROUP_SPLIT") ? atoi(getenv("VITAE_WGRAD_GROUP_SPLIT")) : 0;
+    static const double ws_kt = getenv("VITAE_WGRAD_GROUP_WS_KT") ? atof(getenv("VITAE_WGRAD_GROUP_WS_KT")) : 900.0;
+    static const double bt_kt = getenv("VITAE_WGRAD_GROUP_BT_KT") ? atof(getenv("VITAE_WGRAD_GROUP_BT_KT")) : 2650.0;
+    int split = 1;
+    bool ws_tile = false;
+    double best = 1e30;
+    for (int kind = 0; kind < 2; ++kind) {
+        if (force_ws >= 0 && kind != force_ws) continue;
+        for (int s = 1; s <= 8; ++s) {
+            if ((force_split > 0 && s != force_split) || !split_ok(s)) continue;
+            const double nk = (double)nkt / s, rounds = (double)cdiv(tiles * s, kind ? 256L : 512L);
+            const double per = kind ? 14000 + ws_kt * nk + (s > 1 ? 6000 + 2200 * s : 0) : 12000 + bt_kt * nk + (s > 1 ? 9000 + 4000 * s : 0);
+            if (rounds * per < best) { best = rounds * per; split = s; ws_tile = kind == 1; }
+        }
+    }
+    if (best >= 1e30) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    const int rc = bt_wgrad_group_launch(ps, n, split, (hipStream_t)stream, ws_tile);
     if (rc != VITAE_OK) return rc;
     if (dy_colsum)
         for (int i = 0; i < n; ++i)

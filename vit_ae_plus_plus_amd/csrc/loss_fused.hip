@@ -35,14 +35,50 @@ constexpr int NW = VITAE_LOSS_NW;      // waves = z-planes per workgroup (NW - 2
 #ifndef VITAE_LOSS_ABLATE
 #define VITAE_LOSS_ABLATE 0          // timing ablations (wrong results): 1 no barrier / LDS exchange, 2 no global loads, 3 no stores
 #endif
+#ifndef VITAE_LOSS_DEPTH
+#define VITAE_LOSS_DEPTH 4           // load slots of the march = steps a load flies ahead of its use (2 or 4; 18 VGPRs per slot: 175 / 240 VGPRs;
+                                     // 4: batch 32 475 -> 453 us, batch 4 72 -> 66)
+#endif
 constexpr int NT = 64 * NW;
 constexpr int XO_MAX = 60;             // output columns of a 64-lane row
+constexpr int LD = VITAE_LOSS_DEPTH;
+static_assert(LD == 2 || LD == 4, "the march's parity ring is two deep: load slots 2 or 4");
+
+// Workgroup -> piece of the volume.  Pieces are numbered x-tile fastest, then y-segment, z-tile, batch element; neighbours in that
+// order share their halo planes / rows / columns (a z-tile reads NW + 2 planes for NW - 2 outputs).  The dispatcher deals
+// consecutive workgroup ids round-robin over the 8 XCDs, each with an L2 of its own, so with the identity map every halo is fetched
+// from memory once per workgroup (FETCH_SIZE 2.0x the inputs for the loss kernel, 3.0x for the target's).  Here XCD k (ids = k mod 8)
+// walks the CONTIGUOUS chunk k of the pieces in dispatch order: the pieces in flight on one XCD are neighbours and find each
+// other's halos in their L2.  (chunk = 0: identity map, tools.)
+struct Pieces {
+    int n, chunk, xtiles, nseg, zt;
+};
+__device__ __forceinline__ bool piece_of(const Pieces& pc, int& xt, int& yseg, int& ztile, int& b) {
+    int id = blockIdx.x;
+    if (pc.chunk > 0) id = (id & 7) * pc.chunk + (id >> 3);
+    if (id >= pc.n) return false;
+    xt = id % pc.xtiles; id /= pc.xtiles;
+    yseg = id % pc.nseg; id /= pc.nseg;
+    ztile = id % pc.zt; b = id / pc.zt;
+    return true;
+}
+inline Pieces make_pieces(int xtiles, int nseg, int zt, int B, const char* env, unsigned& grid) {
+    const char* e = getenv(env);
+    const int on = e ? atoi(e) : 1;
+    Pieces pc;
+    pc.xtiles = xtiles; pc.nseg = nseg; pc.zt = zt;
+    pc.n = xtiles * nseg * zt * B;
+    pc.chunk = on ? cdiv(pc.n, 8) : 0;
+    grid = on ? (unsigned)pc.chunk * 8u : (unsigned)pc.n;
+    return pc;
+}
 
 struct FGeom {
     int Lz, Hy, Wx, p, g1, g2, L;
     long P, pred_bstride, V;
     int xo, xtiles, tys;               // outputs per x-tile, number of x-tiles, output rows per y-segment
     float inv_count, inv_pm;           // 1 / (B V), 1 / (P mask.sum())
+    Pieces pc;
 };
 
 // lane i <- lane i - 1 (x - 1) / lane i + 1 (x + 1); lanes without a source read 0 (halo lanes: their results are never used)
@@ -57,12 +93,12 @@ __device__ __forceinline__ f32x4 rgt(f32x4 v) { return f32x4{rgt(v[0]), rgt(v[1]
 __device__ __forceinline__ f32x4 smooth_x(f32x4 v) { return lft(v) + 2.f * v + rgt(v); }        // [1 2 1] along x
 
 struct State {
-    // loaded TWO steps ahead (slot = parity of the step that consumes them; one step of ~200 VALU instructions on two waves per
-    // SIMD does not cover an HBM round trip: 77 -> ... us)
-    f32x4 in[2][3];                   // prediction at (x, row, z - 1 | z | z + 1)
-    float et[2];                      // target edge map at the row whose gradient field is formed in that step
-    f32x4 img[2];                     // image values / mask flag of the row that leaves in that step
-    float mk[2];
+    // loaded LD steps ahead (slot = consuming step mod LD; one step of ~200 VALU instructions on two waves per SIMD does not
+    // cover an HBM round trip: 77 -> ... us with two)
+    f32x4 in[LD][3];                  // prediction at (x, row, z - 1 | z | z + 1)
+    float et[LD];                     // target edge map at the row whose gradient field is formed in that step
+    f32x4 img[LD];                    // image values / mask flag of the row that leaves in that step
+    float mk[LD];
     f32x4 P0[2], P1[2], P2[2];        // forward partials (z and x applied) of the two previous rows
     f32x4 F0[2], F1[2], F2[2];        // gradient field of the two previous rows
     f32x4 ctr[2];                     // the prediction itself at (x, row, z) of the two previous rows (reconstruction term)
@@ -92,8 +128,9 @@ __global__ __launch_bounds__(NT, VITAE_LOSS_MINW) void loss_fwd_bwd_kernel(const
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int Lz = g.Lz, Hy = g.Hy, Wx = g.Wx, p = g.p;
-    const int xt = blockIdx.x % g.xtiles, yseg = blockIdx.x / g.xtiles, b = blockIdx.z;
-    const int x0 = xt * g.xo, ys = yseg * g.tys, z0 = blockIdx.y * (NW - 2);
+    int xt, yseg, ztile, b;
+    if (!piece_of(g.pc, xt, yseg, ztile, b)) return;        // (the grid is rounded up to a multiple of 8: whole workgroups leave)
+    const int x0 = xt * g.xo, ys = yseg * g.tys, z0 = ztile * (NW - 2);
     const int x = x0 - 2 + lane, z = z0 - 1 + w;
     const int rows = min(g.tys, Hy - ys);                 // output rows of this segment
     const float ce = 2.f * hp[VITAE_HP_G_EDGE] * g.inv_count, cr = 2.f * hp[VITAE_HP_G_RECON] * g.inv_pm;
@@ -130,8 +167,8 @@ __global__ __launch_bounds__(NT, VITAE_LOSS_MINW) void loss_fwd_bwd_kernel(const
     for (int q = 0; q < 2; ++q) {
         s.P0[q] = s.P1[q] = s.P2[q] = s.F0[q] = s.F1[q] = s.F2[q] = s.ctr[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    s.img[0] = s.img[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    s.et[0] = s.et[1] = s.mk[0] = s.mk[1] = 0.f;
+#pragma unroll
+    for (int q = 0; q < LD; ++q) { s.img[q] = f32x4{0.f, 0.f, 0.f, 0.f}; s.et[q] = s.mk[q] = 0.f; }
     float sq = 0.f, rc = 0.f, chk = 0.f;
 
     // rows of the NEXT step's loads: input row yy, field row yy - 1, leaving row yy - 2 (clamped into the volume)
@@ -166,16 +203,20 @@ __global__ __launch_bounds__(NT, VITAE_LOSS_MINW) void loss_fwd_bwd_kernel(const
     RowIdx rs_out;                                          // the row that leaves in the CURRENT step (for the store address)
     rs_out.init(ys - 4, p, Hy);
 
-    auto step = [&](int t, auto PARC, auto OUTC) {
+    // (Round 5, measured and removed: finishing a row one step late — its neighbours' u / w requested behind the barrier, consumed
+    // behind the next row's forward + field work — does not move the kernel: 474 vs 475 us at batch 32.  The march is bound by
+    // instruction ISSUE, ~350 VALU + ~145 scalar instructions per row and wave on two lockstepped waves per SIMD, not by the LDS
+    // round trip.)
+    auto step = [&](int t, auto SLOTC, auto OUTC) {
         constexpr bool OUT = decltype(OUTC)::value;             // false: the first four rows of the march (nothing leaves yet)
-        constexpr int cur = decltype(PARC)::value, oth = cur ^ 1;
+        constexpr int sl = decltype(SLOTC)::value, cur = sl & 1, oth = cur ^ 1;
         const int yy = ys - 2 + t;
         // ---- forward partials of input row yy: z, then x
-        const f32x4 c0 = s.in[cur][1];
-        const f32x4 sz = s.in[cur][0] + 2.f * c0 + s.in[cur][2], dz = s.in[cur][2] - s.in[cur][0];
-        const f32x4 im = s.img[cur];
-        const float mk = s.mk[cur], etv = s.et[cur];
-        issue(PARC);                                        // slot cur is free: the loads of step t + 2 fly under two steps
+        const f32x4 c0 = s.in[sl][1];
+        const f32x4 sz = s.in[sl][0] + 2.f * c0 + s.in[sl][2], dz = s.in[sl][2] - s.in[sl][0];
+        const f32x4 im = s.img[sl];
+        const float mk = s.mk[sl], etv = s.et[sl];
+        issue(SLOTC);                                       // slot sl is free: the loads of step t + LD fly under LD steps
         const f32x4 szl = lft(sz), szr = rgt(sz);
         const f32x4 n0 = szl - szr;                         // d(x) s(z)
         const f32x4 n1 = szl + 2.f * sz + szr;              // s(x) s(z)
@@ -202,7 +243,7 @@ __global__ __launch_bounds__(NT, VITAE_LOSS_MINW) void loss_fwd_bwd_kernel(const
         const f32x4 h0 = s.F0[cur] + 2.f * s.F0[oth] + f0;  // s(y) F0
         const f32x4 h1 = s.F1[cur] - f1;                    // row y - 1 minus row y + 1 of F1
         const f32x4 h2 = s.F2[cur] + 2.f * s.F2[oth] + f2;  // s(y) F2
-        const f32x4 u = (rgt(h0) - lft(h0)) + smooth_x(h1); // e(x) s(y) F0 + s(x) d(y) F1
+        const f32x4 u = (rgt(h0 + h1) + lft(h1 - h0)) + 2.f * h1;   // e(x) s(y) F0 + s(x) d(y) F1 = (rgt - lft) h0 + (lft + 2 + rgt) h1: two shifts, not four
         const f32x4 wv = smooth_x(h2);                      // s(x) s(y) F2
         const f32x4 pc = s.ctr[cur];                        // prediction at (x, yy - 2, z)
         // rotate: slot cur now holds row yy
@@ -242,20 +283,35 @@ __global__ __launch_bounds__(NT, VITAE_LOSS_MINW) void loss_fwd_bwd_kernel(const
     };
 
     const int nsteps = rows + 4;
-    issue(std::integral_constant<int, 0>{});
-    issue(std::integral_constant<int, 1>{});
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2 % LD>;
+    using I3 = std::integral_constant<int, 3 % LD>;
+    issue(I0{});
+    issue(I1{});
+    if constexpr (LD == 4) { issue(I2{}); issue(I3{}); }
     step(0, I0{}, std::false_type{});
     step(1, I1{}, std::false_type{});
-    step(2, I0{}, std::false_type{});
-    step(3, I1{}, std::false_type{});
+    step(2, I2{}, std::false_type{});
+    step(3, I3{}, std::false_type{});
     int t = 4;
-    for (; t + 1 < nsteps; t += 2) {
-        step(t, I0{}, std::true_type{});
-        step(t + 1, I1{}, std::true_type{});
+    if constexpr (LD == 4) {
+        for (; t + 3 < nsteps; t += 4) {
+            step(t, I0{}, std::true_type{});
+            step(t + 1, I1{}, std::true_type{});
+            step(t + 2, I2{}, std::true_type{});
+            step(t + 3, I3{}, std::true_type{});
+        }
+        if (t < nsteps) step(t++, I0{}, std::true_type{});
+        if (t < nsteps) step(t++, I1{}, std::true_type{});
+        if (t < nsteps) step(t++, I2{}, std::true_type{});
+    } else {
+        for (; t + 1 < nsteps; t += 2) {
+            step(t, I0{}, std::true_type{});
+            step(t + 1, I1{}, std::true_type{});
+        }
+        if (t < nsteps) step(t, I0{}, std::true_type{});
     }
-    if (t < nsteps) step(t, I0{}, std::true_type{});
 
     const bool bad = !(fabsf(chk) <= 3.4028234e38f);         // NaN or inf
     sq = wave_sum(sq);
@@ -291,9 +347,13 @@ struct TGeom {
     long V;
     int xo, xtiles, tys;
     float k[TAPS];
+    Pieces pc;
 };
 
-__global__ __launch_bounds__(NT, 2) void target_edge_kernel(const float* __restrict__ imgs, float* __restrict__ Et, const TGeom g) {
+#ifndef VITAE_TARGET_MINW
+#define VITAE_TARGET_MINW 2
+#endif
+__global__ __launch_bounds__(NT, VITAE_TARGET_MINW) void target_edge_kernel(const float* __restrict__ imgs, float* __restrict__ Et, const TGeom g) {
     // Round 4: the 18 planes (8 waves x 11 taps overlap that much) x 4 channels x 64 columns a workgroup needs of an input row are
     // staged ONCE in LDS, channel-interleaved (16 bytes per voxel): a thread issues 12 dword loads per row instead of 44 (the round-3
     // kernel was bound by its texture-path instructions: 99 us at batch 4, 45 us without them) and fetches its eleven taps with
@@ -304,8 +364,9 @@ __global__ __launch_bounds__(NT, 2) void target_edge_kernel(const float* __restr
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int Lz = g.Lz, Hy = g.Hy, Wx = g.Wx;
-    const int xt = blockIdx.x % g.xtiles, yseg = blockIdx.x / g.xtiles, b = blockIdx.z;
-    const int x0 = xt * g.xo, ys = yseg * g.tys, z0 = blockIdx.y * (NW - 2);
+    int xt, yseg, ztile, b;
+    if (!piece_of(g.pc, xt, yseg, ztile, b)) return;
+    const int x0 = xt * g.xo, ys = yseg * g.tys, z0 = ztile * (NW - 2);
     const int x = x0 - (RADB + 1) + lane, z = z0 - 1 + w;
     const int rows = min(g.tys, Hy - ys);
     const bool okx = x >= 0 && x < Wx, okzc = z >= 0 && z < Lz;
@@ -459,11 +520,13 @@ extern "C" int vitae_loss_fwd_bwd(const float* pred, long pred_bstride, const fl
     nseg = cdiv(Hy, tys);
     g.inv_count = 1.0f / (float)((long)B * g.V);
     g.inv_pm = 1.0f / ((float)g.P * mask_sum);
+    unsigned grid;
+    g.pc = make_pieces(g.xtiles, nseg, zt, B, "VITAE_LOSS_XCD", grid);
     if (dpred)
-        hipLaunchKernelGGL(loss_fwd_bwd_kernel<true>, dim3(g.xtiles * nseg, zt, B), dim3(NT), 0, (hipStream_t)stream, pred, imgs, mask, edge_tgt,
+        hipLaunchKernelGGL(loss_fwd_bwd_kernel<true>, dim3(grid), dim3(NT), 0, (hipStream_t)stream, pred, imgs, mask, edge_tgt,
                            hp, dpred, reinterpret_cast<__bf16*>(dpred_bf16), nonfinite_flag, acc, g);
     else
-        hipLaunchKernelGGL(loss_fwd_bwd_kernel<false>, dim3(g.xtiles * nseg, zt, B), dim3(NT), 0, (hipStream_t)stream, pred, imgs, mask, edge_tgt,
+        hipLaunchKernelGGL(loss_fwd_bwd_kernel<false>, dim3(grid), dim3(NT), 0, (hipStream_t)stream, pred, imgs, mask, edge_tgt,
                            hp, dpred, reinterpret_cast<__bf16*>(dpred_bf16), nonfinite_flag, acc, g);
     return vitae_launch_status();
 }
@@ -490,6 +553,8 @@ extern "C" int vitae_target_edge(const float* imgs, float* edge_tgt, const float
     if (tys > Hy) tys = Hy;
     g.tys = tys;
     nseg = cdiv(Hy, tys);
-    hipLaunchKernelGGL(target_edge_kernel, dim3(g.xtiles * nseg, zt, B), dim3(NT), 0, (hipStream_t)stream, imgs, edge_tgt, g);
+    unsigned grid;
+    g.pc = make_pieces(g.xtiles, nseg, zt, B, "VITAE_TARGET_XCD", grid);
+    hipLaunchKernelGGL(target_edge_kernel, dim3(grid), dim3(NT), 0, (hipStream_t)stream, imgs, edge_tgt, g);
     return vitae_launch_status();
 }
