@@ -739,6 +739,35 @@ def test_one_pass_loss_nan_semantics_and_flag(lib, C):
     assert float(flag) == 0.0 and bool(torch.isfinite(d).all())
 
 
+def test_one_pass_loss_kernels_do_not_depend_on_the_piece_map(lib, C, monkeypatch):
+    """csrc/loss_fused.hip: which XCD walks which pieces of the volume (VITAE_LOSS_XCD / VITAE_TARGET_XCD, read at every launch) only
+    changes where halos are found — gradient and edge map bit for bit, the loss sums to the order of their atomics.  Ragged geometry:
+    two x-tiles, a z-tile count that is not a multiple of 8 x-tiles (the grid is rounded up), three batch elements."""
+    vol, p, B = (40, 24, 72), 8, 3
+    L, P = (vol[0] // p) * (vol[1] // p) * (vol[2] // p), p ** 3 * 4
+    hp = torch.zeros(C['VITAE_HP_COUNT'], device='cuda')
+    hp[C['VITAE_HP_G_RECON']], hp[C['VITAE_HP_G_EDGE']] = 1.0, 0.5
+    pred, imgs = dev(gen(B, L, P, seed=11)), dev(gen(B, 4, *vol, seed=12))
+    mk = (dev(gen(B, L, seed=13)) > 0).float()
+    taps = np.array([0.0088, 0.0271, 0.0651, 0.1216, 0.1769, 0.2010, 0.1769, 0.1216, 0.0651, 0.0271, 0.0088], dtype=np.float32)
+    outs = {}
+    for xcd in ('0', '1'):
+        monkeypatch.setenv('VITAE_LOSS_XCD', xcd); monkeypatch.setenv('VITAE_TARGET_XCD', xcd)
+        et = torch.full((B, *vol), float('nan'), device='cuda')
+        lib.vitae_target_edge(imgs.data_ptr(), et.data_ptr(), taps.ctypes.data, len(taps), B, 4, *vol, st())
+        d = torch.full((B, L, P), float('nan'), device='cuda')
+        d16 = torch.empty(B, L, P, dtype=torch.bfloat16, device='cuda')
+        acc = torch.zeros(C['VITAE_ACC_COUNT'], dtype=torch.float64, device='cuda')
+        lib.vitae_loss_fwd_bwd(pred.data_ptr(), L * P, imgs.data_ptr(), mk.data_ptr(), et.data_ptr(), hp.data_ptr(), d.data_ptr(), d16.data_ptr(),
+                               None, acc.data_ptr(), float(mk.sum()), B, 4, *vol, p, st())
+        torch.cuda.synchronize()
+        outs[xcd] = (et, d, d16, acc)
+    assert bool(torch.isfinite(outs['1'][0]).all()) and bool(torch.isfinite(outs['1'][1]).all())
+    for a, b in zip(outs['0'][:3], outs['1'][:3]):
+        assert torch.equal(a, b)
+    assert rel_err(outs['1'][3], outs['0'][3]) < 1e-12
+
+
 # --------------------------------------------------------------------------- predictor pieces
 @pytest.mark.parametrize('Rr,D', [(220, 768), (1760, 768), (7, 24), (130, 100)])
 def test_bn1d_relu(lib, Rr, D):

@@ -689,7 +689,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const QT* __rest
 // waves have work at N = 55 (two dQ + two dK/dV items).  qkv-bias column sums are collected with LDS atomics and
 // leave the block as one global atomic per column.
 template <int HD, typename QT = float>
-__global__ __launch_bounds__(256) void attn_bwd_fused_kernel(const QT* __restrict__ qkv, const float* __restrict__ o,
+#ifndef VITAE_ATTN_FUSED_MINW
+#define VITAE_ATTN_FUSED_MINW 2     // waves per SIMD the one-launch backward's registers are cut for.  3 (hd 64: 208 -> 168 VGPRs, 5 spilled,
+                                    // three workgroups per CU) was measured: 768 heads of 55 tokens 17.4 -> 16.6 us, 96 heads 6.8 -> 7.1: not kept
+#endif
+__global__ __launch_bounds__(256, VITAE_ATTN_FUSED_MINW) void attn_bwd_fused_kernel(const QT* __restrict__ qkv, const float* __restrict__ o,
                                                              const float* __restrict__ d_o, const float* __restrict__ lse,
                                                              float* __restrict__ dqkv, __bf16* __restrict__ dqkv16,
                                                              float* __restrict__ dbias, int N, int H, float scale, int NP) {
@@ -960,6 +964,15 @@ static int sdpa_mfma_fwd_launch(const QT* qkv, float* o, void* o_bf16, float* ls
     hipStream_t st = (hipStream_t)stream;
     __bf16* o16 = reinterpret_cast<__bf16*>(o_bf16);
 #define VITAE_FWD(HD_, QB_, KT_, CHK_) hipLaunchKernelGGL((attn_fwd_mfma_kernel<HD_, QB_, KT_, CHK_, QT>), grid, dim3(256), 0, st, qkv, o, o16, lse, N, H, scale)
+    // (N <= 64 — the encoder of the 96^3 / patch-16 model keeps 55 tokens — takes a 64-key chunk: half the LDS, so three workgroups
+    // share a CU instead of two and the 768 heads of a batch-32 step are one round)
+    static const int chk64 = getenv("VITAE_ATTN_FWD_CHK64") ? atoi(getenv("VITAE_ATTN_FWD_CHK64")) : 1;
+    if (var == 0 && N <= 64 && chk64) {
+        if (head_dim == 32) VITAE_FWD(32, 1, 1, 64);
+        else if (head_dim == 64) VITAE_FWD(64, 1, 1, 64);
+        else return VITAE_ERR_UNSUPPORTED_SHAPE;
+        return vitae_launch_status();
+    }
     if (head_dim == 32) {
         switch (var) {
             case 1: VITAE_FWD(32, 1, 2, 128); break;
