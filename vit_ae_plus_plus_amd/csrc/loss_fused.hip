@@ -389,7 +389,9 @@ __global__ __launch_bounds__(NT, VITAE_TARGET_MINW) void target_edge_kernel(cons
 #pragma unroll
     for (int j = 0; j < TAPS; ++j) kk[j] = g.k[j];
 
-    f32x4 stg[NSTG];                                       // this thread's share of the row after next (four channels per voxel)
+    f32x4 stg[2][NSTG];                                    // this thread's share of two rows in flight (four channels per voxel): a row is loaded
+                                                           // TWO steps before it is written to LDS (one set: one step, and every step began
+                                                           // with s_waitcnt vmcnt(0) on loads ~1000 clocks old)
     f32x4 A[TAPS];                                         // running sums of the blur along y: A[j] belongs to row (current row - 5 + j)
     f32x4 P0[2], P1[2], P2[2];                             // Sobel partials (z and x applied) of the two previous blurred rows
 #pragma unroll
@@ -397,20 +399,22 @@ __global__ __launch_bounds__(NT, VITAE_TARGET_MINW) void target_edge_kernel(cons
     P0[0] = P0[1] = P1[0] = P1[1] = P2[0] = P2[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     int yyn = ys - (RADB + 1);                              // input row of the next issue()
-    auto issue = [&]() {                                    // (every load unconditional: see the kernel above)
+    auto issue = [&](auto SETC) {                           // (every load unconditional: see the kernel above)
+        constexpr int set = decltype(SETC)::value;
         const int yc = min(max(yyn, 0), Hy - 1);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const unsigned soff = 4u * (unsigned)((long)c * g.V + (long)yc * Wx);
 #pragma unroll
-            for (int k = 0; k < NSTG; ++k) stg[k][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, offp[k], soff, 0));
+            for (int k = 0; k < NSTG; ++k) stg[set][k][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, offp[k], soff, 0));
         }
         ++yyn;
     };
-    auto commit = [&](int buf) {                            // the staged row -> LDS
+    auto commit = [&](int buf, auto SETC) {                 // a staged row -> LDS
+        constexpr int set = decltype(SETC)::value;
 #pragma unroll
         for (int k = 0; k < NSTG; ++k)
-            if (w + NW * k < NPL) sIn[buf][w + NW * k][lane] = stg[k];
+            if (w + NW * k < NPL) sIn[buf][w + NW * k][lane] = stg[set][k];
     };
 
     auto step = [&](int t, auto PARC, auto SOBC, auto OUTC) {
@@ -423,8 +427,8 @@ __global__ __launch_bounds__(NT, VITAE_TARGET_MINW) void target_edge_kernel(cons
 #pragma unroll
         for (int j = 1; j < TAPS; ++j) bz += kk[j] * sIn[cur][w + j][lane];
         bz *= rowok;
-        commit(oth);                                        // row t + 1 (loaded during step t - 1) -> the other buffer
-        issue();                                            // row t + 2's loads fly under this step
+        commit(oth, PARC);                                  // row t + 1 (loaded during step t - 2) -> the other buffer
+        issue(PARC);                                        // row t + 3's loads fly under two steps
         // ---- blur along x: five wave shifts to either side
         f32x4 bx = kk[RADB] * bz, l = bz, r = bz;
 #pragma unroll
@@ -467,9 +471,10 @@ __global__ __launch_bounds__(NT, VITAE_TARGET_MINW) void target_edge_kernel(cons
     using I1 = std::integral_constant<int, 1>;
     using F = std::false_type;
     using T = std::true_type;
-    issue();                                                // row 0 -> buffer 0, row 1 in flight
-    commit(0);
-    issue();
+    issue(I0{});                                            // row 0 -> buffer 0; rows 1 (set 0) and 2 (set 1) in flight
+    commit(0, I0{});
+    issue(I0{});
+    issue(I1{});
     __syncthreads();
 #pragma unroll 1
     for (int t = 0; t < 10; t += 2) { step(t, I0{}, F{}, F{}); step(t + 1, I1{}, F{}, F{}); }
