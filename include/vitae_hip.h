@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITAE_ABI_VERSION 44
+#define VITAE_ABI_VERSION 45
 
 /* matrix-core arithmetic of the dense contractions */
 #define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
@@ -411,6 +411,17 @@ int vitae_bn1d_relu_bwd(const float* dy, const float* x, const float* y, const f
                         const float* save_rstd, float* dx, void* dx_bf16 /* optional bf16 copy of dx */, float* dw_accum, float* db_accum,
                         int R, int D, void* stream);
 /* (D % 4 == 0 and 16-byte aligned operands: the kernels move float4 column groups) */
+/* The same two ops with the ROWS split over workgroups, two launches each (partial statistics / sums, then the normalisation):
+ * for many rows — the forms above give one 64-column strip all R rows, i.e. D / 64 workgroups whatever R is.  Same results to
+ * fp32 round-off (the statistics are merged with Chan's update, not from E[x^2] - E[x]^2); deterministic.  ws: scratch of
+ * vitae_bn1d_split_ws_floats(R, D) floats (16-byte aligned), used between the two launches of one call only. */
+long vitae_bn1d_split_ws_floats(int R, int D);
+int vitae_bn1d_relu_fwd_split(const float* x, const float* w, const float* b, float* y, void* y_bf16, float* save_mean, float* save_rstd,
+                              float* running_mean, float* running_var, long long* num_batches_tracked, int R, int D,
+                              float eps, float momentum, float* ws, void* stream);
+int vitae_bn1d_relu_bwd_split(const float* dy, const float* x, const float* y, const float* w, const float* save_mean,
+                              const float* save_rstd, float* dx, void* dx_bf16, float* dw_accum, float* db_accum, int R, int D,
+                              float* ws, void* stream);
 /* contr = contr_w * (-(mean cos(p1,z2) + mean cos(p2,z1))/2)  (utils/train_one_epoch.py:113-114) */
 int vitae_cosine_loss_fwd(const float* p1, const float* z2, const float* p2, const float* z1, double* acc,
                           const float* hp, float* out1, int R, int D, void* stream);

@@ -795,6 +795,50 @@ def test_bn1d_relu(lib, Rr, D):
     assert rel_err(dx, xr.grad) < 2e-5 and rel_err(dw, bn.weight.grad) < 2e-5 and rel_err(db, bn.bias.grad) < 2e-5
 
 
+@pytest.mark.parametrize('Rr,D', [(1760, 768), (1732, 768), (100, 64), (33, 24)])
+def test_bn1d_relu_row_split(lib, Rr, D):
+    """vitae_bn1d_relu_{fwd,bwd}_split (rows split over workgroups, two launches each) against nn.BatchNorm1d + ReLU and against the
+    one-strip-per-workgroup kernels; a column mean 100x its deviation (the statistics are merged with Chan's update)."""
+    x, w, b, dy = gen(Rr, D, seed=1) * 2 + 0.5, gen(D, seed=2) + 1, gen(D, seed=3) * 0.1, gen(Rr, D, seed=4)
+    x[:, 0] = 200.0 + 2.0 * gen(Rr, seed=9)
+    bn = torch.nn.BatchNorm1d(D)
+    with torch.no_grad():
+        bn.weight.copy_(w); bn.bias.copy_(b)
+    xr = x.clone().double().requires_grad_(True)
+    bn = bn.double()
+    ref = F.relu(bn(xr))
+    ref.backward(dy.double())
+    ws = torch.empty(int(lib.vitae_bn1d_split_ws_floats(Rr, D)), device='cuda')
+    xd, wd, bd, dyd = dev(x), dev(w), dev(b), dev(dy)
+    outs = {}
+    for split in (True, False):
+        y, sm, sr = torch.empty(Rr, D, device='cuda'), torch.empty(D, device='cuda'), torch.empty(D, device='cuda')
+        rm, rv = torch.zeros(D, device='cuda'), torch.ones(D, device='cuda')
+        nbt = torch.zeros((), dtype=torch.int64, device='cuda')
+        y16 = torch.empty(Rr, D, dtype=torch.bfloat16, device='cuda')
+        fa = (xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), y16.data_ptr(), sm.data_ptr(), sr.data_ptr(), rm.data_ptr(), rv.data_ptr(),
+              nbt.data_ptr(), Rr, D, 1e-5, 0.1)
+        if split:
+            lib.vitae_bn1d_relu_fwd_split(*fa, ws.data_ptr(), st())
+        else:
+            lib.vitae_bn1d_relu_fwd(*fa, st())
+        dx, dw, db = torch.empty(Rr, D, device='cuda'), torch.zeros(D, device='cuda'), torch.zeros(D, device='cuda')
+        dx16 = torch.empty(Rr, D, dtype=torch.bfloat16, device='cuda')
+        ba = (dyd.data_ptr(), xd.data_ptr(), y.data_ptr(), wd.data_ptr(), sm.data_ptr(), sr.data_ptr(), dx.data_ptr(), dx16.data_ptr(), dw.data_ptr(),
+              db.data_ptr(), Rr, D)
+        if split:
+            lib.vitae_bn1d_relu_bwd_split(*ba, ws.data_ptr(), st())
+        else:
+            lib.vitae_bn1d_relu_bwd(*ba, st())
+        assert int(nbt) == 1 and torch.equal(y16, y.to(torch.bfloat16)) and torch.equal(dx16, dx.to(torch.bfloat16))
+        outs[split] = (y, rm, rv, dx, dw, db)
+    y, rm, rv, dx, dw, db = outs[True]
+    assert rel_err(y, ref) < 2e-5 and rel_err(rm, bn.running_mean) < 1e-6 and rel_err(rv, bn.running_var) < 1e-5
+    assert rel_err(dx, xr.grad) < 5e-5 and rel_err(dw, bn.weight.grad) < 5e-5 and rel_err(db, bn.bias.grad) < 2e-5
+    for a, c in zip(outs[True], outs[False]):
+        assert rel_err(a, c) < 5e-5
+
+
 def test_cosine_loss(lib, C):
     Rr, D, w, g_up = 220, 768, 0.001, 0.5
     p1, p2, z1, z2 = (gen(Rr, D, seed=s) for s in (1, 2, 3, 4))

@@ -654,6 +654,183 @@ __global__ __launch_bounds__(256) void bn1d_relu_bwd_kernel(const float* __restr
     }
 }
 
+
+// ---- the same two ops with the ROWS split over workgroups (round 5) -----------------------------------------------------------
+// The kernels above give a 64-column strip ALL R rows: D / 64 = 12 workgroups for the predictor (D = 768) whatever R is — 12 of
+// 256 CUs stream 1760 rows at batch 32 / patch 8 (45 us forward, 78 us backward per view, 0.36 TB/s).  Here a launch is
+// (D / 64) x RS workgroups, and an op is two launches with RS partial records per column in between:
+//   forward:  (1) per split, the local mean and the local sum of squared deviations (two passes over rows that stay in L2);
+//             (2) every workgroup merges the RS records in split order with Chan's update (mean = sum n_i mean_i / R,
+//                 M2 = sum M2_i + n_i (mean_i - mean)^2 — no E[x^2] - E[x]^2 cancellation), then normalises its own rows;
+//   backward: (1) per split, sum(g) and sum(g xhat) (g = dy where y > 0); (2) the sums of all splits in order, then dx of its rows.
+// Deterministic (no atomics between the launches); split 0 writes the statistics / adds the parameter gradients.
+struct BnSplit { int RS, rps; };     // row splits, rows per split
+
+__device__ __forceinline__ void bn_split_rows(const BnSplit sp, int R, int& r0, int& r1) {
+    r0 = blockIdx.y * sp.rps; r1 = min(R, r0 + sp.rps);
+}
+
+__global__ __launch_bounds__(256) void bn1d_stats_part_kernel(const float* __restrict__ x, float* __restrict__ part, int R, int D, const BnSplit sp) {
+    __shared__ f32x4 red[BN_RG][BN_CG];
+    const int cg = threadIdx.x % BN_CG, rg = threadIdx.x / BN_CG;
+    const int c = blockIdx.x * BN_COLS + 4 * cg;
+    const bool ok = c < D;
+    int r0, r1;
+    bn_split_rows(sp, R, r0, r1);
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 s = z;
+    if (ok)
+        for (int r = r0 + rg; r < r1; r += BN_RG) s += *reinterpret_cast<const f32x4*>(x + (long)r * D + c);
+    const f32x4 mean = bn_col_reduce4(s, red, cg, rg) / (float)max(r1 - r0, 1);
+    f32x4 q = z;
+    if (ok)
+        for (int r = r0 + rg; r < r1; r += BN_RG) { const f32x4 d = *reinterpret_cast<const f32x4*>(x + (long)r * D + c) - mean; q += d * d; }
+    q = bn_col_reduce4(q, red, cg, rg);
+    if (ok && rg == 0) {
+        *reinterpret_cast<f32x4*>(part + ((long)blockIdx.y * 2 + 0) * D + c) = mean;
+        *reinterpret_cast<f32x4*>(part + ((long)blockIdx.y * 2 + 1) * D + c) = q;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn1d_relu_apply_part_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                                   const float* __restrict__ part, float* __restrict__ y, __bf16* __restrict__ y16,
+                                                                   float* __restrict__ save_mean, float* __restrict__ save_rstd,
+                                                                   float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                                   long long* __restrict__ num_batches_tracked, int R, int D, float eps,
+                                                                   float momentum, const BnSplit sp) {
+    if (num_batches_tracked && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
+    const int cg = threadIdx.x % BN_CG, rg = threadIdx.x / BN_CG;
+    const int c = blockIdx.x * BN_COLS + 4 * cg;
+    if (c >= D) return;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 mean = z;
+    for (int i = 0; i < sp.RS; ++i) {
+        const float n = (float)(min(R, (i + 1) * sp.rps) - i * sp.rps);
+        mean += n * *reinterpret_cast<const f32x4*>(part + ((long)i * 2 + 0) * D + c);
+    }
+    mean = mean / (float)R;
+    f32x4 q = z;
+    for (int i = 0; i < sp.RS; ++i) {
+        const float n = (float)(min(R, (i + 1) * sp.rps) - i * sp.rps);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(part + ((long)i * 2 + 0) * D + c) - mean;
+        q += *reinterpret_cast<const f32x4*>(part + ((long)i * 2 + 1) * D + c) + n * (d * d);
+    }
+    f32x4 rstd;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) rstd[e] = rsqrtf(q[e] / R + eps);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(w + c), be = *reinterpret_cast<const f32x4*>(b + c);
+    const f32x4 sc = rstd * g;
+    int r0, r1;
+    bn_split_rows(sp, R, r0, r1);
+    for (int r = r0 + rg; r < r1; r += BN_RG) {
+        f32x4 v = (*reinterpret_cast<const f32x4*>(x + (long)r * D + c) - mean) * sc + be;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        *reinterpret_cast<f32x4*>(y + (long)r * D + c) = v;
+        if (y16) {
+            bf16x4 h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[e] = (__bf16)v[e];
+            *reinterpret_cast<bf16x4*>(y16 + (long)r * D + c) = h;
+        }
+    }
+    if (blockIdx.y == 0 && rg == 0) {
+        *reinterpret_cast<f32x4*>(save_mean + c) = mean;
+        *reinterpret_cast<f32x4*>(save_rstd + c) = rstd;
+        if (run_mean) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                run_mean[c + e] = (1.f - momentum) * run_mean[c + e] + momentum * mean[e];
+                run_var[c + e] = (1.f - momentum) * run_var[c + e] + momentum * (q[e] / (R > 1 ? R - 1 : 1));
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn1d_relu_bwd_sums_part_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
+                                                                      const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
+                                                                      float* __restrict__ part, int R, int D, const BnSplit sp) {
+    __shared__ f32x4 red[BN_RG][BN_CG];
+    const int cg = threadIdx.x % BN_CG, rg = threadIdx.x / BN_CG;
+    const int c = blockIdx.x * BN_COLS + 4 * cg;
+    const bool ok = c < D;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 mean = ok ? *reinterpret_cast<const f32x4*>(save_mean + c) : z, rstd = ok ? *reinterpret_cast<const f32x4*>(save_rstd + c) : z;
+    int r0, r1;
+    bn_split_rows(sp, R, r0, r1);
+    f32x4 s1 = z, s2 = z;
+    if (ok)
+        for (int r = r0 + rg; r < r1; r += BN_RG) {
+            const long i = (long)r * D + c;
+            const f32x4 yv = *reinterpret_cast<const f32x4*>(y + i), dv = *reinterpret_cast<const f32x4*>(dy + i), xv = *reinterpret_cast<const f32x4*>(x + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = yv[e] > 0.f ? dv[e] : 0.f;
+                s1[e] += d; s2[e] += d * (xv[e] - mean[e]) * rstd[e];
+            }
+        }
+    s1 = bn_col_reduce4(s1, red, cg, rg);
+    s2 = bn_col_reduce4(s2, red, cg, rg);
+    if (ok && rg == 0) {
+        *reinterpret_cast<f32x4*>(part + ((long)blockIdx.y * 2 + 0) * D + c) = s1;
+        *reinterpret_cast<f32x4*>(part + ((long)blockIdx.y * 2 + 1) * D + c) = s2;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn1d_relu_bwd_apply_part_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
+                                                                       const float* __restrict__ w, const float* __restrict__ save_mean,
+                                                                       const float* __restrict__ save_rstd, const float* __restrict__ part,
+                                                                       float* __restrict__ dx, __bf16* __restrict__ dx16, float* __restrict__ dw,
+                                                                       float* __restrict__ db, int R, int D, const BnSplit sp) {
+    const int cg = threadIdx.x % BN_CG, rg = threadIdx.x / BN_CG;
+    const int c = blockIdx.x * BN_COLS + 4 * cg;
+    if (c >= D) return;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 s1 = z, s2 = z;
+    for (int i = 0; i < sp.RS; ++i) {
+        s1 += *reinterpret_cast<const f32x4*>(part + ((long)i * 2 + 0) * D + c);
+        s2 += *reinterpret_cast<const f32x4*>(part + ((long)i * 2 + 1) * D + c);
+    }
+    if (blockIdx.y == 0 && rg == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { atomicAdd(dw + c + e, s2[e]); atomicAdd(db + c + e, s1[e]); }
+    }
+    const f32x4 mean = *reinterpret_cast<const f32x4*>(save_mean + c), rstd = *reinterpret_cast<const f32x4*>(save_rstd + c);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(w + c);
+    const f32x4 m1 = s1 / (float)R, m2 = s2 / (float)R;
+    int r0, r1;
+    bn_split_rows(sp, R, r0, r1);
+    for (int r = r0 + rg; r < r1; r += BN_RG) {
+        const long i = (long)r * D + c;
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(y + i), dv = *reinterpret_cast<const f32x4*>(dy + i), xv = *reinterpret_cast<const f32x4*>(x + i);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = yv[e] > 0.f ? dv[e] : 0.f;
+            o[e] = g[e] * rstd[e] * (d - m1[e] - (xv[e] - mean[e]) * rstd[e] * m2[e]);
+        }
+        *reinterpret_cast<f32x4*>(dx + i) = o;
+        if (dx16) {
+            bf16x4 h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[e] = (__bf16)o[e];
+            *reinterpret_cast<bf16x4*>(dx16 + i) = h;
+        }
+    }
+}
+
+// row splits of a launch: ~384 workgroups, at least 32 rows each
+inline BnSplit bn_split_plan(int R, int D) {
+    const int strips = cdiv(D, BN_COLS);
+    int rs = cdiv(384, strips);
+    if (rs > cdiv(R, 32)) rs = cdiv(R, 32);
+    if (rs < 1) rs = 1;
+    BnSplit sp;
+    sp.rps = cdiv(R, rs);
+    sp.RS = cdiv(R, sp.rps);
+    return sp;
+}
+
 }  // namespace
 
 extern "C" int vitae_layernorm_fwd(const float* x, const float* w, const float* b, float* y, void* y_bf16, float* mean,
@@ -786,5 +963,38 @@ extern "C" int vitae_bn1d_relu_bwd(const float* dy, const float* x, const float*
     if (!bn_vec_ok(D, {dy, x, y, w, save_mean, save_rstd, dx}) || ((uintptr_t)dx_bf16 & 7)) return VITAE_ERR_UNSUPPORTED_SHAPE;
     hipLaunchKernelGGL(bn1d_relu_bwd_kernel, dim3(cdiv(D, BN_COLS)), dim3(256), 0, (hipStream_t)stream, dy, x, y, w,
                        save_mean, save_rstd, dx, reinterpret_cast<__bf16*>(dx_bf16), dw, db, R, D);
+    return vitae_launch_status();
+}
+
+// Row-split forms (two launches each): for many rows — one 64-column strip per workgroup leaves 244 of 256 CUs idle at D = 768.
+// ws: vitae_bn1d_split_ws_floats(R, D) floats, used between the two launches of a call only.
+extern "C" long vitae_bn1d_split_ws_floats(int R, int D) {
+    if (R <= 0 || D <= 0) return 0;
+    return (long)bn_split_plan(R, D).RS * 2 * D;
+}
+
+extern "C" int vitae_bn1d_relu_fwd_split(const float* x, const float* w, const float* b, float* y, void* y_bf16, float* save_mean,
+                                         float* save_rstd, float* running_mean, float* running_var, long long* num_batches_tracked,
+                                         int R, int D, float eps, float momentum, float* ws, void* stream) {
+    if (!x || !w || !b || !y || !save_mean || !save_rstd || !ws || R <= 0 || D <= 0) return VITAE_ERR_INVALID_ARG;
+    if (!bn_vec_ok(D, {x, w, b, y, save_mean, save_rstd, ws}) || ((uintptr_t)y_bf16 & 7)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    const BnSplit sp = bn_split_plan(R, D);
+    const dim3 grid(cdiv(D, BN_COLS), sp.RS);
+    hipLaunchKernelGGL(bn1d_stats_part_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ws, R, D, sp);
+    hipLaunchKernelGGL(bn1d_relu_apply_part_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, w, b, ws, y, reinterpret_cast<__bf16*>(y_bf16),
+                       save_mean, save_rstd, running_mean, running_var, num_batches_tracked, R, D, eps, momentum, sp);
+    return vitae_launch_status();
+}
+
+extern "C" int vitae_bn1d_relu_bwd_split(const float* dy, const float* x, const float* y, const float* w, const float* save_mean,
+                                         const float* save_rstd, float* dx, void* dx_bf16, float* dw, float* db, int R, int D,
+                                         float* ws, void* stream) {
+    if (!dy || !x || !y || !w || !save_mean || !save_rstd || !dx || !dw || !db || !ws || R <= 0 || D <= 0) return VITAE_ERR_INVALID_ARG;
+    if (!bn_vec_ok(D, {dy, x, y, w, save_mean, save_rstd, dx, ws}) || ((uintptr_t)dx_bf16 & 7)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    const BnSplit sp = bn_split_plan(R, D);
+    const dim3 grid(cdiv(D, BN_COLS), sp.RS);
+    hipLaunchKernelGGL(bn1d_relu_bwd_sums_part_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, x, y, save_mean, save_rstd, ws, R, D, sp);
+    hipLaunchKernelGGL(bn1d_relu_bwd_apply_part_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, x, y, w, save_mean, save_rstd, ws, dx,
+                       reinterpret_cast<__bf16*>(dx_bf16), dw, db, R, D, sp);
     return vitae_launch_status();
 }

@@ -48,10 +48,15 @@ __global__ __launch_bounds__(256) void random_masking_kernel(const float* __rest
 // out[(b*keep + j), c*p^3 + r*p^2 + s*p + q] = vol[b, c, gl*p + r, gh*p + s, gw*p + q]
 // for patch l = ids_shuffle[b, j] = (gl, gh, gw): the Conv3d weight's (C, p, p, p) flattening.
 // (two views in one launch: samples b >= B1 come from vol2 — the contrastive model's second view, vit_autoenc.py:272,277)
+// POW2: p is a power of two (log2p): the (c, r, s, q4) decode of an element index is shifts and masks; the generic path divides.
+// Four 16-byte loads are in flight per thread before the first store: a patch row is only 4 p contiguous bytes (64 at p = 16), so
+// the kernel lives on memory-level parallelism (round 5: one load in flight behind ~100 instructions of index division per element
+// took 95 us for the 113 MB of a batch-32 step).
+template <bool POW2>
 __global__ __launch_bounds__(256) void gather_patches_kernel(const float* __restrict__ vol, const float* __restrict__ vol2, int B1,
                                                              const int* __restrict__ ids_shuffle,
                                                              float* __restrict__ out, __bf16* __restrict__ out16,
-                                                             int C, int Lz, int Hy, int Wx, int p,
+                                                             int C, int Lz, int Hy, int Wx, int p, int log2p,
                                                              int g1, int g2, int L, int keep) {
     const int j = blockIdx.x, b = blockIdx.y;
     const int l = ids_shuffle[(long)b * L + j];
@@ -61,17 +66,36 @@ __global__ __launch_bounds__(256) void gather_patches_kernel(const float* __rest
     const long vstride = (long)Lz * Hy * Wx;
     const float* vb = b < B1 ? vol + (long)b * C * vstride : vol2 + (long)(b - B1) * C * vstride;
     const long rowoff = ((long)b * keep + j) * ((long)C * p * p * p);
+    const float* pb = vb + ((long)(gl * p) * Hy + gh * p) * Wx + gw * p;      // the patch's first voxel (channel 0)
+    auto src_of = [&](int i) -> const float* {
+        int q4, sidx, r, c;
+        if (POW2) {
+            q4 = i & (p4 - 1); const int t = i >> (log2p - 2);
+            sidx = t & (p - 1); r = (t >> log2p) & (p - 1); c = t >> (2 * log2p);
+        } else {
+            q4 = i % p4; sidx = (i / p4) % p; r = (i / (p4 * p)) % p; c = i / (p4 * p * p);
+        }
+        return pb + c * vstride + ((long)r * Hy + sidx) * Wx + q4 * 4;
+    };
     // blockIdx.z splits a patch row over several workgroups (keep * B alone is only ~200 of them)
-    for (int i = blockIdx.z * 256 + threadIdx.x; i < P4; i += 256 * gridDim.z) {
-        const int q4 = i % p4, s = (i / p4) % p, r = (i / (p4 * p)) % p, c = i / (p4 * p * p);
-        const float* src = vb + c * vstride + ((long)(gl * p + r) * Hy + (gh * p + s)) * Wx + gw * p + q4 * 4;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(src);
-        if (out) *reinterpret_cast<f32x4*>(out + rowoff + (long)i * 4) = v;
-        if (out16) {
-            bf16x4 o;
+    constexpr int U = 4;
+    const int stride = 256 * gridDim.z;
+    for (int i0 = blockIdx.z * 256 + threadIdx.x; i0 < P4; i0 += U * stride) {
+        f32x4 v[U];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
-            *reinterpret_cast<bf16x4*>(out16 + rowoff + (long)i * 4) = o;
+        for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const f32x4*>(src_of(min(i0 + u * stride, P4 - 1)));
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * stride;
+            if (i < P4) {
+                if (out) *reinterpret_cast<f32x4*>(out + rowoff + (long)i * 4) = v[u];
+                if (out16) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[u][e];
+                    *reinterpret_cast<bf16x4*>(out16 + rowoff + (long)i * 4) = o;
+                }
+            }
         }
     }
 }
@@ -138,9 +162,19 @@ __global__ __launch_bounds__(256) void encoder_assemble_bwd_kernel(const float* 
     const float* dr = dx + ((long)b * (keep + 1) + t) * D;
     if (t == 0) {
         if (b != 0) return;   // block (0,0) sums the cls rows of every sample
+        // (summed in sample order: deterministic; eight loads in flight — one at a time was a chain of B memory latencies, 47 us at
+        // batch 32 for 0.2 MB)
         for (int d = threadIdx.x; d < D; d += 256) {
             float s = 0.f;
-            for (int bb = 0; bb < B; ++bb) s += dx[((long)bb * (keep + 1)) * D + d];
+            int bb = 0;
+            for (; bb + 8 <= B; bb += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = dx[((long)(bb + u) * (keep + 1)) * D + d];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += v[u];
+            }
+            for (; bb < B; ++bb) s += dx[((long)bb * (keep + 1)) * D + d];
             atomicAdd(dcls + d, s);
         }
     } else {
@@ -193,7 +227,18 @@ __global__ __launch_bounds__(256) void decoder_assemble_bwd_kernel(const float* 
     const int nm = L - keep;
     const int i0 = (mb / col_blocks) * per_block, i1 = min(B * nm, i0 + per_block);
     float s = 0.f;
-    for (int i = i0; i < i1; ++i) {
+    int i = i0;
+    for (; i + 4 <= i1; i += 4) {                     // four rows in flight (summed in row order)
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int b = (i + u) / nm, r = keep + (i + u) % nm;
+            const int l = ids_shuffle[(long)b * L + r];
+            v[u] = dxd[((long)b * (L + 1) + 1 + l) * Dd + d];
+        }
+        s += v[0]; s += v[1]; s += v[2]; s += v[3];
+    }
+    for (; i < i1; ++i) {
         const int b = i / nm, r = keep + i % nm;
         const int l = ids_shuffle[(long)b * L + r];
         s += dxd[((long)b * (L + 1) + 1 + l) * Dd + d];
@@ -238,8 +283,12 @@ extern "C" int vitae_gather_patches(const float* vol, const int* ids_shuffle, fl
     const int P4 = C * p * p * (p / 4);
     int zsplit = (keep * B < 1024) ? cdiv(1024, keep * B) : 1;
     if (zsplit > cdiv(P4, 256)) zsplit = cdiv(P4, 256);
-    hipLaunchKernelGGL(gather_patches_kernel, dim3(keep, B, zsplit), dim3(256), 0, (hipStream_t)stream, vol, vol, B, ids_shuffle, out,
-                       reinterpret_cast<__bf16*>(out_bf16), C, Lz, Hy, Wx, p, g1, g2, g0 * g1 * g2, keep);
+    const bool pow2 = (p & (p - 1)) == 0;
+    const int log2p = pow2 ? __builtin_ctz(p) : 0;
+    if (pow2) hipLaunchKernelGGL(gather_patches_kernel<true>, dim3(keep, B, zsplit), dim3(256), 0, (hipStream_t)stream, vol, vol, B, ids_shuffle, out,
+                                 reinterpret_cast<__bf16*>(out_bf16), C, Lz, Hy, Wx, p, log2p, g1, g2, g0 * g1 * g2, keep);
+    else hipLaunchKernelGGL(gather_patches_kernel<false>, dim3(keep, B, zsplit), dim3(256), 0, (hipStream_t)stream, vol, vol, B, ids_shuffle, out,
+                            reinterpret_cast<__bf16*>(out_bf16), C, Lz, Hy, Wx, p, log2p, g1, g2, g0 * g1 * g2, keep);
     return vitae_launch_status();
 }
 
@@ -253,8 +302,12 @@ extern "C" int vitae_gather_patches_2views(const float* vol1, const float* vol2,
     const int P4 = C * p * p * (p / 4);
     int zsplit = (keep * 2 * B < 1024) ? cdiv(1024, keep * 2 * B) : 1;
     if (zsplit > cdiv(P4, 256)) zsplit = cdiv(P4, 256);
-    hipLaunchKernelGGL(gather_patches_kernel, dim3(keep, 2 * B, zsplit), dim3(256), 0, (hipStream_t)stream, vol1, vol2, B, ids_shuffle,
-                       out, reinterpret_cast<__bf16*>(out_bf16), C, Lz, Hy, Wx, p, g1, g2, g0 * g1 * g2, keep);
+    const bool pow2 = (p & (p - 1)) == 0;
+    const int log2p = pow2 ? __builtin_ctz(p) : 0;
+    if (pow2) hipLaunchKernelGGL(gather_patches_kernel<true>, dim3(keep, 2 * B, zsplit), dim3(256), 0, (hipStream_t)stream, vol1, vol2, B, ids_shuffle,
+                                 out, reinterpret_cast<__bf16*>(out_bf16), C, Lz, Hy, Wx, p, log2p, g1, g2, g0 * g1 * g2, keep);
+    else hipLaunchKernelGGL(gather_patches_kernel<false>, dim3(keep, 2 * B, zsplit), dim3(256), 0, (hipStream_t)stream, vol1, vol2, B, ids_shuffle,
+                            out, reinterpret_cast<__bf16*>(out_bf16), C, Lz, Hy, Wx, p, log2p, g1, g2, g0 * g1 * g2, keep);
     return vitae_launch_status();
 }
 

@@ -515,6 +515,10 @@ class HipMAEEngine:
             self.R = R
             b['ph'], b['pr'], b['pout'] = f(2 * R, D), f(2 * R, D), f(2 * R, D)
             b['bn_mean'], b['bn_rstd'] = f(2, D), f(2, D)
+            # many rows: BatchNorm with the rows split over workgroups (two launches per op; csrc/norm.hip) — one 64-column strip
+            # per workgroup is 12 workgroups at D = 768 whatever R is (batch 32 / patch 8: 45 + 78 us per view)
+            if R >= self.bn_split_min_rows:
+                b['bn_ws'] = f(int(lib.vitae_bn1d_split_ws_floats(R, D)))
             b['dp'], b['dpr'], b['dph'] = f(2 * R, D), f(2 * R, D), f(2 * R, D)
         self.mask_sum = float(B * (L - keep))
         self.edge_count = B * V
@@ -1229,14 +1233,18 @@ class HipMAEEngine:
                                          _ptr(self.buffers['predictor.1.running_var']), b['pr'].data_ptr() + o, R, D, 1e-5,
                                          self.stream)
                 continue
-            lib.vitae_bn1d_relu_fwd(b['ph'].data_ptr() + o, _ptr(p['predictor.1.weight']), _ptr(p['predictor.1.bias']),
-                                    b['pr'].data_ptr() + o, (b['pr_16'].data_ptr() + o // 2) if p16 else None,
-                                    b['bn_mean'].data_ptr() + v * D * 4,
-                                    b['bn_rstd'].data_ptr() + v * D * 4,
-                                    _ptr(self.buffers['predictor.1.running_mean']) if training else None,
-                                    _ptr(self.buffers['predictor.1.running_var']) if training else None,
-                                    _ptr(self.buffers['predictor.1.num_batches_tracked']) if training else None,
-                                    R, D, 1e-5, 0.1, self.stream)
+            args = (b['ph'].data_ptr() + o, _ptr(p['predictor.1.weight']), _ptr(p['predictor.1.bias']),
+                    b['pr'].data_ptr() + o, (b['pr_16'].data_ptr() + o // 2) if p16 else None,
+                    b['bn_mean'].data_ptr() + v * D * 4,
+                    b['bn_rstd'].data_ptr() + v * D * 4,
+                    _ptr(self.buffers['predictor.1.running_mean']) if training else None,
+                    _ptr(self.buffers['predictor.1.running_var']) if training else None,
+                    _ptr(self.buffers['predictor.1.num_batches_tracked']) if training else None,
+                    R, D, 1e-5, 0.1)
+            if 'bn_ws' in b:
+                lib.vitae_bn1d_relu_fwd_split(*args, _ptr(b['bn_ws']), self.stream)
+            else:
+                lib.vitae_bn1d_relu_fwd(*args, self.stream)
         if p16:
             self._g16_fwd(b['pr_16'], p['predictor.3.weight'], p['predictor.3.bias'], 2 * R, D, D, y=b['pout'])
         else:
@@ -1404,11 +1412,15 @@ class HipMAEEngine:
             self._lin_bwd_x(b['dp'], p['predictor.3.weight'], b['dpr'], 2 * R, D, D, db=g['predictor.3.bias'])
         for v in range(2):
             o = v * R * D * 4
-            lib.vitae_bn1d_relu_bwd(b['dpr'].data_ptr() + o, b['ph'].data_ptr() + o, b['pr'].data_ptr() + o,
-                                    _ptr(p['predictor.1.weight']), b['bn_mean'].data_ptr() + v * D * 4,
-                                    b['bn_rstd'].data_ptr() + v * D * 4, b['dph'].data_ptr() + o,
-                                    (b['dph_16'].data_ptr() + o // 2) if p16 else None,
-                                    _ptr(g['predictor.1.weight']), _ptr(g['predictor.1.bias']), R, D, self.stream)
+            args = (b['dpr'].data_ptr() + o, b['ph'].data_ptr() + o, b['pr'].data_ptr() + o,
+                    _ptr(p['predictor.1.weight']), b['bn_mean'].data_ptr() + v * D * 4,
+                    b['bn_rstd'].data_ptr() + v * D * 4, b['dph'].data_ptr() + o,
+                    (b['dph_16'].data_ptr() + o // 2) if p16 else None,
+                    _ptr(g['predictor.1.weight']), _ptr(g['predictor.1.bias']), R, D)
+            if 'bn_ws' in b:
+                lib.vitae_bn1d_relu_bwd_split(*args, _ptr(b['bn_ws']), self.stream)
+            else:
+                lib.vitae_bn1d_relu_bwd(*args, self.stream)
         if p16:      # dW0 = dph16^T @ latent16 (both row-contiguous bf16, reduced over the padded row count)
             lib.vitae_gemm_glds(0, 0, _ptr(b['dph_16']), D, _ptr(b['latent_16']), D, _ptr(g['predictor.0.weight']), D, None, D,
                                 D, D, self.Mpe, None, None, 0, EPI_NONE, None, 0, int(self._accum), 1, None, None, self.stream)
@@ -1592,6 +1604,7 @@ class HipMAEEngine:
     # Round 4 (side-stream grouped launch, wave-specialised input-gradient launches beside it): batch 8 5.40 -> 5.28 ms, batch 12 6.84 -> 6.51
     # with both stacks grouped; batch 4 neutral (4.14 vs 4.17): threshold between them.
     wgrad_group_min = int(float(os.environ.get('VITAE_WGRAD_GROUP_MIN', '0.6e6')))
+    bn_split_min_rows = int(os.environ.get('VITAE_BN_SPLIT_MIN_ROWS', '128'))   # predictor BatchNorm: rows per view from which the row-split kernels run
     target_one_pass = os.environ.get('VITAE_TARGET_ONE_PASS', '1') != '0'
     # optional explicit ascending block boundaries, e.g. "0,2,7,12" (uneven chunks: a smaller last, exposed bucket)
     enc_cuts = [int(v) for v in os.environ['VITAE_ENC_CUTS'].split(',')] if os.environ.get('VITAE_ENC_CUTS') else None
