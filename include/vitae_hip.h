@@ -427,6 +427,9 @@ int vitae_cosine_loss_fwd(const float* p1, const float* z2, const float* p2, con
                           const float* hp, float* out1, int R, int D, void* stream);
 int vitae_cosine_loss_bwd(const float* p1, const float* z2, const float* p2, const float* z1, const float* hp,
                           float* dp1, float* dp2, int R, int D, void* stream);
+/* the same with bf16 copies of dp1 / dp2 (the predictor's bf16 GEMM operands: no cast launch in between); dp1 / dp2 may both be NULL */
+int vitae_cosine_loss_bwd_bf16(const float* p1, const float* z2, const float* p2, const float* z1, const float* hp,
+                               float* dp1, float* dp2, void* dp1_bf16, void* dp2_bf16, int R, int D, void* stream);
 
 /* ---- optimiser -----------------------------------------------------------------------------------
  * utils/misc.py:265-266,280-292 (global grad L2 norm) and torch.optim.AdamW

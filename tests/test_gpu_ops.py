@@ -855,6 +855,23 @@ def test_cosine_loss(lib, C):
     dp1, dp2 = torch.empty(Rr, D, device='cuda'), torch.empty(Rr, D, device='cuda')
     lib.vitae_cosine_loss_bwd(*(t.data_ptr() for t in d), hp.data_ptr(), dp1.data_ptr(), dp2.data_ptr(), Rr, D, st())
     assert rel_err(dp1, a.grad) < 1e-5 and rel_err(dp2, b.grad) < 1e-5
+    # bf16 copies (the predictor's GEMM operands), with and without the fp32 gradients; more rows than 4 x 256 workgroups cover at once
+    for Rb in (Rr, 1760):
+        pz = [dev(gen(Rb, D, seed=s)) for s in (5, 6, 7, 8)]
+        f1, f2 = torch.empty(Rb, D, device='cuda'), torch.empty(Rb, D, device='cuda')
+        lib.vitae_cosine_loss_bwd(*(t.data_ptr() for t in pz), hp.data_ptr(), f1.data_ptr(), f2.data_ptr(), Rb, D, st())
+        for with_f32 in (True, False):
+            g1, g2 = torch.full((Rb, D), float('nan'), device='cuda'), torch.full((Rb, D), float('nan'), device='cuda')
+            h1, h2 = torch.empty(Rb, D, dtype=torch.bfloat16, device='cuda'), torch.empty(Rb, D, dtype=torch.bfloat16, device='cuda')
+            lib.vitae_cosine_loss_bwd_bf16(*(t.data_ptr() for t in pz), hp.data_ptr(), g1.data_ptr() if with_f32 else None,
+                                           g2.data_ptr() if with_f32 else None, h1.data_ptr(), h2.data_ptr(), Rb, D, st())
+            assert torch.equal(h1, f1.to(torch.bfloat16)) and torch.equal(h2, f2.to(torch.bfloat16))
+            if with_f32:
+                assert torch.equal(g1, f1) and torch.equal(g2, f2)
+        acc.zero_()
+        lib.vitae_cosine_loss_fwd(*(t.data_ptr() for t in pz), acc.data_ptr(), hp.data_ptr(), out.data_ptr(), Rb, D, st())
+        want = R.contrastive_loss(pz[0].cpu(), pz[2].cpu(), pz[3].cpu(), pz[1].cpu(), w)
+        assert abs(float(out) - float(want)) < 1e-9 + 1e-5 * abs(float(want))
 
 
 # --------------------------------------------------------------------------- optimiser

@@ -770,7 +770,8 @@ __global__ void cosine_finalize_kernel(const double* __restrict__ acc, const flo
 __global__ __launch_bounds__(256) void cosine_bwd_kernel(const float* __restrict__ p1, const float* __restrict__ z2,
                                                          const float* __restrict__ p2, const float* __restrict__ z1,
                                                          const float* __restrict__ hp, float* __restrict__ dp1,
-                                                         float* __restrict__ dp2, int R, int D, float eps) {
+                                                         float* __restrict__ dp2, __bf16* __restrict__ dp1_16,
+                                                         __bf16* __restrict__ dp2_16, int R, int D, float eps) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= R) return;
     const float coef = hp[VITAE_HP_G_CONTR] * (-0.5f / (float)R);
@@ -778,14 +779,21 @@ __global__ __launch_bounds__(256) void cosine_bwd_kernel(const float* __restrict
     for (int pair = 0; pair < 2; ++pair) {
         const float* p = (pair == 0 ? p1 : p2) + (long)row * D;
         const float* z = (pair == 0 ? z2 : z1) + (long)row * D;
-        float* dp = (pair == 0 ? dp1 : dp2) + (long)row * D;
+        float* dp = (pair == 0 ? dp1 : dp2);
+        __bf16* dp16 = (pair == 0 ? dp1_16 : dp2_16);
+        if (dp) dp += (long)row * D;
+        if (dp16) dp16 += (long)row * D;
         float dot = 0.f, pp = 0.f, zz = 0.f;
         for (int d = lane; d < D; d += 64) { const float a = p[d], b = z[d]; dot += a * b; pp += a * a; zz += b * b; }
         dot = wave_sum(dot); pp = wave_sum(pp); zz = wave_sum(zz);
         const float np = fmaxf(sqrtf(pp), eps), nz = fmaxf(sqrtf(zz), eps);
         const float c = dot / (np * nz);
         const float k1 = coef / (np * nz), k2 = coef * c / (np * np);
-        for (int d = lane; d < D; d += 64) dp[d] = k1 * z[d] - k2 * p[d];
+        for (int d = lane; d < D; d += 64) {
+            const float v = k1 * z[d] - k2 * p[d];
+            if (dp) dp[d] = v;
+            if (dp16) dp16[d] = (__bf16)v;             // the predictor's backward GEMMs read this copy (no cast launch in between)
+        }
     }
 }
 
@@ -968,6 +976,15 @@ extern "C" int vitae_cosine_loss_bwd(const float* p1, const float* z2, const flo
                                      const float* hp, float* dp1, float* dp2, int R, int D, void* stream) {
     if (!p1 || !z2 || !p2 || !z1 || !hp || !dp1 || !dp2 || R <= 0 || D <= 0) return VITAE_ERR_INVALID_ARG;
     hipLaunchKernelGGL(cosine_bwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, p1, z2, p2, z1, hp, dp1,
-                       dp2, R, D, 1e-8f);
+                       dp2, (__bf16*)nullptr, (__bf16*)nullptr, R, D, 1e-8f);
+    return vitae_launch_status();
+}
+
+// the same with bf16 copies of the gradients (what the predictor's LDS-DMA GEMMs consume); dp1 / dp2 may be NULL then
+extern "C" int vitae_cosine_loss_bwd_bf16(const float* p1, const float* z2, const float* p2, const float* z1, const float* hp, float* dp1,
+                                          float* dp2, void* dp1_bf16, void* dp2_bf16, int R, int D, void* stream) {
+    if (!p1 || !z2 || !p2 || !z1 || !hp || !dp1_bf16 || !dp2_bf16 || (!dp1) != (!dp2) || R <= 0 || D <= 0) return VITAE_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(cosine_bwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, p1, z2, p2, z1, hp, dp1, dp2,
+                       reinterpret_cast<__bf16*>(dp1_bf16), reinterpret_cast<__bf16*>(dp2_bf16), R, D, 1e-8f);
     return vitae_launch_status();
 }

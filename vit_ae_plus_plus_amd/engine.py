@@ -1266,12 +1266,18 @@ class HipMAEEngine:
             # the branch's backward accumulates into gradient slots zeroed by begin_grad_window on the main stream
             self.pside.wait_stream(torch.cuda.current_stream(self.device))
             with self._OnPredictorStream(self):
-                lib.vitae_cosine_loss_bwd(p1, z2, p2, z1, _ptr(self.hp), b['dp'].data_ptr(), b['dp'].data_ptr() + o, R, D,
-                                          self.stream)
+                self._cosine_bwd(p1, z2, p2, z1, o)
                 self._predictor_bwd()
             return
-        lib.vitae_cosine_loss_bwd(p1, z2, p2, z1, _ptr(self.hp), b['dp'].data_ptr(), b['dp'].data_ptr() + o, R, D,
-                                  self.stream)
+        self._cosine_bwd(p1, z2, p2, z1, o)
+
+    def _cosine_bwd(self, p1, z2, p2, z1, o):
+        b, R, D = self.buf, self.R, self.cfg.embed_dim
+        if self.pred16:      # the predictor's backward reads bf16 only: the gradient leaves the loss kernel in that form
+            lib.vitae_cosine_loss_bwd_bf16(p1, z2, p2, z1, _ptr(self.hp), None, None, b['dp_16'].data_ptr(), b['dp_16'].data_ptr() + o // 2,
+                                           R, D, self.stream)
+        else:
+            lib.vitae_cosine_loss_bwd(p1, z2, p2, z1, _ptr(self.hp), b['dp'].data_ptr(), b['dp'].data_ptr() + o, R, D, self.stream)
 
     # ------------------------------------------------------------------ backward
     def begin_grad_window(self, accumulate: bool):
@@ -1403,8 +1409,7 @@ class HipMAEEngine:
         R, D = self.R, cfg.embed_dim
         p16 = self.pred16
         if p16:
-            # dp -> bf16, then predictor.3's dgrad + wgrad + bias gradient as one paired launch on bf16 operands
-            lib.vitae_cast_bf16(_ptr(b['dp']), _ptr(b['dp_16']), 2 * R * D, self.stream)
+            # predictor.3's dgrad + wgrad + bias gradient as one paired launch on bf16 operands (dp_16: written by the cosine backward)
             self._g16_bwd(b['dp_16'], p['predictor.3.weight'], b['pr_16'], g['predictor.3.weight'], 2 * R, self.Mpe, D, D, dx=b['dpr'],
                           dy_colsum=g['predictor.3.bias'])
         else:
