@@ -1276,6 +1276,7 @@ class HipMAEEngine:
         if self.pred16:      # the predictor's backward reads bf16 only: the gradient leaves the loss kernel in that form
             lib.vitae_cosine_loss_bwd_bf16(p1, z2, p2, z1, _ptr(self.hp), None, None, b['dp_16'].data_ptr(), b['dp_16'].data_ptr() + o // 2,
                                            R, D, self.stream)
+            self._dp16_ready = True
         else:
             lib.vitae_cosine_loss_bwd(p1, z2, p2, z1, _ptr(self.hp), b['dp'].data_ptr(), b['dp'].data_ptr() + o, R, D, self.stream)
 
@@ -1409,7 +1410,11 @@ class HipMAEEngine:
         R, D = self.R, cfg.embed_dim
         p16 = self.pred16
         if p16:
-            # predictor.3's dgrad + wgrad + bias gradient as one paired launch on bf16 operands (dp_16: written by the cosine backward)
+            # predictor.3's dgrad + wgrad + bias gradient as one paired launch on bf16 operands.  dp_16: written by the fused step's cosine
+            # backward; the autograd route hands the gradient over in fp32 (buf['dp'], model/vit_autoenc.py): cast it here
+            if not getattr(self, '_dp16_ready', False):
+                lib.vitae_cast_bf16(_ptr(b['dp']), _ptr(b['dp_16']), 2 * R * D, self.stream)
+            self._dp16_ready = False
             self._g16_bwd(b['dp_16'], p['predictor.3.weight'], b['pr_16'], g['predictor.3.weight'], 2 * R, self.Mpe, D, D, dx=b['dpr'],
                           dy_colsum=g['predictor.3.bias'])
         else:

@@ -80,6 +80,7 @@ class _MAEStep(torch.autograd.Function):
         if have_dp:
             R = eng.R
             dp = eng.buf['dp']
+            eng._dp16_ready = False      # the gradient arrives in fp32 here: the predictor's backward makes its own bf16 copy
             for half, g in ((dp[:R], g_p1), (dp[R:], g_p2)):
                 if g is None:
                     half.zero_()
