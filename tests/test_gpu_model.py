@@ -239,7 +239,7 @@ def test_three_steps_track_oracle_training():
         assert err < 0.05, (k, err)
 
 
-@pytest.mark.parametrize('precision', ['bf16', 'fp32'])
+@pytest.mark.parametrize('precision', ['bf16', 'fp32', 'fp32x3'])
 def test_grad_norm_fused_step_counts_every_gradient_once(precision):
     """with the optimiser inside the backward (bf16: the matrix share of the norm comes from the weight-gradient
     epilogues) the reported global gradient norm (utils/misc.py:280-292) must equal the norm of the gradient arena — with a

@@ -184,6 +184,11 @@ class HipMAEEngine:
         # fp32x3: the GEMMs of the fp32 schedule on the wave-specialised kernel whose producer waves split the fp32 operands
         # (vitae_gemm_wsx3: in-launch split-K — its workspaces start with zeroed tickets — and bias gradients beside the weight gradients)
         self.x3ws = self.prec == PREC['fp32x3'] and os.environ.get('VITAE_X3_WS', '1') != '0'
+        # fp32x3: the weight-gradient launches of vitae_gemm_wsx3 add their squares to the norm as well; WHICH matrices they serve depends
+        # on the shapes (_x3_ok), so the covered ranges are recorded as the launches are enqueued (_x3_cov) and a bucket reads the rest
+        if self.x3ws and os.environ.get('VITAE_EPI_GRADNORM', '1') != '0':
+            self.epi_norm = True
+        self._x3_cov = []
         self.ws = torch.empty(1 << 24, **f32)   # split-K scratch (64 MiB)
         # (tickets + partial tiles of vitae_gemm_wsx3, one per stream; NOT shared with the older kernels, which park plain partials at offset 0)
         self.ws_x3 = {k: torch.zeros(n, **f32) for k, n in (('main', 1 << 23), ('pside', 1 << 22), ('wside', 1 << 22))} if self.x3ws else None
@@ -679,6 +684,10 @@ class HipMAEEngine:
             lib.vitae_gemm_wsx3(0, 0, _ptr(dy), N, _ptr(x), K, _ptr(dw), K, N, K, M, None, None, 0, EPI_NONE, None, 0, int(self._accum), s3,
                                 ws.data_ptr(), None, _ptr(db), stream)
             db = None
+            if self._epi_norm_on:        # this launch added the squares of dW to acc[GRADSQ] (vitae_gemm_glds_set_wgrad_sqnorm)
+                off = (dw.data_ptr() - self.grads.data_ptr()) // 4
+                if 0 <= off < self.tok_off:
+                    self._x3_cov.append((off, off + N * K))
         elif self.prec == PREC['bf16']:
             lib.vitae_gemm_bf16(0, 0, _ptr(dy), N, _ptr(x), K, 0, _ptr(dw), K, N, K, M, None, None, 0, EPI_NONE, None, 0,
                                 int(self._accum), s, ws.data_ptr(), None, stream)
@@ -1284,6 +1293,7 @@ class HipMAEEngine:
     def begin_grad_window(self, accumulate: bool):
         """accumulate=False: first micro-step after zero_grad (matrix grads written with beta=0)."""
         self._accum = bool(accumulate)
+        self._x3_cov = []
         if not accumulate:
             n = self.n_total - self.tok_off
             lib.vitae_memset_zero(self.grads.data_ptr() + self.tok_off * 4, n * 4,
@@ -1574,6 +1584,18 @@ class HipMAEEngine:
 
     def _epi_norm_uncovered(self):
         """matrix ranges of the arena that no LDS-DMA weight-gradient epilogue writes (cached)"""
+        if self.x3ws:
+            # fp32x3: the matrix segment minus what this step's vitae_gemm_wsx3 weight-gradient launches covered so far (a bucket is
+            # closed only after every weight gradient inside it has been enqueued)
+            cov = sorted(self._x3_cov)
+            out, pos = [], 0
+            for a, e in cov:
+                if a > pos:
+                    out.append((pos, a))
+                pos = max(pos, (e + 3) // 4 * 4)
+            if pos < self.tok_off:
+                out.append((pos, self.tok_off))
+            return out
         u = getattr(self, '_epi_unc', None)
         if u is None:
             # predictor on the LDS-DMA GEMMs (pred16): predictor.3's weight gradient leaves through the paired launch and predictor.0's
