@@ -1193,6 +1193,36 @@ def test_gemm_bt_split_k(lib, C, bt_mode, tile, form, M, N, K, split):
         assert abs(float(sq) - 2 * float(outs[0].double().pow(2).sum())) < 1e-4 * float(sq)      # one share per launch, every element once
 
 
+@pytest.mark.parametrize('M,N,K,split', [(2304, 768, 3520, 1), (768, 3072, 3520, 2), (440, 520, 1024, 2), (296, 264, 640, 1), (16384, 512, 896, 1),
+                                         (136, 776, 192, 1)])
+def test_gemm_ws_128x256_weight_gradient_tile(lib, C, bt_mode, M, N, K, split):
+    """Tile id 6 (csrc/gemm_bt.hip: gemm_wsw_body — wave-specialised 128 x 256, weight-gradient form only): ragged shapes, accumulate,
+    bf16 copy, in-launch split-K (bitwise reproducible, tickets handed back), the squared-norm share; other forms are not served."""
+    akc, bkc, A, B, prod = _bt_operands('wgrad', M, N, K, seed=9)
+    bt_mode(6)
+    assert lib.vitae_gemm_glds_bt_choice(0, 0, M, N, K) == 6 and lib.vitae_gemm_glds_bt_choice(1, 1, M, N, K) == -1
+    ws = torch.zeros(max(lib.vitae_gemm_glds_ws_floats(M, N, split), 4096), device='cuda')
+    old = gen(M, N, seed=5)
+    sq = torch.zeros(1, dtype=torch.float64, device='cuda')
+    outs = []
+    for rep in range(2):
+        y, y16 = torch.full((M, N), float('nan'), device='cuda'), torch.zeros(M, N, dtype=torch.bfloat16, device='cuda')
+        lib.vitae_gemm_glds_set_wgrad_sqnorm(sq.data_ptr())
+        try:
+            lib.vitae_gemm_glds(0, 0, A.data_ptr(), M, B.data_ptr(), N, y.data_ptr(), N, y16.data_ptr(), N, M, N, K, None, None, 0, 0, None, 0, 0, split,
+                                ws.data_ptr(), None, st())
+        finally:
+            lib.vitae_gemm_glds_set_wgrad_sqnorm(None)
+        assert rel_err(y, prod) < 2e-3 and torch.equal(y16, y.to(torch.bfloat16))
+        assert int(ws[:C['VITAE_GLDS_TICKETS']].abs().sum()) == 0
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1])
+    assert abs(float(sq) - 2 * float(outs[0].double().pow(2).sum())) < 1e-4 * float(sq)
+    y2 = dev(old)
+    lib.vitae_gemm_glds(0, 0, A.data_ptr(), M, B.data_ptr(), N, y2.data_ptr(), N, None, 0, M, N, K, None, None, 0, 0, None, 0, 1, split, ws.data_ptr(), None, st())
+    assert rel_err(y2, prod + old) < 2e-3
+
+
 @pytest.mark.parametrize('tile', [0, 3, 4, 5])
 @pytest.mark.parametrize('M,N,K', [(868, 16384, 512), (3464, 768, 768), (880, 3072, 768), (440, 2304, 768)])
 def test_linear_bwd_pair_on_big_tiles(lib, C, bt_mode, tile, M, N, K):
@@ -1228,10 +1258,10 @@ def test_linear_bwd_pair_on_big_tiles(lib, C, bt_mode, tile, M, N, K):
 
 @pytest.mark.parametrize('M,dims', [(3520, [(2304, 768), (768, 768), (3072, 768), (768, 3072)]), (1000, [(1536, 512), (512, 512)]),
                                     (6944, [(512, 2048)]), (260, [(264, 136), (128, 520), (520, 128)])])
-@pytest.mark.parametrize('kind', [-1, 3, 4])
+@pytest.mark.parametrize('kind', [-1, 3, 4, 6])
 def test_wgrad_group_bt(lib, bt_mode, M, dims, kind):
     """vitae_wgrad_group_bt: the weight gradients (and bias gradients) of up to four Linears of a block in one launch of 128x128
-    tiles — the planner's kind, the ping-pong workgroups (forced tile 3) and the wave-specialised ones (4) — against fp32 products of
+    tiles — the planner's kind, the ping-pong workgroups (forced tile 3), the wave-specialised ones (4) and their 128 x 256 form (6) — against fp32 products of
     the same bf16 operands; accumulation and the bf16 copy."""
     import numpy as np
     bt_mode(kind)
@@ -1316,7 +1346,7 @@ def test_planner_pick_is_within_ten_percent_of_the_best_tile(lib, bt_mode, B):
             A = torch.randn((M, K) if akc else (K, M), device='cuda').bfloat16()
             Bm = torch.randn((N, K) if bkc else (K, N), device='cuda').bfloat16()
             Cc = torch.empty(M, N, device='cuda')
-            t = {tile: timed(akc, bkc, A, Bm, Cc, M, N, K, tile) for tile in (5, 4, 3, 0, -2, -1)}
+            t = {tile: timed(akc, bkc, A, Bm, Cc, M, N, K, tile) for tile in ((6,) if form == 'wgrad' else ()) + (5, 4, 3, 0, -2, -1)}
             best = min(v for k, v in t.items() if k != -1)
             if t[-1] > (1.20 if K >= 8192 else 1.15) * best + 1.0:      # (16384-deep reductions stream their operand from HBM: both candidates' models are 2x low there)
                 bad.append((name, form, round(t[-1], 1), round(best, 1), {k: round(v, 1) for k, v in t.items()}))

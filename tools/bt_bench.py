@@ -8,7 +8,7 @@ import torch
 from vit_ae_plus_plus_amd._abi import lib
 
 dev = 'cuda'
-NAMES = {0: '256x256', 1: '256x128', 2: '128x256', 3: '128x128', 4: 'ws128', 5: 'ws64', -2: '64-row', -1: 'auto'}
+NAMES = {0: '256x256', 1: '256x128', 2: '128x256', 3: '128x128', 4: 'ws128', 5: 'ws64', 6: 'ws128x256', -2: '64-row', -1: 'auto'}
 
 
 def graph_time(go, iters):
@@ -67,7 +67,7 @@ def one(form, M, N, K, tile, iters=20, check=True, epi=False):
             err += f' c16 {e16:.1e}' + (' !!!' if not (e16 < 1e-2) else '')
     us = graph_time(go, iters)
     lib.vitae_gemm_glds_set_bt_tile(-1)
-    print(f'{form:5s} M={M:5d} N={N:5d} K={K:5d} tile {NAMES[tile]:>8s}->{got:2d} split={split:2d} {us:8.1f} us {2.0 * M * N * K / us / 1e6:7.1f} TF/s{err}', flush=True)
+    print(f'{form:5s} M={M:5d} N={N:5d} K={K:5d} tile {NAMES[tile]:>9s}->{got:2d} split={split:2d} {us:8.1f} us {2.0 * M * N * K / us / 1e6:7.1f} TF/s{err}', flush=True)
     return us
 
 

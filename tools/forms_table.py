@@ -9,7 +9,7 @@ for l in open(sys.argv[1]):
     m = re.match(r'(\w+)\s+M=\s*(\d+) N=\s*(\d+) K=\s*(\d+) tile\s+(\S+)->\s*(-?\d+) split=\s*(\d+)\s+([\d.]+) us', l)
     if m and cur:
         rows.setdefault((cur, m.group(1)), {})[m.group(5)] = (float(m.group(8)), int(m.group(6)), int(m.group(7)), '!!!' in l)
-tiles = ['ws64', 'ws128', '128x128', '256x256', '64-row']
+tiles = ['ws64', 'ws128', 'ws128x256', '128x128', '256x256', '64-row']
 print(f'{"shape":<16}{"form":<6}' + ''.join(f'{t:>10}' for t in tiles) + f'{"auto":>10}  auto/best (auto tile, split)')
 worst = 0.0
 for (name, form), d in rows.items():

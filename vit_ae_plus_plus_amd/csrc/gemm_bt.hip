@@ -987,6 +987,160 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(const GArgs p) {
     gemm_ws_body<A_KC, B_KC, VITAE_WS_STAGES>(p, blockIdx.x, blockIdx.z, smem);
 }
 
+// ---- a 128 x 256 tile of the same structure for the WEIGHT-GRADIENT form (tile id 6; both operands row-contiguous) ---------------
+// Why (round 5): the wave-specialised loop is bound by the CU's L2 -> LDS rate (37 B/clk), so what a k-tile costs is its BYTES:
+// 32 KB for 128 x 128 (870 clocks), 48 KB for 128 x 256 (~1300) — 1.34x the outputs per byte.  A block's four weight gradients are
+// 432 tiles of 128 x 128 on 256 one-workgroup-per-CU slots (1.69 rounds = 2); as 216 tiles of 128 x 256 they are ONE round.  The
+// consumers keep the 2 x 2 arrangement of the family's tail (BtCfg<128, 256, 2, 2>: a wave owns rows a * 64 + wm * 32 and columns
+// b * 128 + wn * 64 + f * 32, a, b, f in {0, 1}: eight 32 x 32 accumulators); eight MFMAs per k-slice carry the six fragments of a
+// slice two ahead, one per MFMA gap.  Three stages of 48 KB; the tail (split fix-up, wave-private epilogue) aliases them.
+template <int S>
+__device__ __forceinline__ void gemm_wsw_body(const GArgs& p, const int bid, const int zid, unsigned char* smem) {
+    constexpr int BM = 128, BN = 256, NWC = 4, NWP = 4;
+    constexpr int A_T = BM * BK * 2, B_T = BN * BK * 2, STG = A_T + B_T;
+    constexpr int PA = pieces<BM, false, NWP>(), PB = pieces<BN, false, NWP>(), PT = PA + PB;
+    static_assert(S == 3 && S * STG <= 160 * 1024 && (S - 2) * PT <= 63, "three stages fit LDS, one tile of pieces fits the vmcnt field");
+    const int T = p.tiles_m * p.tiles_n;
+    const int xq = T >> 3, xr = T & 7, xcd = bid & 7;
+    const int lin = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    if ((bid >> 3) >= xq + (xcd < xr ? 1 : 0)) return;
+    const int tn = p.xcd_m ? lin % p.tiles_n : lin / p.tiles_m;
+    const int tm = p.xcd_m ? lin / p.tiles_n : lin % p.tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = zid * p.k_per_split;
+    const int nk = (min(p.K, kbeg + p.k_per_split) - kbeg) / BK;         // >= 2 (launcher)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    auto barrier = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto stamp = [&](int) {};
+
+    if (wave >= NWC) {
+        // ---------------- producers: DMA only (the protocol of gemm_ws_body) ----------------
+        const int pw = wave - NWC;
+        auto issue_tile = [&](int t, int stage) {
+            unsigned char* dst = smem + stage * STG;
+            const int k0 = kbeg + t * BK;
+#pragma unroll
+            for (int j = 0; j < PA; ++j) dma_piece<BM, false, NWP>(p.A, p.lda, p.M, m0, k0, dst, pw, lane, j);
+#pragma unroll
+            for (int j = 0; j < PB; ++j) dma_piece<BN, false, NWP>(p.B, p.ldb, p.N, n0, k0, dst + A_T, pw, lane, j);
+        };
+        const int npre = min(S - 1, nk);
+        for (int t = 0; t < npre; ++t) issue_tile(t, t);
+        if (npre > 1) wait_vmcnt<PT>(); else wait_vmcnt<0>();
+        barrier();                                                       // B_0
+        int stage = npre % S;
+#pragma unroll 1
+        for (int t = 0; t + 1 < nk; ++t) {
+            if (t + S - 1 < nk) {
+                issue_tile(t + S - 1, stage);
+                stage = stage + 1 == S ? 0 : stage + 1;
+            }
+            if (min(t + S - 1, nk - 1) - (t + 1) >= 1) wait_vmcnt<PT>(); else wait_vmcnt<0>();     // B_{t+1}: tile t + 1 has landed
+            barrier();
+        }
+        return;                                                          // (a barrier only counts living waves: the tail belongs to the consumers)
+    }
+
+    // ---------------- consumers ----------------
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 acc[2][2][1][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[a][b][0][f][i] = 0.f;
+    bf16x8 fa[BK / 16][2], fb[BK / 16][4];
+    // per-lane offsets inside a stage, computed once: A fragments at rows wm * 32 (+ 64), B fragments at columns wn * 64 + {0, 32, 128, 160}
+    const FragOff<BM, false> offa = frag_offsets<BM, false>(wm * 32, lane);
+    unsigned ob[4];
+    {
+        constexpr int LB = BN * 2;
+        const int gg = lane >> 4, li = lane & 15;
+        const int kl = 8 * (gg >> 1) + (li >> 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int col = wn * 64 + (i >> 1) * 128 + (i & 1) * 32 + 16 * (gg & 1) + 4 * (li & 3);
+            ob[i] = A_T + kl * LB + (((col >> 3) ^ swz<false, BN / 8>(kl)) << 4) + (col & 7) * 2;
+        }
+    }
+    typedef __attribute__((address_space(3))) const unsigned char lds_u8;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_u8*)smem;
+    using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
+    // all six fragments of k-slice KK of the tile at LDS address rb
+    auto rd_slice = [&](const unsigned rb, auto kk_c) {
+        constexpr int KK = decltype(kk_c)::value;
+        fa[KK][0] = frag_rd<BM, false, KK, 0>(rb + offa.o[0]);
+        fa[KK][1] = frag_rd<BM, false, KK, 0>(rb + offa.o[1]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fb[KK][i] = frag_rd<BN, false, KK, 0>(rb + ob[i]);
+    };
+    // Sixteen MFMAs (k-slices S0, S0 + 1) that carry the twelve fragments of slices R0, R0 + 1 of the tile at `rb`, one per gap
+    // (the last four gaps stay empty: the lgkmcnt(0) behind the block finds every read retired)
+    auto half = [&](auto s0_c, const unsigned rb, auto r0_c, bool do_rd) {
+        constexpr int S0 = decltype(s0_c)::value, R0 = decltype(r0_c)::value;
+#pragma unroll
+        for (int k = S0; k < S0 + 2; ++k) {
+            frag_tie(fa[k][0]); frag_tie(fa[k][1]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) frag_tie(fb[k][i]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int kk = S0 + (j >> 3), a = (j >> 2) & 1, bf = j & 3;
+            acc[a][bf >> 1][0][bf & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][a], fb[kk][bf], acc[a][bf >> 1][0][bf & 1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (do_rd && j < 12) {
+                if (j == 0) fa[R0][0] = frag_rd<BM, false, R0, 0>(rb + offa.o[0]);
+                if (j == 1) fb[R0][0] = frag_rd<BN, false, R0, 0>(rb + ob[0]);
+                if (j == 2) fa[R0][1] = frag_rd<BM, false, R0, 0>(rb + offa.o[1]);
+                if (j == 3) fb[R0][1] = frag_rd<BN, false, R0, 0>(rb + ob[1]);
+                if (j == 4) fb[R0][2] = frag_rd<BN, false, R0, 0>(rb + ob[2]);
+                if (j == 5) fb[R0][3] = frag_rd<BN, false, R0, 0>(rb + ob[3]);
+                if (j == 6) fa[R0 + 1][0] = frag_rd<BM, false, R0 + 1, 0>(rb + offa.o[0]);
+                if (j == 7) fb[R0 + 1][0] = frag_rd<BN, false, R0 + 1, 0>(rb + ob[0]);
+                if (j == 8) fa[R0 + 1][1] = frag_rd<BM, false, R0 + 1, 0>(rb + offa.o[1]);
+                if (j == 9) fb[R0 + 1][1] = frag_rd<BN, false, R0 + 1, 0>(rb + ob[1]);
+                if (j == 10) fb[R0 + 1][2] = frag_rd<BN, false, R0 + 1, 0>(rb + ob[2]);
+                if (j == 11) fb[R0 + 1][3] = frag_rd<BN, false, R0 + 1, 0>(rb + ob[3]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    barrier();                                                           // B_0: tile 0 is in LDS
+    rd_slice(lds0, K0{}); rd_slice(lds0, K1{});
+    int stage = 0;
+#pragma unroll 1
+    for (int t = 0; t < nk; ++t) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        half(K0{}, lds0 + stage * STG, K2{}, true);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // every read of tile t has retired
+        const bool more = t + 1 < nk;
+        if (more) {
+            barrier();                                                   // B_{t+1}
+            stage = stage + 1 == S ? 0 : stage + 1;
+        }
+        __builtin_amdgcn_s_setprio(1);
+        half(K2{}, lds0 + stage * STG, K0{}, more);
+        __builtin_amdgcn_s_setprio(0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    bt_tail<BM, BN, 2, 2, 1>(p, acc, smem, m0, n0, tm, tn, zid, wave, lane, stamp);
+}
+
 // ---- the same structure on a 64 x 64 tile (tile id 5): the few-row launches of the batch-4 / batch-8 step ----------------------
 // At 440-1736 token rows a launch is 84-700 workgroups of a handful of k-tiles each, and a workgroup's k-step is a dependent
 // chain (DMA issue, fragment reads, MFMAs, wait + barrier: ~610 clocks per 64-deep step in gemm_glds.hip, ~880 in its pipelined
@@ -1579,6 +1733,14 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_wgrad_group_kernel(const BtGro
     gemm_ws_body<false, false, VITAE_WS_STAGES>(g.p[i], b - g.start[i], blockIdx.z, smem);
 }
 
+// ... and on 128 x 256 tiles of it (gemm_wsw_body): 216 tiles instead of 432 for an encoder block — one round of the 256 slots
+__global__ __launch_bounds__(512, 2) void gemm_wsw_wgrad_group_kernel(const BtGroup g) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * 49152];
+    const int b = blockIdx.x;
+    const int i = (b >= g.start[1]) + (b >= g.start[2]) + (b >= g.start[3]);
+    gemm_wsw_body<3>(g.p[i], b - g.start[i], blockIdx.z, smem);
+}
+
 template <int BM, int BN, int WM, int WN>
 static void bt_launch_cfg(const GArgs& p, bool a_kc, bool b_kc, hipStream_t st) {
     const dim3 grid(8 * cdiv((long)p.tiles_m * p.tiles_n, 8), 1, p.splits), block(64 * WM * WN);
@@ -1593,6 +1755,7 @@ bool bt_tile_dims(int id, int& bm, int& bn) {
         case 3: bm = 128; bn = 128; return true;
         case 4: bm = 128; bn = 128; return true;       // wave-specialised (4 MFMA waves + 4 DMA waves, one workgroup per CU)
         case 5: bm = 64; bn = 64; return true;         // ... on a 64 x 64 tile (unsplit launches)
+        case 6: bm = 128; bn = 256; return true;       // ... on a 128 x 256 tile, weight-gradient form only
         default: return false;
     }
 }
@@ -1613,8 +1776,17 @@ int bt_launch(GArgs p, int a_kc, int b_kc, int id, hipStream_t st) {
     // 128x64 / 128x96 macro tiles: 13.9 vs 13.4 us for the 64-row family on qkv, 15.7 vs 14.4 on fc1 — not kept.)
     // (256x128 and 128x256 on eight waves were built and measured too: four MFMAs per phase against the same barrier / DMA
     // overhead as eight — 2150 clocks per k-tile for 1024 of MFMA — never the best tile on any shape of the step: not kept)
+    if (id == 6 && (a_kc || b_kc)) return VITAE_ERR_UNSUPPORTED_SHAPE;
     if (id == 0) bt_launch_cfg<256, 256, 2, 4>(p, a_kc, b_kc, st);
-    else if (id == 5) {
+    else if (id == 6) {
+        // (through the group kernel as a group of one: the stand-alone instantiation of the same body came out of hipcc with 136
+        // spilled registers, the group one with 4)
+        BtGroup g;
+        const int total = 8 * cdiv(p.tiles_m * p.tiles_n, 8);
+        for (int i = 0; i < 4; ++i) { g.p[i] = p; g.start[i] = i ? total : 0; }
+        g.start[4] = total;
+        hipLaunchKernelGGL(gemm_wsw_wgrad_group_kernel, dim3(total, 1, p.splits), dim3(512), 0, st, g);
+    } else if (id == 5) {
         const dim3 grid(8 * cdiv((long)p.tiles_m * p.tiles_n, 8), 1, p.splits), block(64 * (4 + VITAE_WS64_PRODUCERS));
         if (a_kc && b_kc) hipLaunchKernelGGL((gemm_ws64_kernel<true, true>), grid, block, 0, st, p);
         else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_ws64_kernel<true, false>), grid, block, 0, st, p);
@@ -1630,7 +1802,7 @@ int bt_launch(GArgs p, int a_kc, int b_kc, int id, hipStream_t st) {
 
 // n <= 4 complete weight-gradient descriptors (A = dy16 [K, M] row-contiguous, B = x16 [K, N], same K, vec_epi set); `splits`
 // k-ranges for all of them; ws: tickets + partial tiles for the sum of their tiles
-int bt_wgrad_group_launch(GArgs* ps, int n, int splits, hipStream_t st, bool ws_tile) {
+int bt_wgrad_group_launch(GArgs* ps, int n, int splits, hipStream_t st, int kind /* 0 ping-pong 128x128, 1 ws 128x128, 2 ws 128x256 */) {
     if (n < 1 || n > 4) return VITAE_ERR_INVALID_ARG;
     BtGroup g;
     int total = 0, tiles = 0;
@@ -1644,7 +1816,7 @@ int bt_wgrad_group_launch(GArgs* ps, int n, int splits, hipStream_t st, bool ws_
         GArgs& p = ps[i];
         if (!p.vec_epi || p.a_rowsum || p.K != K || (K % BK)) return VITAE_ERR_UNSUPPORTED_SHAPE;
         p.k_per_split = kps; p.splits = splits;
-        p.tiles_m = cdiv(p.M, 128); p.tiles_n = cdiv(p.N, 128);
+        p.tiles_m = cdiv(p.M, 128); p.tiles_n = cdiv(p.N, kind == 2 ? 256 : 128);
         p.tile0 = tiles;
         tiles += p.tiles_m * p.tiles_n;
         total += 8 * cdiv(p.tiles_m * p.tiles_n, 8);
@@ -1653,7 +1825,8 @@ int bt_wgrad_group_launch(GArgs* ps, int n, int splits, hipStream_t st, bool ws_
     g.start[4] = total;
     for (int i = n; i < 4; ++i) g.start[i] = total;
     if (splits > 1 && (!ps[0].ws || tiles > VITAE_GLDS_TICKETS)) return VITAE_ERR_UNSUPPORTED_SHAPE;
-    if (ws_tile) hipLaunchKernelGGL(gemm_ws_wgrad_group_kernel, dim3(total, 1, splits), dim3(512), 0, st, g);
+    if (kind == 2) hipLaunchKernelGGL(gemm_wsw_wgrad_group_kernel, dim3(total, 1, splits), dim3(512), 0, st, g);
+    else if (kind == 1) hipLaunchKernelGGL(gemm_ws_wgrad_group_kernel, dim3(total, 1, splits), dim3(512), 0, st, g);
     else hipLaunchKernelGGL(gemm_bt_wgrad_group_kernel, dim3(total, 1, splits), dim3(256), 0, st, g);
     return vitae_launch_status();
 }

@@ -663,7 +663,10 @@ inline BtPlan bt_plan(int M, int N, int K, int a_kc, int b_kc, bool allow_split,
     static const int ws_long_any = getenv("VITAE_BT_WS_LONG_ANY") ? atoi(getenv("VITAE_BT_WS_LONG_ANY")) : 1;
     static const double bt_fix0 = getenv("VITAE_BT_FIX0") ? atof(getenv("VITAE_BT_FIX0")) : 9000.0;
     static const double bt_fix1 = getenv("VITAE_BT_FIX1") ? atof(getenv("VITAE_BT_FIX1")) : 4000.0;
-    for (int id : {0, 3, 4, 5}) {
+    static const double wsw_kt = getenv("VITAE_BT_WSW_KT") ? atof(getenv("VITAE_BT_WSW_KT")) : 1350.0;     // 128 x 256 ws tile (weight-gradient form): 48 KB per k-tile at the CU's 37 B/clk
+    static const int wsw_on = getenv("VITAE_BT_WSW") ? atoi(getenv("VITAE_BT_WSW")) : 1;
+    for (int id : {0, 3, 4, 5, 6}) {
+        if (id == 6 && (a_kc || b_kc || (g_bt_mode < 0 && !wsw_on))) continue;
         if (id == 5 && g_bt_mode != 5 && (!ws64_on || !allow_ws64)) continue;
         if (g_bt_mode >= 0 && id != g_bt_mode) continue;
         if (id == 4 && g_bt_mode < 0 && !ws_on) continue;
@@ -672,6 +675,7 @@ inline BtPlan bt_plan(int M, int N, int K, int a_kc, int b_kc, bool allow_split,
         // (round 5: a very long reduction qualifies at any row count — decoder_pred's input gradient at batch 8, 1736 x 512 x 16384, ran
         // 76.8 us on 128 x 128 with split 4 against 51.0 here; such launches are never paired anyway)
         if (id == 4 && g_bt_mode < 0 && (a_kc ? M : K) < ((a_kc && b_kc) ? ws_min_rows_fwd : ws_min_rows) && !(K >= ws_long_k && (ws_long_any || (a_kc ? M : K) < 1024))) continue;
+        if (id == 6 && g_bt_mode < 0 && K < ws_min_rows && K < ws_long_k && (long)M * N < (1L << 22)) continue;      // (as the 128 x 128 ws tile: many token rows only — or a big output: decoder_pred's 16384 x 512 at batch 8, 36 against 41 us)
         int bm, bn;
         bt_tile_dims(id, bm, bn);
         // (a FORCED tile — tests, tools — is held to what the kernel itself needs: two k-tiles per split, any M / N)
@@ -679,7 +683,7 @@ inline BtPlan bt_plan(int M, int N, int K, int a_kc, int b_kc, bool allow_split,
         if (!forced && (M < bm / 2 || N < bn / 2)) continue;
         const long tiles = (long)cdiv(M, bm) * cdiv(N, bn);
         static const int fsplit = getenv("VITAE_BT_SPLIT") ? atoi(getenv("VITAE_BT_SPLIT")) : 0;   // tools: with a forced tile, this split only
-        for (int s = 1; s <= (id >= 3 && allow_split ? 8 : 1); ++s) {
+        for (int s = 1; s <= (id >= 3 && allow_split ? (id == 6 ? 4 : 8) : 1); ++s) {
             if (forced && fsplit > 0 && s != fsplit) continue;
             const int kps = cdiv(cdiv(K, s), BK) * BK;
             if (cdiv(K, kps) != s || kps < (forced ? 2 : 4) * BK || K - (s - 1) * kps < 2 * BK) continue;
@@ -687,7 +691,8 @@ inline BtPlan bt_plan(int M, int N, int K, int a_kc, int b_kc, bool allow_split,
             const double wgs = (double)tiles * s, slots = id == 3 ? 512 : 256;
             const double rounds = (double)cdiv((long)wgs, (long)slots);
             const double nk = (double)nkt / s;
-            const double per = id == 0 ? 3000 + 2950 * nk + 14500
+            const double per = id == 0 ? 3000 + ((!a_kc && !b_kc) ? 4300 : 2950) * nk + 14500      // (weight-gradient form: every fragment through two transposing reads — 768 x 16384 x 3456: 105-114 us on 192 tiles)
+                             : id == 6 ? ws_fix + 4000 + wsw_kt * nk + (s > 1 ? 9000 + 4000 * s : 0)
                              : id == 4 ? ws_fix + ((!a_kc && !b_kc) ? ws_kt_w : ws_kt) * nk + (s > 1 ? 6000 + 2200 * s : 0)
                                        : 4500 + 1800 * nk + 7500 + (s > 1 ? bt_fix0 + bt_fix1 * s : 0);
             double clk = rounds * per;
@@ -721,7 +726,7 @@ void launch_pair(int id2, dim3 grid, hipStream_t st, const GArgs& p1, const GArg
 }  // namespace
 
 extern "C" int vitae_gemm_glds_set_bt_tile(int mode) {
-    if (mode < -2 || mode > 5 || mode == 1 || mode == 2) return VITAE_ERR_INVALID_ARG;
+    if (mode < -2 || mode > 6 || mode == 1 || mode == 2) return VITAE_ERR_INVALID_ARG;
     g_bt_mode = mode;
     return VITAE_OK;
 }
@@ -747,7 +752,10 @@ extern "C" long vitae_gemm_glds_ws_floats(int M, int N, int split_k) {
     const Tile t = pick_tile(M, N);
     // whichever family serves the problem: the 128-row padding of the big tiles covers the 64-row one
     const long small = (long)cdiv(M, t.bm) * cdiv(N, t.bn) * t.bm * t.bn, big = (long)cdiv(M, 128) * cdiv(N, 128) * 128 * 128;
-    return VITAE_GLDS_TICKETS + (small > big ? small : big) * split_k;
+    const long wide = (long)cdiv(M, 128) * cdiv(N, 256) * 128 * 256;          // (the 128 x 256 tile of the weight-gradient form)
+    long m = small > big ? small : big;
+    if (wide > m) m = wide;
+    return VITAE_GLDS_TICKETS + m * split_k;
 }
 
 static int gemm_glds_launch(int a_kcontig, int b_kcontig, const void* A16, long lda, const void* B16, long ldb,
@@ -1061,7 +1069,7 @@ extern "C" int vitae_wgrad_group_bt(int n, const void* const* dy16, const void* 
     if (n < 1 || n > 4 || !dy16 || !x16 || !dw || !N || !K || M <= 0 || Mpad < M) return VITAE_ERR_INVALID_ARG;
     if ((Mpad % BK) || Mpad < 4 * BK) return VITAE_ERR_UNSUPPORTED_SHAPE;
     GArgs ps[4];
-    long tiles = 0;
+    long tiles = 0, tiles2 = 0;      // 128 x 128 tiles; 128 x 256 tiles
     for (int i = 0; i < n; ++i) {
         if (!dy16[i] || !x16[i] || !dw[i] || N[i] <= 0 || K[i] <= 0) return VITAE_ERR_INVALID_ARG;
         if ((N[i] & 7) || (K[i] & 7) || (long)N[i] * K[i] >= (1L << 31) || (long)Mpad * N[i] >= (1L << 30) || (long)Mpad * K[i] >= (1L << 30)) return VITAE_ERR_UNSUPPORTED_SHAPE;
@@ -1080,35 +1088,48 @@ extern "C" int vitae_wgrad_group_bt(int n, const void* const* dy16, const void* 
         p.vec_epi = vec_epilogue_ok(p);
         if (!p.vec_epi) return VITAE_ERR_UNSUPPORTED_SHAPE;
         tiles += (long)p.tiles_m * p.tiles_n;
+        tiles2 += (long)cdiv(N[i], 128) * cdiv(K[i], 256);
     }
     // Two workgroup kinds (csrc/gemm_bt.hip), each with its own split of the reduction; the cheaper by the clocks fitted to
     // tools/wgrad_group_bench.py wins:
     //   ping-pong 128 x 128, two per CU: 12000 + 2650 per k-tile (both co-resident workgroups advance one) + the split fix-up
     //     (batch 32: encoder block, 432 tiles x 55 k-tiles unsplit, 66 us; decoder block, 192 x 109 at split 2, 73 us);
-    //   wave-specialised 128 x 128, one per CU: 14000 + 900 per k-tile + fix-up.
+    //   wave-specialised 128 x 128, one per CU: 14000 + 900 per k-tile + fix-up;
+    //   wave-specialised 128 x 256, one per CU: 18000 + 1350 per k-tile + fix-up (half the tiles: an encoder block's 216 are ONE round).
     const long cap = splitk_ws && splitk_ws_floats > 0 ? splitk_ws_floats : 0;
     const int nkt = Mpad / BK;
-    auto split_ok = [&](int s) {
+    auto split_ok = [&](int s, int kind) {
         if (s == 1) return true;
         const int kps = cdiv(cdiv(Mpad, s), BK) * BK;
-        return cdiv(Mpad, kps) == s && kps >= 8 * BK && Mpad - (s - 1) * kps >= 2 * BK && tiles <= VITAE_GLDS_TICKETS &&
-               VITAE_GLDS_TICKETS + tiles * s * 128 * 128 <= cap;
+        const long nt = kind == 2 ? tiles2 : tiles, area = kind == 2 ? 128 * 256 : 128 * 128;
+        return cdiv(Mpad, kps) == s && kps >= 8 * BK && Mpad - (s - 1) * kps >= 2 * BK && nt <= VITAE_GLDS_TICKETS &&
+               VITAE_GLDS_TICKETS + nt * s * area <= cap;
     };
     static const int env_ws = getenv("VITAE_WGRAD_GROUP_WS") ? atoi(getenv("VITAE_WGRAD_GROUP_WS")) : -1;          // 0 / 1: that kind only
-    const int force_ws = g_bt_mode == 3 ? 0 : g_bt_mode == 4 ? 1 : env_ws;                                       // (a forced tile 3 / 4 — tests, tools — forces the kind)
+    const int force_ws = g_bt_mode == 3 ? 0 : g_bt_mode == 4 ? 1 : g_bt_mode == 6 ? 2 : env_ws;                                       // (a forced tile 3 / 4 — tests, tools — forces the kind)
     static const int force_split = getenv("VITAE_WGRAD_GROUP_SPLIT") ? atoi(getenv("VITAE_WGRAD_GROUP_SPLIT")) : 0;
     static const double ws_kt = getenv("VITAE_WGRAD_GROUP_WS_KT") ? atof(getenv("VITAE_WGRAD_GROUP_WS_KT")) : 900.0;
     static const double bt_kt = getenv("VITAE_WGRAD_GROUP_BT_KT") ? atof(getenv("VITAE_WGRAD_GROUP_BT_KT")) : 2650.0;
-    int split = 1;
-    bool ws_tile = false;
+    static const double wsw_kt = getenv("VITAE_WGRAD_GROUP_WSW_KT") ? atof(getenv("VITAE_WGRAD_GROUP_WSW_KT")) : 1300.0;
+    // The wave-specialised kinds are bound by whichever is longer: a CU's own L2 -> LDS rate (900 / 1300 clocks per k-tile of 32 /
+    // 48 KB) over its rounds, or the CHIP's — a grouped launch keeps every CU streaming and the eight L2s deliver ~13 TB/s between
+    // them (5400 B/clk: tools/wgrad_group_bench.py, encoder block at batch 32: 432 x 55 x 32 KB in 62 us, 216 x 55 x 48 KB in 53).
+    static const double chip_bpc = getenv("VITAE_WGRAD_GROUP_CHIP_BPC") ? atof(getenv("VITAE_WGRAD_GROUP_CHIP_BPC")) : 5400.0;
+    int split = 1, ws_tile = 0;
     double best = 1e30;
-    for (int kind = 0; kind < 2; ++kind) {
+    for (int kind = 0; kind < 3; ++kind) {
         if (force_ws >= 0 && kind != force_ws) continue;
-        for (int s = 1; s <= 8; ++s) {
-            if ((force_split > 0 && s != force_split) || !split_ok(s)) continue;
-            const double nk = (double)nkt / s, rounds = (double)cdiv(tiles * s, kind ? 256L : 512L);
-            const double per = kind ? 14000 + ws_kt * nk + (s > 1 ? 6000 + 2200 * s : 0) : 12000 + bt_kt * nk + (s > 1 ? 9000 + 4000 * s : 0);
-            if (rounds * per < best) { best = rounds * per; split = s; ws_tile = kind == 1; }
+        for (int s = 1; s <= (kind == 2 ? 4 : 8); ++s) {
+            if ((force_split > 0 && s != force_split) || !split_ok(s, kind)) continue;
+            const double nk = (double)nkt / s, wgs = (double)(kind == 2 ? tiles2 : tiles) * s, rounds = (double)cdiv((long)wgs, kind ? 256L : 512L);
+            double clk;
+            if (kind == 0) clk = rounds * (12000 + bt_kt * nk + (s > 1 ? 9000 + 4000 * s : 0));
+            else {
+                const double own = rounds * (kind == 2 ? wsw_kt : ws_kt) * nk, chip = wgs * nk * (kind == 2 ? 49152.0 : 32768.0) / chip_bpc;
+                clk = (own > chip ? own : chip) + (kind == 2 ? 20000 : 6000) + (s > 1 ? (kind == 2 ? 9000 + 4000 * s : 6000 + 2200 * s) : 0);
+                if (kind == 2) clk *= 1.03;        // (ties go to the smaller tile)
+            }
+            if (clk < best) { best = clk; split = s; ws_tile = kind; }
         }
     }
     if (best >= 1e30) return VITAE_ERR_UNSUPPORTED_SHAPE;

@@ -113,7 +113,7 @@ __device__ __forceinline__ float epilogue_frag(const GArgs& p, const float (&v)[
 // descriptor of ONE unsplit problem; tiles_m / tiles_n are set by the launcher.
 bool bt_tile_dims(int id, int& bm, int& bn);
 int bt_launch(GArgs p, int a_kc, int b_kc, int id, hipStream_t st);
-int bt_wgrad_group_launch(GArgs* ps, int n, int splits, hipStream_t st, bool ws_tile);
+int bt_wgrad_group_launch(GArgs* ps, int n, int splits, hipStream_t st, int kind);
 // gemm_bt.hip: input gradient + weight gradient of one Linear as ONE launch of wave-specialised 64 x 64 workgroups (tile id 5)
 int ws64_pair_launch(GArgs p1, GArgs p2, hipStream_t st);
 // gemm_bt.hip: fp32 operands split into bf16 hi + lo by the producer waves of a wave-specialised 64 x 64 workgroup (fp32x3 mode);
