@@ -154,7 +154,7 @@ int vitae_gemm_glds_w2_pick_split_k(int M, int N, int K);
  * four MFMA waves + four LDS-DMA producer waves per workgroup; with tile 5 both halves of vitae_linear_bwd_pair_glds stay ONE
  * launch).  mode -1 (default): picked per problem by the cost
  * model together with the split (vitae_gemm_glds_pick_split_k returns the split of the plan: pass it on unchanged); -2: never;
- * 0 / 3 / 4 / 5: that tile for every eligible problem (tests, tools).  vitae_gemm_glds_bt_choice = the tile a problem would get (-1 = none).
+ * 0 / 3 / 4 / 5 / 6: that tile for every eligible problem (tests, tools; 6 = the wave-specialised 128 x 256 tile, weight-gradient form only).  vitae_gemm_glds_bt_choice = the tile a problem would get (-1 = none).
  * vitae_linear_bwd_pair_glds / vitae_wgrad_group_bt plan their own splits: they are told what the workspace holds per call
  * (splitk_ws_floats) and never make a plan that needs more. */
 int vitae_gemm_glds_set_bt_tile(int mode);
