@@ -1126,7 +1126,10 @@ extern "C" int vitae_wgrad_group_bt(int n, const void* const* dy16, const void* 
             if (kind == 0) clk = rounds * (12000 + bt_kt * nk + (s > 1 ? 9000 + 4000 * s : 0));
             else {
                 const double own = rounds * (kind == 2 ? wsw_kt : ws_kt) * nk, chip = wgs * nk * (kind == 2 ? 49152.0 : 32768.0) / chip_bpc;
-                clk = (own > chip ? own : chip) + (kind == 2 ? 20000 : 6000) + (s > 1 ? (kind == 2 ? 9000 + 4000 * s : 6000 + 2200 * s) : 0);
+                // fixed part (fill, tail): 20 k clocks for the 128 x 256 tile; for 128 x 128 it shrinks with the length of the k-loop
+                // (5.6 k / 14.7 k / 22 k at 55 / 28 / 14 k-tiles: a tile's tail runs under its successor's k-loop)
+                const double fix1 = 27500 - 400 * nk > 5000 ? 27500 - 400 * nk : 5000;
+                clk = (own > chip ? own : chip) + (kind == 2 ? 20000 : fix1) + (s > 1 ? (kind == 2 ? 9000 + 4000 * s : 6000 + 2200 * s) : 0);
                 if (kind == 2) clk *= 1.03;        // (ties go to the smaller tile)
             }
             if (clk < best) { best = clk; split = s; ws_tile = kind; }
