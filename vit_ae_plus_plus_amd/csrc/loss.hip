@@ -739,8 +739,8 @@ __global__ void loss_finalize_kernel(const double* __restrict__ acc, const float
 __global__ __launch_bounds__(256) void cosine_fwd_kernel(const float* __restrict__ p1, const float* __restrict__ z2,
                                                          const float* __restrict__ p2, const float* __restrict__ z1,
                                                          double* __restrict__ acc, int R, int D, float eps) {
-    // ONE atomic per workgroup, and at most 256 workgroups (round 5: one double atomic per row and pair — 7040 on the same address at
-    // batch 32 — serialised in L2: 49 us for 22 MB)
+    // ONE atomic per workgroup (round 5: one double atomic per row and pair — 7040 on the same address at batch 32 — serialised in L2:
+    // 49 us for 22 MB)
     __shared__ double red[4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double csum = 0.0;
@@ -967,7 +967,8 @@ extern "C" int vitae_cosine_loss_fwd(const float* p1, const float* z2, const flo
                                      const float* hp, float* out1, int R, int D, void* stream) {
     if (!p1 || !z2 || !p2 || !z1 || !acc || !hp || !out1 || R <= 0 || D <= 0) return VITAE_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(cosine_fwd_kernel, dim3(cdiv(R, 4) < 256 ? cdiv(R, 4) : 256), dim3(256), 0, st, p1, z2, p2, z1, acc, R, D, 1e-8f);
+    // (one row per wave up to 1024 workgroups: a wave that walks several rows is a chain of memory latencies — 26 us at 1732 rows on 256)
+    hipLaunchKernelGGL(cosine_fwd_kernel, dim3(cdiv(R, 4) < 1024 ? cdiv(R, 4) : 1024), dim3(256), 0, st, p1, z2, p2, z1, acc, R, D, 1e-8f);
     hipLaunchKernelGGL(cosine_finalize_kernel, dim3(1), dim3(64), 0, st, acc, hp, out1, 1.0f / (float)R);
     return vitae_launch_status();
 }
