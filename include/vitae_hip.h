@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITAE_ABI_VERSION 45
+#define VITAE_ABI_VERSION 46
 
 /* matrix-core arithmetic of the dense contractions */
 #define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
@@ -75,7 +75,15 @@ extern "C" {
 #define VITAE_ACC_NONFINITE 7 /* the first 4 bytes of this slot are a FLOAT: 0 after the per-step zeroing, NaN once the loss
                                 * backward produced a non-finite gradient (the early form of GradScaler.step's inf check:
                                 * a `grad_norm` pointer for vitae_adamw_step before the global norm exists) */
-#define VITAE_ACC_COUNT 8
+/* Round 6: the squared gradient norm is accumulated in VITAE_ACC_SQ_SLOTS spread slots, acc[VITAE_ACC_SQ_BASE + s * VITAE_ACC_SQ_STRIDE]
+ * (one 128-byte line each), workgroup b adding to slot b mod SLOTS: double atomics on ONE address retire one per ~10 ns, and a
+ * weight-gradient launch of the batch-4 step has 400-600 workgroups (tools/pair_bench.py: 18.2 -> 14.1 us for the encoder's fc2 pair).
+ * acc[VITAE_ACC_GRADSQ] stays a valid place to add to; every reader (vitae_grad_norm_finalize, vitae_opt_tail, vitae_grad_sqnorm's own
+ * finalisation) takes acc[GRADSQ] + the sum of the slots. */
+#define VITAE_ACC_SQ_BASE 16
+#define VITAE_ACC_SQ_SLOTS 64
+#define VITAE_ACC_SQ_STRIDE 16
+#define VITAE_ACC_COUNT 1040
 
 #define VITAE_MAX_TAPS 33
 
@@ -165,7 +173,10 @@ int vitae_gemm_glds_set_debug(void* buf);
  * (vitae_linear_bwd_pair_glds' wgrad half; vitae_gemm_glds called with a_kcontig = b_kcontig = 0) adds the sum of squares
  * of the tile it stores to *slot (double; the step's acc[VITAE_ACC_GRADSQ]).  Process-global, launch-time. */
 int vitae_gemm_glds_set_wgrad_sqnorm(double* slot);
-/* norm_out[0] = sqrt(acc[VITAE_ACC_GRADSQ]) (the finalisation vitae_grad_sqnorm appends, on its own) */
+/* The same over n_slots (a power of two) addresses `stride` doubles apart: workgroup b adds to slots[(b mod n_slots) * stride].
+ * The step passes acc + VITAE_ACC_SQ_BASE, VITAE_ACC_SQ_SLOTS, VITAE_ACC_SQ_STRIDE. */
+int vitae_gemm_glds_set_wgrad_sqnorm_spread(double* slots, int n_slots, int stride);
+/* norm_out[0] = sqrt(acc[VITAE_ACC_GRADSQ] + the VITAE_ACC_SQ_SLOTS spread slots) (the finalisation vitae_grad_sqnorm appends, on its own) */
 int vitae_grad_norm_finalize(const double* acc, float* norm_out, void* stream);
 /* Backward of one nn.Linear on bf16 operands in one launch: dx / dx16 [M,K] = epi(dy16 W16), optional
  * dx_colsum_accum[k] += sum_m dx(m,k); dW[N,K] (+)= dy16^T x16 reduced over Mpad (>= M, multiple of 64) token

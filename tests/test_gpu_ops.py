@@ -1193,6 +1193,42 @@ def test_gemm_bt_split_k(lib, C, bt_mode, tile, form, M, N, K, split):
         assert abs(float(sq) - 2 * float(outs[0].double().pow(2).sum())) < 1e-4 * float(sq)      # one share per launch, every element once
 
 
+def test_wgrad_sqnorm_spread_slots(lib, C):
+    """vitae_gemm_glds_set_wgrad_sqnorm_spread (round 6): the weight-gradient workgroups of a paired launch add their squares to the
+    VITAE_ACC_SQ_SLOTS spread slots of the accumulator block (same-address double atomics retire one per ~10 ns); vitae_grad_norm_finalize
+    sums the slots and acc[GRADSQ]; a second launch keeps adding; bad slot counts are refused."""
+    M, N, K = 440, 768, 3072
+    Mp = (M + 63) // 64 * 64
+    x16 = torch.zeros(Mp, K, dtype=torch.bfloat16, device='cuda'); x16[:M] = gen(M, K, seed=1).cuda().to(torch.bfloat16)
+    dy16 = torch.zeros(Mp, N, dtype=torch.bfloat16, device='cuda'); dy16[:M] = gen(M, N, seed=5).cuda().to(torch.bfloat16)
+    w16 = gen(N, K, seed=2, scale=K ** -0.5).cuda().to(torch.bfloat16)
+    dx, dw = torch.empty(M, K, device='cuda'), torch.empty(N, K, device='cuda')
+    acc = torch.zeros(C['VITAE_ACC_COUNT'], dtype=torch.float64, device='cuda')
+    gn = torch.zeros(1, device='cuda')
+    ws = torch.zeros(1 << 22, device='cuda')
+    base, slots, stride = C['VITAE_ACC_SQ_BASE'], C['VITAE_ACC_SQ_SLOTS'], C['VITAE_ACC_SQ_STRIDE']
+    assert C['VITAE_ACC_COUNT'] >= base + slots * stride
+    with pytest.raises(Exception):
+        lib.vitae_gemm_glds_set_wgrad_sqnorm_spread(acc.data_ptr(), 48, 16)
+    split = lib.vitae_linear_bwd_pair_pick_split_k(M, Mp, N, K)
+    lib.vitae_gemm_glds_set_wgrad_sqnorm_spread(acc.data_ptr() + 8 * base, slots, stride)
+    try:
+        for rep in (1, 2):
+            lib.vitae_linear_bwd_pair_glds(dy16.data_ptr(), w16.data_ptr(), x16.data_ptr(), dx.data_ptr(), None, dw.data_ptr(), None, M, Mp, N, K,
+                                           0, None, None, None, 0, 0, split, ws.data_ptr(), ws.numel(), st())
+            lib.vitae_grad_norm_finalize(acc.data_ptr(), gn.data_ptr(), st())
+            want = float(dw.double().pow(2).sum()) * rep
+            got = acc[base:base + slots * stride].view(slots, stride)
+            assert float(got[:, 1:].abs().sum()) == 0.0 and int((got[:, 0] != 0).sum()) == slots      # every slot used, nothing beside them
+            assert abs(float(got[:, 0].sum()) - want) < 1e-6 * want
+            assert abs(float(gn) - want ** 0.5) < 1e-5 * want ** 0.5
+    finally:
+        lib.vitae_gemm_glds_set_wgrad_sqnorm(None)
+    acc[C['VITAE_ACC_GRADSQ']] = 9.0          # the single slot still counts
+    lib.vitae_grad_norm_finalize(acc.data_ptr(), gn.data_ptr(), st())
+    assert abs(float(gn) - (want + 9.0) ** 0.5) < 1e-5 * want ** 0.5
+
+
 @pytest.mark.parametrize('M,N,K,split', [(2304, 768, 3520, 1), (768, 3072, 3520, 2), (440, 520, 1024, 2), (296, 264, 640, 1), (16384, 512, 896, 1),
                                          (136, 776, 192, 1)])
 def test_gemm_ws_128x256_weight_gradient_tile(lib, C, bt_mode, M, N, K, split):

@@ -421,7 +421,7 @@ __device__ __forceinline__ void bt_tail(const GArgs& p, f32x16 (&acc)[2][2][NACC
             float tot = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) tot += red[w];
-            atomicAdd(p.sqacc, (double)tot);
+            atomicAdd(sq_slot(p), (double)tot);
         }
     }
     if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(25); }
@@ -973,7 +973,7 @@ __device__ __forceinline__ void gemm_ws_body(const GArgs& p, const int bid, cons
                 float tot = 0.f;
 #pragma unroll
                 for (int w = 0; w < 8; ++w) tot += red[w];
-                atomicAdd(p.sqacc, (double)tot);
+                atomicAdd(sq_slot(p), (double)tot);
             }
         }
         return;
@@ -1351,7 +1351,7 @@ __device__ __forceinline__ void gemm_ws64_body(const GArgs& p, const int bid, co
         float* red = reinterpret_cast<float*>(smem + 4 * 4096 + 64);
         if (lane == 0) red[wave] = sqs;
         __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(p.sqacc, (double)((red[0] + red[1]) + (red[2] + red[3])));
+        if (threadIdx.x == 0) atomicAdd(sq_slot(p), (double)((red[0] + red[1]) + (red[2] + red[3])));
     }
 }
 
@@ -1652,7 +1652,7 @@ __device__ __forceinline__ void gemm_wsx3_body(const GArgs& p, const int bid, co
         float* red = reinterpret_cast<float*>(smem + 4 * 4096 + 64);
         if (lane == 0) red[wave] = sqs;
         __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(p.sqacc, (double)((red[0] + red[1]) + (red[2] + red[3])));
+        if (threadIdx.x == 0) atomicAdd(sq_slot(p), (double)((red[0] + red[1]) + (red[2] + red[3])));
     }
 }
 

@@ -27,7 +27,9 @@ namespace {
 using namespace vglds;
 
 long long* g_gemm_dbg = nullptr;
-double* g_wgrad_sqacc = nullptr;   // vitae_gemm_glds_set_wgrad_sqnorm: picked up by every weight-gradient launch while set
+double* g_wgrad_sqacc = nullptr;   // vitae_gemm_glds_set_wgrad_sqnorm(_spread): picked up by every weight-gradient launch while set
+int g_wgrad_sq_mask = 0, g_wgrad_sq_stride = 0;
+static inline void set_sq(vglds::GArgs& p) { p.sqacc = g_wgrad_sqacc; p.sq_mask = g_wgrad_sq_mask; p.sq_stride = g_wgrad_sq_stride; }
 
 // Row-major epilogue.  The MFMA result has one COLUMN per lane (16 rows of it), so storing from registers means 4-byte
 // accesses (2-byte for the bf16 copy), two 128-byte row pieces per instruction.  Here the finished tile is parked in
@@ -174,7 +176,7 @@ __device__ __forceinline__ void epilogue_rows(const GArgs& p, const float (&a)[N
         // the gradient norm's share of this tile (every stored element exactly once): one double atomic per workgroup, instead
         // of a separate pass over the 0.5 GB gradient arena (grad_sqnorm_kernel: 45 us per bucket, the last one exposed)
         const float tot = block_sum_256(sqs, cs + BN);
-        if (threadIdx.x == 0) atomicAdd(p.sqacc, (double)tot);
+        if (threadIdx.x == 0) atomicAdd(sq_slot(p), (double)tot);
     }
     if (p.out_colsum) {
 #pragma unroll
@@ -483,7 +485,7 @@ __device__ __forceinline__ void gemm_glds_body(const GArgs& p, const int bid, co
     }
     if (p.sqacc) {
         sqsum = wave_sum(sqsum);
-        if (lane == 0) atomicAdd(p.sqacc, (double)sqsum);
+        if (lane == 0) atomicAdd(sq_slot(p), (double)sqsum);
     }
 }
 
@@ -795,7 +797,7 @@ static int gemm_glds_launch(int a_kcontig, int b_kcontig, const void* A16, long 
     p.tiles_m = cdiv(M, t.bm); p.tiles_n = cdiv(N, t.bn);
     p.xcd_m = xcd_by_rows(M, N);
     p.vec_epi = vec_epilogue_ok(p);
-    if (!a_kcontig && !b_kcontig) p.sqacc = g_wgrad_sqacc;      // the weight-gradient form (dy^T @ x)
+    if (!a_kcontig && !b_kcontig) set_sq(p);      // the weight-gradient form (dy^T @ x)
     if (p.vec_epi) {
         const BtPlan bp = forced ? *forced : bt_plan(M, N, K, a_kcontig, b_kcontig, epi != VITAE_EPI_GELU);
         if (bp.tile >= 0 && bp.split == split_k) {
@@ -917,7 +919,7 @@ extern "C" int vitae_gemm_wsx3(int a_kcontig, int b_kcontig, const float* A, lon
     p.tiles_m = 0; p.tiles_n = 0;
     p.xcd_m = xcd_by_rows(M, N);
     p.vec_epi = vec_epilogue_ok(p);
-    if (!a_kcontig && !b_kcontig) p.sqacc = g_wgrad_sqacc;
+    if (!a_kcontig && !b_kcontig) set_sq(p);
     return wsx3_launch(p, a_kcontig, b_kcontig, (hipStream_t)stream);
 }
 
@@ -984,7 +986,7 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
             p2.M = N; p2.N = K; p2.K = Mpad; p2.k_per_split = Mpad; p2.splits = 1;
             p2.bias = nullptr; p2.residual = nullptr; p2.ldr = 0; p2.aux = nullptr; p2.ldaux = 0; p2.epi = VITAE_EPI_NONE;
             p2.accumulate = dw_accumulate; p2.ws = nullptr; p2.out_colsum = nullptr; p2.a_rowsum = dy_colsum_accum; p2.dbg = nullptr;
-            p2.sqacc = g_wgrad_sqacc;
+            set_sq(p2);
             p2.xcd_m = xcd_by_rows(N, K); p2.tiles_m = 0; p2.tiles_n = 0;
             p2.vec_epi = vec_epilogue_ok(p2);
             if (p1.vec_epi && p2.vec_epi) {
@@ -1037,7 +1039,7 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
     p2.M = N; p2.N = K; p2.K = Mpad; p2.k_per_split = Mpad; p2.splits = 1;
     p2.bias = nullptr; p2.residual = nullptr; p2.ldr = 0; p2.aux = nullptr; p2.ldaux = 0; p2.epi = VITAE_EPI_NONE;
     p2.accumulate = dw_accumulate; p2.ws = nullptr; p2.out_colsum = nullptr; p2.a_rowsum = dy_colsum_accum;
-    p2.sqacc = g_wgrad_sqacc;
+    set_sq(p2);
     const Tile t2 = pick_tile(N, K);
     p2.tiles_m = cdiv(N, t2.bm); p2.tiles_n = cdiv(K, t2.bn);
     p2.xcd_m = xcd_by_rows(N, K);
@@ -1082,7 +1084,7 @@ extern "C" int vitae_wgrad_group_bt(int n, const void* const* dy16, const void* 
         p.M = N[i]; p.N = K[i]; p.K = Mpad; p.k_per_split = Mpad; p.splits = 1;
         p.bias = nullptr; p.residual = nullptr; p.ldr = 0; p.aux = nullptr; p.ldaux = 0; p.epi = VITAE_EPI_NONE;
         p.accumulate = dw_accumulate; p.ws = splitk_ws; p.out_colsum = nullptr; p.a_rowsum = nullptr; p.dbg = nullptr;
-        p.sqacc = g_wgrad_sqacc;
+        set_sq(p);
         p.xcd_m = xcd_by_rows(N[i], K[i]);
         p.tiles_m = cdiv(N[i], 128); p.tiles_n = cdiv(K[i], 128);
         p.vec_epi = vec_epilogue_ok(p);
@@ -1152,4 +1154,13 @@ extern "C" int vitae_gemm_glds_set_debug(void* buf) { g_gemm_dbg = reinterpret_c
 // vitae_gemm_glds in its dy^T @ x form — adds the sum of squares of the gradient tile it stores to *slot (a double: the caller's
 // acc[VITAE_ACC_GRADSQ]).  Process-global launch-time state of the (single) thread that issues the step; captured graphs keep
 // the value it had at capture.  Not for split-K wgrads (the paired launch never splits its wgrad half).
-extern "C" int vitae_gemm_glds_set_wgrad_sqnorm(double* slot) { g_wgrad_sqacc = slot; return VITAE_OK; }
+extern "C" int vitae_gemm_glds_set_wgrad_sqnorm(double* slot) { g_wgrad_sqacc = slot; g_wgrad_sq_mask = 0; g_wgrad_sq_stride = 0; return VITAE_OK; }
+// The same over n_slots (a power of two) addresses `stride` doubles apart: workgroup b adds to slots[(b mod n_slots) * stride].  Double
+// atomics on ONE address retire one per ~10 ns whoever issues them (tools/pair_bench.py, round 6: the 576 weight-gradient workgroups of
+// an encoder fc2 launch spent 5.8 of their 16 us there); the step's accumulator block carries VITAE_ACC_SQ_SLOTS such slots and
+// vitae_grad_norm_finalize / vitae_opt_tail sum them.
+extern "C" int vitae_gemm_glds_set_wgrad_sqnorm_spread(double* slots, int n_slots, int stride) {
+    if (slots && (n_slots < 1 || (n_slots & (n_slots - 1)) || stride < 1)) return VITAE_ERR_INVALID_ARG;
+    g_wgrad_sqacc = slots; g_wgrad_sq_mask = slots ? n_slots - 1 : 0; g_wgrad_sq_stride = slots ? stride : 0;
+    return VITAE_OK;
+}

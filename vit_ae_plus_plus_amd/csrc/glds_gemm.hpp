@@ -25,7 +25,10 @@ struct GArgs {
     int vec_epi;         // all epilogue arrays are 16-byte addressable by 4-column groups (N, the leading dimensions and the
                          // base pointers allow it): the tile goes through LDS and leaves row-major, 16 bytes per lane
     int tiles_m, tiles_n;
-    double* sqacc = nullptr;     // optional: *sqacc += sum of squares of the stored result (the gradient norm's share of a wgrad)
+    double* sqacc = nullptr;     // optional: the sum of squares of the stored result (the gradient norm's share of a wgrad) is added to
+                                 // sqacc[(blockIdx.x & sq_mask) * sq_stride] — ONE address (mask 0) or spread slots: same-address double
+                                 // atomics retire one per ~10 ns (round 6: 576 of them were 5.8 of the 16 us of a weight-gradient launch)
+    int sq_mask = 0, sq_stride = 0;
     int tile0 = 0;               // index of this problem's first tile among the tickets / partial tiles of a grouped launch
     int aux16 = 0;               // aux holds bf16 (VITAE_EPI_AUX_BF16): the saved GELU pre-activation at half the bytes
     int exact = 0;               // GELU / GELU' through erff (the fp32-grade modes) instead of the 1.5e-7 polynomial
@@ -36,6 +39,9 @@ struct GArgs {
     int xcd_m;           // 0: an XCD owns column tiles tn = xcd (mod 8) and walks every row tile (its L2 holds 1/8 of B and all
                          // of A); 1: it owns row tiles tm = xcd (mod 8) instead — picked when A is the larger operand
 };
+
+// where this workgroup adds its share of the gradient norm
+__device__ __forceinline__ double* sq_slot(const GArgs& p) { return p.sqacc + (long)((int)blockIdx.x & p.sq_mask) * p.sq_stride; }
 
 // workgroups of one launch (per k-split) under either XCD mapping
 inline int glds_blocks(const GArgs& p) {

@@ -24,6 +24,11 @@ template <> __device__ __forceinline__ f32x4 grad4<__bf16>(const __bf16* g, long
     return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
 }
 
+// where workgroup b adds its share of the squared gradient norm: spread slots (same-address double atomics retire one per ~10 ns)
+__device__ __forceinline__ double* gradsq_slot(double* acc) {
+    return acc + VITAE_ACC_SQ_BASE + ((int)blockIdx.x & (VITAE_ACC_SQ_SLOTS - 1)) * VITAE_ACC_SQ_STRIDE;
+}
+
 template <typename G>
 __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const G* __restrict__ g, long n, double* __restrict__ acc) {
     __shared__ float red[4];
@@ -35,11 +40,17 @@ __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const G* __restrict__ 
     }
     if (blockIdx.x == 0) for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) s += (float)g[i] * (float)g[i];
     s = block_sum_256(s, red);
-    if (threadIdx.x == 0) atomicAdd(acc + VITAE_ACC_GRADSQ, (double)s);
+    if (threadIdx.x == 0) atomicAdd(gradsq_slot(acc), (double)s);
 }
 
-__global__ void grad_norm_finalize_kernel(const double* __restrict__ acc, float* __restrict__ out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = (float)sqrt(acc[VITAE_ACC_GRADSQ]);
+// one wave: lane s reads spread slot s (vitae_hip.h VITAE_ACC_SQ_*), lane 0 adds acc[GRADSQ]
+__global__ __launch_bounds__(64) void grad_norm_finalize_kernel(const double* __restrict__ acc, float* __restrict__ out) {
+    static_assert(VITAE_ACC_SQ_SLOTS == 64, "one slot per lane");
+    double v = acc[VITAE_ACC_SQ_BASE + threadIdx.x * VITAE_ACC_SQ_STRIDE];
+    if (threadIdx.x == 0) v += acc[VITAE_ACC_GRADSQ];
+#pragma unroll
+    for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d, 64);
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = (float)sqrt(v);
 }
 
 // 1 - beta^t on the device.  A NEGATIVE slot carries -(1 - beta) from the host's double (relative error 6e-8; fp32(0.999) itself is
@@ -147,15 +158,18 @@ __global__ __launch_bounds__(256) void opt_tail_norm_kernel(const G* __restrict_
     if (blockIdx.x == 0) for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) s += (float)g[i] * (float)g[i];
     s = block_sum_256(s, red);
     if (threadIdx.x == 0) {
-        atomicAdd(acc + VITAE_ACC_GRADSQ, (double)s);
+        atomicAdd(gradsq_slot(acc), (double)s);
         __threadfence();
         last = atomicAdd(reinterpret_cast<int*>(acc + VITAE_ACC_TICKET_A), 1) == (int)gridDim.x - 1;
     }
     __syncthreads();
-    if (last && threadIdx.x == 0) {
-        // every other workgroup's double atomic is ordered before its ticket: read the total through the atomic unit too
-        const double tot = atomicAdd(acc + VITAE_ACC_GRADSQ, 0.0);
-        out[0] = (float)sqrt(tot);
+    if (last && threadIdx.x < 64) {
+        // every other workgroup's double atomic is ordered before its ticket: read the slots through the atomic unit too
+        double tot = atomicAdd(acc + VITAE_ACC_SQ_BASE + threadIdx.x * VITAE_ACC_SQ_STRIDE, 0.0);
+        if (threadIdx.x == 0) tot += atomicAdd(acc + VITAE_ACC_GRADSQ, 0.0);
+#pragma unroll
+        for (int d = 32; d; d >>= 1) tot += __shfl_xor(tot, d, 64);
+        if (threadIdx.x == 0) out[0] = (float)sqrt(tot);
     }
 }
 
@@ -226,7 +240,7 @@ __global__ __launch_bounds__(256) void step_prologue_kernel(float* __restrict__ 
     const float* src = ring + (s % slots) * VITAE_HP_COUNT;      // pinned host memory, read over the link (64 bytes)
     if (blockIdx.x == 0) {
         if (threadIdx.x < VITAE_HP_HOST_COUNT) hp[threadIdx.x] = src[threadIdx.x];
-        if (threadIdx.x >= 64 && threadIdx.x < 64 + VITAE_ACC_COUNT) acc[threadIdx.x - 64] = 0.0;
+        for (int i = threadIdx.x; i < VITAE_ACC_COUNT; i += 256) acc[i] = 0.0;
     }
     const long tid = (long)blockIdx.x * 256 + threadIdx.x, nth = (long)gridDim.x * 256;
     if (noise && src[VITAE_HP_NOISE_KEEP] == 0.f) {

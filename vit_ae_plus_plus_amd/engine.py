@@ -1680,7 +1680,13 @@ class HipMAEEngine:
         cfg = self.cfg
         n, nd = self.enc_chunks, self.dec_chunks
         self._epi_norm_on = bool(self.epi_norm and update and self._optimizer_in_backward_ok())
-        lib.vitae_gemm_glds_set_wgrad_sqnorm(self.acc.data_ptr() + 8 * _C['VITAE_ACC_GRADSQ'] if self._epi_norm_on else None)
+        if self._epi_norm_on and os.environ.get('VITAE_SQ_SPREAD', '1') == '0':      # (A/B knob: everything on acc[GRADSQ], the form up to round 5)
+            lib.vitae_gemm_glds_set_wgrad_sqnorm(self.acc.data_ptr() + 8 * _C['VITAE_ACC_GRADSQ'])
+        elif self._epi_norm_on:    # (spread slots: same-address double atomics retire one per ~10 ns — 576 of them per weight-gradient launch)
+            lib.vitae_gemm_glds_set_wgrad_sqnorm_spread(self.acc.data_ptr() + 8 * _C['VITAE_ACC_SQ_BASE'], _C['VITAE_ACC_SQ_SLOTS'],
+                                                        _C['VITAE_ACC_SQ_STRIDE'])
+        else:
+            lib.vitae_gemm_glds_set_wgrad_sqnorm(None)
         try:
             self._train_phase(k, view1, view2, noise, mask_ratio, update, accumulate)
         finally:
