@@ -233,7 +233,7 @@ def roofline_block(args, recs, overhead_ms, ms_step, world):
     ach = d_fl / (d_ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS[args.precision]
     traffic, tnote, rp_us, mfma_busy = None, None, None, None   # PMC counters cannot be read in-process: last committed rocprofv3 --pmc result
-    for name in ('round5_gemm_traffic.json', 'round4_gemm_traffic.json', 'round3_gemm_traffic.json', 'round2_gemm_traffic.json', 'round1_gemm_traffic.json'):
+    for name in ('round6_gemm_traffic.json', 'round5_gemm_traffic.json', 'round4_gemm_traffic.json', 'round3_gemm_traffic.json', 'round2_gemm_traffic.json', 'round1_gemm_traffic.json'):
         tfile = os.path.join(ROOT, 'profiles', name)
         if args.precision == 'bf16' and args.batch == 4 and os.path.exists(tfile):
             tj = json.load(open(tfile))
@@ -248,7 +248,8 @@ def roofline_block(args, recs, overhead_ms, ms_step, world):
     sec = ms_step * 1e-3
     return {'bound': 'mfma', 'kernel': KNAMES.get(dom, dom), 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
             'frac': round(ach / peak, 4), 'traffic': traffic, 'traffic_unit': tnote,
-            'mfma_busy_frac': mfma_busy, 'mfma_busy_note': 'matrix-pipe busy cycles of that kernel (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES, committed pass) / (1024 SIMDs x its duration x 2.4 GHz)',
+            # (NOT measured by this run: PMC counters cannot be read in-process — the value of the last committed rocprofv3 --pmc pass)
+            'mfma_busy_frac_committed_profile': mfma_busy, 'mfma_busy_note': 'matrix-pipe busy cycles of that kernel (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES, committed pass) / (1024 SIMDs x its duration x 2.4 GHz)',
             'launches_per_step': d_n / n, 'gflop_per_launch': round(d_fl / d_n / 1e9, 3), 'avg_launch_us': round(d_ms * 1e3 / d_n, 2),
             'avg_launch_us_events_raw': round(d_raw * 1e3 / d_n, 2), 'event_pair_overhead_us': round(overhead_ms * 1e3, 2),
             # the same kernel's mean in the committed rocprofv3 profile and the fraction it gives (graph replays: launches beside an
@@ -267,8 +268,8 @@ def roofline_block(args, recs, overhead_ms, ms_step, world):
 def _committed_b8_mfma_busy():
     """MFMA-busy share of the GEMM + attention kernels of a batch-8 step from the committed counter pass (profiles/round5_pmc_sq_b8.json,
     tools/probes/refresh_profiles_r5.sh): sum of busy cycles / (1024 SIMDs x sum of durations x 2.4 GHz).  None when the file is absent."""
-    f = os.path.join(ROOT, 'profiles', 'round5_pmc_sq_b8.json')
-    if not os.path.exists(f):
+    f = next((q for q in (os.path.join(ROOT, 'profiles', n) for n in ('round6_pmc_sq_b8.json', 'round5_pmc_sq_b8.json')) if os.path.exists(q)), None)
+    if f is None:
         return None
     try:
         return json.load(open(f)).get('gemm_attn_mfma_busy_frac')
@@ -293,7 +294,7 @@ def encoder_attn_mlp_point(args, dev, model, eng, contr, batch=8):
              'gflop_reference_formulation_one_view': round(batch * ENC_ATTN_MLP_GFLOP_PER_VOL, 1), 'views': views,
              'sum_kernel_ms': round(ms, 3), 'achieved': round(fl / (ms * 1e-3) / 1e12, 1), 'peak': peak, 'unit': 'TFLOP/s',
              'frac': round(fl / (ms * 1e-3) / 1e12 / peak, 4), 'target_frac': 0.40,
-             'mfma_busy_frac': _committed_b8_mfma_busy(),
+             'mfma_busy_frac_committed_profile': _committed_b8_mfma_busy(),
              'event_pair_overhead_us': round(ov * 1e3, 2)})
 
 
@@ -357,6 +358,43 @@ def patch8_point(args, dev):
             'gemm_attn_gflop_executed_per_step': round(k_fl / 1e9, 1), 'gemm_attn_kernel_ms_per_step': round(k_ms, 3),
             'gemm_attn_frac_of_peak': round(k_fl / (k_ms * 1e-3) / 1e12 / peak, 4),
             'by_kernel': {k: {'ms': round(v[0], 3), 'tflops': round(v[1] / (v[0] * 1e-3) / 1e12, 1), 'launches': v[2]} for k, v in fam.items()}}
+
+
+def other_config_point(args, dev, which):
+    """BASELINE configs 4 and 5 through the same fused step / graph replay (parity cases elsewhere: tests/test_gpu_model.py
+    ::test_config4_vit_large_128, ::test_config5_anisotropic_egd_shape): config 4 = mae_vit_large_patch16 on 128^3 x 4ch
+    (model/vit_autoenc.py:288-293: 513 decoder tokens, 129 kept), config 5 = mae_vit_base_patch16 on EGD-shape 192 x 192 x 32 x 1ch
+    volumes (the non-cubic patch grid 12 x 12 x 2).  GFLOP per volume of the reference formulation: BASELINE.md section 4."""
+    from vit_ae_plus_plus_amd.model import vit_autoenc as VA
+    from vit_ae_plus_plus_amd.optim import FusedAdamW
+    c = {4: dict(ctor='mae_vit_large_patch16', vol=(128, 128, 128), ch=4, gflop=406.8, batch=4,
+                 label='BASELINE config 4: ViT-L/16 MAE, 128^3 x 4ch'),
+         5: dict(ctor='mae_vit_base_patch16', vol=(192, 192, 32), ch=1, gflop=94.8, batch=4,
+                 label='BASELINE config 5: ViT-B/16 MAE, EGD-shape 192 x 192 x 32 x 1ch (per-rank workload)')}[which]
+    model = getattr(VA, c['ctor'])(volume_size=c['vol'][0] if which == 4 else c['vol'], in_chans=c['ch'], patch_size=16,
+                                   args=argparse.Namespace(use_imagenet=False, perceptual_weight=0), precision=args.precision).to(dev).train()
+    eng = model._ensure_engine(dev)
+    opt = FusedAdamW(model, lr=1e-4, weight_decay=0.05, betas=(0.9, 0.95)); _ = opt.engine
+    eng.set_loss_weights(0.01, 0.0, 1, 1)
+    B = c['batch']
+    g = torch.Generator(device=dev).manual_seed(1)
+    vols = [torch.randn(B, c['ch'], *c['vol'], device=dev, generator=g) for _ in range(3)]
+    runner = model._step_runner(B, 0.75, True, False, not args.no_graph)
+    warm, steps = 2 * len(vols) + 2, 10
+    for i in range(warm + steps):
+        if i == warm:
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+        runner.load(vols[i % 3], None); eng.optimizer_hparams(lr=1e-4); runner.run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    out = {'model': c['label'], 'batch': B, 'params_m': round(sum(q.numel() for q in model.parameters() if q.requires_grad) / 1e6, 1),
+           'value': round(B / dt, 2), 'unit': 'volumes/s', 'ms_per_step': round(dt * 1e3, 3), 'steps': steps,
+           'gflop_per_volume_reference_formulation': c['gflop'],
+           'step_frac_of_peak_reference_formulation': round(c['gflop'] * B / dt / 1e3 / PEAK_TFLOPS[args.precision], 4),
+           'final_losses': [round(x, 5) for x in eng.losses.cpu().tolist()[:3]]}
+    del model, eng, opt, runner, vols
+    torch.cuda.empty_cache()
+    return out
 
 
 def epoch_loop_point(args, dev, bare_ms):
@@ -644,6 +682,12 @@ def main():
             extra['also_p8'] = patch8_point(args, dev)
         except Exception as e:
             extra['also_p8'] = {'error': repr(e)[:200]}
+    if single and args.patch == 16:
+        for which in (4, 5):      # the two BASELINE configs that had no throughput figure
+            try:
+                extra[f'also_cfg{which}'] = other_config_point(args, dev, which)
+            except Exception as e:
+                extra[f'also_cfg{which}'] = {'error': repr(e)[:200]}
 
     cpu, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITAE_ABI_VERSION 46
+#define VITAE_ABI_VERSION 47
 
 /* matrix-core arithmetic of the dense contractions */
 #define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
@@ -454,6 +454,13 @@ int vitae_adamw_step(float* params, const float* grads, float* exp_avg, float* e
 int vitae_grad_sqnorm_bf16(const void* grads_bf16, long n, double* acc, float* norm_out, void* stream);
 int vitae_adamw_step_bf16g(float* params, const void* grads_bf16, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
                            long n, const float* hp, const float* grad_norm, float weight_decay, void* stream);
+/* Round 6: the same pass with BOTH moments stored in bf16 (22 instead of 30 bytes of HBM traffic per parameter).  The step is computed
+ * in fp32 from the stored values and m_new / v_new enter the parameter update unrounded; only what is written back is rounded
+ * (tools/opt_state_ablation.py: the reference's pinned ViT-B trajectory moves by 2e-7..2e-6).  The caller must keep 1 - beta >= 2^-6
+ * for both betas (a smaller update would stall under round-to-nearest); grads: fp32, or the bf16 wire copy when grads_bf16 != 0.
+ * vitae_opt_tail takes the same storage through its state_bf16 flag. */
+int vitae_adamw_step_s16(float* params, const void* grads, int grads_bf16, void* exp_avg_bf16, void* exp_avg_sq_bf16,
+                         void* shadow_bf16, long n, const float* hp, const float* grad_norm, float weight_decay, void* stream);
 /* hp[VITAE_HP_STEP] += 1 unless grad_norm[0] is not finite: the end of an optimiser step issued as separate vitae_adamw_step calls */
 int vitae_opt_count_bump(float* hp, const float* grad_norm, void* stream);
 /* The tail of one optimisation step in TWO launches (was: norm pass, finalisation, two AdamW launches): the last n_decay +
@@ -462,7 +469,7 @@ int vitae_opt_count_bump(float* hp, const float* grad_norm, void* stream);
  * norm_out[0] = sqrt(acc[GRADSQ]): the global gradient norm of utils/misc.py:265-266; (2) AdamW over both segments, skipped
  * when that norm is not finite; the last workgroup (acc[VITAE_ACC_TICKET_B]) bumps hp[VITAE_HP_STEP].  grads: fp32, or bf16 when
  * grads_bf16 != 0 (the wire copy of a bf16 gradient exchange).  All pointers at the first of the n_decay elements. */
-int vitae_opt_tail(float* params, const void* grads, int grads_bf16, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
+int vitae_opt_tail(float* params, const void* grads, int grads_bf16, void* exp_avg, void* exp_avg_sq, int state_bf16, void* shadow_bf16,
                    long n_decay, long n_plain, float* hp, double* acc, float* norm_out, float weight_decay, void* stream);
 /* The head of one optimisation step as ONE launch inside the captured step (was, between two graph replays: torch's uniform_,
  * a host-to-device copy of hp, and two zeroing launches): hp[0 .. VITAE_HP_HOST_COUNT) <- hp_ring[(*step_seq) % ring_slots] (a

@@ -673,13 +673,54 @@ B4_LOSS_RTOL_STEP0, B4_LOSS_RTOL_LATER, B4_EDGE_RTOL, B4_CONTR_RTOL, B4_GRAD_RTO
 # <= 6.4e-4, contrastive term (magnitude 1e-5) <= 5.7e-3, gradient norms <= 1.2e-3; the fp32 mode: everything <= 7e-7)
 
 
+def test_two_plane_weights_follow_the_bucketed_optimiser():
+    """the two-plane forward reads BOTH planes of a weight from ``hilo`` (never the bf16 shadow), and the only thing that
+    keeps them current is ``refresh_w2`` behind every AdamW bucket.  After fused steps with the optimiser inside the backward the hi
+    plane must equal the shadow bit for bit and the lo plane bf16(W - hi); a range that cuts through a two-plane tensor is refused
+    instead of silently leaving it stale."""
+    from vit_ae_plus_plus_amd.optim import FusedAdamW
+    from vit_ae_plus_plus_amd._abi import VitaeError
+    cfg = R.vit_base_cfg(contrastive=True, **VITB)
+    model = build(cfg, R.init_state_dict(cfg, seed=0), precision='bf16').train()
+    opt = FusedAdamW(model, lr=1e-3, weight_decay=0.05, betas=(0.9, 0.95))
+    model._ensure_engine(torch.device('cuda', 0))
+    eng = opt.engine
+    assert eng._w2, 'bf16 mode carries two-plane weights by default (decoder fc1)'
+    eng.set_loss_weights(0.01, 0.001, 1)
+    B = 2
+    runner = model._step_runner(B, 0.75, True, False, True)
+    for it in range(3):
+        v1, v2 = R.synthetic_views((B, cfg.in_chans, *cfg.volume_size), seed=50 + it)
+        model.set_masking_noise(*R.masking_noise(B, cfg.num_patches, seed=60 + it))
+        runner.load(v1.cuda(), v2.cuda())
+        eng.optimizer_hparams(lr=1e-3)
+        runner.run()
+    torch.cuda.synchronize()
+    for name, hilo in eng._w2.items():
+        K = hilo.shape[1] // 2
+        w, hi, lo = eng.p[name], hilo[:, :K], hilo[:, K:]
+        assert torch.equal(hi, eng.p16[name]), name                              # the plane the forward multiplies by IS the shadow's value
+        assert torch.equal(hi, w.to(torch.bfloat16)), name                       # ... and the shadow follows the master
+        assert torch.equal(lo, (w - hi.float()).to(torch.bfloat16)), name
+        assert float((w - R.init_state_dict(cfg, seed=0)[name].cuda()).abs().max()) > 0      # (the weights did move)
+    off0, ln, stride, count = eng._w2_groups[0][:4]
+    with pytest.raises(VitaeError):
+        eng.refresh_w2(lo=off0 + 4, hi=off0 + stride * count)                    # cuts through the first tensor
+    with pytest.raises(VitaeError):
+        eng.refresh_w2(lo=0, hi=off0 + ln // 2)
+    eng.refresh_w2(lo=off0, hi=off0 + ln)                                         # exactly one tensor: fine
+    eng.refresh_w2(lo=0, hi=off0)                                                 # nothing touched: fine
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize('precision', ['bf16', 'fp32', 'fp32x3'])   # fp32x3 (split-operand bf16 MFMA) is held to the fp32 mode's bounds
-def test_bench_workload_b4_fused_graph_vs_reference_pins(precision):
+def test_bench_workload_b4_fused_graph_vs_reference_pins(precision, monkeypatch):
     """BASELINE config 2 at the batch the metric is quoted on (B = 4, contrastive ViT-B/16, 96^3 x 4ch) through the
     route bench.py times — the fused optimisation step replayed from a HIP graph: first-step loss scalars, per-parameter
     gradient norms and the loss trajectory of three AdamW steps against pins from the reference's own model (SURVEY §8c
     item 2; reference model/vit_autoenc.py:205-238, utils/train_one_epoch.py:52-75)."""
     from vit_ae_plus_plus_amd.optim import FusedAdamW
+    monkeypatch.setenv('VITAE_W2', 'dec.fc1')      # the bf16 bounds below were recorded with this class on two planes (the default): pinned (ADVICE r5)
     g = load_golden('vitb_b4.npz')
     B, steps, lr, wd, mask_ratio, edge_w, contr_w = [float(v) for v in g['hp']]
     B, steps = int(B), int(steps)

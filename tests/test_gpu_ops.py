@@ -906,6 +906,65 @@ def test_adamw_and_gradnorm(lib, C):
     assert torch.equal(p, before)
 
 
+def test_adamw_bf16_moments(lib, C):
+    """vitae_adamw_step_s16 / vitae_opt_tail(state_bf16=1) (round 6): both moments STORED in bf16, the step computed in fp32 from the
+    stored values with the unrounded m_new / v_new in the parameter update — against exactly that arithmetic in torch, over four
+    steps, with fp32 and with bf16 gradients; the parameters stay within fp32 round-off of the emulation and within 1e-3 of the
+    update size of a plain fp32-state AdamW."""
+    n = 100_003
+    npad = (n + 3) // 4 * 4
+    gen_ = torch.Generator(device='cuda').manual_seed(5)
+    p0 = torch.randn(npad, device='cuda', generator=gen_) * 0.02
+    lr, b1, b2, eps, wd = 3e-4, 0.9, 0.95, 1e-8, 0.05
+    hp = torch.zeros(C['VITAE_HP_COUNT'], device='cuda')
+    hp[C['VITAE_HP_LR']], hp[C['VITAE_HP_BETA1']], hp[C['VITAE_HP_BETA2']], hp[C['VITAE_HP_EPS']], hp[C['VITAE_HP_GRAD_MUL']] = lr, b1, b2, eps, 1.0
+    # the kernel's coefficients: 1 - beta formed in fp32 from the fp32 beta (with bf16 gradients many results sit next to a bf16 rounding
+    # boundary, and the 2e-7 between fp32(1 - beta) and 1 - fp32(beta) would flip a few per cent of them)
+    f32 = lambda x: torch.tensor(x, dtype=torch.float32)
+    omb1, omb2, b2f = float(f32(1.0) - f32(b1)), float(f32(1.0) - f32(b2)), float(f32(b2))
+    for g_bf16 in (False, True):
+        p, sh = p0.clone(), torch.zeros(npad, dtype=torch.bfloat16, device='cuda')
+        m16, v16 = torch.zeros(npad, dtype=torch.bfloat16, device='cuda'), torch.zeros(npad, dtype=torch.bfloat16, device='cuda')
+        rp, rm, rv = p0.clone(), torch.zeros(npad, device='cuda'), torch.zeros(npad, device='cuda')
+        fp, fm, fv = p0.clone(), torch.zeros(npad, device='cuda'), torch.zeros(npad, device='cuda')       # plain fp32-state AdamW
+        for t in range(1, 5):
+            g = torch.randn(npad, device='cuda', generator=gen_) * 0.01
+            if g_bf16:
+                g16 = g.to(torch.bfloat16); g = g16.float()
+            bc1, bc2 = 1 - b1 ** t, 1 - b2 ** t
+            hp[C['VITAE_HP_BC1']], hp[C['VITAE_HP_BC2']] = bc1, bc2
+            lib.vitae_adamw_step_s16(p.data_ptr(), (g16 if g_bf16 else g).data_ptr(), 1 if g_bf16 else 0, m16.data_ptr(), v16.data_ptr(), sh.data_ptr(),
+                                     n, hp.data_ptr(), None, wd, st())
+            for (qp, qm, qv, rnd) in ((rp, rm, rv, True), (fp, fm, fv, False)):
+                mn = qm + omb1 * (g - qm)
+                vn = b2f * qv + omb2 * g * g
+                qp.mul_(1 - lr * wd).sub_((lr / bc1) * (mn / (vn.sqrt() / bc2 ** 0.5 + eps)))
+                qm.copy_(mn.to(torch.bfloat16).float() if rnd else mn); qv.copy_(vn.to(torch.bfloat16).float() if rnd else vn)
+            # (against the emulation: equal up to the few elements whose fp32 moment straddles a bf16 rounding boundary — there the
+            # stored values differ by one ulp and so does a 2^-8 share of the next update)
+            assert float((p[:n] - rp[:n]).norm()) < 5e-4 * float((rp[:n] - p0[:n]).norm())
+            assert torch.equal(sh[:n], p[:n].to(torch.bfloat16))
+            # stored moments: the emulation's value, up to one bf16 ulp where the fp32 results straddle a rounding boundary
+            for got, want in ((m16, rm), (v16, rv)):
+                d = got[:n].float() - want[:n]
+                assert float(d.norm()) < 5e-4 * float(want[:n].norm()) and float((d != 0).float().mean()) < 2e-2
+        upd = float((fp[:n] - p0[:n]).norm())
+        assert float((p[:n] - fp[:n]).norm()) < 3e-3 * upd          # bf16 moments vs fp32 moments: a 2^-9-sized wobble of the update
+    # the tail launcher with bf16 moments: the same arithmetic on its two segments (decayed, plain), the step count bumped
+    nd, npl = 1024, 2048
+    p, g = p0[:nd + npl].clone(), torch.randn(nd + npl, device='cuda', generator=gen_) * 0.01
+    m16, v16 = torch.zeros(nd + npl, dtype=torch.bfloat16, device='cuda'), torch.zeros(nd + npl, dtype=torch.bfloat16, device='cuda')
+    acc, gn = torch.zeros(C['VITAE_ACC_COUNT'], dtype=torch.float64, device='cuda'), torch.zeros(1, device='cuda')
+    hp[C['VITAE_HP_BC1']], hp[C['VITAE_HP_BC2']], hp[C['VITAE_HP_STEP']] = 1 - b1, 1 - b2, 0.0
+    lib.vitae_opt_tail(p.data_ptr(), g.data_ptr(), 0, m16.data_ptr(), v16.data_ptr(), 1, None, nd, npl, hp.data_ptr(), acc.data_ptr(), gn.data_ptr(), wd, st())
+    want = p0[:nd + npl].clone()
+    want[:nd] *= 1 - lr * wd
+    mn, vn = (1 - b1) * g, (1 - b2) * g * g
+    want -= (lr / (1 - b1)) * (mn / (vn.sqrt() / (1 - b2) ** 0.5 + eps))
+    assert rel_err(p, want) < 2e-6 and abs(float(gn) - float(g.norm())) < 1e-5 * float(g.norm()) and float(hp[C['VITAE_HP_STEP']]) == 1.0
+    assert torch.equal(m16, mn.to(torch.bfloat16)) and rel_err(v16.float(), vn) < 2.0 ** -8
+
+
 def test_adamw_and_gradnorm_from_bf16_gradients(lib, C):
     """The bf16-gradient entry points (reduced gradients consumed from the all-reduce's wire buffer) equal the fp32
     ones applied to the same bf16-rounded values, bit for bit."""

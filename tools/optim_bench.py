@@ -11,7 +11,7 @@ sh = torch.empty(n, dtype=torch.bfloat16, device='cuda')
 hp = torch.zeros(C['VITAE_HP_COUNT'], device='cuda')
 hp[C['VITAE_HP_LR']] = 1e-4; hp[C['VITAE_HP_BETA1']] = 0.9; hp[C['VITAE_HP_BETA2']] = 0.95; hp[C['VITAE_HP_EPS']] = 1e-8
 hp[C['VITAE_HP_BC1']] = 0.1; hp[C['VITAE_HP_BC2']] = 0.05; hp[C['VITAE_HP_GRAD_MUL']] = 1.0
-acc = torch.zeros(8, dtype=torch.float64, device='cuda'); gn = torch.zeros(1, device='cuda')
+acc = torch.zeros(C['VITAE_ACC_COUNT'], dtype=torch.float64, device='cuda'); gn = torch.zeros(1, device='cuda')
 st = torch.cuda.current_stream().cuda_stream
 def t(fn, k=10):
     for _ in range(2): fn()
@@ -22,6 +22,9 @@ def t(fn, k=10):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / k * 1e3
 us = t(lambda: lib.vitae_adamw_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), sh.data_ptr(), n, hp.data_ptr(), None, 0.05, st))
-print(f'adamw {us:.1f} us  {n * 30 / us / 1e6:.2f} TB/s')
+print(f'adamw, fp32 moments {us:.1f} us  {n * 30 / us / 1e6:.2f} TB/s (30 B per parameter)')
+m16, v16 = m.to(torch.bfloat16), v.to(torch.bfloat16)
+us = t(lambda: lib.vitae_adamw_step_s16(p.data_ptr(), g.data_ptr(), 0, m16.data_ptr(), v16.data_ptr(), sh.data_ptr(), n, hp.data_ptr(), None, 0.05, st))
+print(f'adamw, bf16 moments {us:.1f} us  {n * 22 / us / 1e6:.2f} TB/s (22 B per parameter)')
 us = t(lambda: lib.vitae_grad_sqnorm(g.data_ptr(), n, acc.data_ptr(), gn.data_ptr(), st))
 print(f'gradnorm {us:.1f} us  {n * 4 / us / 1e6:.2f} TB/s')

@@ -47,10 +47,15 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, float v, int m
     const int kind = p.epi & 15;
     const bool auxd = (p.epi & VITAE_EPI_AUX_DERIV) != 0;      // aux holds GELU'(pre-activation) instead of the pre-activation
     if (kind == VITAE_EPI_GELU) {
-        float y, dy;
-        gelu_erf_both(v, y, dy);
-        p.aux[(long)m * p.ldaux + n] = auxd ? dy : v;
-        v = y;
+        if (auxd) {                                            // (the pdf's exp only when the derivative is what gets saved)
+            float y, dy;
+            gelu_erf_both(v, y, dy);
+            p.aux[(long)m * p.ldaux + n] = dy;
+            v = y;
+        } else {
+            p.aux[(long)m * p.ldaux + n] = v;
+            v = gelu_erf(v);
+        }
     } else if (kind == VITAE_EPI_DGELU) {
         const float a = p.aux[(long)m * p.ldaux + n];
         v *= auxd ? a : gelu_erf_grad(a);
@@ -232,6 +237,7 @@ extern "C" int vitae_gemm(int prec, int a_kcontig, int b_kcontig,
     if (prec != 0 && prec != 1) return VITAE_ERR_INVALID_ARG;
     if (epi != VITAE_EPI_NONE && !aux) return VITAE_ERR_INVALID_ARG;
     if (epi & VITAE_EPI_AUX_BF16) return VITAE_ERR_UNSUPPORTED_SHAPE;      // (fp32 aux only in this family)
+    if ((epi & VITAE_EPI_AUX_DERIV) && (epi & 15) != VITAE_EPI_GELU && (epi & 15) != VITAE_EPI_DGELU) return VITAE_ERR_INVALID_ARG;   // (as vitae_gemm_glds does)
     // 16-byte vector loads run along the contiguous dimension of each operand.
     const int a_vec = a_kcontig ? K : M, b_vec = b_kcontig ? K : N;
     if ((a_vec & 3) || (b_vec & 3) || (lda & 3) || (ldb & 3)) return VITAE_ERR_UNSUPPORTED_SHAPE;

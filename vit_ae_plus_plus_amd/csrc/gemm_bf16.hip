@@ -47,10 +47,15 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, float v, int m
     const int kind = p.epi & 15;
     const bool auxd = (p.epi & VITAE_EPI_AUX_DERIV) != 0;      // aux holds GELU'(pre-activation) instead of the pre-activation
     if (kind == VITAE_EPI_GELU) {
-        float y, dy;
-        gelu_erf_both(v, y, dy);
-        p.aux[(long)m * p.ldaux + n] = auxd ? dy : v;
-        v = y;
+        if (auxd) {                                            // (the pdf's exp only when the derivative is what gets saved)
+            float y, dy;
+            gelu_erf_both(v, y, dy);
+            p.aux[(long)m * p.ldaux + n] = dy;
+            v = y;
+        } else {
+            p.aux[(long)m * p.ldaux + n] = v;
+            v = gelu_erf(v);
+        }
     } else if (kind == VITAE_EPI_DGELU) {
         const float a = p.aux[(long)m * p.ldaux + n];
         v *= auxd ? a : gelu_erf_grad(a);
@@ -361,6 +366,7 @@ extern "C" int vitae_gemm_bf16(int a_kcontig, int b_kcontig, const float* A, lon
     if (a_colsum_accum && !a_kcontig) return VITAE_ERR_INVALID_ARG;
     if (epi != VITAE_EPI_NONE && !aux) return VITAE_ERR_INVALID_ARG;
     if (epi & VITAE_EPI_AUX_BF16) return VITAE_ERR_UNSUPPORTED_SHAPE;      // (fp32 aux only in this family)
+    if ((epi & VITAE_EPI_AUX_DERIV) && (epi & 15) != VITAE_EPI_GELU && (epi & 15) != VITAE_EPI_DGELU) return VITAE_ERR_INVALID_ARG;   // (as vitae_gemm_glds does)
     const int b_epp = b_is_bf16 ? 8 : 4;
     const int a_vec = a_kcontig ? K : M, b_vec = b_kcontig ? K : N;
     if ((a_vec & 3) || (lda & 3) || (b_vec % b_epp) || (ldb % b_epp)) return VITAE_ERR_UNSUPPORTED_SHAPE;
@@ -420,6 +426,7 @@ extern "C" int vitae_gemm_bf16x3(int a_kcontig, int b_kcontig, const float* A, l
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return VITAE_ERR_INVALID_ARG;
     if (epi != VITAE_EPI_NONE && !aux) return VITAE_ERR_INVALID_ARG;
     if (epi & VITAE_EPI_AUX_BF16) return VITAE_ERR_UNSUPPORTED_SHAPE;      // (fp32 aux only in this family)
+    if ((epi & VITAE_EPI_AUX_DERIV) && (epi & 15) != VITAE_EPI_GELU && (epi & 15) != VITAE_EPI_DGELU) return VITAE_ERR_INVALID_ARG;   // (as vitae_gemm_glds does)
     const int a_vec = a_kcontig ? K : M, b_vec = b_kcontig ? K : N;
     if ((a_vec & 3) || (lda & 3) || (b_vec & 3) || (ldb & 3)) return VITAE_ERR_UNSUPPORTED_SHAPE;
     if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return VITAE_ERR_UNSUPPORTED_SHAPE;
@@ -462,6 +469,7 @@ extern "C" int vitae_linear_bwd_pair_bf16(const float* dy, const void* w_bf16, c
     if (!dy || !w_bf16 || !x || !dx || !dw || M <= 0 || N <= 0 || K <= 0) return VITAE_ERR_INVALID_ARG;
     if (epi != VITAE_EPI_NONE && !aux) return VITAE_ERR_INVALID_ARG;
     if (epi & VITAE_EPI_AUX_BF16) return VITAE_ERR_UNSUPPORTED_SHAPE;      // (fp32 aux only in this family)
+    if ((epi & VITAE_EPI_AUX_DERIV) && (epi & 15) != VITAE_EPI_GELU && (epi & 15) != VITAE_EPI_DGELU) return VITAE_ERR_INVALID_ARG;   // (as vitae_gemm_glds does)
     if ((N & 7) || (K & 7)) return VITAE_ERR_UNSUPPORTED_SHAPE;
     if (((uintptr_t)dy & 15) || ((uintptr_t)w_bf16 & 15) || ((uintptr_t)x & 15)) return VITAE_ERR_UNSUPPORTED_SHAPE;
     GemmArgs p1, p2;

@@ -1186,9 +1186,15 @@ __device__ __forceinline__ void gemm_ws64_body(const GArgs& p, const int bid, co
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
+    // tools/ws64_phase_probe.py: s_memtime stamps of consumer wave 0 (slots 0-7) and producer wave 4 (8-15) of every workgroup,
+    // 16 per workgroup indexed by its position in the launch (blockIdx.x + gridDim.x * blockIdx.z)
+    auto stamp = [&](int i) {
+        if (p.dbg && (threadIdx.x & 255) == 0) p.dbg[((long)blockIdx.z * gridDim.x + blockIdx.x) * 16 + i] = __builtin_amdgcn_s_memtime();
+    };
     if (wave >= NWC) {
         // ---------------- producers ----------------
         const int pw = wave - NWC;
+        stamp(8);
         auto issue_tile = [&](int t, int stage) {
             unsigned char* dst = smem + stage * STG;
             const int k0 = kbeg + t * BK;
@@ -1209,7 +1215,9 @@ __device__ __forceinline__ void gemm_ws64_body(const GArgs& p, const int bid, co
         };
         const int npre = min(S - 1, nk);
         for (int t = 0; t < npre; ++t) issue_tile(t, t);
+        stamp(9);                                                        // prologue issued
         wait_tiles(npre - 1);
+        stamp(10);                                                       // first k-tile landed
         barrier();                                                       // B_0
         int stage = npre % S;
 #pragma unroll 1
@@ -1221,6 +1229,7 @@ __device__ __forceinline__ void gemm_ws64_body(const GArgs& p, const int bid, co
             wait_tiles(min(t + S - 1, nk - 1) - (t + 1));
             barrier();                                                   // B_{t+1}
         }
+        stamp(11);                                                       // last k-tile handed over
         return;
     }
     // ---------------- consumers ----------------
@@ -1264,7 +1273,9 @@ __device__ __forceinline__ void gemm_ws64_body(const GArgs& p, const int bid, co
     const int nq = n0 + wn * 32 + 4 * (lane % 8);
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if (p.bias && nq < p.N) bias4 = *reinterpret_cast<const f32x4*>(p.bias + nq);
+    stamp(0);
     barrier();                                                           // B_0
+    stamp(1);
     rd(smem, K0{}); rd(smem, K1{});
     int stage = 0;
 #pragma unroll 1
@@ -1294,6 +1305,7 @@ __device__ __forceinline__ void gemm_ws64_body(const GArgs& p, const int bid, co
             if (m < p.M) atomicAdd(p.a_rowsum + m, accx[r]);
         }
     }
+    stamp(2);                                                            // k-loop done
     f32x16 accs[1][1];
 #pragma unroll
     for (int i = 0; i < 16; ++i) accs[0][0][i] = acc[0][i] + acc[1][i];
@@ -1318,6 +1330,7 @@ __device__ __forceinline__ void gemm_ws64_body(const GArgs& p, const int bid, co
         int* flag = reinterpret_cast<int*>(smem + 4 * 4096);
         if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(reinterpret_cast<int*>(p.ws) + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
+        stamp(3);                                                        // partials parked, ticket taken
         if (*flag != p.splits - 1) return;
 #pragma unroll
         for (int i = 0; i < 16; ++i) accs[0][0][i] = 0.f;
@@ -1342,10 +1355,12 @@ __device__ __forceinline__ void gemm_ws64_body(const GArgs& p, const int bid, co
         }
         if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<int*>(p.ws) + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    stamp(4);                                                            // epilogue starts
     bt_park_quadrant<1, 1, 1>(accs, lane, Tw);
     __builtin_amdgcn_wave_barrier();
     float sqs = 0.f;
     { f32x4 cz = {0.f, 0.f, 0.f, 0.f}; bt_wave_epilogue<1, 1>(p, bt_epilogue_kind(p), m0 + wm * 32, n0 + wn * 32, Tw, lane, sqs, bias4, cz, false); }
+    stamp(5);                                                            // stores issued
     if (p.sqacc) {                                                       // one atomic per workgroup (see bt_tail)
         sqs = wave_sum(sqs);
         float* red = reinterpret_cast<float*>(smem + 4 * 4096 + 64);
@@ -1353,6 +1368,7 @@ __device__ __forceinline__ void gemm_ws64_body(const GArgs& p, const int bid, co
         __syncthreads();
         if (threadIdx.x == 0) atomicAdd(sq_slot(p), (double)((red[0] + red[1]) + (red[2] + red[3])));
     }
+    if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(6); }      // stores drained
 }
 
 template <bool A_KC, bool B_KC>

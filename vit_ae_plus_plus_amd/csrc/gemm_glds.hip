@@ -977,7 +977,7 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
             p1.C = dx; p1.ldc = K; p1.C16 = reinterpret_cast<__bf16*>(dx16); p1.ldc16 = K;
             p1.M = M; p1.N = K; p1.K = N; p1.k_per_split = N; p1.splits = pd.split;
             p1.bias = nullptr; p1.residual = nullptr; p1.ldr = 0; p1.aux = aux; p1.ldaux = K; p1.epi = epi; p1.aux16 = aux16; p1.auxd = auxd;
-            p1.accumulate = dx_accumulate != 0; p1.ws = splitk_ws; p1.out_colsum = dx_colsum_accum; p1.a_rowsum = nullptr; p1.dbg = nullptr;
+            p1.accumulate = dx_accumulate != 0; p1.ws = splitk_ws; p1.out_colsum = dx_colsum_accum; p1.a_rowsum = nullptr; p1.dbg = g_gemm_dbg;
             p1.xcd_m = xcd_by_rows(M, K); p1.tiles_m = 0; p1.tiles_n = 0;
             p1.vec_epi = vec_epilogue_ok(p1);
             p2.A = reinterpret_cast<const __bf16*>(dy16); p2.lda = N;
@@ -985,7 +985,7 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
             p2.C = dw; p2.ldc = K; p2.C16 = reinterpret_cast<__bf16*>(dw16); p2.ldc16 = K;
             p2.M = N; p2.N = K; p2.K = Mpad; p2.k_per_split = Mpad; p2.splits = 1;
             p2.bias = nullptr; p2.residual = nullptr; p2.ldr = 0; p2.aux = nullptr; p2.ldaux = 0; p2.epi = VITAE_EPI_NONE;
-            p2.accumulate = dw_accumulate; p2.ws = nullptr; p2.out_colsum = nullptr; p2.a_rowsum = dy_colsum_accum; p2.dbg = nullptr;
+            p2.accumulate = dw_accumulate; p2.ws = nullptr; p2.out_colsum = nullptr; p2.a_rowsum = dy_colsum_accum; p2.dbg = g_gemm_dbg;
             set_sq(p2);
             p2.xcd_m = xcd_by_rows(N, K); p2.tiles_m = 0; p2.tiles_n = 0;
             p2.vec_epi = vec_epilogue_ok(p2);

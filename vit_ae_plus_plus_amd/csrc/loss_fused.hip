@@ -62,6 +62,8 @@ __device__ __forceinline__ bool piece_of(const Pieces& pc, int& xt, int& yseg, i
     ztile = id % pc.zt; b = id / pc.zt;
     return true;
 }
+// (the knob is read at EVERY launch on purpose — tests/test_gpu_ops.py flips it inside one process to show the results do not
+// depend on the map; a getenv is ~0.1 us of host time per launch.  The 8 is the XCD count of the one chip this library is built for.)
 inline Pieces make_pieces(int xtiles, int nseg, int zt, int B, const char* env, unsigned& grid) {
     const char* e = getenv(env);
     const int on = e ? atoi(e) : 1;

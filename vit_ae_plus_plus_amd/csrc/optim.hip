@@ -61,11 +61,35 @@ __device__ __forceinline__ void device_bias_corrections(float b1, float b2, floa
     bc2 = -expm1f(t * log1pf(-omb2));
 }
 
+// The moments are stored either as fp32 or as bf16 (round 6: `S`).  bf16 moments: the step is COMPUTED in fp32 from the stored
+// values — m_new and v_new enter the parameter update unrounded — and only what is written back for the next step is rounded, so the
+// stored moment carries a relative error of 2^-9 per step that decays with beta (tools/opt_state_ablation.py: the pinned ViT-B
+// trajectory moves by 2e-7..2e-6, an 80-step loss curve by 1e-7, where another masking seed moves it by 1e-3).  8 B per parameter
+// less HBM traffic (30 -> 22).  Round-to-nearest would stall an update smaller than half an ulp: the launchers refuse 1 - beta < 2^-6.
+template <typename S> __device__ __forceinline__ f32x4 state4_ld(const S* s, long i);
+template <> __device__ __forceinline__ f32x4 state4_ld<float>(const float* s, long i) {
+    return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(s) + i);
+}
+template <> __device__ __forceinline__ f32x4 state4_ld<__bf16>(const __bf16* s, long i) {
+    const bf16x4 h = __builtin_nontemporal_load(reinterpret_cast<const bf16x4*>(s) + i);
+    return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+}
+template <typename S> __device__ __forceinline__ void state4_st(S* s, long i, const f32x4 v);
+template <> __device__ __forceinline__ void state4_st<float>(float* s, long i, const f32x4 v) {
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(s) + i);
+}
+template <> __device__ __forceinline__ void state4_st<__bf16>(__bf16* s, long i, const f32x4 v) {
+    bf16x4 h;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) h[e] = (__bf16)v[e];
+    __builtin_nontemporal_store(h, reinterpret_cast<bf16x4*>(s) + i);
+}
+
 // torch.optim.AdamW (single-tensor form): p *= 1 - lr*wd; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
 // p -= (lr / bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
-template <bool NT, typename G, int U = 8>
-__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const G* __restrict__ g, float* __restrict__ m,
-                                                    float* __restrict__ v, __bf16* __restrict__ shadow, long n,
+template <bool NT, typename G, int U = 8, typename S = float>
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const G* __restrict__ g, S* __restrict__ m,
+                                                    S* __restrict__ v, __bf16* __restrict__ shadow, long n,
                                                     const float* __restrict__ hp, const float* __restrict__ gnorm,
                                                     float weight_decay) {
     if (gnorm) { const float gn = gnorm[0]; if (!(gn == gn) || fabsf(gn) == INFINITY) return; }
@@ -80,8 +104,6 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     const float decay = 1.0f - lr * weight_decay, step = lr / bc1;
     const long n4 = n / 4;
     f32x4* p4 = reinterpret_cast<f32x4*>(p);
-    f32x4* m4 = reinterpret_cast<f32x4*>(m);
-    f32x4* v4 = reinterpret_cast<f32x4*>(v);
     // two independent 16-byte groups per thread and iteration: 8 loads in flight before the first dependent use.
     // The moments stream through (nothing re-reads them for a whole step): non-temporal loads and stores keep them
     // from evicting the bf16 shadow / activations out of L2 and the MALL.
@@ -97,8 +119,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
             live[u] = i0 + u * stride < n4;
             idx[u] = live[u] ? i0 + u * stride : i0;
             pp[u] = p4[idx[u]];
-            mm[u] = NT ? __builtin_nontemporal_load(m4 + idx[u]) : m4[idx[u]];
-            vv[u] = NT ? __builtin_nontemporal_load(v4 + idx[u]) : v4[idx[u]];
+            mm[u] = state4_ld<S>(m, idx[u]);
+            vv[u] = state4_ld<S>(v, idx[u]);
             gg[u] = grad4<G>(g, idx[u]);
         }
 #pragma unroll
@@ -114,8 +136,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                 pp[u][e] -= step * (mm[u][e] / (sqrtf(vv[u][e]) / sq_bc2 + eps));
             }
             p4[i] = pp[u];
-            if (NT) { __builtin_nontemporal_store(mm[u], m4 + i); __builtin_nontemporal_store(vv[u], v4 + i); }
-            else { m4[i] = mm[u]; v4[i] = vv[u]; }
+            state4_st<S>(m, i, mm[u]);
+            state4_st<S>(v, i, vv[u]);
             if (shadow) {
                 bf16x4 sh;
 #pragma unroll
@@ -128,10 +150,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) {
             const float gg = (float)g[i] * gs;
             float pp = p[i] * decay;
-            const float mm = m[i] + (1.f - b1) * (gg - m[i]);
-            const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
+            const float mo = (float)m[i];
+            const float mm = mo + (1.f - b1) * (gg - mo);
+            const float vv = b2 * (float)v[i] + (1.f - b2) * gg * gg;
             pp -= step * (mm / (sqrtf(vv) / sq_bc2 + eps));
-            p[i] = pp; m[i] = mm; v[i] = vv;
+            p[i] = pp; m[i] = (S)mm; v[i] = (S)vv;
             if (shadow) shadow[i] = (__bf16)pp;
         }
     }
@@ -173,9 +196,9 @@ __global__ __launch_bounds__(256) void opt_tail_norm_kernel(const G* __restrict_
     }
 }
 
-template <typename G>
-__global__ __launch_bounds__(256) void opt_tail_adamw_kernel(float* __restrict__ p, const G* __restrict__ g, float* __restrict__ m,
-                                                             float* __restrict__ v, __bf16* __restrict__ shadow, long n_decay, long n_plain,
+template <typename G, typename S = float>
+__global__ __launch_bounds__(256) void opt_tail_adamw_kernel(float* __restrict__ p, const G* __restrict__ g, S* __restrict__ m,
+                                                             S* __restrict__ v, __bf16* __restrict__ shadow, long n_decay, long n_plain,
                                                              float* __restrict__ hp, double* __restrict__ acc,
                                                              const float* __restrict__ gnorm, float weight_decay) {
     const float gn = gnorm[0];
@@ -191,7 +214,7 @@ __global__ __launch_bounds__(256) void opt_tail_adamw_kernel(float* __restrict__
         const long n = n_decay + n_plain;                  // both segment lengths are multiples of 4 (arena alignment)
         for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
             const float decay = 1.0f - lr * (i < n_decay ? weight_decay : 0.f);
-            f32x4 pp = *reinterpret_cast<f32x4*>(p + i), mm = *reinterpret_cast<f32x4*>(m + i), vv = *reinterpret_cast<f32x4*>(v + i);
+            f32x4 pp = *reinterpret_cast<f32x4*>(p + i), mm = state4_ld<S>(m, i / 4), vv = state4_ld<S>(v, i / 4);
             const f32x4 gg = grad4<G>(g, i / 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -202,8 +225,8 @@ __global__ __launch_bounds__(256) void opt_tail_adamw_kernel(float* __restrict__
                 pp[e] -= step * (mm[e] / (sqrtf(vv[e]) / sq_bc2 + eps));
             }
             *reinterpret_cast<f32x4*>(p + i) = pp;
-            *reinterpret_cast<f32x4*>(m + i) = mm;
-            *reinterpret_cast<f32x4*>(v + i) = vv;
+            state4_st<S>(m, i / 4, mm);
+            state4_st<S>(v, i / 4, vv);
             if (shadow) {
                 bf16x4 sh;
 #pragma unroll
@@ -295,11 +318,11 @@ extern "C" int vitae_grad_sqnorm_bf16(const void* grads_bf16, long n, double* ac
     return grad_sqnorm_launch<__bf16>(reinterpret_cast<const __bf16*>(grads_bf16), n, acc, norm_out, stream);
 }
 
-template <typename G>
-static int adamw_launch(float* params, const G* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, long n,
+template <typename G, typename S = float>
+static int adamw_launch(float* params, const G* grads, S* exp_avg, S* exp_avg_sq, void* shadow_bf16, long n,
                         const float* hp, const float* grad_norm, float weight_decay, void* stream) {
     if (!params || !grads || !exp_avg || !exp_avg_sq || !hp || n <= 0) return VITAE_ERR_INVALID_ARG;
-    if (((uintptr_t)params | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return VITAE_ERR_INVALID_ARG;
+    if (((uintptr_t)params & 15) || (((uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & (4 * sizeof(S) - 1))) return VITAE_ERR_INVALID_ARG;
     if (((uintptr_t)grads & (4 * sizeof(G) - 1)) || ((uintptr_t)shadow_bf16 & 7)) return VITAE_ERR_INVALID_ARG;
     long blocks = (n / 4 + 255) / 256;
     // one 256-thread workgroup per CU: as fast alone as any larger grid (5.4-5.7 TB/s) and it leaves the CUs' other wave
@@ -313,15 +336,28 @@ static int adamw_launch(float* params, const G* grads, float* exp_avg, float* ex
     // spends less time beside the backward kernels it slows down); 12 and 16 are slower again (5.21 / 5.32 ms)
     static const int unroll = getenv("VITAE_ADAMW_UNROLL") ? atoi(getenv("VITAE_ADAMW_UNROLL")) : 8;
     if (unroll == 4)
-        hipLaunchKernelGGL((adamw_kernel<true, G, 4>), dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
+        hipLaunchKernelGGL((adamw_kernel<true, G, 4, S>), dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
+                           exp_avg_sq, reinterpret_cast<__bf16*>(shadow_bf16), n, hp, grad_norm, weight_decay);
+    else if (unroll == 12)
+        hipLaunchKernelGGL((adamw_kernel<true, G, 12, S>), dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
                            exp_avg_sq, reinterpret_cast<__bf16*>(shadow_bf16), n, hp, grad_norm, weight_decay);
     else if (unroll == 8)
-        hipLaunchKernelGGL((adamw_kernel<true, G, 8>), dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
+        hipLaunchKernelGGL((adamw_kernel<true, G, 8, S>), dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
                            exp_avg_sq, reinterpret_cast<__bf16*>(shadow_bf16), n, hp, grad_norm, weight_decay);
     else
-        hipLaunchKernelGGL((adamw_kernel<true, G, 2>), dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
+        hipLaunchKernelGGL((adamw_kernel<true, G, 2, S>), dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
                            exp_avg_sq, reinterpret_cast<__bf16*>(shadow_bf16), n, hp, grad_norm, weight_decay);
     return vitae_launch_status();
+}
+
+// bf16 moments (round 6): the same pass at 22 instead of 30 bytes per parameter.  grads: fp32, or the bf16 wire copy when grads_bf16.
+extern "C" int vitae_adamw_step_s16(float* params, const void* grads, int grads_bf16, void* exp_avg_bf16, void* exp_avg_sq_bf16,
+                                    void* shadow_bf16, long n, const float* hp, const float* grad_norm, float weight_decay, void* stream) {
+    __bf16* m = reinterpret_cast<__bf16*>(exp_avg_bf16);
+    __bf16* v = reinterpret_cast<__bf16*>(exp_avg_sq_bf16);
+    if (grads_bf16)
+        return adamw_launch<__bf16, __bf16>(params, reinterpret_cast<const __bf16*>(grads), m, v, shadow_bf16, n, hp, grad_norm, weight_decay, stream);
+    return adamw_launch<float, __bf16>(params, reinterpret_cast<const float*>(grads), m, v, shadow_bf16, n, hp, grad_norm, weight_decay, stream);
 }
 
 extern "C" int vitae_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
@@ -343,27 +379,31 @@ extern "C" int vitae_opt_count_bump(float* hp, const float* grad_norm, void* str
     return vitae_launch_status();
 }
 
-extern "C" int vitae_opt_tail(float* params, const void* grads, int grads_bf16, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
+extern "C" int vitae_opt_tail(float* params, const void* grads, int grads_bf16, void* exp_avg, void* exp_avg_sq, int state_bf16, void* shadow_bf16,
                               long n_decay, long n_plain, float* hp, double* acc, float* norm_out, float weight_decay, void* stream) {
     if (!params || !grads || !exp_avg || !exp_avg_sq || !hp || !acc || !norm_out || n_decay < 0 || n_plain < 0 || n_decay + n_plain <= 0)
         return VITAE_ERR_INVALID_ARG;
-    if ((n_decay & 3) || (n_plain & 3) || (((uintptr_t)params | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq | (uintptr_t)grads) & 15) ||
+    const uintptr_t smask = state_bf16 ? 7 : 15;
+    if ((n_decay & 3) || (n_plain & 3) || (((uintptr_t)params | (uintptr_t)grads) & 15) || (((uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & smask) ||
         ((uintptr_t)shadow_bf16 & 7))
         return VITAE_ERR_UNSUPPORTED_SHAPE;
     const long n = n_decay + n_plain;
     long blocks = (n / 4 + 255) / 256;
     if (blocks > 256) blocks = 256;
     hipStream_t st = (hipStream_t)stream;
+    __bf16* sh = reinterpret_cast<__bf16*>(shadow_bf16);
+    float *m32 = reinterpret_cast<float*>(exp_avg), *v32 = reinterpret_cast<float*>(exp_avg_sq);
+    __bf16 *m16 = reinterpret_cast<__bf16*>(exp_avg), *v16 = reinterpret_cast<__bf16*>(exp_avg_sq);
     if (grads_bf16) {
         const __bf16* g = reinterpret_cast<const __bf16*>(grads);
         hipLaunchKernelGGL(opt_tail_norm_kernel<__bf16>, dim3((int)blocks), dim3(256), 0, st, g, n, acc, norm_out);
-        hipLaunchKernelGGL(opt_tail_adamw_kernel<__bf16>, dim3((int)blocks), dim3(256), 0, st, params, g, exp_avg, exp_avg_sq,
-                           reinterpret_cast<__bf16*>(shadow_bf16), n_decay, n_plain, hp, acc, norm_out, weight_decay);
+        if (state_bf16) hipLaunchKernelGGL((opt_tail_adamw_kernel<__bf16, __bf16>), dim3((int)blocks), dim3(256), 0, st, params, g, m16, v16, sh, n_decay, n_plain, hp, acc, norm_out, weight_decay);
+        else hipLaunchKernelGGL((opt_tail_adamw_kernel<__bf16, float>), dim3((int)blocks), dim3(256), 0, st, params, g, m32, v32, sh, n_decay, n_plain, hp, acc, norm_out, weight_decay);
     } else {
         const float* g = reinterpret_cast<const float*>(grads);
         hipLaunchKernelGGL(opt_tail_norm_kernel<float>, dim3((int)blocks), dim3(256), 0, st, g, n, acc, norm_out);
-        hipLaunchKernelGGL(opt_tail_adamw_kernel<float>, dim3((int)blocks), dim3(256), 0, st, params, g, exp_avg, exp_avg_sq,
-                           reinterpret_cast<__bf16*>(shadow_bf16), n_decay, n_plain, hp, acc, norm_out, weight_decay);
+        if (state_bf16) hipLaunchKernelGGL((opt_tail_adamw_kernel<float, __bf16>), dim3((int)blocks), dim3(256), 0, st, params, g, m16, v16, sh, n_decay, n_plain, hp, acc, norm_out, weight_decay);
+        else hipLaunchKernelGGL((opt_tail_adamw_kernel<float, float>), dim3((int)blocks), dim3(256), 0, st, params, g, m32, v32, sh, n_decay, n_plain, hp, acc, norm_out, weight_decay);
     }
     return vitae_launch_status();
 }

@@ -203,7 +203,11 @@ class HipMAEEngine:
         self.wgrad_group_side = os.environ.get('VITAE_WGRAD_GROUP_SIDE', '1') == '1'
         self.ws16_wside = torch.zeros(1 << 24, **f32) if (self.act16 and self.wgrad_group_side) else None
         self.ln_part_on = os.environ.get('VITAE_LN_PART', '1') != '0'
-        self.ln_part_min = int(float(os.environ.get('VITAE_LN_PART_MIN', '1.2e6')))   # LayerNorm backward through partial records (no atomics)
+        # LayerNorm backward through partial records (no atomics) from this many elements on.  Round 6: at EVERY size — the records of all
+        # LayerNorms of a step are summed by ONE launch in front of the optimiser's tail (``ln_flush_once``), not by one per backward
+        # phase on the dependent chain (that form lost to the 3 D float atomics per workgroup at batch 4: 10.8 + 4 x 13 us against 10.2)
+        self.ln_part_min = int(float(os.environ.get('VITAE_LN_PART_MIN', '0')))
+        self.ln_flush_once = os.environ.get('VITAE_LN_FLUSH_ONCE', '1') != '0'
         self._ln_pending = []
         self.B = None
         self.buf: Dict[str, torch.Tensor] = {}
@@ -295,12 +299,17 @@ class HipMAEEngine:
         cls = [c for c in os.environ.get('VITAE_W2', 'dec.fc1').split(',') if c]
         if not (self.act16 and cls):
             return
-        for c in cls:
-            stack, leaf = c.split('.')
-            pre = {'dec': 'decoder_blocks', 'enc': 'blocks'}[stack]
-            depth = self.cfg.decoder_depth if stack == 'dec' else self.cfg.depth
-            sub = {'fc1': 'mlp.fc1', 'fc2': 'mlp.fc2', 'qkv': 'attn.qkv', 'proj': 'attn.proj'}[leaf]
-            names = [f'{pre}.{i}.{sub}.weight' for i in range(depth)]
+        if 'decoder' in cls:       # shorthand: every Linear of the decoder (round 6: the raw edge term needs ALL of them, LABNOTES)
+            cls = [c for c in cls if c != 'decoder'] + ['dec.qkv', 'dec.proj', 'dec.fc1', 'dec.fc2', 'decoder_pred', 'decoder_embed']
+        for c in dict.fromkeys(cls):
+            if c in ('decoder_pred', 'decoder_embed'):      # a Linear outside the block stacks: a group of one
+                names, depth = [c + '.weight'], 1
+            else:
+                stack, leaf = c.split('.')
+                pre = {'dec': 'decoder_blocks', 'enc': 'blocks'}[stack]
+                depth = self.cfg.decoder_depth if stack == 'dec' else self.cfg.depth
+                sub = {'fc1': 'mlp.fc1', 'fc2': 'mlp.fc2', 'qkv': 'attn.qkv', 'proj': 'attn.proj'}[leaf]
+                names = [f'{pre}.{i}.{sub}.weight' for i in range(depth)]
             offs = [self.layout[n][0] for n in names]
             ln = int(np.prod(self.layout[names[0]][1]))
             stride = offs[1] - offs[0] if depth > 1 else ln
@@ -319,6 +328,14 @@ class HipMAEEngine:
         st = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
         for off0, ln, stride, count, t, rows, kdim in self._w2_groups:
             inside = [i for i in range(count) if off0 + i * stride >= lo and off0 + i * stride + ln <= hi]
+            # The two-plane forward reads BOTH planes from ``hilo`` (never the shadow), so a tensor that [lo, hi) only touches would
+            # keep a stale hi plane with no error anywhere: every two-plane tensor overlapping the range must lie inside it, and the
+            # hits must be one contiguous run (they are one strided cast launch).  Holds for ddp.engine_bucket_ranges' cuts, which
+            # fall on the first matrix of a block; a future cut through a block fails HERE.
+            touched = [i for i in range(count) if off0 + i * stride < hi and off0 + i * stride + ln > lo]
+            if touched != inside or (inside and inside != list(range(inside[0], inside[0] + len(inside)))):
+                raise VitaeError(f'refresh_w2: arena range [{lo}, {hi}) cuts through a two-plane weight (tensors {touched} of the group at '
+                                 f'{off0}, fully inside: {inside}); optimiser buckets must end on tensor boundaries of these weights')
             if not inside:
                 continue
             i0, n = inside[0], len(inside)          # (a bucket covers a contiguous run of blocks)
@@ -375,6 +392,7 @@ class HipMAEEngine:
     def step_prologue(self, noise: torch.Tensor, accumulate: bool):
         """First launch of a fused step (captured with it): hp <- ring, masking noise, acc <- 0, token / vector gradients <- 0."""
         self._accum = bool(accumulate)
+        self._x3_cov = []          # (a new grad window, like begin_grad_window: the fp32x3 coverage list restarts with every fused step)
         st = torch.cuda.current_stream(self.device).cuda_stream
         n = self.n_total - self.tok_off
         lib.vitae_step_prologue(self.hp.data_ptr(), self.hp_ring.data_ptr(), self.hp_ring.shape[0], self.step_seq.data_ptr(),
@@ -687,6 +705,10 @@ class HipMAEEngine:
             if self._epi_norm_on:        # this launch added the squares of dW to acc[GRADSQ] (vitae_gemm_glds_set_wgrad_sqnorm)
                 off = (dw.data_ptr() - self.grads.data_ptr()) // 4
                 if 0 <= off < self.tok_off:
+                    # the kernel adds the squares of whatever it stores: a second launch into the same dW inside one grad window
+                    # would count partial + total — every matrix has exactly one weight-gradient launch per step
+                    if any(a < off + N * K and off < e for a, e in self._x3_cov):
+                        raise VitaeError('fp32x3 gradient-norm coverage: two weight-gradient launches into one dW range in one step')
                     self._x3_cov.append((off, off + N * K))
         elif self.prec == PREC['bf16']:
             lib.vitae_gemm_bf16(0, 0, _ptr(dy), N, _ptr(x), K, 0, _ptr(dw), K, N, K, M, None, None, 0, EPI_NONE, None, 0,
@@ -774,10 +796,12 @@ class HipMAEEngine:
                                 _ptr(self.g[pre + 'weight']), _ptr(self.g[pre + 'bias']), _ptr(dx16), _ptr(dx_colsum),
                                 M, D, dx_accumulate, self.stream)
 
-    def _ln_flush(self):
-        """Add the pending LayerNorm partial records into the gradient arena (end of a backward phase)."""
+    def _ln_flush(self, final=False):
+        """Add the pending LayerNorm partial records into the gradient arena: once per step, at the end of the last backward phase
+        (``final``; nothing reads these vector gradients earlier — the optimiser's tail and the data-parallel exchange of the
+        token / vector bucket both follow it), or at the end of every phase (``ln_flush_once`` off)."""
         pend = self._ln_pending
-        if not pend:
+        if not pend or (self.ln_flush_once and not final):
             return
         u64 = lambda k: np.array([t[k] for t in pend], dtype=np.uint64)
         i32 = lambda k: np.array([t[k] for t in pend], dtype=np.int32)
@@ -806,7 +830,9 @@ class HipMAEEngine:
                 while s2 > 1 and lib.vitae_gemm_glds_ws_floats(M, N, s2) > self.ws16.numel():
                     s2 -= 1
                 self._split_cache[key2] = s2
-            t = self._timed(2.0 * M * N * K, 'ws64')     # (algorithmic FLOPs: the second plane's MFMAs are not counted as work)
+            # (algorithmic FLOPs: the second plane's MFMAs are not counted as work; the tag follows the planner of the two-plane form:
+            # the 64 x 64 two-plane workgroup, or a big tile over 2 K)
+            t = self._timed(2.0 * M * N * K, self._w2_tag(M, N, K))
             lib.vitae_gemm_glds_w2(_ptr(x16), K, _ptr(w2), _ptr(y), N, _ptr(y16), N, M, N, K, _ptr(bias), _ptr(res), N,
                                    epi, _ptr(aux), N, 0, s2, self.ws16.data_ptr(), None, self.stream)
             if t is not None:
@@ -817,6 +843,16 @@ class HipMAEEngine:
                             epi, _ptr(aux), N, 0, s, self.ws16.data_ptr(), None, self.stream)
         if t is not None:
             t.record()
+
+    def _w2_tag(self, M, N, K):
+        if self.gemm_timer is None:
+            return 'ws64'
+        key = ('w2tag', M, N, K)
+        tag = self._split_cache.get(key)
+        if tag is None:
+            c = lib.vitae_gemm_glds_bt_choice(1, 1, M, N, 2 * K)       # (a big tile serves the planes as ONE reduction over 2 K)
+            tag = self._split_cache[key] = {0: 'bt256', 3: 'bt128', 4: 'ws128'}.get(c, 'ws64')
+        return tag
 
     def _gemm_tag(self, akc, bkc, M, N, K, split, default):
         """Instrumentation only: which kernel family serves this problem (csrc/gemm_glds.hip's planner)."""
@@ -1185,7 +1221,7 @@ class HipMAEEngine:
             target_branch()
         # --- decoder (view 1 only)
         if a16:
-            self._g16_fwd(b['latent_16'], p['decoder_embed.weight'], p['decoder_embed.bias'], B * Ne, Dd, D, y=b['e'])
+            self._g16_fwd(b['latent_16'], p['decoder_embed.weight'], p['decoder_embed.bias'], B * Ne, Dd, D, y=b['e'], name='decoder_embed.weight')
         else:
             self._lin_fwd(b['latent'], p['decoder_embed.weight'], p['decoder_embed.bias'], b['e'], B * Ne, Dd, D)
         dx_ = b['decx']
@@ -1196,7 +1232,7 @@ class HipMAEEngine:
                             self.hdd, self.Hmd)
         if a16:
             self._ln_fwd(dx_[cfg.decoder_depth], 'decoder_norm.', None, b['dn_mean'], b['dn_rstd'], Md, Dd, y16=b['dn_16'])
-            self._g16_fwd(b['dn_16'], p['decoder_pred.weight'], p['decoder_pred.bias'], Md, P, Dd, y=b['predfull'])
+            self._g16_fwd(b['dn_16'], p['decoder_pred.weight'], p['decoder_pred.bias'], Md, P, Dd, y=b['predfull'], name='decoder_pred.weight')
         else:
             self._ln_fwd(dx_[cfg.decoder_depth], 'decoder_norm.', b['dn'], b['dn_mean'], b['dn_rstd'], Md, Dd)
             self._lin_fwd(b['dn'], p['decoder_pred.weight'], p['decoder_pred.bias'], b['predfull'], Md, P, Dd)
@@ -1279,6 +1315,10 @@ class HipMAEEngine:
                 self._predictor_bwd()
             return
         self._cosine_bwd(p1, z2, p2, z1, o)
+
+    # set by the fused step's cosine backward (which then writes bf16 dp_16 ONLY — buf['dp'] is dead on that route), consumed and cleared
+    # by _predictor_bwd; any other producer of the predictor's output gradient fills fp32 buf['dp'] and leaves it False
+    _dp16_ready = False
 
     def _cosine_bwd(self, p1, z2, p2, z1, o):
         b, R, D = self.buf, self.R, self.cfg.embed_dim
@@ -1422,7 +1462,7 @@ class HipMAEEngine:
         if p16:
             # predictor.3's dgrad + wgrad + bias gradient as one paired launch on bf16 operands.  dp_16: written by the fused step's cosine
             # backward; the autograd route hands the gradient over in fp32 (buf['dp'], model/vit_autoenc.py): cast it here
-            if not getattr(self, '_dp16_ready', False):
+            if not self._dp16_ready:
                 lib.vitae_cast_bf16(_ptr(b['dp']), _ptr(b['dp_16']), 2 * R * D, self.stream)
             self._dp16_ready = False
             self._g16_bwd(b['dp_16'], p['predictor.3.weight'], b['pr_16'], g['predictor.3.weight'], 2 * R, self.Mpe, D, D, dx=b['dpr'],
@@ -1481,18 +1521,54 @@ class HipMAEEngine:
                 t.record()
         else:
             self._lin_bwd_w(b['dtok'], b['patches'], g['patch_embed.proj.weight'], g['patch_embed.proj.bias'], T, D, P)
+        self._ln_flush(final=True)
         self._wg_join()
 
     # ------------------------------------------------------------------ optimiser
+    # bf16 precision mode (round 6): AdamW's two moments are STORED in bf16 — computed in fp32 from the stored values, the unrounded
+    # m_new / v_new enter the parameter update, only the write-back is rounded: 22 instead of 30 bytes of HBM traffic per parameter
+    # (the optimiser was 0.65 ms of the 4.0 ms batch-4 step).  tools/opt_state_ablation.py: the reference's pinned ViT-B trajectory
+    # moves by 2e-7..2e-6 and an 80-step loss curve by 1e-7 (another masking seed: 1e-3).  fp32 / fp32x3 modes keep fp32 moments;
+    # VITAE_OPT_STATE16=0 keeps them in bf16 mode too.  Round-to-nearest would stall a moment whose update is under half an ulp, so
+    # betas closer to 1 than 1 - 2^-6 (torch's default beta2 = 0.999) keep fp32 storage.
+    _STATE16_MAX_BETA = 1.0 - 2.0 ** -6
+
+    def _state16_ok(self, betas) -> bool:
+        return (self.prec == PREC['bf16'] and os.environ.get('VITAE_OPT_STATE16', '1') != '0'
+                and max(float(betas[0]), float(betas[1])) <= self._STATE16_MAX_BETA)
+
     def init_optimizer(self, weight_decay: float = 0.05, betas=(0.9, 0.95), eps: float = 1e-8):
-        self.opt_state = {'exp_avg': torch.zeros_like(self.params), 'exp_avg_sq': torch.zeros_like(self.params)}
+        self.state16 = self._state16_ok(betas)
+        dt = torch.bfloat16 if self.state16 else torch.float32
+        self.opt_state = {'exp_avg': torch.zeros(self.n_total, dtype=dt, device=self.device),
+                          'exp_avg_sq': torch.zeros(self.n_total, dtype=dt, device=self.device)}
         self.weight_decay, self.betas, self.eps = weight_decay, betas, eps
         self.write_opt_step(0)
+
+    state16 = False
+
+    def _adamw(self, o: int, n: int, gnorm, weight_decay: float, st, g16=None):
+        """One AdamW launch over arena elements [o, o + n): fp32 or bf16 moments, fp32 gradients or the bf16 wire copy."""
+        s = self.opt_state
+        sh = (self.params16.data_ptr() + 2 * o) if self.params16 is not None else None
+        es = s['exp_avg'].element_size()
+        m, v = s['exp_avg'].data_ptr() + es * o, s['exp_avg_sq'].data_ptr() + es * o
+        p = self.params.data_ptr() + 4 * o
+        if self.state16:
+            g = (g16.data_ptr() + 2 * o) if g16 is not None else (self.grads.data_ptr() + 4 * o)
+            lib.vitae_adamw_step_s16(p, g, 1 if g16 is not None else 0, m, v, sh, n, _ptr(self.hp), gnorm, weight_decay, st)
+        elif g16 is not None:
+            lib.vitae_adamw_step_bf16g(p, g16.data_ptr() + 2 * o, m, v, sh, n, _ptr(self.hp), gnorm, weight_decay, st)
+        else:
+            lib.vitae_adamw_step(p, self.grads.data_ptr() + 4 * o, m, v, sh, n, _ptr(self.hp), gnorm, weight_decay, st)
 
     def optimizer_hparams(self, lr: float):
         """Host side of one AdamW step: advances the step count, refreshes lr / bias corrections."""
         self.opt_step += 1          # the host's belief; the device count (hp[VITAE_HP_STEP], read_opt_step) is the truth
         b1, b2 = self.betas
+        if self.state16 and max(float(b1), float(b2)) > self._STATE16_MAX_BETA:
+            raise VitaeError(f'betas {self.betas}: the optimiser state was allocated in bf16 (betas <= {self._STATE16_MAX_BETA:.6f} at '
+                             'init_optimizer); a moment this slow would stall under round-to-nearest — set VITAE_OPT_STATE16=0')
         # bc1, bc2 < 0: the AdamW kernels derive 1 - beta^t from the device-side count of APPLIED steps and from -(1 - beta), which
         # the host forms in double (csrc/optim.hip: device_bias_corrections)
         self.set_hparams(lr=lr, beta1=b1, beta2=b2, eps=self.eps, bc1=-(1.0 - float(b1)), bc2=-(1.0 - float(b2)))
@@ -1503,30 +1579,15 @@ class HipMAEEngine:
         st = torch.cuda.current_stream(self.device).cuda_stream
         self.flush_hparams()
         gn = self.losses.data_ptr() + 20
-        s = self.opt_state
-        sh = self.params16.data_ptr() if self.params16 is not None else 0
-        o = self.vec_off * 4
         # bf16 data-parallel exchange: the reduced gradients live in the wire buffer (only on the fused-step route, which
         # raises the flag right after the exchange it issued)
         g16 = self.grads_wire16 if self._wire_ready else None
         if g16 is not None:
             lib.vitae_grad_sqnorm_bf16(g16.data_ptr(), self.n_total, _ptr(self.acc), gn, st)
-            lib.vitae_adamw_step_bf16g(self.params.data_ptr(), g16.data_ptr(), s['exp_avg'].data_ptr(),
-                                       s['exp_avg_sq'].data_ptr(), sh if sh else None, self.vec_off, _ptr(self.hp), gn,
-                                       self.weight_decay, st)
-            lib.vitae_adamw_step_bf16g(self.params.data_ptr() + o, g16.data_ptr() + o // 2, s['exp_avg'].data_ptr() + o,
-                                       s['exp_avg_sq'].data_ptr() + o, (sh + o // 2) if sh else None,
-                                       self.n_total - self.vec_off, _ptr(self.hp), gn, 0.0, st)
-            lib.vitae_opt_count_bump(_ptr(self.hp), gn, st)
-            self.refresh_w2(st)
-            return
-        lib.vitae_grad_sqnorm(self.grads.data_ptr(), self.n_total, _ptr(self.acc), gn, st)
-        lib.vitae_adamw_step(self.params.data_ptr(), self.grads.data_ptr(), s['exp_avg'].data_ptr(),
-                             s['exp_avg_sq'].data_ptr(), sh if sh else None, self.vec_off, _ptr(self.hp), gn,
-                             self.weight_decay, st)
-        lib.vitae_adamw_step(self.params.data_ptr() + o, self.grads.data_ptr() + o, s['exp_avg'].data_ptr() + o,
-                             s['exp_avg_sq'].data_ptr() + o, (sh + o // 2) if sh else None, self.n_total - self.vec_off,
-                             _ptr(self.hp), gn, 0.0, st)
+        else:
+            lib.vitae_grad_sqnorm(self.grads.data_ptr(), self.n_total, _ptr(self.acc), gn, st)
+        self._adamw(0, self.vec_off, gn, self.weight_decay, st, g16)                              # matrices + tokens: decayed
+        self._adamw(self.vec_off, self.n_total - self.vec_off, gn, 0.0, st, g16)                  # vectors: not
         lib.vitae_opt_count_bump(_ptr(self.hp), gn, st)
         self.refresh_w2(st)
 
@@ -1556,14 +1617,11 @@ class HipMAEEngine:
             self.oside.wait_stream(torch.cuda.current_stream(self.device))
         st = self.oside.cuda_stream
         o = s0 * 4
-        sh = self.params16.data_ptr() if self.params16 is not None else 0
         run = self.losses.data_ptr() + 24          # losses[6]: norm of the buckets finished so far
-        m, v = self.opt_state['exp_avg'].data_ptr() + o, self.opt_state['exp_avg_sq'].data_ptr() + o
         g16 = self.grads_wire16 if self._wire_ready else None
         if g16 is not None:
             lib.vitae_grad_sqnorm_bf16(g16.data_ptr() + o // 2, n, _ptr(self.acc), run, st)
-            lib.vitae_adamw_step_bf16g(self.params.data_ptr() + o, g16.data_ptr() + o // 2, m, v, (sh + o // 2) if sh else None, n,
-                                       _ptr(self.hp), run, self.weight_decay, st)
+            self._adamw(s0, n, run, self.weight_decay, st, g16)
         else:
             if self._epi_norm_on:
                 # the weight-gradient epilogues of this bucket already added their squares; only what no such epilogue writes
@@ -1575,8 +1633,7 @@ class HipMAEEngine:
                 lib.vitae_grad_norm_finalize(_ptr(self.acc), run, st)
             else:
                 lib.vitae_grad_sqnorm(self.grads.data_ptr() + o, n, _ptr(self.acc), run, st)
-            lib.vitae_adamw_step(self.params.data_ptr() + o, self.grads.data_ptr() + o, m, v, (sh + o // 2) if sh else None, n,
-                                 _ptr(self.hp), run, self.weight_decay, st)
+            self._adamw(s0, n, run, self.weight_decay, st)
         self.refresh_w2(st, s0, e0)          # lo planes of the two-plane weights this bucket holds (same stream, behind their update)
         self._opt_pending = True
 
@@ -1618,8 +1675,10 @@ class HipMAEEngine:
         ot = self.tok_off * 4
         g16 = self.grads_wire16 if self._wire_ready else None
         # norm share of tokens + vectors, the global norm (last workgroup), AdamW over both segments, the step count: 2 launches
+        es = s['exp_avg'].element_size()
         lib.vitae_opt_tail(self.params.data_ptr() + ot, (g16.data_ptr() + ot // 2) if g16 is not None else self.grads.data_ptr() + ot,
-                           1 if g16 is not None else 0, s['exp_avg'].data_ptr() + ot, s['exp_avg_sq'].data_ptr() + ot,
+                           1 if g16 is not None else 0, s['exp_avg'].data_ptr() + es * self.tok_off, s['exp_avg_sq'].data_ptr() + es * self.tok_off,
+                           1 if self.state16 else 0,
                            (sh + ot // 2) if sh else None, self.vec_off - self.tok_off, self.n_total - self.vec_off, _ptr(self.hp),
                            _ptr(self.acc), gn, self.weight_decay, st)
 

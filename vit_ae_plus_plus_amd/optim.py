@@ -64,8 +64,9 @@ class FusedAdamW:
         eng = self.engine
         state = {'step': 0, 'exp_avg': None, 'exp_avg_sq': None}
         if eng is not None:
-            state = {'step': eng.read_opt_step(), 'exp_avg': eng.opt_state['exp_avg'].detach().cpu(),
-                     'exp_avg_sq': eng.opt_state['exp_avg_sq'].detach().cpu(),
+            # (the wire format is fp32 whatever the engine stores: bf16 moments of the bf16 precision mode are widened here, narrowed by _restore)
+            state = {'step': eng.read_opt_step(), 'exp_avg': eng.opt_state['exp_avg'].detach().float().cpu(),
+                     'exp_avg_sq': eng.opt_state['exp_avg_sq'].detach().float().cpu(),
                      'layout': {k: (o, list(s)) for k, (o, s) in eng.layout.items()}}
         groups = [{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups]
         return {'fused_adamw': state, 'param_groups': groups}
