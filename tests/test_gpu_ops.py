@@ -184,9 +184,13 @@ def test_linear_bwd_pair_bf16(lib, C, M, N, K):
     assert rel_err(dx, hh.grad + dy @ w) < 2e-2 and rel_err(dw, 2 * (dy.t() @ x)) < 2e-2
 
 
+@pytest.mark.parametrize('wsq', ['0', '1'])
 @pytest.mark.parametrize('M,N,K', [(440, 2304, 768), (868, 512, 2048), (440, 768, 3072), (868, 16384, 512), (100, 64, 64)])
-def test_linear_bwd_pair_glds(lib, C, M, N, K):
-    """bf16-operand backward of one Linear (LDS-DMA kernels): dx, bf16 dx, colsum(dx), dW."""
+def test_linear_bwd_pair_glds(lib, C, M, N, K, wsq, monkeypatch):
+    """bf16-operand backward of one Linear (LDS-DMA kernels): dx, bf16 dx, colsum(dx), dW.  wsq = 1: the persistent form of the paired
+    launch (VITAE_WS64Q=1, round 6: workgroups walk a tile queue, tiles pipelined across each other, per-wave split-K tickets) — opt-in
+    because it measured slower, kept correct here."""
+    monkeypatch.setenv('VITAE_WS64Q', wsq)
     Mp = (M + 63) // 64 * 64
     x, w, dy, h = gen(M, K, seed=1), gen(N, K, seed=2, scale=K ** -0.5), gen(M, N, seed=5), gen(M, K, seed=6)
     x16 = torch.zeros(Mp, K, dtype=torch.bfloat16, device='cuda'); x16[:M] = x.cuda().to(torch.bfloat16)

@@ -1726,6 +1726,412 @@ int ws64_pair_launch(GArgs p1, GArgs p2, hipStream_t st) {
     return vitae_launch_status();
 }
 
+// ---- the paired launch as PERSISTENT workgroups with the tiles pipelined ACROSS each other (round 6) ------------
+// tools/ws64_phase_probe.py on gemm_ws64_pair_kernel (batch 4, encoder fc2: 912 tiles on 512 slots): a workgroup lives ~10.5 k clocks
+// of which the k-loop is 4.0-5.8 k — 1.4 k of prologue issue + 0.5 k until the first k-tile lands before the first MFMA, 1.5-2.4 k of
+// epilogue and 1.6 k until its stores have drained behind it, and the 400 second-round workgroups pay all of that again behind the
+// first round.  Here a launch is at most one workgroup per slot and every workgroup walks a queue of tiles (virtual ids bid, bid + G,
+// ...: input-gradient tiles first, then weight-gradient tiles; G a multiple of 8 so a workgroup stays on the XCD chunk of its tiles):
+//   * the producer waves see ONE flat stream of k-tiles — behind the last k-tile of a tile they go straight on with the first ones
+//     of the next tile, so those have landed when the consumers come out of their epilogue;
+//   * the epilogue is wave-private: the split-K hand-over takes one ticket per WAVE (a wave's 32 x 32 quadrant of the partials is
+//     its own), the gradient norm's share is carried across the tiles in a register and leaves once per workgroup.  It parks its
+//     fragments in the stage of the tile's LAST k-tile — the one stage the producers cannot restage before the consumers reach the
+//     next tile's first barrier — behind one more workgroup barrier per tile (E: every consumer's reads of that stage have retired);
+//     both roles count nk + 1 barriers per tile;
+//   * DMA addresses: one 32-bit offset per lane and piece, computed once per tile; the k-tile enters through the instruction's
+//     scalar offset (the stand-alone kernel recomputed ~40 instructions of address arithmetic per piece).
+// What the first builds taught (tools/pair_bench.py, tools/ws64_phase_probe.py with VITAE_WS64Q=1):
+//   * two by-value descriptors (2 x 58 dwords) stayed live in SGPRs across the tile loop: 170-180 spilled into VGPR lanes, ~300
+//     v_readlane on every epilogue path, the launch 20 % slower than one tile per workgroup.  Now ONE kernel-argument struct is read
+//     through the kernarg segment pointer, the epilogue's fields re-read per tile (the pointer is laundered through an empty asm);
+//   * a select between fields of the two structs is canonicalised into a select of ADDRESSES, and hipcc then copied both structs to
+//     scratch (488 bytes, 172 VGPRs): everything the tile decoding and the producers need sits in a header of plain values (QHead),
+//     loaded once at entry in one batch — a second, dependent batch of scalar loads (other cache lines of the segment) cost the
+//     prologue another ~1 k clocks;
+//   * three stages (two k-tiles in flight) ran the k-loop at 695 clocks per k-tile against 462 with four: the DMA latency needs three
+//     in flight.  Four stages of 16 KB with the epilogue aliased as above: 64 KB, two workgroups per CU as before.
+#ifndef VITAE_WSQ_STAGES
+#define VITAE_WSQ_STAGES 4
+#endif
+constexpr int WSQ_S = VITAE_WSQ_STAGES, WSQ_STG = 16384, WSQ_MISC = WSQ_S * WSQ_STG, WSQ_SMEM = WSQ_MISC + 64;
+static_assert(2 * WSQ_SMEM <= 160 * 1024, "two workgroups per CU");
+
+struct QTile { int kind, m0, n0, tm, tn, zid, kbeg, nk; };       // kind 0: a tile of the input gradient (p1), 1: of the weight gradient (p2)
+struct QHead {
+    int nb1, nv, nd, tm1, tn1, xm1, kps1, K1, tm2, tn2, xm2, K2;                 // tile decoding
+    // ... without a division: x / d = umulhi(x, floor(2^32 / d) + 1), exact for x * d < 2^32 (all of these are below 2^16).  The
+    // compiler's expansion of four scalar divisions by run-time values was ~450 instructions = ~2000 clocks in front of the first
+    // DMA piece of BOTH roles (tools/ws64_phase_probe.py, second build).
+    unsigned mg_nb1, dv1, mg1, dv2, mg2;                                          // dv: tiles_n if xcd_m else tiles_m
+    const __bf16 *A1, *B1; int lda1, ldb1, M1, N1;                               // input gradient: dy (k-contiguous), W (row-contiguous)
+    const __bf16 *A2, *B2; int lda2, ldb2, M2, N2;                               // weight gradient: dy, x (both row-contiguous)
+    long long* dbg; double* sqacc; int sq_mask, sq_stride;
+};
+struct PairArgs { QHead h; GArgs p1, p2; };
+typedef __attribute__((address_space(4))) const PairArgs* wsq_kargs_t;
+__device__ __forceinline__ const PairArgs* wsq_kargs() {
+    wsq_kargs_t k = (wsq_kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));                  // (whatever is loaded through the result is loaded HERE, not at kernel entry)
+    return (const PairArgs*)k;
+}
+// virtual id -> tile (wave-uniform; H: the header's values); ok = false: a padding id of the XCD chunk map
+#define WSQ_DECODE(v, q, ok)                                                                                               \
+    do {                                                                                                                   \
+        const bool w_ = (v) >= h_nd;                                                                                       \
+        const int zid_ = w_ ? 0 : (int)__umulhi((unsigned)(v), h_mg_nb1);                                                  \
+        const int bid_ = w_ ? (v) - h_nd : (v) - zid_ * h_nb1;                                                             \
+        const int tiles_m_ = w_ ? h_tm2 : h_tm1, tiles_n_ = w_ ? h_tn2 : h_tn1, xcd_m_ = w_ ? h_xm2 : h_xm1;               \
+        const unsigned dv_ = w_ ? h_dv2 : h_dv1, mg_ = w_ ? h_mg2 : h_mg1;                                                 \
+        const int T_ = tiles_m_ * tiles_n_;                                                                                \
+        const int xq_ = T_ >> 3, xr_ = T_ & 7, xcd_ = bid_ & 7;                                                            \
+        (ok) = (bid_ >> 3) < xq_ + (xcd_ < xr_ ? 1 : 0);                                                                   \
+        const int lin_ = (xcd_ < xr_ ? xcd_ * (xq_ + 1) : xr_ * (xq_ + 1) + (xcd_ - xr_) * xq_) + (bid_ >> 3);             \
+        const int qa_ = (int)__umulhi((unsigned)lin_, mg_), qb_ = lin_ - qa_ * (int)dv_;                                   \
+        (q).tn = xcd_m_ ? qb_ : qa_;                                                                                       \
+        (q).tm = xcd_m_ ? qa_ : qb_;                                                                                       \
+        (q).m0 = (q).tm * 64; (q).n0 = (q).tn * 64; (q).zid = zid_; (q).kind = w_ ? 1 : 0;                                 \
+        const int kps_ = w_ ? h_K2 : h_kps1, K_ = w_ ? h_K2 : h_K1;                                                        \
+        (q).kbeg = zid_ * kps_;                                                                                            \
+        (q).nk = (min(K_, (q).kbeg + kps_) - (q).kbeg) >> 6;                                                               \
+    } while (0)
+
+// one tile on the four consumer waves: k-loop (one workgroup barrier per k-tile, crossed in the middle of a k-tile), barrier E,
+// wave-private epilogue out of the last k-tile's stage
+template <bool A_KC, bool RS>
+__device__ __forceinline__ void wsq_consume(const GArgs& pk, const QTile& q, unsigned char* smem, int& cstage, float& sqs,
+                                            const int wave, const int lane, long long* dbg) {
+    // what the epilogue reads of the descriptor, loaded NOW (one batch of scalar loads that lands under the k-loop; pinned by empty
+    // asms): left to the compiler the loads sat in front of their first use, an exposed scalar-memory round trip inside every epilogue
+    GArgs p = pk;
+#define WSQ_PIN(x) asm volatile("" : "+s"(x))
+    WSQ_PIN(p.C); WSQ_PIN(p.ldc); WSQ_PIN(p.C16); WSQ_PIN(p.ldc16); WSQ_PIN(p.M); WSQ_PIN(p.N); WSQ_PIN(p.aux); WSQ_PIN(p.ldaux);
+    WSQ_PIN(p.epi); WSQ_PIN(p.aux16); WSQ_PIN(p.auxd); WSQ_PIN(p.exact); WSQ_PIN(p.accumulate); WSQ_PIN(p.residual); WSQ_PIN(p.ldr);
+    WSQ_PIN(p.out_colsum); WSQ_PIN(p.sqacc); WSQ_PIN(p.splits); WSQ_PIN(p.ws); WSQ_PIN(p.tile0); WSQ_PIN(p.tiles_n); WSQ_PIN(p.a_rowsum);
+#undef WSQ_PIN
+    constexpr bool B_KC = false;
+    constexpr int BM = 64, BN = 64, A_T = BM * BK * 2;
+    // tools/ws64_phase_probe.py (VITAE_WS64Q=1): the stamps of gemm_ws64_body, for the FIRST tile of every workgroup (dbg null after it)
+    auto stamp = [&](int i) {
+        if (dbg && threadIdx.x == 0) dbg[(long)blockIdx.x * 16 + i] = __builtin_amdgcn_s_memtime();
+    };
+    auto barrier = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int m0 = q.m0, n0 = q.n0, nk = q.nk;
+    f32x16 acc[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[h][i] = 0.f;
+    const bool rowsum = RS && p.a_rowsum != nullptr && q.tn == 0 && wn == 0;
+    f32x16 accx;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accx[i] = 0.f;
+    bf16x8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
+    bf16x8 fa[BK / 16], fb[BK / 16];
+    constexpr int RK = (A_KC ? 1 : 2) + 2;
+    auto rd = [&](const unsigned char* TA, auto kk_c) {
+        constexpr int kk = decltype(kk_c)::value;
+        fa[kk] = frag_asm<BM, A_KC>(TA, wm * 32, kk, lane);
+        fb[kk] = frag_asm<BN, B_KC>(TA + A_T, wn * 32, kk, lane);
+    };
+    auto mm = [&](auto kk_c) {
+        constexpr int kk = decltype(kk_c)::value;
+        frag_tie(fa[kk]); frag_tie(fb[kk]);
+        acc[kk & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk], fb[kk], acc[kk & 1], 0, 0, 0);
+        if constexpr (RS) {
+            if (rowsum) accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk], ones, accx, 0, 0, 0);
+        }
+    };
+    using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
+    const f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};                           // (neither half of a backward has a bias: refused by the launcher)
+    stamp(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // (the previous tile's epilogue is done with its LDS region)
+    barrier();                                                           // first k-tile of this tile has landed
+    stamp(1);
+    rd(smem + cstage * WSQ_STG, K0{}); rd(smem + cstage * WSQ_STG, K1{});
+    int last = cstage;
+#pragma unroll 1
+    for (int t = 0; t < nk; ++t) {
+        const unsigned char* TA = smem + cstage * WSQ_STG;
+        __builtin_amdgcn_sched_barrier(0);
+        rd(TA, K2{}); rd(TA, K3{});
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * RK) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mm(K0{}); mm(K1{});
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // every read of this k-tile has retired
+        last = cstage;
+        cstage = cstage + 1 == WSQ_S ? 0 : cstage + 1;
+        if (t + 1 < nk) {
+            barrier();
+            const unsigned char* TN = smem + cstage * WSQ_STG;
+            rd(TN, K0{}); rd(TN, K1{});
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        mm(K2{}); mm(K3{});
+    }
+    barrier();                                                           // E: nobody reads the last k-tile's stage any more
+    if (RS && rowsum && l31 == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 32 + crow(r, hi);
+            if (m < p.M) atomicAdd(p.a_rowsum + m, accx[r]);
+        }
+    }
+    stamp(2);
+    f32x16 accs[1][1];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accs[0][0][i] = acc[0][i] + acc[1][i];
+    float* Tw = reinterpret_cast<float*>(smem + last * WSQ_STG) + wave * 1024;    // this wave's 4 KB of the stage nobody restages before the next tile's first barrier
+    if (p.splits > 1) {
+        // split-K hand-over per WAVE: this wave's quadrant of the partial tile leaves as write-through stores, the wave takes the
+        // ticket of (tile, quadrant), and the LAST wave to arrive for that quadrant sums all partials in split order
+        const int tile = p.tile0 + q.tm * p.tiles_n + q.tn;
+        float* part = p.ws + VITAE_GLDS_TICKETS + (long)tile * p.splits * (BM * BN);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(part, 0, p.splits * (BM * BN * 4), 0x00020000);
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const int toff = (wave * 64 + lane) * 16;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = {accs[0][0][4 * g], accs[0][0][4 * g + 1], accs[0][0][4 * g + 2], accs[0][0][4 * g + 3]};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (q.zid * 4 + g) * (256 * 16) + toff, 0, 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int* ticket = reinterpret_cast<int*>(p.ws) + tile * 4 + wave;
+        int tk = 0;
+        if (lane == 0) tk = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tk = __builtin_amdgcn_readfirstlane(tk);
+        stamp(3);
+        if (tk != p.splits - 1) return;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accs[0][0][i] = 0.f;
+#pragma unroll 1
+        for (int sp0 = 0; sp0 < p.splits; sp0 += 4) {
+            f32x4 v[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int sp = min(sp0 + u, p.splits - 1);               // (clamped: a repeated load, never added)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    v[u][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (sp * 4 + g) * (256 * 16) + toff, 0, 16));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (sp0 + u < p.splits) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) accs[0][0][4 * g + e] += v[u][g][e];
+                }
+        }
+        if (lane == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+    }
+    stamp(4);
+    bt_park_quadrant<1, 1, 1>(accs, lane, Tw);
+    __builtin_amdgcn_wave_barrier();
+    { f32x4 cz = {0.f, 0.f, 0.f, 0.f}; bt_wave_epilogue<1, 1>(p, bt_epilogue_kind(p), m0 + wm * 32, n0 + wn * 32, Tw, lane, sqs, bias4, cz, false); }
+    __builtin_amdgcn_wave_barrier();
+    stamp(5);
+    if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(6); }
+}
+
+template <bool RS>
+__global__ __launch_bounds__(512, 4) void gemm_ws64q_pair_kernel(const PairArgs unused_by_name) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[WSQ_SMEM];
+    constexpr int S = WSQ_S, PT = 4;                                      // DMA instructions per wave and k-tile: 2 for A + 2 for B
+    // the header as VALUES that are not loads (each passed through an empty asm: zero instructions — as readfirstlane results they cost a
+    // v_mov + v_readfirstlane + hazard nops each, ~450 clocks at entry): a struct copy went to scratch again, indexed through selected
+    // addresses (184-200 bytes of private segment, the launch twice as slow)
+    const QHead* hp_ = &((const PairArgs*)(wsq_kargs_t)__builtin_amdgcn_kernarg_segment_ptr())->h;
+#define WSQ_VAL(T, name, field) T name = hp_->field; asm volatile("" : "+s"(name))
+    WSQ_VAL(int, h_nb1, nb1); WSQ_VAL(int, h_nv, nv); WSQ_VAL(int, h_nd, nd); WSQ_VAL(int, h_tm1, tm1); WSQ_VAL(int, h_tn1, tn1); WSQ_VAL(int, h_xm1, xm1);
+    WSQ_VAL(int, h_kps1, kps1); WSQ_VAL(int, h_K1, K1); WSQ_VAL(int, h_tm2, tm2); WSQ_VAL(int, h_tn2, tn2); WSQ_VAL(int, h_xm2, xm2); WSQ_VAL(int, h_K2, K2);
+    WSQ_VAL(unsigned, h_mg_nb1, mg_nb1); WSQ_VAL(unsigned, h_dv1, dv1); WSQ_VAL(unsigned, h_mg1, mg1); WSQ_VAL(unsigned, h_dv2, dv2); WSQ_VAL(unsigned, h_mg2, mg2);
+    WSQ_VAL(long long*, h_dbg, dbg);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int G = gridDim.x, nv = h_nv;
+    auto barrier = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if (wave >= 4) {
+        // ---------------- producers: one flat stream of k-tiles over all tiles of this workgroup ----------------
+        // (their share of the header is loaded in THIS branch only: live here, not in the consumers' registers)
+        WSQ_VAL(const __bf16*, h_A1, A1); WSQ_VAL(const __bf16*, h_B1, B1); WSQ_VAL(const __bf16*, h_A2, A2); WSQ_VAL(const __bf16*, h_B2, B2);
+        WSQ_VAL(int, h_lda1, lda1); WSQ_VAL(int, h_ldb1, ldb1); WSQ_VAL(int, h_M1, M1); WSQ_VAL(int, h_N1, N1);
+        WSQ_VAL(int, h_lda2, lda2); WSQ_VAL(int, h_ldb2, ldb2); WSQ_VAL(int, h_M2, M2); WSQ_VAL(int, h_N2, N2);
+        const int pw = wave - 4;
+        // geometry of this wave's two pieces of a 64-row operand tile: piece j = instruction pw * 2 + j = 8 LDS lines of 128 bytes
+        int line[2], slot = lane & 7;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) line[j] = (pw * 2 + j) * 8 + (lane >> 3);
+        int v = blockIdx.x;
+        QTile q;
+        bool have = false;
+        int ti = 0, issued = 0, handed = 0, istage = 0;
+        int hleft = 0, hnext = 0;                                        // k-tiles left to hand over in the tile the consumers are in; nk of the tile after it
+        int voA[2], voB[2], ksA = 0, ksB = 0;
+        __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((__bf16*)nullptr, 0, 0, 0x00020000), rB = rA;
+        auto enter = [&]() {
+            // advance to the next valid tile of this workgroup's queue and set up its DMA offsets
+            have = false;
+            while (v < nv) {
+                WSQ_DECODE(v, q, have);
+                if (have) break;
+                v += G;
+            }
+            if (!have) return;
+            ti = 0;
+            {   // (as selects of VALUES: `if (hleft == 0) hleft = nk; else hnext = nk;` became a store through a selected ADDRESS — two
+                // ints in scratch, and every scratch access of the producer loop drained the DMA queue with s_waitcnt vmcnt(0))
+                const bool first_ = hleft == 0;
+                const int nk_ = q.nk, hl_ = hleft, hn_ = hnext;
+                hleft = first_ ? nk_ : hl_;
+                hnext = first_ ? hn_ : nk_;
+            }
+            // B of both kinds is row-contiguous ([k][rows], columns n0 ..): W for the input gradient, x for the weight gradient.  The
+            // per-kind values are BLENDED arithmetically (kind is 0 / 1): a select or an if / else over them was turned into a two-entry
+            // table in scratch indexed by the kind, and a scratch load inside this loop waits with vmcnt(0) — the whole DMA queue.
+            const int k = q.kind;
+            const int ldb = h_ldb1 + (h_ldb2 - h_ldb1) * k, Nb = h_N1 + (h_N2 - h_N1) * k;
+            const unsigned long long b1 = (unsigned long long)h_B1, b2 = (unsigned long long)h_B2, a1 = (unsigned long long)h_A1, a2 = (unsigned long long)h_A2;
+            rB = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<__bf16*>(b1 + (b2 - b1) * (unsigned long long)k), 0, 0x7fffffff, 0x00020000);
+            rA = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<__bf16*>(a1 + (a2 - a1) * (unsigned long long)k), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int cK = slot ^ swz<true, 8>(line[j]), cR = slot ^ swz<false, 8>(line[j]);
+                voB[j] = ((q.kbeg + line[j]) * ldb + min(q.n0 + cR * 8, Nb - 8)) * 2;
+                // A: dy — k-contiguous rows m0 .. for the input gradient (kind 0), row-contiguous columns m0 .. for the weight gradient
+                const int a_kc = (min(q.m0 + line[j], h_M1 - 1) * h_lda1 + q.kbeg + cK * 8) * 2;
+                const int a_rc = ((q.kbeg + line[j]) * h_lda2 + min(q.m0 + cR * 8, h_M2 - 8)) * 2;
+                voA[j] = a_kc + (a_rc - a_kc) * k;
+            }
+            ksA = BK * 2 + (BK * h_lda2 * 2 - BK * 2) * k;
+            ksB = BK * ldb * 2;
+        };
+        auto issue = [&]() {
+            unsigned char* dst = smem + istage * WSQ_STG + pw * 2048;
+            const int sA = ti * ksA, sB = ti * ksB;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, voA[j], sA, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)(dst + 8192 + j * 1024), 16, voB[j], sB, 0, 0);
+            istage = istage + 1 == S ? 0 : istage + 1;
+            ++issued;
+            if (++ti == q.nk) { v += G; enter(); }
+        };
+        long long* dbg = h_dbg;
+        auto pstamp = [&](int i) { if (dbg && threadIdx.x == 256) dbg[(long)blockIdx.x * 16 + i] = __builtin_amdgcn_s_memtime(); };
+        pstamp(8);
+        enter();
+        while (have && issued < S - 1) issue();
+        pstamp(9);
+#pragma unroll 1
+        while (handed < issued) {
+            // k-tile `handed` has landed once at most (issued - handed - 1) younger k-tiles are still in flight
+            const int fly = issued - handed - 1;
+            if (S >= 4 && fly >= 2) wait_vmcnt<2 * PT>();
+            else if (fly >= 1) wait_vmcnt<PT>();
+            else wait_vmcnt<0>();
+            if (handed == 0) pstamp(10);
+            barrier();                                                   // this k-tile is the consumers'; every read of the one before it has retired
+            ++handed;
+            if (have) issue();                                           // ... so that one's stage is restaged right away
+            if (--hleft == 0) {
+                barrier();                                               // E of the tile just handed over completely
+                hleft = hnext; hnext = 0;
+            }
+            if (dbg && handed == 1) dbg = nullptr, pstamp(11);
+        }
+        return;
+    }
+    // ---------------- consumers ----------------
+    if (threadIdx.x == 0) { *reinterpret_cast<float*>(smem + WSQ_MISC) = 0.f; *reinterpret_cast<int*>(smem + WSQ_MISC + 4) = 0; }
+    int cstage = 0;
+    float sqs = 0.f;
+    bool any = false;
+    long long* dbg = h_dbg;
+#pragma unroll 1
+    for (int v = blockIdx.x; v < nv; v += G) {
+        QTile q;
+        bool ok;
+        WSQ_DECODE(v, q, ok);
+        if (!ok) continue;
+        any = true;
+        const PairArgs* ka = wsq_kargs();
+        // (the lane index is laundered per tile: otherwise the per-lane address arithmetic of BOTH tile kinds — fragment offsets, epilogue
+        // rows — is hoisted out of the tile loop and stays live across it: 145-170 VGPRs, or spills inside the k-loop under the 128 cap)
+        int lane_t = lane;
+        asm volatile("" : "+v"(lane_t));
+        if (q.kind == 0) wsq_consume<true, false>(ka->p1, q, smem, cstage, sqs, wave, lane_t, dbg);
+        else wsq_consume<false, RS>(ka->p2, q, smem, cstage, sqs, wave, lane_t, dbg);
+        dbg = nullptr;
+    }
+    WSQ_VAL(double*, h_sqacc, sqacc); WSQ_VAL(int, h_sq_mask, sq_mask); WSQ_VAL(int, h_sq_stride, sq_stride);
+    if (any && h_sqacc) {
+        // the gradient norm's share of every weight-gradient tile of this workgroup: ONE atomic (LDS meeting point without a barrier:
+        // a wave's LDS operations execute in order, so whoever draws the last ticket sees all four sums)
+        sqs = wave_sum(sqs);
+        float* red = reinterpret_cast<float*>(smem + WSQ_MISC);
+        int* cnt = reinterpret_cast<int*>(smem + WSQ_MISC + 4);
+        if (lane == 0) {
+            __hip_atomic_fetch_add(red, sqs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int c = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (c == 3) {
+                const float tot = __hip_atomic_load(red, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                atomicAdd(h_sqacc + (long)((int)blockIdx.x & h_sq_mask) * h_sq_stride, (double)tot);
+            }
+        }
+    }
+}
+
+// p1 / p2 as for ws64_pair_launch
+int ws64q_pair_launch(GArgs p1, GArgs p2, hipStream_t st) {
+    if (!p1.vec_epi || !p2.vec_epi || (p1.K % BK) || (p2.K % BK) || p1.a_rowsum || p1.sqacc || p1.bias || p2.bias) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    if (p1.splits < 1) p1.splits = 1;
+    p1.k_per_split = cdiv(cdiv(p1.K, p1.splits), BK) * BK;
+    p1.splits = cdiv(p1.K, p1.k_per_split);
+    // every tile at least WSQ_S - 1 k-tiles deep: the producers run that far ahead, and only ONE tile boundary may lie inside that window
+    if (p2.K < (WSQ_S - 1) * BK || p1.k_per_split < (WSQ_S - 1) * BK || p1.K - (p1.splits - 1) * p1.k_per_split < (WSQ_S - 1) * BK) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    p1.tiles_m = cdiv(p1.M, 64); p1.tiles_n = cdiv(p1.N, 64); p1.tile0 = 0;
+    p2.tiles_m = cdiv(p2.M, 64); p2.tiles_n = cdiv(p2.N, 64); p2.tile0 = 0;
+    p2.k_per_split = p2.K; p2.splits = 1;
+    // one ticket per (tile, consumer wave)
+    if (p1.splits > 1 && (!p1.ws || (long)p1.tiles_m * p1.tiles_n * 4 > VITAE_GLDS_TICKETS)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    if (p1.M < 8 || p1.N < 8 || p2.M < 8 || p2.N < 8) return VITAE_ERR_UNSUPPORTED_SHAPE;        // (clamped 8-column groups of the row-contiguous operands)
+    const int nb1 = 8 * cdiv((long)p1.tiles_m * p1.tiles_n, 8), nb2 = 8 * cdiv((long)p2.tiles_m * p2.tiles_n, 8);
+    const int nv = nb1 * p1.splits + nb2;
+    if (nv >= 65536 || p1.tiles_m * p1.tiles_n >= 65536 || p2.tiles_m * p2.tiles_n >= 65536) return VITAE_ERR_UNSUPPORTED_SHAPE;     // (the multiply-high divisions)
+    auto magic = [](unsigned d) { return (unsigned)((1ull << 32) / d) + 1u; };
+    const unsigned dv1 = p1.xcd_m ? p1.tiles_n : p1.tiles_m, dv2 = p2.xcd_m ? p2.tiles_n : p2.tiles_m;
+    static const int slots = getenv("VITAE_WSQ_SLOTS") ? atoi(getenv("VITAE_WSQ_SLOTS")) : 512;       // two workgroups on each of the 256 CUs
+    const int g = nv < slots ? nv : slots / 8 * 8;
+    const dim3 grid(g), block(512);
+    PairArgs a;
+    a.h = QHead{nb1, nv, nb1 * p1.splits, p1.tiles_m, p1.tiles_n, p1.xcd_m, p1.k_per_split, p1.K, p2.tiles_m, p2.tiles_n, p2.xcd_m, p2.K,
+                magic((unsigned)nb1), dv1, magic(dv1), dv2, magic(dv2),
+                p1.A, p1.B, (int)p1.lda, (int)p1.ldb, p1.M, p1.N, p2.A, p2.B, (int)p2.lda, (int)p2.ldb, p2.M, p2.N,
+                p1.dbg, p2.sqacc, p2.sq_mask, p2.sq_stride};
+    a.p1 = p1; a.p2 = p2;
+    if (p2.a_rowsum) hipLaunchKernelGGL((gemm_ws64q_pair_kernel<true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((gemm_ws64q_pair_kernel<false>), grid, block, 0, st, a);
+    return vitae_launch_status();
+}
+
 // Up to four weight-gradient problems dW_i[N_i, K_i] (+)= dy_i^T x_i of one transformer block (same reduction length: the padded
 // token count) as ONE launch of 128x128 tiles: together they have enough tiles that the reduction needs no split (batch 32
 // encoder: 432 tiles) or a split of two (decoder: 192) where each of them alone wanted 3-8 — and the in-launch split-K fix-up was

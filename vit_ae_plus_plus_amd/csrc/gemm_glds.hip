@@ -990,7 +990,13 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
             p2.xcd_m = xcd_by_rows(N, K); p2.tiles_m = 0; p2.tiles_n = 0;
             p2.vec_epi = vec_epilogue_ok(p2);
             if (p1.vec_epi && p2.vec_epi) {
-                const int rc = ws64_pair_launch(p1, p2, (hipStream_t)stream);
+                // VITAE_WS64Q=1: the persistent form (round 6: csrc/gemm_bt.hip gemm_ws64q_pair_kernel — correct, measured 6-10 % SLOWER than
+                // one tile per workgroup on the batch-4 / batch-8 pair launches, so it is opt-in; read per call so that a test can switch it)
+                const char* wsq_env = getenv("VITAE_WS64Q");
+                const int wsq = wsq_env ? atoi(wsq_env) : 0;
+                int rc = wsq ? ws64q_pair_launch(p1, p2, (hipStream_t)stream) : VITAE_ERR_UNSUPPORTED_SHAPE;
+                if (rc != VITAE_ERR_UNSUPPORTED_SHAPE) return rc;
+                rc = ws64_pair_launch(p1, p2, (hipStream_t)stream);
                 if (rc != VITAE_ERR_UNSUPPORTED_SHAPE) return rc;
             }
         }

@@ -122,6 +122,8 @@ int bt_launch(GArgs p, int a_kc, int b_kc, int id, hipStream_t st);
 int bt_wgrad_group_launch(GArgs* ps, int n, int splits, hipStream_t st, int kind);
 // gemm_bt.hip: input gradient + weight gradient of one Linear as ONE launch of wave-specialised 64 x 64 workgroups (tile id 5)
 int ws64_pair_launch(GArgs p1, GArgs p2, hipStream_t st);
+// ... the same as persistent workgroups walking a tile queue with the tiles pipelined across each other (round 6)
+int ws64q_pair_launch(GArgs p1, GArgs p2, hipStream_t st);
 // gemm_bt.hip: fp32 operands split into bf16 hi + lo by the producer waves of a wave-specialised 64 x 64 workgroup (fp32x3 mode);
 // p.A / p.B point at FLOATS here, p.K any multiple of 4
 int wsx3_launch(GArgs p, int a_kc, int b_kc, hipStream_t st);
