@@ -707,6 +707,25 @@ def main():
             parity['worst_contr_rel_err'] = pt.get('worst_contr_rel_err')
         except Exception as e:
             parity['pinned_trajectory'] = {'error': repr(e)[:200]}
+        if args.precision == 'bf16' and args.model == 'contr' and args.patch == 16 and not args.no_extra:
+            # the option that holds EVERY loss term of the bf16 route to 1e-4 (two-plane weights for the whole decoder + the encoder's attention
+            # projection: tests/test_gpu_model.py::test_bf16_with_the_decoder_on_two_plane_weights_holds_every_loss_term) and what it costs
+            prev = os.environ.get('VITAE_W2')
+            os.environ['VITAE_W2'] = 'decoder,enc.proj'
+            try:
+                pt2 = pinned_trajectory_parity(args, dev)
+                pnt = secondary_model_point(args, dev, args.model, 'bf16', batches, 'VITAE_W2=decoder,enc.proj')
+                parity['option_w2_decoder'] = {'env': 'VITAE_W2=decoder,enc.proj', 'worst_total_loss_rel_err': pt2['worst_total_loss_rel_err'],
+                                               'worst_raw_edge_rel_err': pt2['worst_raw_edge_rel_err'], 'worst_recon_loss_rel_err': pt2['worst_recon_loss_rel_err'],
+                                               'worst_contr_rel_err': pt2['worst_contr_rel_err'], 'value': pnt['value'], 'unit': 'volumes/s',
+                                               'ms_per_step': pnt['ms_per_step']}
+            except Exception as e:
+                parity['option_w2_decoder'] = {'error': repr(e)[:200]}
+            finally:
+                if prev is None:
+                    os.environ.pop('VITAE_W2', None)
+                else:
+                    os.environ['VITAE_W2'] = prev
         parity['parity_note'] = ('cubic volumes (configs 1, 2, 4 and patch 8): pinned to the reference itself (tests/golden); '
                                  'non-cubic (config 5, 192x192x32): oracle only (the reference cannot construct it)')
 
