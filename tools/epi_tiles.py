@@ -58,7 +58,8 @@ for pre, M, d, h in (('enc', Me, 768, 3072), ('dec', Md, 512, 2048)):
     case(f'{pre} proj +res', 'fwd', M, d, d, out32=True, bias=True, res=True)
     case(f'{pre} fc1  GELU', 'fwd', M, h, d, out16=True, bias=True, epi=GELU | A16)
     case(f'{pre} fc2  +res', 'fwd', M, d, h, out32=True, bias=True, res=True)
-    case(f'{pre} fc2 dgrad GELU\'', 'dgrad', M, h, d, out16=True, epi=DGELU | A16, colsum=True)
+    case(f'{pre} fc2 dgrad GELU\'+cs', 'dgrad', M, h, d, out16=True, epi=DGELU | A16, colsum=True)      # + the fc1 bias gradient as column sums (batch >= 8)
+    case(f'{pre} fc2 dgrad GELU\'', 'dgrad', M, h, d, out16=True, epi=DGELU | A16 | CONSTS['VITAE_EPI_AUX_DERIV'])   # what the batch-4 step launches: the saved derivative, bias gradient by the wgrad half
     case(f'{pre} fc2 dgrad plain', 'dgrad', M, h, d, out16=True)
     case(f'{pre} fc1 dgrad', 'dgrad', M, d, h, out32=True)
     case(f'{pre} proj dgrad', 'dgrad', M, d, d, out32=True)
