@@ -673,6 +673,63 @@ B4_LOSS_RTOL_STEP0, B4_LOSS_RTOL_LATER, B4_EDGE_RTOL, B4_CONTR_RTOL, B4_GRAD_RTO
 # <= 6.4e-4, contrastive term (magnitude 1e-5) <= 5.7e-3, gradient norms <= 1.2e-3; the fp32 mode: everything <= 7e-7)
 
 
+def test_bf16_optimizer_moments_checkpoint_and_beta_guard():
+    """Round 6: in precision='bf16' AdamW's moments are STORED in bf16 (engine.state16).  (1) The FusedAdamW state dict carries them in fp32
+    and a fresh model that loads it takes the same next step bit for bit; (2) an optimiser whose betas are closer to 1 than 1 - 2^-6
+    (torch's default beta2 = 0.999) keeps fp32 moments — adopted torch.optim.AdamW included — and fp32 modes never use bf16 storage."""
+    from vit_ae_plus_plus_amd.optim import FusedAdamW, adopt
+    cfg = R.RefConfig(contrastive=True, **ACT16)
+    sd0 = R.init_state_dict(cfg, seed=3)
+    B = 2
+
+    def make(betas=(0.9, 0.95), precision='bf16'):
+        model = build(cfg, sd0, precision=precision).train()
+        opt = FusedAdamW(model, lr=1e-3, weight_decay=0.05, betas=betas)
+        model._ensure_engine(torch.device('cuda', 0))
+        eng = opt.engine
+        eng.set_loss_weights(0.01, 0.001, 1)
+        return model, opt, eng
+
+    def step(model, eng, i):
+        v1, v2 = R.synthetic_views((B, cfg.in_chans, *cfg.volume_size), seed=700 + i)
+        model.set_masking_noise(*R.masking_noise(B, cfg.num_patches, seed=800 + i))
+        runner = model._step_runner(B, 0.75, True, False, False)
+        runner.load(v1.cuda(), v2.cuda())
+        eng.optimizer_hparams(lr=1e-3)
+        runner.run()
+        torch.cuda.synchronize()
+
+    model, opt, eng = make()
+    assert eng.state16 and eng.opt_state['exp_avg'].dtype == torch.bfloat16 and eng.opt_state['exp_avg_sq'].dtype == torch.bfloat16
+    for i in range(2):
+        step(model, eng, i)
+    sd_opt, sd_model = opt.state_dict(), {k: v.detach().clone() for k, v in model.state_dict().items()}
+    assert sd_opt['fused_adamw']['exp_avg'].dtype == torch.float32 and sd_opt['fused_adamw']['step'] == 2
+    assert float(sd_opt['fused_adamw']['exp_avg'].abs().max()) > 0
+    model2, opt2, eng2 = make()
+    model2.load_state_dict(sd_model)
+    opt2.load_state_dict(sd_opt)
+    assert torch.equal(eng2.opt_state['exp_avg'], eng.opt_state['exp_avg']) and torch.equal(eng2.opt_state['exp_avg_sq'], eng.opt_state['exp_avg_sq'])
+    before = eng.params.clone()
+    step(model, eng, 2); step(model2, eng2, 2)
+    upd = float((eng.params - before).norm())
+    # (the same step up to the summation order of the atomically accumulated bias / token gradients)
+    assert upd > 0 and float((eng.params - eng2.params).norm()) < 1e-3 * upd
+    assert float((eng.opt_state['exp_avg'].float() - eng2.opt_state['exp_avg'].float()).norm()) < 1e-3 * float(eng.opt_state['exp_avg'].float().norm())
+    # the guard
+    _, _, eng3 = make(betas=(0.9, 0.999))
+    assert not eng3.state16 and eng3.opt_state['exp_avg_sq'].dtype == torch.float32
+    _, _, eng4 = make(precision='fp32')
+    assert not eng4.state16
+    model5 = build(cfg, sd0, precision='bf16').train()
+    model5._ensure_engine(torch.device('cuda', 0))
+    topt = _ref_adamw(dict(model5.named_parameters()), 1e-3, 0.05)          # betas (0.9, 0.95)
+    assert adopt(topt, model5) is topt and model5.engine.state16
+    eng.betas = (0.9, 0.999)
+    with pytest.raises(Exception):
+        eng.optimizer_hparams(lr=1e-3)                                       # a moment that slow would stall in bf16 storage: refused
+
+
 def test_two_plane_weights_follow_the_bucketed_optimiser():
     """the two-plane forward reads BOTH planes of a weight from ``hilo`` (never the bf16 shadow), and the only thing that
     keeps them current is ``refresh_w2`` behind every AdamW bucket.  After fused steps with the optimiser inside the backward the hi

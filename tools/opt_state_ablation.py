@@ -22,13 +22,29 @@ torch.set_num_threads(int(os.environ.get('ABL_THREADS', '8')))
 args = dict(a.split('=') for a in sys.argv[1:] if '=' in a)
 what = [a for a in sys.argv[1:] if '=' not in a] or ['pins', 'tiny']
 bf = lambda t: t.to(torch.bfloat16).to(torch.float32)
-VARIANTS = {'fp32 state': (), 'm bf16': ('exp_avg',), 'v bf16': ('exp_avg_sq',), 'm + v bf16': ('exp_avg', 'exp_avg_sq')}
+VARIANTS = {'fp32 state': (), 'm bf16': ('exp_avg',), 'v bf16': ('exp_avg_sq',), 'm + v bf16': ('exp_avg', 'exp_avg_sq'),
+            'm + v + matrix gradients bf16': ('exp_avg', 'exp_avg_sq', 'GRAD')}     # GRAD: the gradients of the matrices rounded before the step
 
 
 def round_state(tr, keys):
     for st in tr.optimizer.state.values():
         for k in keys:
-            st[k].copy_(bf(st[k]))
+            if k != 'GRAD':
+                st[k].copy_(bf(st[k]))
+
+
+def install_grad_rounding(tr, keys):
+    """'GRAD': round the gradient of every matrix to bf16 right before optimizer.step() (what a weight-gradient epilogue that stores bf16 only does)"""
+    if 'GRAD' not in keys:
+        return
+    orig = tr.optimizer.step
+
+    def step(*a, **k):
+        for p in tr.params.values():
+            if p.grad is not None and p.ndim >= 2:
+                p.grad.copy_(bf(p.grad))
+        return orig(*a, **k)
+    tr.optimizer.step = step
 
 
 def pins():
@@ -38,6 +54,7 @@ def pins():
     cfg = R.vit_base_cfg(contrastive=True, **VITB)
     for name, keys in VARIANTS.items():
         tr = T.RefTrainer(cfg, R.init_state_dict(cfg, seed=0), lr=lr, weight_decay=wd)
+        install_grad_rounding(tr, keys)
         worst, t0 = [0.0] * 4, time.time()
         for it in range(steps + 1):
             v1, v2 = R.synthetic_views((4, 4, 96, 96, 96), seed=1234 + it)
@@ -58,6 +75,7 @@ def tiny():
 
     def curve(keys, noise_seed):
         tr = T.RefTrainer(cfg, R.init_state_dict(cfg, seed=0), lr=lr, weight_decay=0.05)
+        install_grad_rounding(tr, keys)
         out = []
         for it in range(steps):
             v1, v2 = vols[it % len(vols)]

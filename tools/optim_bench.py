@@ -26,5 +26,8 @@ print(f'adamw, fp32 moments {us:.1f} us  {n * 30 / us / 1e6:.2f} TB/s (30 B per 
 m16, v16 = m.to(torch.bfloat16), v.to(torch.bfloat16)
 us = t(lambda: lib.vitae_adamw_step_s16(p.data_ptr(), g.data_ptr(), 0, m16.data_ptr(), v16.data_ptr(), sh.data_ptr(), n, hp.data_ptr(), None, 0.05, st))
 print(f'adamw, bf16 moments {us:.1f} us  {n * 22 / us / 1e6:.2f} TB/s (22 B per parameter)')
+g16 = g.to(torch.bfloat16)
+us = t(lambda: lib.vitae_adamw_step_s16(p.data_ptr(), g16.data_ptr(), 1, m16.data_ptr(), v16.data_ptr(), sh.data_ptr(), n, hp.data_ptr(), None, 0.05, st))
+print(f'adamw, bf16 moments + bf16 gradients {us:.1f} us  {n * 20 / us / 1e6:.2f} TB/s (20 B per parameter)')
 us = t(lambda: lib.vitae_grad_sqnorm(g.data_ptr(), n, acc.data_ptr(), gn.data_ptr(), st))
 print(f'gradnorm {us:.1f} us  {n * 4 / us / 1e6:.2f} TB/s')
