@@ -2,7 +2,7 @@
 vitae_linear_bwd_pair_glds (input gradient + weight gradient in ONE launch) with the step's real epilogues — GELU' from the saved
 bf16 derivative on fc2, the bias gradients as row sums in the weight-gradient workgroups, the gradient norm's share — next to the
 same halves as launches of their own.
-    python tools/pair_bench.py [B=4] [iters=20]
+    python tools/pair_bench.py [B=4] [iters=20] [model=L128] [tile=5]
 Prints us per launch (graph replay of `iters` back-to-back launches, 4 operand sets cycled) and the launch's algorithmic TFLOP/s."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -70,7 +70,12 @@ def case(name, M, N, K, gelu=False, dx32=True, dx16=True, dycs=False):
 
 tot = 0.0
 Me, Md = 2 * B * 55, B * 217
-for pre, M, d, h, depth in (('enc', Me, 768, 3072, 12), ('dec', Md, 512, 2048, 8)):
+shapes = (('enc', Me, 768, 3072, 12), ('dec', Md, 512, 2048, 8))
+if args.get('model') == 'L128':       # BASELINE config 4: ViT-L/16 on 128^3 volumes (512 patches, 25 % kept + cls; decoder 512 wide on 513 tokens)
+    shapes = (('enc', B * 129, 1024, 4096, 24), ('dec', B * 513, 512, 2048, 8))
+if 'tile' in args:                    # force one tile family of the planner (5 = wave-specialised 64 x 64 pair)
+    lib.vitae_gemm_glds_set_bt_tile(int(args['tile']))
+for pre, M, d, h, depth in shapes:
     t = 0.0
     t += case(f'{pre} fc2', M, d, h, gelu=True, dx32=False)
     t += case(f'{pre} fc1', M, h, d, dx16=False, dycs=True)

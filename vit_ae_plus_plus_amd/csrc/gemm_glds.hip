@@ -646,7 +646,8 @@ inline double est_64row(int M, int N, int K, bool allow_split, bool wgrad_form) 
 }
 
 // cap: floats of split-K workspace a plan may need (< 0: no limit — the caller sizes the workspace from the plan's split)
-inline BtPlan bt_plan(int M, int N, int K, int a_kc, int b_kc, bool allow_split, long cap = -1, bool allow_ws64 = true) {
+inline BtPlan bt_plan(int M, int N, int K, int a_kc, int b_kc, bool allow_split, long cap = -1, bool allow_ws64 = true, int only = -1) {
+    // only >= 0: the best split of THAT tile family alone, by the planner's own (unforced) rules and without the 64-row comparison
     BtPlan best{-1, 1, 1e30};
     if (g_bt_mode == -2 || K < 2 * BK || (K % BK) || (!a_kc && b_kc) || (N & 3)) return best;
     const int nkt = K / BK;
@@ -668,6 +669,7 @@ inline BtPlan bt_plan(int M, int N, int K, int a_kc, int b_kc, bool allow_split,
     static const double wsw_kt = getenv("VITAE_BT_WSW_KT") ? atof(getenv("VITAE_BT_WSW_KT")) : 1350.0;     // 128 x 256 ws tile (weight-gradient form): 48 KB per k-tile at the CU's 37 B/clk
     static const int wsw_on = getenv("VITAE_BT_WSW") ? atoi(getenv("VITAE_BT_WSW")) : 1;
     for (int id : {0, 3, 4, 5, 6}) {
+        if (only >= 0 && id != only) continue;
         if (id == 6 && (a_kc || b_kc || (g_bt_mode < 0 && !wsw_on))) continue;
         if (id == 5 && g_bt_mode != 5 && (!ws64_on || !allow_ws64)) continue;
         if (g_bt_mode >= 0 && id != g_bt_mode) continue;
@@ -713,7 +715,7 @@ inline BtPlan bt_plan(int M, int N, int K, int a_kc, int b_kc, bool allow_split,
             if (clk < best.clocks) best = BtPlan{id, s, clk};
         }
     }
-    if (best.tile < 0 || g_bt_mode >= 0) return best;
+    if (best.tile < 0 || g_bt_mode >= 0 || only >= 0) return best;
     if (best.clocks >= 0.92 * est_64row(M, N, K, allow_split, !a_kc && !b_kc) * (nkt >= 128 ? 1.25 : 1.0)) return BtPlan{-1, 1, 0.0};     // (the same HBM-stream factor as above)
     return best;
 }
@@ -967,38 +969,40 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
         return gemm_glds_launch(1, 0, dy16, N, w16, K, dx, K, dx16, K, M, K, N, nullptr, nullptr, 0, epi | epi_flags,
                                 aux, K, dx_accumulate, sp, splitk_ws, dx_colsum_accum, stream, &pd);
     }
+    // both halves as wave-specialised 64 x 64 workgroups of ONE launch (gemm_bt.hip: gemm_ws64_pair_kernel), the input gradient cut `split` ways
+    auto ws64_pair = [&](int split) -> int {
+        GArgs p1, p2;
+        p1.A = reinterpret_cast<const __bf16*>(dy16); p1.lda = N;
+        p1.B = reinterpret_cast<const __bf16*>(w16); p1.ldb = K;
+        p1.C = dx; p1.ldc = K; p1.C16 = reinterpret_cast<__bf16*>(dx16); p1.ldc16 = K;
+        p1.M = M; p1.N = K; p1.K = N; p1.k_per_split = N; p1.splits = split;
+        p1.bias = nullptr; p1.residual = nullptr; p1.ldr = 0; p1.aux = aux; p1.ldaux = K; p1.epi = epi; p1.aux16 = aux16; p1.auxd = auxd;
+        p1.accumulate = dx_accumulate != 0; p1.ws = splitk_ws; p1.out_colsum = dx_colsum_accum; p1.a_rowsum = nullptr; p1.dbg = g_gemm_dbg;
+        p1.xcd_m = xcd_by_rows(M, K); p1.tiles_m = 0; p1.tiles_n = 0;
+        p1.vec_epi = vec_epilogue_ok(p1);
+        p2.A = reinterpret_cast<const __bf16*>(dy16); p2.lda = N;
+        p2.B = reinterpret_cast<const __bf16*>(x16); p2.ldb = K;
+        p2.C = dw; p2.ldc = K; p2.C16 = reinterpret_cast<__bf16*>(dw16); p2.ldc16 = K;
+        p2.M = N; p2.N = K; p2.K = Mpad; p2.k_per_split = Mpad; p2.splits = 1;
+        p2.bias = nullptr; p2.residual = nullptr; p2.ldr = 0; p2.aux = nullptr; p2.ldaux = 0; p2.epi = VITAE_EPI_NONE;
+        p2.accumulate = dw_accumulate; p2.ws = nullptr; p2.out_colsum = nullptr; p2.a_rowsum = dy_colsum_accum; p2.dbg = g_gemm_dbg;
+        set_sq(p2);
+        p2.xcd_m = xcd_by_rows(N, K); p2.tiles_m = 0; p2.tiles_n = 0;
+        p2.vec_epi = vec_epilogue_ok(p2);
+        if (!p1.vec_epi || !p2.vec_epi) return VITAE_ERR_UNSUPPORTED_SHAPE;
+        // VITAE_WS64Q=1: the persistent form (round 6: csrc/gemm_bt.hip gemm_ws64q_pair_kernel — correct, measured 6-10 % SLOWER than
+        // one tile per workgroup on the batch-4 / batch-8 pair launches, so it is opt-in; read per call so that a test can switch it)
+        const char* wsq_env = getenv("VITAE_WS64Q");
+        const int wsq = wsq_env ? atoi(wsq_env) : 0;
+        const int rc = wsq ? ws64q_pair_launch(p1, p2, (hipStream_t)stream) : VITAE_ERR_UNSUPPORTED_SHAPE;
+        return rc != VITAE_ERR_UNSUPPORTED_SHAPE ? rc : ws64_pair_launch(p1, p2, (hipStream_t)stream);
+    };
     if (g_bt_mode == -1 || g_bt_mode == 5) {
-        // Few token rows: both halves as wave-specialised 64 x 64 workgroups of ONE launch (gemm_bt.hip: gemm_ws64_pair_kernel)
+        // Few token rows: the planner puts BOTH halves on that tile
         const BtPlan pd = bt_plan(M, K, N, 1, 0, true, cap), pw = bt_plan(N, K, Mpad, 0, 0, false, cap);
         if (pd.tile == 5 && pw.tile == 5) {
-            GArgs p1, p2;
-            p1.A = reinterpret_cast<const __bf16*>(dy16); p1.lda = N;
-            p1.B = reinterpret_cast<const __bf16*>(w16); p1.ldb = K;
-            p1.C = dx; p1.ldc = K; p1.C16 = reinterpret_cast<__bf16*>(dx16); p1.ldc16 = K;
-            p1.M = M; p1.N = K; p1.K = N; p1.k_per_split = N; p1.splits = pd.split;
-            p1.bias = nullptr; p1.residual = nullptr; p1.ldr = 0; p1.aux = aux; p1.ldaux = K; p1.epi = epi; p1.aux16 = aux16; p1.auxd = auxd;
-            p1.accumulate = dx_accumulate != 0; p1.ws = splitk_ws; p1.out_colsum = dx_colsum_accum; p1.a_rowsum = nullptr; p1.dbg = g_gemm_dbg;
-            p1.xcd_m = xcd_by_rows(M, K); p1.tiles_m = 0; p1.tiles_n = 0;
-            p1.vec_epi = vec_epilogue_ok(p1);
-            p2.A = reinterpret_cast<const __bf16*>(dy16); p2.lda = N;
-            p2.B = reinterpret_cast<const __bf16*>(x16); p2.ldb = K;
-            p2.C = dw; p2.ldc = K; p2.C16 = reinterpret_cast<__bf16*>(dw16); p2.ldc16 = K;
-            p2.M = N; p2.N = K; p2.K = Mpad; p2.k_per_split = Mpad; p2.splits = 1;
-            p2.bias = nullptr; p2.residual = nullptr; p2.ldr = 0; p2.aux = nullptr; p2.ldaux = 0; p2.epi = VITAE_EPI_NONE;
-            p2.accumulate = dw_accumulate; p2.ws = nullptr; p2.out_colsum = nullptr; p2.a_rowsum = dy_colsum_accum; p2.dbg = g_gemm_dbg;
-            set_sq(p2);
-            p2.xcd_m = xcd_by_rows(N, K); p2.tiles_m = 0; p2.tiles_n = 0;
-            p2.vec_epi = vec_epilogue_ok(p2);
-            if (p1.vec_epi && p2.vec_epi) {
-                // VITAE_WS64Q=1: the persistent form (round 6: csrc/gemm_bt.hip gemm_ws64q_pair_kernel — correct, measured 6-10 % SLOWER than
-                // one tile per workgroup on the batch-4 / batch-8 pair launches, so it is opt-in; read per call so that a test can switch it)
-                const char* wsq_env = getenv("VITAE_WS64Q");
-                const int wsq = wsq_env ? atoi(wsq_env) : 0;
-                int rc = wsq ? ws64q_pair_launch(p1, p2, (hipStream_t)stream) : VITAE_ERR_UNSUPPORTED_SHAPE;
-                if (rc != VITAE_ERR_UNSUPPORTED_SHAPE) return rc;
-                rc = ws64_pair_launch(p1, p2, (hipStream_t)stream);
-                if (rc != VITAE_ERR_UNSUPPORTED_SHAPE) return rc;
-            }
+            const int rc = ws64_pair(pd.split);
+            if (rc != VITAE_ERR_UNSUPPORTED_SHAPE) return rc;
         }
     }
     if (g_bt_mode != -2) {
@@ -1023,6 +1027,18 @@ extern "C" int vitae_linear_bwd_pair_glds(const void* dy16, const void* w16, con
             if (dy_colsum_accum)
                 launch_colsum_bf16(dy16, dy_colsum_accum, M, N, (hipStream_t)stream);
             return vitae_launch_status();
+        }
+    }
+    static const int pair_ws64_rest = getenv("VITAE_PAIR_WS64_REST") ? atoi(getenv("VITAE_PAIR_WS64_REST")) : 1;
+    if (g_bt_mode == -1 && pair_ws64_rest) {
+        // Neither the big tiles nor (for both halves) the planner's 64 x 64 choice: what used to fall through to the 64-row pair kernel
+        // below.  Round 6, ViT-L/16 on 128^3 (BASELINE config 4, 516 token rows x 1024 / 4096): the wave-specialised pair takes 26.7 /
+        // 27.6 us on fc2 / fc1 where that kernel takes 38.3 / 36.7 (tools/pair_bench.py model=L128) — the planner had priced the weight
+        // gradient alone on 128 x 128 tiles a little cheaper, which un-paired nothing and only kept the faster pair out.
+        const BtPlan p5 = bt_plan(M, K, N, 1, 0, true, cap, true, 5);
+        if (p5.tile == 5) {
+            const int rc = ws64_pair(p5.split);
+            if (rc != VITAE_ERR_UNSUPPORTED_SHAPE) return rc;
         }
     }
     GArgs p1, p2;
