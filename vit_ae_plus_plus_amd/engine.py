@@ -220,13 +220,16 @@ class HipMAEEngine:
         self._accum = False
         self._split_cache: Dict[Tuple[int, int, int], int] = {}
         self.stream = 0
-        self.side = torch.cuda.Stream(device=device)   # target-side loss branch runs beside the transformer
-        self.wside = torch.cuda.Stream(device=device)  # weight-gradient GEMMs run beside the dgrad chain
-        self.pside = torch.cuda.Stream(device=device)  # predictor branch (fwd, cosine loss, bwd) beside the decoder
+        # Branch streams (properties ``side`` / ``wside`` / ``pside`` / ``oside`` below):
+        #   side   target-side loss branch beside the transformer        wside  weight-gradient GEMMs beside the dgrad chain
+        #   pside  predictor branch (fwd, cosine loss, bwd) beside the decoder    oside  per-bucket grad-norm + AdamW beside the backward
+        self._branch_streams = {n: torch.cuda.Stream(device=device) for n in ('side', 'wside', 'pside', 'oside')}
+        sel = os.environ.get('VITAE_SIDE_STREAMS', 'auto')       # 'auto' | 'all' | 'none' | comma list of the four names
+        self.side_streams = None if sel == 'auto' else set(self._branch_streams) if sel == 'all' else set(filter(None, sel.split(','))) - {'none'}
+        self.side_min_rows = int(os.environ.get('VITAE_SIDE_MIN_ROWS', '2500'))
         self.ws_side = torch.empty(1 << 22, **f32)     # its own split-K scratch
         self.ws_wside = torch.empty(1 << 23, **f32)    # ... and the wgrad side stream's (fp32 / fp32x3 schedules: split weight gradients)
         self.overlap_predictor = os.environ.get('VITAE_PREDICTOR_SIDE', '1') != '0'
-        self.oside = torch.cuda.Stream(device=device)  # per-bucket grad-norm + AdamW beside the rest of the backward
         self.overlap_optimizer = os.environ.get('VITAE_OPT_IN_BACKWARD', '1') != '0'
         self._opt_pending = False
         self._pred_pending = False
@@ -1694,6 +1697,27 @@ class HipMAEEngine:
     # patch 8 328 vs 294; batch 8 1336 vs 1361-1372 when its decoder (1792 x 512) is grouped, 1314-1343 when everything is
     # Round 4 (side-stream grouped launch, wave-specialised input-gradient launches beside it): batch 8 5.40 -> 5.28 ms, batch 12 6.84 -> 6.51
     # with both stacks grouped; batch 4 neutral (4.14 vs 4.17): threshold between them.
+    def _branch(self, name):
+        """The stream of a branch of the step — or the CURRENT stream when the step is small (round 6).  A captured step whose
+        branches fork is replayed by the HIP runtime on several hardware queues, and every edge between two queues is a signal
+        the command processors hand over: with DEBUG_HIP_FORCE_GRAPH_QUEUES=1 (everything on one queue) the batch-4 step ran
+        3.72 instead of 3.93 ms, config 5 3.78 / 4.02, ViT-L/16 128^3 8.86 / 9.18, batch 8 even — and batch 16 / 32 / patch 8
+        lost 1.2 / 4.1 / 2.4 % (profiles/round6_graph_queues.txt): what runs beside the chain there is worth more than the
+        hand-overs cost.  So the branches fork only from ``side_min_rows`` decoder token rows up (VITAE_SIDE_MIN_ROWS; VITAE_SIDE_STREAMS
+        = all | none | a comma list forces the set); data parallel always forks (the runner joins the optimiser stream between
+        the graphs of a step)."""
+        if self.side_streams is None:
+            on = self._ddp_active or getattr(self, 'Md', 0) >= self.side_min_rows
+        else:
+            on = name in self.side_streams
+        return self._branch_streams[name] if on else torch.cuda.current_stream(self.device)
+
+    def _branch_prop(name):
+        return property(lambda self: self._branch(name), lambda self, st: self._branch_streams.__setitem__(name, st))
+
+    side, wside, pside, oside = _branch_prop('side'), _branch_prop('wside'), _branch_prop('pside'), _branch_prop('oside')
+    del _branch_prop
+
     wgrad_group_min = int(float(os.environ.get('VITAE_WGRAD_GROUP_MIN', '0.6e6')))
     bn_split_min_rows = int(os.environ.get('VITAE_BN_SPLIT_MIN_ROWS', '128'))   # predictor BatchNorm: rows per view from which the row-split kernels run
     target_one_pass = os.environ.get('VITAE_TARGET_ONE_PASS', '1') != '0'
