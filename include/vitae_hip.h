@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VITAE_ABI_VERSION 47
+#define VITAE_ABI_VERSION 48
 
 /* matrix-core arithmetic of the dense contractions */
 #define VITAE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 (the reference's precision, autocast off at utils/train_one_epoch.py:50) */
@@ -72,6 +72,7 @@ extern "C" {
 #define VITAE_ACC_GRADSQ 3
 #define VITAE_ACC_TICKET_A 4  /* first 4 bytes: workgroup arrival counter of vitae_opt_tail's norm pass (zero after the per-step zeroing) */
 #define VITAE_ACC_TICKET_B 5  /* ... of its AdamW pass */
+#define VITAE_ACC_TICKET_C 6  /* ... of vitae_cosine_loss_fwd (its last workgroup writes the scalar and leaves the counter at zero) */
 #define VITAE_ACC_NONFINITE 7 /* the first 4 bytes of this slot are a FLOAT: 0 after the per-step zeroing, NaN once the loss
                                 * backward produced a non-finite gradient (the early form of GradScaler.step's inf check:
                                 * a `grad_norm` pointer for vitae_adamw_step before the global norm exists) */
@@ -461,6 +462,11 @@ int vitae_adamw_step_bf16g(float* params, const void* grads_bf16, float* exp_avg
  * vitae_opt_tail takes the same storage through its state_bf16 flag. */
 int vitae_adamw_step_s16(float* params, const void* grads, int grads_bf16, void* exp_avg_bf16, void* exp_avg_sq_bf16,
                          void* shadow_bf16, long n, const float* hp, const float* grad_norm, float weight_decay, void* stream);
+/* ... gated by the accumulator block itself instead of a finalised norm: the pass is skipped when acc[VITAE_ACC_GRADSQ] + the
+ * VITAE_ACC_SQ_* slots (the squares collected so far) are not finite — the verdict vitae_grad_norm_finalize + grad_norm would give,
+ * without that launch in front of every gradient bucket (round 6: a node of a replayed step costs 4-5 us whatever it does). */
+int vitae_adamw_step_s16_acc(float* params, const void* grads, int grads_bf16, void* exp_avg_bf16, void* exp_avg_sq_bf16,
+                             void* shadow_bf16, long n, const float* hp, const double* acc, float weight_decay, void* stream);
 /* hp[VITAE_HP_STEP] += 1 unless grad_norm[0] is not finite: the end of an optimiser step issued as separate vitae_adamw_step calls */
 int vitae_opt_count_bump(float* hp, const float* grad_norm, void* stream);
 /* The tail of one optimisation step in TWO launches (was: norm pass, finalisation, two AdamW launches): the last n_decay +

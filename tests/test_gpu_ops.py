@@ -876,6 +876,21 @@ def test_cosine_loss(lib, C):
         lib.vitae_cosine_loss_fwd(*(t.data_ptr() for t in pz), acc.data_ptr(), hp.data_ptr(), out.data_ptr(), Rb, D, st())
         want = R.contrastive_loss(pz[0].cpu(), pz[2].cpu(), pz[3].cpu(), pz[1].cpu(), w)
         assert abs(float(out) - float(want)) < 1e-9 + 1e-5 * abs(float(want))
+    # round 6: the scalar leaves with the last workgroup of the forward launch (vector widths) — the arrival counter is back at zero
+    # afterwards, so a second call on the same block (sum slot cleared, nothing else) gives the same scalar; a width outside the
+    # vector forms (and an unaligned operand) takes the two-launch path
+    assert int(acc.view(torch.int32)[2 * C['VITAE_ACC_TICKET_C']]) == 0
+    first = float(out)
+    acc[C['VITAE_ACC_COS']] = 0
+    out.fill_(7.0)
+    lib.vitae_cosine_loss_fwd(*(t.data_ptr() for t in pz), acc.data_ptr(), hp.data_ptr(), out.data_ptr(), Rb, D, st())
+    assert float(out) == pytest.approx(first, rel=1e-6)
+    for Dw in (256, 512, 1024, 320):
+        pz = [dev(gen(37, Dw, seed=s)) for s in (9, 10, 11, 12)]
+        acc.zero_(); out.fill_(7.0)
+        lib.vitae_cosine_loss_fwd(*(t.data_ptr() for t in pz), acc.data_ptr(), hp.data_ptr(), out.data_ptr(), 37, Dw, st())
+        want = R.contrastive_loss(pz[0].cpu(), pz[2].cpu(), pz[3].cpu(), pz[1].cpu(), w)
+        assert abs(float(out) - float(want)) < 1e-9 + 1e-5 * abs(float(want)), Dw
 
 
 # --------------------------------------------------------------------------- optimiser
@@ -908,6 +923,50 @@ def test_adamw_and_gradnorm(lib, C):
     gn.fill_(float('inf'))
     lib.vitae_adamw_step(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), None, n, hp.data_ptr(), gn.data_ptr(), 0.05, st())
     assert torch.equal(p, before)
+
+
+def test_adamw_gated_by_the_accumulator(lib, C):
+    """vitae_adamw_step_s16_acc (round 6): the finiteness gate read from the accumulator block — the same update as
+    vitae_grad_norm_finalize + vitae_adamw_step_s16, and no update at all once any slot of the block is not finite."""
+    n = 70_001
+    npad = (n + 3) // 4 * 4
+    gen_ = torch.Generator(device='cuda').manual_seed(11)
+    hp = torch.zeros(C['VITAE_HP_COUNT'], device='cuda')
+    hp[C['VITAE_HP_LR']], hp[C['VITAE_HP_BETA1']], hp[C['VITAE_HP_BETA2']], hp[C['VITAE_HP_EPS']], hp[C['VITAE_HP_GRAD_MUL']] = 3e-4, 0.9, 0.95, 1e-8, 1.0
+    hp[C['VITAE_HP_BC1']], hp[C['VITAE_HP_BC2']] = 0.1, 0.05
+    p0 = torch.randn(npad, device='cuda', generator=gen_) * 0.02
+    g = torch.randn(npad, device='cuda', generator=gen_) * 0.01
+    m0 = (torch.randn(npad, device='cuda', generator=gen_) * 0.01).bfloat16()
+    v0 = (torch.rand(npad, device='cuda', generator=gen_) * 1e-4).bfloat16()
+    acc = torch.zeros(C['VITAE_ACC_COUNT'], dtype=torch.float64, device='cuda')
+    acc[C['VITAE_ACC_GRADSQ']] = 2.0
+    acc[C['VITAE_ACC_SQ_BASE'] + 5 * C['VITAE_ACC_SQ_STRIDE']] = 7.0
+    norm = torch.zeros(1, device='cuda')
+
+    def run(gated_by_acc):
+        p, m, v = p0.clone(), m0.clone(), v0.clone()
+        sh = torch.zeros(npad, dtype=torch.bfloat16, device='cuda')
+        if gated_by_acc:
+            rc = lib.vitae_adamw_step_s16_acc(p.data_ptr(), g.data_ptr(), 0, m.data_ptr(), v.data_ptr(), sh.data_ptr(), n, hp.data_ptr(),
+                                              acc.data_ptr(), 0.05, st())
+        else:
+            lib.vitae_grad_norm_finalize(acc.data_ptr(), norm.data_ptr(), st())
+            rc = lib.vitae_adamw_step_s16(p.data_ptr(), g.data_ptr(), 0, m.data_ptr(), v.data_ptr(), sh.data_ptr(), n, hp.data_ptr(),
+                                          norm.data_ptr(), 0.05, st())
+        assert rc == 0
+        torch.cuda.synchronize()
+        return p, m, v, sh
+
+    a, b = run(True), run(False)
+    assert float(norm) == pytest.approx(3.0)
+    assert all(torch.equal(x, y) for x, y in zip(a, b)) and not torch.equal(a[0], p0)
+    for slot, bad in ((C['VITAE_ACC_GRADSQ'], float('nan')), (C['VITAE_ACC_SQ_BASE'] + 63 * C['VITAE_ACC_SQ_STRIDE'], float('inf'))):
+        keep = float(acc[slot]); acc[slot] = bad
+        a, b = run(True), run(False)
+        assert torch.equal(a[0], p0) and torch.equal(a[1], m0) and torch.equal(a[2], v0) and torch.equal(b[0], p0)
+        acc[slot] = keep
+    with pytest.raises(Exception, match='INVALID_ARG'):
+        lib.vitae_adamw_step_s16_acc(p0.data_ptr(), g.data_ptr(), 0, m0.data_ptr(), v0.data_ptr(), None, n, hp.data_ptr(), None, 0.0, st())
 
 
 def test_adamw_bf16_moments(lib, C):

@@ -760,6 +760,54 @@ __global__ __launch_bounds__(256) void cosine_fwd_kernel(const float* __restrict
     if (threadIdx.x == 0) atomicAdd(acc + VITAE_ACC_COS, (red[0] + red[1]) + (red[2] + red[3]));
 }
 
+// The same for D = 256 NV with everything a row needs in flight at once (round 6: the scalar form above walks a row in twelve
+// dependent 4-byte steps per pair, the pairs one after the other — 14 us for 220 x 768 at batch 4, on the step's one queue), and the
+// scalar result written by the LAST workgroup to arrive (acc[VITAE_ACC_TICKET_C]; it leaves the ticket at zero) instead of by a
+// launch of its own.
+template <int NV>
+__global__ __launch_bounds__(256) void cosine_fwd_vec_kernel(const float* __restrict__ p1, const float* __restrict__ z2,
+                                                             const float* __restrict__ p2, const float* __restrict__ z1,
+                                                             double* __restrict__ acc, const float* __restrict__ hp,
+                                                             float* __restrict__ out, float inv_rows, int R, float eps) {
+    constexpr int D = 256 * NV;
+    __shared__ double red[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double csum = 0.0;
+    for (int row = blockIdx.x * 4 + wave; row < R; row += gridDim.x * 4) {
+        f32x4 a[2][NV], b[2][NV];
+#pragma unroll
+        for (int pair = 0; pair < 2; ++pair) {
+            const f32x4* p = reinterpret_cast<const f32x4*>((pair == 0 ? p1 : p2) + (long)row * D);
+            const f32x4* z = reinterpret_cast<const f32x4*>((pair == 0 ? z2 : z1) + (long)row * D);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) { a[pair][i] = p[lane + 64 * i]; b[pair][i] = z[lane + 64 * i]; }
+        }
+#pragma unroll
+        for (int pair = 0; pair < 2; ++pair) {
+            float dot = 0.f, pp = 0.f, zz = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float x = a[pair][i][e], y = b[pair][i][e]; dot += x * y; pp += x * x; zz += y * y; }
+            dot = wave_sum(dot); pp = wave_sum(pp); zz = wave_sum(zz);
+            csum += (double)(dot / (fmaxf(sqrtf(pp), eps) * fmaxf(sqrtf(zz), eps)));
+        }
+    }
+    if (lane == 0) red[wave] = csum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(acc + VITAE_ACC_COS, (red[0] + red[1]) + (red[2] + red[3]));
+        __threadfence();
+        unsigned* ticket = reinterpret_cast<unsigned*>(acc + VITAE_ACC_TICKET_C);
+        if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+            __threadfence();
+            const double total = atomicAdd(acc + VITAE_ACC_COS, 0.0);      // (device-scope read of what every workgroup added)
+            out[0] = hp[VITAE_HP_CONTR_W] * (float)(-0.5 * total * (double)inv_rows);
+            atomicExch(ticket, 0u);
+        }
+    }
+}
+
 // contr = contr_w * (-(mean cos(p1,z2) + mean cos(p2,z1)) / 2)
 __global__ void cosine_finalize_kernel(const double* __restrict__ acc, const float* __restrict__ hp, float* __restrict__ out, float inv_rows) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -968,6 +1016,16 @@ extern "C" int vitae_cosine_loss_fwd(const float* p1, const float* z2, const flo
     if (!p1 || !z2 || !p2 || !z1 || !acc || !hp || !out1 || R <= 0 || D <= 0) return VITAE_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
     // (one row per wave up to 1024 workgroups: a wave that walks several rows is a chain of memory latencies — 26 us at 1732 rows on 256)
+    const dim3 grid(cdiv(R, 4) < 1024 ? cdiv(R, 4) : 1024);
+    const bool al = !(((uintptr_t)p1 | (uintptr_t)z2 | (uintptr_t)p2 | (uintptr_t)z1) & 15);
+    if (al && (D == 768 || D == 1024 || D == 512 || D == 256)) {
+        const float ir = 1.0f / (float)R;
+        if (D == 768) hipLaunchKernelGGL(cosine_fwd_vec_kernel<3>, grid, dim3(256), 0, st, p1, z2, p2, z1, acc, hp, out1, ir, R, 1e-8f);
+        else if (D == 1024) hipLaunchKernelGGL(cosine_fwd_vec_kernel<4>, grid, dim3(256), 0, st, p1, z2, p2, z1, acc, hp, out1, ir, R, 1e-8f);
+        else if (D == 512) hipLaunchKernelGGL(cosine_fwd_vec_kernel<2>, grid, dim3(256), 0, st, p1, z2, p2, z1, acc, hp, out1, ir, R, 1e-8f);
+        else hipLaunchKernelGGL(cosine_fwd_vec_kernel<1>, grid, dim3(256), 0, st, p1, z2, p2, z1, acc, hp, out1, ir, R, 1e-8f);
+        return vitae_launch_status();
+    }
     hipLaunchKernelGGL(cosine_fwd_kernel, dim3(cdiv(R, 4) < 1024 ? cdiv(R, 4) : 1024), dim3(256), 0, st, p1, z2, p2, z1, acc, R, D, 1e-8f);
     hipLaunchKernelGGL(cosine_finalize_kernel, dim3(1), dim3(64), 0, st, acc, hp, out1, 1.0f / (float)R);
     return vitae_launch_status();

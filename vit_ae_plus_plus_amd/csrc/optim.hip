@@ -91,8 +91,18 @@ template <bool NT, typename G, int U = 8, typename S = float>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const G* __restrict__ g, S* __restrict__ m,
                                                     S* __restrict__ v, __bf16* __restrict__ shadow, long n,
                                                     const float* __restrict__ hp, const float* __restrict__ gnorm,
-                                                    float weight_decay) {
+                                                    float weight_decay, const double* __restrict__ gacc = nullptr) {
     if (gnorm) { const float gn = gnorm[0]; if (!(gn == gn) || fabsf(gn) == INFINITY) return; }
+    if (gacc) {
+        // the gate straight from the accumulator (round 6): what grad_norm_finalize_kernel would have written for this bucket — every
+        // wave sums the 64 spread slots + acc[GRADSQ] itself (65 L2 hits) instead of one more 4-5 us node in front of every bucket
+        double q = gacc[VITAE_ACC_SQ_BASE + (threadIdx.x & 63) * VITAE_ACC_SQ_STRIDE];
+        if ((threadIdx.x & 63) == 0) q += gacc[VITAE_ACC_GRADSQ];
+#pragma unroll
+        for (int d = 32; d; d >>= 1) q += __shfl_xor(q, d, 64);
+        const float gn = (float)sqrt(q);
+        if (!(gn == gn) || fabsf(gn) == INFINITY) return;
+    }
     const float lr = hp[VITAE_HP_LR], b1 = hp[VITAE_HP_BETA1], b2 = hp[VITAE_HP_BETA2], eps = hp[VITAE_HP_EPS];
     float bc1 = hp[VITAE_HP_BC1], bc2 = hp[VITAE_HP_BC2];
     if (bc1 <= 0.f) {            // the host left the bias corrections to the device: t = applied steps + 1 (vitae_hip.h VITAE_HP_STEP)
@@ -320,7 +330,7 @@ extern "C" int vitae_grad_sqnorm_bf16(const void* grads_bf16, long n, double* ac
 
 template <typename G, typename S = float>
 static int adamw_launch(float* params, const G* grads, S* exp_avg, S* exp_avg_sq, void* shadow_bf16, long n,
-                        const float* hp, const float* grad_norm, float weight_decay, void* stream) {
+                        const float* hp, const float* grad_norm, float weight_decay, void* stream, const double* gacc = nullptr) {
     if (!params || !grads || !exp_avg || !exp_avg_sq || !hp || n <= 0) return VITAE_ERR_INVALID_ARG;
     if (((uintptr_t)params & 15) || (((uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & (4 * sizeof(S) - 1))) return VITAE_ERR_INVALID_ARG;
     if (((uintptr_t)grads & (4 * sizeof(G) - 1)) || ((uintptr_t)shadow_bf16 & 7)) return VITAE_ERR_INVALID_ARG;
@@ -337,16 +347,16 @@ static int adamw_launch(float* params, const G* grads, S* exp_avg, S* exp_avg_sq
     static const int unroll = getenv("VITAE_ADAMW_UNROLL") ? atoi(getenv("VITAE_ADAMW_UNROLL")) : 8;
     if (unroll == 4)
         hipLaunchKernelGGL((adamw_kernel<true, G, 4, S>), dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
-                           exp_avg_sq, reinterpret_cast<__bf16*>(shadow_bf16), n, hp, grad_norm, weight_decay);
+                           exp_avg_sq, reinterpret_cast<__bf16*>(shadow_bf16), n, hp, grad_norm, weight_decay, gacc);
     else if (unroll == 12)
         hipLaunchKernelGGL((adamw_kernel<true, G, 12, S>), dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
-                           exp_avg_sq, reinterpret_cast<__bf16*>(shadow_bf16), n, hp, grad_norm, weight_decay);
+                           exp_avg_sq, reinterpret_cast<__bf16*>(shadow_bf16), n, hp, grad_norm, weight_decay, gacc);
     else if (unroll == 8)
         hipLaunchKernelGGL((adamw_kernel<true, G, 8, S>), dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
-                           exp_avg_sq, reinterpret_cast<__bf16*>(shadow_bf16), n, hp, grad_norm, weight_decay);
+                           exp_avg_sq, reinterpret_cast<__bf16*>(shadow_bf16), n, hp, grad_norm, weight_decay, gacc);
     else
         hipLaunchKernelGGL((adamw_kernel<true, G, 2, S>), dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
-                           exp_avg_sq, reinterpret_cast<__bf16*>(shadow_bf16), n, hp, grad_norm, weight_decay);
+                           exp_avg_sq, reinterpret_cast<__bf16*>(shadow_bf16), n, hp, grad_norm, weight_decay, gacc);
     return vitae_launch_status();
 }
 
@@ -358,6 +368,18 @@ extern "C" int vitae_adamw_step_s16(float* params, const void* grads, int grads_
     if (grads_bf16)
         return adamw_launch<__bf16, __bf16>(params, reinterpret_cast<const __bf16*>(grads), m, v, shadow_bf16, n, hp, grad_norm, weight_decay, stream);
     return adamw_launch<float, __bf16>(params, reinterpret_cast<const float*>(grads), m, v, shadow_bf16, n, hp, grad_norm, weight_decay, stream);
+}
+
+// ... gated by the gradient-norm accumulator itself (acc: the double[VITAE_ACC_COUNT] block; the step is skipped when the sum of
+// acc[VITAE_ACC_GRADSQ] and the VITAE_ACC_SQ_* slots is not finite — what vitae_grad_norm_finalize + grad_norm would say, without that launch)
+extern "C" int vitae_adamw_step_s16_acc(float* params, const void* grads, int grads_bf16, void* exp_avg_bf16, void* exp_avg_sq_bf16,
+                                        void* shadow_bf16, long n, const float* hp, const double* acc, float weight_decay, void* stream) {
+    if (!acc) return VITAE_ERR_INVALID_ARG;
+    __bf16* m = reinterpret_cast<__bf16*>(exp_avg_bf16);
+    __bf16* v = reinterpret_cast<__bf16*>(exp_avg_sq_bf16);
+    if (grads_bf16)
+        return adamw_launch<__bf16, __bf16>(params, reinterpret_cast<const __bf16*>(grads), m, v, shadow_bf16, n, hp, nullptr, weight_decay, stream, acc);
+    return adamw_launch<float, __bf16>(params, reinterpret_cast<const float*>(grads), m, v, shadow_bf16, n, hp, nullptr, weight_decay, stream, acc);
 }
 
 extern "C" int vitae_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,

@@ -1559,7 +1559,10 @@ class HipMAEEngine:
         p = self.params.data_ptr() + 4 * o
         if self.state16:
             g = (g16.data_ptr() + 2 * o) if g16 is not None else (self.grads.data_ptr() + 4 * o)
-            lib.vitae_adamw_step_s16(p, g, 1 if g16 is not None else 0, m, v, sh, n, _ptr(self.hp), gnorm, weight_decay, st)
+            if gnorm is None:       # gated by the accumulator block itself (per-bucket launches: no finalisation node in front)
+                lib.vitae_adamw_step_s16_acc(p, g, 1 if g16 is not None else 0, m, v, sh, n, _ptr(self.hp), _ptr(self.acc), weight_decay, st)
+            else:
+                lib.vitae_adamw_step_s16(p, g, 1 if g16 is not None else 0, m, v, sh, n, _ptr(self.hp), gnorm, weight_decay, st)
         elif g16 is not None:
             lib.vitae_adamw_step_bf16g(p, g16.data_ptr() + 2 * o, m, v, sh, n, _ptr(self.hp), gnorm, weight_decay, st)
         else:
@@ -1633,7 +1636,10 @@ class HipMAEEngine:
                     a, e = max(a, s0), min(e, e0)
                     if e > a:
                         lib.vitae_grad_sqnorm(self.grads.data_ptr() + 4 * a, e - a, _ptr(self.acc), None, st)
-                lib.vitae_grad_norm_finalize(_ptr(self.acc), run, st)
+                if self.state16 and self.adamw_acc_gate:
+                    run = None       # the AdamW launch reads the accumulator itself
+                else:
+                    lib.vitae_grad_norm_finalize(_ptr(self.acc), run, st)
             else:
                 lib.vitae_grad_sqnorm(self.grads.data_ptr() + o, n, _ptr(self.acc), run, st)
             self._adamw(s0, n, run, self.weight_decay, st)
@@ -1718,6 +1724,7 @@ class HipMAEEngine:
     side, wside, pside, oside = _branch_prop('side'), _branch_prop('wside'), _branch_prop('pside'), _branch_prop('oside')
     del _branch_prop
 
+    adamw_acc_gate = os.environ.get('VITAE_ADAMW_ACC_GATE', '1') != '0'
     wgrad_group_min = int(float(os.environ.get('VITAE_WGRAD_GROUP_MIN', '0.6e6')))
     bn_split_min_rows = int(os.environ.get('VITAE_BN_SPLIT_MIN_ROWS', '128'))   # predictor BatchNorm: rows per view from which the row-split kernels run
     target_one_pass = os.environ.get('VITAE_TARGET_ONE_PASS', '1') != '0'
