@@ -622,6 +622,7 @@ def main():
     if ddp_on and ONE_GPU:
         also_exchange = {'skipped': 'native RCCL leg needs one GPU per rank (plumbing mode: all ranks on one GPU over gloo)'}
     elapsed, first_gpu, last, exchange = legs[0]
+    forked = eng.forked_branches()      # (of the timed workload: the extra points below rebind the workspace)
     ms = elapsed / args.steps * 1e3
     value = world * args.batch * args.steps / elapsed
 
@@ -741,6 +742,8 @@ def main():
                           'parallelism': f'dp{world}' + (' (PLUMBING CHECK: all ranks on ONE GPU, gloo transport)' if ONE_GPU else ''),
                           'rccl_ranks': dist.get_world_size() if (world > 1 or force_ddp) else 1,
                           'hip_graph': not args.no_graph, 'weights': 'product initialize_weights, seed 0',
+                          # which branch streams the step forks (engine._branch): none = the captured step is ONE chain on one hardware queue
+                          'step_branches_forked': forked,
                           'grad_allreduce': (f'{grad_comm}, {len(model._reducer.ranges)} buckets' if model._reducer is not None else None),
                           'exchange': exchange, 'also_exchange': also_exchange, 'gemm_dispatch': BT_NOTE,
                           'ddp_streams_on_own_hw_queues': (getattr(model, '_stream_report', None) or {}).get('ok'),

@@ -563,10 +563,12 @@ def test_grouped_weight_gradients_match_the_paired_launches():
         model = build(cfg, sd, precision='bf16').train()
         eng = model._ensure_engine(torch.device('cuda', 0))
         eng.wgrad_group_min = rows
+        eng.side_min_rows = 1        # (round 6: grouped launches exist only where the branch streams fork — few rows run as one chain)
         model.set_masking_noise(n1, n2)
         loss, pred, mask, p1, p2, z1, z2 = model(view1=v1.cuda(), view2=v2.cuda(), mask_ratio=0.75, edge_map_weight=0.01)
         loss[0].backward()
         torch.cuda.synchronize()
+        assert eng._grouped(256, 768) == (rows == 1) and ('encdx_16b' in eng.buf) == (rows == 1)
         res.append(([float(x.detach()) for x in loss],
                     {k: p.grad.detach().double().clone() for k, p in model.named_parameters() if p.requires_grad}))
         del model
@@ -652,8 +654,56 @@ def test_recurring_device_batches_are_read_in_place():
         assert direct == ([False, True, True, True] if in_place else [False] * 4)
         finals.append((eng.losses.cpu().tolist(), model.state_dict()['blocks.0.mlp.fc1.weight'].clone()))
     close(finals[1][0][0], finals[0][0][0], 1e-5, 1e-7)
-    # four Adam steps at lr 1e-3: stale or misplaced input would show at the 1e-3 level; atomics order accounts for ~1e-6
-    assert float((finals[0][1] - finals[1][1]).abs().max()) < 1e-5
+    # four Adam steps at lr 1e-3: stale or misplaced input would move EVERY weight at the 1e-3 level.  The order of the float atomics
+    # (token / bias gradients) usually leaves the two runs bit-identical and otherwise moves a typical weight by ~1e-6 — and a rare
+    # one by far more: an element whose gradient is next to zero sits on a step of m / (sqrt(v) + eps), and with the moments stored in
+    # bf16 (round 6) next to a rounding boundary as well (seen once in a full-suite run: max 5.6e-5).  So the sharp bound is on the
+    # root mean square and the bound on the worst element is loose.
+    diff = (finals[0][1] - finals[1][1]).float()
+    stats = (float(diff.pow(2).mean().sqrt()), float(diff.abs().max()), int((diff.abs() > 1e-5).sum()))
+    assert stats[0] < 5e-6 and stats[1] < 3e-4, stats
+
+
+def test_small_steps_are_one_chain_and_forked_branches_give_the_same_step(monkeypatch):
+    """Round 6: below ``side_min_rows`` decoder token rows the step's branches (target edge map, predictor, per-bucket optimiser,
+    grouped weight gradients) are issued on the current stream — the captured graph is one chain on one hardware queue; with the
+    branch streams forced on, the same three steps land on the same losses and weights."""
+    from vit_ae_plus_plus_amd.optim import FusedAdamW
+    cfg = R.RefConfig(contrastive=True, **ACT16)
+    sd = R.init_state_dict(cfg, seed=23)
+    B, outs = 2, {}
+    shape = (B, cfg.in_chans, *cfg.volume_size)
+    for sel in ('auto', 'all', 'oside,side'):
+        monkeypatch.setenv('VITAE_SIDE_STREAMS', sel)
+        model = build(cfg, sd, precision='bf16')
+        opt = FusedAdamW(model, lr=1e-3, weight_decay=0.05)
+        model._ensure_engine(torch.device('cuda', 0))
+        eng = opt.engine
+        eng.set_loss_weights(0.01, 0.001, 1, 1)
+        runner = model._step_runner(B, 0.75, True, False, True)
+        for step in range(3):
+            v1, v2 = R.synthetic_views(shape, seed=900 + step)
+            model.set_masking_noise(*R.masking_noise(B, cfg.num_patches, seed=950 + step))
+            runner.load(v1.cuda(), v2.cuda())
+            eng.optimizer_hparams(lr=1e-3)
+            runner.run()
+        torch.cuda.synchronize()
+        assert eng.forked_branches() == {'auto': [], 'all': ['oside', 'pside', 'side', 'wside'], 'oside,side': ['oside', 'side']}[sel]
+        outs[sel] = (eng.losses.cpu().tolist(), model.state_dict()['decoder_blocks.0.mlp.fc2.weight'].clone())
+        if sel == 'auto':       # the rule itself: rows of the decoder's token matrix against the threshold; data parallel always forks
+            assert eng.Md == B * (cfg.num_patches + 1) < eng.side_min_rows
+            eng.side_min_rows = eng.Md
+            assert eng.forked_branches() == ['oside', 'pside', 'side', 'wside']
+            eng.side_min_rows = eng.Md + 1
+            assert eng.forked_branches() == []
+            eng._ddp_active = True
+            assert eng.forked_branches() == ['oside', 'pside', 'side', 'wside']
+            eng._ddp_active = False
+    for sel in ('all', 'oside,side'):
+        for k in range(6):
+            close(outs[sel][0][k], outs['auto'][0][k], 1e-5, 1e-7)
+        diff = (outs[sel][1] - outs['auto'][1]).float()
+        assert float(diff.pow(2).mean().sqrt()) < 5e-6 and float(diff.abs().max()) < 3e-4
 
 
 # --------------------------------------------------------------------------- the benchmarked path itself, pinned

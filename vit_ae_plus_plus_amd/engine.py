@@ -497,7 +497,7 @@ class HipMAEEngine:
                     if self.qkv16:
                         b[q + 'qkv_16'] = z16(Mp, 3 * d)
                 b[pre + 'dx_16'], b[pre + 'dh_16'], b[pre + 'dqkv_16'] = z16(Mp, d), z16(Mp, h), z16(Mp, 3 * d)
-                if Mp * d >= self.wgrad_group_min:
+                if self._grouped(Mp, d):
                     b[pre + 'dx_16b'] = z16(Mp, d)
                     if self.wgrad_group_side:
                         for nm, w in (('dx_16', d), ('dx_16b', d), ('dh_16', h), ('dqkv_16', 3 * d)):
@@ -995,7 +995,7 @@ class HipMAEEngine:
     def _dyset(self, i, Mp, d) -> str:
         """Suffix of the buffer set that holds block i's output-gradient operands (side-stream grouped weight gradients: two
         alternating sets, so that block i's weight-gradient launch may still read its set while block i - 1 runs)."""
-        return '_alt' if (self.wgrad_group_side and (i & 1) and Mp * d >= self.wgrad_group_min) else ''
+        return '_alt' if (self.wgrad_group_side and (i & 1) and self._grouped(Mp, d)) else ''
 
     def _block_bwd16(self, pre, q, s, x_in, Bs, N, d, heads, hd, hid, Mp, prev_fc2_bias, idx=0):
         """Backward of one block on bf16 operands.  On entry buf[s+'dx'] (fp32) and buf[s+'dx_16'] hold the
@@ -1010,7 +1010,7 @@ class HipMAEEngine:
         # Many token rows (batch >= ~16, patch 8): the four weight gradients of the block leave as ONE launch at its end
         # (``_wgrad_group``) and the Linears' backward launches compute the input gradients only.  Each dy operand then has to
         # survive until that launch: the gradient w.r.t. the block's middle (norm2's output) goes to a second bf16 buffer.
-        grp = Mp * d >= self.wgrad_group_min
+        grp = self._grouped(Mp, d)
         side = grp and self.wgrad_group_side and self.gemm_timer is None
         dw = (lambda name: None) if grp else (lambda name: g[name])
         dmid16 = b[s + 'dx_16b' + sfx] if grp else dx16
@@ -1717,6 +1717,22 @@ class HipMAEEngine:
         else:
             on = name in self.side_streams
         return self._branch_streams[name] if on else torch.cuda.current_stream(self.device)
+
+    def _grouped(self, Mp: int, d: int) -> bool:
+        """A block's four weight gradients as ONE grouped launch (and its Linears' backward launches input gradients only)?  From
+        ``wgrad_group_min`` padded rows x width up — and only where that launch runs BESIDE the chain: on one queue the paired
+        launches (input + weight gradient together) are fewer nodes for the same work (round 6, batch 8 on one queue: 4.90 ms
+        grouped, 4.80 paired).  Decided by the workspace's shape alone (not by ``_ddp_active``: buffers are sized by it)."""
+        if Mp * d < self.wgrad_group_min:
+            return False
+        if self.side_streams is None:
+            return getattr(self, 'Md', 0) >= self.side_min_rows
+        return 'wside' in self.side_streams
+
+    def forked_branches(self):
+        """Names of the branch streams the step forks at the current workspace (empty: one chain on the current stream)."""
+        cur = torch.cuda.current_stream(self.device)
+        return sorted(n for n in self._branch_streams if self._branch(n) != cur)
 
     def _branch_prop(name):
         return property(lambda self: self._branch(name), lambda self, st: self._branch_streams.__setitem__(name, st))
