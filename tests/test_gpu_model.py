@@ -820,14 +820,17 @@ def test_two_plane_weights_follow_the_bucketed_optimiser():
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize('precision', ['bf16', 'fp32', 'fp32x3'])   # fp32x3 (split-operand bf16 MFMA) is held to the fp32 mode's bounds
-def test_bench_workload_b4_fused_graph_vs_reference_pins(precision, monkeypatch):
+# fp32x3 (split-operand bf16 MFMA) is held to the fp32 mode's bounds; 'all': the step's branches FORKED (what batch >= 16 and data parallel
+# run; batch 4 itself is one chain since round 6) must hold the same pins
+@pytest.mark.parametrize('precision,branches', [('bf16', 'auto'), ('fp32', 'auto'), ('fp32x3', 'auto'), ('bf16', 'all')])
+def test_bench_workload_b4_fused_graph_vs_reference_pins(precision, branches, monkeypatch):
     """BASELINE config 2 at the batch the metric is quoted on (B = 4, contrastive ViT-B/16, 96^3 x 4ch) through the
     route bench.py times — the fused optimisation step replayed from a HIP graph: first-step loss scalars, per-parameter
     gradient norms and the loss trajectory of three AdamW steps against pins from the reference's own model (SURVEY §8c
     item 2; reference model/vit_autoenc.py:205-238, utils/train_one_epoch.py:52-75)."""
     from vit_ae_plus_plus_amd.optim import FusedAdamW
     monkeypatch.setenv('VITAE_W2', 'dec.fc1')      # the bf16 bounds below were recorded with this class on two planes (the default): pinned (ADVICE r5)
+    monkeypatch.setenv('VITAE_SIDE_STREAMS', branches)
     g = load_golden('vitb_b4.npz')
     B, steps, lr, wd, mask_ratio, edge_w, contr_w = [float(v) for v in g['hp']]
     B, steps = int(B), int(steps)
@@ -845,6 +848,7 @@ def test_bench_workload_b4_fused_graph_vs_reference_pins(precision, monkeypatch)
     r0.load(v1.cuda(), v2.cuda())
     r0.run()
     torch.cuda.synchronize()
+    assert eng.forked_branches() == ([] if branches == 'auto' else ['oside', 'pside', 'side', 'wside'])
     assert torch.equal(eng.buf['mask'][:B].sum(1).cpu(), t(g['mask_sum']))
     named = dict(model._trainable_named)
     worst = 0.0
