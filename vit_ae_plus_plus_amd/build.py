@@ -19,7 +19,10 @@ OBJ = os.path.join(CSRC, '_obj')
 LIB = os.path.join(PKG, 'libvitae_hip.so')
 SOURCES = ['gemm.hip', 'gemm_bf16.hip', 'gemm_glds.hip', 'gemm_bt.hip', 'norm.hip', 'attention.hip', 'attention_mfma.hip', 'tokens.hip', 'loss.hip', 'loss_fused.hip',
            'optim.hip', 'input.hip', 'ddp.hip', 'percep.hip']
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast',
+# -amdgpu-kernarg-preload-count=16: the first 16 dwords of a kernel's scalar / pointer arguments arrive in SGPRs with the dispatch instead
+# of through a cold scalar load at the top of every launch (round 6: the batch-4 step 3.662 -> 3.636 ms, alternating A/B; kernels that take
+# their arguments as ONE by-value struct — the LDS-DMA GEMM family's GArgs — are not covered by the option)
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast', '-mllvm', '-amdgpu-kernarg-preload-count=16',
          '-I', os.path.join(ROOT, 'include'), '-I', CSRC] + os.environ.get('VITAE_HIPCC_FLAGS', '').split()
 
 
