@@ -1160,8 +1160,22 @@ constexpr int WS64_SMEM = VITAE_WS64_STAGES * 16384;
 // enters at ~2^-17 instead of 2^-9 while the activations stay bf16.  Why: tools/bf16_rounding_ablation.py — the bf16 schedule's
 // loss error against the fp32 reference is carried by the rounding of the WEIGHTS in the forward (1.3e-4 of 1.5e-4 on the total;
 // activations 9e-6, the whole backward 4e-6), and the decoder's fc1 alone is 1.2e-4 of it.
+// What a workgroup needs before its first DMA can leave (tile decoding + operand addressing).  The stand-alone kernels take these as
+// LEADING SCALAR kernel arguments: with -amdgpu-kernarg-preload-count=16 they arrive in SGPRs with the dispatch, while the by-value
+// descriptor behind them is fetched by scalar loads that nothing on the producers' path waits for (round 6).
+struct WsHot {
+    const __bf16* A; const __bf16* B; const __bf16* B2;        // (B2: the lo plane of a two-plane weight, else unused)
+    int lda, ldb, M, N, K, tiles_m, tiles_n, xcd_m, kps;      // xcd_m: bit 0 the XCD map, bit 1 "p.dbg is set"
+};
+__device__ __forceinline__ WsHot ws_hot(const GArgs& p) {
+    return WsHot{p.A, p.B, p.B2, (int)p.lda, (int)p.ldb, p.M, p.N, p.K, p.tiles_m, p.tiles_n, p.xcd_m | (p.dbg ? 2 : 0), p.k_per_split};
+}
+// the stand-alone kernels' leading scalars (13 dwords; 14 can be preloaded): the tile counts follow from M and N (64 x 64 tiles)
+#define WS_HOT_PARAMS const __bf16* A, const __bf16* B, const __bf16* B2, int lda, int ldb, int M, int N, int K, int xcd_m, int kps
+#define WS_HOT_FROM_PARAMS WsHot{A, B, B2, lda, ldb, M, N, K, (M + 63) >> 6, (N + 63) >> 6, xcd_m, kps}
+#define WS_HOT_ARGS(p) (p).A, (p).B, (p).B2, (int)(p).lda, (int)(p).ldb, (p).M, (p).N, (p).K, (p).xcd_m | ((p).dbg ? 2 : 0), (p).k_per_split
 template <bool A_KC, bool B_KC, int S, bool RS, bool W2 = false>
-__device__ __forceinline__ void gemm_ws64_body(const GArgs& p, const int bid, const int zid, unsigned char* smem) {
+__device__ __forceinline__ void gemm_ws64_body(const GArgs& p, const WsHot& h, const int bid, const int zid, unsigned char* smem) {
 #ifndef VITAE_WS64_PRODUCERS
 #define VITAE_WS64_PRODUCERS 4
 #endif
@@ -1170,15 +1184,15 @@ __device__ __forceinline__ void gemm_ws64_body(const GArgs& p, const int bid, co
     constexpr int PA = pieces<BM, A_KC, NWP>(), PB = pieces<BN, B_KC, NWP>(), PT = PA + (W2 ? 2 : 1) * PB;
     static_assert(!W2 || (A_KC && B_KC && !RS), "two weight planes: the forward form");
     static_assert(S >= 3 && S <= 5 && (S - 2) * PT <= 63, "stage count");
-    const int T = p.tiles_m * p.tiles_n;
+    const int T = h.tiles_m * h.tiles_n;
     const int xq = T >> 3, xr = T & 7, xcd = bid & 7;
     const int lin = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
     if ((bid >> 3) >= xq + (xcd < xr ? 1 : 0)) return;
-    const int tn = p.xcd_m ? lin % p.tiles_n : lin / p.tiles_m;
-    const int tm = p.xcd_m ? lin / p.tiles_n : lin % p.tiles_m;
+    const int tn = (h.xcd_m & 1) ? lin % h.tiles_n : lin / h.tiles_m;
+    const int tm = (h.xcd_m & 1) ? lin / h.tiles_n : lin % h.tiles_m;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int kbeg = zid * p.k_per_split;
-    const int nk = (min(p.K, kbeg + p.k_per_split) - kbeg) / BK;         // >= 2 (launcher)
+    const int kbeg = zid * h.kps;
+    const int nk = (min(h.K, kbeg + h.kps) - kbeg) / BK;         // >= 2 (launcher)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     auto barrier = [&]() {
@@ -1189,7 +1203,7 @@ __device__ __forceinline__ void gemm_ws64_body(const GArgs& p, const int bid, co
     // tools/ws64_phase_probe.py: s_memtime stamps of consumer wave 0 (slots 0-7) and producer wave 4 (8-15) of every workgroup,
     // 16 per workgroup indexed by its position in the launch (blockIdx.x + gridDim.x * blockIdx.z)
     auto stamp = [&](int i) {
-        if (p.dbg && (threadIdx.x & 255) == 0) p.dbg[((long)blockIdx.z * gridDim.x + blockIdx.x) * 16 + i] = __builtin_amdgcn_s_memtime();
+        if ((h.xcd_m & 2) && (threadIdx.x & 255) == 0) p.dbg[((long)blockIdx.z * gridDim.x + blockIdx.x) * 16 + i] = __builtin_amdgcn_s_memtime();
     };
     if (wave >= NWC) {
         // ---------------- producers ----------------
@@ -1199,12 +1213,12 @@ __device__ __forceinline__ void gemm_ws64_body(const GArgs& p, const int bid, co
             unsigned char* dst = smem + stage * STG;
             const int k0 = kbeg + t * BK;
 #pragma unroll
-            for (int j = 0; j < PA; ++j) dma_piece<BM, A_KC, NWP>(p.A, p.lda, p.M, m0, k0, dst, pw, lane, j);
+            for (int j = 0; j < PA; ++j) dma_piece<BM, A_KC, NWP>(h.A, h.lda, h.M, m0, k0, dst, pw, lane, j);
 #pragma unroll
-            for (int j = 0; j < PB; ++j) dma_piece<BN, B_KC, NWP>(p.B, p.ldb, p.N, n0, k0, dst + A_T, pw, lane, j);
+            for (int j = 0; j < PB; ++j) dma_piece<BN, B_KC, NWP>(h.B, h.ldb, h.N, n0, k0, dst + A_T, pw, lane, j);
             if constexpr (W2) {
 #pragma unroll
-                for (int j = 0; j < PB; ++j) dma_piece<BN, B_KC, NWP>(p.B2, p.ldb, p.N, n0, k0, dst + A_T + B_T, pw, lane, j);
+                for (int j = 0; j < PB; ++j) dma_piece<BN, B_KC, NWP>(h.B2, h.ldb, h.N, n0, k0, dst + A_T + B_T, pw, lane, j);
             }
         };
         auto wait_tiles = [&](int fly) {
@@ -1372,15 +1386,16 @@ __device__ __forceinline__ void gemm_ws64_body(const GArgs& p, const int bid, co
 }
 
 template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(64 * (4 + VITAE_WS64_PRODUCERS), 2) void gemm_ws64_kernel(const GArgs p) {
+__global__ __launch_bounds__(64 * (4 + VITAE_WS64_PRODUCERS), 2) void gemm_ws64_kernel(WS_HOT_PARAMS, const GArgs p) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[WS64_SMEM];      // the ONLY LDS object
-    gemm_ws64_body<A_KC, B_KC, VITAE_WS64_STAGES, false>(p, blockIdx.x, blockIdx.z, smem);
+    const WsHot h = WS_HOT_FROM_PARAMS;
+    gemm_ws64_body<A_KC, B_KC, VITAE_WS64_STAGES, false>(p, h, blockIdx.x, blockIdx.z, smem);
 }
 
 constexpr int WS64W2_STAGES = 3;            // [A | B hi | B lo] = 24 KB per stage: three stages = 72 KB, two workgroups per CU
-__global__ __launch_bounds__(64 * (4 + VITAE_WS64_PRODUCERS), 2) void gemm_ws64_w2_kernel(const GArgs p) {
+__global__ __launch_bounds__(64 * (4 + VITAE_WS64_PRODUCERS), 2) void gemm_ws64_w2_kernel(WS_HOT_PARAMS, const GArgs p) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[WS64W2_STAGES * 24576];      // the ONLY LDS object
-    gemm_ws64_body<true, true, WS64W2_STAGES, false, true>(p, blockIdx.x, blockIdx.z, smem);
+    gemm_ws64_body<true, true, WS64W2_STAGES, false, true>(p, WS_HOT_FROM_PARAMS, blockIdx.x, blockIdx.z, smem);
 }
 
 // p: a complete forward-form descriptor (both operands k-contiguous, vec_epi set, p.B2 = the lo plane, p.splits k-ranges)
@@ -1392,7 +1407,7 @@ int ws64_w2_launch(GArgs p, hipStream_t st) {
     p.tiles_m = cdiv(p.M, 64); p.tiles_n = cdiv(p.N, 64); p.tile0 = 0;
     if (p.splits > 1 && (!p.ws || (long)p.tiles_m * p.tiles_n > VITAE_GLDS_TICKETS || p.epi == VITAE_EPI_GELU)) return VITAE_ERR_UNSUPPORTED_SHAPE;
     const dim3 grid(8 * cdiv((long)p.tiles_m * p.tiles_n, 8), 1, p.splits), block(64 * (4 + VITAE_WS64_PRODUCERS));
-    hipLaunchKernelGGL(gemm_ws64_w2_kernel, grid, block, 0, st, p);
+    hipLaunchKernelGGL(gemm_ws64_w2_kernel, grid, block, 0, st, WS_HOT_ARGS(p), p);
     return vitae_launch_status();
 }
 
@@ -1701,11 +1716,23 @@ int wsx3_launch(GArgs p, int a_kc, int b_kc, hipStream_t st) {
 // Backward of one Linear as ONE launch of such workgroups: the first nb1 * p1.splits blocks compute the input gradient
 // dx = epi(dy W) (A = dy k-contiguous, B = W row-contiguous; its long reduction cut into p1.splits), the rest the weight gradient
 // dW (+)= dy^T x (both row-contiguous; RS: + colsum(dy)).
+// The leading scalars are what either half needs before its first DMA (WsHot), in 14 dwords so that all of them are preloaded: the
+// halves of one Linear's backward SHARE dy (A of both), its leading dimension, the leading dimension of W / x, the width K of the layer
+// (N of both), and the weight gradient's rows are the input gradient's reduction length (ws64_pair_launch checks exactly that).
+//   packed = nb1 | p1.splits << 20 | p1.xcd_m << 24 | p2.xcd_m << 25 | (dbg set) << 26
 template <bool RS>
-__global__ __launch_bounds__(64 * (4 + VITAE_WS64_PRODUCERS), 2) void gemm_ws64_pair_kernel(const GArgs p1, const GArgs p2, const int nb1) {
+__global__ __launch_bounds__(64 * (4 + VITAE_WS64_PRODUCERS), 2) void gemm_ws64_pair_kernel(const __bf16* A, const __bf16* B1, const __bf16* B2, int lda, int ldb,
+                                                                                           int M1, int N1, int K1, int K2, int kps1, int packed,
+                                                                                           const GArgs p1, const GArgs p2) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[WS64_SMEM];
-    if ((int)blockIdx.x < nb1 * p1.splits) gemm_ws64_body<true, false, VITAE_WS64_STAGES, false>(p1, blockIdx.x % nb1, blockIdx.x / nb1, smem);
-    else gemm_ws64_body<false, false, VITAE_WS64_STAGES, RS>(p2, blockIdx.x - nb1 * p1.splits, 0, smem);
+    const int nb1 = packed & 0xfffff, splits1 = (packed >> 20) & 15, dbg2 = (packed >> 25) & 2;
+    if ((int)blockIdx.x < nb1 * splits1) {
+        const WsHot h{A, B1, nullptr, lda, ldb, M1, N1, K1, (M1 + 63) >> 6, (N1 + 63) >> 6, ((packed >> 24) & 1) | dbg2, kps1};
+        gemm_ws64_body<true, false, VITAE_WS64_STAGES, false>(p1, h, blockIdx.x % nb1, blockIdx.x / nb1, smem);
+    } else {
+        const WsHot h{A, B2, nullptr, lda, ldb, K1, N1, K2, (K1 + 63) >> 6, (N1 + 63) >> 6, ((packed >> 25) & 1) | dbg2, K2};
+        gemm_ws64_body<false, false, VITAE_WS64_STAGES, RS>(p2, h, blockIdx.x - nb1 * splits1, 0, smem);
+    }
 }
 
 // p1 / p2: complete descriptors of the two halves (vec_epi set, K % 64 == 0); p1.splits k-ranges of >= 2 k-tiles each
@@ -1721,8 +1748,14 @@ int ws64_pair_launch(GArgs p1, GArgs p2, hipStream_t st) {
     if (p1.splits > 1 && (!p1.ws || (long)p1.tiles_m * p1.tiles_n > VITAE_GLDS_TICKETS)) return VITAE_ERR_UNSUPPORTED_SHAPE;
     const int nb1 = 8 * cdiv((long)p1.tiles_m * p1.tiles_n, 8), nb2 = 8 * cdiv((long)p2.tiles_m * p2.tiles_n, 8);
     const dim3 grid(nb1 * p1.splits + nb2), block(64 * (4 + VITAE_WS64_PRODUCERS));
-    if (p2.a_rowsum) hipLaunchKernelGGL((gemm_ws64_pair_kernel<true>), grid, block, 0, st, p1, p2, nb1);
-    else hipLaunchKernelGGL((gemm_ws64_pair_kernel<false>), grid, block, 0, st, p1, p2, nb1);
+    // what the kernel's leading scalars assume (the two halves of ONE Linear's backward: gemm_ws64_pair_kernel)
+    if (p1.A != p2.A || p1.lda != p2.lda || p1.ldb != p2.ldb || p2.M != p1.K || p2.N != p1.N || nb1 >= (1 << 20) || p1.splits > 15 ||
+        p1.lda >= (1L << 31) || p1.ldb >= (1L << 31)) return VITAE_ERR_UNSUPPORTED_SHAPE;
+    const int packed = nb1 | p1.splits << 20 | (p1.xcd_m & 1) << 24 | (p2.xcd_m & 1) << 25 | ((p1.dbg || p2.dbg) ? 1 << 26 : 0);
+    if (p2.a_rowsum) hipLaunchKernelGGL((gemm_ws64_pair_kernel<true>), grid, block, 0, st, p1.A, p1.B, p2.B, (int)p1.lda, (int)p1.ldb, p1.M, p1.N, p1.K,
+                                        p2.K, p1.k_per_split, packed, p1, p2);
+    else hipLaunchKernelGGL((gemm_ws64_pair_kernel<false>), grid, block, 0, st, p1.A, p1.B, p2.B, (int)p1.lda, (int)p1.ldb, p1.M, p1.N, p1.K,
+                            p2.K, p1.k_per_split, packed, p1, p2);
     return vitae_launch_status();
 }
 
@@ -2210,9 +2243,9 @@ int bt_launch(GArgs p, int a_kc, int b_kc, int id, hipStream_t st) {
         hipLaunchKernelGGL(gemm_wsw_wgrad_group_kernel, dim3(total, 1, p.splits), dim3(512), 0, st, g);
     } else if (id == 5) {
         const dim3 grid(8 * cdiv((long)p.tiles_m * p.tiles_n, 8), 1, p.splits), block(64 * (4 + VITAE_WS64_PRODUCERS));
-        if (a_kc && b_kc) hipLaunchKernelGGL((gemm_ws64_kernel<true, true>), grid, block, 0, st, p);
-        else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_ws64_kernel<true, false>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((gemm_ws64_kernel<false, false>), grid, block, 0, st, p);
+        if (a_kc && b_kc) hipLaunchKernelGGL((gemm_ws64_kernel<true, true>), grid, block, 0, st, WS_HOT_ARGS(p), p);
+        else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_ws64_kernel<true, false>), grid, block, 0, st, WS_HOT_ARGS(p), p);
+        else hipLaunchKernelGGL((gemm_ws64_kernel<false, false>), grid, block, 0, st, WS_HOT_ARGS(p), p);
     } else if (id == 4) {
         const dim3 grid(8 * cdiv((long)p.tiles_m * p.tiles_n, 8), 1, p.splits), block(512);
         if (a_kc && b_kc) hipLaunchKernelGGL((gemm_ws_kernel<true, true>), grid, block, 0, st, p);
