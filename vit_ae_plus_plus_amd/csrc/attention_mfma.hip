@@ -695,8 +695,9 @@ template <int HD, typename QT = float>
 #endif
 __global__ __launch_bounds__(256, VITAE_ATTN_FUSED_MINW) void attn_bwd_fused_kernel(const QT* __restrict__ qkv, const float* __restrict__ o,
                                                              const float* __restrict__ d_o, const float* __restrict__ lse,
+                                                             int N, int H, float scale, int NP,      // (what the loads need: inside the 14 preloaded dwords)
                                                              float* __restrict__ dqkv, __bf16* __restrict__ dqkv16,
-                                                             float* __restrict__ dbias, int N, int H, float scale, int NP) {
+                                                             float* __restrict__ dbias) {
     constexpr int LD = HD + 8, NKK = HD / 16, NT = HD / 32, V4 = HD / 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
     __bf16* Qs = reinterpret_cast<__bf16*>(fsm);
@@ -1076,14 +1077,14 @@ extern "C" int vitae_sdpa_mfma_bwd_bf16in(const void* qkv_bf16, const float* o, 
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<32, __bf16>),
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         (void)attr;
-        hipLaunchKernelGGL((attn_bwd_fused_kernel<32, __bf16>), fgrid, dim3(256), lds, st, q16, o, d_o, lse, dqkv, g16,
-                           dqkv_colsum_accum, N, H, scale, NP);
+        hipLaunchKernelGGL((attn_bwd_fused_kernel<32, __bf16>), fgrid, dim3(256), lds, st, q16, o, d_o, lse, N, H, scale, NP, dqkv, g16,
+                           dqkv_colsum_accum);
     } else {
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<64, __bf16>),
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         (void)attr;
-        hipLaunchKernelGGL((attn_bwd_fused_kernel<64, __bf16>), fgrid, dim3(256), lds, st, q16, o, d_o, lse, dqkv, g16,
-                           dqkv_colsum_accum, N, H, scale, NP);
+        hipLaunchKernelGGL((attn_bwd_fused_kernel<64, __bf16>), fgrid, dim3(256), lds, st, q16, o, d_o, lse, N, H, scale, NP, dqkv, g16,
+                           dqkv_colsum_accum);
     }
     return vitae_launch_status();
 }
@@ -1112,14 +1113,14 @@ extern "C" int vitae_sdpa_mfma_bwd(const float* qkv, const float* o, const float
             static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<32>),
                                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
             (void)attr;
-            hipLaunchKernelGGL((attn_bwd_fused_kernel<32>), fgrid, dim3(256), lds, st, qkv, o, d_o, lse, dqkv, g16,
-                               dqkv_colsum_accum, N, H, scale, NP);
+            hipLaunchKernelGGL((attn_bwd_fused_kernel<32>), fgrid, dim3(256), lds, st, qkv, o, d_o, lse, N, H, scale, NP, dqkv, g16,
+                               dqkv_colsum_accum);
         } else {
             static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<64>),
                                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
             (void)attr;
-            hipLaunchKernelGGL((attn_bwd_fused_kernel<64>), fgrid, dim3(256), lds, st, qkv, o, d_o, lse, dqkv, g16,
-                               dqkv_colsum_accum, N, H, scale, NP);
+            hipLaunchKernelGGL((attn_bwd_fused_kernel<64>), fgrid, dim3(256), lds, st, qkv, o, d_o, lse, N, H, scale, NP, dqkv, g16,
+                               dqkv_colsum_accum);
         }
         return vitae_launch_status();
     }

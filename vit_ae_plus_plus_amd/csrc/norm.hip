@@ -55,10 +55,11 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 // D = 256 * NV: every lane owns NV float4 groups (columns 4 * (lane + 64 i) ..): 16-byte loads of x, w, b, 16-byte
 // stores of y and 8-byte stores of the bf16 copy instead of 4- and 2-byte ones.
 template <int NV>
-__global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ w,
+// (argument order: what the first loads and the bounds need sits inside the first 14 dwords, which arrive preloaded in SGPRs — build.py)
+__global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const float* __restrict__ x, int M, float eps, const float* __restrict__ w,
                                                                 const float* __restrict__ b, float* __restrict__ y,
                                                                 __bf16* __restrict__ y16, float* __restrict__ mean_out,
-                                                                float* __restrict__ rstd_out, int M, float eps) {
+                                                                float* __restrict__ rstd_out) {
     constexpr int D = 256 * NV;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -336,8 +337,8 @@ template <int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_part_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                  const float* __restrict__ w, const float* __restrict__ mean,
                                                                  const float* __restrict__ rstd, float* __restrict__ dx,
-                                                                 float* __restrict__ part, __bf16* __restrict__ dx16,
-                                                                 int M, int dx_accumulate) {
+                                                                 int M, int dx_accumulate,          // (14 dwords up to here: preloaded)
+                                                                 float* __restrict__ part, __bf16* __restrict__ dx16) {
     constexpr int D = 256 * NV, RPW = 2;
     extern __shared__ float red[];   // [3][4][D]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -841,10 +842,10 @@ extern "C" int vitae_layernorm_fwd(const float* x, const float* w, const float* 
     static const int vec_on = getenv("VITAE_LN_VEC") ? atoi(getenv("VITAE_LN_VEC")) : 1;     // 0: 4-byte accesses (A/B)
     const bool aligned = vec_on && !(((uintptr_t)x | (uintptr_t)w | (uintptr_t)b | (uintptr_t)y) & 15) && !((uintptr_t)y16 & 7);
     hipStream_t st = (hipStream_t)stream;
-    if (aligned && D == 768) hipLaunchKernelGGL(layernorm_fwd_vec_kernel<3>, dim3(cdiv(M, 4)), dim3(256), 0, st, x, w, b, y, y16, mean, rstd, M, eps);
-    else if (aligned && D == 512) hipLaunchKernelGGL(layernorm_fwd_vec_kernel<2>, dim3(cdiv(M, 4)), dim3(256), 0, st, x, w, b, y, y16, mean, rstd, M, eps);
-    else if (aligned && D == 1024) hipLaunchKernelGGL(layernorm_fwd_vec_kernel<4>, dim3(cdiv(M, 4)), dim3(256), 0, st, x, w, b, y, y16, mean, rstd, M, eps);
-    else if (aligned && D == 256) hipLaunchKernelGGL(layernorm_fwd_vec_kernel<1>, dim3(cdiv(M, 4)), dim3(256), 0, st, x, w, b, y, y16, mean, rstd, M, eps);
+    if (aligned && D == 768) hipLaunchKernelGGL(layernorm_fwd_vec_kernel<3>, dim3(cdiv(M, 4)), dim3(256), 0, st, x, M, eps, w, b, y, y16, mean, rstd);
+    else if (aligned && D == 512) hipLaunchKernelGGL(layernorm_fwd_vec_kernel<2>, dim3(cdiv(M, 4)), dim3(256), 0, st, x, M, eps, w, b, y, y16, mean, rstd);
+    else if (aligned && D == 1024) hipLaunchKernelGGL(layernorm_fwd_vec_kernel<4>, dim3(cdiv(M, 4)), dim3(256), 0, st, x, M, eps, w, b, y, y16, mean, rstd);
+    else if (aligned && D == 256) hipLaunchKernelGGL(layernorm_fwd_vec_kernel<1>, dim3(cdiv(M, 4)), dim3(256), 0, st, x, M, eps, w, b, y, y16, mean, rstd);
     else hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, x, w, b, y, y16, mean, rstd, M, D, eps);
     return vitae_launch_status();
 }
@@ -896,10 +897,10 @@ extern "C" int vitae_layernorm_bwd_part(const float* dy, const float* x, const f
     const int nb = vitae_layernorm_bwd_part_records(M);
     const size_t lds = (size_t)12 * D * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
-    if (D == 768) hipLaunchKernelGGL(layernorm_bwd_part_kernel<3>, dim3(nb), dim3(256), lds, st, dy, x, w, mean, rstd, dx, part, dx16v, M, dx_accumulate);
-    else if (D == 512) hipLaunchKernelGGL(layernorm_bwd_part_kernel<2>, dim3(nb), dim3(256), lds, st, dy, x, w, mean, rstd, dx, part, dx16v, M, dx_accumulate);
-    else if (D == 256) hipLaunchKernelGGL(layernorm_bwd_part_kernel<1>, dim3(nb), dim3(256), lds, st, dy, x, w, mean, rstd, dx, part, dx16v, M, dx_accumulate);
-    else hipLaunchKernelGGL(layernorm_bwd_part_kernel<4>, dim3(nb), dim3(256), lds, st, dy, x, w, mean, rstd, dx, part, dx16v, M, dx_accumulate);
+    if (D == 768) hipLaunchKernelGGL(layernorm_bwd_part_kernel<3>, dim3(nb), dim3(256), lds, st, dy, x, w, mean, rstd, dx, M, dx_accumulate, part, dx16v);
+    else if (D == 512) hipLaunchKernelGGL(layernorm_bwd_part_kernel<2>, dim3(nb), dim3(256), lds, st, dy, x, w, mean, rstd, dx, M, dx_accumulate, part, dx16v);
+    else if (D == 256) hipLaunchKernelGGL(layernorm_bwd_part_kernel<1>, dim3(nb), dim3(256), lds, st, dy, x, w, mean, rstd, dx, M, dx_accumulate, part, dx16v);
+    else hipLaunchKernelGGL(layernorm_bwd_part_kernel<4>, dim3(nb), dim3(256), lds, st, dy, x, w, mean, rstd, dx, M, dx_accumulate, part, dx16v);
     return vitae_launch_status();
 }
 
