@@ -1489,21 +1489,21 @@ __device__ __forceinline__ void x3_store_piece(const f32x4 (&v)[2], int K, int k
 }
 
 template <bool A_KC, bool B_KC, bool RS>
-__device__ __forceinline__ void gemm_wsx3_body(const GArgs& p, const int bid, const int zid, unsigned char* smem) {
+__device__ __forceinline__ void gemm_wsx3_body(const GArgs& p, const WsHot& h, const int bid, const int zid, unsigned char* smem) {
     constexpr int BM = 64, BN = 64, NWC = 4;
     constexpr int IMG = 64 * BK * 2, STG = 4 * IMG;                      // [A hi | B hi | A lo | B lo]
     constexpr int PA = pieces<BM, A_KC, VITAE_X3_PRODUCERS>(), PB = pieces<BN, B_KC, VITAE_X3_PRODUCERS>();
-    const float* Af = reinterpret_cast<const float*>(p.A);
-    const float* Bf = reinterpret_cast<const float*>(p.B);
-    const int T = p.tiles_m * p.tiles_n;
+    const float* Af = reinterpret_cast<const float*>(h.A);
+    const float* Bf = reinterpret_cast<const float*>(h.B);
+    const int T = h.tiles_m * h.tiles_n;
     const int xq = T >> 3, xr = T & 7, xcd = bid & 7;
     const int lin = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
     if ((bid >> 3) >= xq + (xcd < xr ? 1 : 0)) return;
-    const int tn = p.xcd_m ? lin % p.tiles_n : lin / p.tiles_m;
-    const int tm = p.xcd_m ? lin / p.tiles_n : lin % p.tiles_m;
+    const int tn = (h.xcd_m & 1) ? lin % h.tiles_n : lin / h.tiles_m;
+    const int tm = (h.xcd_m & 1) ? lin / h.tiles_n : lin % h.tiles_m;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int kbeg = zid * p.k_per_split;
-    const int kend = min(p.K, kbeg + p.k_per_split);
+    const int kbeg = zid * h.kps;
+    const int kend = min(h.K, kbeg + h.kps);
     const int nk = (kend - kbeg + BK - 1) / BK;                          // >= 1; the last tile may be partly past kend (zero-filled)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1520,9 +1520,9 @@ __device__ __forceinline__ void gemm_wsx3_body(const GArgs& p, const int bid, co
             constexpr int SET = decltype(set_c)::value;
             const int k0 = kbeg + t * BK;
 #pragma unroll
-            for (int j = 0; j < PA; ++j) x3_load_piece<BM, A_KC>(Af, p.lda, p.M, kend, m0, k0, pw, lane, j, ra[SET][j]);
+            for (int j = 0; j < PA; ++j) x3_load_piece<BM, A_KC>(Af, h.lda, h.M, kend, m0, k0, pw, lane, j, ra[SET][j]);
 #pragma unroll
-            for (int j = 0; j < PB; ++j) x3_load_piece<BN, B_KC>(Bf, p.ldb, p.N, kend, n0, k0, pw, lane, j, rb[SET][j]);
+            for (int j = 0; j < PB; ++j) x3_load_piece<BN, B_KC>(Bf, h.ldb, h.N, kend, n0, k0, pw, lane, j, rb[SET][j]);
         };
         auto store = [&](int t, int stage, auto set_c, bool other_in_flight) {
             constexpr int SET = decltype(set_c)::value;
@@ -1688,9 +1688,9 @@ __device__ __forceinline__ void gemm_wsx3_body(const GArgs& p, const int bid, co
 }
 
 template <bool A_KC, bool B_KC, bool RS>
-__global__ __launch_bounds__(64 * (4 + VITAE_X3_PRODUCERS), VITAE_X3_PRODUCERS == 4 ? 4 : 3) void gemm_wsx3_kernel(const GArgs p) {      // (4 producers: 4 waves per SIMD = <= 128 VGPRs, two workgroups per CU — the row-sum variant took 132)
+__global__ __launch_bounds__(64 * (4 + VITAE_X3_PRODUCERS), VITAE_X3_PRODUCERS == 4 ? 4 : 3) void gemm_wsx3_kernel(WS_HOT_PARAMS, const GArgs p) {      // (4 producers: 4 waves per SIMD = <= 128 VGPRs, two workgroups per CU — the row-sum variant took 132)
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * 4 * 8192];      // the ONLY LDS object
-    gemm_wsx3_body<A_KC, B_KC, RS>(p, blockIdx.x, blockIdx.z, smem);
+    gemm_wsx3_body<A_KC, B_KC, RS>(p, WS_HOT_FROM_PARAMS, blockIdx.x, blockIdx.z, smem);
 }
 
 // resident workgroup slots of the chip for this kernel (the split-K rule fills about that many)
@@ -1706,10 +1706,10 @@ int wsx3_launch(GArgs p, int a_kc, int b_kc, hipStream_t st) {
     if (p.splits > 1 && (!p.ws || (long)p.tiles_m * p.tiles_n > VITAE_GLDS_TICKETS || p.epi == VITAE_EPI_GELU)) return VITAE_ERR_UNSUPPORTED_SHAPE;
     if (p.a_rowsum && (a_kc || b_kc)) return VITAE_ERR_UNSUPPORTED_SHAPE;
     const dim3 grid(8 * cdiv((long)p.tiles_m * p.tiles_n, 8), 1, p.splits), block(64 * (4 + VITAE_X3_PRODUCERS));
-    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_wsx3_kernel<true, true, false>), grid, block, 0, st, p);
-    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_wsx3_kernel<true, false, false>), grid, block, 0, st, p);
-    else if (p.a_rowsum) hipLaunchKernelGGL((gemm_wsx3_kernel<false, false, true>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((gemm_wsx3_kernel<false, false, false>), grid, block, 0, st, p);
+    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_wsx3_kernel<true, true, false>), grid, block, 0, st, WS_HOT_ARGS(p), p);
+    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_wsx3_kernel<true, false, false>), grid, block, 0, st, WS_HOT_ARGS(p), p);
+    else if (p.a_rowsum) hipLaunchKernelGGL((gemm_wsx3_kernel<false, false, true>), grid, block, 0, st, WS_HOT_ARGS(p), p);
+    else hipLaunchKernelGGL((gemm_wsx3_kernel<false, false, false>), grid, block, 0, st, WS_HOT_ARGS(p), p);
     return vitae_launch_status();
 }
 
