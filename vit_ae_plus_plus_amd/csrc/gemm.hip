@@ -121,12 +121,15 @@ __device__ __forceinline__ void store_tile(void* lds, const f32x4 (&v)[NPC]) {
 template <int PREC> struct TileBytes { static constexpr int value = (PREC == 0) ? BK * SM32 * 4 : 64 * SK16 * 2; };
 
 template <int PREC, bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
+// (leading scalars: what the first tile loads need, preloaded into SGPRs with the dispatch — build.py; the descriptor's own scalar
+// loads are waited for by the epilogue only)
+__global__ __launch_bounds__(256) void gemm_kernel(const float* hA, const float* hB, int hlda, int hldb, int hM, int hN, int hK, int hkps,
+                                                   const GemmArgs p) {
     constexpr int TB = TileBytes<PREC>::value;
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TB];   // [buf][A|B]
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kbeg = blockIdx.z * p.k_per_split;
-    const int kend = min(p.K, kbeg + p.k_per_split);
+    const int kbeg = blockIdx.z * hkps;
+    const int kend = min(hK, kbeg + hkps);
     const int nk = (kend - kbeg + BK - 1) / BK;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -138,8 +141,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 
     f32x4 ra[NPC], rb[NPC];
     if (nk > 0) {
-        load_tile<A_KC>(p.A, p.lda, p.M, m0, kbeg, kend, ra);
-        load_tile<B_KC>(p.B, p.ldb, p.N, n0, kbeg, kend, rb);
+        load_tile<A_KC>(hA, hlda, hM, m0, kbeg, kend, ra);
+        load_tile<B_KC>(hB, hldb, hN, n0, kbeg, kend, rb);
         store_tile<PREC, A_KC>(smem, ra);
         store_tile<PREC, B_KC>(smem + TB, rb);
     }
@@ -147,8 +150,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     for (int t = 0; t < nk; ++t) {
         const bool more = (t + 1 < nk);
         if (more) {
-            load_tile<A_KC>(p.A, p.lda, p.M, m0, kbeg + (t + 1) * BK, kend, ra);
-            load_tile<B_KC>(p.B, p.ldb, p.N, n0, kbeg + (t + 1) * BK, kend, rb);
+            load_tile<A_KC>(hA, hlda, hM, m0, kbeg + (t + 1) * BK, kend, ra);
+            load_tile<B_KC>(hB, hldb, hN, n0, kbeg + (t + 1) * BK, kend, rb);
         }
         unsigned char* cur = smem + (t & 1) * 2 * TB;
         if (PREC == 0) {
@@ -201,10 +204,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
 template <int PREC>
 void launch_gemm(const GemmArgs& p, bool a_kc, bool b_kc, hipStream_t st) {
     dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM), p.splits), block(256);
-    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_kernel<PREC, true, true>), grid, block, 0, st, p);
-    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_kernel<PREC, true, false>), grid, block, 0, st, p);
-    else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_kernel<PREC, false, true>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((gemm_kernel<PREC, false, false>), grid, block, 0, st, p);
+    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_kernel<PREC, true, true>), grid, block, 0, st, p.A, p.B, (int)p.lda, (int)p.ldb, p.M, p.N, p.K, p.k_per_split, p);
+    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_kernel<PREC, true, false>), grid, block, 0, st, p.A, p.B, (int)p.lda, (int)p.ldb, p.M, p.N, p.K, p.k_per_split, p);
+    else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_kernel<PREC, false, true>), grid, block, 0, st, p.A, p.B, (int)p.lda, (int)p.ldb, p.M, p.N, p.K, p.k_per_split, p);
+    else hipLaunchKernelGGL((gemm_kernel<PREC, false, false>), grid, block, 0, st, p.A, p.B, (int)p.lda, (int)p.ldb, p.M, p.N, p.K, p.k_per_split, p);
 }
 
 }  // namespace
